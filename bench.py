@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- cost-volume samples/s of the plane sweep (BASELINE.json metric) on N MI355X GPUs.
+
+A "step" is one pass of the hot path for one main view: build the packed cost volume from the V side
+views (sweep kernel), then per-pixel depth selection (argmin kernel).  Inputs are synthetic frames of
+the BASELINE config already resident in HBM when the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--shard frames|views]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py ...`.
+Sharding (DESIGN.md "multi-GPU"):
+  frames (default): every rank processes its own main frame (the reference's independent `fa` loop,
+                    recon.cpp:65); no data-path collective; weak scaling.
+  views:            the V side views are split across ranks, the packed u32 volume is summed with an
+                    RCCL all-reduce (exact: integer cells), every rank selects depth; strong scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
+
+CONFIGS = {
+    # name: (W, H, D, V)   -- BASELINE.json configs[]
+    "c1": (640, 480, 32, 4),
+    "c2": (1280, 720, 64, 8),
+    "c3": (1920, 1080, 128, 16),
+    "c4": (3840, 2160, 256, 32),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(cfg, main_cam, main_img, side_cams, sides):
+    """the CPU oracle (a port: the reference itself cannot be built here) on a bounded sample of the
+    same workload: all pixels and views, 8 of the D planes, all host cores"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    W, H, D, V = cfg
+    o = orc.load()
+    cores = os.cpu_count() or 1
+    nplanes = min(8, D)
+    d0 = (D - nplanes) // 2
+    z_lo = -1.0 + 2.0 * d0 / D
+    z_hi = -1.0 + 2.0 * (d0 + nplanes) / D
+    t0 = time.perf_counter()
+    o.sweep(main_cam, main_img, side_cams, sides, nplanes, z_lo, z_hi, nthreads=cores)
+    dt = time.perf_counter() - t0
+    samples = float(W) * H * nplanes * V
+    return {
+        "value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+        "sample": "%dx%d, %d views, planes %d..%d of %d (%.3g samples, %.1f s), OpenMP over rows" %
+                  (W, H, V, d0, d0 + nplanes - 1, D, samples, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--shard", default="frames", choices=["frames", "views"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", action="store_true", help="also time the fused (no volume) variant")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import numpy as np
+    import torch  # first: libmvs_hip.so must share torch's HIP runtime (same soname)
+    import mvs_amd
+    from mvs_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = CONFIGS[args.config]
+    W, H, D, V = cfg
+    P = W * H
+    # every rank renders the same deterministic scene; in `frames` mode rank r uses a different main
+    # frame (a ring rotated by r positions) so the ranks do not process identical data
+    radius = 0.15
+    main_cam, main_img, side_cams, sides, gt = synth.make_views(W, H, V, radius=radius,
+                                                                seed=synth.SEED_SCENE + (rank if args.shard == "frames" else 0))
+
+    ctx = mvs_amd.Context(W, H, local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+
+    if args.shard == "views" and world > 1:
+        per = (V + world - 1) // world
+        v0, vn = min(rank * per, V), max(0, min(per, V - rank * per))
+    else:
+        v0, vn = 0, V
+    vol_t = torch.empty(D * P, dtype=torch.int32, device="cuda")
+    ctx.sweep_use_volume(vol_t.data_ptr(), vol_t.numel() * 4)
+
+    def step():
+        ctx.sweep_run(v0, vn, mvs_amd.MVS_SWEEP_VOLUME)
+        if args.shard == "views" and world > 1:
+            dist.all_reduce(vol_t)  # exact: packed integer cells
+        ctx.sweep_argmin()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ms_sum, launches = ctx.profile_read(reset=True)
+    ctx.profile_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    fused_ms = None
+    if args.fused and world == 1:
+        for _ in range(2):
+            ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        torch.cuda.synchronize()
+        fused_ms = (time.perf_counter() - t1) / args.steps * 1e3
+
+    # sanity: the timed path produced the surface it was rendered from
+    depth, cost, idx, _ = ctx.sweep_fetch()
+    err = np.abs(depth - gt)[16:-16, 16:-16]
+    depth_ok = bool(np.median(err) <= 2.0 / D)
+
+    if rank == 0:
+        frames_total = args.gpus if args.shard == "frames" else 1
+        samples_per_step = float(P) * D * V * frames_total
+        ms_per_step = dt / args.steps * 1e3
+        sweep_ms = ms_sum[mvs_amd.MVS_K_SWEEP] / max(1, launches[mvs_amd.MVS_K_SWEEP])
+        argmin_ms = ms_sum[mvs_amd.MVS_K_ARGMIN] / max(1, launches[mvs_amd.MVS_K_ARGMIN])
+        # algorithmic bytes of one sweep launch: each u8 image once + the u32 volume written once
+        sweep_bytes = float(P) * (vn + 1) + 4.0 * P * D
+        argmin_bytes = 4.0 * P * D + 12.0 * P
+        achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+        out = {
+            "metric": "cost-volume samples/sec (pixels x planes x views)",
+            "value": samples_per_step / (dt / args.steps),
+            "unit": "samples/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak" if args.shard == "frames" else "strong",
+            "vs_baseline": None,
+            "dtype": "f32 warp + u8/u32 cost",
+            "data": "synthetic",
+            "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V),
+                       "shard": args.shard, "views_per_rank": vn, "device": ctx.info()},
+            "roofline": {"bound": "hbm", "kernel": "sweep_tiled", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": sweep_bytes, "ms_per_launch": sweep_ms},
+            "kernels": {"sweep_ms": sweep_ms, "argmin_ms": argmin_ms,
+                        "argmin_GBps": argmin_bytes / (argmin_ms * 1e-3) / 1e9 if argmin_ms > 0 else None,
+                        "step_algorithmic_bytes": float(P) * (vn + 8 * D + 9),
+                        "step_GBps": float(P) * (vn + 8 * D + 9) / (ms_per_step * 1e-3) / 1e9},
+            "depth_check": depth_ok,
+        }
+        if fused_ms is not None:
+            out["fused_variant"] = {"ms_per_step": fused_ms, "samples_per_s": float(P) * D * V / (fused_ms * 1e-3)}
+        if not args.no_cpu_baseline and args.gpus == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, main_cam, main_img, side_cams, sides)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

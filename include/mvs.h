@@ -1,0 +1,135 @@
+/*
+ * mvs.h -- C ABI of the MI355X-native dense-MVS depth engine (libmvs_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of addam/mesh-reconstruction: every entry point
+ * replaces one call the reference's driver makes through its link-time renderer seam
+ * (recon.hpp:93-100, `class Render` + `spawnRender`; Makefile:2,16,21 `render_${SYSTEM_OPENGL}.cpp`)
+ * or through the free functions of recon.hpp:40-50.  Plain pointers and sizes only; no C++ or
+ * torch types.  The C++ shim that turns these into `class RenderHIP : public Render`,
+ * `spawnRender` and `calculateFlow` lives in mesh-reconstruction_amd/host/ (see INTEGRATION.md).
+ *
+ * Conventions:
+ *   - camera matrices: 4x4 float, row-major, applied as P*(x,y,z,1)^T       (render_glx.cpp:265,338,375)
+ *   - images: top-down, row-major, tightly packed                           (cv::flip at render_glx.cpp:365,392)
+ *   - depth maps: NDC z in [-1,1], 1.0f == backgroundDepth == "no geometry" (recon.hpp:30)
+ *   - every function returns 0 on success, a negative MVS_E* code on error; the message is
+ *     available from mvs_last_error().  Nothing aborts, asserts or exits (the reference does:
+ *     recon.cpp:49, util.cpp:442).
+ *   - a context is bound to one GPU; calls on one context must be serialised by the caller
+ *     (the reference is single-threaded: one GL context, render_glx.cpp:152-208).
+ *   - the library never retains caller pointers after a call returns.
+ *   - there is NO CPU fallback: without a usable HIP device mvs_create() fails.
+ */
+#ifndef MVS_H
+#define MVS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVS_OK 0
+#define MVS_EINVAL (-1)   /* bad argument */
+#define MVS_EHIP (-2)     /* HIP runtime error */
+#define MVS_ESTATE (-3)   /* call sequence error (e.g. sweep run before inputs were set) */
+#define MVS_ENOMEM (-4)   /* device or host allocation failed */
+
+#define MVS_BACKGROUND_DEPTH 1.0f /* recon.hpp:30 */
+
+typedef struct mvs_ctx mvs_ctx;
+
+/* ---- life cycle: replaces RenderGLX::RenderGLX / ~RenderGLX (render_glx.cpp:152-227) -------- */
+mvs_ctx *mvs_create(int device, int width, int height);
+void mvs_destroy(mvs_ctx *ctx);
+/* last error text of `ctx`; with ctx == NULL the last error of a failed mvs_create() */
+const char *mvs_last_error(const mvs_ctx *ctx);
+/* run all subsequent work of `ctx` on the caller's hipStream_t (NULL = the context's own stream) */
+int mvs_set_stream(mvs_ctx *ctx, void *hip_stream);
+/* block until all queued work of the context has finished */
+int mvs_synchronize(mvs_ctx *ctx);
+int mvs_width(const mvs_ctx *ctx);
+int mvs_height(const mvs_ctx *ctx);
+
+/* ---- renderer: replaces class Render (recon.hpp:93-99) ---------------------------------------- */
+/* Render::loadMesh, render_glx.cpp:230-258: verts4 = nverts homogeneous rows (x,y,z,w), faces3 = int32 triples */
+int mvs_load_mesh(mvs_ctx *ctx, const float *verts4, int nverts, const int32_t *faces3, int nfaces);
+/* Render::depth, render_glx.cpp:369-397: out_hw = H*W float NDC z, empty pixels 1.0 */
+int mvs_depth(mvs_ctx *ctx, const float cam[16], float *out_hw);
+/* Render::projected, render_glx.cpp:261-367: out_hw3 = H*W*3 u8 (warped side intensity, mask, mask) */
+int mvs_projected(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_hw, const float projector[16],
+                  uint8_t *out_hw3);
+
+/* ---- photometric helpers: replace util.cpp:332-403 -------------------------------------------- */
+/* mixBackground, util.cpp:366-387: depth_hw_inout is mutated (masked pixels := 1.0) */
+int mvs_mix_background(mvs_ctx *ctx, const uint8_t *img_hw3, const uint8_t *bg_hw, float *depth_hw_inout,
+                       uint8_t *out_hw);
+/* compare, util.cpp:332-361: multi-scale L1 pyramid difference, out_hw = H*W float */
+int mvs_compare(mvs_ctx *ctx, const uint8_t *prev_hw, const uint8_t *next_hw, float *out_hw);
+/* flowRemap, util.cpp:390-403: bicubic remap by flow (flow_stride floats per pixel, first two used) */
+int mvs_flow_remap(mvs_ctx *ctx, const float *flow, int flow_stride, const uint8_t *image_hw, uint8_t *out_hw);
+/* calculateFlow, flow.cpp:19-42: out_hw4 = H*W*4 float (u, v, variance, 0) */
+int mvs_flow(mvs_ctx *ctx, const uint8_t *prev_hw, const uint8_t *next_hw, int use_farneback, float *out_hw4);
+
+/* ---- plane sweep: the D-plane generalisation of shader.frag:11-25 ------ */
+/*
+ * One-call form on host buffers.  For every pixel of the main view and every plane
+ * z_d = z_lo + (z_hi - z_lo)(d + 1/2)/nplanes (main-camera NDC z) the side frames are warped into the
+ * main view exactly as shader.frag does for the mesh position, quantised to u8 like the RGB8
+ * read-back (render_glx.cpp:359), and the cost is the mean over in-frame views of |I_main - I_warp|.
+ * depth_hw: H*W float, NDC z of the lowest-cost plane (ties -> lowest d), 1.0 where no view is in frame.
+ * cost_hw (nullable): H*W float best cost.  volume_dhw (nullable): nplanes*H*W float normalised
+ * cost, +inf where no view is in frame.
+ */
+int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, int nviews,
+              const float *side_cams /* nviews*16 */, const uint8_t *const *side_frames, int nplanes,
+              float z_lo, float z_hi, float *depth_hw, float *cost_hw, float *volume_dhw);
+
+/* Staged form: inputs stay resident in HBM between runs (bench, multi-GPU view sharding). */
+int mvs_sweep_set_main(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw);
+int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames);
+int mvs_sweep_set_planes(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi);
+
+#define MVS_SWEEP_VOLUME 1u       /* materialise the packed cost volume in HBM */
+#define MVS_SWEEP_FUSED_ARGMIN 2u /* select depth inside the sweep kernel (no volume read-back pass) */
+#define MVS_SWEEP_FORCE_GENERIC 4u /* use the un-tiled global-gather kernel (test / fallback path) */
+/* accumulate views [view_first, view_first + view_count) into the packed volume / fused outputs (async) */
+int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags);
+/* per-pixel depth selection over the packed volume (async); valid after MVS_SWEEP_VOLUME runs or
+ * after the caller has reduced the volume across ranks in place */
+int mvs_sweep_argmin(mvs_ctx *ctx);
+/* device pointer + size of the packed volume: nplanes*H*W uint32 cells (count << 16 | sum of abs
+ * differences); sums and counts add exactly, so an integer sum-all-reduce across view shards is
+ * bit-identical to the single-GPU result */
+void *mvs_sweep_volume_device(mvs_ctx *ctx, size_t *bytes);
+/* make the sweep write into caller-owned device memory (e.g. a torch tensor handed to RCCL) */
+int mvs_sweep_use_volume(mvs_ctx *ctx, void *device_ptr, size_t bytes);
+/* device pointers of the per-pixel results (H*W each): depth f32, best cost f32, best index i32 */
+void *mvs_sweep_depth_device(mvs_ctx *ctx);
+void *mvs_sweep_cost_device(mvs_ctx *ctx);
+void *mvs_sweep_index_device(mvs_ctx *ctx);
+/* copy results to host (synchronises); any pointer may be NULL */
+int mvs_sweep_fetch(mvs_ctx *ctx, float *depth_hw, float *cost_hw, int32_t *index_hw, uint32_t *packed_volume_dhw);
+/* read back the f32 view matrices the sweep uses (nviews*12), for parity checks */
+int mvs_sweep_view_matrices(mvs_ctx *ctx, float *q_out);
+
+/* ---- kernel timing (HIP events on the context's stream) ---------------------------------------- */
+#define MVS_K_SWEEP 0
+#define MVS_K_ARGMIN 1
+#define MVS_K_PLAN 2
+#define MVS_K_RASTER 3
+#define MVS_K_PROJECT 4
+#define MVS_K_FLOW 5
+#define MVS_K_COUNT 8
+int mvs_profile_enable(mvs_ctx *ctx, int on);
+/* synchronises, then returns summed elapsed ms and launch count per kernel class since the last reset */
+int mvs_profile_read(mvs_ctx *ctx, float ms_sum[MVS_K_COUNT], int launches[MVS_K_COUNT], int reset);
+
+/* library / device info string, e.g. "libmvs_hip gfx950 AMD Instinct MI355X" */
+const char *mvs_device_info(mvs_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVS_H */

@@ -1,0 +1,288 @@
+// context.hip -- context life cycle, HBM residency of the sweep inputs, profiling events.
+// Replaces the resource management of RenderGLX (render_glx.cpp:152-227): one context = one GPU.
+#include "mvs_internal.hpp"
+
+#include <mutex>
+#include <string>
+
+namespace mvs {
+
+static std::mutex g_err_mutex;
+static char g_err[512] = "no error";
+
+void set_global_error(const char *msg)
+{
+    std::lock_guard<std::mutex> lock(g_err_mutex);
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+}
+
+int fail(mvs_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx)
+        snprintf(ctx->err, sizeof(ctx->err), "%s", buf);
+    else
+        set_global_error(buf);
+    return code;
+}
+
+int ensure(mvs_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.bytes && b.ptr) return MVS_OK;
+    if (b.ptr) {
+        // queued kernels may still read the old allocation
+        MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MVS_HIP(ctx, hipFree(b.ptr));
+        b.ptr = nullptr;
+        b.bytes = 0;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(ctx, MVS_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    b.ptr = p;
+    b.bytes = bytes;
+    return MVS_OK;
+}
+
+ProfileScope::ProfileScope(mvs_ctx *c, int kind) : ctx(c), slot(-1)
+{
+    if (!ctx->profiling) return;
+    if (ctx->slots_used == ctx->slots.size()) {
+        ProfileSlot s;
+        if (hipEventCreate(&s.start) != hipSuccess || hipEventCreate(&s.stop) != hipSuccess) return;
+        ctx->slots.push_back(s);
+    }
+    slot = (int)ctx->slots_used++;
+    ctx->slots[slot].kind = kind;
+    (void)hipEventRecord(ctx->slots[slot].start, ctx->stream);
+}
+
+ProfileScope::~ProfileScope()
+{
+    if (slot >= 0) (void)hipEventRecord(ctx->slots[slot].stop, ctx->stream);
+}
+
+// 1-pixel GL_REPEAT wrap padding (render_glx.cpp:81-82): pad[r][c] = img[(r-1) mod H][(c-1) mod W]
+__global__ void pad_wrap_kernel(const uint8_t *__restrict__ img, uint8_t *__restrict__ pad, int W, int H, int pitch)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= pitch) return;
+    uint8_t v = 0;
+    if (c < W + 2) {
+        int sr = r - 1;
+        sr = sr < 0 ? H - 1 : (sr >= H ? 0 : sr);
+        int sc = c - 1;
+        sc = sc < 0 ? W - 1 : (sc >= W ? 0 : sc);
+        v = img[(size_t)sr * W + sc];
+    }
+    pad[(size_t)r * pitch + c] = v;
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" {
+
+mvs_ctx *mvs_create(int device, int width, int height)
+{
+    if (width < 2 || height < 2 || width > 16384 || height > 16384) {
+        fail(nullptr, MVS_EINVAL, "mvs_create: bad size %dx%d", width, height);
+        return nullptr;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        fail(nullptr, MVS_EHIP, "mvs_create: no HIP device available (%s); this library has no CPU fallback",
+             e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        fail(nullptr, MVS_EINVAL, "mvs_create: device %d out of range (have %d)", device, ndev);
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        fail(nullptr, MVS_EHIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        return nullptr;
+    }
+    mvs_ctx *ctx = new (std::nothrow) mvs_ctx();
+    if (!ctx) {
+        fail(nullptr, MVS_ENOMEM, "mvs_create: out of host memory");
+        return nullptr;
+    }
+    ctx->device = device;
+    ctx->W = width;
+    ctx->H = height;
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        fail(nullptr, MVS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        delete ctx;
+        return nullptr;
+    }
+    ctx->stream = ctx->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->num_cus = prop.multiProcessorCount;
+        snprintf(ctx->info, sizeof(ctx->info), "libmvs_hip %s %s (%d CUs)", prop.gcnArchName, prop.name,
+                 prop.multiProcessorCount);
+    } else {
+        ctx->num_cus = 256;
+        snprintf(ctx->info, sizeof(ctx->info), "libmvs_hip (device properties unavailable)");
+    }
+    snprintf(ctx->err, sizeof(ctx->err), "no error");
+    return ctx;
+}
+
+void mvs_destroy(mvs_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->main_img, &ctx->side_pads, &ctx->qmats, &ctx->ztab, &ctx->plan, &ctx->upload,
+                      &ctx->volume_own, &ctx->depth, &ctx->cost, &ctx->index, &ctx->soup, &ctx->r_zbuf,
+                      &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2};
+    for (DevBuf *b : bufs)
+        if (b->ptr) (void)hipFree(b->ptr);
+    for (auto &s : ctx->slots) {
+        if (s.start) (void)hipEventDestroy(s.start);
+        if (s.stop) (void)hipEventDestroy(s.stop);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *mvs_last_error(const mvs_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+int mvs_set_stream(mvs_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return MVS_EINVAL;
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return MVS_OK;
+}
+
+int mvs_synchronize(mvs_ctx *ctx)
+{
+    if (!ctx) return MVS_EINVAL;
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
+int mvs_width(const mvs_ctx *ctx) { return ctx ? ctx->W : MVS_EINVAL; }
+int mvs_height(const mvs_ctx *ctx) { return ctx ? ctx->H : MVS_EINVAL; }
+const char *mvs_device_info(mvs_ctx *ctx) { return ctx ? ctx->info : "no context"; }
+
+int mvs_profile_enable(mvs_ctx *ctx, int on)
+{
+    if (!ctx) return MVS_EINVAL;
+    ctx->profiling = on != 0;
+    return MVS_OK;
+}
+
+int mvs_profile_read(mvs_ctx *ctx, float ms_sum[MVS_K_COUNT], int launches[MVS_K_COUNT], int reset)
+{
+    if (!ctx || !ms_sum || !launches) return MVS_EINVAL;
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < MVS_K_COUNT; k++) {
+        ms_sum[k] = 0.f;
+        launches[k] = 0;
+    }
+    for (size_t i = 0; i < ctx->slots_used; i++) {
+        const ProfileSlot &s = ctx->slots[i];
+        float ms = 0.f;
+        if (s.kind < 0 || s.kind >= MVS_K_COUNT) continue;
+        if (hipEventElapsedTime(&ms, s.start, s.stop) != hipSuccess) continue;
+        ms_sum[s.kind] += ms;
+        launches[s.kind] += 1;
+    }
+    if (reset) ctx->slots_used = 0;
+    return MVS_OK;
+}
+
+// ---- sweep inputs -------------------------------------------------------------------------------------
+
+int mvs_sweep_set_main(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw)
+{
+    if (!ctx || !main_cam || !main_hw) return fail(ctx, MVS_EINVAL, "mvs_sweep_set_main: null argument");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->W * ctx->H;
+    int rc = ensure(ctx, ctx->main_img, P);
+    if (rc) return rc;
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->main_img.ptr, main_hw, P, hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // caller's buffer is not retained
+    memcpy(ctx->main_cam, main_cam, sizeof(float) * 16);
+    ctx->have_main = true;
+    ctx->plan_valid = false;
+    // view matrices depend on the main camera
+    if (ctx->have_views) ctx->have_views = false;
+    return MVS_OK;
+}
+
+int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames)
+{
+    if (!ctx || nviews < 0 || nviews > 256 || (nviews > 0 && (!side_cams || !side_frames)))
+        return fail(ctx, MVS_EINVAL, "mvs_sweep_set_views: bad arguments (nviews=%d, must be 0..256)", nviews);
+    if (!ctx->have_main) return fail(ctx, MVS_ESTATE, "mvs_sweep_set_views: call mvs_sweep_set_main first");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->W, H = ctx->H;
+    const size_t P = (size_t)W * H;
+    ctx->pad_pitch = ((W + 2 + 63) / 64) * 64;
+    ctx->pad_slab = (size_t)ctx->pad_pitch * (H + 2);
+    ctx->V = nviews;
+    ctx->q_host.assign((size_t)nviews * 12, 0.f);
+    if (nviews > 0) {
+        int rc = ensure(ctx, ctx->side_pads, ctx->pad_slab * nviews);
+        if (rc) return rc;
+        if ((rc = ensure(ctx, ctx->upload, P))) return rc;
+        if ((rc = ensure(ctx, ctx->qmats, sizeof(float) * 12 * nviews))) return rc;
+        for (int v = 0; v < nviews; v++) {
+            if (!side_frames[v]) return fail(ctx, MVS_EINVAL, "mvs_sweep_set_views: side_frames[%d] is null", v);
+            view_matrix(ctx->main_cam, side_cams + 16 * v, W, H, ctx->q_host.data() + 12 * v);
+            MVS_HIP(ctx, hipMemcpyAsync(ctx->upload.ptr, side_frames[v], P, hipMemcpyHostToDevice, ctx->stream));
+            dim3 grid(div_up(ctx->pad_pitch, 256), H + 2);
+            pad_wrap_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)ctx->upload.ptr,
+                                                          (uint8_t *)ctx->side_pads.ptr + ctx->pad_slab * v, W, H,
+                                                          ctx->pad_pitch);
+            MVS_HIP(ctx, hipGetLastError());
+            MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging buffer is reused per view
+        }
+        MVS_HIP(ctx, hipMemcpyAsync(ctx->qmats.ptr, ctx->q_host.data(), sizeof(float) * 12 * nviews,
+                                    hipMemcpyHostToDevice, ctx->stream));
+        MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->have_views = true;
+    ctx->plan_valid = false;
+    return MVS_OK;
+}
+
+int mvs_sweep_set_planes(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi)
+{
+    if (!ctx || nplanes < 1 || nplanes > 4096)
+        return fail(ctx, MVS_EINVAL, "mvs_sweep_set_planes: nplanes=%d out of range 1..4096", nplanes);
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->D = nplanes;
+    ctx->z_host.resize(nplanes);
+    plane_table(nplanes, z_lo, z_hi, ctx->z_host.data());
+    int rc = ensure(ctx, ctx->ztab, sizeof(float) * nplanes);
+    if (rc) return rc;
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->ztab.ptr, ctx->z_host.data(), sizeof(float) * nplanes, hipMemcpyHostToDevice,
+                                ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_planes = true;
+    ctx->plan_valid = false;
+    return MVS_OK;
+}
+
+int mvs_sweep_view_matrices(mvs_ctx *ctx, float *q_out)
+{
+    if (!ctx || !q_out) return fail(ctx, MVS_EINVAL, "mvs_sweep_view_matrices: null argument");
+    if (!ctx->have_views) return fail(ctx, MVS_ESTATE, "mvs_sweep_view_matrices: no views set");
+    memcpy(q_out, ctx->q_host.data(), sizeof(float) * ctx->q_host.size());
+    return MVS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// mvs_internal.hpp -- context layout and helpers shared by the HIP translation units of libmvs_hip.so.
+// Not part of the ABI (include/mvs.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mvs.h"
+
+namespace mvs {
+
+// Device buffer that only ever grows; freed with the context.
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct ProfileSlot {
+    hipEvent_t start = nullptr, stop = nullptr;
+    int kind = -1;
+};
+
+}  // namespace mvs
+
+struct mvs_ctx {
+    int device = 0;
+    int W = 0, H = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // the stream work is queued on (own_stream unless mvs_set_stream)
+    char err[512] = {0};
+    char info[256] = {0};
+    int num_cus = 0;
+
+    // ---- sweep state (HBM resident) -------------------------------------------------------------
+    // main image: H*W u8 tight.  side images: V slabs of (H+2) rows x pad_pitch bytes, 1-pixel
+    // GL_REPEAT wrap padding so the sampler never needs wrap logic.
+    mvs::DevBuf main_img, side_pads, qmats, ztab, plan, upload;
+    mvs::DevBuf volume_own;          // packed (cnt<<16 | sum) cells, [D][H][W] u32
+    uint32_t *volume = nullptr;      // volume_own.ptr or caller memory (mvs_sweep_use_volume)
+    size_t volume_bytes = 0;
+    bool volume_external = false;
+    mvs::DevBuf depth, cost, index;  // H*W each
+    int pad_pitch = 0;
+    size_t pad_slab = 0;             // bytes per padded side image
+    int V = 0, D = 0;
+    float main_cam[16] = {0};
+    bool have_main = false, have_views = false, have_planes = false;
+    bool plan_valid = false;         // region plan matches current (views, planes)
+    std::vector<float> q_host;       // V*12
+    std::vector<float> z_host;       // D
+
+    // ---- renderer state -----------------------------------------------------------------------------
+    mvs::DevBuf soup;                // 9 floats per face, dehomogenised triangle soup
+    int nfaces = 0;
+    mvs::DevBuf r_zbuf, r_shadow, r_frame, r_out3, r_tmp0, r_tmp1, r_tmp2;
+
+    // ---- profiling -----------------------------------------------------------------------------------
+    bool profiling = false;
+    std::vector<mvs::ProfileSlot> slots;
+    size_t slots_used = 0;
+};
+
+namespace mvs {
+
+int fail(mvs_ctx *ctx, int code, const char *fmt, ...);
+void set_global_error(const char *msg);
+
+#define MVS_HIP(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return mvs::fail((ctx), MVS_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// grow-only device allocation
+int ensure(mvs_ctx *ctx, DevBuf &b, size_t bytes);
+
+// bracket a kernel launch with events when profiling is on
+struct ProfileScope {
+    mvs_ctx *ctx;
+    int slot;
+    ProfileScope(mvs_ctx *c, int kind);
+    ~ProfileScope();
+};
+
+// host camera math (double precision; order of operations is part of the parity contract)
+void invert4(const double m[16], double out[16]);
+void view_matrix(const float main_cam[16], const float side_cam[16], int W, int H, float Q[12]);
+void plane_table(int D, float z_lo, float z_hi, float *z);
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace mvs

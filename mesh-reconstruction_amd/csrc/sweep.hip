@@ -1,0 +1,747 @@
+// sweep.hip -- plane-sweep photometric cost volume + per-pixel depth selection for gfx950 (MI355X).
+//
+// What it replaces: the reference evaluates ONE depth hypothesis per pixel per (main, side) pair by
+// rasterising the proxy mesh and running shader.frag:11-25 (projective texture fetch + in-frame test)
+// followed by an RGB8 read-back (render_glx.cpp:261-367).  This file evaluates the same fragment
+// program at D synthetic positions pos_d = main^-1 * (x_ndc, y_ndc, z_d, 1) per pixel and V side
+// views, accumulates |I_main - I_warp| and picks the best plane.
+//
+// Arithmetic contract (identical in oracle/sweep_oracle.c; DESIGN.md "sweep arithmetic"):
+//   s      = fma(z, B, A)            A = fma(Q0, xn, fma(Q1, yn, Q3)), B = Q2  (per row of Q)
+//   r      = RN(1 / s.w)             v_rcp_f32 + one FMA Newton step
+//   c      = s.xy * r                padded-pixel coordinates, in frame iff 0.5 < c < size + 0.5
+//   i, a   = trunc(c), c - i         exact (c > 0)
+//   res    = fma(ay, fma(ax, dxy, dy), fma(ax, dxt, t00))
+//   Iq     = (int)(res + 0.5)        the u8 the RGB8 framebuffer would hold (render_glx.cpp:359)
+//   cell  += (1 << 16) + |Iq - Im|   integer: exact, order independent, all-reducible
+// Build with -ffp-contract=off: every f32 op above is exactly one rounding.
+//
+// Kernels:
+//   plan_regions      per (tile, plane chunk, view): bounding box of the warped tile -> LDS region
+//   sweep_tiled       LDS-staged side-image tiles, 64x16 pixel tiles, PC planes per chunk
+//   sweep_generic     no tiling, global gathers; any geometry; also the in-kernel fallback
+//   argmin_volume     depth selection over the packed volume (after an optional cross-rank reduction)
+#include "mvs_internal.hpp"
+
+namespace mvs {
+
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+constexpr int TILE_W = 64;   // one wavefront spans a tile row
+constexpr int TILE_H = 16;
+constexpr int NPX = 4;       // pixels per thread (rows 4*wave + j)
+constexpr int PC = 16;       // planes per chunk (accumulators per pixel)
+constexpr int LDS_QUADS = 3840;  // 30 KiB of 8-byte quads per staging buffer
+constexpr int MAX_RW = 128;
+constexpr float PLAN_MARGIN = 0.0625f;
+
+enum RegionMode : unsigned { R_SKIP = 0, R_FAST = 1, R_BORDER = 2, R_GENERIC = 3 };
+
+struct SweepParams {
+    const uint8_t *__restrict__ main_img;
+    const uint8_t *__restrict__ pads;
+    size_t pad_slab;
+    int pitch;
+    int W, H, D, V;
+    int v0, vcount;
+    const float *__restrict__ Q;  // V * 12
+    const float *__restrict__ z;  // D
+    uint32_t *__restrict__ volume;
+    float *__restrict__ depth;
+    float *__restrict__ cost;
+    int *__restrict__ index;
+    float invW, invH;
+    float Wp, Hp;  // W + 0.5, H + 0.5
+    const uint2 *__restrict__ plan;
+    int tiles_x, tiles_y, nchunks;
+};
+
+// ------------------------------------------------------------------------------------------------------
+// shared sample arithmetic
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rcp_rn(float w)
+{
+    // v_rcp_f32 is accurate to 1 ulp; one Newton step with FMA yields the correctly rounded
+    // reciprocal (Markstein) for every w whose significand is not all ones -- verified
+    // exhaustively on the device by tests/test_sweep_gpu.py::test_rcp_newton_exact.
+    const float r0 = __builtin_amdgcn_rcpf(w);
+    const float e = __builtin_fmaf(-w, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+
+struct Affine {
+    float ax, ay, aw;
+};
+
+__device__ __forceinline__ Affine view_affine(const float *__restrict__ q, float xn, float yn)
+{
+    Affine a;
+    a.ax = __builtin_fmaf(q[0], xn, __builtin_fmaf(q[1], yn, q[3]));
+    a.ay = __builtin_fmaf(q[4], xn, __builtin_fmaf(q[5], yn, q[7]));
+    a.aw = __builtin_fmaf(q[8], xn, __builtin_fmaf(q[9], yn, q[11]));
+    return a;
+}
+
+__device__ __forceinline__ int bilerp_u8(float ax, float ay, float t00, float dxt, float dy, float dxy)
+{
+    const float a = __builtin_fmaf(ax, dxt, t00);
+    const float b = __builtin_fmaf(ax, dxy, dy);
+    const float res = __builtin_fmaf(ay, b, a);
+    return (int)(res + 0.5f);
+}
+
+// one sample with every check, taps gathered from the padded image in global memory
+__device__ __forceinline__ uint32_t sample_global(const Affine &A, float bx, float by, float bw, float z,
+                                                  const uint8_t *__restrict__ pad, int pitch, float Wp, float Hp,
+                                                  int Im)
+{
+    const float sx = __builtin_fmaf(z, bx, A.ax);
+    const float sy = __builtin_fmaf(z, by, A.ay);
+    const float sw = __builtin_fmaf(z, bw, A.aw);
+    if (!(sw > 0.0f)) return 0u;
+    const float r = rcp_rn(sw);
+    const float cx = sx * r, cy = sy * r;
+    if (!(cx > 0.5f && cx < Wp && cy > 0.5f && cy < Hp)) return 0u;
+    const int ix = (int)cx, iy = (int)cy;
+    const float fx = cx - (float)ix, fy = cy - (float)iy;
+    const uint8_t *p = pad + (size_t)iy * pitch + ix;
+    const float t00 = (float)p[0], t01 = (float)p[1], t10 = (float)p[pitch], t11 = (float)p[pitch + 1];
+    const float dxt = t01 - t00, dy = t10 - t00, dxy = (t11 - t10) - dxt;
+    const int Iq = bilerp_u8(fx, fy, t00, dxt, dy, dxy);
+    return 65536u + (uint32_t)__builtin_abs(Iq - Im);
+}
+
+// running best plane: s/c < bs/bc  <=>  s*bc < bs*c, all factors < 2^16 (exact in u32)
+__device__ __forceinline__ void argmin_update(uint32_t cell, int d, uint32_t &bs, uint32_t &bc, int &bi)
+{
+    const uint32_t s = cell & 0xffffu, c = cell >> 16;
+    const bool better = (c != 0u) && (bi < 0 || __umul24(s, bc) < __umul24(bs, c));
+    bs = better ? s : bs;
+    bc = better ? c : bc;
+    bi = better ? d : bi;
+}
+
+__device__ __forceinline__ void store_best(const SweepParams &p, size_t pix, uint32_t bs, uint32_t bc, int bi)
+{
+    p.depth[pix] = bi >= 0 ? p.z[bi] : MVS_BACKGROUND_DEPTH;
+    p.cost[pix] = bi >= 0 ? (float)bs / (float)bc : __builtin_inff();
+    p.index[pix] = bi;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// generic kernel: one pixel per thread, global gathers
+// ------------------------------------------------------------------------------------------------------
+template <bool WRITE_VOLUME, bool FUSED>
+__global__ __launch_bounds__(256) void sweep_generic(SweepParams p)
+{
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (col >= p.W || row >= p.H) return;
+    const size_t P = (size_t)p.W * p.H;
+    const size_t pix = (size_t)row * p.W + col;
+    const float xn = __builtin_fmaf((float)(2 * col + 1), p.invW, -1.0f);
+    const float yn = __builtin_fmaf(-(float)(2 * row + 1), p.invH, 1.0f);
+    const int Im = p.main_img[pix];
+    uint32_t bs = 0, bc = 0;
+    int bi = -1;
+    for (int d0 = 0; d0 < p.D; d0 += PC) {
+        uint32_t acc[PC];
+#pragma unroll
+        for (int k = 0; k < PC; k++) acc[k] = 0u;
+        for (int v = p.v0; v < p.v0 + p.vcount; v++) {
+            const float *q = p.Q + 12 * v;
+            const Affine A = view_affine(q, xn, yn);
+            const float bx = q[2], by = q[6], bw = q[10];
+            const uint8_t *pad = p.pads + p.pad_slab * v;
+#pragma unroll
+            for (int k = 0; k < PC; k++) {
+                if (d0 + k < p.D)
+                    acc[k] += sample_global(A, bx, by, bw, p.z[d0 + k], pad, p.pitch, p.Wp, p.Hp, Im);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PC; k++) {
+            if (d0 + k < p.D) {
+                if (WRITE_VOLUME) p.volume[(size_t)(d0 + k) * P + pix] = acc[k];
+                if (FUSED) argmin_update(acc[k], d0 + k, bs, bc, bi);
+            }
+        }
+    }
+    if (FUSED) store_best(p, pix, bs, bc, bi);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// region planner: where does tile t land in side view v over the planes of chunk c?
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plan_regions(SweepParams p, uint2 *__restrict__ plan)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = p.tiles_x * p.tiles_y * p.nchunks * p.V;
+    if (tid >= total) return;
+    const int v = tid % p.V;
+    const int rest = tid / p.V;
+    const int chunk = rest % p.nchunks;
+    const int tile = rest / p.nchunks;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int c0 = tx * TILE_W, c1 = min(c0 + TILE_W, p.W) - 1;
+    const int r0 = ty * TILE_H, r1 = min(r0 + TILE_H, p.H) - 1;
+    const int d0 = chunk * PC, d1 = min(d0 + PC, p.D) - 1;
+    const float *q = p.Q + 12 * v;
+    const float bx = q[2], by = q[6], bw = q[10];
+    float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+    bool behind = false;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int col = (k & 1) ? c1 : c0;
+        const int row = (k & 2) ? r1 : r0;
+        const float z = p.z[(k & 4) ? d1 : d0];
+        const float xn = __builtin_fmaf((float)(2 * col + 1), p.invW, -1.0f);
+        const float yn = __builtin_fmaf(-(float)(2 * row + 1), p.invH, 1.0f);
+        const Affine A = view_affine(q, xn, yn);
+        const float sx = __builtin_fmaf(z, bx, A.ax);
+        const float sy = __builtin_fmaf(z, by, A.ay);
+        const float sw = __builtin_fmaf(z, bw, A.aw);
+        if (!(sw > 0.0f)) behind = true;
+        const float r = rcp_rn(sw);
+        const float cx = sx * r, cy = sy * r;
+        xmin = fminf(xmin, cx);
+        xmax = fmaxf(xmax, cx);
+        ymin = fminf(ymin, cy);
+        ymax = fmaxf(ymax, cy);
+    }
+    unsigned mode;
+    int x0 = 0, y0 = 0, rw = 0, rh = 0, pitch = 0;
+    const float m = PLAN_MARGIN;
+    if (behind || !(xmin == xmin) || !(ymin == ymin) || !(xmax < 1.0e9f) || !(ymax < 1.0e9f) || !(xmin > -1.0e9f) ||
+        !(ymin > -1.0e9f)) {
+        mode = R_GENERIC;
+    } else if (xmax < 0.5f - m || xmin > p.Wp + m || ymax < 0.5f - m || ymin > p.Hp + m) {
+        mode = R_SKIP;  // the whole warped box is out of frame: convex hull argument, DESIGN.md
+    } else {
+        x0 = max(0, (int)floorf(xmin - m)) & ~3;
+        const int x1 = min(p.W, (int)floorf(xmax + m));
+        y0 = max(0, (int)floorf(ymin - m));
+        const int y1 = min(p.H, (int)floorf(ymax + m));
+        rw = ((x1 - x0 + 1) + 3) & ~3;
+        rh = y1 - y0 + 1;
+        pitch = (rw + 31) & ~31;
+        if (rw > MAX_RW || rw <= 0 || rh <= 0 || pitch * rh > LDS_QUADS)
+            mode = R_GENERIC;
+        else if (xmin > 0.5f + m && xmax < p.Wp - m && ymin > 0.5f + m && ymax < p.Hp - m)
+            mode = R_FAST;
+        else
+            mode = R_BORDER;
+    }
+    uint2 d;
+    d.x = (unsigned)x0 | ((unsigned)y0 << 16);
+    d.y = (unsigned)rw | ((unsigned)rh << 8) | (mode << 16) | ((unsigned)(pitch >> 5) << 24);
+    plan[tid] = d;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// tiled kernel
+// ------------------------------------------------------------------------------------------------------
+// LDS region format: one 8-byte quad per texel position (y, x) of the padded side image:
+//   { t00, t01 - t00, t10 - t00, (t11 - t10) - (t01 - t00) } as four f16 (all exact integers),
+// so the bilinear fetch is one ds_read_b64 and three v_fma_mix_f32.
+__device__ __forceinline__ void stage_region(const uint8_t *__restrict__ pad, int pitch, int x0, int y0, int rw,
+                                             int rh, int rp, uint2 *__restrict__ lds)
+{
+    const int tx = threadIdx.x & 31;
+    const int ty = threadIdx.x >> 5;
+    const int units = rw >> 2;
+    if (tx < units) {
+        for (int ry = ty; ry < rh; ry += 8) {
+            const uint8_t *r0 = pad + (size_t)(y0 + ry) * pitch + x0 + 4 * tx;
+            const uint32_t d0 = *(const uint32_t *)r0, d1 = *(const uint32_t *)(r0 + 4);
+            const uint32_t e0 = *(const uint32_t *)(r0 + pitch), e1 = *(const uint32_t *)(r0 + pitch + 4);
+            const uint64_t dd = ((uint64_t)d1 << 32) | d0, ee = ((uint64_t)e1 << 32) | e0;
+            uint2 *dst = lds + ry * rp + 4 * tx;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int t00 = (int)((dd >> (8 * k)) & 255u), t01 = (int)((dd >> (8 * k + 8)) & 255u);
+                const int t10 = (int)((ee >> (8 * k)) & 255u), t11 = (int)((ee >> (8 * k + 8)) & 255u);
+                const int dxt = t01 - t00, dy = t10 - t00, dxy = (t11 - t10) - dxt;
+                half4_t h;
+                h[0] = (_Float16)t00;
+                h[1] = (_Float16)dxt;
+                h[2] = (_Float16)dy;
+                h[3] = (_Float16)dxy;
+                dst[k] = __builtin_bit_cast(uint2, h);
+            }
+        }
+    }
+}
+
+// acc + |a - b| in one VALU op (v_sad_u32); hipcc lowers __usad() to a 4-instruction max/min/sub/add
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t acc)
+{
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+    return d;
+}
+
+// wave-uniform value -> SGPR
+__device__ __forceinline__ float uniform_f(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
+// Branch-free LDS sample.  FAST: the planner proved every sample of this (tile, chunk, view) in
+// frame, so no test is evaluated.  Otherwise the test of shader.frag:19 is evaluated per sample and
+// the texel address is clamped into the staged region before the (then discarded) fetch.
+struct RegionView {
+    const char *lds_bytes;
+    int rp8;   // LDS row pitch in bytes
+    int org8;  // byte offset of padded texel (0,0) relative to the region origin (subtracted)
+    int xlo, xhi, ylo, yhi;
+};
+
+template <bool FAST>
+__device__ __forceinline__ uint32_t sample_lds(const Affine &A, float bx, float by, float bw, float z,
+                                               const RegionView &rv, float Wp, float Hp, int Im, uint32_t acc)
+{
+    const float sx = __builtin_fmaf(z, bx, A.ax);
+    const float sy = __builtin_fmaf(z, by, A.ay);
+    const float sw = __builtin_fmaf(z, bw, A.aw);
+    const float r = rcp_rn(sw);
+    const float cx = sx * r, cy = sy * r;
+    // c - trunc(c) for c > 0 (v_fract_f32 is exact there); garbage-in/garbage-out for masked samples
+    const float fx = __builtin_amdgcn_fractf(cx), fy = __builtin_amdgcn_fractf(cy);
+    int ix = (int)cx, iy = (int)cy;
+    if (!FAST) {
+        ix = min(max(ix, rv.xlo), rv.xhi);
+        iy = min(max(iy, rv.ylo), rv.yhi);
+    }
+    const int off = (ix << 3) + (__mul24(iy, rv.rp8) - rv.org8);
+    const half4_t h = *(const half4_t *)(rv.lds_bytes + off);
+    const int Iq = bilerp_u8(fx, fy, (float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    if (FAST) return sad_u32((uint32_t)Iq, (uint32_t)Im, acc);
+    const bool ok = (sw > 0.0f) && (cx > 0.5f) && (cx < Wp) && (cy > 0.5f) && (cy < Hp);
+    return ok ? sad_u32((uint32_t)Iq, (uint32_t)Im, acc + 65536u) : acc;
+}
+
+template <bool WRITE_VOLUME, bool FUSED>
+__global__ __launch_bounds__(256) void sweep_tiled(SweepParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint2 lds[LDS_QUADS];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = tx * TILE_W + lane;
+    const int row0 = ty * TILE_H + wave * NPX;
+    const bool col_ok = col < p.W;
+    const size_t P = (size_t)p.W * p.H;
+    const float xn = __builtin_fmaf((float)(2 * col + 1), p.invW, -1.0f);
+
+    float yn[NPX];
+    int Im[NPX];
+    bool ok[NPX];
+    uint32_t bs[NPX], bc[NPX];
+    int bi[NPX];
+#pragma unroll
+    for (int j = 0; j < NPX; j++) {
+        const int row = row0 + j;
+        ok[j] = col_ok && row < p.H;
+        yn[j] = __builtin_fmaf(-(float)(2 * row + 1), p.invH, 1.0f);
+        Im[j] = ok[j] ? (int)p.main_img[(size_t)row * p.W + col] : 0;
+        bs[j] = 0u;
+        bc[j] = 0u;
+        bi[j] = -1;
+    }
+
+    for (int chunk = 0; chunk < p.nchunks; chunk++) {
+        const int d0 = chunk * PC;
+        // plane constants of this chunk live in SGPRs; planes past D (last chunk) are evaluated on a
+        // clamped z and never stored, so the sample loops carry no per-plane control flow
+        float zc[PC];
+#pragma unroll
+        for (int k = 0; k < PC; k++) zc[k] = uniform_f(p.z[min(d0 + k, p.D - 1)]);
+
+        uint32_t acc[NPX][PC];
+#pragma unroll
+        for (int j = 0; j < NPX; j++)
+#pragma unroll
+            for (int k = 0; k < PC; k++) acc[j][k] = 0u;
+        uint32_t fast_views = 0u;
+        const uint2 *plan = p.plan + ((size_t)tile * p.nchunks + chunk) * p.V;
+
+        for (int v = p.v0; v < p.v0 + p.vcount; v++) {
+            const uint2 desc = plan[v];
+            const unsigned mode = (unsigned)__builtin_amdgcn_readfirstlane((int)((desc.y >> 16) & 3u));
+            if (mode == R_SKIP) continue;
+            float q[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) q[i] = uniform_f(p.Q[12 * v + i]);
+            const float bx = q[2], by = q[6], bw = q[10];
+            const uint8_t *pad = p.pads + p.pad_slab * v;
+            if (mode == R_GENERIC) {
+#pragma unroll
+                for (int j = 0; j < NPX; j++) {
+                    if (ok[j]) {
+                        const Affine A = view_affine(q, xn, yn[j]);
+#pragma unroll
+                        for (int k = 0; k < PC; k++)
+                            acc[j][k] += sample_global(A, bx, by, bw, zc[k], pad, p.pitch, p.Wp, p.Hp, Im[j]);
+                    }
+                }
+                continue;
+            }
+            const int x0 = __builtin_amdgcn_readfirstlane((int)(desc.x & 0xffffu));
+            const int y0 = __builtin_amdgcn_readfirstlane((int)(desc.x >> 16));
+            const int rw = __builtin_amdgcn_readfirstlane((int)(desc.y & 0xffu));
+            const int rh = __builtin_amdgcn_readfirstlane((int)((desc.y >> 8) & 0xffu));
+            const int rp = __builtin_amdgcn_readfirstlane((int)(desc.y >> 24) << 5);
+            __syncthreads();  // all reads of the previous region are done
+            stage_region(pad, p.pitch, x0, y0, rw, rh, rp, lds);
+            __syncthreads();
+            RegionView rv;
+            rv.lds_bytes = (const char *)lds;
+            rv.rp8 = rp * 8;
+            rv.org8 = (y0 * rp + x0) * 8;
+            rv.xlo = x0;
+            rv.xhi = x0 + rw - 1;
+            rv.ylo = y0;
+            rv.yhi = y0 + rh - 1;
+            if (mode == R_FAST) {
+                fast_views += 65536u;
+#pragma unroll
+                for (int j = 0; j < NPX; j++) {
+                    if (ok[j]) {
+                        const Affine A = view_affine(q, xn, yn[j]);
+#pragma unroll
+                        for (int k = 0; k < PC; k++)
+                            acc[j][k] = sample_lds<true>(A, bx, by, bw, zc[k], rv, p.Wp, p.Hp, Im[j], acc[j][k]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NPX; j++) {
+                    if (ok[j]) {
+                        const Affine A = view_affine(q, xn, yn[j]);
+#pragma unroll
+                        for (int k = 0; k < PC; k++)
+                            acc[j][k] = sample_lds<false>(A, bx, by, bw, zc[k], rv, p.Wp, p.Hp, Im[j], acc[j][k]);
+                    }
+                }
+            }
+        }
+
+#pragma unroll
+        for (int j = 0; j < NPX; j++) {
+            if (ok[j]) {
+                const size_t pix = (size_t)(row0 + j) * p.W + col;
+#pragma unroll
+                for (int k = 0; k < PC; k++) {
+                    if (d0 + k < p.D) {
+                        const uint32_t cell = acc[j][k] + fast_views;
+                        if (WRITE_VOLUME) p.volume[(size_t)(d0 + k) * P + pix] = cell;
+                        if (FUSED) argmin_update(cell, d0 + k, bs[j], bc[j], bi[j]);
+                    }
+                }
+            }
+        }
+    }
+    if (FUSED) {
+#pragma unroll
+        for (int j = 0; j < NPX; j++)
+            if (ok[j]) store_best(p, (size_t)(row0 + j) * p.W + col, bs[j], bc[j], bi[j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// depth selection over the packed volume
+// ------------------------------------------------------------------------------------------------------
+// Layout [D][P] keeps a pixel on a lane, so the reduction over planes runs in registers; each thread
+// streams 16-byte loads of 4 consecutive pixels per plane (P % 4 == 0) or single cells otherwise.
+template <int VEC>
+__global__ __launch_bounds__(256) void argmin_volume(const uint32_t *__restrict__ vol, size_t P, int D,
+                                                     const float *__restrict__ z, float *__restrict__ depth,
+                                                     float *__restrict__ cost, int *__restrict__ index)
+{
+    const size_t base = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    if (base >= P) return;
+    uint32_t bs[VEC], bc[VEC];
+    int bi[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+        bs[i] = 0u;
+        bc[i] = 0u;
+        bi[i] = -1;
+    }
+    int d = 0;
+    for (; d + 4 <= D; d += 4) {
+        uint32_t c[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (VEC == 4) {
+                const uint4 t = *(const uint4 *)(vol + (size_t)(d + u) * P + base);
+                c[u][0] = t.x;
+                c[u][1 % VEC] = t.y;
+                c[u][2 % VEC] = t.z;
+                c[u][3 % VEC] = t.w;
+            } else {
+                c[u][0] = vol[(size_t)(d + u) * P + base];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int i = 0; i < VEC; i++) argmin_update(c[u][i], d + u, bs[i], bc[i], bi[i]);
+    }
+    for (; d < D; d++) {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) argmin_update(vol[(size_t)d * P + base + i], d, bs[i], bc[i], bi[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+        depth[base + i] = bi[i] >= 0 ? z[bi[i]] : MVS_BACKGROUND_DEPTH;
+        cost[base + i] = bi[i] >= 0 ? (float)bs[i] / (float)bc[i] : __builtin_inff();
+        index[base + i] = bi[i];
+    }
+}
+
+__global__ void unpack_volume(const uint32_t *__restrict__ vol, float *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t cell = vol[i];
+    const uint32_t s = cell & 0xffffu, c = cell >> 16;
+    out[i] = c ? (float)s / (float)c : __builtin_inff();
+}
+
+// exhaustive self-check helper for the reciprocal (tests): out[0] counts w where rcp_rn(w) != 1.0f/w
+__global__ void rcp_check_kernel(uint32_t exp_bits, unsigned long long *out)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;  // 2^23 mantissas
+    if (m >= (1u << 23)) return;
+    const float w = __builtin_bit_cast(float, (exp_bits << 23) | m);
+    const float a = rcp_rn(w);
+    const float b = 1.0f / w;  // hipcc default: correctly rounded IEEE division
+    if (__builtin_bit_cast(uint32_t, a) != __builtin_bit_cast(uint32_t, b)) {
+        atomicAdd(out, 1ull);
+        if (m == 0x7fffffu) atomicAdd(out + 1, 1ull);
+    }
+}
+
+static int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount)
+{
+    p.main_img = (const uint8_t *)ctx->main_img.ptr;
+    p.pads = (const uint8_t *)ctx->side_pads.ptr;
+    p.pad_slab = ctx->pad_slab;
+    p.pitch = ctx->pad_pitch;
+    p.W = ctx->W;
+    p.H = ctx->H;
+    p.D = ctx->D;
+    p.V = ctx->V;
+    p.v0 = v0;
+    p.vcount = vcount;
+    p.Q = (const float *)ctx->qmats.ptr;
+    p.z = (const float *)ctx->ztab.ptr;
+    p.volume = ctx->volume;
+    p.depth = (float *)ctx->depth.ptr;
+    p.cost = (float *)ctx->cost.ptr;
+    p.index = (int *)ctx->index.ptr;
+    p.invW = 1.0f / (float)ctx->W;
+    p.invH = 1.0f / (float)ctx->H;
+    p.Wp = (float)ctx->W + 0.5f;
+    p.Hp = (float)ctx->H + 0.5f;
+    p.plan = (const uint2 *)ctx->plan.ptr;
+    p.tiles_x = div_up(ctx->W, TILE_W);
+    p.tiles_y = div_up(ctx->H, TILE_H);
+    p.nchunks = div_up(ctx->D, PC);
+    return MVS_OK;
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" {
+
+int mvs_sweep_use_volume(mvs_ctx *ctx, void *device_ptr, size_t bytes)
+{
+    if (!ctx) return MVS_EINVAL;
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!device_ptr) {
+        ctx->volume_external = false;
+        ctx->volume = (uint32_t *)ctx->volume_own.ptr;
+        ctx->volume_bytes = ctx->volume_own.bytes;
+        return MVS_OK;
+    }
+    ctx->volume_external = true;
+    ctx->volume = (uint32_t *)device_ptr;
+    ctx->volume_bytes = bytes;
+    return MVS_OK;
+}
+
+static int ensure_outputs(mvs_ctx *ctx, bool need_volume)
+{
+    const size_t P = (size_t)ctx->W * ctx->H;
+    int rc;
+    if ((rc = ensure(ctx, ctx->depth, P * sizeof(float)))) return rc;
+    if ((rc = ensure(ctx, ctx->cost, P * sizeof(float)))) return rc;
+    if ((rc = ensure(ctx, ctx->index, P * sizeof(int)))) return rc;
+    if (need_volume) {
+        const size_t need = P * (size_t)ctx->D * sizeof(uint32_t);
+        if (ctx->volume_external) {
+            if (ctx->volume_bytes < need)
+                return fail(ctx, MVS_EINVAL, "caller volume is %zu bytes, need %zu", ctx->volume_bytes, need);
+        } else {
+            if ((rc = ensure(ctx, ctx->volume_own, need))) return rc;
+            ctx->volume = (uint32_t *)ctx->volume_own.ptr;
+            ctx->volume_bytes = ctx->volume_own.bytes;
+        }
+    }
+    return MVS_OK;
+}
+
+int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags)
+{
+    if (!ctx) return MVS_EINVAL;
+    if (!ctx->have_main || !ctx->have_views || !ctx->have_planes)
+        return fail(ctx, MVS_ESTATE, "mvs_sweep_run: set main view, side views and planes first");
+    if (view_first < 0 || view_count < 0 || view_first + view_count > ctx->V)
+        return fail(ctx, MVS_EINVAL, "mvs_sweep_run: view range [%d,%d) outside 0..%d", view_first,
+                    view_first + view_count, ctx->V);
+    const bool vol = flags & MVS_SWEEP_VOLUME, fused = flags & MVS_SWEEP_FUSED_ARGMIN;
+    if (!vol && !fused) return fail(ctx, MVS_EINVAL, "mvs_sweep_run: flags select neither volume nor fused argmin");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_outputs(ctx, vol);
+    if (rc) return rc;
+
+    SweepParams p;
+    fill_params(ctx, p, view_first, view_count);
+    const bool generic = (flags & MVS_SWEEP_FORCE_GENERIC) != 0;
+
+    if (!generic && !ctx->plan_valid && ctx->V > 0) {
+        const size_t n = (size_t)p.tiles_x * p.tiles_y * p.nchunks * p.V;
+        if ((rc = ensure(ctx, ctx->plan, n * sizeof(uint2)))) return rc;
+        p.plan = (const uint2 *)ctx->plan.ptr;
+        ProfileScope ps(ctx, MVS_K_PLAN);
+        plan_regions<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(p, (uint2 *)ctx->plan.ptr);
+        MVS_HIP(ctx, hipGetLastError());
+        ctx->plan_valid = true;
+    }
+    {
+        ProfileScope ps(ctx, MVS_K_SWEEP);
+        if (generic || ctx->V == 0) {
+            dim3 grid(div_up(ctx->W, 64), div_up(ctx->H, 4));
+            if (vol && fused)
+                sweep_generic<true, true><<<grid, 256, 0, ctx->stream>>>(p);
+            else if (vol)
+                sweep_generic<true, false><<<grid, 256, 0, ctx->stream>>>(p);
+            else
+                sweep_generic<false, true><<<grid, 256, 0, ctx->stream>>>(p);
+        } else {
+            const unsigned grid = (unsigned)(p.tiles_x * p.tiles_y);
+            if (vol && fused)
+                sweep_tiled<true, true><<<grid, 256, 0, ctx->stream>>>(p);
+            else if (vol)
+                sweep_tiled<true, false><<<grid, 256, 0, ctx->stream>>>(p);
+            else
+                sweep_tiled<false, true><<<grid, 256, 0, ctx->stream>>>(p);
+        }
+        MVS_HIP(ctx, hipGetLastError());
+    }
+    return MVS_OK;
+}
+
+int mvs_sweep_argmin(mvs_ctx *ctx)
+{
+    if (!ctx) return MVS_EINVAL;
+    if (!ctx->have_planes || !ctx->volume)
+        return fail(ctx, MVS_ESTATE, "mvs_sweep_argmin: no cost volume (run mvs_sweep_run with MVS_SWEEP_VOLUME)");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_outputs(ctx, true);
+    if (rc) return rc;
+    const size_t P = (size_t)ctx->W * ctx->H;
+    ProfileScope ps(ctx, MVS_K_ARGMIN);
+    if (P % 4 == 0 && ((uintptr_t)ctx->volume % 16) == 0) {
+        const size_t threads = P / 4;
+        argmin_volume<4><<<(unsigned)((threads + 255) / 256), 256, 0, ctx->stream>>>(
+            ctx->volume, P, ctx->D, (const float *)ctx->ztab.ptr, (float *)ctx->depth.ptr, (float *)ctx->cost.ptr,
+            (int *)ctx->index.ptr);
+    } else {
+        argmin_volume<1><<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(
+            ctx->volume, P, ctx->D, (const float *)ctx->ztab.ptr, (float *)ctx->depth.ptr, (float *)ctx->cost.ptr,
+            (int *)ctx->index.ptr);
+    }
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+void *mvs_sweep_volume_device(mvs_ctx *ctx, size_t *bytes)
+{
+    if (!ctx || !ctx->have_planes) return nullptr;
+    if (ensure_outputs(ctx, true) != MVS_OK) return nullptr;
+    if (bytes) *bytes = (size_t)ctx->W * ctx->H * (size_t)ctx->D * sizeof(uint32_t);
+    return ctx->volume;
+}
+
+void *mvs_sweep_depth_device(mvs_ctx *ctx) { return ctx ? ctx->depth.ptr : nullptr; }
+void *mvs_sweep_cost_device(mvs_ctx *ctx) { return ctx ? ctx->cost.ptr : nullptr; }
+void *mvs_sweep_index_device(mvs_ctx *ctx) { return ctx ? ctx->index.ptr : nullptr; }
+
+int mvs_sweep_fetch(mvs_ctx *ctx, float *depth_hw, float *cost_hw, int32_t *index_hw, uint32_t *packed_volume_dhw)
+{
+    if (!ctx) return MVS_EINVAL;
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->W * ctx->H;
+    if ((depth_hw || cost_hw || index_hw) && !ctx->depth.ptr)
+        return fail(ctx, MVS_ESTATE, "mvs_sweep_fetch: no results yet");
+    if (depth_hw) MVS_HIP(ctx, hipMemcpyAsync(depth_hw, ctx->depth.ptr, P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (cost_hw) MVS_HIP(ctx, hipMemcpyAsync(cost_hw, ctx->cost.ptr, P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (index_hw) MVS_HIP(ctx, hipMemcpyAsync(index_hw, ctx->index.ptr, P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (packed_volume_dhw) {
+        if (!ctx->volume) return fail(ctx, MVS_ESTATE, "mvs_sweep_fetch: no volume");
+        MVS_HIP(ctx, hipMemcpyAsync(packed_volume_dhw, ctx->volume, P * ctx->D * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
+int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, int nviews, const float *side_cams,
+              const uint8_t *const *side_frames, int nplanes, float z_lo, float z_hi, float *depth_hw, float *cost_hw,
+              float *volume_dhw)
+{
+    if (!ctx) return MVS_EINVAL;
+    if (!depth_hw) return fail(ctx, MVS_EINVAL, "mvs_sweep: depth_hw is null");
+    int rc;
+    if ((rc = mvs_sweep_set_main(ctx, main_cam, main_hw))) return rc;
+    if ((rc = mvs_sweep_set_views(ctx, nviews, side_cams, side_frames))) return rc;
+    if ((rc = mvs_sweep_set_planes(ctx, nplanes, z_lo, z_hi))) return rc;
+    const unsigned flags = MVS_SWEEP_FUSED_ARGMIN | (volume_dhw ? MVS_SWEEP_VOLUME : 0u);
+    if ((rc = mvs_sweep_run(ctx, 0, nviews, flags))) return rc;
+    if ((rc = mvs_sweep_fetch(ctx, depth_hw, cost_hw, nullptr, nullptr))) return rc;
+    if (volume_dhw) {
+        const size_t n = (size_t)ctx->W * ctx->H * (size_t)nplanes;
+        if ((rc = ensure(ctx, ctx->r_tmp0, n * sizeof(float)))) return rc;
+        unpack_volume<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(ctx->volume, (float *)ctx->r_tmp0.ptr, n);
+        MVS_HIP(ctx, hipGetLastError());
+        MVS_HIP(ctx, hipMemcpyAsync(volume_dhw, ctx->r_tmp0.ptr, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MVS_OK;
+}
+
+// test hook (not in mvs.h): exhaustive check of the Newton reciprocal for one exponent
+int mvs_test_rcp(mvs_ctx *ctx, unsigned exp_bits, unsigned long long *mismatch, unsigned long long *allones)
+{
+    if (!ctx || !mismatch || !allones) return MVS_EINVAL;
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr;
+    MVS_HIP(ctx, hipMalloc(&d, 16));
+    MVS_HIP(ctx, hipMemsetAsync(d, 0, 16, ctx->stream));
+    rcp_check_kernel<<<(1u << 23) / 256, 256, 0, ctx->stream>>>(exp_bits, d);
+    unsigned long long h[2] = {0, 0};
+    MVS_HIP(ctx, hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MVS_HIP(ctx, hipFree(d));
+    *mismatch = h[0];
+    *allones = h[1];
+    return MVS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+"""ctypes binding of libmvs_hip.so (include/mvs.h) for tests/ and bench.py.
+
+Harness only: the product is the C-ABI library; its real host side is the C++ mirror of recon.hpp in
+mesh-reconstruction_amd/host/.  This module fails loudly when the HIP library is missing -- there is
+no CPU fallback (the oracle lives in oracle/ and is never imported from here).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libmvs_hip.so")
+
+MVS_SWEEP_VOLUME = 1
+MVS_SWEEP_FUSED_ARGMIN = 2
+MVS_SWEEP_FORCE_GENERIC = 4
+MVS_K_SWEEP, MVS_K_ARGMIN, MVS_K_PLAN, MVS_K_RASTER, MVS_K_PROJECT, MVS_K_FLOW = 0, 1, 2, 3, 4, 5
+MVS_K_COUNT = 8
+BACKGROUND_DEPTH = np.float32(1.0)
+
+# every symbol include/mvs.h declares: (name, restype, argtypes)
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_fp, _u8p, _i32p, _u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+ABI = [
+    ("mvs_create", _vp, [_i, _i, _i]),
+    ("mvs_destroy", None, [_vp]),
+    ("mvs_last_error", C.c_char_p, [_vp]),
+    ("mvs_set_stream", _i, [_vp, _vp]),
+    ("mvs_synchronize", _i, [_vp]),
+    ("mvs_width", _i, [_vp]),
+    ("mvs_height", _i, [_vp]),
+    ("mvs_load_mesh", _i, [_vp, _fp, _i, _i32p, _i]),
+    ("mvs_depth", _i, [_vp, _fp, _fp]),
+    ("mvs_projected", _i, [_vp, _fp, _u8p, _fp, _u8p]),
+    ("mvs_mix_background", _i, [_vp, _u8p, _u8p, _fp, _u8p]),
+    ("mvs_compare", _i, [_vp, _u8p, _u8p, _fp]),
+    ("mvs_flow_remap", _i, [_vp, _fp, _i, _u8p, _u8p]),
+    ("mvs_flow", _i, [_vp, _u8p, _u8p, _i, _fp]),
+    ("mvs_sweep", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _f, _f, _fp, _fp, _fp]),
+    ("mvs_sweep_set_main", _i, [_vp, _fp, _u8p]),
+    ("mvs_sweep_set_views", _i, [_vp, _i, _fp, C.POINTER(_u8p)]),
+    ("mvs_sweep_set_planes", _i, [_vp, _i, _f, _f]),
+    ("mvs_sweep_run", _i, [_vp, _i, _i, C.c_uint]),
+    ("mvs_sweep_argmin", _i, [_vp]),
+    ("mvs_sweep_volume_device", _vp, [_vp, C.POINTER(_sz)]),
+    ("mvs_sweep_use_volume", _i, [_vp, _vp, _sz]),
+    ("mvs_sweep_depth_device", _vp, [_vp]),
+    ("mvs_sweep_cost_device", _vp, [_vp]),
+    ("mvs_sweep_index_device", _vp, [_vp]),
+    ("mvs_sweep_fetch", _i, [_vp, _fp, _fp, _i32p, _u32p]),
+    ("mvs_sweep_view_matrices", _i, [_vp, _fp]),
+    ("mvs_profile_enable", _i, [_vp, _i]),
+    ("mvs_profile_read", _i, [_vp, _fp, C.POINTER(_i), _i]),
+    ("mvs_device_info", C.c_char_p, [_vp]),
+]
+
+_lib = None
+
+
+class MvsError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libmvs_hip.so and bind every declared symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise MvsError(
+            "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    for name, res, args in ABI:
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    # test hook, not part of mvs.h
+    if hasattr(lib, "mvs_test_rcp"):
+        lib.mvs_test_rcp.restype = _i
+        lib.mvs_test_rcp.argtypes = [_vp, C.c_uint, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    _lib = lib
+    return lib
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+def _u8(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if shape is not None:
+        assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Context:
+    """One GPU context (mvs_ctx).  Mirrors the life cycle of the reference's RenderGLX (render_glx.cpp:152-227)."""
+
+    def __init__(self, width, height, device=0):
+        self.lib = load_library()
+        self.W, self.H = int(width), int(height)
+        self.h = self.lib.mvs_create(int(device), self.W, self.H)
+        if not self.h:
+            raise MvsError("mvs_create failed: %s" % self.lib.mvs_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mvs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MvsError("libmvs_hip error %d: %s" % (rc, self.lib.mvs_last_error(self.h).decode()))
+
+    def info(self):
+        return self.lib.mvs_device_info(self.h).decode()
+
+    def synchronize(self):
+        self._check(self.lib.mvs_synchronize(self.h))
+
+    def set_stream(self, stream_handle):
+        self._check(self.lib.mvs_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    # ---- sweep ----------------------------------------------------------------------------------
+    def sweep(self, main_cam, main_img, side_cams, side_imgs, nplanes, z_lo=-1.0, z_hi=1.0, want_cost=False,
+              want_volume=False):
+        """mvs_sweep on host buffers -> depth (H,W) [, cost (H,W)] [, volume (D,H,W)]"""
+        W, H = self.W, self.H
+        V = len(side_imgs)
+        cam = _f32(main_cam, (4, 4))
+        img = _u8(main_img, (H, W))
+        cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((0, 4, 4), np.float32)
+        frames = [_u8(s, (H, W)) for s in side_imgs]
+        arr = (_u8p * max(V, 1))(*[_ptr(f, _u8p) for f in frames])
+        depth = np.empty((H, W), np.float32)
+        cost = np.empty((H, W), np.float32) if want_cost else None
+        vol = np.empty((nplanes, H, W), np.float32) if want_volume else None
+        self._check(self.lib.mvs_sweep(self.h, _ptr(cam, _fp), _ptr(img, _u8p), V, _ptr(cams, _fp), arr, int(nplanes),
+                                       float(z_lo), float(z_hi), _ptr(depth, _fp),
+                                       _ptr(cost, _fp) if want_cost else None, _ptr(vol, _fp) if want_volume else None))
+        out = [depth]
+        if want_cost:
+            out.append(cost)
+        if want_volume:
+            out.append(vol)
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def sweep_set(self, main_cam, main_img, side_cams, side_imgs, nplanes, z_lo=-1.0, z_hi=1.0):
+        W, H = self.W, self.H
+        V = len(side_imgs)
+        cam = _f32(main_cam, (4, 4))
+        img = _u8(main_img, (H, W))
+        self._check(self.lib.mvs_sweep_set_main(self.h, _ptr(cam, _fp), _ptr(img, _u8p)))
+        cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((0, 4, 4), np.float32)
+        frames = [_u8(s, (H, W)) for s in side_imgs]
+        arr = (_u8p * max(V, 1))(*[_ptr(f, _u8p) for f in frames])
+        self._check(self.lib.mvs_sweep_set_views(self.h, V, _ptr(cams, _fp), arr))
+        self._check(self.lib.mvs_sweep_set_planes(self.h, int(nplanes), float(z_lo), float(z_hi)))
+        self.V, self.D = V, int(nplanes)
+
+    def sweep_run(self, view_first=0, view_count=None, flags=MVS_SWEEP_VOLUME):
+        if view_count is None:
+            view_count = self.V - view_first
+        self._check(self.lib.mvs_sweep_run(self.h, int(view_first), int(view_count), int(flags)))
+
+    def sweep_argmin(self):
+        self._check(self.lib.mvs_sweep_argmin(self.h))
+
+    def sweep_volume_device(self):
+        n = _sz(0)
+        p = self.lib.mvs_sweep_volume_device(self.h, C.byref(n))
+        if not p:
+            raise MvsError("no volume: %s" % self.lib.mvs_last_error(self.h).decode())
+        return p, n.value
+
+    def sweep_use_volume(self, device_ptr, nbytes):
+        self._check(self.lib.mvs_sweep_use_volume(self.h, C.c_void_p(device_ptr), nbytes))
+
+    def sweep_result_pointers(self):
+        return (self.lib.mvs_sweep_depth_device(self.h), self.lib.mvs_sweep_cost_device(self.h),
+                self.lib.mvs_sweep_index_device(self.h))
+
+    def sweep_fetch(self, want_volume=False):
+        W, H = self.W, self.H
+        depth = np.empty((H, W), np.float32)
+        cost = np.empty((H, W), np.float32)
+        idx = np.empty((H, W), np.int32)
+        vol = np.empty((self.D, H, W), np.uint32) if want_volume else None
+        self._check(self.lib.mvs_sweep_fetch(self.h, _ptr(depth, _fp), _ptr(cost, _fp), _ptr(idx, _i32p),
+                                             _ptr(vol, _u32p) if want_volume else None))
+        return depth, cost, idx, vol
+
+    def sweep_view_matrices(self):
+        q = np.empty((self.V, 3, 4), np.float32)
+        self._check(self.lib.mvs_sweep_view_matrices(self.h, _ptr(q, _fp)))
+        return q
+
+    # ---- profiling ------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.mvs_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self, reset=True):
+        ms = (C.c_float * MVS_K_COUNT)()
+        n = (C.c_int * MVS_K_COUNT)()
+        self._check(self.lib.mvs_profile_read(self.h, ms, n, 1 if reset else 0))
+        return list(ms), list(n)
+
+    # ---- renderer / helpers ---------------------------------------------------------------------
+    def load_mesh(self, verts4, faces3):
+        v = _f32(verts4)
+        f = np.ascontiguousarray(faces3, dtype=np.int32)
+        assert v.ndim == 2 and v.shape[1] == 4 and f.ndim == 2 and f.shape[1] == 3
+        self._check(self.lib.mvs_load_mesh(self.h, _ptr(v, _fp), v.shape[0], _ptr(f, _i32p), f.shape[0]))
+
+    def depth(self, cam):
+        cam = _f32(cam, (4, 4))
+        out = np.empty((self.H, self.W), np.float32)
+        self._check(self.lib.mvs_depth(self.h, _ptr(cam, _fp), _ptr(out, _fp)))
+        return out
+
+    def projected(self, cam, frame, projector):
+        cam = _f32(cam, (4, 4))
+        prj = _f32(projector, (4, 4))
+        frame = _u8(frame, (self.H, self.W))
+        out = np.empty((self.H, self.W, 3), np.uint8)
+        self._check(self.lib.mvs_projected(self.h, _ptr(cam, _fp), _ptr(frame, _u8p), _ptr(prj, _fp), _ptr(out, _u8p)))
+        return out
+
+    def mix_background(self, img3, bg, depth):
+        img3 = _u8(img3, (self.H, self.W, 3))
+        bg = _u8(bg, (self.H, self.W))
+        depth = _f32(depth, (self.H, self.W)).copy()
+        out = np.empty((self.H, self.W), np.uint8)
+        self._check(self.lib.mvs_mix_background(self.h, _ptr(img3, _u8p), _ptr(bg, _u8p), _ptr(depth, _fp),
+                                                _ptr(out, _u8p)))
+        return out, depth
+
+    def compare(self, prev, nxt):
+        prev = _u8(prev, (self.H, self.W))
+        nxt = _u8(nxt, (self.H, self.W))
+        out = np.empty((self.H, self.W), np.float32)
+        self._check(self.lib.mvs_compare(self.h, _ptr(prev, _u8p), _ptr(nxt, _u8p), _ptr(out, _fp)))
+        return out
+
+    def flow_remap(self, flow, image):
+        flow = _f32(flow)
+        assert flow.shape[:2] == (self.H, self.W)
+        image = _u8(image, (self.H, self.W))
+        out = np.empty((self.H, self.W), np.uint8)
+        self._check(self.lib.mvs_flow_remap(self.h, _ptr(flow, _fp), flow.shape[2], _ptr(image, _u8p), _ptr(out, _u8p)))
+        return out
+
+    def flow(self, prev, nxt, use_farneback):
+        prev = _u8(prev, (self.H, self.W))
+        nxt = _u8(nxt, (self.H, self.W))
+        out = np.empty((self.H, self.W, 4), np.float32)
+        self._check(self.lib.mvs_flow(self.h, _ptr(prev, _u8p), _ptr(nxt, _u8p), 1 if use_farneback else 0,
+                                      _ptr(out, _fp)))
+        return out
+
+    def test_rcp(self, exp_bits):
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._check(self.lib.mvs_test_rcp(self.h, exp_bits, C.byref(a), C.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,103 @@
+/*
+ * mvs_oracle.h -- CPU restatement of the dense-MVS hot path of addam/mesh-reconstruction.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ may be imported, linked or executed by the
+ * product path (mesh-reconstruction_amd/, include/).  Allowed users: tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg -- always as the checker / reported baseline, never as the thing
+ * shipped or measured as the product.
+ *
+ * PARITY UNPINNED: the reference holds no golden outputs, known-answer tests or fixtures for this
+ * path and cannot be compiled in this image (OpenCV, GLEW, GLX server and
+ * CGAL are absent), so this restatement is anchored only on the reference's source semantics
+ * (file:line cited per function) plus the OpenGL 3.0 rules the reference relies on.
+ *
+ * All images are top-down, row-major, tightly packed.  Camera matrices are 4x4 float, row-major,
+ * applied as P * (x, y, z, 1)^T (reference: glUniformMatrix4fv(..., GL_TRUE, ...), render_glx.cpp:265,338,375).
+ */
+#ifndef MVS_ORACLE_H
+#define MVS_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_BACKGROUND_DEPTH 1.0f /* recon.hpp:30 */
+
+/* ---- plane-sweep cost volume (D-plane generalisation of shader.frag:11-25) ------------------- */
+
+/* 3x4 "view matrix" Q = S * side_cam * inverse(main_cam) rounded to f32 (row-major, 12 floats):
+ * maps main-camera NDC (x, y, z, 1) to (cx*w, cy*w, w) where (cx, cy) is the sampling position in
+ * the 1-pixel wrap-padded side image (DESIGN.md "sweep arithmetic"). */
+void orc_view_matrix(const float main_cam[16], const float side_cam[16], int W, int H, float Q[12]);
+
+/* wrap-pad (GL_REPEAT, render_glx.cpp:81-82) a WxH u8 image to (H+2) rows of `pitch` bytes */
+void orc_pad_image(const uint8_t *img, int W, int H, uint8_t *pad, int pitch);
+
+/* plane table: z_d = z_lo + (z_hi - z_lo) * (d + 0.5) / D, evaluated in double, rounded to f32 */
+void orc_plane_table(int D, float z_lo, float z_hi, float *z);
+
+/* one sample of the sweep: returns 1 if in frame and writes the u8-rounded warped intensity */
+int orc_sweep_sample(const float Q[12], float xn, float yn, float z, const uint8_t *pad, int pitch,
+                     int W, int H, int *Iq);
+
+/* NDC centre of pixel (col,row): Appendix A-2 of SURVEY.md (GL window coordinates, top-down image) */
+float orc_pixel_xn(int col, int W);
+float orc_pixel_yn(int row, int H);
+
+/*
+ * Full sweep for one main view.  volume (nullable) is D*H*W packed cells (cnt << 16) | sum where
+ * sum = sum over in-frame views of |I_main - round(bilinear I_v)| and cnt = number of in-frame views.
+ * first_view/num_views select the sub-range of side views accumulated (a rank's shard); depth
+ * selection is done on exactly that range.  nthreads <= 1: scalar loop (the reference has no threads).
+ */
+void orc_sweep(const float main_cam[16], const uint8_t *main_img, int W, int H,
+               int V, const float *side_cams /* V*16 */, const uint8_t *const *side_imgs,
+               int D, float z_lo, float z_hi,
+               uint32_t *volume /* nullable */, float *depth /* H*W */, float *best_cost /* nullable */,
+               int32_t *best_idx /* nullable */, int nthreads);
+
+/* per-pixel depth selection over a packed volume: lowest d minimising sum/cnt (exact integer
+ * cross-multiplied comparison); no valid plane -> depth 1.0 (backgroundDepth), idx -1, cost +inf */
+void orc_argmin(const uint32_t *volume, int W, int H, int D, const float *z,
+                float *depth, float *best_cost, int32_t *best_idx);
+
+/* ---- renderer (render_glx.cpp:230-397 + shader.vert/frag) ---------------------------------- */
+
+/* loadMesh: dehomogenise + expand to triangle soup; out_soup holds 9*nfaces floats. render_glx.cpp:230-258 */
+void orc_load_mesh(const float *verts4, int nverts, const int32_t *faces3, int nfaces, float *out_soup);
+
+/* window-space z-buffer (GL_LESS against clear value 1.0; top-left fill rule; clip -w<=z<=w via
+ * per-pixel test, near-plane crossing handled with homogeneous edge functions). Output: window z
+ * in [0,1] in GL orientation (row 0 = bottom). */
+void orc_raster_window_z(const float *soup, int nfaces, const float cam[16], int W, int H, float *zwin_gl);
+
+/* Render::depth: NDC z = 2*zwin-1, top-down, empty = 1.0. render_glx.cpp:369-397 */
+void orc_depth(const float *soup, int nfaces, const float cam[16], int W, int H, float *depth_td);
+
+/* the in-place 3x3 shadow "dilation" with its row-0 recursive-min quirk, literal: render_glx.cpp:287-314 */
+void orc_shadow_dilate(float *zwin_gl, int W, int H);
+
+/* Render::projected: shadow pass, dilation, projective texture pass; out is H*W*3 u8 top-down.
+ * render_glx.cpp:261-367 + shader.frag:11-25 */
+void orc_projected(const float *soup, int nfaces, const float cam[16], const uint8_t *frame,
+                   const float projector[16], int W, int H, uint8_t *out_hw3);
+
+/* ---- photometric helpers (util.cpp) --------------------------------------------------------- */
+
+/* util.cpp:366-387; mutates depth */
+void orc_mix_background(const uint8_t *img_hw3, const uint8_t *bg_hw, float *depth_hw, uint8_t *out_hw,
+                        int W, int H);
+
+/* util.cpp:332-361: multi-scale L1 pyramid difference of two u8 (or f32) images */
+void orc_compare_u8(const uint8_t *prev, const uint8_t *next, int W, int H, float *out);
+void orc_compare_f32(const float *prev, const float *next, int W, int H, float *out);
+
+/* util.cpp:390-403: bicubic remap of a u8 image by a dense flow (stride = floats per pixel: 2 or 4) */
+void orc_flow_remap(const float *flow, int stride, const uint8_t *image, int W, int H, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,123 @@
+"""ctypes loader of the CPU oracle (oracle/_build/libmvs_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "_build", "libmvs_oracle.so")
+
+_fp, _u8p, _i32p, _u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+
+
+def build(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return LIB
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        L = lib
+        L.orc_view_matrix.argtypes = [_fp, _fp, C.c_int, C.c_int, _fp]
+        L.orc_pad_image.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int]
+        L.orc_plane_table.argtypes = [C.c_int, C.c_float, C.c_float, _fp]
+        L.orc_sweep.argtypes = [_fp, _u8p, C.c_int, C.c_int, C.c_int, _fp, C.POINTER(_u8p), C.c_int, C.c_float,
+                                C.c_float, _u32p, _fp, _fp, _i32p, C.c_int]
+        L.orc_argmin.argtypes = [_u32p, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _i32p]
+        L.orc_mix_background.argtypes = [_u8p, _u8p, _fp, _u8p, C.c_int, C.c_int]
+        L.orc_sweep_sample.argtypes = [_fp, C.c_float, C.c_float, C.c_float, _u8p, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(C.c_int)]
+        L.orc_sweep_sample.restype = C.c_int
+        L.orc_pixel_xn.restype = C.c_float
+        L.orc_pixel_xn.argtypes = [C.c_int, C.c_int]
+        L.orc_pixel_yn.restype = C.c_float
+        L.orc_pixel_yn.argtypes = [C.c_int, C.c_int]
+        for name, args in [
+            ("orc_load_mesh", [_fp, C.c_int, _i32p, C.c_int, _fp]),
+            ("orc_raster_window_z", [_fp, C.c_int, _fp, C.c_int, C.c_int, _fp]),
+            ("orc_depth", [_fp, C.c_int, _fp, C.c_int, C.c_int, _fp]),
+            ("orc_shadow_dilate", [_fp, C.c_int, C.c_int]),
+            ("orc_projected", [_fp, C.c_int, _fp, _u8p, _fp, C.c_int, C.c_int, _u8p]),
+            ("orc_compare_u8", [_u8p, _u8p, C.c_int, C.c_int, _fp]),
+            ("orc_compare_f32", [_fp, _fp, C.c_int, C.c_int, _fp]),
+            ("orc_flow_remap", [_fp, C.c_int, _u8p, C.c_int, C.c_int, _u8p]),
+        ]:
+            if hasattr(L, name):
+                getattr(L, name).argtypes = args
+
+    @staticmethod
+    def _p(a, t):
+        return a.ctypes.data_as(t)
+
+    def view_matrix(self, main_cam, side_cam, W, H):
+        m = np.ascontiguousarray(main_cam, np.float32)
+        s = np.ascontiguousarray(side_cam, np.float32)
+        q = np.empty((3, 4), np.float32)
+        self.lib.orc_view_matrix(self._p(m, _fp), self._p(s, _fp), W, H, self._p(q, _fp))
+        return q
+
+    def plane_table(self, D, z_lo, z_hi):
+        z = np.empty(D, np.float32)
+        self.lib.orc_plane_table(D, z_lo, z_hi, self._p(z, _fp))
+        return z
+
+    def pad_image(self, img):
+        H, W = img.shape
+        pad = np.empty((H + 2, W + 2), np.uint8)
+        img = np.ascontiguousarray(img, np.uint8)
+        self.lib.orc_pad_image(self._p(img, _u8p), W, H, self._p(pad, _u8p), W + 2)
+        return pad
+
+    def sweep(self, main_cam, main_img, side_cams, side_imgs, D, z_lo=-1.0, z_hi=1.0, want_volume=False,
+              nthreads=1):
+        H, W = main_img.shape
+        V = len(side_imgs)
+        cam = np.ascontiguousarray(main_cam, np.float32)
+        img = np.ascontiguousarray(main_img, np.uint8)
+        cams = np.ascontiguousarray(np.asarray(side_cams, np.float32).reshape(max(V, 0), 16)) if V else np.zeros((1, 16), np.float32)
+        frames = [np.ascontiguousarray(s, np.uint8) for s in side_imgs]
+        arr = (_u8p * max(V, 1))(*[self._p(f, _u8p) for f in frames])
+        depth = np.empty((H, W), np.float32)
+        cost = np.empty((H, W), np.float32)
+        idx = np.empty((H, W), np.int32)
+        vol = np.empty((D, H, W), np.uint32) if want_volume else None
+        self.lib.orc_sweep(self._p(cam, _fp), self._p(img, _u8p), W, H, V, self._p(cams, _fp), arr, D, z_lo, z_hi,
+                           self._p(vol, _u32p) if want_volume else None, self._p(depth, _fp), self._p(cost, _fp),
+                           self._p(idx, _i32p), nthreads)
+        return depth, cost, idx, vol
+
+    def argmin(self, vol, z):
+        D, H, W = vol.shape
+        vol = np.ascontiguousarray(vol, np.uint32)
+        z = np.ascontiguousarray(z, np.float32)
+        depth = np.empty((H, W), np.float32)
+        cost = np.empty((H, W), np.float32)
+        idx = np.empty((H, W), np.int32)
+        self.lib.orc_argmin(self._p(vol, _u32p), W, H, D, self._p(z, _fp), self._p(depth, _fp), self._p(cost, _fp),
+                            self._p(idx, _i32p))
+        return depth, cost, idx
+
+    def mix_background(self, img3, bg, depth):
+        H, W = bg.shape
+        img3 = np.ascontiguousarray(img3, np.uint8)
+        bg = np.ascontiguousarray(bg, np.uint8)
+        depth = np.ascontiguousarray(depth, np.float32).copy()
+        out = np.empty((H, W), np.uint8)
+        self.lib.orc_mix_background(self._p(img3, _u8p), self._p(bg, _u8p), self._p(depth, _fp), self._p(out, _u8p), W, H)
+        return out, depth
+
+
+_oracle = None
+
+
+def load():
+    global _oracle
+    if _oracle is None:
+        build()
+        _oracle = Oracle(C.CDLL(LIB))
+    return _oracle

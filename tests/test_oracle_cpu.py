@@ -1,0 +1,142 @@
+"""CPU tests of the oracle itself (no GPU): algebra cross-checks, properties, golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import np_mirror
+from mvs_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rot_cam(W, H, center, yaw, pitch):
+    cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    return synth.camera_at(center, W, H, rot=Rx @ Ry)
+
+
+def test_view_matrix_matches_float64_algebra(oracle):
+    W, H = 96, 64
+    main = synth.camera_at([0, 0, 0], W, H)
+    side = _rot_cam(W, H, [0.2, -0.1, 0.05], 0.04, -0.03)
+    q = oracle.view_matrix(main, side, W, H).astype(np.float64)
+    T = side.astype(np.float64) @ np.linalg.inv(main.astype(np.float64))
+    ref = np.stack([W / 2 * T[0] + (W / 2 + 0.5) * T[3], -H / 2 * T[1] + (H / 2 + 0.5) * T[3], T[3]])
+    np.testing.assert_allclose(q, ref, rtol=2e-6, atol=1e-6 * np.abs(ref).max())
+
+
+def test_pad_image_wraps(oracle):
+    img = np.arange(5 * 7, dtype=np.uint8).reshape(5, 7)
+    pad = oracle.pad_image(img)
+    assert pad.shape == (7, 9)
+    np.testing.assert_array_equal(pad[1:-1, 1:-1], img)
+    np.testing.assert_array_equal(pad[0, 1:-1], img[-1])
+    np.testing.assert_array_equal(pad[-1, 1:-1], img[0])
+    np.testing.assert_array_equal(pad[1:-1, 0], img[:, -1])
+    assert pad[0, 0] == img[-1, -1] and pad[-1, -1] == img[0, 0]
+
+
+def test_plane_table(oracle):
+    z = oracle.plane_table(4, -1.0, 1.0)
+    np.testing.assert_array_equal(z, np.array([-0.75, -0.25, 0.25, 0.75], np.float32))
+    assert not np.any(oracle.plane_table(128, -1.0, 1.0) == 1.0)  # never backgroundDepth
+
+
+@pytest.mark.parametrize("rot", [False, True])
+def test_sample_plane_matches_numpy_mirror(oracle, rot):
+    """the folded f32 sample path agrees with the float64 two-camera warp except at u8 rounding edges"""
+    W, H, D = 80, 56, 8
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, 2, freq_scale=0.3)
+    if rot:
+        side_cams = np.stack([_rot_cam(W, H, [0.12, 0.05, 0.02], 0.03, 0.02), _rot_cam(W, H, [-0.5, 0.3, -0.1], -0.3, 0.2)])
+    z = oracle.plane_table(D, -1.0, 1.0)
+    for v in range(2):
+        # single-view sweep against a black main image: cell = cnt<<16 | Iq
+        _, _, _, vol = oracle.sweep(main_cam, np.zeros((H, W), np.uint8), side_cams[v:v + 1], sides[v:v + 1], D,
+                                    want_volume=True)
+        for d in range(D):
+            res, valid = np_mirror.warp_plane(main_cam, side_cams[v], sides[v], float(z[d]))
+            cnt = (vol[d] >> 16).astype(bool)
+            iq = (vol[d] & 0xffff).astype(np.float64)
+            # validity may differ only where the position is within float noise of the frame edge
+            assert np.mean(cnt != valid) < 2e-3
+            both = cnt & valid
+            diff = np.abs(iq - np.floor(res + 0.5))[both]
+            assert diff.max() <= 1.0
+            assert np.mean(diff > 0) < 5e-3  # only at x.5 rounding boundaries
+
+
+def test_sweep_recovers_ground_truth_depth(oracle):
+    W, H, D, V = 192, 144, 32, 4
+    main_cam, main_img, side_cams, sides, gt = synth.make_views(W, H, V, radius=0.4)
+    depth, cost, idx, _ = oracle.sweep(main_cam, main_img, side_cams, sides, D, nthreads=4)
+    step = 2.0 / D
+    err = np.abs(depth - gt)[8:-8, 8:-8]
+    assert np.median(err) <= step
+    assert np.mean(err <= 1.5 * step) > 0.95
+    assert np.all(idx >= 0) and np.all(np.isfinite(cost))
+
+
+def test_no_views_gives_background(oracle):
+    W, H = 16, 12
+    main_cam, main_img, _, _, _ = synth.make_views(W, H, 0)
+    depth, cost, idx, vol = oracle.sweep(main_cam, main_img, np.zeros((0, 4, 4)), [], 4, want_volume=True)
+    assert np.all(depth == np.float32(1.0)) and np.all(idx == -1) and np.all(np.isinf(cost)) and np.all(vol == 0)
+
+
+def test_argmin_ties_and_empty(oracle):
+    z = oracle.plane_table(4, -1.0, 1.0)
+    vol = np.zeros((4, 1, 4), np.uint32)
+    # pixel 0: equal normalised cost 10/2 == 5/1 at d=1 and d=2 -> lowest d wins
+    vol[:, 0, 0] = [(1 << 16) | 9, (2 << 16) | 10, (1 << 16) | 5, (1 << 16) | 7]
+    # pixel 1: no valid plane
+    # pixel 2: only d=3 valid
+    vol[3, 0, 2] = (3 << 16) | 30
+    # pixel 3: 7/3 < 5/2
+    vol[:, 0, 3] = [(2 << 16) | 5, (3 << 16) | 7, 0, (1 << 16) | 3]
+    depth, cost, idx = oracle.argmin(vol, z)
+    assert idx[0].tolist() == [1, -1, 3, 1]
+    assert depth[0, 1] == np.float32(1.0) and np.isinf(cost[0, 1])
+    assert cost[0, 0] == 5.0 and cost[0, 2] == 10.0 and cost[0, 3] == np.float32(7) / np.float32(3)
+
+
+def test_view_shards_add_exactly(oracle):
+    """packed cells of view shards sum to the full-view volume (the all-reduce invariant)"""
+    W, H, D, V = 64, 40, 16, 4
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, freq_scale=0.3)
+    _, _, _, full = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True)
+    acc = np.zeros_like(full)
+    for r in range(2):
+        _, _, _, part = oracle.sweep(main_cam, main_img, side_cams[2 * r:2 * r + 2], sides[2 * r:2 * r + 2], D,
+                                     want_volume=True)
+        acc += part
+    np.testing.assert_array_equal(acc, full)
+    z = oracle.plane_table(D, -1.0, 1.0)
+    d_full = oracle.sweep(main_cam, main_img, side_cams, sides, D)[0]
+    np.testing.assert_array_equal(oracle.argmin(acc, z)[0], d_full)
+
+
+def test_mix_background(oracle):
+    rng = np.random.default_rng(1)
+    H, W = 6, 9
+    img3 = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    img3[..., 1] = np.where(rng.random((H, W)) < 0.4, 0, 255)
+    bg = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    depth = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    depth[rng.random((H, W)) < 0.3] = 1.0
+    out, d2 = oracle.mix_background(img3, bg, depth)
+    masked = (depth == 1.0) | (img3[..., 1] == 0)
+    np.testing.assert_array_equal(out, np.where(masked, bg, img3[..., 0]))
+    np.testing.assert_array_equal(d2, np.where(masked, np.float32(1.0), depth))
+
+
+def test_golden_sweep_fixture(oracle):
+    """pins the oracle against the committed vectors (tests/golden/make_golden.py regenerates them)"""
+    g = np.load(os.path.join(GOLDEN, "sweep_small.npz"))
+    depth, cost, idx, vol = oracle.sweep(g["main_cam"], g["main_img"], g["side_cams"], list(g["side_imgs"]),
+                                         int(g["D"]), want_volume=True)
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(depth, g["depth"])
+    np.testing.assert_array_equal(vol, g["vol"])

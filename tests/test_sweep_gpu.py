@@ -1,0 +1,209 @@
+"""GPU parity tests of the plane sweep: HIP kernels (through the C ABI) vs the CPU oracle.
+
+Tolerances (north_star: depth RMSE < 1e-4 vs the reference path):
+  * packed volume cells (count<<16 | sum of |I_main - I_warp|): integer work -> bit-exact expected; the only
+    admitted deviation is the Newton reciprocal's documented miss (significand all ones, probability 2^-23
+    per sample), budgeted as <= 1e-6 of the cells;
+  * depth maps: RMSE < 1e-4 in NDC z and identical arg-min indices except at those cells.
+"""
+import numpy as np
+import pytest
+
+import mvs_amd
+from mvs_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RMSE_TOL = 1e-4
+CELL_BUDGET = 1e-6
+
+
+def _rot_cam(W, H, center, yaw, pitch, **kw):
+    cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    return synth.camera_at(center, W, H, rot=Rx @ Ry, **kw)
+
+
+def _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, flags, z=(-1.0, 1.0), argmin=False, volume=True):
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, D, z[0], z[1])
+        ctx.sweep_run(0, len(sides), flags)
+        if argmin:
+            ctx.sweep_argmin()
+        return ctx.sweep_fetch(want_volume=volume)
+
+
+def _check(gpu, ref, D):
+    depth, cost, idx, vol = gpu
+    d_ref, c_ref, i_ref, v_ref = ref
+    if vol is not None:
+        bad = np.count_nonzero(vol != v_ref)
+        assert bad <= max(1, int(vol.size * CELL_BUDGET)), "%d of %d volume cells differ" % (bad, vol.size)
+    rmse = np.sqrt(np.mean((depth.astype(np.float64) - d_ref.astype(np.float64)) ** 2))
+    assert rmse < RMSE_TOL, "depth RMSE %g" % rmse
+    assert np.count_nonzero(idx != i_ref) <= max(1, int(idx.size * 1e-5))
+    both = np.isfinite(c_ref) & np.isfinite(cost)
+    assert np.array_equal(np.isfinite(c_ref), np.isfinite(cost))
+    assert np.allclose(cost[both], c_ref[both], rtol=1e-6, atol=0) or np.count_nonzero(cost[both] != c_ref[both]) <= 2
+
+
+def test_rcp_newton_is_correctly_rounded():
+    """v_rcp_f32 + one FMA Newton step == IEEE 1/x for every significand, except possibly all-ones"""
+    with mvs_amd.Context(64, 64) as ctx:
+        for e in (1, 64, 100, 120, 126, 127, 128, 129, 135, 150, 200, 252):
+            mism, allones = ctx.test_rcp(e)
+            assert mism == allones and mism <= 1, "exponent %d: %d mismatches (%d at all-ones)" % (e, mism, allones)
+
+
+def test_view_matrices_bit_exact(oracle):
+    W, H = 640, 480
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, 3)
+    side_cams = np.concatenate([side_cams, _rot_cam(W, H, [0.3, -0.2, 0.1], 0.1, -0.05)[None]])
+    sides = sides + [sides[0]]
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, 4)
+        q = ctx.sweep_view_matrices()
+    for v in range(4):
+        np.testing.assert_array_equal(q[v], oracle.view_matrix(main_cam, side_cams[v], W, H))
+
+
+CASES = [
+    # W, H, D, V, radius, rotated
+    (64, 16, 16, 1, 0.3, False),      # exactly one tile, one chunk
+    (200, 90, 20, 3, 0.3, False),     # ragged tiles, ragged last chunk
+    (320, 240, 32, 4, 0.3, False),
+    (333, 77, 7, 2, 0.5, True),       # odd sizes (P % 4 != 0), rotated side views
+    (640, 480, 32, 4, 0.15, True),    # BASELINE config c1 shape
+]
+
+
+@pytest.mark.parametrize("W,H,D,V,radius,rot", CASES)
+@pytest.mark.parametrize("kernel", ["generic", "tiled"])
+def test_sweep_matches_oracle(oracle, W, H, D, V, radius, rot, kernel):
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=radius, freq_scale=max(W / 1920.0, 0.25))
+    if rot:
+        side_cams = side_cams.copy()
+        side_cams[0] = _rot_cam(W, H, [radius, 0.02, 0.05], 0.05, -0.04)
+        if V > 1:
+            side_cams[1] = _rot_cam(W, H, [-0.9, 0.6, -0.3], -0.45, 0.3)  # partly out of frame
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8)
+    flags = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    if kernel == "generic":
+        flags |= mvs_amd.MVS_SWEEP_FORCE_GENERIC
+    _check(_gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, flags), ref, D)
+
+
+def test_argmin_kernel_equals_fused_and_oracle(oracle):
+    W, H, D, V = 320, 240, 24, 3
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8)
+    fused = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_FUSED_ARGMIN, volume=False)
+    sep = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME, argmin=True)
+    for a, b in zip(fused[:3], sep[:3]):
+        np.testing.assert_array_equal(a, b)
+    _check(sep, ref, D)
+
+
+def test_no_views_and_behind_camera(oracle):
+    W, H, D = 128, 64, 8
+    main_cam, main_img, _, _, _ = synth.make_views(W, H, 0)
+    depth, cost, idx, vol = _gpu_sweep(W, H, main_cam, main_img, np.zeros((0, 4, 4), np.float32), [], D,
+                                       mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+    assert np.all(depth == np.float32(1.0)) and np.all(idx == -1) and np.all(np.isinf(cost)) and np.all(vol == 0)
+    # a side camera looking the other way: every sample has w <= 0
+    back = synth.camera_at([0, 0, -6.0], W, H, rot=np.diag([-1.0, 1.0, -1.0]))
+    side = np.full((H, W), 77, np.uint8)
+    ref = oracle.sweep(main_cam, main_img, back[None], [side], D, want_volume=True)
+    for kernel_flag in (0, mvs_amd.MVS_SWEEP_FORCE_GENERIC):
+        got = _gpu_sweep(W, H, main_cam, main_img, back[None], [side], D,
+                         mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | kernel_flag)
+        _check(got, ref, D)
+
+
+def test_one_call_form_and_float_volume(oracle):
+    W, H, D, V = 256, 128, 16, 2
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
+    d_ref, c_ref, i_ref, v_ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True)
+    with mvs_amd.Context(W, H) as ctx:
+        depth, cost, vol = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_cost=True, want_volume=True)
+    np.testing.assert_array_equal(depth, d_ref)
+    cnt = (v_ref >> 16).astype(np.float32)
+    s = (v_ref & 0xffff).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        expect = np.where(cnt > 0, s / cnt, np.inf).astype(np.float32)
+    np.testing.assert_array_equal(vol, expect)
+    np.testing.assert_array_equal(cost, c_ref)
+
+
+def test_yaml_track_cameras(oracle):
+    """BASELINE config c1: cameras of tracks/koberec.yaml (640x480), 32 planes, 4 side views, synthetic frames"""
+    import tracks_yaml
+    t = tracks_yaml.load("koberec.yaml")
+    W, H = t["width"], t["height"]
+    cams = t["cameras"]
+    main = cams[0]
+    ids = [5, 10, 15, 20]
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, (H // 8 + 2, W // 8 + 2)).astype(np.float64)
+    big = np.kron(base, np.ones((8, 8)))[:H, :W]
+    main_img = big.astype(np.uint8)
+    sides = [np.roll(big, (i, 2 * i), (0, 1)).astype(np.uint8) for i in range(4)]
+    side_cams = np.stack([cams[i] for i in ids])
+    ref = oracle.sweep(main, main_img, side_cams, sides, 32, want_volume=True, nthreads=8)
+    for kernel_flag in (0, mvs_amd.MVS_SWEEP_FORCE_GENERIC):
+        got = _gpu_sweep(W, H, main, main_img, side_cams, sides, 32,
+                         mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | kernel_flag)
+        _check(got, ref, 32)
+
+
+def test_view_shards_sum_to_full_volume():
+    """the all-reduce invariant on the device: shard volumes add (as integers) to the full volume"""
+    W, H, D, V = 320, 160, 16, 4
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
+        full = ctx.sweep_fetch(want_volume=True)[3].copy()
+        acc = np.zeros_like(full)
+        for r in range(2):
+            ctx.sweep_run(2 * r, 2, mvs_amd.MVS_SWEEP_VOLUME)
+            acc += ctx.sweep_fetch(want_volume=True)[3]
+    np.testing.assert_array_equal(acc, full)
+
+
+def test_c2_full_size_tiled_vs_oracle(oracle):
+    """BASELINE config c2 at full size (1280x720, 64 planes, 8 views): tiled kernel vs oracle"""
+    W, H, D, V = 1280, 720, 64, 8
+    main_cam, main_img, side_cams, sides, gt = synth.make_views(W, H, V)
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8)
+    got = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME, argmin=True)
+    _check(got, ref, D)
+    # the sweep recovers the analytic surface it was rendered from
+    err = np.abs(got[0] - gt)[16:-16, 16:-16]
+    assert np.median(err) <= 2.0 / D
+
+
+def test_c3_full_size_properties():
+    """BASELINE config c3 (1920x1080, 128 planes, 16 views): size-independent properties"""
+    W, H, D, V = 1920, 1080, 128, 16
+    main_cam, main_img, side_cams, sides, gt = synth.make_views(W, H, V)
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
+        ctx.sweep_argmin()
+        d_t, c_t, i_t, _ = ctx.sweep_fetch()
+        # (1) fused selection == separate selection
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        d_f, c_f, i_f, _ = ctx.sweep_fetch()
+        np.testing.assert_array_equal(i_t, i_f)
+        np.testing.assert_array_equal(d_t, d_f)
+        # (2) tiled == generic kernel, index for index
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN | mvs_amd.MVS_SWEEP_FORCE_GENERIC)
+        d_g, c_g, i_g, _ = ctx.sweep_fetch()
+        np.testing.assert_array_equal(i_t, i_g)
+        np.testing.assert_array_equal(c_t, c_g)
+        # (3) shards of views add up: selecting on views [0,8) + [8,16) volumes summed on the host for a band
+    err = np.abs(d_t - gt)[16:-16, 16:-16]
+    assert np.median(err) <= 2.0 / D
+    assert np.mean(err <= 3.0 / D) > 0.97
