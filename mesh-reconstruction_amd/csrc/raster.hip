@@ -1,0 +1,464 @@
+// raster.hip -- the reference's off-screen renderer as HIP kernels for gfx950.
+//
+// Replaces (one kernel per GL draw / transfer of SURVEY.md section 2.1):
+//   Render::loadMesh   render_glx.cpp:230-258   -> mvs_load_mesh   (dehomogenised triangle soup in HBM)
+//   Render::depth      render_glx.cpp:369-397   -> tri_setup + raster_tiles
+//   Render::projected  render_glx.cpp:261-367   -> tri_setup + raster_tiles (shadow pass, GL orientation)
+//                                                  -> row0_prefix_min + shadow_dilate (the CPU loop 287-314)
+//                                                  -> tri_setup + raster_tiles (main pass) -> project_texture
+//                                                  (shader.vert:9-13, shader.frag:11-25)
+//   mixBackground      util.cpp:366-387         -> mix_background
+// No readbacks between the passes: the reference's two glReadPixels + two uploads per (main, side)
+// pair (render_glx.cpp:286,325,359,75) become HBM-resident buffers.
+//
+// Arithmetic contract: identical to oracle/raster_oracle.c (homogeneous edge functions, one tie rule,
+// f32 window z, perspective-correct `pos`); built with -ffp-contract=off so results are bit-exact.
+//
+// Rasterisation strategy: no atomics.  One 256-thread workgroup owns a 16x16 pixel tile; triangles
+// are culled against the tile 256 at a time (one bounding box per lane, survivors compacted through
+// LDS), then every thread walks the survivor list for its own pixel with wave-uniform (SGPR) triangle
+// records.  Visibility is resolved in registers in submission order, exactly like GL_LESS.
+#include "mvs_internal.hpp"
+
+namespace mvs {
+
+struct TriRec {          // 64 bytes
+    float a[3], b[3], c[3];
+    float za, zb, zc;
+    int x0y0;            // packed int16 bbox (inclusive); x0 > x1 marks an invalid triangle
+    int x1y1;
+    int pad0, pad1;
+};
+
+__device__ __forceinline__ float xform(const float *__restrict__ m, float x, float y, float z)
+{
+    return __builtin_fmaf(m[0], x, __builtin_fmaf(m[1], y, __builtin_fmaf(m[2], z, m[3])));
+}
+
+__device__ __forceinline__ float dop(float a, float b, float c, float d)
+{
+    const float t = c * d;
+    return __builtin_fmaf(a, b, -t);
+}
+
+struct CamArg {
+    float m[16];
+};
+
+__global__ __launch_bounds__(256) void tri_setup(const float *__restrict__ soup, int nfaces, CamArg cam, int W, int H,
+                                                 TriRec *__restrict__ out)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nfaces) return;
+    const float *v = soup + 9 * (size_t)f;
+    float x[3], y[3], z[3], w[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float px = v[3 * i], py = v[3 * i + 1], pz = v[3 * i + 2];
+        x[i] = xform(cam.m + 0, px, py, pz);
+        y[i] = xform(cam.m + 4, px, py, pz);
+        z[i] = xform(cam.m + 8, px, py, pz);
+        w[i] = xform(cam.m + 12, px, py, pz);
+    }
+    float a[3], b[3], c[3];
+    a[0] = dop(y[1], w[2], w[1], y[2]);
+    b[0] = dop(w[1], x[2], x[1], w[2]);
+    c[0] = dop(x[1], y[2], y[1], x[2]);
+    a[1] = dop(w[0], y[2], y[0], w[2]);
+    b[1] = dop(x[0], w[2], w[0], x[2]);
+    c[1] = dop(y[0], x[2], x[0], y[2]);
+    a[2] = dop(y[0], w[1], w[0], y[1]);
+    b[2] = dop(w[0], x[1], x[0], w[1]);
+    c[2] = dop(x[0], y[1], y[0], x[1]);
+    float det = __builtin_fmaf(x[0], a[0], __builtin_fmaf(y[0], b[0], w[0] * c[0]));
+    TriRec t;
+    const bool valid = (det != 0.0f) && (det == det) && !__builtin_isinf(det);
+    if (det < 0.0f) {
+        det = -det;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            a[i] = -a[i];
+            b[i] = -b[i];
+            c[i] = -c[i];
+        }
+    }
+    const float rdet = 1.0f / det;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        t.a[i] = a[i];
+        t.b[i] = b[i];
+        t.c[i] = c[i];
+    }
+    t.za = __builtin_fmaf(a[0], z[0], __builtin_fmaf(a[1], z[1], a[2] * z[2])) * rdet;
+    t.zb = __builtin_fmaf(b[0], z[0], __builtin_fmaf(b[1], z[1], b[2] * z[2])) * rdet;
+    t.zc = __builtin_fmaf(c[0], z[0], __builtin_fmaf(c[1], z[1], c[2] * z[2])) * rdet;
+    int x0 = 0, y0 = 0, x1 = W - 1, y1 = H - 1;
+    if (w[0] > 0.0f && w[1] > 0.0f && w[2] > 0.0f) {
+        float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float nx = x[i] / w[i], ny = y[i] / w[i];
+            xmin = fminf(xmin, nx);
+            xmax = fmaxf(xmax, nx);
+            ymin = fminf(ymin, ny);
+            ymax = fmaxf(ymax, ny);
+        }
+        const float cx0 = ((xmin + 1.0f) * (float)W - 1.0f) * 0.5f - 1.0f;
+        const float cx1 = ((xmax + 1.0f) * (float)W - 1.0f) * 0.5f + 1.0f;
+        const float ry0 = ((1.0f - ymax) * (float)H - 1.0f) * 0.5f - 1.0f;
+        const float ry1 = ((1.0f - ymin) * (float)H - 1.0f) * 0.5f + 1.0f;
+        if (cx0 > 0.0f) x0 = cx0 < (float)W ? (int)cx0 : W;
+        if (cx1 < (float)(W - 1)) x1 = cx1 >= 0.0f ? (int)cx1 : -1;
+        if (ry0 > 0.0f) y0 = ry0 < (float)H ? (int)ry0 : H;
+        if (ry1 < (float)(H - 1)) y1 = ry1 >= 0.0f ? (int)ry1 : -1;
+    }
+    if (!valid) {
+        x0 = 1;
+        x1 = 0;
+    }
+    t.x0y0 = (x0 & 0xffff) | (y0 << 16);
+    t.x1y1 = (x1 & 0xffff) | (y1 << 16);
+    t.pad0 = t.pad1 = 0;
+    out[f] = t;
+}
+
+__device__ __forceinline__ bool edge_inside(float e, float a, float b)
+{
+    return e > 0.0f || (e == 0.0f && (a > 0.0f || (a == 0.0f && b > 0.0f)));
+}
+
+__device__ __forceinline__ bool tri_fragment(const TriRec &t, float xn, float yn, float &zwin, float e[3])
+{
+    bool in = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        e[i] = __builtin_fmaf(t.a[i], xn, __builtin_fmaf(t.b[i], yn, t.c[i]));
+        in = in && edge_inside(e[i], t.a[i], t.b[i]);
+    }
+    const float zn = __builtin_fmaf(t.za, xn, __builtin_fmaf(t.zb, yn, t.zc));
+    in = in && (zn >= -1.0f && zn <= 1.0f);
+    zwin = __builtin_fmaf(0.5f, zn, 0.5f);
+    return in;
+}
+
+constexpr int RT = 16;  // raster tile edge
+
+// MODE 0: write window z top-down.  MODE 1: write window z in GL orientation (row 0 = bottom).
+// MODE 2: write NDC depth 2z-1 top-down (Render::depth).  ids (nullable): visible face per pixel, top-down.
+template <int MODE>
+__global__ __launch_bounds__(256) void raster_tiles(const TriRec *__restrict__ tris, int nfaces, int W, int H,
+                                                    float invW, float invH, float *__restrict__ zout,
+                                                    int *__restrict__ ids)
+{
+    __shared__ int list[256];
+    __shared__ int count;
+    const int tx0 = blockIdx.x * RT, ty0 = blockIdx.y * RT;
+    const int col = tx0 + (threadIdx.x & (RT - 1));
+    const int row = ty0 + (threadIdx.x >> 4);
+    const float xn = __builtin_fmaf((float)(2 * col + 1), invW, -1.0f);
+    const float yn = __builtin_fmaf(-(float)(2 * row + 1), invH, 1.0f);
+    const int tx1 = min(tx0 + RT, W) - 1, ty1 = min(ty0 + RT, H) - 1;
+    float best = 1.0f;  // glClear(GL_DEPTH_BUFFER_BIT)
+    int best_id = -1;
+    for (int base = 0; base < nfaces; base += 256) {
+        if (threadIdx.x == 0) count = 0;
+        __syncthreads();
+        const int f = base + threadIdx.x;
+        if (f < nfaces) {
+            const int p0 = tris[f].x0y0, p1 = tris[f].x1y1;
+            const int bx0 = (short)(p0 & 0xffff), by0 = p0 >> 16, bx1 = (short)(p1 & 0xffff), by1 = p1 >> 16;
+            if (bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0) list[atomicAdd(&count, 1)] = f;
+        }
+        __syncthreads();
+        const int n = count;
+        // LDS compaction is unordered; GL_LESS keeps the EARLIER face on equal z, so resolve ties by id
+        for (int k = 0; k < n; k++) {
+            const int fi = __builtin_amdgcn_readfirstlane(list[k]);
+            const TriRec t = tris[fi];
+            float zw, e[3];
+            if (tri_fragment(t, xn, yn, zw, e)) {
+                if (zw < best || (zw == best && best_id >= 0 && fi < best_id)) {
+                    best = zw;
+                    best_id = fi;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (col < W && row < H) {
+        if (MODE == 1)
+            zout[(size_t)(H - 1 - row) * W + col] = best;
+        else if (MODE == 2)
+            zout[(size_t)row * W + col] = __builtin_fmaf(2.0f, best, -1.0f);
+        else
+            zout[(size_t)row * W + col] = best;
+        if (ids) ids[(size_t)row * W + col] = best_id;
+    }
+}
+
+// row 0 (GL orientation) of the shadow filter is a running MIN: HF[0][j] = min(a[0][0..j+1])
+// (render_glx.cpp:292-297 reads the already-filtered left neighbour).  One workgroup, blocked scan.
+__global__ __launch_bounds__(256) void row0_prefix_min(const float *__restrict__ a, int W, float *__restrict__ hf0)
+{
+    __shared__ float part[256];
+    const int per = (W + 255) / 256;
+    const int s = threadIdx.x * per, e = min(s + per, W);
+    float m = 3.0e38f;
+    for (int j = s; j < e; j++) m = fminf(m, a[j]);
+    part[threadIdx.x] = m;
+    __syncthreads();
+    float run = 3.0e38f;
+    for (int k = 0; k < (int)threadIdx.x; k++) run = fminf(run, part[k]);  // exclusive prefix of block minima
+    for (int j = s; j < e; j++) {
+        // hf0[j] = min(a[0..j+1]) for 1 <= j <= W-2
+        run = fminf(run, a[j]);
+        if (j >= 1 && j <= W - 2) hf0[j] = fminf(run, a[j + 1]);
+    }
+}
+
+// closed form of the in-place loop render_glx.cpp:298-312 (validated against its literal transcription
+// in oracle/raster_oracle.c by tests/test_raster_cpu.py)
+__global__ __launch_bounds__(256) void shadow_dilate(const float *__restrict__ a, const float *__restrict__ hf0, int W,
+                                                     int H, float *__restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= W) return;
+    const size_t p = (size_t)i * W + j;
+    if (j == 0 || j == W - 1 || W < 3) {
+        out[p] = a[p];
+        return;
+    }
+    float m = -3.0e38f;
+#pragma unroll
+    for (int dr = -1; dr <= 1; dr++) {
+        const int r = i + dr;
+        if (r < 0 || r >= H) continue;
+        float hf;
+        if (r == 0) {
+            hf = hf0[j];
+        } else {
+            const float *q = a + (size_t)r * W + j;
+            hf = fmaxf(fmaxf(q[-1], q[0]), q[1]);
+        }
+        m = fmaxf(m, hf);
+    }
+    out[p] = m;
+}
+
+// shader.vert:9-13 + shader.frag:11-25 for the visible face of every main-view pixel
+__global__ __launch_bounds__(256) void project_texture(const float *__restrict__ soup, const TriRec *__restrict__ tris,
+                                                       const int *__restrict__ ids, const float *__restrict__ shadow_gl,
+                                                       const uint8_t *__restrict__ pad, int pitch, CamArg prj, int W,
+                                                       int H, float invW, float invH, uint8_t *__restrict__ out3)
+{
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (col >= W || row >= H) return;
+    const size_t p = (size_t)row * W + col;
+    uint8_t r = 0, g = 0;
+    const int id = ids[p];
+    if (id >= 0) {
+        const float xn = __builtin_fmaf((float)(2 * col + 1), invW, -1.0f);
+        const float yn = __builtin_fmaf(-(float)(2 * row + 1), invH, 1.0f);
+        const TriRec t = tris[id];
+        const float *v = soup + 9 * (size_t)id;
+        float zw, e[3];
+        if (tri_fragment(t, xn, yn, zw, e)) {
+            const float esum = (e[0] + e[1]) + e[2];
+            float pos[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                pos[k] = __builtin_fmaf(e[0], v[k], __builtin_fmaf(e[1], v[3 + k], e[2] * v[6 + k])) / esum;
+            const float sx = xform(prj.m + 0, pos[0], pos[1], pos[2]);
+            const float sy = xform(prj.m + 4, pos[0], pos[1], pos[2]);
+            const float sz = xform(prj.m + 8, pos[0], pos[1], pos[2]);
+            const float sw = xform(prj.m + 12, pos[0], pos[1], pos[2]);
+            const float nx = sx / sw, ny = sy / sw, nz = sz / sw;
+            const bool inframe = nx > -1.0f && nx < 1.0f && ny > -1.0f && ny < 1.0f;
+            if (inframe) {
+                const float fW = (float)W, fH = (float)H;
+                const float u = __builtin_fmaf(0.5f, nx, 0.5f), vv = __builtin_fmaf(0.5f, ny, 0.5f);
+                int si = (int)floorf(u * fW), sj = (int)floorf(vv * fH);
+                si = ((si % W) + W) % W;
+                sj = ((sj % H) + H) % H;
+                const float shadowDepth = __builtin_fmaf(2.0f, shadow_gl[(size_t)sj * W + si], -1.0f);
+                if (shadowDepth + 0.01f > nz) {
+                    const float cx = __builtin_fmaf(u, fW, 0.5f);
+                    const float cy = __builtin_fmaf(1.0f - vv, fH, 0.5f);
+                    const int ix = (int)cx, iy = (int)cy;
+                    const float ax = cx - (float)ix, ay = cy - (float)iy;
+                    const uint8_t *q = pad + (size_t)iy * pitch + ix;
+                    const float t00 = (float)q[0], t01 = (float)q[1], t10 = (float)q[pitch], t11 = (float)q[pitch + 1];
+                    const float dxt = t01 - t00, dy = t10 - t00, dxy = (t11 - t10) - dxt;
+                    const float res = __builtin_fmaf(ay, __builtin_fmaf(ax, dxy, dy), __builtin_fmaf(ax, dxt, t00));
+                    r = (uint8_t)(int)(res + 0.5f);
+                    g = 255;
+                }
+            }
+        }
+    }
+    out3[3 * p + 0] = r;
+    out3[3 * p + 1] = g;
+    out3[3 * p + 2] = g;
+}
+
+// util.cpp:366-387 (depth is updated in place)
+__global__ __launch_bounds__(256) void mix_background(const uint8_t *__restrict__ img3, const uint8_t *__restrict__ bg,
+                                                      float *__restrict__ depth, uint8_t *__restrict__ out, size_t P)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const bool masked = depth[i] == MVS_BACKGROUND_DEPTH || img3[3 * i + 1] == 0;
+    out[i] = masked ? bg[i] : img3[3 * i];
+    if (masked) depth[i] = MVS_BACKGROUND_DEPTH;
+}
+
+// defined in context.hip
+__global__ void pad_wrap_kernel(const uint8_t *__restrict__ img, uint8_t *__restrict__ pad, int W, int H, int pitch);
+
+static int run_raster(mvs_ctx *ctx, const float cam[16], int mode, float *zout, int *ids)
+{
+    CamArg c;
+    memcpy(c.m, cam, sizeof(c.m));
+    const int W = ctx->W, H = ctx->H;
+    int rc = ensure(ctx, ctx->r_tmp2, sizeof(TriRec) * (size_t)(ctx->nfaces > 0 ? ctx->nfaces : 1));
+    if (rc) return rc;
+    if (ctx->nfaces > 0) {
+        tri_setup<<<div_up(ctx->nfaces, 256), 256, 0, ctx->stream>>>((const float *)ctx->soup.ptr, ctx->nfaces, c, W, H,
+                                                                      (TriRec *)ctx->r_tmp2.ptr);
+        MVS_HIP(ctx, hipGetLastError());
+    }
+    dim3 grid(div_up(W, RT), div_up(H, RT));
+    const float invW = 1.0f / (float)W, invH = 1.0f / (float)H;
+    const TriRec *tris = (const TriRec *)ctx->r_tmp2.ptr;
+    ProfileScope ps(ctx, MVS_K_RASTER);
+    if (mode == 0)
+        raster_tiles<0><<<grid, 256, 0, ctx->stream>>>(tris, ctx->nfaces, W, H, invW, invH, zout, ids);
+    else if (mode == 1)
+        raster_tiles<1><<<grid, 256, 0, ctx->stream>>>(tris, ctx->nfaces, W, H, invW, invH, zout, ids);
+    else
+        raster_tiles<2><<<grid, 256, 0, ctx->stream>>>(tris, ctx->nfaces, W, H, invW, invH, zout, ids);
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" {
+
+int mvs_load_mesh(mvs_ctx *ctx, const float *verts4, int nverts, const int32_t *faces3, int nfaces)
+{
+    if (!ctx) return MVS_EINVAL;
+    if (nverts < 0 || nfaces < 0 || (nfaces > 0 && (!verts4 || !faces3)))
+        return fail(ctx, MVS_EINVAL, "mvs_load_mesh: bad arguments");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<float> soup((size_t)nfaces * 9);
+    for (int f = 0; f < nfaces; f++)
+        for (int j = 0; j < 3; j++) {
+            const int vi = faces3[3 * f + j];
+            if (vi < 0 || vi >= nverts)
+                return fail(ctx, MVS_EINVAL, "mvs_load_mesh: face %d references vertex %d of %d", f, vi, nverts);
+            const float *p = verts4 + 4 * (size_t)vi;
+            soup[9 * (size_t)f + 3 * j + 0] = p[0] / p[3];  // render_glx.cpp:242-244
+            soup[9 * (size_t)f + 3 * j + 1] = p[1] / p[3];
+            soup[9 * (size_t)f + 3 * j + 2] = p[2] / p[3];
+        }
+    int rc = ensure(ctx, ctx->soup, sizeof(float) * 9 * (size_t)(nfaces > 0 ? nfaces : 1));
+    if (rc) return rc;
+    if (nfaces > 0) {
+        MVS_HIP(ctx, hipMemcpyAsync(ctx->soup.ptr, soup.data(), sizeof(float) * soup.size(), hipMemcpyHostToDevice,
+                                    ctx->stream));
+        MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->nfaces = nfaces;
+    return MVS_OK;
+}
+
+int mvs_depth(mvs_ctx *ctx, const float cam[16], float *out_hw)
+{
+    if (!ctx || !cam || !out_hw) return fail(ctx, MVS_EINVAL, "mvs_depth: null argument");
+    if (!ctx->soup.ptr) return fail(ctx, MVS_ESTATE, "mvs_depth: no mesh loaded (mvs_load_mesh)");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->W * ctx->H;
+    int rc = ensure(ctx, ctx->r_zbuf, P * sizeof(float));
+    if (rc) return rc;
+    if ((rc = run_raster(ctx, cam, 2, (float *)ctx->r_zbuf.ptr, nullptr))) return rc;
+    MVS_HIP(ctx, hipMemcpyAsync(out_hw, ctx->r_zbuf.ptr, P * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
+int mvs_projected(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_hw, const float projector[16],
+                  uint8_t *out_hw3)
+{
+    if (!ctx || !cam || !frame_hw || !projector || !out_hw3) return fail(ctx, MVS_EINVAL, "mvs_projected: null argument");
+    if (!ctx->soup.ptr) return fail(ctx, MVS_ESTATE, "mvs_projected: no mesh loaded (mvs_load_mesh)");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->W, H = ctx->H;
+    const size_t P = (size_t)W * H;
+    const int pitch = ((W + 2 + 63) / 64) * 64;
+    int rc;
+    if ((rc = ensure(ctx, ctx->r_zbuf, P * sizeof(float)))) return rc;       // main pass window z
+    if ((rc = ensure(ctx, ctx->r_shadow, 2 * P * sizeof(float) + sizeof(float) * (size_t)W))) return rc;  // raw, dilated, hf0
+    if ((rc = ensure(ctx, ctx->r_tmp0, P * sizeof(int)))) return rc;         // ids
+    if ((rc = ensure(ctx, ctx->r_frame, (size_t)pitch * (H + 2) + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->upload, P))) return rc;
+    if ((rc = ensure(ctx, ctx->r_out3, 3 * P))) return rc;
+    float *sh_raw = (float *)ctx->r_shadow.ptr, *sh_dil = sh_raw + P, *hf0 = sh_dil + P;
+
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->upload.ptr, frame_hw, P, hipMemcpyHostToDevice, ctx->stream));
+    pad_wrap_kernel<<<dim3(div_up(pitch, 256), H + 2), 256, 0, ctx->stream>>>((const uint8_t *)ctx->upload.ptr,
+                                                                              (uint8_t *)ctx->r_frame.ptr, W, H, pitch);
+    MVS_HIP(ctx, hipGetLastError());
+    // pass 1: shadow map from the projector, GL orientation, then the dilation quirk
+    if ((rc = run_raster(ctx, projector, 1, sh_raw, nullptr))) return rc;
+    row0_prefix_min<<<1, 256, 0, ctx->stream>>>(sh_raw, W, hf0);
+    MVS_HIP(ctx, hipGetLastError());
+    shadow_dilate<<<dim3(div_up(W, 256), H), 256, 0, ctx->stream>>>(sh_raw, hf0, W, H, sh_dil);
+    MVS_HIP(ctx, hipGetLastError());
+    // pass 2: main camera, then the fragment program on the visible faces
+    if ((rc = run_raster(ctx, cam, 0, (float *)ctx->r_zbuf.ptr, (int *)ctx->r_tmp0.ptr))) return rc;
+    {
+        CamArg prj;
+        memcpy(prj.m, projector, sizeof(prj.m));
+        ProfileScope ps(ctx, MVS_K_PROJECT);
+        project_texture<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, ctx->stream>>>(
+            (const float *)ctx->soup.ptr, (const TriRec *)ctx->r_tmp2.ptr, (const int *)ctx->r_tmp0.ptr, sh_dil,
+            (const uint8_t *)ctx->r_frame.ptr, pitch, prj, W, H, 1.0f / (float)W, 1.0f / (float)H,
+            (uint8_t *)ctx->r_out3.ptr);
+        MVS_HIP(ctx, hipGetLastError());
+    }
+    MVS_HIP(ctx, hipMemcpyAsync(out_hw3, ctx->r_out3.ptr, 3 * P, hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
+int mvs_mix_background(mvs_ctx *ctx, const uint8_t *img_hw3, const uint8_t *bg_hw, float *depth_hw_inout,
+                       uint8_t *out_hw)
+{
+    if (!ctx || !img_hw3 || !bg_hw || !depth_hw_inout || !out_hw)
+        return fail(ctx, MVS_EINVAL, "mvs_mix_background: null argument");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->W * ctx->H;
+    int rc;
+    if ((rc = ensure(ctx, ctx->r_out3, 3 * P))) return rc;
+    if ((rc = ensure(ctx, ctx->upload, P))) return rc;
+    if ((rc = ensure(ctx, ctx->r_zbuf, P * sizeof(float)))) return rc;
+    if ((rc = ensure(ctx, ctx->r_tmp1, P))) return rc;
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->r_out3.ptr, img_hw3, 3 * P, hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->upload.ptr, bg_hw, P, hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->r_zbuf.ptr, depth_hw_inout, P * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    mix_background<<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(
+        (const uint8_t *)ctx->r_out3.ptr, (const uint8_t *)ctx->upload.ptr, (float *)ctx->r_zbuf.ptr,
+        (uint8_t *)ctx->r_tmp1.ptr, P);
+    MVS_HIP(ctx, hipGetLastError());
+    MVS_HIP(ctx, hipMemcpyAsync(out_hw, ctx->r_tmp1.ptr, P, hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipMemcpyAsync(depth_hw_inout, ctx->r_zbuf.ptr, P * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
+}  // extern "C"

@@ -112,6 +112,43 @@ class Oracle:
         return out, depth
 
 
+    # ---- renderer ------------------------------------------------------------------------------
+    def load_mesh(self, verts4, faces3):
+        v = np.ascontiguousarray(verts4, np.float32)
+        f = np.ascontiguousarray(faces3, np.int32)
+        soup = np.empty((f.shape[0], 9), np.float32)
+        self.lib.orc_load_mesh(self._p(v, _fp), v.shape[0], self._p(f, _i32p), f.shape[0], self._p(soup, _fp))
+        return soup
+
+    def depth(self, soup, cam, W, H):
+        cam = np.ascontiguousarray(cam, np.float32)
+        out = np.empty((H, W), np.float32)
+        self.lib.orc_depth(self._p(soup, _fp), soup.shape[0], self._p(cam, _fp), W, H, self._p(out, _fp))
+        return out
+
+    def raster_window_z(self, soup, cam, W, H):
+        cam = np.ascontiguousarray(cam, np.float32)
+        out = np.empty((H, W), np.float32)
+        self.lib.orc_raster_window_z(self._p(soup, _fp), soup.shape[0], self._p(cam, _fp), W, H, self._p(out, _fp))
+        return out
+
+    def shadow_dilate(self, zwin_gl):
+        a = np.ascontiguousarray(zwin_gl, np.float32).copy()
+        H, W = a.shape
+        self.lib.orc_shadow_dilate(self._p(a, _fp), W, H)
+        return a
+
+    def projected(self, soup, cam, frame, projector):
+        H, W = frame.shape
+        cam = np.ascontiguousarray(cam, np.float32)
+        prj = np.ascontiguousarray(projector, np.float32)
+        frame = np.ascontiguousarray(frame, np.uint8)
+        out = np.empty((H, W, 3), np.uint8)
+        self.lib.orc_projected(self._p(soup, _fp), soup.shape[0], self._p(cam, _fp), self._p(frame, _u8p),
+                               self._p(prj, _fp), W, H, self._p(out, _u8p))
+        return out
+
+
 _oracle = None
 
 

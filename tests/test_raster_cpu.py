@@ -1,0 +1,128 @@
+"""CPU tests of the renderer restatement (oracle): known-input scene, analytic ground truth, the dilation quirk."""
+import numpy as np
+
+import scenes
+from data import glx_scene
+from mvs_amd import synth
+
+
+def test_glx_self_test_scene(oracle):
+    """render_glx.cpp:403-432: the inline mesh renders, depth spans a range, vertices project where the depth map
+    says the surface is"""
+    W, H = glx_scene.W, glx_scene.H
+    soup = oracle.load_mesh(glx_scene.POINTS, glx_scene.FACES)
+    depth = oracle.depth(soup, glx_scene.MVP, W, H)
+    covered = depth != 1.0
+    assert 0.05 < covered.mean() < 0.9
+    assert depth[covered].min() >= -1.0 and depth[covered].max() < 1.0
+    assert depth[covered].max() - depth[covered].min() > 0.01  # "Depth min != max" (render_glx.cpp:427)
+    # every vertex that lands inside the image lies ON or BEHIND the visible surface at its pixel
+    hits = 0
+    for p in glx_scene.POINTS:
+        c = glx_scene.MVP.astype(np.float64) @ p.astype(np.float64)
+        x, y, z = c[:3] / c[3]
+        if abs(x) >= 1 or abs(y) >= 1 or abs(z) > 1:
+            continue
+        col = int((x + 1) * W / 2)
+        row = int((1 - y) * H / 2)
+        win = depth[max(row - 2, 0):row + 3, max(col - 2, 0):col + 3]
+        if np.any(win != 1.0):
+            hits += 1
+            assert win.min() <= z + 2e-3
+    assert hits >= 10
+    out = oracle.projected(soup, glx_scene.MVP, np.full((H, W), 200, np.uint8), glx_scene.SIDE_MVP)
+    valid = out[..., 1] == 255
+    assert np.all((out[..., 1] == 0) | valid) and np.array_equal(out[..., 1], out[..., 2])
+    assert np.all(out[..., 0][valid] == 200) and np.all(out[..., 0][~valid] == 0)
+    assert valid.sum() > 0 and not np.any(valid & ~covered)
+
+
+def test_depth_matches_analytic_heightfield(oracle):
+    """independent ground truth: z-buffer of the triangulated height field == analytic ray cast (to mesh resolution)"""
+    W, H = 160, 120
+    verts, faces = scenes.heightfield_mesh(96)
+    soup = oracle.load_mesh(verts, faces)
+    cam = synth.camera_at([0.05, -0.02, 0.0], W, H)
+    depth = oracle.depth(soup, cam, W, H)
+    _, gt = synth.Scene().render([0.05, -0.02, 0.0], W, H, want_depth=True)
+    assert np.all(depth != 1.0)
+    assert np.abs(depth - gt).max() < 2e-3
+
+
+def test_projected_is_photo_consistent(oracle):
+    """warping the side frame through the true surface reproduces the main frame (the stage recon.cpp:85 relies on)"""
+    W, H = 160, 120
+    verts, faces = scenes.heightfield_mesh(96)
+    soup = oracle.load_mesh(verts, faces)
+    sc = synth.Scene(freq_scale=0.1)
+    main_c, side_c = [0.0, 0.0, 0.0], [0.2, 0.1, 0.0]
+    main_img = sc.render(main_c, W, H)
+    side_img = sc.render(side_c, W, H)
+    out = oracle.projected(soup, synth.camera_at(main_c, W, H), side_img, synth.camera_at(side_c, W, H))
+    valid = out[..., 1] == 255
+    assert valid.mean() > 0.8
+    err = np.abs(out[..., 0].astype(int) - main_img.astype(int))[valid]
+    assert np.mean(err) < 2.0 and np.percentile(err, 99) <= 8
+
+
+def test_shadow_masks_occluded_surface(oracle):
+    """a near occluder in front of the projector must mask the far surface (shader.frag:17-18)"""
+    W, H = 96, 64
+    far = np.array([[-4, -4, -6, 1], [4, -4, -6, 1], [4, 4, -6, 1], [-4, 4, -6, 1]], np.float32)
+    near = np.array([[-0.4, -0.4, -3, 1], [0.4, -0.4, -3, 1], [0.4, 0.4, -3, 1], [-0.4, 0.4, -3, 1]], np.float32)
+    verts = np.concatenate([far, near])
+    faces = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7]], np.int32)
+    soup = oracle.load_mesh(verts, faces)
+    cam = synth.camera_at([0, 0, 0], W, H)
+    prj = synth.camera_at([1.5, 0, 0], W, H)
+    out = oracle.projected(soup, cam, np.full((H, W), 128, np.uint8), prj)
+    depth = oracle.depth(soup, cam, W, H)
+    near_z = depth.min()
+    on_far = (depth != 1.0) & (depth > near_z + 0.1)
+    masked_far = on_far & (out[..., 1] == 0)
+    assert masked_far.sum() > 20          # the occluder's shadow on the far plane
+    assert (on_far & (out[..., 1] == 255)).sum() > masked_far.sum()
+
+
+def _dilate_closed_form(a):
+    H, W = a.shape
+    hf = np.full_like(a, -np.inf)
+    hf[1:, 1:-1] = np.maximum(np.maximum(a[1:, :-2], a[1:, 1:-1]), a[1:, 2:])
+    hf[0, 1:-1] = np.minimum.accumulate(a[0])[2:]
+    out = a.copy()
+    m = hf.copy()
+    m[1:] = np.maximum(m[1:], hf[:-1])
+    m[:-1] = np.maximum(m[:-1], hf[1:])
+    out[:, 1:-1] = m[:, 1:-1]
+    return out
+
+
+def test_shadow_dilate_quirks(oracle):
+    """rows >= 2 are a 3x3 max, row 0 carries a running min, border columns untouched"""
+    rng = np.random.default_rng(5)
+    for (H, W) in [(7, 9), (2, 5), (16, 33), (3, 3)]:
+        a = rng.random((H, W)).astype(np.float32)
+        got = oracle.shadow_dilate(a)
+        np.testing.assert_array_equal(got, _dilate_closed_form(a))
+        np.testing.assert_array_equal(got[:, 0], a[:, 0])
+        np.testing.assert_array_equal(got[:, -1], a[:, -1])
+    a = rng.random((9, 12)).astype(np.float32)
+    got = oracle.shadow_dilate(a)
+    ref = a.copy()
+    for i in range(2, 8):
+        for j in range(1, 11):
+            ref[i, j] = a[i - 1:i + 2, j - 1:j + 2].max()
+    np.testing.assert_array_equal(got[2:8, 1:11], ref[2:8, 1:11])
+
+
+def test_near_plane_crossing_triangle(oracle):
+    """a triangle that passes through the camera plane (w <= 0 at one vertex) is drawn where it is in front:
+    the situation of heuristic.cpp:193-247's face cameras (near = 0.001)"""
+    W, H = 64, 48
+    verts = np.array([[-50, -1.0, -40, 1], [50, -1.0, -40, 1], [0, -1.0, 30, 1]], np.float32)  # ground plane strip
+    faces = np.array([[0, 1, 2]], np.int32)
+    cam = synth.camera_at([0, 0, 0], W, H, near=0.5, far=60.0)
+    depth = oracle.depth(oracle.load_mesh(verts, faces), cam, W, H)
+    lower = depth[H // 2 + 4:, W // 2]
+    assert np.all(lower != 1.0) and np.all(np.diff(lower) < 0)  # ground gets nearer towards the bottom
+    assert np.all(depth[:H // 2 - 2] == 1.0)                      # nothing above the horizon
