@@ -144,7 +144,8 @@ void mvs_destroy(mvs_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->main_img, &ctx->side_pads, &ctx->qmats, &ctx->ztab, &ctx->plan, &ctx->upload,
                       &ctx->volume_own, &ctx->depth, &ctx->cost, &ctx->index, &ctx->soup, &ctx->r_zbuf,
-                      &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2};
+                      &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2,
+                      &ctx->cubic_tab, &ctx->flow_arena};
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     for (auto &s : ctx->slots) {

@@ -58,6 +58,8 @@ struct mvs_ctx {
     mvs::DevBuf soup;                // 9 floats per face, dehomogenised triangle soup
     int nfaces = 0;
     mvs::DevBuf r_zbuf, r_shadow, r_frame, r_out3, r_tmp0, r_tmp1, r_tmp2;
+    mvs::DevBuf cubic_tab;           // Q15 bicubic weights for remap (32*32*16 shorts)
+    mvs::DevBuf flow_arena;          // optical-flow pyramids and work buffers
 
     // ---- profiling -----------------------------------------------------------------------------------
     bool profiling = false;
@@ -95,5 +97,9 @@ void view_matrix(const float main_cam[16], const float side_cam[16], int W, int 
 void plane_table(int D, float z_lo, float z_hi, float *z);
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// device-buffer forms used by the flow stage (photometric.hip)
+int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, float *out);
+int remap_device(mvs_ctx *ctx, const float *flow, int stride, const uint8_t *img, uint8_t *out);
 
 }  // namespace mvs

@@ -6,14 +6,6 @@ using namespace mvs;
 
 extern "C" {
 
-int mvs_compare(mvs_ctx *ctx, const uint8_t *, const uint8_t *, float *)
-{
-    return fail(ctx, MVS_ESTATE, "mvs_compare: not built yet");
-}
-int mvs_flow_remap(mvs_ctx *ctx, const float *, int, const uint8_t *, uint8_t *)
-{
-    return fail(ctx, MVS_ESTATE, "mvs_flow_remap: not built yet");
-}
 int mvs_flow(mvs_ctx *ctx, const uint8_t *, const uint8_t *, int, float *)
 {
     return fail(ctx, MVS_ESTATE, "mvs_flow: not built yet");

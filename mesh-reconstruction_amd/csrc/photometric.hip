@@ -1,0 +1,288 @@
+// photometric.hip -- compare() and flowRemap() of the reference (util.cpp:332-361, 390-403) on gfx950.
+//
+// The reference calls OpenCV for the arithmetic (pyrDown / pyrUp / absdiff / remap, CV_INTER_CUBIC);
+// these kernels restate those routines (OpenCV 3.x behaviour for CV_32F pyramids and CV_8U remap) with
+// the operation order documented in oracle/photometric_oracle.c so both sides agree bit for bit.
+// All levels stay in HBM; the reference's Mat temporaries (one allocation per level per call) become
+// one arena carved per context.
+//
+//   pyr_down_kernel    5x5 binomial, REFLECT_101, one thread per coarse pixel (25 taps, L2-resident)
+//   pyr_up_add_kernel  zero-insert x2 + [1 4 6 4 1]/8, fused with the `diffPyramid[i] += upscaled` of
+//                      util.cpp:357 so the up-sampled level is never materialised
+//   absdiff_kernel     |a - b| (util.cpp:343), with the u8 -> f32 conversion of util.cpp:337-338 fused at level 0
+//   remap_cubic_kernel 1/32-pixel Q15 bicubic, BORDER_CONSTANT 0 (util.cpp:401)
+#include "mvs_internal.hpp"
+
+#include <cmath>
+
+namespace mvs {
+
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) {
+        if (p < 0) p = -p;
+        if (p >= n) p = 2 * n - 2 - p;
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__ src, int w, int h, float *__restrict__ dst,
+                                                       int dw, int dh)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    int xs[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) xs[k] = reflect101(2 * x + k - 2, w);
+    float r[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const float *s = src + (size_t)reflect101(2 * y + k - 2, h) * w;
+        r[k] = s[xs[2]] * 6.0f + (s[xs[1]] + s[xs[3]]) * 4.0f + s[xs[0]] + s[xs[4]];
+    }
+    dst[(size_t)y * dw + x] = (r[2] * 6.0f + (r[1] + r[3]) * 4.0f + r[0] + r[4]) * (1.0f / 256.0f);
+}
+
+// horizontal pyrUp value at fine column x of coarse row s (sw entries)
+__device__ __forceinline__ float up_row(const float *__restrict__ s, int sw, int x)
+{
+    const int k = x >> 1;
+    if (sw == 1) return s[0] * 8.0f;
+    if (x & 1) return k < sw - 1 ? (s[k] + s[k + 1]) * 4.0f : s[sw - 1] * 8.0f;
+    if (k == 0) return s[0] * 6.0f + s[1] * 2.0f;
+    if (k == sw - 1) return s[sw - 2] + s[sw - 1] * 7.0f;
+    return s[k - 1] + s[k] * 6.0f + s[k + 1];
+}
+
+// acc[y][x] += pyrUp(src)[y][x]
+__global__ __launch_bounds__(256) void pyr_up_add_kernel(const float *__restrict__ src, int sw, int sh,
+                                                         float *__restrict__ acc, int dw, int dh)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const int j = y >> 1;
+    const int jm = j > 0 ? j - 1 : (sh > 1 ? 1 : 0);
+    const int jp = j < sh - 1 ? j + 1 : sh - 1;
+    const float r1 = up_row(src + (size_t)j * sw, sw, x);
+    const float r2 = up_row(src + (size_t)jp * sw, sw, x);
+    float t;
+    if (y & 1) {
+        t = (r1 + r2) * 4.0f * (1.0f / 64.0f);
+    } else {
+        const float r0 = up_row(src + (size_t)jm * sw, sw, x);
+        t = (r0 + r1 * 6.0f + r2) * (1.0f / 64.0f);
+    }
+    acc[(size_t)y * dw + x] += t;
+}
+
+__global__ __launch_bounds__(256) void u8_to_f32_pair_absdiff(const uint8_t *__restrict__ a8, const uint8_t *__restrict__ b8,
+                                                              float *__restrict__ a, float *__restrict__ b,
+                                                              float *__restrict__ d, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float fa = (float)a8[i], fb = (float)b8[i];
+    a[i] = fa;
+    b[i] = fb;
+    d[i] = fabsf(fa - fb);
+}
+
+__global__ __launch_bounds__(256) void absdiff_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                      float *__restrict__ d, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    d[i] = fabsf(a[i] - b[i]);
+}
+
+__global__ __launch_bounds__(256) void remap_cubic_kernel(const float *__restrict__ flow, int stride,
+                                                          const uint8_t *__restrict__ img, int W, int H,
+                                                          const short *__restrict__ itab, uint8_t *__restrict__ out)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float *f = flow + ((size_t)y * W + x) * stride;
+    const float mx = f[0] + (float)x, my = f[1] + (float)y;
+    const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
+    int sx = (qx >> 5) - 1, sy = (qy >> 5) - 1;
+    const int fx = qx & 31, fy = qy & 31;
+    sx = max(-32767, min(32767, sx));
+    sy = max(-32767, min(32767, sy));
+    const short *wt = itab + (size_t)(fy * 32 + fx) * 16;
+    int sum = 0;
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) {
+        const int yy = sy + k1;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) {
+            const int xx = sx + k2;
+            if (xx < 0 || xx >= W) continue;
+            sum += (int)img[(size_t)yy * W + xx] * (int)wt[k1 * 4 + k2];
+        }
+    }
+    const int v = (sum + (1 << 14)) >> 15;
+    out[(size_t)y * W + x] = (uint8_t)max(0, min(255, v));
+}
+
+// host: the Q15 bicubic table of OpenCV's initInterTab2D(INTER_CUBIC, fixpt) (a = -0.75)
+static void build_cubic_table(short *itab)
+{
+    float t1[32][4];
+    for (int i = 0; i < 32; i++) {
+        const float x = (float)i * (1.0f / 32), A = -0.75f;
+        float *c = t1[i];
+        c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+        c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+        c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+    }
+    for (int i = 0; i < 32; i++)
+        for (int j = 0; j < 32; j++) {
+            short *it = itab + (size_t)(i * 32 + j) * 16;
+            int isum = 0;
+            for (int k1 = 0; k1 < 4; k1++)
+                for (int k2 = 0; k2 < 4; k2++) {
+                    long r = lrintf(t1[i][k1] * t1[j][k2] * 32768.0f);
+                    r = r > 32767 ? 32767 : (r < -32768 ? -32768 : r);
+                    it[k1 * 4 + k2] = (short)r;
+                    isum += (int)r;
+                }
+            if (isum != 32768) {
+                const int diff = isum - 32768;
+                int Mk = 2 * 4 + 2, mk = 2 * 4 + 2;
+                for (int k1 = 2; k1 < 4; k1++)
+                    for (int k2 = 2; k2 < 4; k2++) {
+                        const int k = k1 * 4 + k2;
+                        if (it[k] < it[mk])
+                            mk = k;
+                        else if (it[k] > it[Mk])
+                            Mk = k;
+                    }
+                if (diff < 0)
+                    it[Mk] = (short)(it[Mk] - diff);
+                else
+                    it[mk] = (short)(it[mk] - diff);
+            }
+        }
+}
+
+static dim3 grid2d(int w, int h) { return dim3(div_up(w, 64), div_up(h, 4)); }
+
+// compare() on device buffers: prev8/next8 (W*H u8) -> out (W*H f32).  All in-stream, no sync.
+int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, float *out)
+{
+    const int W = ctx->W, H = ctx->H;
+    // level geometry (util.cpp:335,341-351)
+    int lw[32], lh[32], nlev = 0;
+    {
+        int size = H < W ? H : W, w = W, h = H;
+        for (;;) {
+            lw[nlev] = w;
+            lh[nlev] = h;
+            nlev++;
+            if (size <= 2) break;
+            w = (w + 1) / 2;
+            h = (h + 1) / 2;
+            size /= 2;
+        }
+    }
+    size_t total = 0;
+    for (int i = 0; i < nlev; i++) total += (size_t)lw[i] * lh[i];
+    // arena: a-pyramid, b-pyramid, diff-pyramid (level 0 of diff is `out`)
+    int rc = ensure(ctx, ctx->r_tmp1, sizeof(float) * total * 3);
+    if (rc) return rc;
+    float *A = (float *)ctx->r_tmp1.ptr, *B = A + total, *D = B + total;
+    std::vector<size_t> off(nlev);
+    size_t o = 0;
+    for (int i = 0; i < nlev; i++) {
+        off[i] = o;
+        o += (size_t)lw[i] * lh[i];
+    }
+    const size_t P = (size_t)W * H;
+    u8_to_f32_pair_absdiff<<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(prev8, next8, A, B, out, P);
+    MVS_HIP(ctx, hipGetLastError());
+    for (int i = 1; i < nlev; i++) {
+        pyr_down_kernel<<<grid2d(lw[i], lh[i]), 256, 0, ctx->stream>>>(A + off[i - 1], lw[i - 1], lh[i - 1], A + off[i], lw[i], lh[i]);
+        pyr_down_kernel<<<grid2d(lw[i], lh[i]), 256, 0, ctx->stream>>>(B + off[i - 1], lw[i - 1], lh[i - 1], B + off[i], lw[i], lh[i]);
+        const size_t n = (size_t)lw[i] * lh[i];
+        absdiff_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(A + off[i], B + off[i], D + off[i], n);
+        MVS_HIP(ctx, hipGetLastError());
+    }
+    for (int i = nlev - 2; i >= 0; i--) {
+        float *dst = i == 0 ? out : D + off[i];
+        pyr_up_add_kernel<<<grid2d(lw[i], lh[i]), 256, 0, ctx->stream>>>(D + off[i + 1], lw[i + 1], lh[i + 1], dst, lw[i], lh[i]);
+        MVS_HIP(ctx, hipGetLastError());
+    }
+    return MVS_OK;
+}
+
+int ensure_cubic_table(mvs_ctx *ctx)
+{
+    if (ctx->cubic_tab.ptr) return MVS_OK;
+    int rc = ensure(ctx, ctx->cubic_tab, sizeof(short) * 1024 * 16);
+    if (rc) return rc;
+    std::vector<short> tab(1024 * 16);
+    build_cubic_table(tab.data());
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->cubic_tab.ptr, tab.data(), sizeof(short) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
+// flowRemap on device buffers
+int remap_device(mvs_ctx *ctx, const float *flow, int stride, const uint8_t *img, uint8_t *out)
+{
+    int rc = ensure_cubic_table(ctx);
+    if (rc) return rc;
+    remap_cubic_kernel<<<grid2d(ctx->W, ctx->H), 256, 0, ctx->stream>>>(flow, stride, img, ctx->W, ctx->H,
+                                                                       (const short *)ctx->cubic_tab.ptr, out);
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" {
+
+int mvs_compare(mvs_ctx *ctx, const uint8_t *prev_hw, const uint8_t *next_hw, float *out_hw)
+{
+    if (!ctx || !prev_hw || !next_hw || !out_hw) return fail(ctx, MVS_EINVAL, "mvs_compare: null argument");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->W * ctx->H;
+    int rc;
+    if ((rc = ensure(ctx, ctx->upload, 2 * P))) return rc;
+    if ((rc = ensure(ctx, ctx->r_zbuf, P * sizeof(float)))) return rc;
+    uint8_t *a = (uint8_t *)ctx->upload.ptr, *b = a + P;
+    MVS_HIP(ctx, hipMemcpyAsync(a, prev_hw, P, hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(ctx, hipMemcpyAsync(b, next_hw, P, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = compare_device(ctx, a, b, (float *)ctx->r_zbuf.ptr))) return rc;
+    MVS_HIP(ctx, hipMemcpyAsync(out_hw, ctx->r_zbuf.ptr, P * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
+int mvs_flow_remap(mvs_ctx *ctx, const float *flow, int flow_stride, const uint8_t *image_hw, uint8_t *out_hw)
+{
+    if (!ctx || !flow || !image_hw || !out_hw) return fail(ctx, MVS_EINVAL, "mvs_flow_remap: null argument");
+    if (flow_stride < 2 || flow_stride > 4) return fail(ctx, MVS_EINVAL, "mvs_flow_remap: flow_stride %d not in 2..4", flow_stride);
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->W * ctx->H;
+    int rc;
+    if ((rc = ensure(ctx, ctx->upload, 2 * P))) return rc;
+    if ((rc = ensure(ctx, ctx->r_tmp0, P * sizeof(float) * flow_stride))) return rc;
+    uint8_t *img = (uint8_t *)ctx->upload.ptr, *out = img + P;
+    MVS_HIP(ctx, hipMemcpyAsync(img, image_hw, P, hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->r_tmp0.ptr, flow, P * sizeof(float) * flow_stride, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = remap_device(ctx, (const float *)ctx->r_tmp0.ptr, flow_stride, img, out))) return rc;
+    MVS_HIP(ctx, hipMemcpyAsync(out_hw, out, P, hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
+}  // extern "C"

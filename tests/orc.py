@@ -149,6 +149,32 @@ class Oracle:
         return out
 
 
+    # ---- photometric helpers -------------------------------------------------------------------
+    def compare(self, prev, nxt):
+        H, W = prev.shape
+        out = np.empty((H, W), np.float32)
+        if prev.dtype == np.uint8:
+            a, b = np.ascontiguousarray(prev), np.ascontiguousarray(nxt, np.uint8)
+            self.lib.orc_compare_u8(self._p(a, _u8p), self._p(b, _u8p), W, H, self._p(out, _fp))
+        else:
+            a, b = np.ascontiguousarray(prev, np.float32), np.ascontiguousarray(nxt, np.float32)
+            self.lib.orc_compare_f32(self._p(a, _fp), self._p(b, _fp), W, H, self._p(out, _fp))
+        return out
+
+    def flow_remap(self, flow, image):
+        H, W = image.shape
+        flow = np.ascontiguousarray(flow, np.float32)
+        image = np.ascontiguousarray(image, np.uint8)
+        out = np.empty((H, W), np.uint8)
+        self.lib.orc_flow_remap(self._p(flow, _fp), flow.shape[2], self._p(image, _u8p), W, H, self._p(out, _u8p))
+        return out
+
+    def cubic_table(self):
+        t = np.empty((1024, 16), np.int16)
+        self.lib.orc_remap_cubic_table(t.ctypes.data_as(C.POINTER(C.c_short)))
+        return t
+
+
 _oracle = None
 
 
