@@ -1,0 +1,360 @@
+// heuristic.cpp -- view-selection / iteration policy of the reference (heuristic.cpp:23-551), host side.
+//
+// All of this is scalar f32 policy code whose one heavy callee is Render::depth (200 depth renders per
+// iteration from cameras placed ON mesh faces, heuristic.cpp:445-456) -- that callee is the HIP rasteriser.
+// The logic below restates the reference statement by statement, quirks included:
+//   * filterCameras looks the depth map up with an un-flipped y and accepts col == cols (heuristic.cpp:307-309);
+//     the read is clamped here instead of running one past the row;
+//   * the random stream is cv::theRNG()'s default, never seeded (HeuristicRNG in recon.hpp);
+//   * FLANN's L2_Simple returns SQUARED distances which filterPoints uses as distances (heuristic.cpp:81-89);
+//     FLANN's randomised KD-tree is replaced by an exact grid search (a superset of what an approximate
+//     search returns; the reference already filters by index to restore symmetry, heuristic.cpp:86).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <unordered_map>
+
+#include "recon.hpp"
+
+namespace {
+
+typedef std::pair<int, float> Neighbor;
+const float focal = 0.5f;  // heuristic.cpp:9
+
+struct CameraLabel {  // heuristic.cpp:12-17
+    int index;
+    float cosFromViewer, distance;
+    float viewX, viewY;
+};
+const CameraLabel dummyLabel = {-1, 0, 0, 0, 0};  // heuristic.cpp:19
+typedef std::vector<std::pair<CameraLabel, Mat>> LabelledCameras;
+
+inline float pow2(float x) { return x * x; }
+inline unsigned compact(unsigned short i, unsigned short j) { return (unsigned(i) << 16) + unsigned(j); }  // heuristic.cpp:43-46
+inline float densityFn(float dist, float radius) { return (float)(1. - dist / radius); }                    // heuristic.cpp:49-52
+
+struct V3 {
+    float x, y, z;
+};
+inline V3 vertex(const Mat &verts, int i)
+{
+    const float *p = verts.ptr<float>(i);
+    return {p[0] / p[3], p[1] / p[3], p[2] / p[3]};
+}
+inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float norm(V3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+
+// heuristic.cpp:179-190
+float faceArea(const Mat &points, int ia, int ib, int ic)
+{
+    V3 a = vertex(points, ia), b = vertex(points, ib), c = vertex(points, ic);
+    return norm(cross(sub(b, a), sub(c, b))) / 2;
+}
+
+Mat mat44(const float (&m)[16])
+{
+    Mat r(4, 4, mvs::F32C1);
+    std::memcpy(r.data, m, sizeof(m));
+    return r;
+}
+
+// heuristic.cpp:193-247: a camera sitting on the face, looking along its normal
+Mat faceCamera(const Mesh &mesh, int faceIdx, float far, float focalLen, HeuristicRNG &rng)
+{
+    const int32_t *vi = mesh.faces.ptr<int32_t>(faceIdx);
+    V3 a = vertex(mesh.vertices, vi[0]), b = vertex(mesh.vertices, vi[1]), c = vertex(mesh.vertices, vi[2]);
+    V3 n = cross(sub(b, a), sub(c, b));
+    const float len = norm(n);
+    n = {n.x / len, n.y / len, n.z / len};
+    float u1 = rng.uniform(), u2 = rng.uniform();  // heuristic.cpp:207
+    if (u1 + u2 > 1) {
+        u1 = 1 - u1;
+        u2 = 1 - u2;
+    }
+    const float u3 = 1 - u1 - u2;
+    const float ce[3] = {a.x * u1 + b.x * u2 + c.x * u3, a.y * u1 + b.y * u2 + c.y * u3, a.z * u1 + b.z * u2 + c.z * u3};
+    const float x = n.x, y = n.y, z = n.z;
+    const float xys = x * x + y * y, xy = std::sqrt(xys);
+    float RT[16];
+    if (xy > 0) {  // heuristic.cpp:221-227
+        const float m[16] = {z * x / xy, z * y / xy, xy, -z * (ce[0] * x + ce[1] * y) / xy - ce[2] * xy,
+                             -y / xy,    x / xy,     0,  (ce[0] * y - ce[1] * x) / xy,
+                             -x,         -y,         z,  ce[0] * x + ce[1] * y - ce[2] * z,
+                             0,          0,          0,  1};
+        std::memcpy(RT, m, sizeof(m));
+    } else {  // heuristic.cpp:228-236
+        const float s = (z > 0) ? 1.f : -1.f;
+        const float m[16] = {1, 0, 0, -ce[0], 0, s, 0, -ce[1], 0, 0, s, -ce[2], 0, 0, 0, 1};
+        std::memcpy(RT, m, sizeof(m));
+    }
+    const float near = 0.001f;  // heuristic.cpp:239
+    const float K[16] = {focalLen, 0, 0, 0, 0, focalLen, 0, 0, 0, 0, (near + far) / (far - near), 2 * near * far / (near - far), 0, 0, 1, 0};
+    return mvs::matmul(mat44(K), mat44(RT));
+}
+
+// heuristic.cpp:250-258: linear search; returns list.size() when nothing exceeds `choice`
+int bisect(const std::vector<float> &list, float choice)
+{
+    for (int i = 0; i < (int)list.size(); i++)
+        if (list[i] > choice) return i - 1;
+    return (int)list.size();
+}
+
+int myFind(const std::vector<numberedVector> &list, int index)
+{
+    for (int i = 0; i < (int)list.size(); i++)
+        if (list[i].first == index) return i;
+    return -1;
+}
+int myFind(const std::vector<int> &list, int index)
+{
+    for (int i = 0; i < (int)list.size(); i++)
+        if (list[i] == index) return i;
+    return -1;
+}
+
+// heuristic.cpp:285-341
+LabelledCameras filterCameras(const Mat &viewer, const Mat &depth, const std::vector<Mat> &cameras)
+{
+    LabelledCameras filtered;
+    const Mat viewerCenter = extractCameraCenter(viewer);
+    for (int i = 0; i < (int)cameras.size(); i++) {
+        const Mat &camera = cameras[i];
+        CameraLabel label = dummyLabel;
+        label.index = i;
+        Mat cfvM = mvs::matmul(viewer, extractCameraCenter(camera));
+        float cfv[4];
+        for (int k = 0; k < 4; k++) cfv[k] = cfvM.at<float>(k, 0) / cfvM.at<float>(3, 0);
+        if (cfv[2] > 1 || cfv[2] < -1) continue;  // wrong side of the face
+        label.viewX = cfv[0];
+        label.viewY = cfv[1];
+        int row = (int)((cfv[1] + 1) * depth.rows / 2), col = (int)((cfv[0] + 1) * depth.cols / 2);
+        if (row < 0 || row >= depth.rows || col < 0 || col > depth.cols) continue;  // `col > cols`, heuristic.cpp:309
+        const float obstacleDepth = depth.at<float>(row, std::min(col, depth.cols - 1));
+        if (obstacleDepth != backgroundDepth && obstacleDepth <= cfv[2]) continue;
+        Mat vfcM = mvs::matmul(camera, viewerCenter);
+        label.distance = vfcM.at<float>(3, 0) / viewerCenter.at<float>(3, 0);
+        if (label.distance < 0) continue;
+        const float w = vfcM.at<float>(3, 0);
+        const float vfc0 = vfcM.at<float>(0, 0) / w, vfc1 = vfcM.at<float>(1, 0) / w;
+        if (vfc0 < -1 || vfc0 > 1 || vfc1 < -1 || vfc1 > 1) continue;
+        label.cosFromViewer = std::sqrt(1 / (1 + (cfv[0] * cfv[0] + cfv[1] * cfv[1]) / (focal * focal)));
+        filtered.push_back(std::make_pair(label, camera));
+    }
+    return filtered;
+}
+
+// heuristic.cpp:345-369
+CameraLabel chooseMain(std::map<unsigned, float> &weights, const LabelledCameras &fc, float *outWeightSum, float boostFactor,
+                       HeuristicRNG &rng)
+{
+    if (fc.empty()) throw std::runtime_error("chooseMain: no camera passed the visibility tests");
+    std::vector<float> weightSum(fc.size() + 1, 0.f);
+    *outWeightSum = 0;
+    for (int i = 0; i < (int)fc.size(); i++) {
+        const CameraLabel &label = fc[i].first;
+        float weight = label.cosFromViewer / pow2(label.distance);
+        *outWeightSum += weight;
+        if (weights.count(compact(label.index, label.index))) weight += weight * boostFactor * fc.size();
+        weightSum[i + 1] = weightSum[i] + weight;
+    }
+    const float choice = rng.uniform() * weightSum.back();  // heuristic.cpp:365
+    const int index = bisect(weightSum, choice);
+    return fc[std::min(std::max(index, 0), (int)fc.size() - 1)].first;
+}
+
+// heuristic.cpp:372-426
+CameraLabel chooseSide(std::map<unsigned, float> &weights, CameraLabel mainCamera, float threshold, float boostFactor,
+                       const LabelledCameras &fc, HeuristicRNG &rng)
+{
+    if (fc.size() < 2) throw std::runtime_error("chooseSide: fewer than two cameras");
+    std::vector<float> weightSum(fc.size(), 0.f);
+    std::vector<CameraLabel> labels;
+    float actualWeightSum = 0;
+    int i = 0;
+    for (const auto &entry : fc) {
+        const CameraLabel &label = entry.first;
+        if (label.index == mainCamera.index) continue;
+        const float parallaxSqr = (pow2(label.viewX - mainCamera.viewX) + pow2(label.viewY - mainCamera.viewY)) / focal;
+        float weight = label.cosFromViewer * parallaxSqr / pow2(label.distance);
+        actualWeightSum += weight;
+        const unsigned key = compact(mainCamera.index, label.index);
+        if (weights.count(key) && weights[key] >= 1) weight += weight * boostFactor * fc.size();
+        if (i + 1 < (int)weightSum.size()) weightSum[i + 1] = weightSum[i] + weight;
+        labels.push_back(label);
+        i++;
+    }
+    if (labels.empty()) return dummyLabel;
+    const float choice = rng.uniform() * weightSum.back();  // heuristic.cpp:400
+    int index = bisect(weightSum, choice);
+    index = std::min(std::max(index, 0), i - 1);  // assert(index >= 0 && index < i), heuristic.cpp:402
+    const unsigned key = compact(mainCamera.index, labels[index].index);
+    if (weights[key] >= 1) return dummyLabel;  // already selected
+    weights[compact(mainCamera.index, mainCamera.index)] = 1;
+    const float addWeight = (weightSum[index + 1] - weightSum[index]) / (threshold * actualWeightSum);
+    weights[key] += addWeight;
+    return weights[key] >= 1 ? labels[index] : dummyLabel;
+}
+
+}  // namespace
+
+Heuristic::Heuristic(Configuration *iconfig) : config(iconfig), iteration(0), mainIdx(0), sideIdx(0) {}
+
+// heuristic.cpp:31-35
+bool Heuristic::notHappy(const Mat)
+{
+    iteration++;
+    return iteration <= config->iterationCount;
+}
+
+// heuristic.cpp:429-486
+int Heuristic::chooseCameras(const Mesh mesh, const std::vector<Mat> cameras, const Render &render)
+{
+    chosenCameras.clear();
+    int cameraCount = 0;
+    const int F = mesh.faces.rows;
+    std::vector<float> areaSum(F + 1, 0.f);
+    for (int i = 0; i < F; i++) {
+        const int32_t *vi = mesh.faces.ptr<int32_t>(i);
+        areaSum[i + 1] = areaSum[i] + faceArea(mesh.vertices, vi[0], vi[1], vi[2]);
+    }
+    const float totalArea = areaSum.back();
+    const float samplingResolution = std::sqrt((float)cameras.size()) * config->width * config->height / (totalArea * config->cameraThreshold);
+    const int shotCount = 200;  // heuristic.cpp:445
+    std::map<unsigned, float> weights;
+    for (int i = 0; i < shotCount; i++) {
+        const float choice = rng.uniform() * totalArea;  // heuristic.cpp:450
+        int chosenIdx = bisect(areaSum, choice);
+        chosenIdx = std::min(std::max(chosenIdx, 0), F - 1);
+        const float far = 10;  // heuristic.cpp:454
+        const Mat viewer = faceCamera(mesh, chosenIdx, far, focal, rng);
+        const Mat depth = render.depth(viewer);  // the hot callee
+        const LabelledCameras filtered = filterCameras(viewer, depth, cameras);
+        if (filtered.size() >= 2) {
+            float mainWeightSum;
+            const CameraLabel mainCamera = chooseMain(weights, filtered, &mainWeightSum, config->cameraThreshold, rng);
+            const CameraLabel sideCamera = chooseSide(weights, mainCamera, shotCount * mainWeightSum / samplingResolution,
+                                                      config->cameraThreshold / 10, filtered, rng);
+            if (sideCamera.index == dummyLabel.index) continue;
+            cameraCount += 1;
+            const int positionMain = myFind(chosenCameras, mainCamera.index);
+            if (positionMain == -1)
+                chosenCameras.push_back(numberedVector(mainCamera.index, std::vector<int>(1, sideCamera.index)));
+            else if (myFind(chosenCameras[positionMain].second, sideCamera.index) == -1)
+                chosenCameras[positionMain].second.push_back(sideCamera.index);
+        }
+    }
+    std::sort(chosenCameras.begin(), chosenCameras.end());
+    return cameraCount;
+}
+
+// heuristic.cpp:489-522
+int Heuristic::beginMain() { return chosenCameras.empty() ? sentinel : chosenCameras[mainIdx = 0].first; }
+int Heuristic::nextMain() { return ++mainIdx < (int)chosenCameras.size() ? chosenCameras[mainIdx].first : sentinel; }
+int Heuristic::beginSide(int imain)
+{
+    if (imain != chosenCameras[mainIdx].first || chosenCameras[mainIdx].second.empty()) return sentinel;
+    return chosenCameras[mainIdx].second[sideIdx = 0];
+}
+int Heuristic::nextSide(int imain)
+{
+    if (imain != chosenCameras[mainIdx].first || ++sideIdx >= (int)chosenCameras[mainIdx].second.size()) return sentinel;
+    return chosenCameras[mainIdx].second[sideIdx];
+}
+
+// heuristic.cpp:548-551
+mvs::Size Heuristic::renderSize() { return mvs::Size(config->width, config->height); }
+
+// heuristic.cpp:55-176
+void Heuristic::filterPoints(Mat &points, Mat &normals)
+{
+    const int pointCount = points.rows;
+    if (pointCount == 0) return;
+    if (alphaVals.empty()) throw std::runtime_error("filterPoints: no alpha value recorded (tessellate was never called)");
+    const Mat points3 = dehomogenize(points);
+    const float radius = alphaVals.back() / 4.f;  // heuristic.cpp:63
+    // L2_Simple yields squared distances and the reference compares them with `radius` (heuristic.cpp:81-89):
+    // the neighbourhood is |p - q|^2 <= radius, i.e. a ball of sqrt(radius)
+    const float reach = std::sqrt(std::max(radius, 0.f));
+    std::vector<int> neighborBlocks(pointCount + 1, 0);
+    std::vector<Neighbor> neighbors;
+    {
+        const float cell = reach > 0 ? reach : 1.f;
+        auto key = [&](int ix, int iy, int iz) { return ((int64_t)ix * 73856093LL) ^ ((int64_t)iy * 19349663LL) ^ ((int64_t)iz * 83492791LL); };
+        std::unordered_map<int64_t, std::vector<int>> grid;
+        auto cellOf = [&](int i, int c) { return (int)std::floor(points3.at<float>(i, c) / cell); };
+        for (int i = 0; i < pointCount; i++) {
+            neighborBlocks[i] = (int)neighbors.size();
+            const int cx = cellOf(i, 0), cy = cellOf(i, 1), cz = cellOf(i, 2);
+            std::vector<Neighbor> found;
+            for (int dx = -1; dx <= 1; dx++)
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dz = -1; dz <= 1; dz++) {
+                        auto it = grid.find(key(cx + dx, cy + dy, cz + dz));
+                        if (it == grid.end()) continue;
+                        for (int j : it->second) {  // only smaller indices are in the grid yet (heuristic.cpp:86)
+                            const float ddx = points3.at<float>(i, 0) - points3.at<float>(j, 0);
+                            const float ddy = points3.at<float>(i, 1) - points3.at<float>(j, 1);
+                            const float ddz = points3.at<float>(i, 2) - points3.at<float>(j, 2);
+                            const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                            if (d2 <= radius) found.push_back(Neighbor(j, densityFn(d2, radius)));
+                        }
+                    }
+            std::sort(found.begin(), found.end());
+            neighbors.insert(neighbors.end(), found.begin(), found.end());
+            grid[key(cx, cy, cz)].push_back(i);
+        }
+    }
+    neighborBlocks[pointCount] = (int)neighbors.size();
+
+    // clamped, L1-normalised power iteration (heuristic.cpp:103-136)
+    std::vector<float> density(pointCount, 1.f), score(pointCount, 0.f);
+    double change;
+    int it = 0;
+    do {
+        std::fill(score.begin(), score.end(), 0.f);
+        double sum = 0.;
+        for (int i = 0; i < pointCount; i++) {
+            float densityTemp = 0.f;
+            for (int j = neighborBlocks[i]; j < neighborBlocks[i + 1]; j++) {
+                densityTemp += density[neighbors[j].first] * neighbors[j].second;
+                score[neighbors[j].first] += density[i] * neighbors[j].second;
+                sum += (density[i] + density[neighbors[j].first]) * neighbors[j].second;
+            }
+            score[i] += densityTemp;
+        }
+        const float normalizer = (float)(pointCount / sum);
+        change = 0.;
+        for (int i = 0; i < pointCount; i++) {
+            float nd = score[i] * normalizer;
+            if (nd > 2.f) nd = 2.f;
+            change += pow2(density[i] - nd);
+            density[i] = nd;
+        }
+        change /= pointCount;
+        it++;
+    } while (change > 1e-6 && it < 200);
+
+    const float densityLimit = .7f;  // heuristic.cpp:139
+    std::vector<int> order(pointCount);
+    for (int i = 0; i < pointCount; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return density[a] > density[b]; });
+    int writeIndex = 0;
+    for (int i = 0; i < pointCount; i++) {
+        const int ord = order[i];
+        if (score[ord] < densityLimit) continue;
+        const double localDensity = density[ord];
+        for (int j = neighborBlocks[ord]; j < neighborBlocks[ord + 1]; j++) score[neighbors[j].first] -= (float)(localDensity * neighbors[j].second);
+        if (i > writeIndex) order[writeIndex] = order[i];
+        writeIndex++;
+    }
+    std::sort(order.begin(), order.begin() + writeIndex);
+    Mat np(writeIndex, 4, mvs::F32C1), nn(writeIndex, 3, mvs::F32C1);
+    for (int i = 0; i < writeIndex; i++) {
+        std::memcpy(np.ptr<float>(i), points.ptr<float>(order[i]), 4 * sizeof(float));
+        std::memcpy(nn.ptr<float>(i), normals.ptr<float>(order[i]), 3 * sizeof(float));
+    }
+    points = np;
+    normals = nn;
+}

@@ -1,0 +1,135 @@
+// recon.hpp -- host-side mirror of the reference's public interface for the hot path (recon.hpp:17-123 of
+// addam/mesh-reconstruction), backed by libmvs_hip.so (include/mvs.h).
+//
+// Same names, argument meaning and ownership rules as the reference so that code written against the
+// reference's header (recon.cpp:12-141) reads the same here:
+//   Mat / Mesh / MatList / backgroundDepth            recon.hpp:17-30
+//   class Render { loadMesh, projected, depth }       recon.hpp:93-99     -> RenderHIP (render_hip.cpp)
+//   Render *spawnRender(Heuristic)                    recon.hpp:100, render_glx.cpp:57-62
+//   calculateFlow / compare / mixBackground / flowRemap / extractCameraCenter / dehomogenize   recon.hpp:40-50
+//   class Heuristic                                   recon.hpp:104-123, heuristic.cpp
+//   class Configuration                               recon.hpp:58-90, configuration.cpp
+// Differences, all forced by the missing OpenCV: Mat is mvs::Mat (matlite.hpp)
+// unless MVS_WITH_OPENCV is defined; errors are C++ exceptions (std::runtime_error) instead of
+// assert/exit(1) (recon.cpp:49, configuration.cpp:136,141,172); video decoding is replaced by a frame
+// directory (the clips are not in the reference checkout either: .MISSING_LARGE_BLOBS).
+#pragma once
+
+#include <list>
+#include <map>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "matlite.hpp"
+
+typedef unsigned char uchar;
+typedef mvs::Mat Mat;
+typedef struct Mesh {
+    Mat vertices, faces;  // N x 4 f32 homogeneous rows; F x 3 i32
+    Mesh() {}
+    Mesh(Mat v, Mat f) : vertices(v), faces(f) {}
+} Mesh;
+typedef std::list<Mat> MatList;
+
+class Configuration;
+class Heuristic;
+
+const float backgroundDepth = 1.0;  // recon.hpp:30
+
+// == flow (flow.cpp:19-42) ==
+Mat calculateFlow(const Mat prev, const Mat next, bool useFarneback);
+
+// == util (util.cpp) ==
+Mat extractCameraCenter(const Mat camera);                 // util.cpp:33-41: homogeneous 4x1 centre
+Mat compare(const Mat prev, const Mat next);               // util.cpp:332-361
+Mat dehomogenize(Mat points);                              // util.cpp:16-29
+Mat mixBackground(const Mat image, const Mat background, Mat &depth);  // util.cpp:366-387 (mutates depth)
+Mat flowRemap(const Mat flow, const Mat image);            // util.cpp:390-403
+
+// == configuration (configuration.cpp) ==
+class Configuration {
+public:
+    Configuration(int argc, char **argv);      // same 12 getopt options as configuration.cpp:37-53
+    explicit Configuration(const std::string &yamlPath, int skipFrames = 1);
+    Mat reconstructedPoints();                 // bundles, N x 4            configuration.cpp:432-435
+    const Mat frame(int frameNo) const;        // H x W u8                  configuration.cpp:437-440
+    const Mat camera(int frameNo) const;       // 4 x 4 f32                 configuration.cpp:442-445
+    const std::vector<Mat> allCameras() const; // configuration.cpp:447-450
+    float nearVal(int frameNo) const { return nearVals.at(frameNo); }
+    float farVal(int frameNo) const { return farVals.at(frameNo); }
+    int frameCount() const { return (int)cameras.size(); }
+    void setFrame(int frameNo, const Mat gray); // supplies a decoded frame (replaces cv::VideoCapture)
+    int iterationCount = 2;        // configuration.cpp:28
+    char verbosity = 0;
+    bool useFarneback = false;     // configuration.cpp:26
+    float cameraThreshold = 10.f;  // configuration.cpp:30
+    float sceneResolution = 1.f;
+    float scalingFactor = 1.f;
+    unsigned skipFrames = 1;
+    int width = 0, height = 0;
+    std::string outFileName = "output.obj";
+    std::string inMeshFile;
+    std::string clipPath;
+    std::vector<float> lensDistortion;
+    float centerX = 0, centerY = 0;
+    bool doEstimateExposure = false;
+
+protected:
+    void parseYaml(const std::string &path);
+    std::vector<Mat> frames;
+    std::vector<Mat> cameras;
+    std::vector<float> nearVals, farVals;
+    Mat bundles;
+    std::vector<std::set<int>> bundlesEnabled;
+};
+
+// == renderer ==
+class Render {
+public:
+    virtual ~Render() {}
+    virtual void loadMesh(const Mesh) = 0;
+    virtual Mat projected(const Mat camera, const Mat frame, const Mat projector) = 0;
+    virtual Mat depth(const Mat camera) const = 0;
+};
+Render *spawnRender(Heuristic hint);
+
+// == heuristic ==
+typedef std::pair<int, std::vector<int>> numberedVector;
+
+// cv::theRNG() as the reference uses it through cv::randu<float>() (heuristic.cpp:207,365,400,450): OpenCV's
+// multiply-with-carry generator, default state 0xffffffff, never seeded by the reference -> a fixed stream.
+struct HeuristicRNG {
+    uint64_t state = 0xffffffffULL;
+    unsigned next()
+    {
+        state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
+        return (unsigned)state;
+    }
+    float uniform() { return next() * 2.3283064365386963e-10f; }
+};
+
+class Heuristic {
+public:
+    Heuristic(Configuration *iconfig);
+    int chooseCameras(const Mesh mesh, const std::vector<Mat> cameras, const Render &);
+    bool notHappy(const Mat points);
+    int beginMain();
+    int nextMain();
+    int beginSide(int mainNumber);
+    int nextSide(int mainNumber);
+    void filterPoints(Mat &points, Mat &normals);
+    mvs::Size renderSize();
+    static const int sentinel = -1;
+    HeuristicRNG rng;  // explicit and seedable (SURVEY 8b "determinism hook")
+    const std::vector<numberedVector> &chosen() const { return chosenCameras; }
+    std::vector<float> alphaVals;
+
+protected:
+    Configuration *config;
+    int iteration;
+    int mainIdx, sideIdx;
+    std::vector<numberedVector> chosenCameras;
+};

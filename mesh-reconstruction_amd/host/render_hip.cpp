@@ -1,0 +1,182 @@
+// render_hip.cpp -- `class RenderHIP : public Render` + `spawnRender`: the link-time renderer seam of the
+// reference (render_${SYSTEM_OPENGL}.cpp, Makefile:2,16,21; "render_<whatever>.cpp in the future", recon.hpp:92)
+// implemented on libmvs_hip.so.  Also the free functions of recon.hpp:40-50 that sit on the hot path.
+//
+// Ownership as in the reference: returned Mats are freshly allocated and owned by the caller; the Render*
+// from spawnRender is a raw owning pointer the caller deletes (recon.cpp:130); inputs are copied to the
+// device inside each call and never retained.
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+
+#include "../../include/mvs.h"
+#include "recon.hpp"
+
+namespace {
+
+[[noreturn]] void raise(mvs_ctx *ctx, const char *what)
+{
+    throw std::runtime_error(std::string(what) + ": " + mvs_last_error(ctx));
+}
+
+int device_from_env()
+{
+    const char *e = getenv("MVS_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+// the reference's free functions carry no context argument; they share one context per image size
+std::mutex g_mutex;
+std::map<std::pair<int, int>, mvs_ctx *> g_ctx;
+
+mvs_ctx *shared_ctx(int w, int h)
+{
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto key = std::make_pair(w, h);
+    auto it = g_ctx.find(key);
+    if (it != g_ctx.end()) return it->second;
+    mvs_ctx *c = mvs_create(device_from_env(), w, h);
+    if (!c) raise(nullptr, "mvs_create");
+    g_ctx[key] = c;
+    return c;
+}
+
+void expect(const Mat &m, int type, const char *what)
+{
+    if (m.empty() || m.type() != type) throw std::runtime_error(std::string(what) + ": unexpected matrix type or empty matrix");
+}
+
+}  // namespace
+
+class RenderHIP : public Render {
+public:
+    RenderHIP(int width, int height) : w(width), h(height)
+    {
+        ctx = mvs_create(device_from_env(), width, height);  // replaces the GLX pbuffer + GL 3.0 context (render_glx.cpp:152-208)
+        if (!ctx) raise(nullptr, "RenderHIP: mvs_create");
+    }
+    ~RenderHIP() override { mvs_destroy(ctx); }
+
+    void loadMesh(const Mesh mesh) override  // render_glx.cpp:230-258
+    {
+        expect(mesh.vertices, mvs::F32C1, "loadMesh vertices");
+        if (mesh.vertices.cols != 4) throw std::runtime_error("loadMesh: vertices must be N x 4 homogeneous rows");
+        const int nf = mesh.faces.rows;
+        if (nf > 0) expect(mesh.faces, mvs::S32C1, "loadMesh faces");
+        if (mvs_load_mesh(ctx, mesh.vertices.ptr<float>(), mesh.vertices.rows, nf ? mesh.faces.ptr<int32_t>() : nullptr, nf))
+            raise(ctx, "loadMesh");
+    }
+
+    Mat projected(const Mat camera, const Mat frame, const Mat projector) override  // render_glx.cpp:261-367
+    {
+        expect(camera, mvs::F32C1, "projected camera");
+        expect(projector, mvs::F32C1, "projected projector");
+        expect(frame, mvs::U8C1, "projected frame");  // assert(image.channels() == 1), render_glx.cpp:66
+        if (frame.cols != w || frame.rows != h) throw std::runtime_error("projected: frame size differs from the render size");
+        Mat result(h, w, mvs::U8C3);
+        if (mvs_projected(ctx, camera.ptr<float>(), frame.ptr<uint8_t>(), projector.ptr<float>(), result.ptr<uint8_t>()))
+            raise(ctx, "projected");
+        return result;
+    }
+
+    Mat depth(const Mat camera) const override  // render_glx.cpp:369-397
+    {
+        expect(camera, mvs::F32C1, "depth camera");
+        Mat result(h, w, mvs::F32C1);
+        if (mvs_depth(ctx, camera.ptr<float>(), result.ptr<float>())) raise(ctx, "depth");
+        return result;
+    }
+
+    mvs_ctx *context() const { return ctx; }
+
+protected:
+    mvs_ctx *ctx;
+    int w, h;
+};
+
+// render_glx.cpp:57-62
+Render *spawnRender(Heuristic hint)
+{
+    mvs::Size size = hint.renderSize();
+    return new RenderHIP(size.width, size.height);
+}
+
+// flow.cpp:19-42
+Mat calculateFlow(const Mat prev, const Mat next, bool useFarneback)
+{
+    expect(prev, mvs::U8C1, "calculateFlow prev");
+    expect(next, mvs::U8C1, "calculateFlow next");
+    mvs_ctx *ctx = shared_ctx(prev.cols, prev.rows);
+    Mat mixed(prev.rows, prev.cols, mvs::F32C4);
+    if (mvs_flow(ctx, prev.ptr<uint8_t>(), next.ptr<uint8_t>(), useFarneback ? 1 : 0, mixed.ptr<float>())) raise(ctx, "calculateFlow");
+    return mixed;
+}
+
+// util.cpp:332-361
+Mat compare(const Mat prev, const Mat next)
+{
+    expect(prev, mvs::U8C1, "compare prev");
+    expect(next, mvs::U8C1, "compare next");
+    mvs_ctx *ctx = shared_ctx(prev.cols, prev.rows);
+    Mat out(prev.rows, prev.cols, mvs::F32C1);
+    if (mvs_compare(ctx, prev.ptr<uint8_t>(), next.ptr<uint8_t>(), out.ptr<float>())) raise(ctx, "compare");
+    return out;
+}
+
+// util.cpp:366-387
+Mat mixBackground(const Mat image, const Mat background, Mat &depth)
+{
+    expect(image, mvs::U8C3, "mixBackground image");       // assert(image.channels() == 3)
+    expect(background, mvs::U8C1, "mixBackground background");
+    expect(depth, mvs::F32C1, "mixBackground depth");
+    mvs_ctx *ctx = shared_ctx(depth.cols, depth.rows);
+    Mat result(depth.rows, depth.cols, mvs::U8C1);
+    if (mvs_mix_background(ctx, image.ptr<uint8_t>(), background.ptr<uint8_t>(), depth.ptr<float>(), result.ptr<uint8_t>()))
+        raise(ctx, "mixBackground");
+    return result;
+}
+
+// util.cpp:390-403
+Mat flowRemap(const Mat flow, const Mat image)
+{
+    expect(image, mvs::U8C1, "flowRemap image");
+    if (flow.empty() || (flow.type() != mvs::F32C2 && flow.type() != mvs::F32C4)) throw std::runtime_error("flowRemap: flow must be 2 or 4 channel f32");
+    mvs_ctx *ctx = shared_ctx(image.cols, image.rows);
+    Mat out(image.rows, image.cols, mvs::U8C1);
+    if (mvs_flow_remap(ctx, flow.ptr<float>(), flow.channels(), image.ptr<uint8_t>(), out.ptr<uint8_t>())) raise(ctx, "flowRemap");
+    return out;
+}
+
+// util.cpp:16-29
+Mat dehomogenize(Mat points)
+{
+    Mat result(points.rows, 3, mvs::F32C1);
+    for (int i = 0; i < points.rows; i++) {
+        const float *inp = points.ptr<float>(i);
+        float *out = result.ptr<float>(i);
+        out[0] = inp[0] / inp[3];
+        out[1] = inp[1] / inp[3];
+        out[2] = inp[2] / inp[3];
+    }
+    return result;
+}
+
+// util.cpp:33-41: the reference takes rows 0,1,3 of the 4x4 and asks cv::decomposeProjectionMatrix for the
+// camera position, i.e. the null vector of that 3x4 (unit length, sign unspecified).  Closed form: the signed
+// 3x3 minors.  Every caller divides by the 4th component (heuristic.cpp:293-295,317-320), so scale and sign cancel.
+Mat extractCameraCenter(const Mat camera)
+{
+    const int rows[3] = {0, 1, 3};
+    double p[3][4];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) p[r][c] = camera.at<float>(rows[r], c);
+    auto det3 = [&](int c0, int c1, int c2) {
+        return p[0][c0] * (p[1][c1] * p[2][c2] - p[1][c2] * p[2][c1]) - p[0][c1] * (p[1][c0] * p[2][c2] - p[1][c2] * p[2][c0]) +
+               p[0][c2] * (p[1][c0] * p[2][c1] - p[1][c1] * p[2][c0]);
+    };
+    double c[4] = {det3(1, 2, 3), -det3(0, 2, 3), det3(0, 1, 3), -det3(0, 1, 2)};
+    const double n = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]);
+    Mat T(4, 1, mvs::F32C1);
+    for (int i = 0; i < 4; i++) T.at<float>(i, 0) = (float)(n > 0 ? c[i] / n : c[i]);
+    return T;
+}

@@ -1,0 +1,212 @@
+// selftest.cpp -- exercises the host mirror (recon.hpp interface) the way recon.cpp uses it; driven by tests/.
+//   host_selftest cpu <tracks dir>            RNG known answers, YAML reader, camera centre, filterPoints, getopt
+//   host_selftest gpu <tracks dir> <out dir>  spawnRender -> loadMesh -> depth/projected -> mixBackground ->
+//                                             compare/flowRemap, chooseCameras; raw outputs for the oracle check
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "recon.hpp"
+
+static int fails = 0;
+#define CHECK(cond, ...)                       \
+    do {                                       \
+        if (!(cond)) {                         \
+            fails++;                           \
+            printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+            printf(__VA_ARGS__);               \
+            printf("\n");                      \
+        }                                      \
+    } while (0)
+
+static void writeRaw(const std::string &path, const Mat &m)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char *>(m.data), (std::streamsize)(m.total() * m.elemSize()));
+}
+
+static Mesh heightfield(int n, float extent)
+{
+    Mat v(n * n, 4, mvs::F32C1), f(2 * (n - 1) * (n - 1), 3, mvs::S32C1);
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) {
+            const double x = -extent + 2.0 * extent * i / (n - 1), y = -extent + 2.0 * extent * j / (n - 1);
+            float *p = v.ptr<float>(j * n + i);
+            p[0] = (float)x;
+            p[1] = (float)y;
+            p[2] = (float)(-3.0 - 0.4 * std::sin(1.3 * x + 0.7) * std::cos(1.1 * y - 0.2));
+            p[3] = 1.f;
+        }
+    int k = 0;
+    for (int j = 0; j < n - 1; j++)
+        for (int i = 0; i < n - 1; i++) {
+            const int a = j * n + i, b = a + 1, c = a + n, d = c + 1;
+            int32_t *t0 = f.ptr<int32_t>(k++), *t1 = f.ptr<int32_t>(k++);
+            t0[0] = a; t0[1] = b; t0[2] = c;
+            t1[0] = b; t1[1] = d; t1[2] = c;
+        }
+    return Mesh(v, f);
+}
+
+static int run_cpu(const std::string &tracks)
+{
+    // cv::theRNG() default stream: known answers
+    HeuristicRNG rng;
+    const float expect[4] = {0.030282794f, 0.6992592f, 0.90105945f, 0.3143851f};
+    for (int i = 0; i < 4; i++) {
+        const float u = rng.uniform();
+        CHECK(std::fabs(u - expect[i]) < 1e-7f, "rng[%d] = %.9g, expected %.9g", i, u, expect[i]);
+    }
+    // YAML reader on the four bundled calibration files
+    struct { const char *name; int w, h, frames, bundles; } files[] = {
+        {"koberec-.yaml", 640, 480, 55, 30}, {"koberec.yaml", 640, 480, 173, 18}, {"koule-tr.yaml", 640, 480, 31, 21}, {"zatisi.yaml", 640, 480, 120, 23}};
+    for (auto &f : files) {
+        Configuration c(tracks + "/" + f.name);
+        CHECK(c.width == f.w && c.height == f.h, "%s size %dx%d", f.name, c.width, c.height);
+        CHECK(c.frameCount() == f.frames, "%s frames %d", f.name, c.frameCount());
+        CHECK(c.reconstructedPoints().rows == f.bundles, "%s bundles %d", f.name, c.reconstructedPoints().rows);
+        // projection[2][2] = -(far+near)/(far-near), [2][3] = 2 far near/(near-far) for the identity-pose frame 1
+        const Mat P = c.camera(0);
+        const float n = c.nearVal(0), fa = c.farVal(0);
+        CHECK(std::fabs(std::fabs(P.at<float>(2, 2)) - (fa + n) / (fa - n)) < 2e-3f, "%s P22 %g", f.name, P.at<float>(2, 2));
+        CHECK(std::fabs(P.at<float>(1, 1) / P.at<float>(0, 0) - 4.f / 3.f) < 1e-3f, "%s aspect", f.name);
+        // every camera centre is annihilated by rows 0,1,3 of its matrix
+        for (int i = 0; i < c.frameCount(); i += 7) {
+            const Mat cam = c.camera(i), ctr = extractCameraCenter(cam);
+            const Mat s = mvs::matmul(cam, ctr);
+            CHECK(std::fabs(s.at<float>(0, 0)) < 1e-4f && std::fabs(s.at<float>(1, 0)) < 1e-4f && std::fabs(s.at<float>(3, 0)) < 1e-4f,
+                  "%s centre of camera %d", f.name, i);
+        }
+    }
+    {   // skipFrames re-indexing (configuration.cpp:186-187, 210-212)
+        Configuration c(tracks + "/zatisi.yaml", 4);
+        CHECK(c.frameCount() == 30, "skip 4 -> %d frames", c.frameCount());
+        Configuration full(tracks + "/zatisi.yaml");
+        CHECK(std::memcmp(c.camera(3).data, full.camera(12).data, 64) == 0, "skip re-index");
+    }
+    {   // command line (configuration.cpp:35-131)
+        std::string y = tracks + "/koule-tr.yaml";
+        const char *argv[] = {"recon", "-n", "3", "-c", "7.5", "-f", "-v", "-o", "x.obj", y.c_str()};
+        Configuration c(10, const_cast<char **>(argv));
+        CHECK(c.iterationCount == 3 && c.cameraThreshold == 7.5f && c.useFarneback && c.verbosity == 2 && c.outFileName == "x.obj", "getopt");
+        Heuristic h(&c);
+        CHECK(h.notHappy(Mat()) && h.notHappy(Mat()) && h.notHappy(Mat()) && !h.notHappy(Mat()), "notHappy counts iterations");
+        CHECK(h.renderSize().width == 640 && h.renderSize().height == 480, "renderSize");
+        bool threw = false;
+        try {
+            const char *bad[] = {"recon"};
+            Configuration b(1, const_cast<char **>(bad));
+        } catch (const std::exception &) { threw = true; }
+        CHECK(threw, "missing YAML must throw");
+    }
+    {   // filterPoints: a dense cluster survives thinned, isolated outliers go (heuristic.cpp:55-176)
+        Configuration c(tracks + "/koule-tr.yaml");
+        Heuristic h(&c);
+        h.alphaVals.push_back(0.16f);  // radius 0.04 -> reach 0.2
+        HeuristicRNG r;
+        const int N = 400;
+        Mat pts(N + 5, 4, mvs::F32C1), nrm = Mat::zeros(N + 5, 3, mvs::F32C1);
+        for (int i = 0; i < N; i++) {
+            float *p = pts.ptr<float>(i);
+            p[0] = r.uniform(); p[1] = r.uniform(); p[2] = 0.05f * r.uniform(); p[3] = 1.f;
+        }
+        for (int i = 0; i < 5; i++) {
+            float *p = pts.ptr<float>(N + i);
+            p[0] = 10.f + 3 * i; p[1] = -7.f; p[2] = 4.f; p[3] = 1.f;
+        }
+        h.filterPoints(pts, nrm);
+        CHECK(pts.rows > 10 && pts.rows < N, "filterPoints kept %d of %d", pts.rows, N + 5);
+        bool outlier = false;
+        for (int i = 0; i < pts.rows; i++) outlier |= pts.at<float>(i, 0) > 5.f;
+        CHECK(!outlier, "isolated points must be removed");
+        CHECK(nrm.rows == pts.rows, "normals follow points");
+    }
+    printf("cpu selftest: %d failures\n", fails);
+    return fails ? 1 : 0;
+}
+
+static int run_gpu(const std::string &tracks, const std::string &out)
+{
+    Configuration config(tracks + "/zatisi.yaml");
+    Heuristic hint(&config);
+    Render *render = spawnRender(hint);  // recon.cpp:21
+    const Mesh mesh = heightfield(40, 1.6f);
+    render->loadMesh(mesh);  // recon.cpp:42
+    const int W = config.width, H = config.height;
+    // synthetic frames (the clip is missing): a smooth pattern per frame index
+    for (int fi = 0; fi < config.frameCount(); fi++) {
+        Mat g(H, W, mvs::U8C1);
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) g.at<uint8_t>(y, x) = (uint8_t)(127 + 100 * std::sin((x + 3 * fi) / 23.0) * std::cos((y - fi) / 17.0));
+        config.setFrame(fi, g);
+    }
+    const int cameraCount = hint.chooseCameras(mesh, config.allCameras(), *render);  // recon.cpp:46
+    printf("chooseCameras: %d pairs, %zu main cameras\n", cameraCount, hint.chosen().size());
+    CHECK(cameraCount > 0, "heuristic chose no cameras");
+    std::ofstream sel(out + "/chosen.txt");
+    int mains = 0, pairs = 0;
+    for (int fa = hint.beginMain(); fa != Heuristic::sentinel; fa = hint.nextMain()) {  // recon.cpp:65
+        sel << fa << ":";
+        mains++;
+        for (int fb = hint.beginSide(fa); fb != Heuristic::sentinel; fb = hint.nextSide(fa)) {  // recon.cpp:81
+            sel << " " << fb;
+            pairs++;
+            CHECK(fb != fa && fb >= 0 && fb < config.frameCount(), "side camera index");
+        }
+        sel << "\n";
+    }
+    CHECK(mains == (int)hint.chosen().size() && pairs >= mains, "iterator protocol");
+    // one (main, side) pair exactly as recon.cpp:69-89 runs it
+    const int fa = hint.beginMain();
+    const int fb = hint.beginSide(fa);
+    Mat originalImage = config.frame(fa);
+    Mat depth = render->depth(config.camera(fa));
+    writeRaw(out + "/depth.f32", depth);
+    Mat projectedImage = render->projected(config.camera(fa), config.frame(fb), config.camera(fb));
+    writeRaw(out + "/projected.u8", projectedImage);
+    Mat mixed = mixBackground(projectedImage, originalImage, depth);
+    writeRaw(out + "/mixed.u8", mixed);
+    writeRaw(out + "/depth_after_mix.f32", depth);
+    Mat var = compare(originalImage, mixed);
+    writeRaw(out + "/compare.f32", var);
+    Mat flow = Mat::zeros(H, W, mvs::F32C4);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            flow.at<float>(y, 4 * x) = 1.5f * std::sin(y / 40.0f);
+            flow.at<float>(y, 4 * x + 1) = -0.75f;
+        }
+    writeRaw(out + "/remap.u8", flowRemap(flow, mixed));
+    {
+        std::ofstream meta(out + "/meta.txt");
+        meta << fa << " " << fb << " " << W << " " << H << " " << mesh.faces.rows << "\n";
+        writeRaw(out + "/mesh_verts.f32", mesh.vertices);
+        writeRaw(out + "/mesh_faces.i32", mesh.faces);
+        writeRaw(out + "/frame_a.u8", originalImage);
+        writeRaw(out + "/frame_b.u8", config.frame(fb));
+        writeRaw(out + "/cam_a.f32", config.camera(fa));
+        writeRaw(out + "/cam_b.f32", config.camera(fb));
+        writeRaw(out + "/flow.f32", flow);
+    }
+    bool threw = false;
+    try {
+        render->projected(config.camera(fa), Mat(10, 10, mvs::U8C1), config.camera(fb));
+    } catch (const std::exception &) { threw = true; }
+    CHECK(threw, "wrong frame size must throw");
+    delete render;  // recon.cpp:130
+    printf("gpu selftest: %d failures\n", fails);
+    return fails ? 1 : 0;
+}
+
+int main(int argc, char **argv)
+{
+    try {
+        if (argc >= 3 && !strcmp(argv[1], "cpu")) return run_cpu(argv[2]);
+        if (argc >= 4 && !strcmp(argv[1], "gpu")) return run_gpu(argv[2], argv[3]);
+    } catch (const std::exception &e) {
+        printf("exception: %s\n", e.what());
+        return 2;
+    }
+    printf("usage: host_selftest cpu <tracks dir> | gpu <tracks dir> <out dir>\n");
+    return 64;
+}

@@ -1,0 +1,44 @@
+"""The reference's per-pair stage driven through the C++ mirror exactly as recon.cpp:21,42,46,65-89 does it
+(spawnRender -> loadMesh -> chooseCameras -> depth -> projected -> mixBackground -> compare / flowRemap), outputs
+checked against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SELFTEST = os.path.join(ROOT, "mesh-reconstruction_amd", "bin", "host_selftest")
+TRACKS = os.path.join(ROOT, "tests", "data", "tracks")
+
+
+def test_recon_stage_through_cpp_mirror(oracle, tmp_path):
+    r = subprocess.run([SELFTEST, "gpu", TRACKS, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "gpu selftest: 0 failures" in r.stdout
+    fa, fb, W, H, F = [int(x) for x in open(tmp_path / "meta.txt").read().split()]
+
+    def raw(name, dtype, shape):
+        return np.fromfile(tmp_path / name, dtype).reshape(shape)
+
+    verts = raw("mesh_verts.f32", np.float32, (-1, 4))
+    faces = raw("mesh_faces.i32", np.int32, (F, 3))
+    cam_a, cam_b = raw("cam_a.f32", np.float32, (4, 4)), raw("cam_b.f32", np.float32, (4, 4))
+    frame_a, frame_b = raw("frame_a.u8", np.uint8, (H, W)), raw("frame_b.u8", np.uint8, (H, W))
+    soup = oracle.load_mesh(verts, faces)
+    d_ref = oracle.depth(soup, cam_a, W, H)
+    np.testing.assert_array_equal(raw("depth.f32", np.float32, (H, W)), d_ref)
+    p_ref = oracle.projected(soup, cam_a, frame_b, cam_b)
+    np.testing.assert_array_equal(raw("projected.u8", np.uint8, (H, W, 3)), p_ref)
+    m_ref, d2_ref = oracle.mix_background(p_ref, frame_a, d_ref)
+    np.testing.assert_array_equal(raw("mixed.u8", np.uint8, (H, W)), m_ref)
+    np.testing.assert_array_equal(raw("depth_after_mix.f32", np.float32, (H, W)), d2_ref)
+    np.testing.assert_array_equal(raw("compare.f32", np.float32, (H, W)), oracle.compare(frame_a, m_ref))
+    flow = raw("flow.f32", np.float32, (H, W, 4))
+    np.testing.assert_array_equal(raw("remap.u8", np.uint8, (H, W)), oracle.flow_remap(flow, m_ref))
+    # camera selection produced a usable, sorted schedule (heuristic.cpp:484)
+    mains = [int(l.split(":")[0]) for l in open(tmp_path / "chosen.txt")]
+    assert mains == sorted(mains) and len(mains) >= 1
+    assert (d_ref != 1.0).mean() > 0.05
