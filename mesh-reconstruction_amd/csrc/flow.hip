@@ -1,0 +1,672 @@
+// flow.hip -- calculateFlow() of the reference (flow.cpp:19-42) on gfx950: dense optical flow (u, v), the
+// per-pixel "variance" channel compare(prev, flowRemap(flow, next)) and the CV_32FC4 packing.
+//
+// The reference calls OpenCV: cv::FarnebackOpticalFlow::create(10, 0.8, false, (H+W)/100, 7, 5|7, (H+W)/1000, 0)
+// (flow.cpp:24-26) or cv::optflow::createVariationalFlowRefinement() (flow.cpp:29, the default path).  OpenCV is
+// neither in the reference tree nor in this image, so both algorithms are restated from their publications in
+// OpenCV's organisation; the operation order is the one documented in oracle/flow_oracle.c, which these kernels
+// reproduce bit for bit (f32 ops one rounding each under -ffp-contract=off, f64 where OpenCV accumulates in double).
+//
+// Farneback, per pyramid level (coarse to fine): gauss_row/gauss_col -> resize_linear -> polyexp_vert/polyexp_horiz
+// for both frames, then update_matrices and `iterations` x [box_vert, box_horiz_solve, update_matrices].
+// Everything stays in one HBM arena per context; the reference's per-level Mat allocations and the CPU
+// round trip of every intermediate disappear.
+//
+// Variational refinement: warp_q5 -> avg_diff -> central differences -> 5 x [data_term, diffusivity,
+// smooth_gather, 5 x (sor red, sor black)] -> add increment.
+#include "mvs_internal.hpp"
+
+#include <cmath>
+
+namespace mvs {
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int refl101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) {
+        if (p < 0) p = -p;
+        if (p >= n) p = 2 * n - 2 - p;
+    }
+    return p;
+}
+
+struct Taps {
+    float k[64];
+};
+
+#define PIX2D                                             \
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);   \
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);    \
+    if (x >= w || y >= h) return;
+
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t *__restrict__ s, float *__restrict__ d, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = (float)s[i];
+}
+
+// symmetric separable filter, REFLECT_101: acc = k[c]*S[0]; acc += k[c+j]*(S[+j] + S[-j])
+template <bool COLS>
+__global__ __launch_bounds__(256) void gauss_kernel(const float *__restrict__ src, int w, int h, Taps t, int ksize,
+                                                    float *__restrict__ dst)
+{
+    PIX2D
+    const int c = ksize / 2;
+    float acc = t.k[c] * src[(size_t)y * w + x];
+    for (int j = 1; j <= c; j++) {
+        float a, b;
+        if (COLS) {
+            a = src[(size_t)refl101(y + j, h) * w + x];
+            b = src[(size_t)refl101(y - j, h) * w + x];
+        } else {
+            a = src[(size_t)y * w + refl101(x + j, w)];
+            b = src[(size_t)y * w + refl101(x - j, w)];
+        }
+        acc += t.k[c + j] * (a + b);
+    }
+    dst[(size_t)y * w + x] = acc;
+}
+
+__device__ __forceinline__ void linear_coeff(int d, int dsize, int ssize, int &ofs, float &a0, float &a1)
+{
+    const double scale = 1. / ((double)dsize / ssize);
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= s;
+    if (s < 0) {
+        f = 0;
+        s = 0;
+    }
+    if (s >= ssize - 1) {
+        f = 0;
+        s = ssize - 1;
+    }
+    ofs = s;
+    a0 = 1.f - f;
+    a1 = f;
+}
+
+// cv::resize INTER_LINEAR (f32, CN interleaved channels), optionally followed by `*= mul` (flow *= 1/pyrScale)
+template <int CN>
+__global__ __launch_bounds__(256) void resize_linear_kernel(const float *__restrict__ src, int sw, int sh,
+                                                            float *__restrict__ dst, int w, int h, float mul, int domul)
+{
+    PIX2D
+    int sx, sy;
+    float a0, a1, b0, b1;
+    linear_coeff(x, w, sw, sx, a0, a1);
+    linear_coeff(y, h, sh, sy, b0, b1);
+    const int sx1 = sx + 1 < sw ? sx + 1 : sx, sy1 = sy + 1 < sh ? sy + 1 : sy;
+#pragma unroll
+    for (int c = 0; c < CN; c++) {
+        const float r0 = src[((size_t)sy * sw + sx) * CN + c] * a0 + src[((size_t)sy * sw + sx1) * CN + c] * a1;
+        const float r1 = src[((size_t)sy1 * sw + sx) * CN + c] * a0 + src[((size_t)sy1 * sw + sx1) * CN + c] * a1;
+        float v = r0 * b0 + r1 * b1;
+        if (domul) v *= mul;
+        dst[((size_t)y * w + x) * CN + c] = v;
+    }
+}
+
+struct PolyTaps {
+    float g[16], xg[16], xxg[16];  // index k = 0..n (symmetric / antisymmetric halves)
+    double ig11, ig03, ig33, ig55;
+    int n;
+};
+
+// FarnebackPolyExp, vertical pass: row[x] = (sum g I, sum y g I, sum y^2 g I) over the column, replicate border
+__global__ __launch_bounds__(256) void polyexp_vert(const float *__restrict__ src, int w, int h, PolyTaps t,
+                                                    float *__restrict__ row3)
+{
+    PIX2D
+    float t0 = src[(size_t)y * w + x] * t.g[0], t1 = 0.f, t2 = 0.f;
+    for (int k = 1; k <= t.n; k++) {
+        const float a = src[(size_t)(y - k > 0 ? y - k : 0) * w + x];
+        const float b = src[(size_t)(y + k < h - 1 ? y + k : h - 1) * w + x];
+        const float p = a + b;
+        t0 = t0 + t.g[k] * p;
+        t1 = t1 + t.xg[k] * (b - a);
+        t2 = t2 + t.xxg[k] * p;
+    }
+    float *r = row3 + ((size_t)y * w + x) * 3;
+    r[0] = t0;
+    r[1] = t1;
+    r[2] = t2;
+}
+
+// horizontal pass + projection onto the polynomial basis: 5 coefficients per pixel (y, x, y^2, x^2, xy)
+__global__ __launch_bounds__(256) void polyexp_horiz(const float *__restrict__ row3, int w, int h, PolyTaps t,
+                                                     float *__restrict__ dst5)
+{
+    PIX2D
+    const float *base = row3 + (size_t)y * w * 3;
+    const float *c = base + (size_t)x * 3;
+    float g0 = t.g[0];
+    double b1 = c[0] * g0, b2 = 0, b3 = c[1] * g0, b4 = 0, b5 = c[2] * g0, b6 = 0;
+    for (int k = 1; k <= t.n; k++) {
+        const float *p = base + (size_t)clampi(x + k, 0, w - 1) * 3;
+        const float *m = base + (size_t)clampi(x - k, 0, w - 1) * 3;
+        const double tg = p[0] + m[0];
+        g0 = t.g[k];
+        b1 += tg * g0;
+        b4 += tg * t.xxg[k];
+        b2 += (p[0] - m[0]) * t.xg[k];
+        b3 += (p[1] + m[1]) * g0;
+        b6 += (p[1] - m[1]) * t.xg[k];
+        b5 += (p[2] + m[2]) * g0;
+    }
+    float *d = dst5 + ((size_t)y * w + x) * 5;
+    d[1] = (float)(b2 * t.ig11);
+    d[0] = (float)(b3 * t.ig11);
+    d[3] = (float)(b1 * t.ig03 + b4 * t.ig33);
+    d[2] = (float)(b1 * t.ig03 + b5 * t.ig33);
+    d[4] = (float)(b6 * t.ig55);
+}
+
+__global__ __launch_bounds__(256) void update_matrices_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                              const float *__restrict__ flow, int w, int h,
+                                                              float *__restrict__ M)
+{
+    PIX2D
+    const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+    const size_t step1 = (size_t)w * 5;
+    const float *r0 = R0 + ((size_t)y * w + x) * 5;
+    const float dx = flow[((size_t)y * w + x) * 2], dy = flow[((size_t)y * w + x) * 2 + 1];
+    float fx = x + dx, fy = y + dy;
+    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    float r2, r3, r4, r5, r6;
+    fx -= x1;
+    fy -= y1;
+    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
+        const float *p = R1 + (size_t)y1 * step1 + (size_t)x1 * 5;
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        r2 = a00 * p[0] + a01 * p[5] + a10 * p[step1] + a11 * p[step1 + 5];
+        r3 = a00 * p[1] + a01 * p[6] + a10 * p[step1 + 1] + a11 * p[step1 + 6];
+        r4 = a00 * p[2] + a01 * p[7] + a10 * p[step1 + 2] + a11 * p[step1 + 7];
+        r5 = a00 * p[3] + a01 * p[8] + a10 * p[step1 + 3] + a11 * p[step1 + 8];
+        r6 = a00 * p[4] + a01 * p[9] + a10 * p[step1 + 4] + a11 * p[step1 + 9];
+        r4 = (r0[2] + r4) * 0.5f;
+        r5 = (r0[3] + r5) * 0.5f;
+        r6 = (r0[4] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = r0[2];
+        r5 = r0[3];
+        r6 = r0[4] * 0.5f;
+    }
+    r2 = (r0[0] - r2) * 0.5f;
+    r3 = (r0[1] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    if ((unsigned)(x - 5) >= (unsigned)(w - 10) || (unsigned)(y - 5) >= (unsigned)(h - 10)) {
+        const float scale = (x < 5 ? border[x] : 1.f) * (x >= w - 5 ? border[w - x - 1] : 1.f) *
+                            (y < 5 ? border[y] : 1.f) * (y >= h - 5 ? border[h - y - 1] : 1.f);
+        r2 *= scale;
+        r3 *= scale;
+        r4 *= scale;
+        r5 *= scale;
+        r6 *= scale;
+    }
+    float *m = M + ((size_t)y * w + x) * 5;
+    m[0] = r4 * r4 + r6 * r6;
+    m[1] = (r4 + r5) * r6;
+    m[2] = r5 * r5 + r6 * r6;
+    m[3] = r4 * r2 + r6 * r3;
+    m[4] = r6 * r2 + r5 * r3;
+}
+
+__global__ __launch_bounds__(256) void box_vert_kernel(const float *__restrict__ M, int w, int h, int m,
+                                                       double *__restrict__ vs)
+{
+    PIX2D
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int d = -m; d <= m; d++) {
+        const float *p = M + ((size_t)clampi(y + d, 0, h - 1) * w + x) * 5;
+#pragma unroll
+        for (int c = 0; c < 5; c++) s[c] += p[c];
+    }
+    double *o = vs + ((size_t)y * w + x) * 5;
+#pragma unroll
+    for (int c = 0; c < 5; c++) o[c] = s[c];
+}
+
+__global__ __launch_bounds__(256) void box_horiz_solve_kernel(const double *__restrict__ vs, int w, int h, int m,
+                                                              double scale, float *__restrict__ flow)
+{
+    PIX2D
+    double t[5] = {0, 0, 0, 0, 0};
+    for (int d = -m; d <= m; d++) {
+        const double *p = vs + ((size_t)y * w + clampi(x + d, 0, w - 1)) * 5;
+#pragma unroll
+        for (int c = 0; c < 5; c++) t[c] += p[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) t[c] = t[c] * scale;
+    const double idet = 1. / (t[0] * t[2] - t[1] * t[1] + 1e-3);
+    flow[((size_t)y * w + x) * 2] = (float)((t[0] * t[4] - t[1] * t[3]) * idet);
+    flow[((size_t)y * w + x) * 2 + 1] = (float)((t[2] * t[3] - t[1] * t[4]) * idet);
+}
+
+// ---- variational refinement -------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void split_flow_kernel(const float *__restrict__ flow, float *__restrict__ u,
+                                                         float *__restrict__ v, float *__restrict__ du,
+                                                         float *__restrict__ dv, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u[i] = flow[2 * i];
+    v[i] = flow[2 * i + 1];
+    du[i] = 0.f;
+    dv[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void warp_q5_kernel(const float *__restrict__ img, int w, int h,
+                                                      const float *__restrict__ u, const float *__restrict__ v,
+                                                      const float *__restrict__ I0, float *__restrict__ A,
+                                                      float *__restrict__ Iz)
+{
+    PIX2D
+    const size_t p = (size_t)y * w + x;
+    const float mx = (float)x + u[p], my = (float)y + v[p];
+    const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
+    const int sx = qx >> 5, sy = qy >> 5;
+    const float fx = (float)(qx & 31) * (1.0f / 32), fy = (float)(qy & 31) * (1.0f / 32);
+    const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+    const int x0 = clampi(sx, 0, w - 1), x1 = clampi(sx + 1, 0, w - 1), y0 = clampi(sy, 0, h - 1), y1 = clampi(sy + 1, 0, h - 1);
+    const float warped = img[(size_t)y0 * w + x0] * w0 + img[(size_t)y0 * w + x1] * w1 + img[(size_t)y1 * w + x0] * w2 +
+                         img[(size_t)y1 * w + x1] * w3;
+    A[p] = (I0[p] + warped) * 0.5f;
+    Iz[p] = warped - I0[p];
+}
+
+template <bool DY>
+__global__ __launch_bounds__(256) void diff_kernel(const float *__restrict__ a, int w, int h, float *__restrict__ o)
+{
+    PIX2D
+    if (DY)
+        o[(size_t)y * w + x] = a[(size_t)clampi(y + 1, 0, h - 1) * w + x] - a[(size_t)clampi(y - 1, 0, h - 1) * w + x];
+    else
+        o[(size_t)y * w + x] = a[(size_t)y * w + clampi(x + 1, 0, w - 1)] - a[(size_t)y * w + clampi(x - 1, 0, w - 1)];
+}
+
+struct VarBufs {
+    float *Wu, *Wv, *du, *dv, *Iz, *Ix, *Iy, *Ixx, *Ixy, *Iyy, *Ixz, *Iyz, *a11, *a12, *a22, *b1, *b2, *wgt;
+};
+
+__global__ __launch_bounds__(256) void var_data_term(VarBufs B, int w, int h)
+{
+    PIX2D
+    const size_t p = (size_t)y * w + x;
+    const float zeta2 = 0.1f * 0.1f, eps2 = 0.001f * 0.001f, gamma2 = 10.f / 2, delta2 = 5.f / 2;
+    const float Ix = B.Ix[p], Iy = B.Iy[p], Iz = B.Iz[p], Ixx = B.Ixx[p], Ixy = B.Ixy[p], Iyy = B.Iyy[p], Ixz = B.Ixz[p],
+                Iyz = B.Iyz[p], du = B.du[p], dv = B.dv[p];
+    float derivNorm = Ix * Ix + Iy * Iy + zeta2;
+    const float Ik1z = Iz + Ix * du + Iy * dv;
+    float weight = (delta2 / sqrtf(Ik1z * Ik1z / derivNorm + eps2)) / derivNorm;
+    float A11 = weight * (Ix * Ix) + zeta2;
+    float A12 = weight * (Ix * Iy);
+    float A22 = weight * (Iy * Iy) + zeta2;
+    float B1 = -weight * (Iz * Ix);
+    float B2 = -weight * (Iz * Iy);
+    derivNorm = Ixx * Ixx + Ixy * Ixy + zeta2;
+    const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + zeta2;
+    const float Ik1zx = Ixz + Ixx * du + Ixy * dv;
+    const float Ik1zy = Iyz + Ixy * du + Iyy * dv;
+    weight = gamma2 / sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + eps2);
+    A11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
+    A12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
+    A22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
+    B1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
+    B2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
+    B.a11[p] = A11;
+    B.a12[p] = A12;
+    B.a22[p] = A22;
+    B.b1[p] = B1;
+    B.b2[p] = B2;
+}
+
+__global__ __launch_bounds__(256) void var_diffusivity(VarBufs B, int w, int h)
+{
+    PIX2D
+    const size_t p = (size_t)y * w + x;
+    const float eps2 = 0.001f * 0.001f, alpha2 = 20.f / 2;
+    const float cu = B.Wu[p] + B.du[p], cv = B.Wv[p] + B.dv[p];
+    const float ux = x + 1 < w ? (B.Wu[p + 1] + B.du[p + 1]) - cu : 0.f, vx = x + 1 < w ? (B.Wv[p + 1] + B.dv[p + 1]) - cv : 0.f;
+    const float uy = y + 1 < h ? (B.Wu[p + w] + B.du[p + w]) - cu : 0.f, vy = y + 1 < h ? (B.Wv[p + w] + B.dv[p + w]) - cv : 0.f;
+    B.wgt[p] = alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + eps2);
+}
+
+__global__ __launch_bounds__(256) void var_smooth_gather(VarBufs B, int w, int h)
+{
+    PIX2D
+    const size_t p = (size_t)y * w + x;
+    float A11 = B.a11[p], A22 = B.a22[p], B1 = B.b1[p], B2 = B.b2[p];
+    if (x > 0) {
+        const float wt = B.wgt[p - 1];
+        B1 -= wt * (B.Wu[p] - B.Wu[p - 1]);
+        B2 -= wt * (B.Wv[p] - B.Wv[p - 1]);
+        A11 += wt;
+        A22 += wt;
+    }
+    if (x + 1 < w) {
+        const float wt = B.wgt[p];
+        B1 += wt * (B.Wu[p + 1] - B.Wu[p]);
+        B2 += wt * (B.Wv[p + 1] - B.Wv[p]);
+        A11 += wt;
+        A22 += wt;
+    }
+    if (y > 0) {
+        const float wt = B.wgt[p - w];
+        B1 -= wt * (B.Wu[p] - B.Wu[p - w]);
+        B2 -= wt * (B.Wv[p] - B.Wv[p - w]);
+        A11 += wt;
+        A22 += wt;
+    }
+    if (y + 1 < h) {
+        const float wt = B.wgt[p];
+        B1 += wt * (B.Wu[p + w] - B.Wu[p]);
+        B2 += wt * (B.Wv[p + w] - B.Wv[p]);
+        A11 += wt;
+        A22 += wt;
+    }
+    B.a11[p] = A11;
+    B.a22[p] = A22;
+    B.b1[p] = B1;
+    B.b2[p] = B2;
+}
+
+// one colour of a red-black SOR sweep: thread per pixel of that colour
+__global__ __launch_bounds__(256) void var_sor_pass(VarBufs B, int w, int h, int colour)
+{
+    const int xi = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = 2 * xi + ((y + colour) & 1);
+    if (x >= w || y >= h) return;
+    const size_t p = (size_t)y * w + x;
+    const float omega = 1.6f;
+    float sU = 0.f, sV = 0.f;
+    if (x > 0) {
+        sU += B.wgt[p - 1] * B.du[p - 1];
+        sV += B.wgt[p - 1] * B.dv[p - 1];
+    }
+    if (x + 1 < w) {
+        sU += B.wgt[p] * B.du[p + 1];
+        sV += B.wgt[p] * B.dv[p + 1];
+    }
+    if (y > 0) {
+        sU += B.wgt[p - w] * B.du[p - w];
+        sV += B.wgt[p - w] * B.dv[p - w];
+    }
+    if (y + 1 < h) {
+        sU += B.wgt[p] * B.du[p + w];
+        sV += B.wgt[p] * B.dv[p + w];
+    }
+    float du = B.du[p], dv = B.dv[p];
+    du += omega * ((sU + B.b1[p] - dv * B.a12[p]) / B.a11[p] - du);
+    dv += omega * ((sV + B.b2[p] - du * B.a12[p]) / B.a22[p] - dv);
+    B.du[p] = du;
+    B.dv[p] = dv;
+}
+
+__global__ __launch_bounds__(256) void var_finish(VarBufs B, float *__restrict__ flow, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flow[2 * i] = B.Wu[i] + B.du[i];
+    flow[2 * i + 1] = B.Wv[i] + B.dv[i];
+}
+
+__global__ __launch_bounds__(256) void pack_flow4(const float *__restrict__ flow2, const float *__restrict__ var,
+                                                  float *__restrict__ out4, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out4[4 * i] = flow2[2 * i];
+    out4[4 * i + 1] = flow2[2 * i + 1];
+    out4[4 * i + 2] = var[i];
+    out4[4 * i + 3] = 0.f;  // mixChannels {-1, 3}, flow.cpp:39
+}
+
+// ---- host orchestration ------------------------------------------------------------------------------------------
+
+static void gaussian_taps(int n, double sigma, float *k)  // cv::getGaussianKernel(n, sigma, CV_32F)
+{
+    if (sigma <= 0 && n == 3) {
+        k[0] = 0.25f; k[1] = 0.5f; k[2] = 0.25f;
+        return;
+    }
+    if (sigma <= 0 && n == 5) {
+        const float t[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+        memcpy(k, t, sizeof(t));
+        return;
+    }
+    if (sigma <= 0 && n == 7) {
+        const float t[7] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+        memcpy(k, t, sizeof(t));
+        return;
+    }
+    const double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2X = -0.5 / (sigmaX * sigmaX);
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        const double x = i - (n - 1) * 0.5;
+        k[i] = (float)std::exp(scale2X * x * x);
+        sum += k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) k[i] = (float)(k[i] * sum);
+}
+
+static void farneback_taps(int n, double sigma, PolyTaps &t)  // FarnebackPrepareGaussian
+{
+    std::vector<float> g(2 * n + 1), xg(2 * n + 1), xxg(2 * n + 1);
+    if (sigma < 1.1920929e-07) sigma = n * 0.3;
+    double s = 0.;
+    for (int x = -n; x <= n; x++) {
+        g[x + n] = (float)std::exp(-x * x / (2 * sigma * sigma));
+        s += g[x + n];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) {
+        g[x + n] = (float)(g[x + n] * s);
+        xg[x + n] = (float)(x * g[x + n]);
+        xxg[x + n] = (float)(x * x * g[x + n]);
+    }
+    double G[6][6] = {};
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            G[0][0] += g[y + n] * g[x + n];
+            G[1][1] += g[y + n] * g[x + n] * x * x;
+            G[3][3] += g[y + n] * g[x + n] * x * x * x * x;
+            G[5][5] += g[y + n] * g[x + n] * x * x * y * y;
+        }
+    G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+    G[4][4] = G[3][3];
+    G[3][4] = G[4][3] = G[5][5];
+    double A[6][12];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            A[i][j] = G[i][j];
+            A[i][j + 6] = i == j;
+        }
+    for (int c = 0; c < 6; c++) {  // Gauss-Jordan, partial pivoting (same elimination order as the oracle)
+        int p = c;
+        for (int r = c + 1; r < 6; r++)
+            if (std::fabs(A[r][c]) > std::fabs(A[p][c])) p = r;
+        if (p != c)
+            for (int j = 0; j < 12; j++) std::swap(A[c][j], A[p][j]);
+        const double d = 1. / A[c][c];
+        for (int j = 0; j < 12; j++) A[c][j] *= d;
+        for (int r = 0; r < 6; r++)
+            if (r != c) {
+                const double f = A[r][c];
+                if (f != 0)
+                    for (int j = 0; j < 12; j++) A[r][j] -= f * A[c][j];
+            }
+    }
+    t.n = n;
+    t.ig11 = A[1][7];
+    t.ig03 = A[0][9];
+    t.ig33 = A[3][9];
+    t.ig55 = A[5][11];
+    for (int k = 0; k <= n; k++) {
+        t.g[k] = g[n + k];
+        t.xg[k] = xg[n + k];
+        t.xxg[k] = xxg[n + k];
+    }
+}
+
+static dim3 g2(int w, int h) { return dim3(div_up(w, 64), div_up(h, 4)); }
+static unsigned g1(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// cv::FarnebackOpticalFlow::calc, flags 0.  f0/f1: f32 frames (W*H); flow_out: W*H*2.  arena: >= 30*P floats.
+static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, float *flow_out, float *arena, int levels,
+                            double pyr_scale, int winsize, int iterations, int poly_n, double poly_sigma)
+{
+    const int W = ctx->W, H = ctx->H;
+    const size_t P = (size_t)W * H;
+    if (poly_n > 15) return fail(ctx, MVS_EINVAL, "farneback: poly_n %d too large", poly_n);
+    int lw[64], lh[64];
+    double ls[64];
+    {
+        int k;
+        double scale = 1;
+        for (k = 0; k < levels; k++) {
+            scale *= pyr_scale;
+            if (W * scale < 32 || H * scale < 32) break;
+        }
+        levels = k;
+        for (k = 0; k <= levels; k++) {
+            scale = 1;
+            for (int i = 0; i < k; i++) scale *= pyr_scale;
+            ls[k] = scale;
+            lw[k] = (int)std::lrint(W * scale);
+            lh[k] = (int)std::lrint(H * scale);
+        }
+    }
+    double *vs = (double *)arena;  // 5*P doubles first: keeps them 8-byte aligned for any P
+    float *tmp = arena + 10 * P, *blur = tmp + P, *I = blur + P, *row3 = I + P, *R0 = row3 + 3 * P, *R1 = R0 + 5 * P,
+          *M = R1 + 5 * P, *flowA = M + 5 * P, *flowB = flowA + 2 * P;  // 35*P floats in total
+    PolyTaps pt;
+    farneback_taps(poly_n, poly_sigma, pt);
+    hipStream_t st = ctx->stream;
+    float *flow = nullptr, *prevflow = nullptr;
+    int pw = 0, ph = 0;
+    for (int k = levels; k >= 0; k--) {
+        const double sigma = (1. / ls[k] - 1) * 0.5;
+        int smooth_sz = (int)std::lrint(sigma * 5) | 1;
+        if (smooth_sz < 3) smooth_sz = 3;
+        if (smooth_sz > 63) return fail(ctx, MVS_EINVAL, "farneback: smoothing kernel %d too large", smooth_sz);
+        const int w = lw[k], h = lh[k];
+        flow = k == 0 ? flow_out : (prevflow == flowA ? flowB : flowA);
+        if (!prevflow) {
+            MVS_HIP(ctx, hipMemsetAsync(flow, 0, sizeof(float) * (size_t)w * h * 2, st));
+        } else {
+            resize_linear_kernel<2><<<g2(w, h), 256, 0, st>>>(prevflow, pw, ph, flow, w, h, (float)(1. / pyr_scale), 1);
+        }
+        Taps taps;
+        gaussian_taps(smooth_sz, sigma, taps.k);
+        for (int i = 0; i < 2; i++) {
+            gauss_kernel<false><<<g2(W, H), 256, 0, st>>>(i == 0 ? f0 : f1, W, H, taps, smooth_sz, tmp);
+            gauss_kernel<true><<<g2(W, H), 256, 0, st>>>(tmp, W, H, taps, smooth_sz, blur);
+            resize_linear_kernel<1><<<g2(w, h), 256, 0, st>>>(blur, W, H, I, w, h, 1.f, 0);
+            polyexp_vert<<<g2(w, h), 256, 0, st>>>(I, w, h, pt, row3);
+            polyexp_horiz<<<g2(w, h), 256, 0, st>>>(row3, w, h, pt, i == 0 ? R0 : R1);
+        }
+        update_matrices_kernel<<<g2(w, h), 256, 0, st>>>(R0, R1, flow, w, h, M);
+        const int m = winsize / 2;
+        const double bscale = 1. / ((double)winsize * winsize);
+        for (int it = 0; it < iterations; it++) {
+            box_vert_kernel<<<g2(w, h), 256, 0, st>>>(M, w, h, m, vs);
+            box_horiz_solve_kernel<<<g2(w, h), 256, 0, st>>>(vs, w, h, m, bscale, flow);
+            if (it < iterations - 1) update_matrices_kernel<<<g2(w, h), 256, 0, st>>>(R0, R1, flow, w, h, M);
+        }
+        MVS_HIP(ctx, hipGetLastError());
+        prevflow = flow;
+        pw = w;
+        ph = h;
+    }
+    return MVS_OK;
+}
+
+// VariationalRefinement::calc with OpenCV's defaults; flow (W*H*2) is refined in place.  arena: >= 22*P floats.
+static int variational_device(mvs_ctx *ctx, const float *I0, const float *I1, float *flow, float *arena)
+{
+    const int w = ctx->W, h = ctx->H;
+    const size_t P = (size_t)w * h;
+    hipStream_t st = ctx->stream;
+    VarBufs B;
+    float *A;
+    float **slots[] = {&B.Wu, &B.Wv, &B.du, &B.dv, &A, &B.Iz, &B.Ix, &B.Iy, &B.Ixx, &B.Ixy, &B.Iyy, &B.Ixz, &B.Iyz,
+                       &B.a11, &B.a12, &B.a22, &B.b1, &B.b2, &B.wgt};
+    for (size_t i = 0; i < sizeof(slots) / sizeof(slots[0]); i++) *slots[i] = arena + i * P;
+    split_flow_kernel<<<g1(P), 256, 0, st>>>(flow, B.Wu, B.Wv, B.du, B.dv, P);
+    warp_q5_kernel<<<g2(w, h), 256, 0, st>>>(I1, w, h, B.Wu, B.Wv, I0, A, B.Iz);
+    diff_kernel<false><<<g2(w, h), 256, 0, st>>>(A, w, h, B.Ix);
+    diff_kernel<true><<<g2(w, h), 256, 0, st>>>(A, w, h, B.Iy);
+    diff_kernel<false><<<g2(w, h), 256, 0, st>>>(B.Iz, w, h, B.Ixz);
+    diff_kernel<true><<<g2(w, h), 256, 0, st>>>(B.Iz, w, h, B.Iyz);
+    diff_kernel<false><<<g2(w, h), 256, 0, st>>>(B.Ix, w, h, B.Ixx);
+    diff_kernel<true><<<g2(w, h), 256, 0, st>>>(B.Ix, w, h, B.Ixy);
+    diff_kernel<true><<<g2(w, h), 256, 0, st>>>(B.Iy, w, h, B.Iyy);
+    const dim3 half(div_up((w + 1) / 2, 64), div_up(h, 4));
+    for (int fp = 0; fp < 5; fp++) {
+        var_data_term<<<g2(w, h), 256, 0, st>>>(B, w, h);
+        var_diffusivity<<<g2(w, h), 256, 0, st>>>(B, w, h);
+        var_smooth_gather<<<g2(w, h), 256, 0, st>>>(B, w, h);
+        for (int it = 0; it < 5; it++) {
+            var_sor_pass<<<half, 256, 0, st>>>(B, w, h, 0);
+            var_sor_pass<<<half, 256, 0, st>>>(B, w, h, 1);
+        }
+    }
+    var_finish<<<g1(P), 256, 0, st>>>(B, flow, P);
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" {
+
+int mvs_flow(mvs_ctx *ctx, const uint8_t *prev_hw, const uint8_t *next_hw, int use_farneback, float *out_hw4)
+{
+    if (!ctx || !prev_hw || !next_hw || !out_hw4) return fail(ctx, MVS_EINVAL, "mvs_flow: null argument");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->W, H = ctx->H;
+    const size_t P = (size_t)W * H;
+    int rc;
+    // arena: work (36P floats, starts with 5P doubles) first, then f0, f1, flow2, var, out4; u8: prev, next, remapped
+    const size_t work = 36;
+    if ((rc = ensure(ctx, ctx->flow_arena, sizeof(float) * P * (2 + 2 + 1 + 4 + work) + 3 * P + 256))) return rc;
+    float *arena = (float *)ctx->flow_arena.ptr, *f0 = arena + work * P, *f1 = f0 + P, *flow2 = f1 + P, *var = flow2 + 2 * P,
+          *out4 = var + P;
+    uint8_t *p8 = (uint8_t *)(out4 + 4 * P), *n8 = p8 + P, *r8 = n8 + P;
+    hipStream_t st = ctx->stream;
+    MVS_HIP(ctx, hipMemcpyAsync(p8, prev_hw, P, hipMemcpyHostToDevice, st));
+    MVS_HIP(ctx, hipMemcpyAsync(n8, next_hw, P, hipMemcpyHostToDevice, st));
+    {
+    ProfileScope ps(ctx, MVS_K_FLOW);
+    u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(p8, f0, P);
+    u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(n8, f1, P);
+    if (use_farneback) {
+        const double poly_sigma = (H + W) / 1000.0;  // flow.cpp:24-25
+        const int winsize = (H + W) / 100, poly_n = poly_sigma < 1.5 ? 5 : 7;
+        if ((rc = farneback_device(ctx, f0, f1, flow2, arena, 10, 0.8, winsize, 7, poly_n, poly_sigma))) return rc;
+    } else {
+        MVS_HIP(ctx, hipMemsetAsync(flow2, 0, sizeof(float) * 2 * P, st));  // flow.cpp:31 (uninitialised there), A-11
+        if ((rc = variational_device(ctx, f0, f1, flow2, arena))) return rc;
+    }
+    if ((rc = remap_device(ctx, flow2, 2, n8, r8))) return rc;  // flow.cpp:34
+    if ((rc = compare_device(ctx, p8, r8, var))) return rc;
+    pack_flow4<<<g1(P), 256, 0, st>>>(flow2, var, out4, P);
+    MVS_HIP(ctx, hipGetLastError());
+    }
+    MVS_HIP(ctx, hipMemcpyAsync(out_hw4, out4, sizeof(float) * 4 * P, hipMemcpyDeviceToHost, st));
+    MVS_HIP(ctx, hipStreamSynchronize(st));
+    return MVS_OK;
+}
+
+}  // extern "C"

@@ -99,6 +99,19 @@ void orc_flow_remap(const float *flow, int stride, const uint8_t *image, int W, 
 /* the Q15 4x4 bicubic weight table (32*32 sub-pixel positions x 16 taps) remap uses; out nullable */
 void orc_remap_cubic_table(short *out);
 
+/* ---- optical flow (flow.cpp:19-42) ---------------------------------------------------------------- */
+
+void orc_gaussian_kernel(int n, double sigma, float *k);
+void orc_farneback_gaussian(int n, double sigma, float *g, float *xg, float *xxg, double ig[4]);
+int orc_farneback_levels(int W, int H, int levels, double pyr_scale, int *lw, int *lh, double *lscale);
+/* cv::FarnebackOpticalFlow::calc with flags 0 (box window, zero initial flow); flow_out = H*W*2 */
+void orc_farneback(const uint8_t *prev, const uint8_t *next, int W, int H, int levels, double pyr_scale, int winsize,
+                   int iterations, int poly_n, double poly_sigma, float *flow_out);
+/* cv::optflow VariationalRefinement::calc with default parameters; flow = H*W*2, refined in place */
+void orc_variational_refine(const uint8_t *I0, const uint8_t *I1, int W, int H, float *flow);
+/* calculateFlow: out4 = H*W*4 (u, v, variance, 0) */
+void orc_calculate_flow(const uint8_t *prev, const uint8_t *next, int W, int H, int use_farneback, float *out4);
+
 #ifdef __cplusplus
 }
 #endif

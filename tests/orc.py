@@ -175,6 +175,38 @@ class Oracle:
         return t
 
 
+    # ---- optical flow ---------------------------------------------------------------------------
+    def farneback(self, prev, nxt, levels=10, pyr_scale=0.8, winsize=None, iterations=7, poly_n=None, poly_sigma=None):
+        H, W = prev.shape
+        poly_sigma = (H + W) / 1000.0 if poly_sigma is None else poly_sigma
+        winsize = (H + W) // 100 if winsize is None else winsize
+        poly_n = (5 if poly_sigma < 1.5 else 7) if poly_n is None else poly_n
+        a, b = np.ascontiguousarray(prev, np.uint8), np.ascontiguousarray(nxt, np.uint8)
+        flow = np.empty((H, W, 2), np.float32)
+        f = self.lib.orc_farneback
+        f.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, _fp]
+        f(self._p(a, _u8p), self._p(b, _u8p), W, H, levels, pyr_scale, winsize, iterations, poly_n, poly_sigma, self._p(flow, _fp))
+        return flow
+
+    def variational_refine(self, prev, nxt, flow=None):
+        H, W = prev.shape
+        a, b = np.ascontiguousarray(prev, np.uint8), np.ascontiguousarray(nxt, np.uint8)
+        flow = np.zeros((H, W, 2), np.float32) if flow is None else np.ascontiguousarray(flow, np.float32).copy()
+        f = self.lib.orc_variational_refine
+        f.argtypes = [_u8p, _u8p, C.c_int, C.c_int, _fp]
+        f(self._p(a, _u8p), self._p(b, _u8p), W, H, self._p(flow, _fp))
+        return flow
+
+    def calculate_flow(self, prev, nxt, use_farneback):
+        H, W = prev.shape
+        a, b = np.ascontiguousarray(prev, np.uint8), np.ascontiguousarray(nxt, np.uint8)
+        out = np.empty((H, W, 4), np.float32)
+        f = self.lib.orc_calculate_flow
+        f.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, _fp]
+        f(self._p(a, _u8p), self._p(b, _u8p), W, H, 1 if use_farneback else 0, self._p(out, _fp))
+        return out
+
+
 _oracle = None
 
 
