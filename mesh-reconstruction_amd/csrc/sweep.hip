@@ -11,8 +11,8 @@
 //   r      = RN(1 / s.w)             v_rcp_f32 + one FMA Newton step
 //   c      = s.xy * r                padded-pixel coordinates, in frame iff 0.5 < c < size + 0.5
 //   i, a   = trunc(c), c - i         exact (c > 0)
-//   res    = fma(ay, fma(ax, dxy, dy), fma(ax, dxt, t00))
-//   Iq     = (int)(res + 0.5)        the u8 the RGB8 framebuffer would hold (render_glx.cpp:359)
+//   res    = fma(ay, fma(ax, dxy, dy), fma(ax, dxt, t00 + 0.5))   (t00 + 0.5 is exact)
+//   Iq     = (int)res                the u8 the RGB8 framebuffer would hold (render_glx.cpp:359)
 //   cell  += (1 << 16) + |Iq - Im|   integer: exact, order independent, all-reducible
 // Build with -ffp-contract=off: every f32 op above is exactly one rounding.
 //
@@ -82,12 +82,13 @@ __device__ __forceinline__ Affine view_affine(const float *__restrict__ q, float
     return a;
 }
 
-__device__ __forceinline__ int bilerp_u8(float ax, float ay, float t00, float dxt, float dy, float dxy)
+// t00h = t00 + 0.5 (exact): the rounding bias of the u8 conversion rides on the first term
+__device__ __forceinline__ int bilerp_u8(float ax, float ay, float t00h, float dxt, float dy, float dxy)
 {
-    const float a = __builtin_fmaf(ax, dxt, t00);
+    const float a = __builtin_fmaf(ax, dxt, t00h);
     const float b = __builtin_fmaf(ax, dxy, dy);
     const float res = __builtin_fmaf(ay, b, a);
-    return (int)(res + 0.5f);
+    return (int)res;
 }
 
 // one sample with every check, taps gathered from the padded image in global memory
@@ -107,7 +108,7 @@ __device__ __forceinline__ uint32_t sample_global(const Affine &A, float bx, flo
     const uint8_t *p = pad + (size_t)iy * pitch + ix;
     const float t00 = (float)p[0], t01 = (float)p[1], t10 = (float)p[pitch], t11 = (float)p[pitch + 1];
     const float dxt = t01 - t00, dy = t10 - t00, dxy = (t11 - t10) - dxt;
-    const int Iq = bilerp_u8(fx, fy, t00, dxt, dy, dxy);
+    const int Iq = bilerp_u8(fx, fy, t00 + 0.5f, dxt, dy, dxy);
     return 65536u + (uint32_t)__builtin_abs(Iq - Im);
 }
 
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void plan_regions(SweepParams p, uint2 *__rest
 // tiled kernel
 // ------------------------------------------------------------------------------------------------------
 // LDS region format: one 8-byte quad per texel position (y, x) of the padded side image:
-//   { t00, t01 - t00, t10 - t00, (t11 - t10) - (t01 - t00) } as four f16 (all exact integers),
+//   { t00 + 0.5, t01 - t00, t10 - t00, (t11 - t10) - (t01 - t00) } as four f16 (all exactly representable),
 // so the bilinear fetch is one ds_read_b64 and three v_fma_mix_f32.
 __device__ __forceinline__ void stage_region(const uint8_t *__restrict__ pad, int pitch, int x0, int y0, int rw,
                                              int rh, int rp, uint2 *__restrict__ lds)
@@ -263,7 +264,7 @@ __device__ __forceinline__ void stage_region(const uint8_t *__restrict__ pad, in
                 const int t10 = (int)((ee >> (8 * k)) & 255u), t11 = (int)((ee >> (8 * k + 8)) & 255u);
                 const int dxt = t01 - t00, dy = t10 - t00, dxy = (t11 - t10) - dxt;
                 half4_t h;
-                h[0] = (_Float16)t00;
+                h[0] = (_Float16)t00 + (_Float16)0.5f;
                 h[1] = (_Float16)dxt;
                 h[2] = (_Float16)dy;
                 h[3] = (_Float16)dxy;
@@ -321,8 +322,46 @@ __device__ __forceinline__ uint32_t sample_lds(const Affine &A, float bx, float 
     return ok ? sad_u32((uint32_t)Iq, (uint32_t)Im, acc + 65536u) : acc;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Two planes of one (pixel, view) at once on the FAST path.  The cost model (tools/valu_microbench,
+// profiles/r01) prices a wave64 v_fma_f32 at 4 cycles and a v_pk_fma_f32 at 4.7 for two lanes, so the
+// projection s = fma(z, B, A), the Newton step of the reciprocal, c = s * r and the last bilinear FMA are
+// issued as packed pairs; the per-sample remainder (v_rcp, fract/cvt, address, ds_read_b64, 2 v_fma_mix,
+// cvt, v_sad_u32) stays scalar.  Element-wise identical arithmetic to sample_lds<true>.
+__device__ __forceinline__ void sample_lds_pair(const Affine &A, float bx, float by, float bw, float z0, float z1,
+                                                const RegionView &rv, int negorg8, uint32_t Im, uint32_t &acc0,
+                                                uint32_t &acc1)
+{
+    const f32x2 z = {z0, z1};
+    const f32x2 sx = __builtin_elementwise_fma(z, (f32x2)(bx), (f32x2)(A.ax));
+    const f32x2 sy = __builtin_elementwise_fma(z, (f32x2)(by), (f32x2)(A.ay));
+    const f32x2 sw = __builtin_elementwise_fma(z, (f32x2)(bw), (f32x2)(A.aw));
+    const f32x2 r0 = {__builtin_amdgcn_rcpf(sw.x), __builtin_amdgcn_rcpf(sw.y)};
+    const f32x2 e = __builtin_elementwise_fma(-sw, r0, (f32x2)(1.0f));
+    const f32x2 r = __builtin_elementwise_fma(e, r0, r0);
+    const f32x2 cx = sx * r, cy = sy * r;
+    f32x2 fy, a, b;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float fx = __builtin_amdgcn_fractf(cx[i]);
+        fy[i] = __builtin_amdgcn_fractf(cy[i]);
+        const int ix = (int)cx[i], iy = (int)cy[i];
+        // byte offset of the quad: iy * pitch_bytes - origin + ix * 8, as v_mad_i32_i24 + v_lshl_add_u32
+        int row_off, off;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(row_off) : "v"(iy), "s"(rv.rp8), "v"(negorg8));
+        asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(off) : "v"(ix), "v"(row_off));
+        const half4_t h = *(const half4_t *)(rv.lds_bytes + off);
+        a[i] = __builtin_fmaf(fx, (float)h[1], (float)h[0]);
+        b[i] = __builtin_fmaf(fx, (float)h[3], (float)h[2]);
+    }
+    const f32x2 res = __builtin_elementwise_fma(fy, b, a);
+    acc0 = sad_u32((uint32_t)(int)res.x, Im, acc0);
+    acc1 = sad_u32((uint32_t)(int)res.y, Im, acc1);
+}
+
 template <bool WRITE_VOLUME, bool FUSED>
-__global__ __launch_bounds__(256) void sweep_tiled(SweepParams p)
+__global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
 {
     __shared__ __attribute__((aligned(16))) uint2 lds[LDS_QUADS];
 
@@ -406,13 +445,15 @@ __global__ __launch_bounds__(256) void sweep_tiled(SweepParams p)
             rv.yhi = y0 + rh - 1;
             if (mode == R_FAST) {
                 fast_views += 65536u;
+                int negorg8 = -rv.org8;
+                asm volatile("" : "+v"(negorg8));  // keep it in a VGPR so mul24 + add fuses into v_mad_i32_i24
 #pragma unroll
                 for (int j = 0; j < NPX; j++) {
                     if (ok[j]) {
                         const Affine A = view_affine(q, xn, yn[j]);
 #pragma unroll
-                        for (int k = 0; k < PC; k++)
-                            acc[j][k] = sample_lds<true>(A, bx, by, bw, zc[k], rv, p.Wp, p.Hp, Im[j], acc[j][k]);
+                        for (int k = 0; k < PC; k += 2)
+                            sample_lds_pair(A, bx, by, bw, zc[k], zc[k + 1], rv, negorg8, (uint32_t)Im[j], acc[j][k], acc[j][k + 1]);
                     }
                 }
             } else {

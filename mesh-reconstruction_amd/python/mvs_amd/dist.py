@@ -1,0 +1,37 @@
+"""Multi-GPU sharding of the sweep (one process per GPU, torch.distributed; backend nccl = RCCL on ROCm).
+
+Two shardings:
+  frames: rank r owns main frames r, r+world, ... -- the reference's independent `fa` loop (recon.cpp:65); no collective
+  views : the side views of ONE main frame are split across ranks; the packed u32 volume (count<<16 | sum) is summed
+          with all_reduce -- exact, because cells are integers -- and every rank selects depth on the full volume.
+The functions here are backend-agnostic so the CPU tests run them over gloo with the oracle standing in for the GPU.
+"""
+
+
+def view_shard(V, rank, world):
+    """contiguous view range [first, first+count) of `rank`; ranks beyond V get an empty range"""
+    per = (V + world - 1) // world
+    first = min(rank * per, V)
+    return first, max(0, min(per, V - first))
+
+
+def frame_shard(num_frames, rank, world):
+    """main-frame indices processed by `rank` (round robin, like `fa % world == rank`)"""
+    return list(range(rank, num_frames, world))
+
+
+def allreduce_volume(dist, volume_tensor):
+    """in-place SUM all-reduce of the packed volume (an int32/int64 torch tensor aliasing the u32 cells)"""
+    dist.all_reduce(volume_tensor, op=dist.ReduceOp.SUM)
+    return volume_tensor
+
+
+def gather_frames(dist, local_results, num_frames, rank, world):
+    """collect per-frame results (picklable) of the frame sharding on every rank, ordered by frame index"""
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local_results)
+    out = [None] * num_frames
+    for r, items in enumerate(gathered):
+        for idx, value in zip(frame_shard(num_frames, r, world), items):
+            out[idx] = value
+    return out

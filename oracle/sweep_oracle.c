@@ -7,7 +7,7 @@
  *   shader.frag:17,22   uv = s.xy / (2 s.w) - 0.5 with GL_REPEAT        -> padded coordinates, wrap padding
  *   shader.frag:19      strict in-frame test |s.x/s.w| < 1, |s.y/s.w| < 1 -> 0.5 < c < size + 0.5
  *   render_glx.cpp:65-88 GL_LINEAR magnification of a GL_RED u8 texture  -> bilinear, level 0 only
- *   render_glx.cpp:356-359 RGB8 read-back (warped intensity quantised to u8) -> Iq = (int)(res + 0.5)
+ *   render_glx.cpp:356-359 RGB8 read-back (warped intensity quantised to u8) -> Iq = trunc(bilinear + 0.5)
  *   render_glx.cpp:369-397 depth map contract: NDC z, empty = 1.0       -> depth = z[best] or 1.0
  * The D-plane sweep itself is the generalisation described in SURVEY.md section 0.2: the shader's warp
  * evaluated at pos_d = main^-1 * (x_ndc, y_ndc, z_d, 1) for D planes instead of at the mesh position.
@@ -133,10 +133,11 @@ static inline int sample_affine(const float A[3], const float B[3], float z, con
     const float dxt = t01 - t00;
     const float dy = t10 - t00;
     const float dxy = (t11 - t10) - dxt;
-    const float a = fmaf(ax, dxt, t00);
+    /* the +0.5 of the u8 rounding rides on the (exact) t00 term: Iq = trunc(bilinear + 0.5) */
+    const float a = fmaf(ax, dxt, t00 + 0.5f);
     const float b = fmaf(ax, dxy, dy);
     const float res = fmaf(ay, b, a);
-    *Iq = (int)(res + 0.5f);
+    *Iq = (int)res;
     return 1;
 }
 

@@ -1,0 +1,89 @@
+"""world_size-2 gloo tests of the multi-GPU shardings (CPU): the oracle stands in for each rank's GPU sweep, the
+collective and the bookkeeping are the product's (mvs_amd.dist)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, tmp):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import orc
+    from mvs_amd import dist as mdist
+    from mvs_amd import synth
+    o = orc.load()
+    W, H, D, V = 64, 40, 12, 5
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3, freq_scale=0.3)
+    if mode == "views":
+        v0, vn = mdist.view_shard(V, rank, world)
+        _, _, _, part = o.sweep(main_cam, main_img, side_cams[v0:v0 + vn], sides[v0:v0 + vn], D, want_volume=True)
+        t = torch.from_numpy(part.astype(np.int64))  # gloo has no uint32; RCCL path uses int32 on the same bits
+        mdist.allreduce_volume(dist, t)
+        vol = t.numpy().astype(np.uint32)
+        depth, cost, idx = o.argmin(vol, o.plane_table(D, -1.0, 1.0))
+        np.savez(os.path.join(tmp, "views_%d.npz" % rank), vol=vol, depth=depth, idx=idx)
+    else:
+        frames = 5
+        mine = mdist.frame_shard(frames, rank, world)
+        local = []
+        for f in mine:
+            mc, mi, sc, si, _ = synth.make_views(W, H, 2, radius=0.3, freq_scale=0.3, seed=synth.SEED_SCENE + f)
+            local.append(o.sweep(mc, mi, sc, si, D)[0])
+        allres = mdist.gather_frames(dist, local, frames, rank, world)
+        np.savez(os.path.join(tmp, "frames_%d.npz" % rank), depths=np.stack(allres))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["views", "frames"])
+def test_two_rank_sharding(oracle, tmp_path, mode):
+    from mvs_amd import synth
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    W, H, D, V = 64, 40, 12, 5
+    if mode == "views":
+        main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3, freq_scale=0.3)
+        d_ref, _, i_ref, v_ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True)
+        for r in range(world):
+            g = np.load(tmp_path / ("views_%d.npz" % r))
+            np.testing.assert_array_equal(g["vol"], v_ref)      # the all-reduced shards == single-process volume
+            np.testing.assert_array_equal(g["depth"], d_ref)
+            np.testing.assert_array_equal(g["idx"], i_ref)
+    else:
+        ref = []
+        for f in range(5):
+            mc, mi, sc, si, _ = synth.make_views(W, H, 2, radius=0.3, freq_scale=0.3, seed=synth.SEED_SCENE + f)
+            ref.append(oracle.sweep(mc, mi, sc, si, D)[0])
+        for r in range(world):
+            np.testing.assert_array_equal(np.load(tmp_path / ("frames_%d.npz" % r))["depths"], np.stack(ref))
+
+
+def test_shard_bookkeeping():
+    from mvs_amd import dist as mdist
+    for V in (0, 1, 5, 16, 17):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                a, n = mdist.view_shard(V, r, world)
+                cover += list(range(a, a + n))
+            assert cover == list(range(V))
+    assert mdist.frame_shard(5, 1, 2) == [1, 3] and mdist.frame_shard(2, 3, 8) == []
