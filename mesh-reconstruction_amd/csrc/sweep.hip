@@ -54,6 +54,7 @@ struct SweepParams {
     float Wp, Hp;  // W + 0.5, H + 0.5
     const uint2 *__restrict__ plan;
     int tiles_x, tiles_y, nchunks;
+    int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results)
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -245,31 +246,63 @@ __global__ __launch_bounds__(256) void plan_regions(SweepParams p, uint2 *__rest
 // LDS region format: one 8-byte quad per texel position (y, x) of the padded side image:
 //   { t00 + 0.5, t01 - t00, t10 - t00, (t11 - t10) - (t01 - t00) } as four f16 (all exactly representable),
 // so the bilinear fetch is one ds_read_b64 and three v_fma_mix_f32.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// two adjacent bytes -> packed f16 (1024 + b_lo, 1024 + b_hi): v_perm_b32 places the bytes in the low byte of
+// each half, OR-ing 0x6400 turns each half into the f16 with exponent 2^10 whose mantissa is the byte.
+__device__ __forceinline__ f16x2 bytes_to_f16x2(uint32_t hi_word, uint32_t lo_word, uint32_t sel)
+{
+    return __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(hi_word, lo_word, sel) | 0x64006400u);
+}
+
+__device__ __forceinline__ uint32_t interleave_lo(f16x2 hi, f16x2 lo)  // (lo.x, hi.x)
+{
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x05040100u);
+}
+__device__ __forceinline__ uint32_t interleave_hi(f16x2 hi, f16x2 lo)  // (lo.y, hi.y)
+{
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x07060302u);
+}
+
+// Stage the region [x0, x0+rw) x [y0, y0+rh) of the padded side image into LDS quads.  A unit is 4 quads of one
+// region row: 4 aligned dword loads (two image rows), then byte permutes and packed-f16 subtractions only --
+// every value is a small integer (or integer + 0.5), so all of it is exact:
+//   T = (b_k, b_k+1) - 1023.5 -> t00 + 0.5     X  = (b_k+1, b_k+2) - (b_k, b_k+1)   -> t01 - t00
+//   DY = (c_k, c_k+1) - (b_k, b_k+1)           DXY = ((c_k+1, c_k+2) - (c_k, c_k+1)) - X
 __device__ __forceinline__ void stage_region(const uint8_t *__restrict__ pad, int pitch, int x0, int y0, int rw,
                                              int rh, int rp, uint2 *__restrict__ lds)
 {
-    const int tx = threadIdx.x & 31;
-    const int ty = threadIdx.x >> 5;
+    // units (4 quads each) are dealt to the 256 threads in row-major order; (row, unit-in-row) by an exact
+    // float division: (u + 0.5) / units never lands within rounding distance of an integer for u < 2^16
     const int units = rw >> 2;
-    if (tx < units) {
-        for (int ry = ty; ry < rh; ry += 8) {
+    const int total = units * rh;
+    const float inv_units = 1.0f / (float)units;
+    const f16x2 bias = {(_Float16)-1023.5f, (_Float16)-1023.5f};
+    for (int u = threadIdx.x; u < total; u += 256) {
+        {
+            const int ry = (int)(((float)u + 0.5f) * inv_units);
+            const int tx = u - ry * units;
             const uint8_t *r0 = pad + (size_t)(y0 + ry) * pitch + x0 + 4 * tx;
             const uint32_t d0 = *(const uint32_t *)r0, d1 = *(const uint32_t *)(r0 + 4);
             const uint32_t e0 = *(const uint32_t *)(r0 + pitch), e1 = *(const uint32_t *)(r0 + pitch + 4);
-            const uint64_t dd = ((uint64_t)d1 << 32) | d0, ee = ((uint64_t)e1 << 32) | e0;
-            uint2 *dst = lds + ry * rp + 4 * tx;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int t00 = (int)((dd >> (8 * k)) & 255u), t01 = (int)((dd >> (8 * k + 8)) & 255u);
-                const int t10 = (int)((ee >> (8 * k)) & 255u), t11 = (int)((ee >> (8 * k + 8)) & 255u);
-                const int dxt = t01 - t00, dy = t10 - t00, dxy = (t11 - t10) - dxt;
-                half4_t h;
-                h[0] = (_Float16)t00 + (_Float16)0.5f;
-                h[1] = (_Float16)dxt;
-                h[2] = (_Float16)dy;
-                h[3] = (_Float16)dxy;
-                dst[k] = __builtin_bit_cast(uint2, h);
-            }
+            const f16x2 B01 = bytes_to_f16x2(d1, d0, 0x0c010c00u), B12 = bytes_to_f16x2(d1, d0, 0x0c020c01u),
+                        B23 = bytes_to_f16x2(d1, d0, 0x0c030c02u), B34 = bytes_to_f16x2(d1, d0, 0x0c040c03u);
+            const f16x2 C01 = bytes_to_f16x2(e1, e0, 0x0c010c00u), C12 = bytes_to_f16x2(e1, e0, 0x0c020c01u),
+                        C23 = bytes_to_f16x2(e1, e0, 0x0c030c02u), C34 = bytes_to_f16x2(e1, e0, 0x0c040c03u);
+            const f16x2 Ta = B01 + bias, Xa = B12 - B01, DYa = C01 - B01, DXYa = (C12 - C01) - Xa;
+            const f16x2 Tb = B23 + bias, Xb = B34 - B23, DYb = C23 - B23, DXYb = (C34 - C23) - Xb;
+            uint4 q01, q23;
+            q01.x = interleave_lo(Xa, Ta);
+            q01.y = interleave_lo(DXYa, DYa);
+            q01.z = interleave_hi(Xa, Ta);
+            q01.w = interleave_hi(DXYa, DYa);
+            q23.x = interleave_lo(Xb, Tb);
+            q23.y = interleave_lo(DXYb, DYb);
+            q23.z = interleave_hi(Xb, Tb);
+            q23.w = interleave_hi(DXYb, DYb);
+            uint4 *dst = (uint4 *)(lds + ry * rp + 4 * tx);
+            dst[0] = q01;
+            dst[1] = q23;
         }
     }
 }
@@ -433,7 +466,7 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
             const int rh = __builtin_amdgcn_readfirstlane((int)((desc.y >> 8) & 0xffu));
             const int rp = __builtin_amdgcn_readfirstlane((int)(desc.y >> 24) << 5);
             __syncthreads();  // all reads of the previous region are done
-            stage_region(pad, p.pitch, x0, y0, rw, rh, rp, lds);
+            if (!(p.debug & 1)) stage_region(pad, p.pitch, x0, y0, rw, rh, rp, lds);
             __syncthreads();
             RegionView rv;
             rv.lds_bytes = (const char *)lds;
@@ -592,6 +625,7 @@ static int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount)
     p.tiles_x = div_up(ctx->W, TILE_W);
     p.tiles_y = div_up(ctx->H, TILE_H);
     p.nchunks = div_up(ctx->D, PC);
+    p.debug = 0;
     return MVS_OK;
 }
 
@@ -655,6 +689,7 @@ int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags)
     SweepParams p;
     fill_params(ctx, p, view_first, view_count);
     const bool generic = (flags & MVS_SWEEP_FORCE_GENERIC) != 0;
+    p.debug = (int)((flags >> 8) & 0xff);  // undocumented timing-experiment bits
 
     if (!generic && !ctx->plan_valid && ctx->V > 0) {
         const size_t n = (size_t)p.tiles_x * p.tiles_y * p.nchunks * p.V;
