@@ -41,7 +41,8 @@ def cpu_baseline(cfg, main_cam, main_img, side_cams, sides):
     W, H, D, V = cfg
     o = orc.load()
     cores = os.cpu_count() or 1
-    nplanes = min(8, D)
+    # ~35 M samples/s per 8 cores measured in the dev container: aim at 10-30 s of CPU work
+    nplanes = int(min(D, max(8, 8 * (cores // 8))))
     d0 = (D - nplanes) // 2
     z_lo = -1.0 + 2.0 * d0 / D
     z_hi = -1.0 + 2.0 * (d0 + nplanes) / D
@@ -54,6 +55,23 @@ def cpu_baseline(cfg, main_cam, main_img, side_cams, sides):
         "sample": "%dx%d, %d views, planes %d..%d of %d (%.3g samples, %.1f s), OpenMP over rows" %
                   (W, H, V, d0, d0 + nplanes - 1, D, samples, dt),
     }
+
+
+def pmc_traffic(kernel_prefix, config):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*/pmc_*.json, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs;
+    FETCH_SIZE doubled for 16-byte-per-lane streams as MI355X_MICROARCH.md prescribes).  None if absent."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_%s_*.json" % config))):
+        try:
+            rec = json.load(open(path))
+            for name, c in rec.get("kernels", {}).items():
+                if name.startswith(kernel_prefix) and "hbm_bytes_per_launch" in c:
+                    best = {"bytes": c["hbm_bytes_per_launch"], "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            pass
+    return best
 
 
 def main():
@@ -99,9 +117,9 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
 
+    from mvs_amd import dist as mdist
     if args.shard == "views" and world > 1:
-        per = (V + world - 1) // world
-        v0, vn = min(rank * per, V), max(0, min(per, V - rank * per))
+        v0, vn = mdist.view_shard(V, rank, world)
     else:
         v0, vn = 0, V
     vol_t = torch.empty(D * P, dtype=torch.int32, device="cuda")
@@ -110,7 +128,7 @@ def main():
     def step():
         ctx.sweep_run(v0, vn, mvs_amd.MVS_SWEEP_VOLUME)
         if args.shard == "views" and world > 1:
-            dist.all_reduce(vol_t)  # exact: packed integer cells
+            mdist.allreduce_volume(dist, vol_t)  # RCCL sum over xGMI; exact: packed integer cells
         ctx.sweep_argmin()
 
     def barrier():
@@ -163,6 +181,7 @@ def main():
         sweep_bytes = float(P) * (vn + 1) + 4.0 * P * D
         argmin_bytes = 4.0 * P * D + 12.0 * P
         achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+        traffic = pmc_traffic("sweep_tiled", args.config) if args.gpus == 1 else None
         out = {
             "metric": "cost-volume samples/sec (pixels x planes x views)",
             "value": samples_per_step / (dt / args.steps),
@@ -177,7 +196,9 @@ def main():
             "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V),
                        "shard": args.shard, "views_per_rank": vn, "device": ctx.info()},
             "roofline": {"bound": "hbm", "kernel": "sweep_tiled", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
+                         "valu_bound_note": "VALU-issue bound, see DESIGN.md section 4 and profiles/",
                          "bytes_per_launch": sweep_bytes, "ms_per_launch": sweep_ms},
             "kernels": {"sweep_ms": sweep_ms, "argmin_ms": argmin_ms,
                         "argmin_GBps": argmin_bytes / (argmin_ms * 1e-3) / 1e9 if argmin_ms > 0 else None,

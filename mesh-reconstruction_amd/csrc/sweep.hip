@@ -54,7 +54,7 @@ struct SweepParams {
     float Wp, Hp;  // W + 0.5, H + 0.5
     const uint2 *__restrict__ plan;
     int tiles_x, tiles_y, nchunks;
-    int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results)
+    int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: no XCD band remap)
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -393,12 +393,32 @@ __device__ __forceinline__ void sample_lds_pair(const Affine &A, float bx, float
     acc1 = sad_u32((uint32_t)(int)res.y, Im, acc1);
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD, MI355X_MICROARCH.md), each with
+// its own 4 MiB L2.  Tiles are grouped 2 wide x 4 tall (128 x 64 pixels); the 8 tiles of a group get block ids
+// with equal (id % 8), so a group's overlapping side-image regions share one L2, and consecutive groups go to
+// consecutive XCDs, so border tiles (which take the slower per-sample-test path) spread evenly over the chip
+// (a contiguous band per XCD cut HBM fetches 3.2x but ran 5 % slower: profiles/r01).  Bijective onto the padded
+// group grid; ids that fall outside the image exit.  Placement affects speed and traffic only.
+constexpr int GROUP_W = 2, GROUP_H = 4;
+
+__device__ __forceinline__ int grouped_tile(int bid, int tiles_x, int tiles_y)
+{
+    const int gx = (tiles_x + GROUP_W - 1) / GROUP_W;
+    const int sb = bid >> 6, x = bid & 7, m = (bid >> 3) & 7;
+    const int g = sb * 8 + x;
+    const int tx = (g % gx) * GROUP_W + (m & (GROUP_W - 1));
+    const int ty = (g / gx) * GROUP_H + (m >> 1);
+    return (tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : -1;
+}
+
 template <bool WRITE_VOLUME, bool FUSED>
 __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
 {
     __shared__ __attribute__((aligned(16))) uint2 lds[LDS_QUADS];
 
-    const int tile = blockIdx.x;
+    const int tile = (p.debug & 2) ? ((int)blockIdx.x < p.tiles_x * p.tiles_y ? (int)blockIdx.x : -1)
+                                   : grouped_tile(blockIdx.x, p.tiles_x, p.tiles_y);
+    if (tile < 0) return;
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = tx * TILE_W + lane;
@@ -711,7 +731,9 @@ int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags)
             else
                 sweep_generic<false, true><<<grid, 256, 0, ctx->stream>>>(p);
         } else {
-            const unsigned grid = (unsigned)(p.tiles_x * p.tiles_y);
+            // padded group grid: 8 tiles per group, 8 groups per 64-id super block
+            const int groups = div_up(p.tiles_x, 2) * div_up(p.tiles_y, 4);
+            const unsigned grid = (unsigned)(div_up(groups, 8) * 64);
             if (vol && fused)
                 sweep_tiled<true, true><<<grid, 256, 0, ctx->stream>>>(p);
             else if (vol)

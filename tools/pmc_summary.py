@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes (csv) into profiles/<round>/pmc_<config>_<tag>.json.
+
+usage: tools/pmc_summary.py <config> <tag> <out.json> <dir with *_counter_collection.csv> [more dirs ...]
+FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE counts half of the bytes of wide
+(16 B per lane) streaming reads (MI355X_MICROARCH.md, HBM section), so both the raw and the doubled figure are kept;
+`hbm_bytes_per_launch` uses the doubled fetch only for kernels listed in WIDE_READERS (argmin_volume streams uint4),
+the raw one otherwise (the sweep's staging reads are 4-byte loads, uncalibrated: raw figure is the lower bound)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+WIDE_READERS = ("void mvs::argmin_volume<4>",)
+
+
+def main():
+    config, tag, out = sys.argv[1:4]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in sys.argv[4:]:
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    kernels = {}
+    for k, v in agg.items():
+        short = k.replace("void mvs::", "").split("(")[0]
+        c = {n: sum(x) / len(x) for n, x in v.items()}
+        c["dispatches"] = len(next(iter(v.values())))
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            fetch = c["FETCH_SIZE"] * 1024.0
+            c["fetch_bytes_raw"] = fetch
+            c["write_bytes"] = c["WRITE_SIZE"] * 1024.0
+            wide = any(k.startswith(w) for w in WIDE_READERS)
+            c["hbm_bytes_per_launch"] = (2.0 * fetch if wide else fetch) + c["write_bytes"]
+            c["fetch_doubled"] = wide
+        kernels[short] = c
+    json.dump({"config": config, "tag": tag, "kernels": kernels}, open(out, "w"), indent=1)
+    for k, c in kernels.items():
+        if "hbm_bytes_per_launch" in c:
+            print("%-28s hbm bytes/launch %.4g (fetch raw %.4g, write %.4g)" % (k, c["hbm_bytes_per_launch"], c["fetch_bytes_raw"], c["write_bytes"]))
+
+
+if __name__ == "__main__":
+    main()
