@@ -72,6 +72,13 @@ int mvs_flow_remap(mvs_ctx *ctx, const float *flow, int flow_stride, const uint8
 /* calculateFlow, flow.cpp:19-42: out_hw4 = H*W*4 float (u, v, variance, 0) */
 int mvs_flow(mvs_ctx *ctx, const uint8_t *prev_hw, const uint8_t *next_hw, int use_farneback, float *out_hw4);
 
+/* ---- per-pixel triangulation + normals: replaces triangulatePixels (util.cpp:167-329, recon.cpp:114) -------------- */
+/* flows_hw4: nviews pointers to H*W*4 floats (u, v, variance, 0) as mvs_flow writes them; depth_hw: the (mixBackground-
+ * updated) depth map; out_points7: room for H*W rows of (x, y, z, w, nx, ny, nz); *out_count = rows written, in pixel
+ * scan order like the reference's pixelId. */
+int mvs_triangulate(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, const float main_cam[16],
+                    const float *side_cams /* nviews*16 */, const float *depth_hw, float *out_points7, int *out_count);
+
 /* ---- plane sweep: the D-plane generalisation of shader.frag:11-25 ------ */
 /*
  * One-call form on host buffers.  For every pixel of the main view and every plane

@@ -1,0 +1,438 @@
+// triangulate.hip -- triangulatePixels() of the reference (util.cpp:167-329, with triangulatePixel 62-164, goodSample
+// 44-53, sampleImage<T> 438-461, imageGradient 465-479) on gfx950: the consumer of depth + flows (recon.cpp:114).
+//
+// The reference loops over pixels on one CPU thread, allocating cv::Mat temporaries per pixel per Newton step
+// (util.cpp:190-243) and running a PCA per pixel (299).  Here every pixel is a thread:
+//   sobel_kernel       imageGradient(depth)
+//   tri_points_kernel  measured points + inverse covariances per side camera, the <= 50-step Newton solve, the pdf
+//   tri_normals_kernel 21x21-neighbourhood PCA (3x3 Jacobi in f64), orientation vote, pdf scaling
+// Quirks are reproduced as catalogued in oracle/triangulate_oracle.c (swapped bilinear weights, y + fly, the
+// type-punned gradient, the un-dehomogenised fallback normal).  Arithmetic mirrors the oracle statement by statement
+// (f32 storage, f64 accumulation of every matrix product); exp()/pow() come from the device math library, so pdf and
+// the normal scale carry a last-ulp tolerance (tests/test_triangulate_gpu.py).
+#include "mvs_internal.hpp"
+
+#include <cmath>
+
+namespace mvs {
+
+constexpr int TRI_MAXCAM = 32;
+
+struct CamPre {
+    float CM[16];
+    float B[6];
+    float projDeriv[2];
+    float projW[4];
+    float center[3];
+    float pad;
+};
+
+__device__ __forceinline__ int refl(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) {
+        if (p < 0) p = -p;
+        if (p >= n) p = 2 * n - 2 - p;
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(256) void sobel_kernel(const float *__restrict__ img, int W, int H, float *__restrict__ grad2)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    float rdx[3], rsm[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float *r = img + (size_t)refl(y + j - 1, H) * W;
+        const float v0 = r[refl(x - 1, W)], v1 = r[x], v2 = r[refl(x + 1, W)];
+        rdx[j] = v2 - v0;
+        rsm[j] = v0 + v1 * 2.0f + v2;
+    }
+    grad2[((size_t)y * W + x) * 2] = rdx[0] + rdx[1] * 2.0f + rdx[2];
+    grad2[((size_t)y * W + x) * 2 + 1] = rsm[2] - rsm[0];
+}
+
+__device__ __forceinline__ void mat44_vec(const float *a, const float *v, float *o)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) s += (double)a[4 * i + k] * (double)v[k];
+        o[i] = (float)s;
+    }
+}
+
+__device__ __forceinline__ bool good_sample(const float *__restrict__ depth, int W, int H, float x, float y)
+{
+    const int ix = (int)x, iy = (int)y;
+    if (ix <= 0 || ix >= W - 1 || iy <= 0 || iy >= H - 1) return false;
+    const float *p = depth + (size_t)iy * W + ix;
+    return p[0] != MVS_BACKGROUND_DEPTH && p[1] != MVS_BACKGROUND_DEPTH && p[W] != MVS_BACKGROUND_DEPTH &&
+           p[W + 1] != MVS_BACKGROUND_DEPTH;
+}
+
+__device__ __forceinline__ float sample_f32(const float *__restrict__ img, int W, float x, float y)
+{
+    const float lw = fmodf(x, 1.0f), rw = 1 - lw, tw = fmodf(y, 1.0f), bw = 1 - tw;
+    const float *p = img + (size_t)(int)y * W + (int)x;
+    return (p[0] * lw + p[1] * rw) * tw + (p[W] * lw + p[W + 1] * rw) * bw;
+}
+
+__device__ __forceinline__ int round_sat(float v)
+{
+    if (!(v > -2147483648.0f)) return (int)0x80000000;
+    if (!(v < 2147483648.0f)) return 0x7fffffff;
+    return __float2int_rn(v);
+}
+
+__device__ __forceinline__ void sample_point_punned(const float *__restrict__ grad2, int W, int H, float x, float y,
+                                                    float out[2])
+{
+    const float lw = fmodf(x, 1.0f), rw = 1 - lw, tw = fmodf(y, 1.0f), bw = 1 - tw;
+    const int ix = (int)x, iy = (int)y;
+    const int ix1 = ix + 1 < W ? ix + 1 : ix, iy1 = iy + 1 < H ? iy + 1 : iy;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int b00 = __float_as_int(grad2[((size_t)iy * W + ix) * 2 + c]);
+        const int b01 = __float_as_int(grad2[((size_t)iy * W + ix1) * 2 + c]);
+        const int b10 = __float_as_int(grad2[((size_t)iy1 * W + ix) * 2 + c]);
+        const int b11 = __float_as_int(grad2[((size_t)iy1 * W + ix1) * 2 + c]);
+        const int top = (int)((uint32_t)round_sat((float)b00 * lw) + (uint32_t)round_sat((float)b01 * rw));
+        const int bot = (int)((uint32_t)round_sat((float)b10 * lw) + (uint32_t)round_sat((float)b11 * rw));
+        const int r = (int)((uint32_t)round_sat((float)top * tw) + (uint32_t)round_sat((float)bot * bw));
+        out[c] = __int_as_float(r);
+    }
+}
+
+__global__ __launch_bounds__(128) void tri_points_kernel(const float *const *__restrict__ flows, const CamPre *__restrict__ pre,
+                                                         int V, const float *__restrict__ Minv, const float *__restrict__ depth,
+                                                         const float *__restrict__ grad, int W, int H,
+                                                         uint8_t *__restrict__ valid, float *__restrict__ pts,
+                                                         float *__restrict__ pdfs)
+{
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int row = blockIdx.y * 2 + (threadIdx.x >> 6);
+    if (col >= W || row >= H) return;
+    const size_t pix = (size_t)row * W + col;
+    valid[pix] = 0;
+    const float d0 = depth[pix];
+    if (d0 == MVS_BACKGROUND_DEPTH) return;
+    const float centerX = W / 2.0f, centerY = H / 2.0f, scaleX = 2.0f / W, scaleY = 2.0f / H;
+    const float x = (col - centerX) * scaleX, y = (centerY - row) * scaleY;
+    float meas[TRI_MAXCAM][2], icov[TRI_MAXCAM][4];
+    for (int i = 0; i < V; i++) {
+        const float *fl = flows[i] + pix * 4;
+        const float flx = fl[0], fly = fl[1], variance = fl[2];
+        const bool gs = good_sample(depth, W, H, col + flx, row + fly);
+        const float z = gs ? sample_f32(depth, W, col + flx, row + fly) : d0;
+        const float v4[4] = {x + flx * scaleX, y + fly * scaleY, z, 1.0f};
+        float mp[4];
+        mat44_vec(pre[i].CM, v4, mp);
+        float g[2];
+        if (gs)
+            sample_point_punned(grad, W, H, col + flx, row + fly, g);
+        else
+            sample_point_punned(grad, W, H, (float)col, (float)row, g);
+        float A[4];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const double s = (double)pre[i].B[3 * r + 0] * (c == 0 ? 1.0 : 0.0) + (double)pre[i].B[3 * r + 1] * (c == 1 ? 1.0 : 0.0) +
+                                 (double)pre[i].B[3 * r + 2] * (double)g[c];
+                A[2 * r + c] = (float)s / mp[3];
+            }
+        float S[4];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) S[2 * r + c] = (float)((double)A[2 * r] * A[2 * c] + (double)A[2 * r + 1] * A[2 * c + 1]);
+        const double det = (double)S[0] * S[3] - (double)S[1] * S[2];
+        float inv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (det != 0.0) {
+            const double rd = 1.0 / det;
+            inv[0] = (float)(S[3] * rd);
+            inv[1] = (float)(-S[1] * rd);
+            inv[2] = (float)(-S[2] * rd);
+            inv[3] = (float)(S[0] * rd);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) icov[i][k] = inv[k] / variance;
+        const float mz = mp[2] / mp[3];
+        if (mz < -1) return;  // util.cpp:229-233
+        meas[i][0] = mp[0] / mp[3];
+        meas[i][1] = mp[1] / mp[3];
+    }
+    float k[4] = {x, y, d0, 1.0f};
+    float pdf = 1.0f;
+    for (int iter = 0;; iter++) {
+        double firstDz = 0, secondDz = 0;
+        for (int i = 0; i < V; i++) {
+            float ep[4];
+            mat44_vec(pre[i].CM, k, ep);
+            const float px = ep[0] / ep[3], py = ep[1] / ep[3];
+            double w = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) w += (double)pre[i].projW[c] * (double)k[c];
+            const float pw = (float)w;
+            const float dpx = pre[i].projDeriv[0] / pw, dpy = pre[i].projDeriv[1] / pw;
+            const float dfx = px - meas[i][0], dfy = py - meas[i][1];
+            const float t0 = (float)((double)icov[i][0] * dpx + (double)icov[i][1] * dpy);
+            const float t1 = (float)((double)icov[i][2] * dpx + (double)icov[i][3] * dpy);
+            firstDz += (double)dfx * t0 + (double)dfy * t1;
+            secondDz += (double)dpx * t0 + (double)dpy * t1;
+        }
+        const double delta_z = -firstDz / secondDz, eps = 1e-7;
+        if (iter >= 50 || (delta_z < eps && delta_z > -eps)) {
+            double exponent = 0, product_ivar = 1;
+            for (int i = 0; i < V; i++) {
+                float ep[4];
+                mat44_vec(pre[i].CM, k, ep);
+                const float dfx = ep[0] / ep[3] - meas[i][0], dfy = ep[1] / ep[3] - meas[i][1];
+                const float t0 = (float)((double)icov[i][0] * dfx + (double)icov[i][1] * dfy);
+                const float t1 = (float)((double)icov[i][2] * dfx + (double)icov[i][3] * dfy);
+                exponent -= (double)dfx * t0 + (double)dfy * t1;
+                product_ivar *= (double)icov[i][0] * icov[i][3] - (double)icov[i][1] * icov[i][2];
+            }
+            pdf = (float)(0.159 * product_ivar * exp(0.5 * exponent));
+            break;
+        }
+        k[2] = (float)((double)k[2] + delta_z);
+    }
+    mat44_vec(Minv, k, pts + pix * 4);
+    pdfs[pix] = pdf;
+    valid[pix] = 1;
+}
+
+__device__ void smallest_eigvec3(double a[3][3], double v[3])
+{
+    double Vm[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 32; sweep++) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; k++) {
+                    const double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - s * akq;
+                    a[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - s * aqk;
+                    a[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double vkp = Vm[k][p], vkq = Vm[k][q];
+                    Vm[k][p] = c * vkp - s * vkq;
+                    Vm[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int m = 0;
+    if (a[1][1] < a[m][m]) m = 1;
+    if (a[2][2] < a[m][m]) m = 2;
+    for (int k = 0; k < 3; k++) v[k] = Vm[k][m];
+}
+
+__global__ __launch_bounds__(128) void tri_normals_kernel(const uint8_t *__restrict__ valid, const float *__restrict__ pts,
+                                                          const float *__restrict__ pdfs, const CamPre *__restrict__ pre,
+                                                          const float *__restrict__ main_center, int V, int W, int H,
+                                                          float *__restrict__ normals)
+{
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int row = blockIdx.y * 2 + (threadIdx.x >> 6);
+    if (col >= W || row >= H) return;
+    const size_t pix = (size_t)row * W + col;
+    if (!valid[pix]) return;
+    const int radius = 10;
+    float pdf = pdfs[pix];
+    if (V > 1) pdf = (float)pow((double)pdf, 1.0 / V);
+    int n = 0;
+    double mean[3] = {0, 0, 0};
+    for (int ny = row - radius; ny <= row + radius; ny++) {
+        if (ny < 0 || ny >= H) continue;
+        for (int nx = col - radius; nx <= col + radius; nx++) {
+            if (nx < 0 || nx >= W || !valid[(size_t)ny * W + nx]) continue;
+            const float *q = pts + ((size_t)ny * W + nx) * 4;
+            for (int c = 0; c < 3; c++) mean[c] += (double)(q[c] / q[3]);
+            n++;
+        }
+    }
+    float normal[3];
+    const float *pp = pts + pix * 4;
+    if (n >= 3) {
+        for (int c = 0; c < 3; c++) mean[c] /= n;
+        double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int ny = row - radius; ny <= row + radius; ny++) {
+            if (ny < 0 || ny >= H) continue;
+            for (int nx = col - radius; nx <= col + radius; nx++) {
+                if (nx < 0 || nx >= W || !valid[(size_t)ny * W + nx]) continue;
+                const float *q = pts + ((size_t)ny * W + nx) * 4;
+                double d[3];
+                for (int c = 0; c < 3; c++) d[c] = (double)(q[c] / q[3]) - mean[c];
+                for (int a = 0; a < 3; a++)
+                    for (int b = a; b < 3; b++) cov[a][b] += d[a] * d[b];
+            }
+        }
+        for (int a = 0; a < 3; a++)
+            for (int b = a; b < 3; b++) {
+                cov[a][b] /= n;
+                cov[b][a] = cov[a][b];
+            }
+        double ev[3];
+        smallest_eigvec3(cov, ev);
+        for (int c = 0; c < 3; c++) normal[c] = (float)ev[c];
+        float dot = 0.f;  // uninitialised in the reference (util.cpp:302)
+        for (int i = 0; i <= V; i++) {
+            const float *ctr = i == 0 ? main_center : pre[i - 1].center;
+            double s = 0;
+            for (int c = 0; c < 3; c++) s += (double)normal[c] * (double)(ctr[c] - pp[c] / pp[3]);
+            dot += (float)(1.0 / s);
+        }
+        if (dot < 0)
+            for (int c = 0; c < 3; c++) normal[c] = -normal[c];
+    } else {
+        normal[0] = normal[1] = normal[2] = 0.f;
+        for (int i = 0; i <= V; i++) {
+            const float *ctr = i == 0 ? main_center : pre[i - 1].center;
+            float vec[3];
+            double vv = 0;
+            for (int c = 0; c < 3; c++) {
+                vec[c] = ctr[c] - pp[c];  // not dehomogenised: util.cpp:319
+                vv += (double)vec[c] * vec[c];
+            }
+            for (int c = 0; c < 3; c++) normal[c] += (float)(vec[c] / vv);
+        }
+    }
+    const double nn = sqrt((double)normal[0] * normal[0] + (double)normal[1] * normal[1] + (double)normal[2] * normal[2]);
+    for (int c = 0; c < 3; c++) normals[pix * 3 + c] = (float)((double)normal[c] * pdf / nn);
+}
+
+static void host_center(const float *cam, float *c3)
+{
+    const int rows[3] = {0, 1, 3};
+    double p[3][4];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) p[r][c] = cam[4 * rows[r] + c];
+    auto det3 = [&](int c0, int c1, int c2) {
+        return p[0][c0] * (p[1][c1] * p[2][c2] - p[1][c2] * p[2][c1]) - p[0][c1] * (p[1][c0] * p[2][c2] - p[1][c2] * p[2][c0]) +
+               p[0][c2] * (p[1][c0] * p[2][c1] - p[1][c1] * p[2][c0]);
+    };
+    const double c[4] = {det3(1, 2, 3), -det3(0, 2, 3), det3(0, 1, 3), -det3(0, 1, 2)};
+    const double n = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]);
+    float t[4];
+    for (int i = 0; i < 4; i++) t[i] = (float)(n > 0 ? c[i] / n : c[i]);
+    for (int i = 0; i < 3; i++) c3[i] = t[i] / t[3];
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" {
+
+int mvs_triangulate(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, const float main_cam[16], const float *side_cams,
+                    const float *depth_hw, float *out_points7, int *out_count)
+{
+    if (!ctx || !main_cam || !depth_hw || !out_points7 || !out_count || nviews < 0 || (nviews > 0 && (!flows_hw4 || !side_cams)))
+        return fail(ctx, MVS_EINVAL, "mvs_triangulate: bad arguments");
+    if (nviews > TRI_MAXCAM) return fail(ctx, MVS_EINVAL, "mvs_triangulate: at most %d side views", TRI_MAXCAM);
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->W, H = ctx->H, V = nviews;
+    const size_t P = (size_t)W * H;
+    // host precomputation: mainCameraInv (double cofactor inverse -> f32) and the per-camera products
+    double Md[16], Mi[16];
+    for (int i = 0; i < 16; i++) Md[i] = main_cam[i];
+    invert4(Md, Mi);
+    float Minv[16];
+    for (int i = 0; i < 16; i++) Minv[i] = (float)Mi[i];
+    std::vector<CamPre> pre((size_t)(V > 0 ? V : 1));
+    for (int i = 0; i < V; i++) {
+        const float *C = side_cams + 16 * i;
+        CamPre &q = pre[i];
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) {
+                double s = 0;
+                for (int k = 0; k < 4; k++) s += (double)C[4 * r + k] * (double)Minv[4 * k + c];
+                q.CM[4 * r + c] = (float)s;
+            }
+        for (int r = 0; r < 2; r++)
+            for (int c = 0; c < 3; c++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += (double)C[4 * r + k] * (double)Minv[4 * k + c];
+                q.B[3 * r + c] = (float)s;
+            }
+        for (int r = 0; r < 2; r++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += (double)C[4 * r + k] * (double)Minv[4 * k + 2];
+            q.projDeriv[r] = (float)s;
+        }
+        for (int c = 0; c < 4; c++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += (double)C[12 + k] * (double)Minv[4 * k + c];
+            q.projW[c] = (float)s;
+        }
+        host_center(C, q.center);
+        q.pad = 0.f;
+    }
+    float main_center[3];
+    host_center(main_cam, main_center);
+
+    // arena: flows (V*4P) | depth P | grad 2P | pts 4P | pdf P | normals 3P | valid P bytes | tables
+    const size_t floats = (size_t)V * 4 * P + P + 2 * P + 4 * P + P + 3 * P;
+    const size_t tables = sizeof(CamPre) * pre.size() + sizeof(float) * (16 + 4) + sizeof(float *) * (size_t)(V > 0 ? V : 1);
+    int rc = ensure(ctx, ctx->flow_arena, floats * sizeof(float) + P + tables + 256);
+    if (rc) return rc;
+    float *d_flows = (float *)ctx->flow_arena.ptr, *d_depth = d_flows + (size_t)V * 4 * P, *d_grad = d_depth + P, *d_pts = d_grad + 2 * P,
+          *d_pdf = d_pts + 4 * P, *d_nrm = d_pdf + P;
+    uint8_t *d_valid = (uint8_t *)(d_nrm + 3 * P);
+    uintptr_t t = ((uintptr_t)(d_valid + P) + 63) & ~(uintptr_t)63;
+    CamPre *d_pre = (CamPre *)t;
+    float *d_minv = (float *)(d_pre + pre.size());
+    float *d_mc = d_minv + 16;
+    const float **d_ptrs = (const float **)(d_mc + 4);
+    hipStream_t st = ctx->stream;
+    std::vector<const float *> ptrs((size_t)(V > 0 ? V : 1), nullptr);
+    for (int i = 0; i < V; i++) {
+        if (!flows_hw4[i]) return fail(ctx, MVS_EINVAL, "mvs_triangulate: flows[%d] is null", i);
+        MVS_HIP(ctx, hipMemcpyAsync(d_flows + (size_t)i * 4 * P, flows_hw4[i], sizeof(float) * 4 * P, hipMemcpyHostToDevice, st));
+        ptrs[i] = d_flows + (size_t)i * 4 * P;
+    }
+    MVS_HIP(ctx, hipMemcpyAsync(d_depth, depth_hw, sizeof(float) * P, hipMemcpyHostToDevice, st));
+    MVS_HIP(ctx, hipMemcpyAsync(d_pre, pre.data(), sizeof(CamPre) * pre.size(), hipMemcpyHostToDevice, st));
+    MVS_HIP(ctx, hipMemcpyAsync(d_minv, Minv, sizeof(Minv), hipMemcpyHostToDevice, st));
+    MVS_HIP(ctx, hipMemcpyAsync(d_mc, main_center, sizeof(main_center), hipMemcpyHostToDevice, st));
+    MVS_HIP(ctx, hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(float *) * ptrs.size(), hipMemcpyHostToDevice, st));
+    sobel_kernel<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, st>>>(d_depth, W, H, d_grad);
+    tri_points_kernel<<<dim3(div_up(W, 64), div_up(H, 2)), 128, 0, st>>>(d_ptrs, d_pre, V, d_minv, d_depth, d_grad, W, H, d_valid,
+                                                                         d_pts, d_pdf);
+    tri_normals_kernel<<<dim3(div_up(W, 64), div_up(H, 2)), 128, 0, st>>>(d_valid, d_pts, d_pdf, d_pre, d_mc, V, W, H, d_nrm);
+    MVS_HIP(ctx, hipGetLastError());
+    std::vector<float> h_pts(4 * P), h_nrm(3 * P);
+    std::vector<uint8_t> h_valid(P);
+    MVS_HIP(ctx, hipMemcpyAsync(h_pts.data(), d_pts, sizeof(float) * 4 * P, hipMemcpyDeviceToHost, st));
+    MVS_HIP(ctx, hipMemcpyAsync(h_nrm.data(), d_nrm, sizeof(float) * 3 * P, hipMemcpyDeviceToHost, st));
+    MVS_HIP(ctx, hipMemcpyAsync(h_valid.data(), d_valid, P, hipMemcpyDeviceToHost, st));
+    MVS_HIP(ctx, hipStreamSynchronize(st));
+    // compaction in pixel scan order: the reference's pixelId (util.cpp:172,247-248)
+    int n = 0;
+    for (size_t p = 0; p < P; p++)
+        if (h_valid[p]) {
+            float *o = out_points7 + (size_t)n * 7;
+            memcpy(o, &h_pts[4 * p], sizeof(float) * 4);
+            memcpy(o + 4, &h_nrm[3 * p], sizeof(float) * 3);
+            n++;
+        }
+    *out_count = n;
+    return MVS_OK;
+}
+
+}  // extern "C"

@@ -38,6 +38,7 @@ ABI = [
     ("mvs_compare", _i, [_vp, _u8p, _u8p, _fp]),
     ("mvs_flow_remap", _i, [_vp, _fp, _i, _u8p, _u8p]),
     ("mvs_flow", _i, [_vp, _u8p, _u8p, _i, _fp]),
+    ("mvs_triangulate", _i, [_vp, _i, C.POINTER(_fp), _fp, _fp, _fp, _fp, C.POINTER(_i)]),
     ("mvs_sweep", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _f, _f, _fp, _fp, _fp]),
     ("mvs_sweep_set_main", _i, [_vp, _fp, _u8p]),
     ("mvs_sweep_set_views", _i, [_vp, _i, _fp, C.POINTER(_u8p)]),
@@ -280,6 +281,20 @@ class Context:
         self._check(self.lib.mvs_flow(self.h, _ptr(prev, _u8p), _ptr(nxt, _u8p), 1 if use_farneback else 0,
                                       _ptr(out, _fp)))
         return out
+
+    def triangulate(self, flows, main_cam, side_cams, depth):
+        """mvs_triangulate -> (N, 7) rows (x, y, z, w, nx, ny, nz) in pixel scan order"""
+        V = len(flows)
+        fl = [_f32(f, (self.H, self.W, 4)) for f in flows]
+        arr = (_fp * max(V, 1))(*[_ptr(f, _fp) for f in fl])
+        cam = _f32(main_cam, (4, 4))
+        cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((1, 4, 4), np.float32)
+        depth = _f32(depth, (self.H, self.W))
+        out = np.empty((self.H * self.W, 7), np.float32)
+        n = C.c_int(0)
+        self._check(self.lib.mvs_triangulate(self.h, V, arr, _ptr(cam, _fp), _ptr(cams, _fp), _ptr(depth, _fp), _ptr(out, _fp),
+                                             C.byref(n)))
+        return out[:n.value].copy()
 
     def test_rcp(self, exp_bits):
         a, b = C.c_ulonglong(0), C.c_ulonglong(0)

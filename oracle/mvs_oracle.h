@@ -112,6 +112,16 @@ void orc_variational_refine(const uint8_t *I0, const uint8_t *I1, int W, int H, 
 /* calculateFlow: out4 = H*W*4 (u, v, variance, 0) */
 void orc_calculate_flow(const uint8_t *prev, const uint8_t *next, int W, int H, int use_farneback, float *out4);
 
+/* ---- per-pixel triangulation + normals (util.cpp:44-329), the consumer of depth + flows (recon.cpp:114) ---- */
+
+void orc_inv44_f32(const float *m, float *out);
+/* imageGradient (util.cpp:465-479): Sobel 3x3 of a f32 image -> H*W*2 (gx, gy) */
+void orc_image_gradient(const float *img, int W, int H, float *grad2);
+/* triangulatePixels: flows = V pointers to H*W*4 (u, v, variance, 0); returns N and writes N rows of
+ * (x, y, z, w, nx, ny, nz) in pixel scan order; out_points7 must hold H*W*7 floats */
+int orc_triangulate_pixels(const float *const *flows, const float main_cam[16], const float *side_cams, int V,
+                           const float *depth, int W, int H, float *out_points7);
+
 #ifdef __cplusplus
 }
 #endif

@@ -207,6 +207,23 @@ class Oracle:
         return out
 
 
+    # ---- triangulation --------------------------------------------------------------------------
+    def triangulate_pixels(self, flows, main_cam, side_cams, depth):
+        H, W = depth.shape
+        V = len(flows)
+        fl = [np.ascontiguousarray(f, np.float32) for f in flows]
+        arr = (_fp * max(V, 1))(*[self._p(f, _fp) for f in fl])
+        cam = np.ascontiguousarray(main_cam, np.float32)
+        cams = np.ascontiguousarray(np.asarray(side_cams, np.float32).reshape(V, 16)) if V else np.zeros((1, 16), np.float32)
+        depth = np.ascontiguousarray(depth, np.float32)
+        out = np.empty((H * W, 7), np.float32)
+        f = self.lib.orc_triangulate_pixels
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(_fp), _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, _fp]
+        n = f(arr, self._p(cam, _fp), self._p(cams, _fp), V, self._p(depth, _fp), W, H, self._p(out, _fp))
+        return out[:n].copy()
+
+
 _oracle = None
 
 
