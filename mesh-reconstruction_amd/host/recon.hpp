@@ -44,6 +44,8 @@ Mat calculateFlow(const Mat prev, const Mat next, bool useFarneback);
 
 // == util (util.cpp) ==
 Mat extractCameraCenter(const Mat camera);                 // util.cpp:33-41: homogeneous 4x1 centre
+// util.cpp:167-329: rows (x, y, z, w, nx, ny, nz), one per triangulated pixel in scan order
+Mat triangulatePixels(const MatList flows, const Mat mainCamera, const MatList cameras, const Mat depth);
 Mat compare(const Mat prev, const Mat next);               // util.cpp:332-361
 Mat dehomogenize(Mat points);                              // util.cpp:16-29
 Mat mixBackground(const Mat image, const Mat background, Mat &depth);  // util.cpp:366-387 (mutates depth)

@@ -147,6 +147,29 @@ Mat flowRemap(const Mat flow, const Mat image)
     return out;
 }
 
+// util.cpp:167-329 (recon.cpp:114)
+Mat triangulatePixels(const MatList flows, const Mat mainCamera, const MatList cameras, const Mat depth)
+{
+    expect(depth, mvs::F32C1, "triangulatePixels depth");
+    expect(mainCamera, mvs::F32C1, "triangulatePixels mainCamera");
+    if (flows.size() != cameras.size()) throw std::runtime_error("triangulatePixels: one flow per side camera expected");
+    mvs_ctx *ctx = shared_ctx(depth.cols, depth.rows);
+    std::vector<const float *> fl;
+    std::vector<float> cams;
+    auto cam = cameras.begin();
+    for (auto f = flows.begin(); f != flows.end(); ++f, ++cam) {
+        expect(*f, mvs::F32C4, "triangulatePixels flow");
+        expect(*cam, mvs::F32C1, "triangulatePixels camera");
+        fl.push_back(f->ptr<float>());
+        cams.insert(cams.end(), cam->ptr<float>(), cam->ptr<float>() + 16);
+    }
+    Mat all(depth.rows * depth.cols, 7, mvs::F32C1);
+    int n = 0;
+    if (mvs_triangulate(ctx, (int)fl.size(), fl.data(), mainCamera.ptr<float>(), cams.data(), depth.ptr<float>(), all.ptr<float>(), &n))
+        raise(ctx, "triangulatePixels");
+    return all.rowRange(0, n);  // points.resize(pixelId), util.cpp:254
+}
+
 // util.cpp:16-29
 Mat dehomogenize(Mat points)
 {

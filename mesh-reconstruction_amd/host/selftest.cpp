@@ -188,6 +188,27 @@ static int run_gpu(const std::string &tracks, const std::string &out)
         writeRaw(out + "/cam_b.f32", config.camera(fb));
         writeRaw(out + "/flow.f32", flow);
     }
+    {   // recon.cpp:89-116: flows for every side view of this main frame, then triangulatePixels
+        MatList flows, cameras;
+        Mat d2 = render->depth(config.camera(fa));
+        int used = 0;
+        for (int s = hint.beginSide(fa); s != Heuristic::sentinel && used < 2; s = hint.nextSide(fa), used++) {
+            Mat proj = render->projected(config.camera(fa), config.frame(s), config.camera(s));
+            Mat mix = mixBackground(proj, originalImage, d2);
+            flows.push_back(calculateFlow(originalImage, mix, config.useFarneback));
+            cameras.push_back(config.camera(s));
+        }
+        Mat tri = triangulatePixels(flows, config.camera(fa), cameras, d2);
+        printf("triangulatePixels: %d points from %d side views\n", tri.rows, used);
+        CHECK(tri.cols == 7 && tri.rows > 0, "triangulatePixels produced %d x %d", tri.rows, tri.cols);
+        writeRaw(out + "/tri.f32", tri);
+        writeRaw(out + "/tri_depth.f32", d2);
+        int idx = 0;
+        for (const Mat &f : flows) writeRaw(out + "/tri_flow" + std::to_string(idx++) + ".f32", f);
+        idx = 0;
+        for (const Mat &c : cameras) writeRaw(out + "/tri_cam" + std::to_string(idx++) + ".f32", c);
+        std::ofstream(out + "/tri_meta.txt") << used << " " << tri.rows << "\n";
+    }
     bool threw = false;
     try {
         render->projected(config.camera(fa), Mat(10, 10, mvs::U8C1), config.camera(fb));

@@ -38,6 +38,16 @@ def test_recon_stage_through_cpp_mirror(oracle, tmp_path):
     np.testing.assert_array_equal(raw("compare.f32", np.float32, (H, W)), oracle.compare(frame_a, m_ref))
     flow = raw("flow.f32", np.float32, (H, W, 4))
     np.testing.assert_array_equal(raw("remap.u8", np.uint8, (H, W)), oracle.flow_remap(flow, m_ref))
+    # recon.cpp:89-116 through the mirror: calculateFlow per side view + triangulatePixels
+    used, nrows = [int(x) for x in open(tmp_path / "tri_meta.txt").read().split()]
+    tri = raw("tri.f32", np.float32, (nrows, 7))
+    tflows = [raw("tri_flow%d.f32" % i, np.float32, (H, W, 4)) for i in range(used)]
+    tcams = np.stack([raw("tri_cam%d.f32" % i, np.float32, (4, 4)) for i in range(used)])
+    t_ref = oracle.triangulate_pixels(tflows, cam_a, tcams, raw("tri_depth.f32", np.float32, (H, W)))
+    assert tri.shape == t_ref.shape
+    np.testing.assert_array_equal(tri[:, :4], t_ref[:, :4])
+    ok = np.isfinite(t_ref[:, 4:]).all(1)
+    np.testing.assert_allclose(tri[ok, 4:], t_ref[ok, 4:], rtol=1e-5, atol=1e-9)
     # camera selection produced a usable, sorted schedule (heuristic.cpp:484)
     mains = [int(l.split(":")[0]) for l in open(tmp_path / "chosen.txt")]
     assert mains == sorted(mains) and len(mains) >= 1
