@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--shard", default="frames", choices=["frames", "views"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused", action="store_true", help="also time the fused (no volume) variant")
+    ap.add_argument("--plane-groups", type=int, default=4,
+                    help="views sharding: all-reduce the volume in this many plane groups, overlapped with the sweep")
     ap.add_argument("--data", default="scene", choices=["scene", "noise"],
                     help="scene: analytic surface ray-cast per view (SURVEY 8d, seed 0x5EED0001); noise: i.i.d. u8 (seed 0x5EED0002)")
     args = ap.parse_args()
@@ -135,10 +137,25 @@ def main():
     vol_t = torch.empty(D * P, dtype=torch.int32, device="cuda")
     ctx.sweep_use_volume(vol_t.data_ptr(), vol_t.numel() * 4)
 
+    groups = mdist.plane_groups(D, args.plane_groups, ctx.plane_granularity())
+    comm_stream = torch.cuda.Stream()
+
     def step():
-        ctx.sweep_run(v0, vn, mvs_amd.MVS_SWEEP_VOLUME)
         if args.shard == "views" and world > 1:
-            mdist.allreduce_volume(dist, vol_t)  # RCCL sum over xGMI; exact: packed integer cells
+            # sweep plane group g on the compute stream while group g-1 is summed over xGMI on the comm stream
+            # (RCCL, exact: packed integer cells); depth selection waits for the last group
+            works = []
+            for first, count in groups:
+                ctx.sweep_run_planes(v0, vn, first, count, mvs_amd.MVS_SWEEP_VOLUME)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                comm_stream.wait_event(ev)
+                with torch.cuda.stream(comm_stream):
+                    works.append(dist.all_reduce(vol_t[first * P:(first + count) * P], async_op=True))
+            for w in works:
+                w.wait()  # orders the current (compute) stream behind the collective
+        else:
+            ctx.sweep_run(v0, vn, mvs_amd.MVS_SWEEP_VOLUME)
         ctx.sweep_argmin()
 
     def barrier():

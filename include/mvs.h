@@ -103,6 +103,11 @@ int mvs_sweep_set_planes(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi);
 #define MVS_SWEEP_FORCE_GENERIC 4u /* use the un-tiled global-gather kernel (test / fallback path) */
 /* accumulate views [view_first, view_first + view_count) into the packed volume / fused outputs (async) */
 int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags);
+/* the same for planes [plane_first, plane_first + plane_count) only (MVS_SWEEP_VOLUME; boundaries on multiples of
+ * mvs_sweep_plane_granularity(), the last group may end at nplanes): lets a view-sharded job all-reduce one plane group
+ * over xGMI while the next one is being swept (bench.py --shard views --plane-groups G) */
+int mvs_sweep_run_planes(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, unsigned flags);
+int mvs_sweep_plane_granularity(void);
 /* per-pixel depth selection over the packed volume (async); valid after MVS_SWEEP_VOLUME runs or
  * after the caller has reduced the volume across ranks in place */
 int mvs_sweep_argmin(mvs_ctx *ctx);

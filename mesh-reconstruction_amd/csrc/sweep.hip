@@ -54,6 +54,7 @@ struct SweepParams {
     float Wp, Hp;  // W + 0.5, H + 0.5
     const uint2 *__restrict__ plan;
     int tiles_x, tiles_y, nchunks;
+    int chunk0, chunk1;  // plane chunks [chunk0, chunk1) processed by this launch
     int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: no XCD band remap)
 };
 
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void sweep_generic(SweepParams p)
     const int Im = p.main_img[pix];
     uint32_t bs = 0, bc = 0;
     int bi = -1;
-    for (int d0 = 0; d0 < p.D; d0 += PC) {
+    for (int d0 = p.chunk0 * PC; d0 < min(p.D, p.chunk1 * PC); d0 += PC) {
         uint32_t acc[PC];
 #pragma unroll
         for (int k = 0; k < PC; k++) acc[k] = 0u;
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
         bi[j] = -1;
     }
 
-    for (int chunk = 0; chunk < p.nchunks; chunk++) {
+    for (int chunk = p.chunk0; chunk < p.chunk1; chunk++) {
         const int d0 = chunk * PC;
         // plane constants of this chunk live in SGPRs; planes past D (last chunk) are evaluated on a
         // clamped z and never stored, so the sample loops carry no per-plane control flow
@@ -645,6 +646,8 @@ static int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount)
     p.tiles_x = div_up(ctx->W, TILE_W);
     p.tiles_y = div_up(ctx->H, TILE_H);
     p.nchunks = div_up(ctx->D, PC);
+    p.chunk0 = 0;
+    p.chunk1 = p.nchunks;
     p.debug = 0;
     return MVS_OK;
 }
@@ -692,7 +695,29 @@ static int ensure_outputs(mvs_ctx *ctx, bool need_volume)
     return MVS_OK;
 }
 
+static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, unsigned flags);
+
 int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags)
+{
+    if (!ctx) return MVS_EINVAL;
+    return sweep_run_impl(ctx, view_first, view_count, 0, ctx->D, flags);
+}
+
+int mvs_sweep_run_planes(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, unsigned flags)
+{
+    if (!ctx) return MVS_EINVAL;
+    if (flags & MVS_SWEEP_FUSED_ARGMIN)
+        return fail(ctx, MVS_EINVAL, "mvs_sweep_run_planes: depth selection needs all planes; use MVS_SWEEP_VOLUME + mvs_sweep_argmin");
+    if (plane_first < 0 || plane_count < 0 || plane_first + plane_count > ctx->D || (plane_first % mvs_sweep_plane_granularity()) != 0 ||
+        ((plane_first + plane_count) % mvs_sweep_plane_granularity() != 0 && plane_first + plane_count != ctx->D))
+        return fail(ctx, MVS_EINVAL, "mvs_sweep_run_planes: plane range [%d,%d) must lie in 0..%d and start/end on multiples of %d",
+                    plane_first, plane_first + plane_count, ctx->D, mvs_sweep_plane_granularity());
+    return sweep_run_impl(ctx, view_first, view_count, plane_first, plane_count, flags);
+}
+
+int mvs_sweep_plane_granularity(void) { return PC; }
+
+static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, unsigned flags)
 {
     if (!ctx) return MVS_EINVAL;
     if (!ctx->have_main || !ctx->have_views || !ctx->have_planes)
@@ -708,6 +733,8 @@ int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags)
 
     SweepParams p;
     fill_params(ctx, p, view_first, view_count);
+    p.chunk0 = plane_first / PC;
+    p.chunk1 = div_up(plane_first + plane_count, PC);
     const bool generic = (flags & MVS_SWEEP_FORCE_GENERIC) != 0;
     p.debug = (int)((flags >> 8) & 0xff);  // undocumented timing-experiment bits
 

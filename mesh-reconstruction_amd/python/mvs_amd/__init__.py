@@ -44,6 +44,8 @@ ABI = [
     ("mvs_sweep_set_views", _i, [_vp, _i, _fp, C.POINTER(_u8p)]),
     ("mvs_sweep_set_planes", _i, [_vp, _i, _f, _f]),
     ("mvs_sweep_run", _i, [_vp, _i, _i, C.c_uint]),
+    ("mvs_sweep_run_planes", _i, [_vp, _i, _i, _i, _i, C.c_uint]),
+    ("mvs_sweep_plane_granularity", _i, []),
     ("mvs_sweep_argmin", _i, [_vp]),
     ("mvs_sweep_volume_device", _vp, [_vp, C.POINTER(_sz)]),
     ("mvs_sweep_use_volume", _i, [_vp, _vp, _sz]),
@@ -186,6 +188,13 @@ class Context:
         if view_count is None:
             view_count = self.V - view_first
         self._check(self.lib.mvs_sweep_run(self.h, int(view_first), int(view_count), int(flags)))
+
+    def sweep_run_planes(self, view_first, view_count, plane_first, plane_count, flags=MVS_SWEEP_VOLUME):
+        self._check(self.lib.mvs_sweep_run_planes(self.h, int(view_first), int(view_count), int(plane_first), int(plane_count),
+                                                  int(flags)))
+
+    def plane_granularity(self):
+        return self.lib.mvs_sweep_plane_granularity()
 
     def sweep_argmin(self):
         self._check(self.lib.mvs_sweep_argmin(self.h))

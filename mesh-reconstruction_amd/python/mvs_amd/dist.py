@@ -35,3 +35,17 @@ def gather_frames(dist, local_results, num_frames, rank, world):
         for idx, value in zip(frame_shard(num_frames, r, world), items):
             out[idx] = value
     return out
+
+
+def plane_groups(D, groups, granularity):
+    """split planes 0..D into `groups` contiguous ranges whose boundaries are multiples of `granularity`"""
+    units = (D + granularity - 1) // granularity
+    groups = max(1, min(groups, units))
+    out, start = [], 0
+    for g in range(groups):
+        n = units // groups + (1 if g < units % groups else 0)
+        first = start * granularity
+        last = min(D, (start + n) * granularity)
+        out.append((first, last - first))
+        start += n
+    return out

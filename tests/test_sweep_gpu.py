@@ -207,3 +207,82 @@ def test_c3_full_size_properties():
     err = np.abs(d_t - gt)[16:-16, 16:-16]
     assert np.median(err) <= 2.0 / D
     assert np.mean(err <= 3.0 / D) > 0.97
+
+
+def _random_camera(rng, W, H, spread, max_angle):
+    c = rng.uniform(-spread, spread, 3) * np.array([1.0, 1.0, 0.3])
+    yaw, pitch, roll = rng.uniform(-max_angle, max_angle, 3)
+    cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+    near = rng.uniform(0.8, 2.0)
+    return synth.camera_at(c, W, H, near=near, far=near * rng.uniform(3.0, 6.0), rot=Rz @ Rx @ Ry,
+                           fovx=rng.uniform(0.6, 1.4))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_geometry_stress(oracle, seed):
+    """random sizes, plane counts and wildly different side cameras (wide baselines, rotations up to 40 degrees, other
+    intrinsics): exercises the planner's FAST / BORDER / SKIP / GENERIC modes and ragged tiles; tiled == generic ==
+    oracle, cell for cell"""
+    rng = np.random.default_rng(1000 + seed)
+    W = int(rng.integers(2, 400))
+    H = int(rng.integers(2, 200))
+    D = int(rng.integers(1, 40))
+    V = int(rng.integers(1, 6))
+    main_cam = _random_camera(rng, W, H, 0.05, 0.05)
+    side_cams = np.stack([_random_camera(rng, W, H, rng.choice([0.2, 1.5]), rng.choice([0.05, 0.7])) for _ in range(V)])
+    main_img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    sides = [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(V)]
+    z = (float(rng.uniform(-1.0, -0.2)), float(rng.uniform(0.2, 1.0)))
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, z[0], z[1], want_volume=True, nthreads=8)
+    flags = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    tiled = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, flags, z=z)
+    generic = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, flags | mvs_amd.MVS_SWEEP_FORCE_GENERIC, z=z)
+    np.testing.assert_array_equal(tiled[3], generic[3])
+    np.testing.assert_array_equal(tiled[2], generic[2])
+    _check(tiled, ref, D)
+    _check(generic, ref, D)
+
+
+def test_argument_errors():
+    with mvs_amd.Context(64, 32) as ctx:
+        with pytest.raises(mvs_amd.MvsError):
+            ctx.sweep_run(0, 1, mvs_amd.MVS_SWEEP_VOLUME)          # nothing set
+        main_cam, main_img, side_cams, sides, _ = synth.make_views(64, 32, 2)
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, 4)
+        with pytest.raises(mvs_amd.MvsError):
+            ctx.sweep_run(1, 2, mvs_amd.MVS_SWEEP_VOLUME)          # view range past the end
+        with pytest.raises(mvs_amd.MvsError):
+            ctx.sweep_run(0, 2, 0)                                 # neither volume nor fused
+        with pytest.raises(mvs_amd.MvsError):
+            ctx.sweep_set(main_cam, main_img, side_cams, sides, 0)  # zero planes
+    with pytest.raises(mvs_amd.MvsError):
+        mvs_amd.Context(1, 1)
+
+
+def test_plane_groups_reproduce_the_full_volume():
+    """mvs_sweep_run_planes over consecutive plane groups == one full run (the pipelined all-reduce path of bench.py)"""
+    from mvs_amd import dist as mdist
+    W, H, D, V = 320, 160, 40, 3
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
+        ctx.sweep_argmin()
+        d_full, c_full, i_full, v_full = [a.copy() for a in ctx.sweep_fetch(want_volume=True)]
+        for kernel_flag in (0, mvs_amd.MVS_SWEEP_FORCE_GENERIC):
+            # poison the volume, then rebuild it group by group
+            ctx.sweep_run(0, 0, mvs_amd.MVS_SWEEP_VOLUME | kernel_flag)
+            for first, count in mdist.plane_groups(D, 3, ctx.plane_granularity()):
+                ctx.sweep_run_planes(0, V, first, count, mvs_amd.MVS_SWEEP_VOLUME | kernel_flag)
+            ctx.sweep_argmin()
+            d, c, i, v = ctx.sweep_fetch(want_volume=True)
+            np.testing.assert_array_equal(v, v_full)
+            np.testing.assert_array_equal(i, i_full)
+        with pytest.raises(mvs_amd.MvsError):
+            ctx.sweep_run_planes(0, V, 8, 16, mvs_amd.MVS_SWEEP_VOLUME)   # not on the granularity
+    assert mdist.plane_groups(128, 4, 16) == [(0, 32), (32, 32), (64, 32), (96, 32)]
+    assert mdist.plane_groups(40, 3, 16) == [(0, 16), (16, 16), (32, 8)]
+    assert mdist.plane_groups(7, 4, 16) == [(0, 7)]
