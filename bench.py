@@ -82,7 +82,9 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--shard", default="frames", choices=["frames", "views"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fused", action="store_true", help="also time the fused (no volume) variant")
+    ap.add_argument("--fused", action="store_true", help="also time the no-volume variant (depth only)")
+    ap.add_argument("--separate-argmin", action="store_true",
+                    help="single GPU: run argmin_volume as its own pass over the volume (the multi-GPU views pipeline)")
     ap.add_argument("--plane-groups", type=int, default=4,
                     help="views sharding: all-reduce the volume in this many plane groups, overlapped with the sweep")
     ap.add_argument("--data", default="scene", choices=["scene", "noise"],
@@ -154,9 +156,14 @@ def main():
                     works.append(dist.all_reduce(vol_t[first * P:(first + count) * P], async_op=True))
             for w in works:
                 w.wait()  # orders the current (compute) stream behind the collective
-        else:
+            ctx.sweep_argmin()
+        elif args.separate_argmin:
             ctx.sweep_run(v0, vn, mvs_amd.MVS_SWEEP_VOLUME)
-        ctx.sweep_argmin()
+            ctx.sweep_argmin()
+        else:
+            # what mvs_sweep() does on one GPU: the volume is materialised AND the running best plane is kept in
+            # registers, so the volume is never read back
+            ctx.sweep_run(v0, vn, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
 
     def barrier():
         torch.cuda.synchronize()
@@ -205,10 +212,13 @@ def main():
         frames_total = args.gpus if args.shard == "frames" else 1
         samples_per_step = float(P) * D * V * frames_total
         ms_per_step = dt / args.steps * 1e3
-        sweep_ms = ms_sum[mvs_amd.MVS_K_SWEEP] / max(1, launches[mvs_amd.MVS_K_SWEEP])
-        argmin_ms = ms_sum[mvs_amd.MVS_K_ARGMIN] / max(1, launches[mvs_amd.MVS_K_ARGMIN])
-        # algorithmic bytes of one sweep launch: each u8 image once + the u32 volume written once
-        sweep_bytes = float(P) * (vn + 1) + 4.0 * P * D
+        sweep_launches = max(1, launches[mvs_amd.MVS_K_SWEEP]) / (len(groups) if (args.shard == "views" and world > 1) else 1)
+        sweep_ms = ms_sum[mvs_amd.MVS_K_SWEEP] / sweep_launches
+        argmin_ms = ms_sum[mvs_amd.MVS_K_ARGMIN] / max(1, launches[mvs_amd.MVS_K_ARGMIN]) if launches[mvs_amd.MVS_K_ARGMIN] else 0.0
+        separate = launches[mvs_amd.MVS_K_ARGMIN] > 0
+        # algorithmic bytes of one sweep launch: each u8 image once + the u32 volume written once (+ the three result
+        # maps when depth selection is fused into the kernel)
+        sweep_bytes = float(P) * (vn + 1) + 4.0 * P * D + (0.0 if separate else 12.0 * P)
         argmin_bytes = 4.0 * P * D + 12.0 * P
         achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         traffic = pmc_traffic("sweep_tiled", args.config) if args.gpus == 1 else None
@@ -221,7 +231,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak" if args.shard == "frames" else "strong",
             "vs_baseline": None,
-            "dtype": "f32 warp + u8/u32 cost",
+            "dtype": "f32",
             "data": "synthetic (%s)" % args.data,
             "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V),
                        "shard": args.shard, "views_per_rank": vn, "device": ctx.info()},
@@ -230,10 +240,10 @@ def main():
                          "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
                          "valu_bound_note": "VALU-issue bound, see DESIGN.md section 4 and profiles/",
                          "bytes_per_launch": sweep_bytes, "ms_per_launch": sweep_ms},
-            "kernels": {"sweep_ms": sweep_ms, "argmin_ms": argmin_ms,
+            "kernels": {"sweep_ms": sweep_ms, "argmin_ms": argmin_ms if separate else None,
                         "argmin_GBps": argmin_bytes / (argmin_ms * 1e-3) / 1e9 if argmin_ms > 0 else None,
-                        "step_algorithmic_bytes": float(P) * (vn + 8 * D + 9),
-                        "step_GBps": float(P) * (vn + 8 * D + 9) / (ms_per_step * 1e-3) / 1e9},
+                        "depth_selection": "argmin_volume pass" if separate else "fused into sweep_tiled",
+                        "arithmetic": "f32 warp (one rounding per op), u8 intensities, u32 packed cost cells"},
             "depth_check": depth_ok,
         }
         if fused_ms is not None:

@@ -146,6 +146,8 @@ void mvs_destroy(mvs_ctx *ctx)
                       &ctx->volume_own, &ctx->depth, &ctx->cost, &ctx->index, &ctx->soup, &ctx->r_zbuf,
                       &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2,
                       &ctx->cubic_tab, &ctx->flow_arena};
+    for (int i = 0; i < 2; i++)
+        if (ctx->flow_graph[i]) (void)hipGraphExecDestroy(ctx->flow_graph[i]);
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     for (auto &s : ctx->slots) {

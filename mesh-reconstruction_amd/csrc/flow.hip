@@ -17,6 +17,7 @@
 #include "mvs_internal.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace mvs {
 
@@ -647,22 +648,57 @@ int mvs_flow(mvs_ctx *ctx, const uint8_t *prev_hw, const uint8_t *next_hw, int u
     hipStream_t st = ctx->stream;
     MVS_HIP(ctx, hipMemcpyAsync(p8, prev_hw, P, hipMemcpyHostToDevice, st));
     MVS_HIP(ctx, hipMemcpyAsync(n8, next_hw, P, hipMemcpyHostToDevice, st));
+    // everything between the uploads and the download is a fixed sequence of kernels on fixed buffers: record it
+    // once per algorithm as a hipGraph and replay it (MVS_NO_GRAPH=1 forces eager launches)
+    if ((rc = ensure_cubic_table(ctx))) return rc;
+    if ((rc = compare_prepare(ctx))) return rc;
+    auto enqueue = [&]() -> int {
+        u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(p8, f0, P);
+        u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(n8, f1, P);
+        int r;
+        if (use_farneback) {
+            const double poly_sigma = (H + W) / 1000.0;  // flow.cpp:24-25
+            const int winsize = (H + W) / 100, poly_n = poly_sigma < 1.5 ? 5 : 7;
+            if ((r = farneback_device(ctx, f0, f1, flow2, arena, 10, 0.8, winsize, 7, poly_n, poly_sigma))) return r;
+        } else {
+            MVS_HIP(ctx, hipMemsetAsync(flow2, 0, sizeof(float) * 2 * P, st));  // flow.cpp:31 (uninitialised there), A-11
+            if ((r = variational_device(ctx, f0, f1, flow2, arena))) return r;
+        }
+        if ((r = remap_device(ctx, flow2, 2, n8, r8))) return r;  // flow.cpp:34
+        if ((r = compare_device(ctx, p8, r8, var))) return r;
+        pack_flow4<<<g1(P), 256, 0, st>>>(flow2, var, out4, P);
+        MVS_HIP(ctx, hipGetLastError());
+        return MVS_OK;
+    };
     {
-    ProfileScope ps(ctx, MVS_K_FLOW);
-    u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(p8, f0, P);
-    u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(n8, f1, P);
-    if (use_farneback) {
-        const double poly_sigma = (H + W) / 1000.0;  // flow.cpp:24-25
-        const int winsize = (H + W) / 100, poly_n = poly_sigma < 1.5 ? 5 : 7;
-        if ((rc = farneback_device(ctx, f0, f1, flow2, arena, 10, 0.8, winsize, 7, poly_n, poly_sigma))) return rc;
-    } else {
-        MVS_HIP(ctx, hipMemsetAsync(flow2, 0, sizeof(float) * 2 * P, st));  // flow.cpp:31 (uninitialised there), A-11
-        if ((rc = variational_device(ctx, f0, f1, flow2, arena))) return rc;
-    }
-    if ((rc = remap_device(ctx, flow2, 2, n8, r8))) return rc;  // flow.cpp:34
-    if ((rc = compare_device(ctx, p8, r8, var))) return rc;
-    pack_flow4<<<g1(P), 256, 0, st>>>(flow2, var, out4, P);
-    MVS_HIP(ctx, hipGetLastError());
+        const int gi = use_farneback ? 1 : 0;
+        static const bool no_graph = getenv("MVS_NO_GRAPH") != nullptr;
+        if (ctx->flow_graph[gi] && (ctx->flow_graph_arena[gi] != ctx->flow_arena.ptr || ctx->flow_graph_tmp[gi] != ctx->r_tmp1.ptr)) {
+            (void)hipGraphExecDestroy(ctx->flow_graph[gi]);
+            ctx->flow_graph[gi] = nullptr;
+        }
+        if (!ctx->flow_graph[gi] && !no_graph) {
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int r = enqueue();
+                const hipError_t e = hipStreamEndCapture(st, &graph);
+                if (r == MVS_OK && e == hipSuccess && graph &&
+                    hipGraphInstantiate(&ctx->flow_graph[gi], graph, nullptr, nullptr, 0) == hipSuccess) {
+                    ctx->flow_graph_arena[gi] = ctx->flow_arena.ptr;
+                    ctx->flow_graph_tmp[gi] = ctx->r_tmp1.ptr;
+                } else {
+                    ctx->flow_graph[gi] = nullptr;
+                    (void)hipGetLastError();
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+        }
+        ProfileScope ps(ctx, MVS_K_FLOW);
+        if (ctx->flow_graph[gi]) {
+            MVS_HIP(ctx, hipGraphLaunch(ctx->flow_graph[gi], st));
+        } else if ((rc = enqueue())) {
+            return rc;
+        }
     }
     MVS_HIP(ctx, hipMemcpyAsync(out_hw4, out4, sizeof(float) * 4 * P, hipMemcpyDeviceToHost, st));
     MVS_HIP(ctx, hipStreamSynchronize(st));

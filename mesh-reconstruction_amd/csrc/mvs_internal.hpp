@@ -60,6 +60,11 @@ struct mvs_ctx {
     mvs::DevBuf r_zbuf, r_shadow, r_frame, r_out3, r_tmp0, r_tmp1, r_tmp2;
     mvs::DevBuf cubic_tab;           // Q15 bicubic weights for remap (32*32*16 shorts)
     mvs::DevBuf flow_arena;          // optical-flow pyramids and work buffers
+    // the launch-bound flow pipelines (~350 small kernels for Farneback) are captured once into a hipGraph per
+    // algorithm and replayed; invalidated when the arena moves
+    hipGraphExec_t flow_graph[2] = {nullptr, nullptr};
+    void *flow_graph_arena[2] = {nullptr, nullptr};
+    void *flow_graph_tmp[2] = {nullptr, nullptr};
 
     // ---- profiling -----------------------------------------------------------------------------------
     bool profiling = false;
@@ -101,5 +106,7 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // device-buffer forms used by the flow stage (photometric.hip)
 int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, float *out);
 int remap_device(mvs_ctx *ctx, const float *flow, int stride, const uint8_t *img, uint8_t *out);
+int ensure_cubic_table(mvs_ctx *ctx);
+int compare_prepare(mvs_ctx *ctx);  // allocates compare_device's arena (must not happen during graph capture)
 
 }  // namespace mvs

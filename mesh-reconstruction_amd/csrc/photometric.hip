@@ -173,6 +173,22 @@ static void build_cubic_table(short *itab)
 
 static dim3 grid2d(int w, int h) { return dim3(div_up(w, 64), div_up(h, 4)); }
 
+static size_t compare_total(int W, int H)
+{
+    int size = H < W ? H : W, w = W, h = H;
+    size_t total = 0;
+    for (;;) {
+        total += (size_t)w * h;
+        if (size <= 2) break;
+        w = (w + 1) / 2;
+        h = (h + 1) / 2;
+        size /= 2;
+    }
+    return total;
+}
+
+int compare_prepare(mvs_ctx *ctx) { return ensure(ctx, ctx->r_tmp1, sizeof(float) * compare_total(ctx->W, ctx->H) * 3); }
+
 // compare() on device buffers: prev8/next8 (W*H u8) -> out (W*H f32).  All in-stream, no sync.
 int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, float *out)
 {
