@@ -124,6 +124,15 @@ __device__ __forceinline__ void argmin_update(uint32_t cell, int d, uint32_t &bs
     bi = better ? d : bi;
 }
 
+// the same with the best (count, sum) kept as one packed cell: two registers of state per pixel
+__device__ __forceinline__ void argmin_update_packed(uint32_t cell, int d, uint32_t &best, int &bi)
+{
+    const uint32_t s = cell & 0xffffu, c = cell >> 16, bs = best & 0xffffu, bc = best >> 16;
+    const bool better = (c != 0u) && (bi < 0 || __umul24(s, bc) < __umul24(bs, c));
+    best = better ? cell : best;
+    bi = better ? d : bi;
+}
+
 __device__ __forceinline__ void store_best(const SweepParams &p, size_t pix, uint32_t bs, uint32_t bc, int bi)
 {
     p.depth[pix] = bi >= 0 ? p.z[bi] : MVS_BACKGROUND_DEPTH;
@@ -412,10 +421,14 @@ __device__ __forceinline__ int grouped_tile(int bid, int tiles_x, int tiles_y)
     return (tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : -1;
 }
 
+// 3 workgroups per CU (<= 168 VGPRs): 2 per CU measured 9 % slower (not enough waves to cover the two barriers per
+// staged region).  The fused variants keep the running best plane of each pixel in LDS (8 KiB, touched once per
+// plane chunk) instead of 8-12 more registers, which would spill under the cap.
 template <bool WRITE_VOLUME, bool FUSED>
 __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
 {
     __shared__ __attribute__((aligned(16))) uint2 lds[LDS_QUADS];
+    __shared__ uint2 best_state[FUSED ? 256 * NPX : 1];  // (packed best cell, best index) per (pixel j, thread)
 
     const int tile = (p.debug & 2) ? ((int)blockIdx.x < p.tiles_x * p.tiles_y ? (int)blockIdx.x : -1)
                                    : grouped_tile(blockIdx.x, p.tiles_x, p.tiles_y);
@@ -431,17 +444,13 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
     float yn[NPX];
     int Im[NPX];
     bool ok[NPX];
-    uint32_t bs[NPX], bc[NPX];
-    int bi[NPX];
 #pragma unroll
     for (int j = 0; j < NPX; j++) {
         const int row = row0 + j;
         ok[j] = col_ok && row < p.H;
         yn[j] = __builtin_fmaf(-(float)(2 * row + 1), p.invH, 1.0f);
         Im[j] = ok[j] ? (int)p.main_img[(size_t)row * p.W + col] : 0;
-        bs[j] = 0u;
-        bc[j] = 0u;
-        bi[j] = -1;
+        if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(0u, 0xffffffffu);  // own slot only: no barrier needed
     }
 
     for (int chunk = p.chunk0; chunk < p.chunk1; chunk++) {
@@ -527,21 +536,32 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
         for (int j = 0; j < NPX; j++) {
             if (ok[j]) {
                 const size_t pix = (size_t)(row0 + j) * p.W + col;
+                uint32_t best = 0u;
+                int bi = -1;
+                if (FUSED) {
+                    const uint2 st = best_state[j * 256 + threadIdx.x];
+                    best = st.x;
+                    bi = (int)st.y;
+                }
 #pragma unroll
                 for (int k = 0; k < PC; k++) {
                     if (d0 + k < p.D) {
                         const uint32_t cell = acc[j][k] + fast_views;
                         if (WRITE_VOLUME) p.volume[(size_t)(d0 + k) * P + pix] = cell;
-                        if (FUSED) argmin_update(cell, d0 + k, bs[j], bc[j], bi[j]);
+                        if (FUSED) argmin_update_packed(cell, d0 + k, best, bi);
                     }
                 }
+                if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(best, (uint32_t)bi);
             }
         }
     }
     if (FUSED) {
 #pragma unroll
         for (int j = 0; j < NPX; j++)
-            if (ok[j]) store_best(p, (size_t)(row0 + j) * p.W + col, bs[j], bc[j], bi[j]);
+            if (ok[j]) {
+                const uint2 st = best_state[j * 256 + threadIdx.x];
+                store_best(p, (size_t)(row0 + j) * p.W + col, st.x & 0xffffu, st.x >> 16, (int)st.y);
+            }
     }
 }
 
