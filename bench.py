@@ -200,6 +200,21 @@ def main():
         torch.cuda.synchronize()
         fused_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
+    # the spec'd ring geometry (parallel axes, centres in the main focal plane) takes the plane-independent-w path
+    # of sample_lds_pair; time the general path on the same data too (undocumented debug bit 2 << 8)
+    general_ms = None
+    if world == 1:
+        gflags = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | (4 << 8)
+        for _ in range(2):
+            ctx.sweep_run(0, V, gflags)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.sweep_run(0, V, gflags)
+        torch.cuda.synchronize()
+        general_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+
     # sanity: the timed path produced the surface it was rendered from
     depth, cost, idx, _ = ctx.sweep_fetch()
     if gt is not None:
@@ -246,6 +261,11 @@ def main():
                         "arithmetic": "f32 warp (one rounding per op), u8 intensities, u32 packed cost cells"},
             "depth_check": depth_ok,
         }
+        if general_ms is not None:
+            out["general_camera_path"] = {
+                "ms_per_step": general_ms, "samples_per_s": float(P) * D * V / (general_ms * 1e-3),
+                "note": "same data with the plane-independent-w shortcut disabled: the rate for side cameras that are "
+                        "rotated or displaced along the optical axis (DESIGN.md section 4)"}
         if fused_ms is not None:
             out["fused_variant"] = {"ms_per_step": fused_ms, "samples_per_s": float(P) * D * V / (fused_ms * 1e-3)}
         if not args.no_cpu_baseline and args.gpus == 1:

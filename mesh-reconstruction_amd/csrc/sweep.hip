@@ -55,7 +55,7 @@ struct SweepParams {
     const uint2 *__restrict__ plan;
     int tiles_x, tiles_y, nchunks;
     int chunk0, chunk1;  // plane chunks [chunk0, chunk1) processed by this launch
-    int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: no XCD band remap)
+    int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: linear tile order; bit 2: never use the plane-independent-w path)
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -372,17 +372,27 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // projection s = fma(z, B, A), the Newton step of the reciprocal, c = s * r and the last bilinear FMA are
 // issued as packed pairs; the per-sample remainder (v_rcp, fract/cvt, address, ds_read_b64, 2 v_fma_mix,
 // cvt, v_sad_u32) stays scalar.  Element-wise identical arithmetic to sample_lds<true>.
-__device__ __forceinline__ void sample_lds_pair(const Affine &A, float bx, float by, float bw, float z0, float z1,
-                                                const RegionView &rv, int negorg8, uint32_t Im, uint32_t &acc0,
-                                                uint32_t &acc1)
+// WCONST: the view's w row does not depend on the plane (bw == 0: the side camera's centre lies in the main
+// camera's focal plane -- pure sideways translation, the classic fronto-parallel sweep).  Then s.w = fma(z, 0, A.aw)
+// = A.aw exactly for every plane, and r = RN(1/s.w) is the same number for all of them: it is computed once per
+// (pixel, view) and passed in as r_const.  Same values bit for bit, one v_rcp_f32 + three FMAs less per sample.
+template <bool WCONST>
+__device__ __forceinline__ void sample_lds_pair(const Affine &A, float bx, float by, float bw, float r_const, float z0,
+                                                float z1, const RegionView &rv, int negorg8, uint32_t Im,
+                                                uint32_t &acc0, uint32_t &acc1)
 {
     const f32x2 z = {z0, z1};
     const f32x2 sx = __builtin_elementwise_fma(z, (f32x2)(bx), (f32x2)(A.ax));
     const f32x2 sy = __builtin_elementwise_fma(z, (f32x2)(by), (f32x2)(A.ay));
-    const f32x2 sw = __builtin_elementwise_fma(z, (f32x2)(bw), (f32x2)(A.aw));
-    const f32x2 r0 = {__builtin_amdgcn_rcpf(sw.x), __builtin_amdgcn_rcpf(sw.y)};
-    const f32x2 e = __builtin_elementwise_fma(-sw, r0, (f32x2)(1.0f));
-    const f32x2 r = __builtin_elementwise_fma(e, r0, r0);
+    f32x2 r;
+    if (WCONST) {
+        r = (f32x2)(r_const);
+    } else {
+        const f32x2 sw = __builtin_elementwise_fma(z, (f32x2)(bw), (f32x2)(A.aw));
+        const f32x2 r0 = {__builtin_amdgcn_rcpf(sw.x), __builtin_amdgcn_rcpf(sw.y)};
+        const f32x2 e = __builtin_elementwise_fma(-sw, r0, (f32x2)(1.0f));
+        r = __builtin_elementwise_fma(e, r0, r0);
+    }
     const f32x2 cx = sx * r, cy = sy * r;
     f32x2 fy, a, b;
 #pragma unroll
@@ -510,13 +520,26 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
                 fast_views += 65536u;
                 int negorg8 = -rv.org8;
                 asm volatile("" : "+v"(negorg8));  // keep it in a VGPR so mul24 + add fuses into v_mad_i32_i24
+                if (bw == 0.0f && !(p.debug & 4)) {  // wave-uniform: plane-independent w (see sample_lds_pair)
 #pragma unroll
-                for (int j = 0; j < NPX; j++) {
-                    if (ok[j]) {
-                        const Affine A = view_affine(q, xn, yn[j]);
+                    for (int j = 0; j < NPX; j++) {
+                        if (ok[j]) {
+                            const Affine A = view_affine(q, xn, yn[j]);
+                            const float r_const = rcp_rn(__builtin_fmaf(zc[0], bw, A.aw));
 #pragma unroll
-                        for (int k = 0; k < PC; k += 2)
-                            sample_lds_pair(A, bx, by, bw, zc[k], zc[k + 1], rv, negorg8, (uint32_t)Im[j], acc[j][k], acc[j][k + 1]);
+                            for (int k = 0; k < PC; k += 2)
+                                sample_lds_pair<true>(A, bx, by, bw, r_const, zc[k], zc[k + 1], rv, negorg8, (uint32_t)Im[j], acc[j][k], acc[j][k + 1]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NPX; j++) {
+                        if (ok[j]) {
+                            const Affine A = view_affine(q, xn, yn[j]);
+#pragma unroll
+                            for (int k = 0; k < PC; k += 2)
+                                sample_lds_pair<false>(A, bx, by, bw, 0.0f, zc[k], zc[k + 1], rv, negorg8, (uint32_t)Im[j], acc[j][k], acc[j][k + 1]);
+                        }
                     }
                 }
             } else {

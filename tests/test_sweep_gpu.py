@@ -286,3 +286,22 @@ def test_plane_groups_reproduce_the_full_volume():
     assert mdist.plane_groups(128, 4, 16) == [(0, 32), (32, 32), (64, 32), (96, 32)]
     assert mdist.plane_groups(40, 3, 16) == [(0, 16), (16, 16), (32, 8)]
     assert mdist.plane_groups(7, 4, 16) == [(0, 7)]
+
+
+def test_plane_independent_w_path_is_bit_identical(oracle):
+    """ring cameras (parallel axes, centres in the main focal plane) have Q[2][2] == 0 and take the hoisted-reciprocal
+    path; it must equal the general path (debug bit) and the oracle cell for cell; a rotated camera must not take it"""
+    W, H, D, V = 384, 200, 32, 4
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
+    for v in range(V):
+        assert oracle.view_matrix(main_cam, side_cams[v], W, H)[2, 2] == 0.0
+    rot = side_cams.copy()
+    rot[1] = _rot_cam(W, H, [0.0, 0.3, 0.05], 0.01, 0.02)  # pitched and displaced along the optical axis
+    assert oracle.view_matrix(main_cam, rot[1], W, H)[2, 2] != 0.0
+    for cams in (side_cams, rot):
+        ref = oracle.sweep(main_cam, main_img, cams, sides, D, want_volume=True, nthreads=8)
+        fast = _gpu_sweep(W, H, main_cam, main_img, cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        general = _gpu_sweep(W, H, main_cam, main_img, cams, sides, D,
+                             mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | (4 << 8))
+        np.testing.assert_array_equal(fast[3], general[3])
+        _check(fast, ref, D)
