@@ -93,6 +93,13 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
               const float *side_cams /* nviews*16 */, const uint8_t *const *side_frames, int nplanes,
               float z_lo, float z_hi, float *depth_hw, float *cost_hw, float *volume_dhw);
 
+/* The sweep's sampler at ONE plane per pixel, z = depth_hw[p] (e.g. the output of mvs_depth): out_hw2 = H*W pairs
+ * (warped u8 intensity, mask 255/0); background pixels and out-of-frame samples give (0, 0).  With the renderer's depth
+ * map this reproduces Render::projected (render_glx.cpp:261-367) minus its shadow test -- the parity hook between the
+ * D-plane sweep and the reference's single-hypothesis warp. */
+int mvs_warp_by_depth(mvs_ctx *ctx, const float main_cam[16], const float *depth_hw, const float side_cam[16],
+                      const uint8_t *frame_hw, uint8_t *out_hw2);
+
 /* Staged form: inputs stay resident in HBM between runs (bench, multi-GPU view sharding). */
 int mvs_sweep_set_main(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw);
 int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames);

@@ -640,6 +640,27 @@ __global__ __launch_bounds__(256) void argmin_volume(const uint32_t *__restrict_
     }
 }
 
+// the sweep's sampler at one plane per pixel, z = depth[p] (parity hook)
+__global__ __launch_bounds__(256) void warp_by_depth_kernel(const float *__restrict__ depth, const float *__restrict__ Q,
+                                                            const uint8_t *__restrict__ pad, int pitch, int W, int H,
+                                                            float invW, float invH, uint8_t *__restrict__ out2)
+{
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (col >= W || row >= H) return;
+    const size_t pix = (size_t)row * W + col;
+    const float z = depth[pix];
+    uint32_t cell = 0u;
+    if (z != MVS_BACKGROUND_DEPTH) {
+        const float xn = __builtin_fmaf((float)(2 * col + 1), invW, -1.0f);
+        const float yn = __builtin_fmaf(-(float)(2 * row + 1), invH, 1.0f);
+        const Affine A = view_affine(Q, xn, yn);
+        cell = sample_global(A, Q[2], Q[6], Q[10], z, pad, pitch, (float)W + 0.5f, (float)H + 0.5f, 0);  // |Iq - 0| = Iq
+    }
+    out2[2 * pix] = (uint8_t)(cell & 0xffu);
+    out2[2 * pix + 1] = cell ? 255 : 0;
+}
+
 __global__ void unpack_volume(const uint32_t *__restrict__ vol, float *__restrict__ out, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -662,6 +683,9 @@ __global__ void rcp_check_kernel(uint32_t exp_bits, unsigned long long *out)
         if (m == 0x7fffffu) atomicAdd(out + 1, 1ull);
     }
 }
+
+// defined in context.hip
+__global__ void pad_wrap_kernel(const uint8_t *__restrict__ img, uint8_t *__restrict__ pad, int W, int H, int pitch);
 
 static int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount)
 {
@@ -891,6 +915,36 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
         MVS_HIP(ctx, hipMemcpyAsync(volume_dhw, ctx->r_tmp0.ptr, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return MVS_OK;
+}
+
+int mvs_warp_by_depth(mvs_ctx *ctx, const float main_cam[16], const float *depth_hw, const float side_cam[16],
+                      const uint8_t *frame_hw, uint8_t *out_hw2)
+{
+    if (!ctx || !main_cam || !depth_hw || !side_cam || !frame_hw || !out_hw2) return fail(ctx, MVS_EINVAL, "mvs_warp_by_depth: null argument");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->W, H = ctx->H;
+    const size_t P = (size_t)W * H;
+    const int pitch = ((W + 2 + 63) / 64) * 64;
+    int rc;
+    if ((rc = ensure(ctx, ctx->upload, P))) return rc;
+    if ((rc = ensure(ctx, ctx->r_frame, (size_t)pitch * (H + 2) + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->r_zbuf, P * sizeof(float)))) return rc;
+    if ((rc = ensure(ctx, ctx->r_out3, 3 * P))) return rc;
+    if ((rc = ensure(ctx, ctx->r_tmp0, P * sizeof(int) > 64 ? P * sizeof(int) : 64))) return rc;
+    float Q[12];
+    view_matrix(main_cam, side_cam, W, H, Q);
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->r_tmp0.ptr, Q, sizeof(Q), hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->upload.ptr, frame_hw, P, hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->r_zbuf.ptr, depth_hw, P * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    pad_wrap_kernel<<<dim3(div_up(pitch, 256), H + 2), 256, 0, ctx->stream>>>((const uint8_t *)ctx->upload.ptr,
+                                                                              (uint8_t *)ctx->r_frame.ptr, W, H, pitch);
+    warp_by_depth_kernel<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, ctx->stream>>>(
+        (const float *)ctx->r_zbuf.ptr, (const float *)ctx->r_tmp0.ptr, (const uint8_t *)ctx->r_frame.ptr, pitch, W, H,
+        1.0f / (float)W, 1.0f / (float)H, (uint8_t *)ctx->r_out3.ptr);
+    MVS_HIP(ctx, hipGetLastError());
+    MVS_HIP(ctx, hipMemcpyAsync(out_hw2, ctx->r_out3.ptr, 2 * P, hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MVS_OK;
 }
 

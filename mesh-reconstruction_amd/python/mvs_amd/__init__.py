@@ -40,6 +40,7 @@ ABI = [
     ("mvs_flow", _i, [_vp, _u8p, _u8p, _i, _fp]),
     ("mvs_triangulate", _i, [_vp, _i, C.POINTER(_fp), _fp, _fp, _fp, _fp, C.POINTER(_i)]),
     ("mvs_sweep", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _f, _f, _fp, _fp, _fp]),
+    ("mvs_warp_by_depth", _i, [_vp, _fp, _fp, _fp, _u8p, _u8p]),
     ("mvs_sweep_set_main", _i, [_vp, _fp, _u8p]),
     ("mvs_sweep_set_views", _i, [_vp, _i, _fp, C.POINTER(_u8p)]),
     ("mvs_sweep_set_planes", _i, [_vp, _i, _f, _f]),
@@ -170,6 +171,13 @@ class Context:
         if want_volume:
             out.append(vol)
         return out[0] if len(out) == 1 else tuple(out)
+
+    def warp_by_depth(self, main_cam, depth, side_cam, frame):
+        cam, sc = _f32(main_cam, (4, 4)), _f32(side_cam, (4, 4))
+        d, f = _f32(depth, (self.H, self.W)), _u8(frame, (self.H, self.W))
+        out = np.empty((self.H, self.W, 2), np.uint8)
+        self._check(self.lib.mvs_warp_by_depth(self.h, _ptr(cam, _fp), _ptr(d, _fp), _ptr(sc, _fp), _ptr(f, _u8p), _ptr(out, _u8p)))
+        return out
 
     def sweep_set(self, main_cam, main_img, side_cams, side_imgs, nplanes, z_lo=-1.0, z_hi=1.0):
         W, H = self.W, self.H

@@ -58,6 +58,10 @@ void orc_sweep(const float main_cam[16], const uint8_t *main_img, int W, int H,
                uint32_t *volume /* nullable */, float *depth /* H*W */, float *best_cost /* nullable */,
                int32_t *best_idx /* nullable */, int nthreads);
 
+/* the sweep's sampler at one plane per pixel (z = depth map): out_hw2 = (warped u8, mask) pairs; see sweep_oracle.c */
+void orc_warp_by_depth(const float main_cam[16], const float *depth, const float side_cam[16], const uint8_t *frame,
+                       int W, int H, uint8_t *out_hw2);
+
 /* per-pixel depth selection over a packed volume: lowest d minimising sum/cnt (exact integer
  * cross-multiplied comparison); no valid plane -> depth 1.0 (backgroundDepth), idx -1, cost +inf */
 void orc_argmin(const uint32_t *volume, int W, int H, int D, const float *z,

@@ -237,6 +237,29 @@ void orc_sweep(const float main_cam[16], const uint8_t *main_img, int W, int H,
     free(Q);
 }
 
+/* The parity hook of SURVEY.md section 0.2: the sweep's sampler evaluated at ONE plane per pixel, z = depth[p] (e.g.
+ * Render::depth of the main camera).  out_hw2 = (warped u8, mask 255/0) per pixel; background pixels (depth == 1.0)
+ * and out-of-frame samples get (0, 0).  Equals Render::projected without its shadow test. */
+void orc_warp_by_depth(const float main_cam[16], const float *depth, const float side_cam[16], const uint8_t *frame,
+                       int W, int H, uint8_t *out_hw2)
+{
+    const int pitch = W + 2;
+    float Q[12];
+    orc_view_matrix(main_cam, side_cam, W, H, Q);
+    uint8_t *pad = (uint8_t *)malloc((size_t)pitch * (H + 2));
+    orc_pad_image(frame, W, H, pad, pitch);
+    for (int row = 0; row < H; row++)
+        for (int col = 0; col < W; col++) {
+            const size_t p = (size_t)row * W + col;
+            int Iq = 0, ok = 0;
+            if (depth[p] != ORC_BACKGROUND_DEPTH)
+                ok = orc_sweep_sample(Q, orc_pixel_xn(col, W), orc_pixel_yn(row, H), depth[p], pad, pitch, W, H, &Iq);
+            out_hw2[2 * p] = ok ? (uint8_t)Iq : 0;
+            out_hw2[2 * p + 1] = ok ? 255 : 0;
+        }
+    free(pad);
+}
+
 /* util.cpp:366-387 */
 void orc_mix_background(const uint8_t *img_hw3, const uint8_t *bg_hw, float *depth_hw, uint8_t *out_hw,
                         int W, int H)

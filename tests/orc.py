@@ -91,6 +91,16 @@ class Oracle:
                            self._p(idx, _i32p), nthreads)
         return depth, cost, idx, vol
 
+    def warp_by_depth(self, main_cam, depth, side_cam, frame):
+        H, W = frame.shape
+        m, sc = np.ascontiguousarray(main_cam, np.float32), np.ascontiguousarray(side_cam, np.float32)
+        d, f = np.ascontiguousarray(depth, np.float32), np.ascontiguousarray(frame, np.uint8)
+        out = np.empty((H, W, 2), np.uint8)
+        fn = self.lib.orc_warp_by_depth
+        fn.argtypes = [_fp, _fp, _fp, _u8p, C.c_int, C.c_int, _u8p]
+        fn(self._p(m, _fp), self._p(d, _fp), self._p(sc, _fp), self._p(f, _u8p), W, H, self._p(out, _u8p))
+        return out
+
     def argmin(self, vol, z):
         D, H, W = vol.shape
         vol = np.ascontiguousarray(vol, np.uint32)

@@ -126,3 +126,22 @@ def test_reference_stage_per_pair(oracle):
     np.testing.assert_array_equal(mixed, m_ref)
     np.testing.assert_array_equal(depth2, d2_ref)
     assert (depth2 == 1.0).mean() > 0.2 and (depth2 != 1.0).mean() > 0.1
+
+
+def test_parity_hook_warp_by_depth(oracle):
+    """mvs_warp_by_depth == oracle (bit-exact) and ~= Render::projected on unoccluded geometry (SURVEY.md section 0.2)"""
+    W, H = 320, 240
+    verts, faces = scenes.heightfield_mesh(96)
+    soup, ctx = _both(oracle, W, H, verts, faces)
+    sc = synth.Scene(freq_scale=0.2)
+    main_c, side_c = [0.0, 0.0, 0.0], [0.2, 0.1, 0.0]
+    cam, prj = synth.camera_at(main_c, W, H), synth.camera_at(side_c, W, H)
+    side_img = sc.render(side_c, W, H)
+    with ctx:
+        depth = ctx.depth(cam)
+        warp = ctx.warp_by_depth(cam, depth, prj, side_img)
+        proj = ctx.projected(cam, side_img, prj)
+    np.testing.assert_array_equal(warp, oracle.warp_by_depth(cam, depth, prj, side_img))
+    both = (proj[..., 1] == 255) & (warp[..., 1] == 255)
+    diff = np.abs(proj[..., 0].astype(int) - warp[..., 0].astype(int))[both]
+    assert both.mean() > 0.9 and diff.max() <= 1 and np.mean(diff == 0) > 0.97
