@@ -238,7 +238,8 @@ int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const 
     ctx->V = nviews;
     ctx->q_host.assign((size_t)nviews * 12, 0.f);
     if (nviews > 0) {
-        int rc = ensure(ctx, ctx->side_pads, ctx->pad_slab * nviews);
+        // + 64: the staging loads of the tiled sweep read whole dwords up to 7 bytes past a row's last used texel
+        int rc = ensure(ctx, ctx->side_pads, ctx->pad_slab * nviews + 64);
         if (rc) return rc;
         if ((rc = ensure(ctx, ctx->upload, P))) return rc;
         if ((rc = ensure(ctx, ctx->qmats, sizeof(float) * 12 * nviews))) return rc;
