@@ -87,6 +87,8 @@ def main():
                     help="single GPU: run argmin_volume as its own pass over the volume (the multi-GPU views pipeline)")
     ap.add_argument("--plane-groups", type=int, default=4,
                     help="views sharding: all-reduce the volume in this many plane groups, overlapped with the sweep")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed steps (for rocprofv3 runs: keeps per-kernel averages to the timed variant)")
     ap.add_argument("--data", default="scene", choices=["scene", "noise"],
                     help="scene: analytic surface ray-cast per view (SURVEY 8d, seed 0x5EED0001); noise: i.i.d. u8 (seed 0x5EED0002)")
     args = ap.parse_args()
@@ -203,7 +205,7 @@ def main():
     # the spec'd ring geometry (parallel axes, centres in the main focal plane) takes the plane-independent-w path
     # of sample_lds_pair; time the general path on the same data too (undocumented debug bit 2 << 8)
     general_ms = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
         gflags = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | (4 << 8)
         for _ in range(2):
             ctx.sweep_run(0, V, gflags)
