@@ -257,6 +257,11 @@ static void poly_exp(const float *src, int w, int h, int n, double sigma, float 
     free(g);
 }
 
+/* exposed for the independent cross-checks in tests/test_pinning_cpu.py */
+void orc_poly_exp(const float *src, int w, int h, int n, double sigma, float *dst5) { poly_exp(src, w, h, n, sigma, dst5); }
+void orc_gaussian_blur(const float *src, int w, int h, int ksize, double sigma, float *dst) { gaussian_blur(src, w, h, ksize, sigma, dst); }
+void orc_resize_linear(const float *src, int sw, int sh, int cn, float *dst, int dw, int dh) { resize_linear(src, sw, sh, cn, dst, dw, dh); }
+
 /* FarnebackUpdateMatrices */
 static void update_matrices(const float *R0, const float *R1, const float *flow, int w, int h, float *M)
 {

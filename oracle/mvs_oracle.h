@@ -113,6 +113,12 @@ void orc_farneback(const uint8_t *prev, const uint8_t *next, int W, int H, int l
                    int iterations, int poly_n, double poly_sigma, float *flow_out);
 /* cv::optflow VariationalRefinement::calc with default parameters; flow = H*W*2, refined in place */
 void orc_variational_refine(const uint8_t *I0, const uint8_t *I1, int W, int H, float *flow);
+/* building blocks, exposed so tests can check them against independent formulations (scipy / least squares) */
+void orc_pyr_down(const float *src, int w, int h, float *dst);
+void orc_pyr_up(const float *src, int sw, int sh, float *dst, int dw, int dh);
+void orc_poly_exp(const float *src, int w, int h, int n, double sigma, float *dst5);
+void orc_gaussian_blur(const float *src, int w, int h, int ksize, double sigma, float *dst);
+void orc_resize_linear(const float *src, int sw, int sh, int cn, float *dst, int dw, int dh);
 /* calculateFlow: out4 = H*W*4 (u, v, variance, 0) */
 void orc_calculate_flow(const uint8_t *prev, const uint8_t *next, int W, int H, int use_farneback, float *out4);
 

@@ -99,6 +99,10 @@ static void pyr_up(const float *src, int sw, int sh, float *dst, int dw, int dh)
     free(rows);
 }
 
+/* exposed for the independent cross-checks in tests/test_pinning_cpu.py */
+void orc_pyr_down(const float *src, int w, int h, float *dst) { pyr_down(src, w, h, dst); }
+void orc_pyr_up(const float *src, int sw, int sh, float *dst, int dw, int dh) { pyr_up(src, sw, sh, dst, dw, dh); }
+
 void orc_compare_f32(const float *prev, const float *next, int W, int H, float *out)
 {
     /* util.cpp:334-351 */

@@ -1,0 +1,101 @@
+"""Independent cross-checks of the OpenCV routines the oracle restates (the reference pins none of them):
+each building block is compared with a different formulation of the same published algorithm -- scipy.ndimage
+convolutions for the binomial pyramids and the Gaussian blur, a direct weighted least-squares fit for Farneback's
+polynomial expansion, the closed-form bilinear map for resize."""
+import ctypes as C
+
+import numpy as np
+import scipy.ndimage as ndi
+
+_fp = C.POINTER(C.c_float)
+
+
+def _p(a):
+    return a.ctypes.data_as(_fp)
+
+
+def test_pyr_down_is_binomial_filter_plus_decimation(oracle):
+    rng = np.random.default_rng(0)
+    for (H, W) in [(48, 64), (37, 53)]:
+        src = rng.uniform(0, 255, (H, W)).astype(np.float32)
+        dh, dw = (H + 1) // 2, (W + 1) // 2
+        dst = np.empty((dh, dw), np.float32)
+        oracle.lib.orc_pyr_down.argtypes = [_fp, C.c_int, C.c_int, _fp]
+        oracle.lib.orc_pyr_down(_p(src), W, H, _p(dst))
+        k = np.array([1, 4, 6, 4, 1], np.float64) / 16
+        ref = ndi.correlate1d(ndi.correlate1d(src.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")[::2, ::2]
+        np.testing.assert_allclose(dst, ref, rtol=0, atol=2e-4)   # cv::pyrDown: BORDER_REFLECT_101 == scipy 'mirror'
+
+
+def test_pyr_up_is_zero_insertion_plus_binomial_filter(oracle):
+    rng = np.random.default_rng(1)
+    sh, sw = 20, 27
+    src = rng.uniform(0, 255, (sh, sw)).astype(np.float32)
+    for (dh, dw) in [(2 * sh, 2 * sw), (2 * sh - 1, 2 * sw - 1)]:
+        dst = np.empty((dh, dw), np.float32)
+        oracle.lib.orc_pyr_up.argtypes = [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int]
+        oracle.lib.orc_pyr_up(_p(src), sw, sh, _p(dst), dw, dh)
+        up = np.zeros((2 * sh, 2 * sw))
+        up[::2, ::2] = src
+        k = np.array([1, 4, 6, 4, 1], np.float64) / 8     # x4 overall: compensates the inserted zeros
+        ref = ndi.correlate1d(ndi.correlate1d(up, k, axis=1, mode="constant"), k, axis=0, mode="constant")
+        # interior only: the borders follow OpenCV's own reflect/replicate rule, tested through compare()'s constant case
+        np.testing.assert_allclose(dst[2:-3, 2:-3], ref[2:dh - 3, 2:dw - 3], rtol=0, atol=2e-4)
+    # a constant image survives exactly (borders included): weights sum to one everywhere
+    const = np.full((sh, sw), 7.0, np.float32)
+    dst = np.empty((2 * sh, 2 * sw), np.float32)
+    oracle.lib.orc_pyr_up(_p(const), sw, sh, _p(dst), 2 * sw, 2 * sh)
+    assert np.all(dst == 7.0)
+
+
+def test_gaussian_blur_and_resize(oracle):
+    rng = np.random.default_rng(2)
+    H, W = 40, 56
+    src = rng.uniform(0, 255, (H, W)).astype(np.float32)
+    for ksize, sigma in [(3, 0.0), (7, 1.3), (21, 4.16)]:
+        dst = np.empty_like(src)
+        oracle.lib.orc_gaussian_blur.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_double, _fp]
+        oracle.lib.orc_gaussian_blur(_p(src), W, H, ksize, sigma, _p(dst))
+        if sigma <= 0:
+            k = np.array([0.25, 0.5, 0.25])
+        else:
+            x = np.arange(ksize) - (ksize - 1) / 2
+            k = np.exp(-0.5 * x * x / sigma ** 2)
+            k /= k.sum()
+        ref = ndi.correlate1d(ndi.correlate1d(src.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+        np.testing.assert_allclose(dst, ref, rtol=0, atol=3e-4)
+    # cv::resize INTER_LINEAR: pixel-centre aligned bilinear map, edge clamped
+    dh, dw = 29, 45
+    dst = np.empty((dh, dw), np.float32)
+    oracle.lib.orc_resize_linear.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int]
+    oracle.lib.orc_resize_linear(_p(src), W, H, 1, _p(dst), dw, dh)
+    ys = np.clip((np.arange(dh) + 0.5) * H / dh - 0.5, 0, H - 1)
+    xs = np.clip((np.arange(dw) + 0.5) * W / dw - 0.5, 0, W - 1)
+    ref = ndi.map_coordinates(src.astype(np.float64), np.meshgrid(ys, xs, indexing="ij"), order=1, mode="nearest")
+    np.testing.assert_allclose(dst, ref, rtol=0, atol=2e-3)
+
+
+def test_farneback_polynomial_expansion_is_weighted_least_squares(oracle):
+    """Farneback 2003, section 2: each neighbourhood is approximated by r1 + r2 x + r3 y + r4 x^2 + r5 y^2 + r6 xy in the
+    weighted least-squares sense (Gaussian applicability).  The separable implementation must give the same
+    coefficients as solving the normal equations directly."""
+    rng = np.random.default_rng(3)
+    H, W = 40, 48
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = (100 + 40 * np.sin(xx / 4.0) * np.cos(yy / 5.0) + rng.normal(0, 3, (H, W))).astype(np.float32)
+    for n, sigma in [(5, 1.12), (7, 3.0)]:
+        dst = np.empty((H, W, 5), np.float32)
+        oracle.lib.orc_poly_exp.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_double, _fp]
+        oracle.lib.orc_poly_exp(_p(img), W, H, n, sigma, _p(dst))
+        g = np.exp(-np.arange(-n, n + 1) ** 2 / (2 * sigma ** 2))
+        g /= g.sum()
+        wy, wx = np.meshgrid(g, g, indexing="ij")
+        dy, dx = np.mgrid[-n:n + 1, -n:n + 1]
+        B = np.stack([np.ones_like(dx), dx, dy, dx * dx, dy * dy, dx * dy], -1).reshape(-1, 6).astype(np.float64)
+        Wt = (wy * wx).reshape(-1)
+        G = B.T @ (Wt[:, None] * B)
+        for (y, x) in [(n + 3, n + 4), (H // 2, W // 2), (H - n - 2, W - n - 5)]:
+            patch = img[y - n:y + n + 1, x - n:x + n + 1].astype(np.float64).reshape(-1)
+            r = np.linalg.solve(G, B.T @ (Wt * patch))      # r1, r2(x), r3(y), r4(x^2), r5(y^2), r6(xy)
+            got = dst[y, x]                                  # OpenCV channel order: r3(y), r2(x), r5(y^2), r4(x^2), r6(xy)
+            np.testing.assert_allclose([got[1], got[0], got[3], got[2], got[4]], r[1:], rtol=2e-4, atol=2e-4)
