@@ -79,6 +79,12 @@ int mvs_flow(mvs_ctx *ctx, const uint8_t *prev_hw, const uint8_t *next_hw, int u
 int mvs_triangulate(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, const float main_cam[16],
                     const float *side_cams /* nviews*16 */, const float *depth_hw, float *out_points7, int *out_count);
 
+/* ---- point-cloud filter: replaces Heuristic::filterPoints (heuristic.cpp:55-176, recon.cpp:125) ------------------- */
+/* points4: npoints homogeneous rows; alpha = the reference's alphaVals.back() (radius = alpha/4, compared with squared
+ * distances as the reference does).  keep_out receives the ascending indices of the retained points, *out_count how
+ * many; the caller compacts points and normals with them (heuristic.cpp:166-175). */
+int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alpha, int32_t *keep_out, int *out_count);
+
 /* ---- plane sweep: the D-plane generalisation of shader.frag:11-25 ------ */
 /*
  * One-call form on host buffers.  For every pixel of the main view and every plane

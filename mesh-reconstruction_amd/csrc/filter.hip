@@ -1,0 +1,324 @@
+// filter.hip -- Heuristic::filterPoints (heuristic.cpp:55-176) on gfx950: the outlier / redundancy filter the reference
+// runs on the 10^5..10^6-point cloud after every iteration (recon.cpp:125).
+//
+// Reference structure -> here:
+//   FLANN KD-tree build + one radiusSearch per point (heuristic.cpp:74-92, single thread, randomised, approximate)
+//       -> hash grid with cell = sqrt(radius): hash_build, nb_count, nb_fill (exact neighbourhood, 27 cells per point),
+//          lists sorted by index so the result does not depend on atomics' arrival order
+//   power iteration over the symmetric neighbour weights (103-136), scatter `score[j] += ...` on one thread
+//       -> gather form: each point owns its lower list (j < i) AND its upper list (k > i), both ascending, and adds
+//          them in exactly the order the sequential scatter would have produced (density_score); the two global
+//          sums run as fixed-shape two-level reductions (chunk_sums / final on the host) -- deterministic
+//   greedy pass by descending density (139-163) is inherently sequential: it stays on the host, on the lists copied
+//   back once.
+// Quirks kept: squared distances compared with `radius` (81-89), only lower-index neighbours are penalised (152-154).
+#include "mvs_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace mvs {
+
+struct Nb {
+    int idx;
+    float w;
+};
+
+__device__ __forceinline__ unsigned cell_hash(int cx, int cy, int cz, unsigned mask)
+{
+    return ((unsigned)cx * 73856093u ^ (unsigned)cy * 19349663u ^ (unsigned)cz * 83492791u) & mask;
+}
+
+__global__ __launch_bounds__(256) void dehomog_cells(const float *__restrict__ p4, int N, float inv_cell, float *__restrict__ p3,
+                                                     int *__restrict__ cell3)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float v = p4[4 * i + c] / p4[4 * i + 3];  // dehomogenize, util.cpp:16-29
+        p3[3 * i + c] = v;
+        const float f = floorf(v * inv_cell);
+        cell3[3 * i + c] = (int)fminf(fmaxf(f, -1.0e9f), 1.0e9f);
+    }
+}
+
+__global__ __launch_bounds__(256) void hash_build(const int *__restrict__ cell3, int N, unsigned mask, int *__restrict__ head,
+                                                  int *__restrict__ next)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const unsigned h = cell_hash(cell3[3 * i], cell3[3 * i + 1], cell3[3 * i + 2], mask);
+    next[i] = atomicExch(&head[h], i);
+}
+
+// visit every j < i with |p_i - p_j|^2 <= radius; F(j, d2)
+template <class F>
+__device__ __forceinline__ void for_lower_neighbours(int i, const float *__restrict__ p3, const int *__restrict__ cell3,
+                                                     const int *__restrict__ head, const int *__restrict__ next, unsigned mask,
+                                                     float radius, F f)
+{
+    const float x = p3[3 * i], y = p3[3 * i + 1], z = p3[3 * i + 2];
+    const int cx = cell3[3 * i], cy = cell3[3 * i + 1], cz = cell3[3 * i + 2];
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int nx = cx + dx, ny = cy + dy, nz = cz + dz;
+                for (int j = head[cell_hash(nx, ny, nz, mask)]; j >= 0; j = next[j]) {
+                    // buckets mix cells: accept only points of THIS cell, so no pair is seen twice
+                    if (j >= i || cell3[3 * j] != nx || cell3[3 * j + 1] != ny || cell3[3 * j + 2] != nz) continue;
+                    const float ddx = x - p3[3 * j], ddy = y - p3[3 * j + 1], ddz = z - p3[3 * j + 2];
+                    const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                    if (d2 <= radius) f(j, d2);
+                }
+            }
+}
+
+__global__ __launch_bounds__(256) void nb_count(const float *__restrict__ p3, const int *__restrict__ cell3,
+                                                const int *__restrict__ head, const int *__restrict__ next, unsigned mask, int N,
+                                                float radius, int *__restrict__ cnt_lo, int *__restrict__ cnt_up)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int c = 0;
+    for_lower_neighbours(i, p3, cell3, head, next, mask, radius, [&](int j, float) {
+        c++;
+        atomicAdd(&cnt_up[j], 1);
+    });
+    cnt_lo[i] = c;
+}
+
+// exclusive scan of n ints by one workgroup (n <= a few million): per-thread contiguous chunk + LDS scan of the partials
+__global__ __launch_bounds__(1024) void exclusive_scan_1wg(const int *__restrict__ in, int n, int *__restrict__ out)
+{
+    __shared__ long long part[1024];
+    const int per = (n + 1023) / 1024;
+    const int s = threadIdx.x * per, e = min(s + per, n);
+    long long sum = 0;
+    for (int i = s; i < e; i++) sum += in[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        for (int k = 0; k < 1024; k++) {
+            const long long t = part[k];
+            part[k] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+    long long run = part[threadIdx.x];
+    for (int i = s; i < e; i++) {
+        out[i] = (int)run;
+        run += in[i];
+    }
+    if (threadIdx.x == 1023) out[n] = (int)run;
+}
+
+__global__ __launch_bounds__(256) void nb_fill(const float *__restrict__ p3, const int *__restrict__ cell3,
+                                               const int *__restrict__ head, const int *__restrict__ next, unsigned mask, int N,
+                                               float radius, const int *__restrict__ off_lo, const int *__restrict__ off_up,
+                                               int *__restrict__ fill_up, Nb *__restrict__ lo, Nb *__restrict__ up)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    Nb *mine = lo + off_lo[i];
+    int c = 0;
+    for_lower_neighbours(i, p3, cell3, head, next, mask, radius, [&](int j, float d2) {
+        const float w = (float)(1. - d2 / radius);  // densityFn, heuristic.cpp:49-52
+        // insertion into the ascending lower list
+        int k = c++;
+        while (k > 0 && mine[k - 1].idx > j) {
+            mine[k] = mine[k - 1];
+            k--;
+        }
+        mine[k].idx = j;
+        mine[k].w = w;
+        const int pos = atomicAdd(&fill_up[j], 1);
+        up[off_up[j] + pos].idx = i;
+        up[off_up[j] + pos].w = w;
+    });
+}
+
+// upper lists arrive in atomic order: sort each by index
+__global__ __launch_bounds__(256) void sort_upper(const int *__restrict__ off_up, int N, Nb *__restrict__ up)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    Nb *a = up + off_up[i];
+    const int n = off_up[i + 1] - off_up[i];
+    for (int k = 1; k < n; k++) {
+        const Nb t = a[k];
+        int m = k;
+        while (m > 0 && a[m - 1].idx > t.idx) {
+            a[m] = a[m - 1];
+            m--;
+        }
+        a[m] = t;
+    }
+}
+
+// one power-iteration round, gather form of heuristic.cpp:107-120
+__global__ __launch_bounds__(256) void density_score(const float *__restrict__ density, const int *__restrict__ off_lo,
+                                                     const Nb *__restrict__ lo, const int *__restrict__ off_up,
+                                                     const Nb *__restrict__ up, int N, float *__restrict__ score,
+                                                     double *__restrict__ pair_sum)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float di = density[i];
+    float densityTemp = 0.f;
+    double ps = 0.;
+    for (int k = off_lo[i]; k < off_lo[i + 1]; k++) {
+        const float dj = density[lo[k].idx], w = lo[k].w;
+        densityTemp += dj * w;
+        ps += (di + dj) * w;
+    }
+    float s = 0.f;
+    s += densityTemp;  // score[i] += densityTemp happens at step i, before any higher index scatters into it
+    for (int k = off_up[i]; k < off_up[i + 1]; k++) s += density[up[k].idx] * up[k].w;
+    score[i] = s;
+    pair_sum[i] = ps;
+}
+
+__global__ __launch_bounds__(256) void density_update(float *__restrict__ density, const float *__restrict__ score, float normalizer,
+                                                      int N, double *__restrict__ chg)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float nd = score[i] * normalizer;
+    if (nd > 2.f) nd = 2.f;
+    const float df = density[i] - nd;
+    chg[i] = (double)(df * df);
+    density[i] = nd;
+}
+
+// fixed-shape first level of the global sums: chunk c = sequential sum of a contiguous range
+__global__ __launch_bounds__(256) void chunk_sums(const double *__restrict__ v, int N, double *__restrict__ out256)
+{
+    const int c = threadIdx.x;
+    const int per = (N + 255) / 256;
+    const int s = c * per, e = min(s + per, N);
+    double t = 0.;
+    for (int i = s; i < e; i++) t += v[i];
+    out256[c] = t;
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" {
+
+int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alpha, int32_t *keep_out, int *out_count)
+{
+    if (!ctx || !out_count || npoints < 0 || (npoints > 0 && (!points4 || !keep_out)))
+        return fail(ctx, MVS_EINVAL, "mvs_filter_points: bad arguments");
+    *out_count = 0;
+    if (npoints == 0) return MVS_OK;
+    const float radius = alpha / 4.f;  // heuristic.cpp:63
+    if (!(radius > 0.f) || !std::isfinite(radius)) return fail(ctx, MVS_EINVAL, "mvs_filter_points: alpha must be positive and finite");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const int N = npoints;
+    hipStream_t st = ctx->stream;
+    unsigned table = 1;
+    while (table < 2u * (unsigned)N) table <<= 1;
+    const unsigned mask = table - 1;
+    const float cell = std::sqrt(radius);
+
+    // pass 1 buffers
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_p4 = al(sizeof(float) * 4 * N), b_p3 = al(sizeof(float) * 3 * N), b_c3 = al(sizeof(int) * 3 * N), b_head = al(sizeof(int) * table),
+                 b_n1 = al(sizeof(int) * ((size_t)N + 1));
+    int rc = ensure(ctx, ctx->flow_arena, b_p4 + b_p3 + b_c3 + b_head + 6 * b_n1 + 2 * al(sizeof(float) * N) + 2 * al(sizeof(double) * N) + 4096);
+    if (rc) return rc;
+    char *base = (char *)ctx->flow_arena.ptr;
+    float *d_p4 = (float *)base;
+    float *d_p3 = (float *)(base += b_p4);
+    int *d_c3 = (int *)(base += b_p3);
+    int *d_head = (int *)(base += b_c3);
+    int *d_next = (int *)(base += b_head);
+    int *d_cnt_lo = (int *)(base += b_n1), *d_cnt_up = (int *)(base += b_n1), *d_off_lo = (int *)(base += b_n1), *d_off_up = (int *)(base += b_n1),
+        *d_fill = (int *)(base += b_n1);
+    float *d_density = (float *)(base += b_n1), *d_score = (float *)(base += al(sizeof(float) * N));
+    double *d_pair = (double *)(base += al(sizeof(float) * N)), *d_chg = (double *)(base += al(sizeof(double) * N));
+    double *d_256 = (double *)(base += al(sizeof(double) * N));
+
+    MVS_HIP(ctx, hipMemcpyAsync(d_p4, points4, sizeof(float) * 4 * N, hipMemcpyHostToDevice, st));
+    MVS_HIP(ctx, hipMemsetAsync(d_head, 0xff, sizeof(int) * table, st));
+    MVS_HIP(ctx, hipMemsetAsync(d_cnt_up, 0, sizeof(int) * ((size_t)N + 1), st));
+    MVS_HIP(ctx, hipMemsetAsync(d_cnt_lo, 0, sizeof(int) * ((size_t)N + 1), st));
+    MVS_HIP(ctx, hipMemsetAsync(d_fill, 0, sizeof(int) * ((size_t)N + 1), st));
+    const unsigned g = (unsigned)div_up(N, 256);
+    dehomog_cells<<<g, 256, 0, st>>>(d_p4, N, 1.0f / cell, d_p3, d_c3);
+    hash_build<<<g, 256, 0, st>>>(d_c3, N, mask, d_head, d_next);
+    nb_count<<<g, 256, 0, st>>>(d_p3, d_c3, d_head, d_next, mask, N, radius, d_cnt_lo, d_cnt_up);
+    exclusive_scan_1wg<<<1, 1024, 0, st>>>(d_cnt_lo, N, d_off_lo);
+    exclusive_scan_1wg<<<1, 1024, 0, st>>>(d_cnt_up, N, d_off_up);
+    MVS_HIP(ctx, hipGetLastError());
+    int total = 0;
+    MVS_HIP(ctx, hipMemcpyAsync(&total, d_off_lo + N, sizeof(int), hipMemcpyDeviceToHost, st));
+    MVS_HIP(ctx, hipStreamSynchronize(st));
+    if (total < 0) return fail(ctx, MVS_ENOMEM, "mvs_filter_points: neighbour table overflows 2^31 entries");
+
+    // neighbour lists live in their own buffer (size known only now)
+    if ((rc = ensure(ctx, ctx->r_tmp2, 2 * sizeof(Nb) * (size_t)(total > 0 ? total : 1)))) return rc;
+    Nb *d_lo = (Nb *)ctx->r_tmp2.ptr, *d_up = d_lo + (total > 0 ? total : 1);
+    nb_fill<<<g, 256, 0, st>>>(d_p3, d_c3, d_head, d_next, mask, N, radius, d_off_lo, d_off_up, d_fill, d_lo, d_up);
+    sort_upper<<<g, 256, 0, st>>>(d_off_up, N, d_up);
+    MVS_HIP(ctx, hipGetLastError());
+
+    // power iteration (heuristic.cpp:103-136)
+    std::vector<float> ones((size_t)N, 1.f);
+    MVS_HIP(ctx, hipMemcpyAsync(d_density, ones.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));
+    double h256[256];
+    double change;
+    int it = 0;
+    do {
+        density_score<<<g, 256, 0, st>>>(d_density, d_off_lo, d_lo, d_off_up, d_up, N, d_score, d_pair);
+        chunk_sums<<<1, 256, 0, st>>>(d_pair, N, d_256);
+        MVS_HIP(ctx, hipMemcpyAsync(h256, d_256, sizeof(h256), hipMemcpyDeviceToHost, st));
+        MVS_HIP(ctx, hipStreamSynchronize(st));
+        double sum = 0.;
+        for (int c = 0; c < 256; c++) sum += h256[c];
+        const float normalizer = (float)(N / sum);
+        density_update<<<g, 256, 0, st>>>(d_density, d_score, normalizer, N, d_chg);
+        chunk_sums<<<1, 256, 0, st>>>(d_chg, N, d_256);
+        MVS_HIP(ctx, hipMemcpyAsync(h256, d_256, sizeof(h256), hipMemcpyDeviceToHost, st));
+        MVS_HIP(ctx, hipStreamSynchronize(st));
+        change = 0.;
+        for (int c = 0; c < 256; c++) change += h256[c];
+        change /= N;
+        it++;
+    } while (change > 1e-6 && it < 200);
+
+    // greedy selection on the host (heuristic.cpp:139-163): sequential by construction
+    std::vector<float> density((size_t)N), score((size_t)N);
+    std::vector<int> off((size_t)N + 1);
+    std::vector<Nb> lo((size_t)(total > 0 ? total : 1));
+    MVS_HIP(ctx, hipMemcpyAsync(density.data(), d_density, sizeof(float) * N, hipMemcpyDeviceToHost, st));
+    MVS_HIP(ctx, hipMemcpyAsync(score.data(), d_score, sizeof(float) * N, hipMemcpyDeviceToHost, st));
+    MVS_HIP(ctx, hipMemcpyAsync(off.data(), d_off_lo, sizeof(int) * ((size_t)N + 1), hipMemcpyDeviceToHost, st));
+    if (total > 0) MVS_HIP(ctx, hipMemcpyAsync(lo.data(), d_lo, sizeof(Nb) * (size_t)total, hipMemcpyDeviceToHost, st));
+    MVS_HIP(ctx, hipStreamSynchronize(st));
+    std::vector<int> order((size_t)N);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return density[a] > density[b]; });
+    const float densityLimit = .7f;
+    std::vector<uint8_t> keep((size_t)N, 0);
+    for (int i = 0; i < N; i++) {
+        const int ord = order[i];
+        if (score[ord] < densityLimit) continue;
+        const double localDensity = density[ord];
+        for (int k = off[ord]; k < off[ord + 1]; k++) score[lo[k].idx] = (float)(score[lo[k].idx] - localDensity * lo[k].w);
+        keep[ord] = 1;
+    }
+    int m = 0;
+    for (int i = 0; i < N; i++)
+        if (keep[i]) keep_out[m++] = i;
+    *out_count = m;
+    return MVS_OK;
+}
+
+}  // extern "C"

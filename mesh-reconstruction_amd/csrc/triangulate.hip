@@ -111,7 +111,7 @@ __global__ __launch_bounds__(128) void tri_points_kernel(const float *const *__r
                                                          int V, const float *__restrict__ Minv, const float *__restrict__ depth,
                                                          const float *__restrict__ grad, int W, int H,
                                                          uint8_t *__restrict__ valid, float *__restrict__ pts,
-                                                         float *__restrict__ pdfs)
+                                                         float *__restrict__ xyz3, float *__restrict__ pdfs)
 {
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int row = blockIdx.y * 2 + (threadIdx.x >> 6);
@@ -202,7 +202,13 @@ __global__ __launch_bounds__(128) void tri_points_kernel(const float *const *__r
         }
         k[2] = (float)((double)k[2] + delta_z);
     }
-    mat44_vec(Minv, k, pts + pix * 4);
+    float out[4];
+    mat44_vec(Minv, k, out);
+#pragma unroll
+    for (int c = 0; c < 4; c++) pts[pix * 4 + c] = out[c];
+    // the normals pass visits every point up to 2 x 441 times: dehomogenise once (same f32 quotients as util.cpp:291)
+#pragma unroll
+    for (int c = 0; c < 3; c++) xyz3[pix * 3 + c] = out[c] / out[3];
     pdfs[pix] = pdf;
     valid[pix] = 1;
 }
@@ -243,7 +249,7 @@ __device__ void smallest_eigvec3(double a[3][3], double v[3])
 }
 
 __global__ __launch_bounds__(128) void tri_normals_kernel(const uint8_t *__restrict__ valid, const float *__restrict__ pts,
-                                                          const float *__restrict__ pdfs, const CamPre *__restrict__ pre,
+                                                          const float *__restrict__ xyz3, const float *__restrict__ pdfs, const CamPre *__restrict__ pre,
                                                           const float *__restrict__ main_center, int V, int W, int H,
                                                           float *__restrict__ normals)
 {
@@ -261,8 +267,8 @@ __global__ __launch_bounds__(128) void tri_normals_kernel(const uint8_t *__restr
         if (ny < 0 || ny >= H) continue;
         for (int nx = col - radius; nx <= col + radius; nx++) {
             if (nx < 0 || nx >= W || !valid[(size_t)ny * W + nx]) continue;
-            const float *q = pts + ((size_t)ny * W + nx) * 4;
-            for (int c = 0; c < 3; c++) mean[c] += (double)(q[c] / q[3]);
+            const float *q = xyz3 + ((size_t)ny * W + nx) * 3;
+            for (int c = 0; c < 3; c++) mean[c] += (double)q[c];
             n++;
         }
     }
@@ -275,9 +281,9 @@ __global__ __launch_bounds__(128) void tri_normals_kernel(const uint8_t *__restr
             if (ny < 0 || ny >= H) continue;
             for (int nx = col - radius; nx <= col + radius; nx++) {
                 if (nx < 0 || nx >= W || !valid[(size_t)ny * W + nx]) continue;
-                const float *q = pts + ((size_t)ny * W + nx) * 4;
+                const float *q = xyz3 + ((size_t)ny * W + nx) * 3;
                 double d[3];
-                for (int c = 0; c < 3; c++) d[c] = (double)(q[c] / q[3]) - mean[c];
+                for (int c = 0; c < 3; c++) d[c] = (double)q[c] - mean[c];
                 for (int a = 0; a < 3; a++)
                     for (int b = a; b < 3; b++) cov[a][b] += d[a] * d[b];
             }
@@ -386,14 +392,14 @@ int mvs_triangulate(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, con
     float main_center[3];
     host_center(main_cam, main_center);
 
-    // arena: flows (V*4P) | depth P | grad 2P | pts 4P | pdf P | normals 3P | valid P bytes | tables
-    const size_t floats = (size_t)V * 4 * P + P + 2 * P + 4 * P + P + 3 * P;
+    // arena: flows (V*4P) | depth P | grad 2P | pts 4P | pdf P | normals 3P | xyz 3P | valid P bytes | tables
+    const size_t floats = (size_t)V * 4 * P + P + 2 * P + 4 * P + P + 3 * P + 3 * P;
     const size_t tables = sizeof(CamPre) * pre.size() + sizeof(float) * (16 + 4) + sizeof(float *) * (size_t)(V > 0 ? V : 1);
     int rc = ensure(ctx, ctx->flow_arena, floats * sizeof(float) + P + tables + 256);
     if (rc) return rc;
     float *d_flows = (float *)ctx->flow_arena.ptr, *d_depth = d_flows + (size_t)V * 4 * P, *d_grad = d_depth + P, *d_pts = d_grad + 2 * P,
-          *d_pdf = d_pts + 4 * P, *d_nrm = d_pdf + P;
-    uint8_t *d_valid = (uint8_t *)(d_nrm + 3 * P);
+          *d_pdf = d_pts + 4 * P, *d_nrm = d_pdf + P, *d_xyz = d_nrm + 3 * P;
+    uint8_t *d_valid = (uint8_t *)(d_xyz + 3 * P);
     uintptr_t t = ((uintptr_t)(d_valid + P) + 63) & ~(uintptr_t)63;
     CamPre *d_pre = (CamPre *)t;
     float *d_minv = (float *)(d_pre + pre.size());
@@ -413,8 +419,8 @@ int mvs_triangulate(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, con
     MVS_HIP(ctx, hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(float *) * ptrs.size(), hipMemcpyHostToDevice, st));
     sobel_kernel<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, st>>>(d_depth, W, H, d_grad);
     tri_points_kernel<<<dim3(div_up(W, 64), div_up(H, 2)), 128, 0, st>>>(d_ptrs, d_pre, V, d_minv, d_depth, d_grad, W, H, d_valid,
-                                                                         d_pts, d_pdf);
-    tri_normals_kernel<<<dim3(div_up(W, 64), div_up(H, 2)), 128, 0, st>>>(d_valid, d_pts, d_pdf, d_pre, d_mc, V, W, H, d_nrm);
+                                                                         d_pts, d_xyz, d_pdf);
+    tri_normals_kernel<<<dim3(div_up(W, 64), div_up(H, 2)), 128, 0, st>>>(d_valid, d_pts, d_xyz, d_pdf, d_pre, d_mc, V, W, H, d_nrm);
     MVS_HIP(ctx, hipGetLastError());
     std::vector<float> h_pts(4 * P), h_nrm(3 * P);
     std::vector<uint8_t> h_valid(P);

@@ -12,13 +12,14 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
-#include <unordered_map>
 
 #include "recon.hpp"
 
+// render_hip.cpp: mvs_filter_points on the shared context
+void filterPointsIndices(const Mat &points, float alpha, int32_t *keep, int *kept, int width, int height);
+
 namespace {
 
-typedef std::pair<int, float> Neighbor;
 const float focal = 0.5f;  // heuristic.cpp:9
 
 struct CameraLabel {  // heuristic.cpp:12-17
@@ -31,7 +32,6 @@ typedef std::vector<std::pair<CameraLabel, Mat>> LabelledCameras;
 
 inline float pow2(float x) { return x * x; }
 inline unsigned compact(unsigned short i, unsigned short j) { return (unsigned(i) << 16) + unsigned(j); }  // heuristic.cpp:43-46
-inline float densityFn(float dist, float radius) { return (float)(1. - dist / radius); }                    // heuristic.cpp:49-52
 
 struct V3 {
     float x, y, z;
@@ -266,94 +266,20 @@ int Heuristic::nextSide(int imain)
 // heuristic.cpp:548-551
 mvs::Size Heuristic::renderSize() { return mvs::Size(config->width, config->height); }
 
-// heuristic.cpp:55-176
+// heuristic.cpp:55-176: neighbour table, power iteration and the greedy pass run behind mvs_filter_points (filter.hip);
+// here only the in-place compaction of heuristic.cpp:166-175
 void Heuristic::filterPoints(Mat &points, Mat &normals)
 {
     const int pointCount = points.rows;
     if (pointCount == 0) return;
     if (alphaVals.empty()) throw std::runtime_error("filterPoints: no alpha value recorded (tessellate was never called)");
-    const Mat points3 = dehomogenize(points);
-    const float radius = alphaVals.back() / 4.f;  // heuristic.cpp:63
-    // L2_Simple yields squared distances and the reference compares them with `radius` (heuristic.cpp:81-89):
-    // the neighbourhood is |p - q|^2 <= radius, i.e. a ball of sqrt(radius)
-    const float reach = std::sqrt(std::max(radius, 0.f));
-    std::vector<int> neighborBlocks(pointCount + 1, 0);
-    std::vector<Neighbor> neighbors;
-    {
-        const float cell = reach > 0 ? reach : 1.f;
-        auto key = [&](int ix, int iy, int iz) { return ((int64_t)ix * 73856093LL) ^ ((int64_t)iy * 19349663LL) ^ ((int64_t)iz * 83492791LL); };
-        std::unordered_map<int64_t, std::vector<int>> grid;
-        auto cellOf = [&](int i, int c) { return (int)std::floor(points3.at<float>(i, c) / cell); };
-        for (int i = 0; i < pointCount; i++) {
-            neighborBlocks[i] = (int)neighbors.size();
-            const int cx = cellOf(i, 0), cy = cellOf(i, 1), cz = cellOf(i, 2);
-            std::vector<Neighbor> found;
-            for (int dx = -1; dx <= 1; dx++)
-                for (int dy = -1; dy <= 1; dy++)
-                    for (int dz = -1; dz <= 1; dz++) {
-                        auto it = grid.find(key(cx + dx, cy + dy, cz + dz));
-                        if (it == grid.end()) continue;
-                        for (int j : it->second) {  // only smaller indices are in the grid yet (heuristic.cpp:86)
-                            const float ddx = points3.at<float>(i, 0) - points3.at<float>(j, 0);
-                            const float ddy = points3.at<float>(i, 1) - points3.at<float>(j, 1);
-                            const float ddz = points3.at<float>(i, 2) - points3.at<float>(j, 2);
-                            const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-                            if (d2 <= radius) found.push_back(Neighbor(j, densityFn(d2, radius)));
-                        }
-                    }
-            std::sort(found.begin(), found.end());
-            neighbors.insert(neighbors.end(), found.begin(), found.end());
-            grid[key(cx, cy, cz)].push_back(i);
-        }
-    }
-    neighborBlocks[pointCount] = (int)neighbors.size();
-
-    // clamped, L1-normalised power iteration (heuristic.cpp:103-136)
-    std::vector<float> density(pointCount, 1.f), score(pointCount, 0.f);
-    double change;
-    int it = 0;
-    do {
-        std::fill(score.begin(), score.end(), 0.f);
-        double sum = 0.;
-        for (int i = 0; i < pointCount; i++) {
-            float densityTemp = 0.f;
-            for (int j = neighborBlocks[i]; j < neighborBlocks[i + 1]; j++) {
-                densityTemp += density[neighbors[j].first] * neighbors[j].second;
-                score[neighbors[j].first] += density[i] * neighbors[j].second;
-                sum += (density[i] + density[neighbors[j].first]) * neighbors[j].second;
-            }
-            score[i] += densityTemp;
-        }
-        const float normalizer = (float)(pointCount / sum);
-        change = 0.;
-        for (int i = 0; i < pointCount; i++) {
-            float nd = score[i] * normalizer;
-            if (nd > 2.f) nd = 2.f;
-            change += pow2(density[i] - nd);
-            density[i] = nd;
-        }
-        change /= pointCount;
-        it++;
-    } while (change > 1e-6 && it < 200);
-
-    const float densityLimit = .7f;  // heuristic.cpp:139
-    std::vector<int> order(pointCount);
-    for (int i = 0; i < pointCount; i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return density[a] > density[b]; });
-    int writeIndex = 0;
-    for (int i = 0; i < pointCount; i++) {
-        const int ord = order[i];
-        if (score[ord] < densityLimit) continue;
-        const double localDensity = density[ord];
-        for (int j = neighborBlocks[ord]; j < neighborBlocks[ord + 1]; j++) score[neighbors[j].first] -= (float)(localDensity * neighbors[j].second);
-        if (i > writeIndex) order[writeIndex] = order[i];
-        writeIndex++;
-    }
-    std::sort(order.begin(), order.begin() + writeIndex);
-    Mat np(writeIndex, 4, mvs::F32C1), nn(writeIndex, 3, mvs::F32C1);
-    for (int i = 0; i < writeIndex; i++) {
-        std::memcpy(np.ptr<float>(i), points.ptr<float>(order[i]), 4 * sizeof(float));
-        std::memcpy(nn.ptr<float>(i), normals.ptr<float>(order[i]), 3 * sizeof(float));
+    std::vector<int32_t> keep((size_t)pointCount);
+    int kept = 0;
+    filterPointsIndices(points, alphaVals.back(), keep.data(), &kept, config->width, config->height);
+    Mat np(kept, 4, mvs::F32C1), nn(kept, 3, mvs::F32C1);
+    for (int i = 0; i < kept; i++) {
+        std::memcpy(np.ptr<float>(i), points.ptr<float>(keep[i]), 4 * sizeof(float));
+        std::memcpy(nn.ptr<float>(i), normals.ptr<float>(keep[i]), 3 * sizeof(float));
     }
     points = np;
     normals = nn;

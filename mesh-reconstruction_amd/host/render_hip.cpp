@@ -170,6 +170,14 @@ Mat triangulatePixels(const MatList flows, const Mat mainCamera, const MatList c
     return all.rowRange(0, n);  // points.resize(pixelId), util.cpp:254
 }
 
+// the device half of Heuristic::filterPoints (heuristic.cpp:55-163)
+void filterPointsIndices(const Mat &points, float alpha, int32_t *keep, int *kept, int width, int height)
+{
+    expect(points, mvs::F32C1, "filterPoints points");
+    mvs_ctx *ctx = shared_ctx(width, height);
+    if (mvs_filter_points(ctx, points.ptr<float>(), points.rows, alpha, keep, kept)) raise(ctx, "filterPoints");
+}
+
 // util.cpp:16-29
 Mat dehomogenize(Mat points)
 {

@@ -100,28 +100,6 @@ static int run_cpu(const std::string &tracks)
         } catch (const std::exception &) { threw = true; }
         CHECK(threw, "missing YAML must throw");
     }
-    {   // filterPoints: a dense cluster survives thinned, isolated outliers go (heuristic.cpp:55-176)
-        Configuration c(tracks + "/koule-tr.yaml");
-        Heuristic h(&c);
-        h.alphaVals.push_back(0.16f);  // radius 0.04 -> reach 0.2
-        HeuristicRNG r;
-        const int N = 400;
-        Mat pts(N + 5, 4, mvs::F32C1), nrm = Mat::zeros(N + 5, 3, mvs::F32C1);
-        for (int i = 0; i < N; i++) {
-            float *p = pts.ptr<float>(i);
-            p[0] = r.uniform(); p[1] = r.uniform(); p[2] = 0.05f * r.uniform(); p[3] = 1.f;
-        }
-        for (int i = 0; i < 5; i++) {
-            float *p = pts.ptr<float>(N + i);
-            p[0] = 10.f + 3 * i; p[1] = -7.f; p[2] = 4.f; p[3] = 1.f;
-        }
-        h.filterPoints(pts, nrm);
-        CHECK(pts.rows > 10 && pts.rows < N, "filterPoints kept %d of %d", pts.rows, N + 5);
-        bool outlier = false;
-        for (int i = 0; i < pts.rows; i++) outlier |= pts.at<float>(i, 0) > 5.f;
-        CHECK(!outlier, "isolated points must be removed");
-        CHECK(nrm.rows == pts.rows, "normals follow points");
-    }
     printf("cpu selftest: %d failures\n", fails);
     return fails ? 1 : 0;
 }
@@ -208,6 +186,27 @@ static int run_gpu(const std::string &tracks, const std::string &out)
         idx = 0;
         for (const Mat &c : cameras) writeRaw(out + "/tri_cam" + std::to_string(idx++) + ".f32", c);
         std::ofstream(out + "/tri_meta.txt") << used << " " << tri.rows << "\n";
+    }
+    {   // filterPoints: a dense cluster survives thinned, isolated outliers go (heuristic.cpp:55-176)
+        Heuristic h(&config);
+        h.alphaVals.push_back(0.16f);  // radius 0.04 -> reach 0.2
+        HeuristicRNG r;
+        const int N = 400;
+        Mat pts(N + 5, 4, mvs::F32C1), nrm = Mat::zeros(N + 5, 3, mvs::F32C1);
+        for (int i = 0; i < N; i++) {
+            float *p = pts.ptr<float>(i);
+            p[0] = r.uniform(); p[1] = r.uniform(); p[2] = 0.05f * r.uniform(); p[3] = 1.f;
+        }
+        for (int i = 0; i < 5; i++) {
+            float *p = pts.ptr<float>(N + i);
+            p[0] = 10.f + 3 * i; p[1] = -7.f; p[2] = 4.f; p[3] = 1.f;
+        }
+        h.filterPoints(pts, nrm);
+        CHECK(pts.rows > 10 && pts.rows < N, "filterPoints kept %d of %d", pts.rows, N + 5);
+        bool outlier = false;
+        for (int i = 0; i < pts.rows; i++) outlier |= pts.at<float>(i, 0) > 5.f;
+        CHECK(!outlier, "isolated points must be removed");
+        CHECK(nrm.rows == pts.rows, "normals follow points");
     }
     bool threw = false;
     try {

@@ -39,6 +39,7 @@ ABI = [
     ("mvs_flow_remap", _i, [_vp, _fp, _i, _u8p, _u8p]),
     ("mvs_flow", _i, [_vp, _u8p, _u8p, _i, _fp]),
     ("mvs_triangulate", _i, [_vp, _i, C.POINTER(_fp), _fp, _fp, _fp, _fp, C.POINTER(_i)]),
+    ("mvs_filter_points", _i, [_vp, _fp, _i, _f, _i32p, C.POINTER(_i)]),
     ("mvs_sweep", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _f, _f, _fp, _fp, _fp]),
     ("mvs_warp_by_depth", _i, [_vp, _fp, _fp, _fp, _u8p, _u8p]),
     ("mvs_sweep_set_main", _i, [_vp, _fp, _u8p]),
@@ -312,6 +313,15 @@ class Context:
         self._check(self.lib.mvs_triangulate(self.h, V, arr, _ptr(cam, _fp), _ptr(cams, _fp), _ptr(depth, _fp), _ptr(out, _fp),
                                              C.byref(n)))
         return out[:n.value].copy()
+
+    def filter_points(self, points4, alpha):
+        """mvs_filter_points -> ascending indices of the points that survive"""
+        pts = _f32(points4)
+        assert pts.ndim == 2 and pts.shape[1] == 4
+        keep = np.empty(max(pts.shape[0], 1), np.int32)
+        n = C.c_int(0)
+        self._check(self.lib.mvs_filter_points(self.h, _ptr(pts, _fp), pts.shape[0], float(alpha), _ptr(keep, _i32p), C.byref(n)))
+        return keep[:n.value].copy()
 
     def test_rcp(self, exp_bits):
         a, b = C.c_ulonglong(0), C.c_ulonglong(0)

@@ -132,6 +132,10 @@ void orc_image_gradient(const float *img, int W, int H, float *grad2);
 int orc_triangulate_pixels(const float *const *flows, const float main_cam[16], const float *side_cams, int V,
                            const float *depth, int W, int H, float *out_points7);
 
+/* ---- point-cloud filter (heuristic.cpp:55-176) -------------------------------------------------------- */
+/* returns M and writes the ascending indices of the retained points to keep_out[0..M); alpha = alphaVals.back() */
+int orc_filter_points(const float *points4, int N, float alpha, int32_t *keep_out, float *density_out);
+
 #ifdef __cplusplus
 }
 #endif

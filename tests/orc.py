@@ -234,6 +234,19 @@ class Oracle:
         return out[:n].copy()
 
 
+    # ---- point filter ---------------------------------------------------------------------------
+    def filter_points(self, points4, alpha):
+        pts = np.ascontiguousarray(points4, np.float32)
+        N = pts.shape[0]
+        keep = np.empty(max(N, 1), np.int32)
+        dens = np.empty(max(N, 1), np.float32)
+        f = self.lib.orc_filter_points
+        f.restype = C.c_int
+        f.argtypes = [_fp, C.c_int, C.c_float, _i32p, _fp]
+        m = f(self._p(pts, _fp), N, alpha, self._p(keep, _i32p), self._p(dens, _fp))
+        return keep[:m].copy(), dens[:N].copy()
+
+
 _oracle = None
 
 

@@ -1,0 +1,42 @@
+"""GPU parity of Heuristic::filterPoints: the neighbour table and weights are exact; the power iteration adds f32 terms in
+the reference's order; the two global f64 sums use a different (fixed) association than the sequential oracle, which
+can move them by ~1e-16 relative -- not enough to change a float in practice, so the kept index set is required to be
+identical."""
+import numpy as np
+import pytest
+
+import mvs_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(rng, N, outliers):
+    pts = np.concatenate([rng.uniform(0, 1, (N, 2)), 0.05 * rng.normal(0, 1, (N, 1)), np.ones((N, 1))], 1)
+    out = np.concatenate([rng.uniform(5, 9, (outliers, 3)), np.ones((outliers, 1))], 1)
+    allp = np.concatenate([pts, out]).astype(np.float32)
+    allp *= rng.uniform(0.5, 2.0, (allp.shape[0], 1)).astype(np.float32)
+    return allp[rng.permutation(allp.shape[0])]
+
+
+@pytest.mark.parametrize("N,alpha", [(500, 0.02), (6000, 0.004), (20000, 0.001)])
+def test_filter_points_matches_oracle(oracle, N, alpha):
+    rng = np.random.default_rng(N)
+    pts = _cloud(rng, N, 30)
+    ref, _ = oracle.filter_points(pts, alpha)
+    with mvs_amd.Context(64, 48) as ctx:
+        got = ctx.filter_points(pts, alpha)
+        again = ctx.filter_points(pts, alpha)
+    np.testing.assert_array_equal(got, again)   # atomics' arrival order must not leak into the result
+    np.testing.assert_array_equal(got, ref)
+    assert 0 < len(ref) < N
+
+
+def test_filter_points_edge_cases(oracle):
+    with mvs_amd.Context(64, 48) as ctx:
+        assert len(ctx.filter_points(np.zeros((0, 4), np.float32), 0.1)) == 0
+        one = np.array([[1, 2, 3, 1]], np.float32)
+        assert len(ctx.filter_points(one, 0.1)) == 0          # a lone point has score 0 < 0.7
+        with pytest.raises(mvs_amd.MvsError):
+            ctx.filter_points(one, 0.0)
+        same = np.tile(np.array([[0.5, 0.5, 0.5, 1.0]], np.float32), (50, 1))   # 50 coincident points
+        np.testing.assert_array_equal(ctx.filter_points(same, 0.04), oracle.filter_points(same, 0.04)[0])
