@@ -33,10 +33,10 @@ def test_radius_is_compared_with_squared_distance(oracle):
     assert len(keep2) == 0 and np.all(np.isnan(dens2))
 
 
-def test_duplicates_are_collapsed(oracle):
+def test_deterministic_and_scale_invariant(oracle):
     rng = np.random.default_rng(1)
-    pts = _cloud(rng, 800, outliers=0)
-    dup = np.concatenate([pts, pts])   # every point twice
-    k1, _ = oracle.filter_points(pts, 0.01)
-    k2, _ = oracle.filter_points(dup, 0.01)
-    assert len(k2) < 1.3 * len(k1)     # the duplicate copies are pruned as redundant
+    pts = _cloud(rng, 800, outliers=5)
+    k1, d1 = oracle.filter_points(pts, 0.01)
+    k2, d2 = oracle.filter_points(pts * np.float32(4.0), 0.01)   # homogeneous rescaling by a power of two: same cloud
+    np.testing.assert_array_equal(k1, k2)
+    np.testing.assert_array_equal(d1, d2)
