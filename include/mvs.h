@@ -79,6 +79,15 @@ int mvs_flow(mvs_ctx *ctx, const uint8_t *prev_hw, const uint8_t *next_hw, int u
 int mvs_triangulate(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, const float main_cam[16],
                     const float *side_cams /* nviews*16 */, const float *depth_hw, float *out_points7, int *out_count);
 
+/* ---- one main frame, device resident: the body of the loop recon.cpp:65-117 ------------------------------------------ */
+/* depth(main) -> for every side view: projected -> mixBackground (depth mutated cumulatively) -> calculateFlow ->
+ * triangulatePixels, with every intermediate kept in HBM: frames go up once, only the points come back.  Bit-identical
+ * to calling mvs_depth / mvs_projected / mvs_mix_background / mvs_flow / mvs_triangulate in that order.
+ * out_points7 needs room for H*W rows; depth_after_hw (nullable) receives the depth map after the last mixBackground. */
+int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_frame_hw, int nside,
+                      const float *side_cams /* nside*16 */, const uint8_t *const *side_frames_hw, int use_farneback,
+                      float *out_points7, int *out_count, float *depth_after_hw);
+
 /* ---- point-cloud filter: replaces Heuristic::filterPoints (heuristic.cpp:55-176, recon.cpp:125) ------------------- */
 /* points4: npoints homogeneous rows; alpha = the reference's alphaVals.back() (radius = alpha/4, compared with squared
  * distances as the reference does).  keep_out receives the ascending indices of the retained points, *out_count how

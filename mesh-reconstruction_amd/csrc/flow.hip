@@ -626,6 +626,100 @@ static int variational_device(mvs_ctx *ctx, const float *I0, const float *I1, fl
     return MVS_OK;
 }
 
+struct FlowBufs {
+    float *arena, *f0, *f1, *flow2, *var, *out4;
+    uint8_t *p8, *n8, *r8;
+};
+
+static int flow_prepare(mvs_ctx *ctx, FlowBufs &b)
+{
+    const size_t P = (size_t)ctx->W * ctx->H;
+    // arena: work (36P floats, starts with 5P doubles) first, then f0, f1, flow2, var, out4; u8: prev, next, remapped
+    const size_t work = 36;
+    int rc;
+    if ((rc = ensure(ctx, ctx->flow_arena, sizeof(float) * P * (2 + 2 + 1 + 4 + work) + 3 * P + 256))) return rc;
+    b.arena = (float *)ctx->flow_arena.ptr;
+    b.f0 = b.arena + work * P;
+    b.f1 = b.f0 + P;
+    b.flow2 = b.f1 + P;
+    b.var = b.flow2 + 2 * P;
+    b.out4 = b.var + P;
+    b.p8 = (uint8_t *)(b.out4 + 4 * P);
+    b.n8 = b.p8 + P;
+    b.r8 = b.n8 + P;
+    if ((rc = ensure_cubic_table(ctx))) return rc;
+    return compare_prepare(ctx);
+}
+
+// flow.cpp:19-42 on the buffers of `b`: inputs b.p8 / b.n8 (u8), output b.out4.  Everything between is a fixed
+// sequence of kernels on fixed buffers: recorded once per algorithm as a hipGraph and replayed
+// (MVS_NO_GRAPH=1 forces eager launches).
+static int flow_run(mvs_ctx *ctx, const FlowBufs &b, int use_farneback)
+{
+    const int W = ctx->W, H = ctx->H;
+    const size_t P = (size_t)W * H;
+    hipStream_t st = ctx->stream;
+    auto enqueue = [&]() -> int {
+        u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(b.p8, b.f0, P);
+        u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(b.n8, b.f1, P);
+        int r;
+        if (use_farneback) {
+            const double poly_sigma = (H + W) / 1000.0;  // flow.cpp:24-25
+            const int winsize = (H + W) / 100, poly_n = poly_sigma < 1.5 ? 5 : 7;
+            if ((r = farneback_device(ctx, b.f0, b.f1, b.flow2, b.arena, 10, 0.8, winsize, 7, poly_n, poly_sigma))) return r;
+        } else {
+            MVS_HIP(ctx, hipMemsetAsync(b.flow2, 0, sizeof(float) * 2 * P, st));  // flow.cpp:31 (uninitialised there), A-11
+            if ((r = variational_device(ctx, b.f0, b.f1, b.flow2, b.arena))) return r;
+        }
+        if ((r = remap_device(ctx, b.flow2, 2, b.n8, b.r8))) return r;  // flow.cpp:34
+        if ((r = compare_device(ctx, b.p8, b.r8, b.var))) return r;
+        pack_flow4<<<g1(P), 256, 0, st>>>(b.flow2, b.var, b.out4, P);
+        MVS_HIP(ctx, hipGetLastError());
+        return MVS_OK;
+    };
+    const int gi = use_farneback ? 1 : 0;
+    static const bool no_graph = getenv("MVS_NO_GRAPH") != nullptr;
+    if (ctx->flow_graph[gi] && (ctx->flow_graph_arena[gi] != ctx->flow_arena.ptr || ctx->flow_graph_tmp[gi] != ctx->r_tmp1.ptr)) {
+        (void)hipGraphExecDestroy(ctx->flow_graph[gi]);
+        ctx->flow_graph[gi] = nullptr;
+    }
+    if (!ctx->flow_graph[gi] && !no_graph) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int r = enqueue();
+            const hipError_t e = hipStreamEndCapture(st, &graph);
+            if (r == MVS_OK && e == hipSuccess && graph && hipGraphInstantiate(&ctx->flow_graph[gi], graph, nullptr, nullptr, 0) == hipSuccess) {
+                ctx->flow_graph_arena[gi] = ctx->flow_arena.ptr;
+                ctx->flow_graph_tmp[gi] = ctx->r_tmp1.ptr;
+            } else {
+                ctx->flow_graph[gi] = nullptr;
+                (void)hipGetLastError();
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+    }
+    ProfileScope ps(ctx, MVS_K_FLOW);
+    if (ctx->flow_graph[gi]) {
+        MVS_HIP(ctx, hipGraphLaunch(ctx->flow_graph[gi], st));
+        return MVS_OK;
+    }
+    return enqueue();
+}
+
+// calculateFlow on device buffers (prev/next: H*W u8, out4: H*W*4 f32), all in-stream
+int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int use_farneback, float *out4_dev)
+{
+    const size_t P = (size_t)ctx->W * ctx->H;
+    FlowBufs b;
+    int rc = flow_prepare(ctx, b);
+    if (rc) return rc;
+    MVS_HIP(ctx, hipMemcpyAsync(b.p8, prev_dev, P, hipMemcpyDeviceToDevice, ctx->stream));
+    MVS_HIP(ctx, hipMemcpyAsync(b.n8, next_dev, P, hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = flow_run(ctx, b, use_farneback))) return rc;
+    MVS_HIP(ctx, hipMemcpyAsync(out4_dev, b.out4, sizeof(float) * 4 * P, hipMemcpyDeviceToDevice, ctx->stream));
+    return MVS_OK;
+}
+
 }  // namespace mvs
 
 using namespace mvs;
@@ -636,72 +730,15 @@ int mvs_flow(mvs_ctx *ctx, const uint8_t *prev_hw, const uint8_t *next_hw, int u
 {
     if (!ctx || !prev_hw || !next_hw || !out_hw4) return fail(ctx, MVS_EINVAL, "mvs_flow: null argument");
     MVS_HIP(ctx, hipSetDevice(ctx->device));
-    const int W = ctx->W, H = ctx->H;
-    const size_t P = (size_t)W * H;
-    int rc;
-    // arena: work (36P floats, starts with 5P doubles) first, then f0, f1, flow2, var, out4; u8: prev, next, remapped
-    const size_t work = 36;
-    if ((rc = ensure(ctx, ctx->flow_arena, sizeof(float) * P * (2 + 2 + 1 + 4 + work) + 3 * P + 256))) return rc;
-    float *arena = (float *)ctx->flow_arena.ptr, *f0 = arena + work * P, *f1 = f0 + P, *flow2 = f1 + P, *var = flow2 + 2 * P,
-          *out4 = var + P;
-    uint8_t *p8 = (uint8_t *)(out4 + 4 * P), *n8 = p8 + P, *r8 = n8 + P;
-    hipStream_t st = ctx->stream;
-    MVS_HIP(ctx, hipMemcpyAsync(p8, prev_hw, P, hipMemcpyHostToDevice, st));
-    MVS_HIP(ctx, hipMemcpyAsync(n8, next_hw, P, hipMemcpyHostToDevice, st));
-    // everything between the uploads and the download is a fixed sequence of kernels on fixed buffers: record it
-    // once per algorithm as a hipGraph and replay it (MVS_NO_GRAPH=1 forces eager launches)
-    if ((rc = ensure_cubic_table(ctx))) return rc;
-    if ((rc = compare_prepare(ctx))) return rc;
-    auto enqueue = [&]() -> int {
-        u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(p8, f0, P);
-        u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(n8, f1, P);
-        int r;
-        if (use_farneback) {
-            const double poly_sigma = (H + W) / 1000.0;  // flow.cpp:24-25
-            const int winsize = (H + W) / 100, poly_n = poly_sigma < 1.5 ? 5 : 7;
-            if ((r = farneback_device(ctx, f0, f1, flow2, arena, 10, 0.8, winsize, 7, poly_n, poly_sigma))) return r;
-        } else {
-            MVS_HIP(ctx, hipMemsetAsync(flow2, 0, sizeof(float) * 2 * P, st));  // flow.cpp:31 (uninitialised there), A-11
-            if ((r = variational_device(ctx, f0, f1, flow2, arena))) return r;
-        }
-        if ((r = remap_device(ctx, flow2, 2, n8, r8))) return r;  // flow.cpp:34
-        if ((r = compare_device(ctx, p8, r8, var))) return r;
-        pack_flow4<<<g1(P), 256, 0, st>>>(flow2, var, out4, P);
-        MVS_HIP(ctx, hipGetLastError());
-        return MVS_OK;
-    };
-    {
-        const int gi = use_farneback ? 1 : 0;
-        static const bool no_graph = getenv("MVS_NO_GRAPH") != nullptr;
-        if (ctx->flow_graph[gi] && (ctx->flow_graph_arena[gi] != ctx->flow_arena.ptr || ctx->flow_graph_tmp[gi] != ctx->r_tmp1.ptr)) {
-            (void)hipGraphExecDestroy(ctx->flow_graph[gi]);
-            ctx->flow_graph[gi] = nullptr;
-        }
-        if (!ctx->flow_graph[gi] && !no_graph) {
-            hipGraph_t graph = nullptr;
-            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                const int r = enqueue();
-                const hipError_t e = hipStreamEndCapture(st, &graph);
-                if (r == MVS_OK && e == hipSuccess && graph &&
-                    hipGraphInstantiate(&ctx->flow_graph[gi], graph, nullptr, nullptr, 0) == hipSuccess) {
-                    ctx->flow_graph_arena[gi] = ctx->flow_arena.ptr;
-                    ctx->flow_graph_tmp[gi] = ctx->r_tmp1.ptr;
-                } else {
-                    ctx->flow_graph[gi] = nullptr;
-                    (void)hipGetLastError();
-                }
-                if (graph) (void)hipGraphDestroy(graph);
-            }
-        }
-        ProfileScope ps(ctx, MVS_K_FLOW);
-        if (ctx->flow_graph[gi]) {
-            MVS_HIP(ctx, hipGraphLaunch(ctx->flow_graph[gi], st));
-        } else if ((rc = enqueue())) {
-            return rc;
-        }
-    }
-    MVS_HIP(ctx, hipMemcpyAsync(out_hw4, out4, sizeof(float) * 4 * P, hipMemcpyDeviceToHost, st));
-    MVS_HIP(ctx, hipStreamSynchronize(st));
+    const size_t P = (size_t)ctx->W * ctx->H;
+    FlowBufs b;
+    int rc = flow_prepare(ctx, b);
+    if (rc) return rc;
+    MVS_HIP(ctx, hipMemcpyAsync(b.p8, prev_hw, P, hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(ctx, hipMemcpyAsync(b.n8, next_hw, P, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = flow_run(ctx, b, use_farneback))) return rc;
+    MVS_HIP(ctx, hipMemcpyAsync(out_hw4, b.out4, sizeof(float) * 4 * P, hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MVS_OK;
 }
 

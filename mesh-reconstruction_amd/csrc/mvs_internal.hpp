@@ -60,6 +60,7 @@ struct mvs_ctx {
     mvs::DevBuf r_zbuf, r_shadow, r_frame, r_out3, r_tmp0, r_tmp1, r_tmp2;
     mvs::DevBuf cubic_tab;           // Q15 bicubic weights for remap (32*32*16 shorts)
     mvs::DevBuf flow_arena;          // optical-flow pyramids and work buffers
+    mvs::DevBuf frame_buf;           // mvs_process_frame: frames, depth, warped image, flows of one main frame
     // the launch-bound flow pipelines (~350 small kernels for Farneback) are captured once into a hipGraph per
     // algorithm and replayed; invalidated when the arena moves
     hipGraphExec_t flow_graph[2] = {nullptr, nullptr};
@@ -107,6 +108,13 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, float *out);
 int remap_device(mvs_ctx *ctx, const float *flow, int stride, const uint8_t *img, uint8_t *out);
 int ensure_cubic_table(mvs_ctx *ctx);
+// raster.hip / flow.hip / triangulate.hip on device buffers (pipeline.hip strings them together)
+int depth_device(mvs_ctx *ctx, const float cam[16], float *out_dev);
+int projected_device(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev);
+int mix_background_device(mvs_ctx *ctx, const uint8_t *img3_dev, const uint8_t *bg_dev, float *depth_dev, uint8_t *out_dev);
+int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int use_farneback, float *out4_dev);
+int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows, bool on_device, const float main_cam[16],
+                     const float *side_cams, const float *depth, float *out_points7, int *out_count);
 int compare_prepare(mvs_ctx *ctx);  // allocates compare_device's arena (must not happen during graph capture)
 
 }  // namespace mvs

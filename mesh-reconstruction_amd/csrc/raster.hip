@@ -343,6 +343,55 @@ static int run_raster(mvs_ctx *ctx, const float cam[16], int mode, float *zout, 
     return MVS_OK;
 }
 
+// ---- device-buffer forms (also used by pipeline.hip) -----------------------------------------------------------------
+
+int depth_device(mvs_ctx *ctx, const float cam[16], float *out_dev)
+{
+    if (!ctx->soup.ptr) return fail(ctx, MVS_ESTATE, "no mesh loaded (mvs_load_mesh)");
+    return run_raster(ctx, cam, 2, out_dev, nullptr);
+}
+
+// Render::projected on device buffers: frame_dev = H*W u8 (tight), out3_dev = H*W*3 u8
+int projected_device(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev)
+{
+    if (!ctx->soup.ptr) return fail(ctx, MVS_ESTATE, "no mesh loaded (mvs_load_mesh)");
+    const int W = ctx->W, H = ctx->H;
+    const size_t P = (size_t)W * H;
+    const int pitch = ((W + 2 + 63) / 64) * 64;
+    int rc;
+    if ((rc = ensure(ctx, ctx->r_zbuf, P * sizeof(float)))) return rc;       // main pass window z
+    if ((rc = ensure(ctx, ctx->r_shadow, 2 * P * sizeof(float) + sizeof(float) * (size_t)W))) return rc;  // raw, dilated, hf0
+    if ((rc = ensure(ctx, ctx->r_tmp0, P * sizeof(int)))) return rc;         // ids
+    if ((rc = ensure(ctx, ctx->r_frame, (size_t)pitch * (H + 2) + 64))) return rc;
+    float *sh_raw = (float *)ctx->r_shadow.ptr, *sh_dil = sh_raw + P, *hf0 = sh_dil + P;
+    pad_wrap_kernel<<<dim3(div_up(pitch, 256), H + 2), 256, 0, ctx->stream>>>(frame_dev, (uint8_t *)ctx->r_frame.ptr, W, H, pitch);
+    MVS_HIP(ctx, hipGetLastError());
+    // pass 1: shadow map from the projector, GL orientation, then the dilation quirk
+    if ((rc = run_raster(ctx, projector, 1, sh_raw, nullptr))) return rc;
+    row0_prefix_min<<<1, 256, 0, ctx->stream>>>(sh_raw, W, hf0);
+    MVS_HIP(ctx, hipGetLastError());
+    shadow_dilate<<<dim3(div_up(W, 256), H), 256, 0, ctx->stream>>>(sh_raw, hf0, W, H, sh_dil);
+    MVS_HIP(ctx, hipGetLastError());
+    // pass 2: main camera, then the fragment program on the visible faces
+    if ((rc = run_raster(ctx, cam, 0, (float *)ctx->r_zbuf.ptr, (int *)ctx->r_tmp0.ptr))) return rc;
+    CamArg prj;
+    memcpy(prj.m, projector, sizeof(prj.m));
+    ProfileScope ps(ctx, MVS_K_PROJECT);
+    project_texture<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, ctx->stream>>>(
+        (const float *)ctx->soup.ptr, (const TriRec *)ctx->r_tmp2.ptr, (const int *)ctx->r_tmp0.ptr, sh_dil,
+        (const uint8_t *)ctx->r_frame.ptr, pitch, prj, W, H, 1.0f / (float)W, 1.0f / (float)H, out3_dev);
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+int mix_background_device(mvs_ctx *ctx, const uint8_t *img3_dev, const uint8_t *bg_dev, float *depth_dev, uint8_t *out_dev)
+{
+    const size_t P = (size_t)ctx->W * ctx->H;
+    mix_background<<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(img3_dev, bg_dev, depth_dev, out_dev, P);
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
+}
+
 }  // namespace mvs
 
 using namespace mvs;
@@ -397,40 +446,12 @@ int mvs_projected(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_hw, co
     if (!ctx || !cam || !frame_hw || !projector || !out_hw3) return fail(ctx, MVS_EINVAL, "mvs_projected: null argument");
     if (!ctx->soup.ptr) return fail(ctx, MVS_ESTATE, "mvs_projected: no mesh loaded (mvs_load_mesh)");
     MVS_HIP(ctx, hipSetDevice(ctx->device));
-    const int W = ctx->W, H = ctx->H;
-    const size_t P = (size_t)W * H;
-    const int pitch = ((W + 2 + 63) / 64) * 64;
+    const size_t P = (size_t)ctx->W * ctx->H;
     int rc;
-    if ((rc = ensure(ctx, ctx->r_zbuf, P * sizeof(float)))) return rc;       // main pass window z
-    if ((rc = ensure(ctx, ctx->r_shadow, 2 * P * sizeof(float) + sizeof(float) * (size_t)W))) return rc;  // raw, dilated, hf0
-    if ((rc = ensure(ctx, ctx->r_tmp0, P * sizeof(int)))) return rc;         // ids
-    if ((rc = ensure(ctx, ctx->r_frame, (size_t)pitch * (H + 2) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->upload, P))) return rc;
     if ((rc = ensure(ctx, ctx->r_out3, 3 * P))) return rc;
-    float *sh_raw = (float *)ctx->r_shadow.ptr, *sh_dil = sh_raw + P, *hf0 = sh_dil + P;
-
     MVS_HIP(ctx, hipMemcpyAsync(ctx->upload.ptr, frame_hw, P, hipMemcpyHostToDevice, ctx->stream));
-    pad_wrap_kernel<<<dim3(div_up(pitch, 256), H + 2), 256, 0, ctx->stream>>>((const uint8_t *)ctx->upload.ptr,
-                                                                              (uint8_t *)ctx->r_frame.ptr, W, H, pitch);
-    MVS_HIP(ctx, hipGetLastError());
-    // pass 1: shadow map from the projector, GL orientation, then the dilation quirk
-    if ((rc = run_raster(ctx, projector, 1, sh_raw, nullptr))) return rc;
-    row0_prefix_min<<<1, 256, 0, ctx->stream>>>(sh_raw, W, hf0);
-    MVS_HIP(ctx, hipGetLastError());
-    shadow_dilate<<<dim3(div_up(W, 256), H), 256, 0, ctx->stream>>>(sh_raw, hf0, W, H, sh_dil);
-    MVS_HIP(ctx, hipGetLastError());
-    // pass 2: main camera, then the fragment program on the visible faces
-    if ((rc = run_raster(ctx, cam, 0, (float *)ctx->r_zbuf.ptr, (int *)ctx->r_tmp0.ptr))) return rc;
-    {
-        CamArg prj;
-        memcpy(prj.m, projector, sizeof(prj.m));
-        ProfileScope ps(ctx, MVS_K_PROJECT);
-        project_texture<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, ctx->stream>>>(
-            (const float *)ctx->soup.ptr, (const TriRec *)ctx->r_tmp2.ptr, (const int *)ctx->r_tmp0.ptr, sh_dil,
-            (const uint8_t *)ctx->r_frame.ptr, pitch, prj, W, H, 1.0f / (float)W, 1.0f / (float)H,
-            (uint8_t *)ctx->r_out3.ptr);
-        MVS_HIP(ctx, hipGetLastError());
-    }
+    if ((rc = projected_device(ctx, cam, (const uint8_t *)ctx->upload.ptr, projector, (uint8_t *)ctx->r_out3.ptr))) return rc;
     MVS_HIP(ctx, hipMemcpyAsync(out_hw3, ctx->r_out3.ptr, 3 * P, hipMemcpyDeviceToHost, ctx->stream));
     MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MVS_OK;

@@ -339,14 +339,9 @@ static void host_center(const float *cam, float *c3)
     for (int i = 0; i < 3; i++) c3[i] = t[i] / t[3];
 }
 
-}  // namespace mvs
-
-using namespace mvs;
-
-extern "C" {
-
-int mvs_triangulate(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, const float main_cam[16], const float *side_cams,
-                    const float *depth_hw, float *out_points7, int *out_count)
+// triangulatePixels; `flows_hw4` and `depth_hw` are host pointers, or device pointers when on_device (pipeline.hip)
+int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, bool on_device, const float main_cam[16],
+                     const float *side_cams, const float *depth_hw, float *out_points7, int *out_count)
 {
     if (!ctx || !main_cam || !depth_hw || !out_points7 || !out_count || nviews < 0 || (nviews > 0 && (!flows_hw4 || !side_cams)))
         return fail(ctx, MVS_EINVAL, "mvs_triangulate: bad arguments");
@@ -393,11 +388,12 @@ int mvs_triangulate(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, con
     host_center(main_cam, main_center);
 
     // arena: flows (V*4P) | depth P | grad 2P | pts 4P | pdf P | normals 3P | xyz 3P | valid P bytes | tables
-    const size_t floats = (size_t)V * 4 * P + P + 2 * P + 4 * P + P + 3 * P + 3 * P;
+    const size_t flow_floats = on_device ? 0 : (size_t)V * 4 * P;
+    const size_t floats = flow_floats + P + 2 * P + 4 * P + P + 3 * P + 3 * P;
     const size_t tables = sizeof(CamPre) * pre.size() + sizeof(float) * (16 + 4) + sizeof(float *) * (size_t)(V > 0 ? V : 1);
     int rc = ensure(ctx, ctx->flow_arena, floats * sizeof(float) + P + tables + 256);
     if (rc) return rc;
-    float *d_flows = (float *)ctx->flow_arena.ptr, *d_depth = d_flows + (size_t)V * 4 * P, *d_grad = d_depth + P, *d_pts = d_grad + 2 * P,
+    float *d_flows = (float *)ctx->flow_arena.ptr, *d_depth = d_flows + flow_floats, *d_grad = d_depth + P, *d_pts = d_grad + 2 * P,
           *d_pdf = d_pts + 4 * P, *d_nrm = d_pdf + P, *d_xyz = d_nrm + 3 * P;
     uint8_t *d_valid = (uint8_t *)(d_xyz + 3 * P);
     uintptr_t t = ((uintptr_t)(d_valid + P) + 63) & ~(uintptr_t)63;
@@ -409,10 +405,14 @@ int mvs_triangulate(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, con
     std::vector<const float *> ptrs((size_t)(V > 0 ? V : 1), nullptr);
     for (int i = 0; i < V; i++) {
         if (!flows_hw4[i]) return fail(ctx, MVS_EINVAL, "mvs_triangulate: flows[%d] is null", i);
-        MVS_HIP(ctx, hipMemcpyAsync(d_flows + (size_t)i * 4 * P, flows_hw4[i], sizeof(float) * 4 * P, hipMemcpyHostToDevice, st));
-        ptrs[i] = d_flows + (size_t)i * 4 * P;
+        if (on_device) {
+            ptrs[i] = flows_hw4[i];
+        } else {
+            MVS_HIP(ctx, hipMemcpyAsync(d_flows + (size_t)i * 4 * P, flows_hw4[i], sizeof(float) * 4 * P, hipMemcpyHostToDevice, st));
+            ptrs[i] = d_flows + (size_t)i * 4 * P;
+        }
     }
-    MVS_HIP(ctx, hipMemcpyAsync(d_depth, depth_hw, sizeof(float) * P, hipMemcpyHostToDevice, st));
+    MVS_HIP(ctx, hipMemcpyAsync(d_depth, depth_hw, sizeof(float) * P, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     MVS_HIP(ctx, hipMemcpyAsync(d_pre, pre.data(), sizeof(CamPre) * pre.size(), hipMemcpyHostToDevice, st));
     MVS_HIP(ctx, hipMemcpyAsync(d_minv, Minv, sizeof(Minv), hipMemcpyHostToDevice, st));
     MVS_HIP(ctx, hipMemcpyAsync(d_mc, main_center, sizeof(main_center), hipMemcpyHostToDevice, st));
@@ -439,6 +439,18 @@ int mvs_triangulate(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, con
         }
     *out_count = n;
     return MVS_OK;
+}
+
+}  // namespace mvs
+
+using namespace mvs;
+
+extern "C" {
+
+int mvs_triangulate(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, const float main_cam[16], const float *side_cams,
+                    const float *depth_hw, float *out_points7, int *out_count)
+{
+    return triangulate_impl(ctx, nviews, flows_hw4, false, main_cam, side_cams, depth_hw, out_points7, out_count);
 }
 
 }  // extern "C"

@@ -39,6 +39,7 @@ ABI = [
     ("mvs_flow_remap", _i, [_vp, _fp, _i, _u8p, _u8p]),
     ("mvs_flow", _i, [_vp, _u8p, _u8p, _i, _fp]),
     ("mvs_triangulate", _i, [_vp, _i, C.POINTER(_fp), _fp, _fp, _fp, _fp, C.POINTER(_i)]),
+    ("mvs_process_frame", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _fp, C.POINTER(_i), _fp]),
     ("mvs_filter_points", _i, [_vp, _fp, _i, _f, _i32p, C.POINTER(_i)]),
     ("mvs_sweep", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _f, _f, _fp, _fp, _fp]),
     ("mvs_warp_by_depth", _i, [_vp, _fp, _fp, _fp, _u8p, _u8p]),
@@ -313,6 +314,23 @@ class Context:
         self._check(self.lib.mvs_triangulate(self.h, V, arr, _ptr(cam, _fp), _ptr(cams, _fp), _ptr(depth, _fp), _ptr(out, _fp),
                                              C.byref(n)))
         return out[:n.value].copy()
+
+    def process_frame(self, main_cam, main_frame, side_cams, side_frames, use_farneback=False, want_depth=False):
+        """mvs_process_frame: recon.cpp:65-117 for one main frame -> (N, 7) points [, depth after mixBackground]"""
+        V = len(side_frames)
+        cam = _f32(main_cam, (4, 4))
+        mf = _u8(main_frame, (self.H, self.W))
+        cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((1, 4, 4), np.float32)
+        frames = [_u8(f, (self.H, self.W)) for f in side_frames]
+        arr = (_u8p * max(V, 1))(*[_ptr(f, _u8p) for f in frames])
+        out = np.empty((self.H * self.W, 7), np.float32)
+        depth = np.empty((self.H, self.W), np.float32) if want_depth else None
+        n = C.c_int(0)
+        self._check(self.lib.mvs_process_frame(self.h, _ptr(cam, _fp), _ptr(mf, _u8p), V, _ptr(cams, _fp), arr,
+                                               1 if use_farneback else 0, _ptr(out, _fp), C.byref(n),
+                                               _ptr(depth, _fp) if want_depth else None))
+        pts = out[:n.value].copy()
+        return (pts, depth) if want_depth else pts
 
     def filter_points(self, points4, alpha):
         """mvs_filter_points -> ascending indices of the points that survive"""

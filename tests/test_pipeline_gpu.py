@@ -1,0 +1,80 @@
+"""mvs_process_frame (the body of recon.cpp:65-117 on device-resident data) == the stage-by-stage ABI calls == the oracle."""
+import time
+
+import numpy as np
+import pytest
+
+import mvs_amd
+import scenes
+from mvs_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(W, H, nside):
+    verts, faces = scenes.heightfield_mesh(64, extent=1.4)
+    sc = synth.Scene(freq_scale=max(W / 1920.0, 0.2))
+    main_c = [0.0, 0.0, 0.0]
+    side_cs = [[0.15, 0.0, 0.0], [-0.1, 0.12, 0.03], [0.02, -0.14, -0.02], [0.1, 0.1, 0.0]][:nside]
+    main = synth.camera_at(main_c, W, H)
+    sides = np.stack([synth.camera_at(c, W, H) for c in side_cs])
+    return verts, faces, main, sides, sc.render(main_c, W, H), [sc.render(c, W, H) for c in side_cs]
+
+
+@pytest.mark.parametrize("farneback", [False, True])
+def test_process_frame_equals_stagewise_and_oracle(oracle, farneback):
+    W, H, nside = 320, 240, 3
+    verts, faces, main, sides, main_img, side_imgs = _setup(W, H, nside)
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.load_mesh(verts, faces)
+        pts, depth_after = ctx.process_frame(main, main_img, sides, side_imgs, farneback, want_depth=True)
+        # the same through the one-stage entry points, as recon.cpp calls them
+        depth = ctx.depth(main)
+        flows = []
+        for cam, img in zip(sides, side_imgs):
+            mixed, depth = ctx.mix_background(ctx.projected(main, img, cam), main_img, depth)
+            flows.append(ctx.flow(main_img, mixed, farneback))
+        ref_pts = ctx.triangulate(flows, main, sides, depth)
+    np.testing.assert_array_equal(depth_after, depth)
+    np.testing.assert_array_equal(pts, ref_pts)
+    assert pts.shape[0] > 0.2 * W * H
+    # and against the CPU oracle, stage by stage
+    soup = oracle.load_mesh(verts, faces)
+    d = oracle.depth(soup, main, W, H)
+    oflows = []
+    for cam, img in zip(sides, side_imgs):
+        mixed, d = oracle.mix_background(oracle.projected(soup, main, img, cam), main_img, d)
+        oflows.append(oracle.calculate_flow(main_img, mixed, farneback))
+    o_pts = oracle.triangulate_pixels(oflows, main, sides, d)
+    np.testing.assert_array_equal(depth_after, d)
+    assert pts.shape == o_pts.shape
+    np.testing.assert_array_equal(pts[:, :4], o_pts[:, :4])
+    ok = np.isfinite(o_pts[:, 4:]).all(1)
+    np.testing.assert_allclose(pts[ok, 4:], o_pts[ok, 4:], rtol=1e-5, atol=1e-9)
+
+
+def test_process_frame_is_faster_than_stagewise():
+    W, H, nside = 640, 480, 4
+    verts, faces, main, sides, main_img, side_imgs = _setup(W, H, nside)
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.load_mesh(verts, faces)
+        ctx.process_frame(main, main_img, sides, side_imgs, False)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.process_frame(main, main_img, sides, side_imgs, False)
+        fused = (time.perf_counter() - t0) / 5
+
+        def stagewise():
+            depth = ctx.depth(main)
+            flows = []
+            for cam, img in zip(sides, side_imgs):
+                mixed, depth = ctx.mix_background(ctx.projected(main, img, cam), main_img, depth)
+                flows.append(ctx.flow(main_img, mixed, False))
+            return ctx.triangulate(flows, main, sides, depth)
+        stagewise()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            stagewise()
+        staged = (time.perf_counter() - t0) / 5
+    print("process_frame %.2f ms vs stage-by-stage %.2f ms (640x480, 4 side views)" % (fused * 1e3, staged * 1e3))
+    assert fused < staged
