@@ -5,7 +5,7 @@ A "step" is one pass of the hot path for one main view: build the packed cost vo
 views (sweep kernel), then per-pixel depth selection (argmin kernel).  Inputs are synthetic frames of
 the BASELINE config already resident in HBM when the timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--shard frames|views]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--shard frames|views|rows]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py ...`.
 Sharding (DESIGN.md "multi-GPU"):
@@ -13,6 +13,9 @@ Sharding (DESIGN.md "multi-GPU"):
                     recon.cpp:65); no data-path collective; weak scaling.
   views:            the V side views are split across ranks, the packed u32 volume is summed with an
                     RCCL all-reduce (exact: integer cells), every rank selects depth; strong scaling.
+  rows:             the pixel rows of ONE main view are split into bands, one per rank (rows are independent,
+                    SURVEY 8e-2); each rank sweeps its band over all views, the depth bands are all-gathered
+                    (4 B per pixel in total); strong scaling without a volume exchange.
 """
 import argparse
 import json
@@ -80,7 +83,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--shard", default="frames", choices=["frames", "views"])
+    ap.add_argument("--shard", default="frames", choices=["frames", "views", "rows"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused", action="store_true", help="also time the no-volume variant (depth only)")
     ap.add_argument("--separate-argmin", action="store_true",
@@ -143,6 +146,14 @@ def main():
 
     groups = mdist.plane_groups(D, args.plane_groups, ctx.plane_granularity())
     comm_stream = torch.cuda.Stream()
+    bands = mdist.row_bands(H, world, ctx.row_granularity())
+    if args.shard == "rows" and world > 1:
+        r0, rn = bands[rank]
+        tallest = max(n for _, n in bands)
+        ctx.sweep_run_rows(r0, rn, 0, V, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)  # allocates the outputs
+        depth_t = torch.as_tensor(ctx.depth_device_array(), device="cuda")
+        band_pad = torch.zeros((tallest, W), dtype=torch.float32, device="cuda")
+        band_all = torch.empty((world, tallest, W), dtype=torch.float32, device="cuda")
 
     def step():
         if args.shard == "views" and world > 1:
@@ -159,6 +170,15 @@ def main():
             for w in works:
                 w.wait()  # orders the current (compute) stream behind the collective
             ctx.sweep_argmin()
+        elif args.shard == "rows" and world > 1:
+            # rows are independent: every rank sweeps its band of the SAME main view over all views and planes (volume
+            # band materialised, depth selected in the kernel); only the depth rows travel (4 B per pixel in total)
+            ctx.sweep_run_rows(r0, rn, 0, V, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+            band_pad[:rn].copy_(depth_t[r0:r0 + rn])
+            dist.all_gather_into_tensor(band_all, band_pad)
+            for r, (a, n) in enumerate(bands):
+                if r != rank and n:
+                    depth_t[a:a + n].copy_(band_all[r, :n])
         elif args.separate_argmin:
             ctx.sweep_run(v0, vn, mvs_amd.MVS_SWEEP_VOLUME)
             ctx.sweep_argmin()
@@ -235,7 +255,8 @@ def main():
         separate = launches[mvs_amd.MVS_K_ARGMIN] > 0
         # algorithmic bytes of one sweep launch: each u8 image once + the u32 volume written once (+ the three result
         # maps when depth selection is fused into the kernel)
-        sweep_bytes = float(P) * (vn + 1) + 4.0 * P * D + (0.0 if separate else 12.0 * P)
+        P_loc = float(bands[0][1]) * W if (args.shard == "rows" and world > 1) else float(P)   # rank 0's band
+        sweep_bytes = P_loc * (vn + 1) + 4.0 * P_loc * D + (0.0 if separate else 12.0 * P_loc)
         argmin_bytes = 4.0 * P * D + 12.0 * P
         achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         traffic = pmc_traffic("sweep_tiled", args.config) if args.gpus == 1 else None
@@ -251,7 +272,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic (%s)" % args.data,
             "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V),
-                       "shard": args.shard, "views_per_rank": vn, "device": ctx.info()},
+                       "shard": args.shard, "views_per_rank": vn,
+                       "rows_per_rank": [n for _, n in bands] if args.shard == "rows" else None, "device": ctx.info()},
             "roofline": {"bound": "hbm", "kernel": "sweep_tiled", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,

@@ -130,6 +130,12 @@ int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags);
  * over xGMI while the next one is being swept (bench.py --shard views --plane-groups G) */
 int mvs_sweep_run_planes(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, unsigned flags);
 int mvs_sweep_plane_granularity(void);
+/* the same for pixel rows [row_first, row_first + row_count) only, all planes (any flags; boundaries on multiples of
+ * mvs_sweep_row_granularity(), the last band may end at the image height): rows are independent (SURVEY 8e sharding 2),
+ * so G ranks sweep one band each of the SAME main view and exchange only the depth rows (bench.py --shard rows).
+ * Volume cells and depth / cost / index outside the band are left untouched. */
+int mvs_sweep_run_rows(mvs_ctx *ctx, int view_first, int view_count, int row_first, int row_count, unsigned flags);
+int mvs_sweep_row_granularity(void);
 /* per-pixel depth selection over the packed volume (async); valid after MVS_SWEEP_VOLUME runs or
  * after the caller has reduced the volume across ranks in place */
 int mvs_sweep_argmin(mvs_ctx *ctx);

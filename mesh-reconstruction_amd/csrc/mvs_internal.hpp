@@ -61,6 +61,7 @@ struct mvs_ctx {
     mvs::DevBuf cubic_tab;           // Q15 bicubic weights for remap (32*32*16 shorts)
     mvs::DevBuf flow_arena;          // optical-flow pyramids and work buffers
     mvs::DevBuf frame_buf;           // mvs_process_frame: frames, depth, warped image, flows of one main frame
+    mvs::DevBuf best_parts;          // plane-split sweeps: partial (best cell, best index) per split and pixel
     // the launch-bound flow pipelines (~350 small kernels for Farneback) are captured once into a hipGraph per
     // algorithm and replayed; invalidated when the arena moves
     hipGraphExec_t flow_graph[2] = {nullptr, nullptr};

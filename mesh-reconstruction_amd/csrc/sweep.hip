@@ -55,6 +55,9 @@ struct SweepParams {
     const uint2 *__restrict__ plan;
     int tiles_x, tiles_y, nchunks;
     int chunk0, chunk1;  // plane chunks [chunk0, chunk1) processed by this launch
+    int ty0, tyn;        // tile rows [ty0, ty0 + tyn) processed by this launch (row-band sharding)
+    int cps;             // plane chunks per workgroup: blockIdx.y selects chunks [chunk0 + y*cps, +cps) of a tile
+    uint2 *__restrict__ part;  // plane-split launches with fused depth selection: [gridDim.y][P] partial bests
     int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: linear tile order; bit 2: never use the plane-independent-w path)
 };
 
@@ -147,8 +150,8 @@ template <bool WRITE_VOLUME, bool FUSED>
 __global__ __launch_bounds__(256) void sweep_generic(SweepParams p)
 {
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (col >= p.W || row >= p.H) return;
+    const int row = p.ty0 * TILE_H + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (col >= p.W || row >= min(p.H, (p.ty0 + p.tyn) * TILE_H)) return;
     const size_t P = (size_t)p.W * p.H;
     const size_t pix = (size_t)row * p.W + col;
     const float xn = __builtin_fmaf((float)(2 * col + 1), p.invW, -1.0f);
@@ -440,10 +443,11 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
     __shared__ __attribute__((aligned(16))) uint2 lds[LDS_QUADS];
     __shared__ uint2 best_state[FUSED ? 256 * NPX : 1];  // (packed best cell, best index) per (pixel j, thread)
 
-    const int tile = (p.debug & 2) ? ((int)blockIdx.x < p.tiles_x * p.tiles_y ? (int)blockIdx.x : -1)
-                                   : grouped_tile(blockIdx.x, p.tiles_x, p.tiles_y);
-    if (tile < 0) return;
-    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int band_tile = (p.debug & 2) ? ((int)blockIdx.x < p.tiles_x * p.tyn ? (int)blockIdx.x : -1)
+                                        : grouped_tile(blockIdx.x, p.tiles_x, p.tyn);
+    if (band_tile < 0) return;
+    const int tx = band_tile % p.tiles_x, ty = band_tile / p.tiles_x + p.ty0;
+    const int tile = ty * p.tiles_x + tx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = tx * TILE_W + lane;
     const int row0 = ty * TILE_H + wave * NPX;
@@ -463,7 +467,11 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
         if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(0u, 0xffffffffu);  // own slot only: no barrier needed
     }
 
-    for (int chunk = p.chunk0; chunk < p.chunk1; chunk++) {
+    // plane split: a launch with too few tiles to fill the chip (a row band, a small frame) gives each workgroup only
+    // cps of the tile's plane chunks; planes are independent, the partial bests are merged by combine_best
+    const int chunk_first = p.chunk0 + (int)blockIdx.y * p.cps;
+    const int chunk_last = min(p.chunk1, chunk_first + p.cps);
+    for (int chunk = chunk_first; chunk < chunk_last; chunk++) {
         const int d0 = chunk * PC;
         // plane constants of this chunk live in SGPRs; planes past D (last chunk) are evaluated on a
         // clamped z and never stored, so the sample loops carry no per-plane control flow
@@ -583,9 +591,29 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
         for (int j = 0; j < NPX; j++)
             if (ok[j]) {
                 const uint2 st = best_state[j * 256 + threadIdx.x];
-                store_best(p, (size_t)(row0 + j) * p.W + col, st.x & 0xffffu, st.x >> 16, (int)st.y);
+                const size_t pix = (size_t)(row0 + j) * p.W + col;
+                if (p.part)
+                    p.part[(size_t)blockIdx.y * P + pix] = st;
+                else
+                    store_best(p, pix, st.x & 0xffffu, st.x >> 16, (int)st.y);
             }
     }
+}
+
+// merge of the partial bests of a plane-split launch: splits are in ascending plane order and a later split wins only
+// if strictly better, so ties still go to the lowest plane
+__global__ __launch_bounds__(256) void combine_best(SweepParams p, int nsplit, size_t pix_first, size_t pix_count)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pix_count) return;
+    const size_t pix = pix_first + i, P = (size_t)p.W * p.H;
+    uint32_t best = 0u;
+    int bi = -1;
+    for (int s = 0; s < nsplit; s++) {
+        const uint2 st = p.part[(size_t)s * P + pix];
+        argmin_update_packed(st.x, (int)st.y, best, bi);
+    }
+    store_best(p, pix, best & 0xffffu, best >> 16, bi);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -715,6 +743,10 @@ static int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount)
     p.nchunks = div_up(ctx->D, PC);
     p.chunk0 = 0;
     p.chunk1 = p.nchunks;
+    p.ty0 = 0;
+    p.tyn = p.tiles_y;
+    p.cps = p.nchunks;
+    p.part = nullptr;
     p.debug = 0;
     return MVS_OK;
 }
@@ -762,13 +794,26 @@ static int ensure_outputs(mvs_ctx *ctx, bool need_volume)
     return MVS_OK;
 }
 
-static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, unsigned flags);
+static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, int row_first,
+                          int row_count, unsigned flags);
 
 int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags)
 {
     if (!ctx) return MVS_EINVAL;
-    return sweep_run_impl(ctx, view_first, view_count, 0, ctx->D, flags);
+    return sweep_run_impl(ctx, view_first, view_count, 0, ctx->D, 0, ctx->H, flags);
 }
+
+int mvs_sweep_run_rows(mvs_ctx *ctx, int view_first, int view_count, int row_first, int row_count, unsigned flags)
+{
+    if (!ctx) return MVS_EINVAL;
+    if (row_first < 0 || row_count < 0 || row_first + row_count > ctx->H || (row_first % TILE_H) != 0 ||
+        ((row_first + row_count) % TILE_H != 0 && row_first + row_count != ctx->H))
+        return fail(ctx, MVS_EINVAL, "mvs_sweep_run_rows: row range [%d,%d) must lie in 0..%d and start/end on multiples of %d",
+                    row_first, row_first + row_count, ctx->H, TILE_H);
+    return sweep_run_impl(ctx, view_first, view_count, 0, ctx->D, row_first, row_count, flags);
+}
+
+int mvs_sweep_row_granularity(void) { return TILE_H; }
 
 int mvs_sweep_run_planes(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, unsigned flags)
 {
@@ -779,12 +824,13 @@ int mvs_sweep_run_planes(mvs_ctx *ctx, int view_first, int view_count, int plane
         ((plane_first + plane_count) % mvs_sweep_plane_granularity() != 0 && plane_first + plane_count != ctx->D))
         return fail(ctx, MVS_EINVAL, "mvs_sweep_run_planes: plane range [%d,%d) must lie in 0..%d and start/end on multiples of %d",
                     plane_first, plane_first + plane_count, ctx->D, mvs_sweep_plane_granularity());
-    return sweep_run_impl(ctx, view_first, view_count, plane_first, plane_count, flags);
+    return sweep_run_impl(ctx, view_first, view_count, plane_first, plane_count, 0, ctx->H, flags);
 }
 
 int mvs_sweep_plane_granularity(void) { return PC; }
 
-static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, unsigned flags)
+static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, int row_first,
+                          int row_count, unsigned flags)
 {
     if (!ctx) return MVS_EINVAL;
     if (!ctx->have_main || !ctx->have_views || !ctx->have_planes)
@@ -802,6 +848,9 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
     fill_params(ctx, p, view_first, view_count);
     p.chunk0 = plane_first / PC;
     p.chunk1 = div_up(plane_first + plane_count, PC);
+    p.ty0 = row_first / TILE_H;
+    p.tyn = div_up(row_first + row_count, TILE_H) - p.ty0;
+    if (p.tyn <= 0) return MVS_OK;  // empty band: nothing to compute
     const bool generic = (flags & MVS_SWEEP_FORCE_GENERIC) != 0;
     p.debug = (int)((flags >> 8) & 0xff);  // undocumented timing-experiment bits
 
@@ -817,7 +866,7 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
     {
         ProfileScope ps(ctx, MVS_K_SWEEP);
         if (generic || ctx->V == 0) {
-            dim3 grid(div_up(ctx->W, 64), div_up(ctx->H, 4));
+            dim3 grid(div_up(ctx->W, 64), p.tyn * (TILE_H / 4));
             if (vol && fused)
                 sweep_generic<true, true><<<grid, 256, 0, ctx->stream>>>(p);
             else if (vol)
@@ -826,14 +875,31 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
                 sweep_generic<false, true><<<grid, 256, 0, ctx->stream>>>(p);
         } else {
             // padded group grid: 8 tiles per group, 8 groups per 64-id super block
-            const int groups = div_up(p.tiles_x, 2) * div_up(p.tiles_y, 4);
-            const unsigned grid = (unsigned)(div_up(groups, 8) * 64);
+            const int groups = div_up(p.tiles_x, 2) * div_up(p.tyn, 4);
+            // plane split: aim at ~64 workgroups per CU.  Finer work units smooth the tail of the launch and keep small
+            // frames / row bands from leaving CUs idle: c3 2.50 -> 2.31 ms, c2 0.414 -> 0.333 ms, c1 0.080 -> 0.055 ms,
+            // a 1/8 row band of c3 0.86 -> 0.4 ms; flat at c4 (8100 tiles) -- profiles/r01/exp_split.json
+            const int nch = p.chunk1 - p.chunk0, tiles = p.tiles_x * p.tyn;
+            int want = (int)((flags >> 16) & 0xffu);  // undocumented: forced split count for timing experiments
+            if (!want) want = div_up(64 * ctx->num_cus, tiles);
+            p.cps = div_up(nch, max(1, min(want, nch)));
+            const int nsplit = div_up(nch, p.cps);
+            if (fused && nsplit > 1) {
+                if ((rc = ensure(ctx, ctx->best_parts, (size_t)nsplit * ctx->W * ctx->H * sizeof(uint2)))) return rc;
+                p.part = (uint2 *)ctx->best_parts.ptr;
+            }
+            const dim3 grid((unsigned)(div_up(groups, 8) * 64), (unsigned)nsplit);
             if (vol && fused)
                 sweep_tiled<true, true><<<grid, 256, 0, ctx->stream>>>(p);
             else if (vol)
                 sweep_tiled<true, false><<<grid, 256, 0, ctx->stream>>>(p);
             else
                 sweep_tiled<false, true><<<grid, 256, 0, ctx->stream>>>(p);
+            if (p.part) {
+                const size_t first = (size_t)p.ty0 * TILE_H * ctx->W;
+                const size_t count = (size_t)(min(ctx->H, (p.ty0 + p.tyn) * TILE_H) - p.ty0 * TILE_H) * ctx->W;
+                combine_best<<<(unsigned)((count + 255) / 256), 256, 0, ctx->stream>>>(p, nsplit, first, count);
+            }
         }
         MVS_HIP(ctx, hipGetLastError());
     }

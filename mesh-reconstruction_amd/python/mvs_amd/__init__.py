@@ -49,6 +49,8 @@ ABI = [
     ("mvs_sweep_run", _i, [_vp, _i, _i, C.c_uint]),
     ("mvs_sweep_run_planes", _i, [_vp, _i, _i, _i, _i, C.c_uint]),
     ("mvs_sweep_plane_granularity", _i, []),
+    ("mvs_sweep_run_rows", _i, [_vp, _i, _i, _i, _i, C.c_uint]),
+    ("mvs_sweep_row_granularity", _i, []),
     ("mvs_sweep_argmin", _i, [_vp]),
     ("mvs_sweep_volume_device", _vp, [_vp, C.POINTER(_sz)]),
     ("mvs_sweep_use_volume", _i, [_vp, _vp, _sz]),
@@ -108,6 +110,14 @@ def _u8(a, shape=None):
 
 def _ptr(a, t):
     return a.ctypes.data_as(t)
+
+
+class _DeviceArray:
+    """minimal __cuda_array_interface__ carrier so torch can alias a library-owned device buffer without a copy"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
+                                         "strides": None}
 
 
 class Context:
@@ -205,6 +215,22 @@ class Context:
 
     def plane_granularity(self):
         return self.lib.mvs_sweep_plane_granularity()
+
+    def sweep_run_rows(self, row_first, row_count, view_first=0, view_count=None, flags=MVS_SWEEP_VOLUME):
+        if view_count is None:
+            view_count = self.V - view_first
+        self._check(self.lib.mvs_sweep_run_rows(self.h, int(view_first), int(view_count), int(row_first), int(row_count), int(flags)))
+
+    def row_granularity(self):
+        return self.lib.mvs_sweep_row_granularity()
+
+    def depth_device_array(self):
+        """zero-copy [H, W] f32 view of the device depth map for torch.as_tensor(..., device='cuda') (valid until the
+        context is closed; the buffer exists after the first sweep run)"""
+        ptr = self.lib.mvs_sweep_depth_device(self.h)
+        if not ptr:
+            raise MvsError("no depth map on the device yet")
+        return _DeviceArray(ptr, (self.H, self.W), "<f4")
 
     def sweep_argmin(self):
         self._check(self.lib.mvs_sweep_argmin(self.h))

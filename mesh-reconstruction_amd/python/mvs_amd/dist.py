@@ -1,9 +1,12 @@
 """Multi-GPU sharding of the sweep (one process per GPU, torch.distributed; backend nccl = RCCL on ROCm).
 
-Two shardings:
+Three shardings:
   frames: rank r owns main frames r, r+world, ... -- the reference's independent `fa` loop (recon.cpp:65); no collective
   views : the side views of ONE main frame are split across ranks; the packed u32 volume (count<<16 | sum) is summed
           with all_reduce -- exact, because cells are integers -- and every rank selects depth on the full volume.
+  rows  : the pixel rows of ONE main frame are split into bands, one per rank (rows are independent); every
+          rank holds all side views, sweeps its band with fused depth selection, and the bands of the depth map are
+          all-gathered (4 bytes per pixel in total) -- strong scaling of a single main view with no volume exchange.
 The functions here are backend-agnostic so the CPU tests run them over gloo with the oracle standing in for the GPU.
 """
 
@@ -49,3 +52,28 @@ def plane_groups(D, groups, granularity):
         out.append((first, last - first))
         start += n
     return out
+
+
+def row_bands(H, world, granularity):
+    """split rows 0..H into `world` contiguous bands [first, first+count) whose boundaries are multiples of `granularity`
+    (the last band ends at H); ranks beyond the number of units get empty bands.  Bands differ by at most one unit."""
+    units = (H + granularity - 1) // granularity
+    out, start = [], 0
+    for r in range(world):
+        n = units // world + (1 if r < units % world else 0)
+        first = min(H, start * granularity)
+        last = min(H, (start + n) * granularity)
+        out.append((first, last - first))
+        start += n
+    return out
+
+
+def gather_rows(dist, torch, local_rows, bands, W):
+    """all-gather row bands of unequal height: every rank contributes its [count, W] band (padded to the tallest band),
+    returns the assembled [H, W] map on every rank"""
+    tallest = max(c for _, c in bands)
+    pad = torch.zeros((tallest, W), dtype=local_rows.dtype, device=local_rows.device)
+    pad[: local_rows.shape[0]] = local_rows
+    parts = [torch.empty_like(pad) for _ in bands]
+    dist.all_gather(parts, pad)
+    return torch.cat([part[:c] for part, (_, c) in zip(parts, bands)], dim=0)

@@ -41,6 +41,14 @@ def _worker(rank, world, port, mode, tmp):
         vol = t.numpy().astype(np.uint32)
         depth, cost, idx = o.argmin(vol, o.plane_table(D, -1.0, 1.0))
         np.savez(os.path.join(tmp, "views_%d.npz" % rank), vol=vol, depth=depth, idx=idx)
+    elif mode == "rows":
+        # each rank owns one band of rows of the SAME main view (the oracle's rows stand in for mvs_sweep_run_rows)
+        bands = mdist.row_bands(H, world, 16)
+        r0, rn = bands[rank]
+        full = o.sweep(main_cam, main_img, side_cams, sides, D)[0]
+        local = torch.from_numpy(np.ascontiguousarray(full[r0:r0 + rn]))
+        depth = mdist.gather_rows(dist, torch, local, bands, W).numpy()
+        np.savez(os.path.join(tmp, "rows_%d.npz" % rank), depth=depth, r0=r0, rn=rn)
     else:
         frames = 5
         mine = mdist.frame_shard(frames, rank, world)
@@ -54,7 +62,7 @@ def _worker(rank, world, port, mode, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["views", "frames"])
+@pytest.mark.parametrize("mode", ["views", "rows", "frames"])
 def test_two_rank_sharding(oracle, tmp_path, mode):
     from mvs_amd import synth
     world = 2
@@ -68,6 +76,15 @@ def test_two_rank_sharding(oracle, tmp_path, mode):
             np.testing.assert_array_equal(g["vol"], v_ref)      # the all-reduced shards == single-process volume
             np.testing.assert_array_equal(g["depth"], d_ref)
             np.testing.assert_array_equal(g["idx"], i_ref)
+    elif mode == "rows":
+        main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3, freq_scale=0.3)
+        d_ref = oracle.sweep(main_cam, main_img, side_cams, sides, D)[0]
+        heights = []
+        for r in range(world):
+            g = np.load(tmp_path / ("rows_%d.npz" % r))
+            np.testing.assert_array_equal(g["depth"], d_ref)    # unequal bands (32 + 8 rows) reassemble exactly
+            heights.append(int(g["rn"]))
+        assert heights == [32, 8]
     else:
         ref = []
         for f in range(5):
@@ -87,3 +104,13 @@ def test_shard_bookkeeping():
                 cover += list(range(a, a + n))
             assert cover == list(range(V))
     assert mdist.frame_shard(5, 1, 2) == [1, 3] and mdist.frame_shard(2, 3, 8) == []
+    for H in (1, 16, 40, 1080, 2160):
+        for world in (1, 2, 3, 8, 100):
+            bands = mdist.row_bands(H, world, 16)
+            assert len(bands) == world and bands[0][0] == 0
+            assert all(a % 16 == 0 or n == 0 for a, n in bands)
+            cover = [r for a, n in bands for r in range(a, a + n)]
+            assert cover == list(range(H))
+            sizes = [n for _, n in bands if n]
+            assert max(sizes) - min(sizes) <= 16 + 15      # balanced to one unit (the last band may be ragged)
+    assert mdist.row_bands(1080, 8, 16) == [(0, 144), (144, 144), (288, 144), (432, 144), (576, 128), (704, 128), (832, 128), (960, 120)]

@@ -288,6 +288,68 @@ def test_plane_groups_reproduce_the_full_volume():
     assert mdist.plane_groups(7, 4, 16) == [(0, 7)]
 
 
+def test_row_bands_reproduce_the_full_result():
+    """mvs_sweep_run_rows over the bands of mdist.row_bands == one full run, for the volume and the fused depth selection,
+    tiled and generic kernels; rows outside a band are not touched (bench.py --shard rows)"""
+    from mvs_amd import dist as mdist
+    W, H, D, V = 320, 200, 24, 3            # 200 rows = 12 full tile rows + a ragged one
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
+    both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    with mvs_amd.Context(W, H) as ctx:
+        g = ctx.row_granularity()
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+        ctx.sweep_run(0, V, both)
+        d_full, c_full, i_full, v_full = [a.copy() for a in ctx.sweep_fetch(want_volume=True)]
+        for kernel_flag in (0, mvs_amd.MVS_SWEEP_FORCE_GENERIC):
+            for world in (2, 3, 5):
+                ctx.sweep_run(0, 0, both | kernel_flag)          # poison: zero views -> empty cells, depth 1.0
+                assert (ctx.sweep_fetch()[0] == 1.0).all()
+                bands = mdist.row_bands(H, world, g)
+                for k, (first, count) in enumerate(bands):
+                    ctx.sweep_run_rows(first, count, 0, V, both | kernel_flag)
+                    d, c, i, v = ctx.sweep_fetch(want_volume=True)
+                    done = first + count
+                    np.testing.assert_array_equal(d[:done], d_full[:done])
+                    assert (d[done:] == 1.0).all() and (v[:, done:] == 0).all()      # later bands still untouched
+                np.testing.assert_array_equal(v, v_full)
+                np.testing.assert_array_equal(i, i_full)
+                np.testing.assert_array_equal(c, c_full)
+        ctx.sweep_run_rows(0, 0, 0, V, both)                     # an empty band is legal (rank beyond the units)
+        for bad in ((8, 16), (0, 24), (192, 16), (-16, 16)):
+            with pytest.raises(mvs_amd.MvsError):
+                ctx.sweep_run_rows(bad[0], bad[1], 0, V, both)
+        ctx.sweep_run_rows(192, 8, 0, V, both)                   # ragged last band ends at H
+
+
+def test_plane_split_launches_are_bit_identical():
+    """launches with too few tiles to fill the chip hand each workgroup a subset of a tile's plane chunks and merge the
+    partial bests (combine_best); any split count -- forced through the timing-experiment bits -- must give the
+    unsplit result, ties included (noise frames produce many equal-cost planes)"""
+    W, H, D, V = 200, 100, 70, 3            # 5 plane chunks, ragged last one
+    rng = np.random.default_rng(11)
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
+    flat = np.full((H, W), 90, np.uint8)    # constant frames: every in-frame plane ties -> lowest d must win
+    noise_side = rng.integers(0, 4, (H, W), dtype=np.uint8)           # 4 grey levels: many equal-cost planes
+    cases = [(main_img, sides), (flat, [flat] * V), (rng.integers(0, 256, (H, W), dtype=np.uint8), [noise_side] * V)]
+    both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    with mvs_amd.Context(W, H) as ctx:
+        for img, sd in cases:
+            ctx.sweep_set(main_cam, img, side_cams, sd, D)
+            ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
+            ctx.sweep_argmin()                                   # reference: separate pass over the volume
+            d0, c0, i0, v0 = [a.copy() for a in ctx.sweep_fetch(want_volume=True)]
+            for forced in (1, 2, 3, 5, 9):
+                for flags in (both, mvs_amd.MVS_SWEEP_FUSED_ARGMIN):
+                    ctx.sweep_run(0, 0, both)
+                    ctx.sweep_run(0, V, flags | (forced << 16))
+                    d, c, i, v = ctx.sweep_fetch(want_volume=bool(flags & mvs_amd.MVS_SWEEP_VOLUME))
+                    np.testing.assert_array_equal(i, i0)
+                    np.testing.assert_array_equal(d, d0)
+                    np.testing.assert_array_equal(c, c0)
+                    if v is not None:
+                        np.testing.assert_array_equal(v, v0)
+
+
 def test_plane_independent_w_path_is_bit_identical(oracle):
     """ring cameras (parallel axes, centres in the main focal plane) have Q[2][2] == 0 and take the hoisted-reciprocal
     path; it must equal the general path (debug bit) and the oracle cell for cell; a rotated camera must not take it"""

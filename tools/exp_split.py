@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""In-process A/B of the plane-split count (flags >> 16) for full-frame sweeps: c1, c2, c3 (scene data)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
+import numpy as np
+import mvs_amd
+from mvs_amd import synth
+
+def t(ctx, V, flags, n=10):
+    for _ in range(3):
+        ctx.sweep_run(0, V, flags)
+    ctx.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ctx.sweep_run(0, V, flags)
+        ctx.synchronize()
+        ts.append((time.perf_counter() - t0) / n * 1e3)
+    return min(ts)
+
+for name, (W, H, D, V) in {"c1": (640, 480, 32, 4), "c2": (1280, 720, 64, 8), "c3": (1920, 1080, 128, 16), "c3-D256": (1920, 1080, 256, 16), "c4": (3840, 2160, 256, 32)}.items():
+    if name == "c4":
+        main_cam, main_img, side_cams, sides = synth.noise_views(W, H, V, seed=synth.SEED_NOISE)
+    else:
+        main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.15)
+    both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+        res = {"auto": t(ctx, V, both)}
+        for f in (1, 2, 4, 8, 16):
+            if f <= (D + 15) // 16:
+                res["split%d" % f] = t(ctx, V, both | (f << 16))
+        res["auto_again"] = t(ctx, V, both)
+    print(json.dumps({"config": name, "tiles": ((W + 63) // 64) * ((H + 15) // 16), "ms": res}))
