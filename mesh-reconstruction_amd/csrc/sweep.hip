@@ -416,6 +416,69 @@ __device__ __forceinline__ void sample_lds_pair(const Affine &A, float bx, float
     acc1 = sad_u32((uint32_t)(int)res.y, Im, acc1);
 }
 
+// All PC planes of one (pixel, view) on the FAST path, software-pipelined by hand: the LDS reads of plane pair k+1 are
+// issued before the arithmetic of pair k, so each ds_read_b64 has ~100 cycles of this wave's own VALU work between
+// issue and use instead of an immediate s_waitcnt (the compiler's schedule: profiles/r01/README.md).  The reads are
+// inline asm; the wait is tied to the loaded registers ("+v") so no consumer can be scheduled above it.
+// Element-wise the same arithmetic as sample_lds_pair.
+typedef unsigned long long quad_bits_t;
+
+template <bool WCONST>
+__device__ __forceinline__ void sample_chunk_pipelined(const Affine &A, float bx, float by, float bw, float r_const,
+                                                       const float (&zc)[PC], int rp8, int lds_minus_org8, uint32_t Im,
+                                                       uint32_t (&acc)[PC])
+{
+    float fx[2];
+    f32x2 fy;
+    int off[2];
+    quad_bits_t q0, q1;
+    auto address_stage = [&](int k) {
+        const f32x2 z = {zc[k], zc[k + 1]};
+        const f32x2 sx = __builtin_elementwise_fma(z, (f32x2)(bx), (f32x2)(A.ax));
+        const f32x2 sy = __builtin_elementwise_fma(z, (f32x2)(by), (f32x2)(A.ay));
+        f32x2 r;
+        if (WCONST) {
+            r = (f32x2)(r_const);
+        } else {
+            const f32x2 sw = __builtin_elementwise_fma(z, (f32x2)(bw), (f32x2)(A.aw));
+            const f32x2 r0 = {__builtin_amdgcn_rcpf(sw.x), __builtin_amdgcn_rcpf(sw.y)};
+            const f32x2 e = __builtin_elementwise_fma(-sw, r0, (f32x2)(1.0f));
+            r = __builtin_elementwise_fma(e, r0, r0);
+        }
+        const f32x2 cx = sx * r, cy = sy * r;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            fx[i] = __builtin_amdgcn_fractf(cx[i]);
+            fy[i] = __builtin_amdgcn_fractf(cy[i]);
+            const int ix = (int)cx[i], iy = (int)cy[i];
+            int row_off;
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(row_off) : "v"(iy), "s"(rp8), "v"(lds_minus_org8));
+            asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(off[i]) : "v"(ix), "v"(row_off));
+        }
+    };
+    address_stage(0);
+    asm volatile("ds_read_b64 %0, %1" : "=v"(q0) : "v"(off[0]));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(q1) : "v"(off[1]));
+#pragma unroll
+    for (int k = 0; k < PC; k += 2) {
+        const float fx0 = fx[0], fx1 = fx[1];
+        const f32x2 fyk = fy;
+        if (k + 2 < PC) address_stage(k + 2);  // VALU work of the next pair while this pair's reads are in flight
+        // the next pair's offsets are operands too: the scheduler may not sink the address stage below the wait
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(off[0]), "+v"(off[1]));
+        const half4_t h0 = __builtin_bit_cast(half4_t, q0), h1 = __builtin_bit_cast(half4_t, q1);
+        if (k + 2 < PC) {
+            asm volatile("ds_read_b64 %0, %1" : "=v"(q0) : "v"(off[0]));
+            asm volatile("ds_read_b64 %0, %1" : "=v"(q1) : "v"(off[1]));
+        }
+        const f32x2 a = {__builtin_fmaf(fx0, (float)h0[1], (float)h0[0]), __builtin_fmaf(fx1, (float)h1[1], (float)h1[0])};
+        const f32x2 b = {__builtin_fmaf(fx0, (float)h0[3], (float)h0[2]), __builtin_fmaf(fx1, (float)h1[3], (float)h1[2])};
+        const f32x2 res = __builtin_elementwise_fma(fyk, b, a);
+        acc[k] = sad_u32((uint32_t)(int)res.x, Im, acc[k]);
+        acc[k + 1] = sad_u32((uint32_t)(int)res.y, Im, acc[k + 1]);
+    }
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD, MI355X_MICROARCH.md), each with
 // its own 4 MiB L2.  Tiles are grouped 2 wide x 4 tall (128 x 64 pixels); the 8 tiles of a group get block ids
 // with equal (id % 8), so a group's overlapping side-image regions share one L2, and consecutive groups go to
@@ -526,20 +589,23 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
             rv.yhi = y0 + rh - 1;
             if (mode == R_FAST) {
                 fast_views += 65536u;
-                int negorg8 = -rv.org8;
-                asm volatile("" : "+v"(negorg8));  // keep it in a VGPR so mul24 + add fuses into v_mad_i32_i24
+                // the low 32 bits of a generic pointer into LDS are the LDS byte address
+                int lds_minus_org8 = (int)(uint32_t)(uintptr_t)lds - rv.org8;
+                asm volatile("" : "+v"(lds_minus_org8));  // keep it in a VGPR so mul24 + add fuses into v_mad_i32_i24
                 if (bw == 0.0f && !(p.debug & 4)) {  // wave-uniform: plane-independent w (see sample_lds_pair)
 #pragma unroll
                     for (int j = 0; j < NPX; j++) {
                         if (ok[j]) {
                             const Affine A = view_affine(q, xn, yn[j]);
                             const float r_const = rcp_rn(__builtin_fmaf(zc[0], bw, A.aw));
-#pragma unroll
-                            for (int k = 0; k < PC; k += 2)
-                                sample_lds_pair<true>(A, bx, by, bw, r_const, zc[k], zc[k + 1], rv, negorg8, (uint32_t)Im[j], acc[j][k], acc[j][k + 1]);
+                            sample_chunk_pipelined<true>(A, bx, by, bw, r_const, zc, rv.rp8, lds_minus_org8, (uint32_t)Im[j], acc[j]);
                         }
                     }
                 } else {
+                    // general cameras: three more live values per pair (sw, r0, e); the hand-pipelined form measured 2 %
+                    // slower here (2.635 vs 2.58 ms at c3), so this path keeps the compiler-scheduled pair loop
+                    int negorg8 = -rv.org8;
+                    asm volatile("" : "+v"(negorg8));
 #pragma unroll
                     for (int j = 0; j < NPX; j++) {
                         if (ok[j]) {
