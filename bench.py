@@ -22,6 +22,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
@@ -109,11 +110,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # MVS_BENCH_SAME_DEVICE=1 (test hook): all ranks share GPU 0 and talk over gloo, so the multi-rank step logic can be
+    # exercised on a one-GPU box (RCCL refuses two ranks on one device); never used for reported numbers
+    same_device = os.environ.get("MVS_BENCH_SAME_DEVICE") == "1"
+    if same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = CONFIGS[args.config]
     W, H, D, V = cfg
@@ -153,7 +162,8 @@ def main():
         ctx.sweep_run_rows(r0, rn, 0, V, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)  # allocates the outputs
         depth_t = torch.as_tensor(ctx.depth_device_array(), device="cuda")
         band_pad = torch.zeros((tallest, W), dtype=torch.float32, device="cuda")
-        band_all = torch.empty((world, tallest, W), dtype=torch.float32, device="cuda")
+        band_cat = torch.empty((world * tallest, W), dtype=torch.float32, device="cuda")   # concatenated form: every backend
+        band_all = band_cat.view(world, tallest, W)
 
     def step():
         if args.shard == "views" and world > 1:
@@ -175,7 +185,7 @@ def main():
             # band materialised, depth selected in the kernel); only the depth rows travel (4 B per pixel in total)
             ctx.sweep_run_rows(r0, rn, 0, V, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
             band_pad[:rn].copy_(depth_t[r0:r0 + rn])
-            dist.all_gather_into_tensor(band_all, band_pad)
+            dist.all_gather_into_tensor(band_cat, band_pad)
             for r, (a, n) in enumerate(bands):
                 if r != rank and n:
                     depth_t[a:a + n].copy_(band_all[r, :n])
@@ -270,7 +280,7 @@ def main():
             "scaling": "weak" if args.shard == "frames" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (%s)" % args.data,
+            "data": "synthetic (%s)" % args.data + (" [TEST HOOK: ranks share one GPU over gloo -- not a measurement]" if same_device else ""),
             "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V),
                        "shard": args.shard, "views_per_rank": vn,
                        "rows_per_rank": [n for _, n in bands] if args.shard == "rows" else None, "device": ctx.info()},
@@ -284,6 +294,7 @@ def main():
                         "depth_selection": "argmin_volume pass" if separate else "fused into sweep_tiled",
                         "arithmetic": "f32 warp (one rounding per op), u8 intensities, u32 packed cost cells"},
             "depth_check": depth_ok,
+            "depth_crc32": zlib.crc32(np.ascontiguousarray(depth).tobytes()),   # equal across N for the strong-scaling shardings
         }
         if general_ms is not None:
             out["general_camera_path"] = {

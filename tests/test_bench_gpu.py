@@ -1,0 +1,47 @@
+"""bench.py's multi-rank step logic on a one-GPU box: two ranks share GPU 0 and talk over gloo (MVS_BENCH_SAME_DEVICE
+test hook; RCCL refuses two ranks on one device).  The strong-scaling shardings must reproduce the single-GPU depth map
+bit for bit: `views` through the integer all-reduce of the packed volume, `rows` through the all-gather of depth bands."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra, world):
+    env = dict(os.environ)
+    cmd = [sys.executable]
+    if world > 1:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env["MVS_BENCH_SAME_DEVICE"] = "1"
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--config", "c1", "--steps", "2", "--warmup", "1",
+            "--no-cpu-baseline", "--no-extras"] + extra
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_and_two_rank_shardings():
+    single = _bench([], 1)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in single, key
+    assert single["n_gpus"] == 1 and single["vs_baseline"] is None and single["depth_check"] is True
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in single["roofline"], key
+    for shard, scaling in (("views", "strong"), ("rows", "strong"), ("frames", "weak")):
+        two = _bench(["--shard", shard], 2)
+        assert two["n_gpus"] == 2 and two["scaling"] == scaling and two["depth_check"] is True
+        assert "TEST HOOK" in two["data"]
+        assert two["depth_crc32"] == single["depth_crc32"], shard   # rank 0's frame is the single-GPU frame in every mode

@@ -21,6 +21,8 @@ import tracks_yaml  # noqa: E402
 
 
 def main():
+    no_cpu = "--no-cpu" in sys.argv
+    farneback = "--farneback" in sys.argv
     t = tracks_yaml.load("koberec.yaml")
     W, H = t["width"], t["height"]
     cams = t["cameras"]
@@ -49,16 +51,19 @@ def main():
 
     with mvs_amd.Context(W, H) as ctx:
         ctx.load_mesh(verts, faces)
-        pts = ctx.process_frame(main, main_img, sides, side_imgs, False)
+        pts = ctx.process_frame(main, main_img, sides, side_imgs, farneback)
         reps = 40
         samples = []
         for _ in range(reps):
             t0 = time.perf_counter()
-            ctx.process_frame(main, main_img, sides, side_imgs, False)
+            ctx.process_frame(main, main_img, sides, side_imgs, farneback)
             samples.append((time.perf_counter() - t0) * 1e3)
         gpu_ms = float(np.median(samples))
         info = ctx.info()
 
+    if no_cpu:
+        print(json.dumps({"gpu_ms_per_main_frame": gpu_ms, "gpu_ms_min_max": [min(samples), max(samples)], "farneback": farneback}))
+        return
     o = orc.load()
     soup = o.load_mesh(verts, faces)
     t0 = time.perf_counter()
@@ -66,7 +71,7 @@ def main():
     flows = []
     for cam, img in zip(sides, side_imgs):
         mixed, d = o.mix_background(o.projected(soup, main, img, cam), main_img, d)
-        flows.append(o.calculate_flow(main_img, mixed, False))
+        flows.append(o.calculate_flow(main_img, mixed, farneback))
     o_pts = o.triangulate_pixels(flows, main, sides, d)
     cpu_ms = (time.perf_counter() - t0) * 1e3
     same = pts.shape == o_pts.shape and np.array_equal(pts[:, :4], o_pts[:, :4], equal_nan=True)
