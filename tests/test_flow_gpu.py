@@ -20,7 +20,7 @@ def _pair(W, H, dx, dy, seed=0):
     return a, b
 
 
-@pytest.mark.parametrize("W,H", [(320, 240), (333, 201), (640, 480)])
+@pytest.mark.parametrize("W,H", [(70, 50), (320, 240), (333, 201), (640, 480)])
 @pytest.mark.parametrize("farneback", [True, False])
 def test_calculate_flow_matches_oracle(oracle, W, H, farneback):
     a, b = _pair(W, H, 2.5, -1.5, seed=W)
