@@ -27,12 +27,9 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-__global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__ src, int w, int h, float *__restrict__ dst,
-                                                       int dw, int dh)
+// cv::pyrDown value at coarse pixel (x, y) of a w x h source
+__device__ __forceinline__ float pyr_down_at(const float *__restrict__ src, int w, int h, int x, int y)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= dh) return;
     int xs[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) xs[k] = reflect101(2 * x + k - 2, w);
@@ -42,7 +39,31 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__
         const float *s = src + (size_t)reflect101(2 * y + k - 2, h) * w;
         r[k] = s[xs[2]] * 6.0f + (s[xs[1]] + s[xs[3]]) * 4.0f + s[xs[0]] + s[xs[4]];
     }
-    dst[(size_t)y * dw + x] = (r[2] * 6.0f + (r[1] + r[3]) * 4.0f + r[0] + r[4]) * (1.0f / 256.0f);
+    return (r[2] * 6.0f + (r[1] + r[3]) * 4.0f + r[0] + r[4]) * (1.0f / 256.0f);
+}
+
+__global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__ src, int w, int h, float *__restrict__ dst,
+                                                       int dw, int dh)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    dst[(size_t)y * dw + x] = pyr_down_at(src, w, h, x, y);
+}
+
+// one level of compare(): pyrDown of both images and their absolute difference (util.cpp:343-350) in one launch
+__global__ __launch_bounds__(256) void pyr_down_pair_absdiff(const float *__restrict__ a, const float *__restrict__ b, int w, int h,
+                                                             float *__restrict__ da, float *__restrict__ db,
+                                                             float *__restrict__ dd, int dw, int dh)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const float va = pyr_down_at(a, w, h, x, y), vb = pyr_down_at(b, w, h, x, y);
+    const size_t o = (size_t)y * dw + x;
+    da[o] = va;
+    db[o] = vb;
+    dd[o] = fabsf(va - vb);
 }
 
 // horizontal pyrUp value at fine column x of coarse row s (sw entries)
@@ -56,6 +77,19 @@ __device__ __forceinline__ float up_row(const float *__restrict__ s, int sw, int
     return s[k - 1] + s[k] * 6.0f + s[k + 1];
 }
 
+// cv::pyrUp value at fine pixel (x, y) of a sw x sh source
+__device__ __forceinline__ float pyr_up_at(const float *__restrict__ src, int sw, int sh, int x, int y)
+{
+    const int j = y >> 1;
+    const int jm = j > 0 ? j - 1 : (sh > 1 ? 1 : 0);
+    const int jp = j < sh - 1 ? j + 1 : sh - 1;
+    const float r1 = up_row(src + (size_t)j * sw, sw, x);
+    const float r2 = up_row(src + (size_t)jp * sw, sw, x);
+    if (y & 1) return (r1 + r2) * 4.0f * (1.0f / 64.0f);
+    const float r0 = up_row(src + (size_t)jm * sw, sw, x);
+    return (r0 + r1 * 6.0f + r2) * (1.0f / 64.0f);
+}
+
 // acc[y][x] += pyrUp(src)[y][x]
 __global__ __launch_bounds__(256) void pyr_up_add_kernel(const float *__restrict__ src, int sw, int sh,
                                                          float *__restrict__ acc, int dw, int dh)
@@ -63,19 +97,41 @@ __global__ __launch_bounds__(256) void pyr_up_add_kernel(const float *__restrict
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= dw || y >= dh) return;
-    const int j = y >> 1;
-    const int jm = j > 0 ? j - 1 : (sh > 1 ? 1 : 0);
-    const int jp = j < sh - 1 ? j + 1 : sh - 1;
-    const float r1 = up_row(src + (size_t)j * sw, sw, x);
-    const float r2 = up_row(src + (size_t)jp * sw, sw, x);
-    float t;
-    if (y & 1) {
-        t = (r1 + r2) * 4.0f * (1.0f / 64.0f);
-    } else {
-        const float r0 = up_row(src + (size_t)jm * sw, sw, x);
-        t = (r0 + r1 * 6.0f + r2) * (1.0f / 64.0f);
+    acc[(size_t)y * dw + x] += pyr_up_at(src, sw, sh, x, y);
+}
+
+// The small end of compare()'s pyramid in ONE workgroup: from level `first` (already built, <= 4096 cells) down to the
+// coarsest level and back up to `first`, i.e. the launches of levels first+1 .. nlev-1 and the pyrUp-adds that end
+// in level `first`.  Levels are tiny (40x30 and below at 640x480), so a launch each is pure overhead.  Steps are
+// separated by workgroup barriers; every value is computed by the same device functions as the per-level kernels.
+struct PyrTail {
+    int first, nlev;
+    int w[24], h[24];
+    unsigned off[24];  // element offset of each level inside the A / B / D arenas
+};
+
+__global__ __launch_bounds__(1024) void pyramid_tail(float *__restrict__ A, float *__restrict__ B, float *__restrict__ D, PyrTail t)
+{
+    for (int i = t.first + 1; i < t.nlev; i++) {
+        const int n = t.w[i] * t.h[i];
+        for (int c = threadIdx.x; c < n; c += blockDim.x) {
+            const int y = c / t.w[i], x = c - y * t.w[i];
+            const float va = pyr_down_at(A + t.off[i - 1], t.w[i - 1], t.h[i - 1], x, y);
+            const float vb = pyr_down_at(B + t.off[i - 1], t.w[i - 1], t.h[i - 1], x, y);
+            A[t.off[i] + c] = va;
+            B[t.off[i] + c] = vb;
+            D[t.off[i] + c] = fabsf(va - vb);
+        }
+        __syncthreads();
     }
-    acc[(size_t)y * dw + x] += t;
+    for (int i = t.nlev - 2; i >= t.first; i--) {
+        const int n = t.w[i] * t.h[i];
+        for (int c = threadIdx.x; c < n; c += blockDim.x) {
+            const int y = c / t.w[i], x = c - y * t.w[i];
+            D[t.off[i] + c] += pyr_up_at(D + t.off[i + 1], t.w[i + 1], t.h[i + 1], x, y);
+        }
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(256) void u8_to_f32_pair_absdiff(const uint8_t *__restrict__ a8, const uint8_t *__restrict__ b8,
@@ -222,14 +278,33 @@ int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, flo
     const size_t P = (size_t)W * H;
     u8_to_f32_pair_absdiff<<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(prev8, next8, A, B, out, P);
     MVS_HIP(ctx, hipGetLastError());
-    for (int i = 1; i < nlev; i++) {
-        pyr_down_kernel<<<grid2d(lw[i], lh[i]), 256, 0, ctx->stream>>>(A + off[i - 1], lw[i - 1], lh[i - 1], A + off[i], lw[i], lh[i]);
-        pyr_down_kernel<<<grid2d(lw[i], lh[i]), 256, 0, ctx->stream>>>(B + off[i - 1], lw[i - 1], lh[i - 1], B + off[i], lw[i], lh[i]);
-        const size_t n = (size_t)lw[i] * lh[i];
-        absdiff_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(A + off[i], B + off[i], D + off[i], n);
+    // levels of at most 4096 cells (never level 0, whose difference lives in `out`) are finished by one workgroup
+    int tail = nlev;
+    for (int i = 1; i < nlev; i++)
+        if ((size_t)lw[i] * lh[i] <= 4096 && nlev <= 24) {
+            tail = i;
+            break;
+        }
+    for (int i = 1; i < nlev && i <= tail; i++) {
+        pyr_down_pair_absdiff<<<grid2d(lw[i], lh[i]), 256, 0, ctx->stream>>>(A + off[i - 1], B + off[i - 1], lw[i - 1], lh[i - 1],
+                                                                             A + off[i], B + off[i], D + off[i], lw[i], lh[i]);
         MVS_HIP(ctx, hipGetLastError());
     }
-    for (int i = nlev - 2; i >= 0; i--) {
+    int up_from = nlev - 2;
+    if (tail < nlev - 1) {
+        PyrTail t;
+        t.first = tail;
+        t.nlev = nlev;
+        for (int i = 0; i < nlev; i++) {
+            t.w[i] = lw[i];
+            t.h[i] = lh[i];
+            t.off[i] = (unsigned)off[i];
+        }
+        pyramid_tail<<<1, 1024, 0, ctx->stream>>>(A, B, D, t);
+        MVS_HIP(ctx, hipGetLastError());
+        up_from = tail - 1;
+    }
+    for (int i = up_from; i >= 0; i--) {
         float *dst = i == 0 ? out : D + off[i];
         pyr_up_add_kernel<<<grid2d(lw[i], lh[i]), 256, 0, ctx->stream>>>(D + off[i + 1], lw[i + 1], lh[i + 1], dst, lw[i], lh[i]);
         MVS_HIP(ctx, hipGetLastError());

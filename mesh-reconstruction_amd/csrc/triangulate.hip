@@ -340,6 +340,100 @@ static void host_center(const float *cam, float *c3)
 }
 
 // triangulatePixels; `flows_hw4` and `depth_hw` are host pointers, or device pointers when on_device (pipeline.hip)
+
+// ---- ordered compaction of the valid pixels (the reference's pixelId order, util.cpp:172,247-248) on the device -------------
+constexpr int CP_CHUNK = 2048;  // pixels per workgroup: 256 threads x 8 consecutive pixels
+
+__global__ __launch_bounds__(256) void compact_count(const uint8_t *__restrict__ valid, size_t P, int *__restrict__ block_counts)
+{
+    __shared__ int wave_sums[4];
+    const size_t base = (size_t)blockIdx.x * CP_CHUNK + (size_t)threadIdx.x * 8;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (base + i < P && valid[base + i]) c++;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+}
+
+// exclusive scan of the block counts by one workgroup; block_counts[nb] receives the total
+__global__ __launch_bounds__(256) void compact_scan(int *__restrict__ block_counts, int nb)
+{
+    __shared__ int part[256];
+    const int per = (nb + 255) / 256, first = threadIdx.x * per, last = min(nb, first + per);
+    int s = 0;
+    for (int i = first; i < last; i++) s += block_counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; i++) {
+            const int v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        block_counts[nb] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = first; i < last; i++) {
+        const int v = block_counts[i];
+        block_counts[i] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_scatter(const uint8_t *__restrict__ valid, const float *__restrict__ pts,
+                                                       const float *__restrict__ nrm, size_t P,
+                                                       const int *__restrict__ block_offsets, float *__restrict__ out7)
+{
+    __shared__ int thread_off[256];
+    const size_t base = (size_t)blockIdx.x * CP_CHUNK + (size_t)threadIdx.x * 8;
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (base + i < P && valid[base + i]) mask |= 1u << i;
+    thread_off[threadIdx.x] = __popc(mask);
+    __syncthreads();
+    if (threadIdx.x < 64) {  // one wavefront scans the 256 per-thread counts, 4 each
+        int v[4], s = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            v[i] = thread_off[threadIdx.x * 4 + i];
+            s += v[i];
+        }
+        int incl = s;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if ((int)threadIdx.x >= o) incl += t;
+        }
+        int run = incl - s;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            thread_off[threadIdx.x * 4 + i] = run;
+            run += v[i];
+        }
+    }
+    __syncthreads();
+    size_t n = (size_t)block_offsets[blockIdx.x] + (size_t)thread_off[threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (mask & (1u << i)) {
+            const size_t p = base + i;
+            float *o = out7 + n * 7;
+            o[0] = pts[4 * p];
+            o[1] = pts[4 * p + 1];
+            o[2] = pts[4 * p + 2];
+            o[3] = pts[4 * p + 3];
+            o[4] = nrm[3 * p];
+            o[5] = nrm[3 * p + 1];
+            o[6] = nrm[3 * p + 2];
+            n++;
+        }
+}
+
 int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, bool on_device, const float main_cam[16],
                      const float *side_cams, const float *depth_hw, float *out_points7, int *out_count)
 {
@@ -387,15 +481,17 @@ int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, bo
     float main_center[3];
     host_center(main_cam, main_center);
 
-    // arena: flows (V*4P) | depth P | grad 2P | pts 4P | pdf P | normals 3P | xyz 3P | valid P bytes | tables
+    // arena: flows (V*4P) | depth P | grad 2P | pts 4P | pdf P | normals 3P | xyz 3P | packed 7P | block counts | valid P bytes | tables
     const size_t flow_floats = on_device ? 0 : (size_t)V * 4 * P;
-    const size_t floats = flow_floats + P + 2 * P + 4 * P + P + 3 * P + 3 * P;
+    const int nb = (int)((P + CP_CHUNK - 1) / CP_CHUNK);
+    const size_t floats = flow_floats + P + 2 * P + 4 * P + P + 3 * P + 3 * P + 7 * P + (size_t)nb + 2;
     const size_t tables = sizeof(CamPre) * pre.size() + sizeof(float) * (16 + 4) + sizeof(float *) * (size_t)(V > 0 ? V : 1);
     int rc = ensure(ctx, ctx->flow_arena, floats * sizeof(float) + P + tables + 256);
     if (rc) return rc;
     float *d_flows = (float *)ctx->flow_arena.ptr, *d_depth = d_flows + flow_floats, *d_grad = d_depth + P, *d_pts = d_grad + 2 * P,
-          *d_pdf = d_pts + 4 * P, *d_nrm = d_pdf + P, *d_xyz = d_nrm + 3 * P;
-    uint8_t *d_valid = (uint8_t *)(d_xyz + 3 * P);
+          *d_pdf = d_pts + 4 * P, *d_nrm = d_pdf + P, *d_xyz = d_nrm + 3 * P, *d_packed = d_xyz + 3 * P;
+    int *d_counts = (int *)(d_packed + 7 * P);
+    uint8_t *d_valid = (uint8_t *)(d_counts + nb + 2);
     uintptr_t t = ((uintptr_t)(d_valid + P) + 63) & ~(uintptr_t)63;
     CamPre *d_pre = (CamPre *)t;
     float *d_minv = (float *)(d_pre + pre.size());
@@ -421,22 +517,19 @@ int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, bo
     tri_points_kernel<<<dim3(div_up(W, 64), div_up(H, 2)), 128, 0, st>>>(d_ptrs, d_pre, V, d_minv, d_depth, d_grad, W, H, d_valid,
                                                                          d_pts, d_xyz, d_pdf);
     tri_normals_kernel<<<dim3(div_up(W, 64), div_up(H, 2)), 128, 0, st>>>(d_valid, d_pts, d_xyz, d_pdf, d_pre, d_mc, V, W, H, d_nrm);
+    // compaction in pixel scan order (the reference's pixelId, util.cpp:172,247-248) on the device: only the packed
+    // rows cross PCIe, straight into the caller's buffer
+    compact_count<<<nb, 256, 0, st>>>(d_valid, P, d_counts);
+    compact_scan<<<1, 256, 0, st>>>(d_counts, nb);
+    compact_scatter<<<nb, 256, 0, st>>>(d_valid, d_pts, d_nrm, P, d_counts, d_packed);
     MVS_HIP(ctx, hipGetLastError());
-    std::vector<float> h_pts(4 * P), h_nrm(3 * P);
-    std::vector<uint8_t> h_valid(P);
-    MVS_HIP(ctx, hipMemcpyAsync(h_pts.data(), d_pts, sizeof(float) * 4 * P, hipMemcpyDeviceToHost, st));
-    MVS_HIP(ctx, hipMemcpyAsync(h_nrm.data(), d_nrm, sizeof(float) * 3 * P, hipMemcpyDeviceToHost, st));
-    MVS_HIP(ctx, hipMemcpyAsync(h_valid.data(), d_valid, P, hipMemcpyDeviceToHost, st));
-    MVS_HIP(ctx, hipStreamSynchronize(st));
-    // compaction in pixel scan order: the reference's pixelId (util.cpp:172,247-248)
     int n = 0;
-    for (size_t p = 0; p < P; p++)
-        if (h_valid[p]) {
-            float *o = out_points7 + (size_t)n * 7;
-            memcpy(o, &h_pts[4 * p], sizeof(float) * 4);
-            memcpy(o + 4, &h_nrm[3 * p], sizeof(float) * 3);
-            n++;
-        }
+    MVS_HIP(ctx, hipMemcpyAsync(&n, d_counts + nb, sizeof(int), hipMemcpyDeviceToHost, st));
+    MVS_HIP(ctx, hipStreamSynchronize(st));
+    if (n > 0) {
+        MVS_HIP(ctx, hipMemcpyAsync(out_points7, d_packed, sizeof(float) * 7 * (size_t)n, hipMemcpyDeviceToHost, st));
+        MVS_HIP(ctx, hipStreamSynchronize(st));
+    }
     *out_count = n;
     return MVS_OK;
 }
