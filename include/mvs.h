@@ -136,6 +136,10 @@ int mvs_sweep_plane_granularity(void);
  * Volume cells and depth / cost / index outside the band are left untouched. */
 int mvs_sweep_run_rows(mvs_ctx *ctx, int view_first, int view_count, int row_first, int row_count, unsigned flags);
 int mvs_sweep_row_granularity(void);
+/* diagnostic: thread shape the region planner chose for the current (views, planes): 0 = no plan yet,
+ * 1 = 2 pixels x 32 planes per thread (64x8-pixel tiles), 2 = 4 pixels x 16 planes (64x16 tiles).  Results are
+ * bit-identical either way; the choice follows how many warped 32-plane footprints fit the LDS staging buffer. */
+int mvs_sweep_plan_shape(const mvs_ctx *ctx);
 /* per-pixel depth selection over the packed volume (async); valid after MVS_SWEEP_VOLUME runs or
  * after the caller has reduced the volume across ranks in place */
 int mvs_sweep_argmin(mvs_ctx *ctx);

@@ -51,6 +51,9 @@ struct mvs_ctx {
     float main_cam[16] = {0};
     bool have_main = false, have_views = false, have_planes = false;
     bool plan_valid = false;         // region plan matches current (views, planes)
+    int plan_shape = 2;              // thread shape the plan was made for: 1 = 2 px x 32 planes, 2 = 4 px x 16 planes
+    bool plan_forced = false;        // plan made with the 4 x 16 shape forced (timing experiments)
+    mvs::DevBuf plan_stats;          // planner counters (oversize regions, regions not skipped)
     std::vector<float> q_host;       // V*12
     std::vector<float> z_host;       // D
 

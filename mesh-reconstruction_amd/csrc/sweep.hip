@@ -18,7 +18,7 @@
 //
 // Kernels:
 //   plan_regions      per (tile, plane chunk, view): bounding box of the warped tile -> LDS region
-//   sweep_tiled       LDS-staged side-image tiles, 64x16 pixel tiles, PC planes per chunk
+//   sweep_tiled       LDS-staged side-image tiles; 64x8-pixel tiles x 32 planes or 64x16 x 16 planes per chunk
 //   sweep_generic     no tiling, global gathers; any geometry; also the in-kernel fallback
 //   argmin_volume     depth selection over the packed volume (after an optional cross-rank reduction)
 #include "mvs_internal.hpp"
@@ -28,9 +28,13 @@ namespace mvs {
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 
 constexpr int TILE_W = 64;   // one wavefront spans a tile row
-constexpr int TILE_H = 16;
-constexpr int NPX = 4;       // pixels per thread (rows 4*wave + j)
-constexpr int PC = 16;       // planes per chunk (accumulators per pixel)
+// sweep_tiled is instantiated for two thread shapes with 64 accumulators each (NPX pixels x PC planes per thread, tile
+// height 4 * NPX): 2 x 32 amortises the per-(pixel, view) set-up and the staged texels over twice as many planes
+// (c3: 2.20 -> 2.09 ms) but needs the warped footprint of 32 consecutive planes to fit the LDS region; 4 x 16 is the
+// fallback when the planner reports oversize regions (coarse plane spacing: c1, c2).  Chosen per plan, see sweep_run_impl.
+constexpr int PCG = 16;          // planes per accumulator batch of the un-tiled generic kernel
+constexpr int ROW_GRAN = 16;     // public row granularity: a multiple of both tile heights
+constexpr int PLANE_GRAN = 32;   // public plane granularity: a multiple of both chunk sizes
 constexpr int LDS_QUADS = 3840;  // 30 KiB of 8-byte quads per staging buffer
 constexpr int MAX_RW = 128;
 constexpr float PLAN_MARGIN = 0.0625f;
@@ -56,6 +60,9 @@ struct SweepParams {
     int tiles_x, tiles_y, nchunks;
     int chunk0, chunk1;  // plane chunks [chunk0, chunk1) processed by this launch
     int ty0, tyn;        // tile rows [ty0, ty0 + tyn) processed by this launch (row-band sharding)
+    int tile_h, pc;      // shape of the tiled kernel this plan was made for (tile height, planes per chunk)
+    int row_begin, row_end, plane_begin, plane_end;  // the same ranges in pixels / planes (generic kernel)
+    int *__restrict__ plan_stats;  // [0] regions too large for LDS, [1] regions not skipped (planner output)
     int cps;             // plane chunks per workgroup: blockIdx.y selects chunks [chunk0 + y*cps, +cps) of a tile
     uint2 *__restrict__ part;  // plane-split launches with fused depth selection: [gridDim.y][P] partial bests
     int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: linear tile order; bit 2: never use the plane-independent-w path)
@@ -150,8 +157,8 @@ template <bool WRITE_VOLUME, bool FUSED>
 __global__ __launch_bounds__(256) void sweep_generic(SweepParams p)
 {
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int row = p.ty0 * TILE_H + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (col >= p.W || row >= min(p.H, (p.ty0 + p.tyn) * TILE_H)) return;
+    const int row = p.row_begin + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (col >= p.W || row >= p.row_end) return;
     const size_t P = (size_t)p.W * p.H;
     const size_t pix = (size_t)row * p.W + col;
     const float xn = __builtin_fmaf((float)(2 * col + 1), p.invW, -1.0f);
@@ -159,24 +166,24 @@ __global__ __launch_bounds__(256) void sweep_generic(SweepParams p)
     const int Im = p.main_img[pix];
     uint32_t bs = 0, bc = 0;
     int bi = -1;
-    for (int d0 = p.chunk0 * PC; d0 < min(p.D, p.chunk1 * PC); d0 += PC) {
-        uint32_t acc[PC];
+    for (int d0 = p.plane_begin; d0 < p.plane_end; d0 += PCG) {
+        uint32_t acc[PCG];
 #pragma unroll
-        for (int k = 0; k < PC; k++) acc[k] = 0u;
+        for (int k = 0; k < PCG; k++) acc[k] = 0u;
         for (int v = p.v0; v < p.v0 + p.vcount; v++) {
             const float *q = p.Q + 12 * v;
             const Affine A = view_affine(q, xn, yn);
             const float bx = q[2], by = q[6], bw = q[10];
             const uint8_t *pad = p.pads + p.pad_slab * v;
 #pragma unroll
-            for (int k = 0; k < PC; k++) {
-                if (d0 + k < p.D)
+            for (int k = 0; k < PCG; k++) {
+                if (d0 + k < p.plane_end)
                     acc[k] += sample_global(A, bx, by, bw, p.z[d0 + k], pad, p.pitch, p.Wp, p.Hp, Im);
             }
         }
 #pragma unroll
-        for (int k = 0; k < PC; k++) {
-            if (d0 + k < p.D) {
+        for (int k = 0; k < PCG; k++) {
+            if (d0 + k < p.plane_end) {
                 if (WRITE_VOLUME) p.volume[(size_t)(d0 + k) * P + pix] = acc[k];
                 if (FUSED) argmin_update(acc[k], d0 + k, bs, bc, bi);
             }
@@ -199,8 +206,8 @@ __global__ __launch_bounds__(256) void plan_regions(SweepParams p, uint2 *__rest
     const int tile = rest / p.nchunks;
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int c0 = tx * TILE_W, c1 = min(c0 + TILE_W, p.W) - 1;
-    const int r0 = ty * TILE_H, r1 = min(r0 + TILE_H, p.H) - 1;
-    const int d0 = chunk * PC, d1 = min(d0 + PC, p.D) - 1;
+    const int r0 = ty * p.tile_h, r1 = min(r0 + p.tile_h, p.H) - 1;
+    const int d0 = chunk * p.pc, d1 = min(d0 + p.pc, p.D) - 1;
     const float *q = p.Q + 12 * v;
     const float bx = q[2], by = q[6], bw = q[10];
     float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
@@ -240,9 +247,10 @@ __global__ __launch_bounds__(256) void plan_regions(SweepParams p, uint2 *__rest
         rw = ((x1 - x0 + 1) + 3) & ~3;
         rh = y1 - y0 + 1;
         pitch = (rw + 31) & ~31;
-        if (rw > MAX_RW || rw <= 0 || rh <= 0 || pitch * rh > LDS_QUADS)
+        if (rw > MAX_RW || rw <= 0 || rh <= 0 || pitch * rh > LDS_QUADS) {
             mode = R_GENERIC;
-        else if (xmin > 0.5f + m && xmax < p.Wp - m && ymin > 0.5f + m && ymax < p.Hp - m)
+            atomicAdd(p.plan_stats, 1);
+        } else if (xmin > 0.5f + m && xmax < p.Wp - m && ymin > 0.5f + m && ymax < p.Hp - m)
             mode = R_FAST;
         else
             mode = R_BORDER;
@@ -251,6 +259,7 @@ __global__ __launch_bounds__(256) void plan_regions(SweepParams p, uint2 *__rest
     d.x = (unsigned)x0 | ((unsigned)y0 << 16);
     d.y = (unsigned)rw | ((unsigned)rh << 8) | (mode << 16) | ((unsigned)(pitch >> 5) << 24);
     plan[tid] = d;
+    if (mode != R_SKIP) atomicAdd(p.plan_stats + 1, 1);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -423,7 +432,7 @@ __device__ __forceinline__ void sample_lds_pair(const Affine &A, float bx, float
 // Element-wise the same arithmetic as sample_lds_pair.
 typedef unsigned long long quad_bits_t;
 
-template <bool WCONST>
+template <int PC, bool WCONST>
 __device__ __forceinline__ void sample_chunk_pipelined(const Affine &A, float bx, float by, float bw, float r_const,
                                                        const float (&zc)[PC], int rp8, int lds_minus_org8, uint32_t Im,
                                                        uint32_t (&acc)[PC])
@@ -500,9 +509,10 @@ __device__ __forceinline__ int grouped_tile(int bid, int tiles_x, int tiles_y)
 // 3 workgroups per CU (<= 168 VGPRs): 2 per CU measured 9 % slower (not enough waves to cover the two barriers per
 // staged region).  The fused variants keep the running best plane of each pixel in LDS (8 KiB, touched once per
 // plane chunk) instead of 8-12 more registers, which would spill under the cap.
-template <bool WRITE_VOLUME, bool FUSED>
+template <int NPX, int PC, bool WRITE_VOLUME, bool FUSED>
 __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
 {
+    constexpr int TILE_H = 4 * NPX;  // 4 wavefronts, NPX rows each
     __shared__ __attribute__((aligned(16))) uint2 lds[LDS_QUADS];
     __shared__ uint2 best_state[FUSED ? 256 * NPX : 1];  // (packed best cell, best index) per (pixel j, thread)
 
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
                         if (ok[j]) {
                             const Affine A = view_affine(q, xn, yn[j]);
                             const float r_const = rcp_rn(__builtin_fmaf(zc[0], bw, A.aw));
-                            sample_chunk_pipelined<true>(A, bx, by, bw, r_const, zc, rv.rp8, lds_minus_org8, (uint32_t)Im[j], acc[j]);
+                            sample_chunk_pipelined<PC, true>(A, bx, by, bw, r_const, zc, rv.rp8, lds_minus_org8, (uint32_t)Im[j], acc[j]);
                         }
                     }
                 } else {
@@ -781,7 +791,7 @@ __global__ void rcp_check_kernel(uint32_t exp_bits, unsigned long long *out)
 // defined in context.hip
 __global__ void pad_wrap_kernel(const uint8_t *__restrict__ img, uint8_t *__restrict__ pad, int W, int H, int pitch);
 
-static int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount)
+static int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount, int tile_h, int pc)
 {
     p.main_img = (const uint8_t *)ctx->main_img.ptr;
     p.pads = (const uint8_t *)ctx->side_pads.ptr;
@@ -805,14 +815,21 @@ static int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount)
     p.Hp = (float)ctx->H + 0.5f;
     p.plan = (const uint2 *)ctx->plan.ptr;
     p.tiles_x = div_up(ctx->W, TILE_W);
-    p.tiles_y = div_up(ctx->H, TILE_H);
-    p.nchunks = div_up(ctx->D, PC);
+    p.tile_h = tile_h;
+    p.pc = pc;
+    p.tiles_y = div_up(ctx->H, tile_h);
+    p.nchunks = div_up(ctx->D, pc);
     p.chunk0 = 0;
     p.chunk1 = p.nchunks;
     p.ty0 = 0;
     p.tyn = p.tiles_y;
+    p.row_begin = 0;
+    p.row_end = ctx->H;
+    p.plane_begin = 0;
+    p.plane_end = ctx->D;
     p.cps = p.nchunks;
     p.part = nullptr;
+    p.plan_stats = nullptr;
     p.debug = 0;
     return MVS_OK;
 }
@@ -872,14 +889,16 @@ int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags)
 int mvs_sweep_run_rows(mvs_ctx *ctx, int view_first, int view_count, int row_first, int row_count, unsigned flags)
 {
     if (!ctx) return MVS_EINVAL;
-    if (row_first < 0 || row_count < 0 || row_first + row_count > ctx->H || (row_first % TILE_H) != 0 ||
-        ((row_first + row_count) % TILE_H != 0 && row_first + row_count != ctx->H))
+    if (row_first < 0 || row_count < 0 || row_first + row_count > ctx->H || (row_first % ROW_GRAN) != 0 ||
+        ((row_first + row_count) % ROW_GRAN != 0 && row_first + row_count != ctx->H))
         return fail(ctx, MVS_EINVAL, "mvs_sweep_run_rows: row range [%d,%d) must lie in 0..%d and start/end on multiples of %d",
-                    row_first, row_first + row_count, ctx->H, TILE_H);
+                    row_first, row_first + row_count, ctx->H, ROW_GRAN);
     return sweep_run_impl(ctx, view_first, view_count, 0, ctx->D, row_first, row_count, flags);
 }
 
-int mvs_sweep_row_granularity(void) { return TILE_H; }
+int mvs_sweep_row_granularity(void) { return ROW_GRAN; }
+
+int mvs_sweep_plan_shape(const mvs_ctx *ctx) { return (ctx && ctx->plan_valid) ? ctx->plan_shape : 0; }
 
 int mvs_sweep_run_planes(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, unsigned flags)
 {
@@ -893,7 +912,7 @@ int mvs_sweep_run_planes(mvs_ctx *ctx, int view_first, int view_count, int plane
     return sweep_run_impl(ctx, view_first, view_count, plane_first, plane_count, 0, ctx->H, flags);
 }
 
-int mvs_sweep_plane_granularity(void) { return PC; }
+int mvs_sweep_plane_granularity(void) { return PLANE_GRAN; }
 
 static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, int row_first,
                           int row_count, unsigned flags)
@@ -910,29 +929,56 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
     int rc = ensure_outputs(ctx, vol);
     if (rc) return rc;
 
-    SweepParams p;
-    fill_params(ctx, p, view_first, view_count);
-    p.chunk0 = plane_first / PC;
-    p.chunk1 = div_up(plane_first + plane_count, PC);
-    p.ty0 = row_first / TILE_H;
-    p.tyn = div_up(row_first + row_count, TILE_H) - p.ty0;
-    if (p.tyn <= 0) return MVS_OK;  // empty band: nothing to compute
     const bool generic = (flags & MVS_SWEEP_FORCE_GENERIC) != 0;
-    p.debug = (int)((flags >> 8) & 0xff);  // undocumented timing-experiment bits
+    const int debug = (int)((flags >> 8) & 0xff);  // undocumented timing-experiment bits (bit 3: never use the 2 x 32 shape)
+    if (row_count <= 0) return MVS_OK;              // empty band: nothing to compute
 
+    // thread shape of the tiled kernel (see the constants at the top): 2 pixels x 32 planes unless the planner finds
+    // that more than 2 % of the regions a 32-plane chunk touches do not fit the LDS staging buffer
+    const bool force_tall = (debug & 8) != 0;
+    if (ctx->plan_valid && ctx->plan_forced != force_tall) ctx->plan_valid = false;
     if (!generic && !ctx->plan_valid && ctx->V > 0) {
-        const size_t n = (size_t)p.tiles_x * p.tiles_y * p.nchunks * p.V;
-        if ((rc = ensure(ctx, ctx->plan, n * sizeof(uint2)))) return rc;
-        p.plan = (const uint2 *)ctx->plan.ptr;
+        if ((rc = ensure(ctx, ctx->plan_stats, 64))) return rc;
+        int *stats = (int *)ctx->plan_stats.ptr;
         ProfileScope ps(ctx, MVS_K_PLAN);
-        plan_regions<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(p, (uint2 *)ctx->plan.ptr);
-        MVS_HIP(ctx, hipGetLastError());
+        for (int shape = force_tall ? 2 : 1; shape <= 2; shape++) {
+            SweepParams q;
+            fill_params(ctx, q, 0, ctx->V, shape == 1 ? 8 : 16, shape == 1 ? 32 : 16);
+            const size_t n = (size_t)q.tiles_x * q.tiles_y * q.nchunks * q.V;
+            if ((rc = ensure(ctx, ctx->plan, n * sizeof(uint2)))) return rc;
+            q.plan = (const uint2 *)ctx->plan.ptr;
+            q.plan_stats = stats;
+            MVS_HIP(ctx, hipMemsetAsync(stats, 0, 2 * sizeof(int), ctx->stream));
+            plan_regions<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(q, (uint2 *)ctx->plan.ptr);
+            MVS_HIP(ctx, hipGetLastError());
+            ctx->plan_shape = shape;
+            if (shape == 2) break;
+            int h[2] = {0, 0};
+            MVS_HIP(ctx, hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+            MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if ((long long)h[0] * 50 <= (long long)h[1]) break;  // at most 2 % oversize: keep 2 x 32
+        }
         ctx->plan_valid = true;
+        ctx->plan_forced = force_tall;
     }
+    const int shape = (generic || ctx->V == 0) ? 2 : ctx->plan_shape;
+    const int tile_h = shape == 1 ? 8 : 16, pc = shape == 1 ? 32 : 16;
+
+    SweepParams p;
+    fill_params(ctx, p, view_first, view_count, tile_h, pc);
+    p.debug = debug;
+    p.chunk0 = plane_first / pc;
+    p.chunk1 = div_up(plane_first + plane_count, pc);
+    p.ty0 = row_first / tile_h;
+    p.tyn = div_up(row_first + row_count, tile_h) - p.ty0;
+    p.row_begin = row_first;
+    p.row_end = min(ctx->H, row_first + row_count);
+    p.plane_begin = plane_first;
+    p.plane_end = min(ctx->D, plane_first + plane_count);
     {
         ProfileScope ps(ctx, MVS_K_SWEEP);
         if (generic || ctx->V == 0) {
-            dim3 grid(div_up(ctx->W, 64), p.tyn * (TILE_H / 4));
+            dim3 grid(div_up(ctx->W, 64), div_up(p.row_end - p.row_begin, 4));
             if (vol && fused)
                 sweep_generic<true, true><<<grid, 256, 0, ctx->stream>>>(p);
             else if (vol)
@@ -955,15 +1001,24 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
                 p.part = (uint2 *)ctx->best_parts.ptr;
             }
             const dim3 grid((unsigned)(div_up(groups, 8) * 64), (unsigned)nsplit);
-            if (vol && fused)
-                sweep_tiled<true, true><<<grid, 256, 0, ctx->stream>>>(p);
-            else if (vol)
-                sweep_tiled<true, false><<<grid, 256, 0, ctx->stream>>>(p);
-            else
-                sweep_tiled<false, true><<<grid, 256, 0, ctx->stream>>>(p);
+            if (shape == 1) {
+                if (vol && fused)
+                    sweep_tiled<2, 32, true, true><<<grid, 256, 0, ctx->stream>>>(p);
+                else if (vol)
+                    sweep_tiled<2, 32, true, false><<<grid, 256, 0, ctx->stream>>>(p);
+                else
+                    sweep_tiled<2, 32, false, true><<<grid, 256, 0, ctx->stream>>>(p);
+            } else {
+                if (vol && fused)
+                    sweep_tiled<4, 16, true, true><<<grid, 256, 0, ctx->stream>>>(p);
+                else if (vol)
+                    sweep_tiled<4, 16, true, false><<<grid, 256, 0, ctx->stream>>>(p);
+                else
+                    sweep_tiled<4, 16, false, true><<<grid, 256, 0, ctx->stream>>>(p);
+            }
             if (p.part) {
-                const size_t first = (size_t)p.ty0 * TILE_H * ctx->W;
-                const size_t count = (size_t)(min(ctx->H, (p.ty0 + p.tyn) * TILE_H) - p.ty0 * TILE_H) * ctx->W;
+                const size_t first = (size_t)p.row_begin * ctx->W;
+                const size_t count = (size_t)(p.row_end - p.row_begin) * ctx->W;
                 combine_best<<<(unsigned)((count + 255) / 256), 256, 0, ctx->stream>>>(p, nsplit, first, count);
             }
         }

@@ -51,6 +51,7 @@ ABI = [
     ("mvs_sweep_plane_granularity", _i, []),
     ("mvs_sweep_run_rows", _i, [_vp, _i, _i, _i, _i, C.c_uint]),
     ("mvs_sweep_row_granularity", _i, []),
+    ("mvs_sweep_plan_shape", _i, [_vp]),
     ("mvs_sweep_argmin", _i, [_vp]),
     ("mvs_sweep_volume_device", _vp, [_vp, C.POINTER(_sz)]),
     ("mvs_sweep_use_volume", _i, [_vp, _vp, _sz]),
@@ -223,6 +224,9 @@ class Context:
 
     def row_granularity(self):
         return self.lib.mvs_sweep_row_granularity()
+
+    def plan_shape(self):
+        return self.lib.mvs_sweep_plan_shape(self.h)
 
     def depth_device_array(self):
         """zero-copy [H, W] f32 view of the device depth map for torch.as_tensor(..., device='cuda') (valid until the

@@ -350,6 +350,36 @@ def test_plane_split_launches_are_bit_identical():
                         np.testing.assert_array_equal(v, v0)
 
 
+def test_both_thread_shapes_are_bit_identical(oracle):
+    """the tiled kernel exists as 2 px x 32 planes and 4 px x 16 planes per thread; the planner picks per (views, planes).
+    Both must agree with each other and the oracle cell for cell: dense planes (32-plane footprints fit LDS -> 2 x 32)
+    and coarse planes (they do not -> 4 x 16), ragged sizes, general cameras"""
+    both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    seen = set()
+    for (W, H, D, V, radius) in [(384, 200, 96, 3, 0.15), (330, 130, 70, 2, 0.15), (320, 160, 16, 3, 0.5), (384, 200, 200, 2, 0.05)]:
+        main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=radius)
+        side_cams = side_cams.copy()
+        side_cams[0] = _rot_cam(W, H, [0.0, radius, 0.03], 0.01, 0.02)        # one general camera among the ring
+        ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8)
+        with mvs_amd.Context(W, H) as ctx:
+            ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+            assert ctx.plan_shape() == 0
+            ctx.sweep_run(0, V, both)
+            auto = [a.copy() for a in ctx.sweep_fetch(want_volume=True)]
+            shape = ctx.plan_shape()
+            seen.add(shape)
+            ctx.sweep_run(0, 0, both)
+            ctx.sweep_run(0, V, both | (8 << 8))                              # force 4 x 16
+            assert ctx.plan_shape() == 2
+            tall = ctx.sweep_fetch(want_volume=True)
+            for a, b in zip(auto, tall):
+                np.testing.assert_array_equal(a, b)
+            ctx.sweep_run(0, V, both)                                        # back to the planner's choice
+            assert ctx.plan_shape() == shape
+        _check(auto, ref, D)
+    assert seen == {1, 2}, "the cases above are meant to exercise both shapes, got %r" % seen
+
+
 def test_plane_independent_w_path_is_bit_identical(oracle):
     """ring cameras (parallel axes, centres in the main focal plane) have Q[2][2] == 0 and take the hoisted-reciprocal
     path; it must equal the general path (debug bit) and the oracle cell for cell; a rotated camera must not take it"""
