@@ -33,6 +33,9 @@ CONFIGS = {
     "c2": (1280, 720, 64, 8),
     "c3": (1920, 1080, 128, 16),
     "c4": (3840, 2160, 256, 32),
+    # c5: the bundled zatisi sequence (120 calibrated 640x480 frames), 128 planes, 4 side views per main frame; a step is
+    # one main frame through the one-call entry mvs_sweep (upload, pad, plan, sweep, depth download).  Not the default.
+    "c5": (640, 480, 128, 4),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -76,6 +79,81 @@ def pmc_traffic(kernel_prefix, config):
         except Exception:
             pass
     return best
+
+
+def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_device):
+    """BASELINE config 5 without the parts that are out of scope (video decoding, CGAL meshing): every main frame of
+    tracks/zatisi.yaml swept against its 4 neighbours at +-5 and +-10 frames, frames sharded round-robin over the ranks
+    (the reference's independent `fa` loop, recon.cpp:65).  Frames are synthetic (the clip is missing from the checkout)."""
+    from mvs_amd import dist as mdist
+    from mvs_amd import tracks
+    W, H, D, V = CONFIGS["c5"]
+    P = W * H
+    t = tracks.load("zatisi.yaml")
+    cams = t["cameras"]
+    nframes = len(cams)
+    rng = np.random.Generator(np.random.PCG64(0x5EED0005))
+    base = rng.integers(0, 256, (H // 4 + 2, W // 4 + 64), dtype=np.uint8).astype(np.float32)
+    big = np.kron(base, np.ones((4, 4), np.float32))
+
+    # a textured strip scrolling 2 px per frame: deterministic, no depth meaning; built before the timed region
+    frames = [np.ascontiguousarray(big[:H, 2 * (f % 100):2 * (f % 100) + W]).astype(np.uint8) for f in range(nframes)]
+
+    def frame(f):
+        return frames[f]
+
+    def sides_of(f):
+        ids = [min(nframes - 1, max(0, f + o)) for o in (-10, -5, 5, 10)]
+        return ids
+    mine = mdist.frame_shard(nframes, rank, world) or [0]
+    side_cams = [np.stack([cams[j] for j in sides_of(f)]) for f in range(nframes)]
+    ctx = mvs_amd.Context(W, H, local_rank)
+
+    def step(i):
+        f = mine[i % len(mine)]
+        ids = sides_of(f)
+        return ctx.sweep(cams[f], frame(f), side_cams[f], [frame(j) for j in ids], D)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        depth = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    ms_sum, launches = ctx.profile_read(reset=True)
+    shape = ctx.plan_shape()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        sweep_ms = ms_sum[mvs_amd.MVS_K_SWEEP] / max(1, launches[mvs_amd.MVS_K_SWEEP])
+        sweep_bytes = float(P) * (V + 1) + 12.0 * P     # depth only: no volume is materialised by mvs_sweep(volume=NULL)
+        achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+        print(json.dumps({
+            "metric": "cost-volume samples/sec (pixels x planes x views)", "value": float(P) * D * V * args.gpus / (dt / args.steps),
+            "unit": "samples/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic frames on the cameras of tracks/zatisi.yaml" + (" [TEST HOOK: ranks share one GPU over gloo]" if same_device else ""),
+            "config": {"workload": "c5: zatisi.yaml %d frames, 640x480, %d planes, %d side views per main frame, one main frame per step "
+                                   "through mvs_sweep (host frames in, host depth out: PCIe and per-frame planning included)" % (nframes, D, V),
+                       "shard": "frames", "frames_per_rank": len(mine), "plan_shape": shape, "device": ctx.info()},
+            "roofline": {"bound": "hbm", "kernel": "sweep_tiled", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": sweep_bytes, "ms_per_launch": sweep_ms,
+                         "valu_bound_note": "VALU-issue bound, see DESIGN.md section 4"},
+            "depth_in_frame_fraction": float((depth != 1.0).mean())}), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -127,6 +205,8 @@ def main():
     cfg = CONFIGS[args.config]
     W, H, D, V = cfg
     P = W * H
+    if args.config == "c5":
+        return run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_device)
     # every rank renders the same deterministic scene; in `frames` mode rank r uses a different main
     # frame (a ring rotated by r positions) so the ranks do not process identical data
     radius = 0.15
