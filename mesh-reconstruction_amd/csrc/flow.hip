@@ -50,9 +50,11 @@ __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t *__restric
 // symmetric separable filter, REFLECT_101: acc = k[c]*S[0]; acc += k[c+j]*(S[+j] + S[-j])
 template <bool COLS>
 __global__ __launch_bounds__(256) void gauss_kernel(const float *__restrict__ src, int w, int h, Taps t, int ksize,
-                                                    float *__restrict__ dst)
+                                                    float *__restrict__ dst, ptrdiff_t src_z = 0, ptrdiff_t dst_z = 0)
 {
     PIX2D
+    src += (ptrdiff_t)blockIdx.z * src_z;  // blockIdx.z: the second frame of a pair, processed by the same launch
+    dst += (ptrdiff_t)blockIdx.z * dst_z;
     const int c = ksize / 2;
     float acc = t.k[c] * src[(size_t)y * w + x];
     for (int j = 1; j <= c; j++) {
@@ -91,9 +93,12 @@ __device__ __forceinline__ void linear_coeff(int d, int dsize, int ssize, int &o
 // cv::resize INTER_LINEAR (f32, CN interleaved channels), optionally followed by `*= mul` (flow *= 1/pyrScale)
 template <int CN>
 __global__ __launch_bounds__(256) void resize_linear_kernel(const float *__restrict__ src, int sw, int sh,
-                                                            float *__restrict__ dst, int w, int h, float mul, int domul)
+                                                            float *__restrict__ dst, int w, int h, float mul, int domul,
+                                                            ptrdiff_t src_z = 0, ptrdiff_t dst_z = 0)
 {
     PIX2D
+    src += (ptrdiff_t)blockIdx.z * src_z;
+    dst += (ptrdiff_t)blockIdx.z * dst_z;
     int sx, sy;
     float a0, a1, b0, b1;
     linear_coeff(x, w, sw, sx, a0, a1);
@@ -117,9 +122,11 @@ struct PolyTaps {
 
 // FarnebackPolyExp, vertical pass: row[x] = (sum g I, sum y g I, sum y^2 g I) over the column, replicate border
 __global__ __launch_bounds__(256) void polyexp_vert(const float *__restrict__ src, int w, int h, PolyTaps t,
-                                                    float *__restrict__ row3)
+                                                    float *__restrict__ row3, ptrdiff_t src_z = 0, ptrdiff_t dst_z = 0)
 {
     PIX2D
+    src += (ptrdiff_t)blockIdx.z * src_z;
+    row3 += (ptrdiff_t)blockIdx.z * dst_z;
     float t0 = src[(size_t)y * w + x] * t.g[0], t1 = 0.f, t2 = 0.f;
     for (int k = 1; k <= t.n; k++) {
         const float a = src[(size_t)(y - k > 0 ? y - k : 0) * w + x];
@@ -137,9 +144,11 @@ __global__ __launch_bounds__(256) void polyexp_vert(const float *__restrict__ sr
 
 // horizontal pass + projection onto the polynomial basis: 5 coefficients per pixel (y, x, y^2, x^2, xy)
 __global__ __launch_bounds__(256) void polyexp_horiz(const float *__restrict__ row3, int w, int h, PolyTaps t,
-                                                     float *__restrict__ dst5)
+                                                     float *__restrict__ dst5, ptrdiff_t src_z = 0, ptrdiff_t dst_z = 0)
 {
     PIX2D
+    row3 += (ptrdiff_t)blockIdx.z * src_z;
+    dst5 += (ptrdiff_t)blockIdx.z * dst_z;
     const float *base = row3 + (size_t)y * w * 3;
     const float *c = base + (size_t)x * 3;
     float g0 = t.g[0];
@@ -164,15 +173,13 @@ __global__ __launch_bounds__(256) void polyexp_horiz(const float *__restrict__ r
     d[4] = (float)(b6 * t.ig55);
 }
 
-__global__ __launch_bounds__(256) void update_matrices_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
-                                                              const float *__restrict__ flow, int w, int h,
-                                                              float *__restrict__ M)
+// FarnebackUpdateMatrices at one pixel: the five products of the displaced polynomial coefficients, from the pixel's own flow
+__device__ __forceinline__ void update_matrix_at(const float *__restrict__ R0, const float *__restrict__ R1, float dx, float dy,
+                                                 int x, int y, int w, int h, float *__restrict__ m)
 {
-    PIX2D
     const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
     const size_t step1 = (size_t)w * 5;
     const float *r0 = R0 + ((size_t)y * w + x) * 5;
-    const float dx = flow[((size_t)y * w + x) * 2], dy = flow[((size_t)y * w + x) * 2 + 1];
     float fx = x + dx, fy = y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     float r2, r3, r4, r5, r6;
@@ -208,12 +215,20 @@ __global__ __launch_bounds__(256) void update_matrices_kernel(const float *__res
         r5 *= scale;
         r6 *= scale;
     }
-    float *m = M + ((size_t)y * w + x) * 5;
     m[0] = r4 * r4 + r6 * r6;
     m[1] = (r4 + r5) * r6;
     m[2] = r5 * r5 + r6 * r6;
     m[3] = r4 * r2 + r6 * r3;
     m[4] = r6 * r2 + r5 * r3;
+}
+
+__global__ __launch_bounds__(256) void update_matrices_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                              const float *__restrict__ flow, int w, int h,
+                                                              float *__restrict__ M)
+{
+    PIX2D
+    update_matrix_at(R0, R1, flow[((size_t)y * w + x) * 2], flow[((size_t)y * w + x) * 2 + 1], x, y, w, h,
+                     M + ((size_t)y * w + x) * 5);
 }
 
 __global__ __launch_bounds__(256) void box_vert_kernel(const float *__restrict__ M, int w, int h, int m,
@@ -246,6 +261,51 @@ __global__ __launch_bounds__(256) void box_horiz_solve_kernel(const double *__re
     const double idet = 1. / (t[0] * t[2] - t[1] * t[1] + 1e-3);
     flow[((size_t)y * w + x) * 2] = (float)((t[0] * t[4] - t[1] * t[3]) * idet);
     flow[((size_t)y * w + x) * 2 + 1] = (float)((t[2] * t[3] - t[1] * t[4]) * idet);
+}
+
+// One Farneback iteration in ONE launch (box_vert + box_horiz_solve + update_matrices).  A workgroup owns 64 x 4 pixels:
+// it first forms the vertical box sums of M for its 64 + 2m columns (the columns box_horiz will address, clamped like
+// it does) into LDS, then every pixel sums its 2m+1 neighbours horizontally, solves for the flow and -- because
+// FarnebackUpdateMatrices needs only the pixel's OWN new flow -- writes the next M right away.  M is read with a halo by
+// the neighbouring workgroups, so it ping-pongs between two buffers.  Same summation order as the separate kernels.
+constexpr int FB_MAXM = 40;  // window radius the LDS buffer is sized for (winsize <= 81; 4K uses 60 -> m = 30)
+
+__global__ __launch_bounds__(256) void farneback_iteration_fused(const float *__restrict__ M_in, const float *__restrict__ R0,
+                                                                 const float *__restrict__ R1, int w, int h, int m, double scale,
+                                                                 float *__restrict__ flow, float *__restrict__ M_out)
+{
+    __shared__ double vsum[4 * (64 + 2 * FB_MAXM) * 5];
+    const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * 4, cols = 64 + 2 * m;
+    for (int i = threadIdx.x; i < 4 * cols; i += 256) {
+        const int r = i / cols, cx = i - r * cols, gy = Y0 + r;
+        if (gy >= h) continue;
+        const int gx = clampi(X0 - m + cx, 0, w - 1);
+        double s[5] = {0, 0, 0, 0, 0};
+        for (int d = -m; d <= m; d++) {
+            const float *p = M_in + ((size_t)clampi(gy + d, 0, h - 1) * w + gx) * 5;
+#pragma unroll
+            for (int c = 0; c < 5; c++) s[c] += p[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 5; c++) vsum[(size_t)i * 5 + c] = s[c];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, r = threadIdx.x >> 6, x = X0 + lx, y = Y0 + r;
+    if (x >= w || y >= h) return;
+    double t[5] = {0, 0, 0, 0, 0};
+    for (int d = -m; d <= m; d++) {
+        // box_horiz addresses column clampi(x + d, 0, w - 1); LDS column k holds clampi(X0 - m + k, 0, w - 1)
+        const double *p = vsum + ((size_t)r * cols + (lx + d + m)) * 5;
+#pragma unroll
+        for (int c = 0; c < 5; c++) t[c] += p[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) t[c] = t[c] * scale;
+    const double idet = 1. / (t[0] * t[2] - t[1] * t[1] + 1e-3);
+    const float dx = (float)((t[0] * t[4] - t[1] * t[3]) * idet), dy = (float)((t[2] * t[3] - t[1] * t[4]) * idet);
+    flow[((size_t)y * w + x) * 2] = dx;
+    flow[((size_t)y * w + x) * 2 + 1] = dy;
+    if (M_out) update_matrix_at(R0, R1, dx, dy, x, y, w, h, M_out + ((size_t)y * w + x) * 5);
 }
 
 // ---- variational refinement -------------------------------------------------------------------------------------
@@ -741,8 +801,10 @@ static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, floa
         }
     }
     double *vs = (double *)arena;  // 5*P doubles first: keeps them 8-byte aligned for any P
-    float *tmp = arena + 10 * P, *blur = tmp + P, *I = blur + P, *row3 = I + P, *R0 = row3 + 3 * P, *R1 = R0 + 5 * P,
-          *M = R1 + 5 * P, *flowA = M + 5 * P, *flowB = flowA + 2 * P;  // 35*P floats in total
+    // per-frame scratch comes in pairs (frame 0 at the pointer, frame 1 one stride further): both frames go through
+    // every preparation kernel in one launch (blockIdx.z)
+    float *tmp = arena + 10 * P, *blur = tmp + 2 * P, *I = blur + 2 * P, *row3 = I + 2 * P, *R0 = row3 + 6 * P, *R1 = R0 + 5 * P,
+          *M = R1 + 5 * P, *flowA = M + 5 * P, *flowB = flowA + 2 * P;  // 41*P floats in total
     PolyTaps pt;
     farneback_taps(poly_n, poly_sigma, pt);
     hipStream_t st = ctx->stream;
@@ -762,20 +824,34 @@ static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, floa
         }
         Taps taps;
         gaussian_taps(smooth_sz, sigma, taps.k);
-        for (int i = 0; i < 2; i++) {
-            gauss_kernel<false><<<g2(W, H), 256, 0, st>>>(i == 0 ? f0 : f1, W, H, taps, smooth_sz, tmp);
-            gauss_kernel<true><<<g2(W, H), 256, 0, st>>>(tmp, W, H, taps, smooth_sz, blur);
-            resize_linear_kernel<1><<<g2(w, h), 256, 0, st>>>(blur, W, H, I, w, h, 1.f, 0);
-            polyexp_vert<<<g2(w, h), 256, 0, st>>>(I, w, h, pt, row3);
-            polyexp_horiz<<<g2(w, h), 256, 0, st>>>(row3, w, h, pt, i == 0 ? R0 : R1);
+        {
+            const ptrdiff_t sP = (ptrdiff_t)P;
+            dim3 gF = g2(W, H), gL = g2(w, h);
+            gF.z = gL.z = 2;
+            gauss_kernel<false><<<gF, 256, 0, st>>>(f0, W, H, taps, smooth_sz, tmp, f1 - f0, sP);
+            gauss_kernel<true><<<gF, 256, 0, st>>>(tmp, W, H, taps, smooth_sz, blur, sP, sP);
+            resize_linear_kernel<1><<<gL, 256, 0, st>>>(blur, W, H, I, w, h, 1.f, 0, sP, sP);
+            polyexp_vert<<<gL, 256, 0, st>>>(I, w, h, pt, row3, sP, 3 * sP);
+            polyexp_horiz<<<gL, 256, 0, st>>>(row3, w, h, pt, R0, 3 * sP, R1 - R0);
         }
         update_matrices_kernel<<<g2(w, h), 256, 0, st>>>(R0, R1, flow, w, h, M);
         const int m = winsize / 2;
         const double bscale = 1. / ((double)winsize * winsize);
-        for (int it = 0; it < iterations; it++) {
-            box_vert_kernel<<<g2(w, h), 256, 0, st>>>(M, w, h, m, vs);
-            box_horiz_solve_kernel<<<g2(w, h), 256, 0, st>>>(vs, w, h, m, bscale, flow);
-            if (it < iterations - 1) update_matrices_kernel<<<g2(w, h), 256, 0, st>>>(R0, R1, flow, w, h, M);
+        // MVS_FB_UNFUSED=1 keeps the three-launch form of an iteration (A/B timing); windows beyond the LDS buffer use it too
+        static const bool unfused = getenv("MVS_FB_UNFUSED") != nullptr;
+        if (unfused || m > FB_MAXM) {
+            for (int it = 0; it < iterations; it++) {
+                box_vert_kernel<<<g2(w, h), 256, 0, st>>>(M, w, h, m, vs);
+                box_horiz_solve_kernel<<<g2(w, h), 256, 0, st>>>(vs, w, h, m, bscale, flow);
+                if (it < iterations - 1) update_matrices_kernel<<<g2(w, h), 256, 0, st>>>(R0, R1, flow, w, h, M);
+            }
+        } else {
+            float *M_cur = M, *M_nxt = (float *)vs;  // the fused form keeps the vertical sums on chip: vs is free
+            for (int it = 0; it < iterations; it++) {
+                farneback_iteration_fused<<<g2(w, h), 256, 0, st>>>(M_cur, R0, R1, w, h, m, bscale, flow,
+                                                                    it < iterations - 1 ? M_nxt : nullptr);
+                std::swap(M_cur, M_nxt);
+            }
         }
         MVS_HIP(ctx, hipGetLastError());
         prevflow = flow;
@@ -841,8 +917,8 @@ struct FlowBufs {
 static int flow_prepare(mvs_ctx *ctx, FlowBufs &b)
 {
     const size_t P = (size_t)ctx->W * ctx->H;
-    // arena: work (36P floats, starts with 5P doubles) first, then f0, f1, flow2, var, out4; u8: prev, next, remapped
-    const size_t work = 36;
+    // arena: work (42P floats, starts with 5P doubles) first, then f0, f1, flow2, var, out4; u8: prev, next, remapped
+    const size_t work = 42;
     int rc;
     if ((rc = ensure(ctx, ctx->flow_arena, sizeof(float) * P * (2 + 2 + 1 + 4 + work) + 3 * P + 256))) return rc;
     b.arena = (float *)ctx->flow_arena.ptr;
