@@ -203,10 +203,50 @@ def test_c3_full_size_properties():
         d_g, c_g, i_g, _ = ctx.sweep_fetch()
         np.testing.assert_array_equal(i_t, i_g)
         np.testing.assert_array_equal(c_t, c_g)
-        # (3) shards of views add up: selecting on views [0,8) + [8,16) volumes summed on the host for a band
+        # (3) the other thread shape of the tiled kernel (the planner picks 2 x 32 here), index for index
+        assert ctx.plan_shape() == 1
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN | (8 << 8))
+        d_s, c_s, i_s, _ = ctx.sweep_fetch()
+        np.testing.assert_array_equal(i_t, i_s)
+        np.testing.assert_array_equal(c_t, c_s)
+        # (4) linearity over views, as a checksum of the packed cells: shards [0,8) and [8,16) add up to the full volume
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
+        full = int(ctx.sweep_fetch(want_volume=True)[3].sum(dtype=np.uint64))
+        parts = 0
+        for v0 in (0, 8):
+            ctx.sweep_run(v0, 8, mvs_amd.MVS_SWEEP_VOLUME)
+            parts += int(ctx.sweep_fetch(want_volume=True)[3].sum(dtype=np.uint64))
+        assert parts == full
     err = np.abs(d_t - gt)[16:-16, 16:-16]
     assert np.median(err) <= 2.0 / D
     assert np.mean(err <= 3.0 / D) > 0.97
+
+
+def test_c3_full_size_vs_oracle(oracle):
+    """BASELINE config c3 at full size against the oracle, every cell of the 1 GB volume and every depth (the oracle takes
+    a couple of seconds on the GPU box's host threads -- it is bench.py's cpu_baseline on the same workload)"""
+    import os
+    W, H, D, V = 1920, 1080, 128, 16
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V)
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=min(256, os.cpu_count() or 8))
+    got = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+    _check(got, ref, D)
+
+
+def test_c4_full_size_depth_vs_oracle(oracle):
+    """BASELINE config c4 (3840x2160, 256 planes, 32 views) at full size on i.i.d. noise frames (SURVEY 8d's adversarial
+    input): depth, cost and index of every pixel against the oracle; the 8.5 GB volume is not materialised"""
+    import os
+    W, H, D, V = 3840, 2160, 256, 32
+    main_cam, main_img, side_cams, sides = synth.noise_views(W, H, V)
+    d_ref, c_ref, i_ref, _ = oracle.sweep(main_cam, main_img, side_cams, sides, D, nthreads=min(256, os.cpu_count() or 8))
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        depth, cost, idx, _ = ctx.sweep_fetch()
+    np.testing.assert_array_equal(idx, i_ref)
+    np.testing.assert_array_equal(depth, d_ref)
+    np.testing.assert_array_equal(cost, c_ref)
 
 
 def _random_camera(rng, W, H, spread, max_angle):
