@@ -31,12 +31,12 @@ constexpr int TILE_W = 64;   // one wavefront spans a tile row
 // sweep_tiled is instantiated for two thread shapes with 64 accumulators each (NPX pixels x PC planes per thread, tile
 // height 4 * NPX): 2 x 32 amortises the per-(pixel, view) set-up and the staged texels over twice as many planes
 // (c3: 2.20 -> 2.09 ms) but needs the warped footprint of 32 consecutive planes to fit the LDS region; 4 x 16 is the
-// fallback when the planner reports oversize regions (coarse plane spacing: c1, c2).  Chosen per plan, see sweep_run_impl.
+// fallback when the planner reports oversize regions (wide baselines with few planes).  Chosen per plan, see sweep_run_impl.
 constexpr int PCG = 16;          // planes per accumulator batch of the un-tiled generic kernel
 constexpr int ROW_GRAN = 16;     // public row granularity: a multiple of both tile heights
 constexpr int PLANE_GRAN = 32;   // public plane granularity: a multiple of both chunk sizes
-constexpr int LDS_QUADS = 3840;  // 30 KiB of 8-byte quads per staging buffer
-constexpr int MAX_RW = 128;
+constexpr int LDS_QUADS = 5120;  // 40 KiB of 8-byte quads per staging buffer
+constexpr int MAX_RW = 192;
 constexpr float PLAN_MARGIN = 0.0625f;
 
 enum RegionMode : unsigned { R_SKIP = 0, R_FAST = 1, R_BORDER = 2, R_GENERIC = 3 };
