@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stage-by-stage GPU vs oracle comparison on the c1 reference-stage workload (diagnostic)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
