@@ -52,6 +52,12 @@ int mvs_synchronize(mvs_ctx *ctx);
 int mvs_width(const mvs_ctx *ctx);
 int mvs_height(const mvs_ctx *ctx);
 
+/* Render::depth restricted to the pixels a caller actually reads: Heuristic::chooseCameras renders 200 face cameras per
+ * outer iteration (heuristic.cpp:445-456) and filterCameras looks ONE pixel up per real camera in each map
+ * (heuristic.cpp:307-312).  Rasterises the depth map for `cam` on the device and returns out[i] = depth[rows[i]][cols[i]]
+ * (same values as mvs_depth, without moving the map across PCIe).  Pixels outside the map are an error. */
+int mvs_depth_probe(mvs_ctx *ctx, const float cam[16], int n, const int32_t *rows, const int32_t *cols, float *out);
+
 /* ---- renderer: replaces class Render (recon.hpp:93-99) ---------------------------------------- */
 /* Render::loadMesh, render_glx.cpp:230-258: verts4 = nverts homogeneous rows (x,y,z,w), faces3 = int32 triples */
 int mvs_load_mesh(mvs_ctx *ctx, const float *verts4, int nverts, const int32_t *faces3, int nfaces);

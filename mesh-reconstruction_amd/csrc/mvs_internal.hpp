@@ -54,6 +54,7 @@ struct mvs_ctx {
     int plan_shape = 2;              // thread shape the plan was made for: 1 = 2 px x 32 planes, 2 = 4 px x 16 planes
     bool plan_forced = false;        // plan made with the 4 x 16 shape forced (timing experiments)
     mvs::DevBuf plan_stats;          // planner counters (oversize regions, regions not skipped)
+    mvs::DevBuf probe_buf;           // mvs_depth_probe: pixel coordinates in, depths out
     std::vector<float> q_host;       // V*12
     std::vector<float> z_host;       // D
 

@@ -93,8 +93,10 @@ __global__ __launch_bounds__(256) void tri_setup(const float *__restrict__ soup,
     t.zb = __builtin_fmaf(b[0], z[0], __builtin_fmaf(b[1], z[1], b[2] * z[2])) * rdet;
     t.zc = __builtin_fmaf(c[0], z[0], __builtin_fmaf(c[1], z[1], c[2] * z[2])) * rdet;
     int x0 = 0, y0 = 0, x1 = W - 1, y1 = H - 1;
-    if (w[0] > 0.0f && w[1] > 0.0f && w[2] > 0.0f) {
-        float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+    bool culled = false;
+    float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+    const bool in_front = w[0] > 0.0f && w[1] > 0.0f && w[2] > 0.0f;
+    if (in_front) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const float nx = x[i] / w[i], ny = y[i] / w[i];
@@ -103,6 +105,58 @@ __global__ __launch_bounds__(256) void tri_setup(const float *__restrict__ soup,
             ymin = fminf(ymin, ny);
             ymax = fmaxf(ymax, ny);
         }
+    } else {
+        // A vertex at or behind the camera plane: the projected vertices say nothing about the footprint.  tri_fragment only
+        // accepts pixels whose point on the face has w > 0 and |z| <= w (all edge functions positive after the sign
+        // normalisation above implies w > 0), and pixel centres lie inside (-1, 1)^2, so every fragment comes from the part
+        // of the face inside the view frustum.  Clip the triangle against a frustum enlarged by 1 % (Sutherland-Hodgman, six
+        // planes, at most nine vertices) and bound what is left; nothing left -> the face cannot produce a fragment.
+        // The cameras Heuristic::chooseCameras puts ON the mesh (near = 0.001, heuristic.cpp:193-247) have half the mesh
+        // behind them and a band of faces across w = 0; with whole-screen boxes for those, a depth map took ~0.8 ms.
+        const float slack = 1.01f;
+        float P[10][4], Q[10][4];
+        int n = 3;
+        for (int i = 0; i < 3; i++) {
+            P[i][0] = x[i];
+            P[i][1] = y[i];
+            P[i][2] = z[i];
+            P[i][3] = w[i];
+        }
+        for (int plane = 0; plane < 6 && n > 0; plane++) {
+            const int axis = plane >> 1;
+            const float sgn = (plane & 1) ? -1.0f : 1.0f;
+            int m = 0;
+            for (int i = 0; i < n; i++) {
+                const float *cur = P[i], *nxt = P[i + 1 < n ? i + 1 : 0];
+                const float fc = slack * cur[3] + sgn * cur[axis], fn = slack * nxt[3] + sgn * nxt[axis];
+                if (fc >= 0.0f) {
+                    for (int k = 0; k < 4; k++) Q[m][k] = cur[k];
+                    m++;
+                }
+                if ((fc >= 0.0f) != (fn >= 0.0f)) {
+                    const float tt = fc / (fc - fn);
+                    for (int k = 0; k < 4; k++) Q[m][k] = cur[k] + tt * (nxt[k] - cur[k]);
+                    m++;
+                }
+            }
+            n = m;
+            for (int i = 0; i < n; i++)
+                for (int k = 0; k < 4; k++) P[i][k] = Q[i][k];
+        }
+        if (n < 3) {
+            culled = true;
+        } else {
+            for (int i = 0; i < n; i++) {
+                const float ww = fmaxf(P[i][3], 1e-30f);
+                const float nx = P[i][0] / ww, ny = P[i][1] / ww;
+                xmin = fminf(xmin, nx);
+                xmax = fmaxf(xmax, nx);
+                ymin = fminf(ymin, ny);
+                ymax = fmaxf(ymax, ny);
+            }
+        }
+    }
+    if (!culled) {
         const float cx0 = ((xmin + 1.0f) * (float)W - 1.0f) * 0.5f - 1.0f;
         const float cx1 = ((xmax + 1.0f) * (float)W - 1.0f) * 0.5f + 1.0f;
         const float ry0 = ((1.0f - ymax) * (float)H - 1.0f) * 0.5f - 1.0f;
@@ -112,7 +166,7 @@ __global__ __launch_bounds__(256) void tri_setup(const float *__restrict__ soup,
         if (ry0 > 0.0f) y0 = ry0 < (float)H ? (int)ry0 : H;
         if (ry1 < (float)(H - 1)) y1 = ry1 >= 0.0f ? (int)ry1 : -1;
     }
-    if (!valid) {
+    if (!valid || culled) {
         x0 = 1;
         x1 = 0;
     }
@@ -158,6 +212,9 @@ __global__ __launch_bounds__(256) void raster_tiles(const TriRec *__restrict__ t
     const float xn = __builtin_fmaf((float)(2 * col + 1), invW, -1.0f);
     const float yn = __builtin_fmaf(-(float)(2 * row + 1), invH, 1.0f);
     const int tx1 = min(tx0 + RT, W) - 1, ty1 = min(ty0 + RT, H) - 1;
+    // NDC coordinates of the tile's corner pixel centres, computed exactly as xn / yn above
+    const float cxn0 = __builtin_fmaf((float)(2 * tx0 + 1), invW, -1.0f), cxn1 = __builtin_fmaf((float)(2 * tx1 + 1), invW, -1.0f);
+    const float cyn0 = __builtin_fmaf(-(float)(2 * ty0 + 1), invH, 1.0f), cyn1 = __builtin_fmaf(-(float)(2 * ty1 + 1), invH, 1.0f);
     float best = 1.0f;  // glClear(GL_DEPTH_BUFFER_BIT)
     int best_id = -1;
     for (int base = 0; base < nfaces; base += 256) {
@@ -167,7 +224,31 @@ __global__ __launch_bounds__(256) void raster_tiles(const TriRec *__restrict__ t
         if (f < nfaces) {
             const int p0 = tris[f].x0y0, p1 = tris[f].x1y1;
             const int bx0 = (short)(p0 & 0xffff), by0 = p0 >> 16, bx1 = (short)(p1 & 0xffff), by1 = p1 >> 16;
-            if (bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0) list[atomicAdd(&count, 1)] = f;
+            if (bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0) {
+                // tile-level reject: each edge function -- as tri_fragment computes it, fma(a, xn, fma(b, yn, c)) -- is
+                // monotone in xn for fixed yn and in yn for fixed xn (rounding is monotone), so its maximum over the
+                // tile's pixel centres is attained at a corner pixel; a negative maximum means no pixel can pass that
+                // edge.  The same argument bounds zn.  Long slivers seen from a camera on the mesh (chooseCameras) have
+                // whole-screen boxes but touch few tiles: 539 -> see profiles us per depth map.
+                const TriRec t = tris[f];
+                bool keep = true;
+#pragma unroll
+                for (int i = 0; i < 3 && keep; i++) {
+                    const float e00 = __builtin_fmaf(t.a[i], cxn0, __builtin_fmaf(t.b[i], cyn0, t.c[i]));
+                    const float e10 = __builtin_fmaf(t.a[i], cxn1, __builtin_fmaf(t.b[i], cyn0, t.c[i]));
+                    const float e01 = __builtin_fmaf(t.a[i], cxn0, __builtin_fmaf(t.b[i], cyn1, t.c[i]));
+                    const float e11 = __builtin_fmaf(t.a[i], cxn1, __builtin_fmaf(t.b[i], cyn1, t.c[i]));
+                    keep = !(fmaxf(fmaxf(e00, e10), fmaxf(e01, e11)) < 0.0f);  // NaN keeps the face
+                }
+                if (keep) {
+                    const float z00 = __builtin_fmaf(t.za, cxn0, __builtin_fmaf(t.zb, cyn0, t.zc));
+                    const float z10 = __builtin_fmaf(t.za, cxn1, __builtin_fmaf(t.zb, cyn0, t.zc));
+                    const float z01 = __builtin_fmaf(t.za, cxn0, __builtin_fmaf(t.zb, cyn1, t.zc));
+                    const float z11 = __builtin_fmaf(t.za, cxn1, __builtin_fmaf(t.zb, cyn1, t.zc));
+                    keep = !(fmaxf(fmaxf(z00, z10), fmaxf(z01, z11)) < -1.0f) && !(fminf(fminf(z00, z10), fminf(z01, z11)) > 1.0f);
+                }
+                if (keep) list[atomicAdd(&count, 1)] = f;
+            }
         }
         __syncthreads();
         const int n = count;
@@ -345,6 +426,13 @@ static int run_raster(mvs_ctx *ctx, const float cam[16], int mode, float *zout, 
 
 // ---- device-buffer forms (also used by pipeline.hip) -----------------------------------------------------------------
 
+__global__ __launch_bounds__(256) void gather_pixels(const float *__restrict__ map, int W, int n, const int32_t *__restrict__ rows,
+                                                     const int32_t *__restrict__ cols, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = map[(size_t)rows[i] * W + cols[i]];
+}
+
 int depth_device(mvs_ctx *ctx, const float cam[16], float *out_dev)
 {
     if (!ctx->soup.ptr) return fail(ctx, MVS_ESTATE, "no mesh loaded (mvs_load_mesh)");
@@ -436,6 +524,31 @@ int mvs_depth(mvs_ctx *ctx, const float cam[16], float *out_hw)
     if (rc) return rc;
     if ((rc = run_raster(ctx, cam, 2, (float *)ctx->r_zbuf.ptr, nullptr))) return rc;
     MVS_HIP(ctx, hipMemcpyAsync(out_hw, ctx->r_zbuf.ptr, P * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
+int mvs_depth_probe(mvs_ctx *ctx, const float cam[16], int n, const int32_t *rows, const int32_t *cols, float *out)
+{
+    if (!ctx || !cam || n < 0 || (n > 0 && (!rows || !cols || !out))) return fail(ctx, MVS_EINVAL, "mvs_depth_probe: bad argument");
+    if (!ctx->soup.ptr) return fail(ctx, MVS_ESTATE, "mvs_depth_probe: no mesh loaded (mvs_load_mesh)");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n; i++)
+        if (rows[i] < 0 || rows[i] >= ctx->H || cols[i] < 0 || cols[i] >= ctx->W)
+            return fail(ctx, MVS_EINVAL, "mvs_depth_probe: pixel %d (%d, %d) outside the %d x %d map", i, rows[i], cols[i], ctx->H, ctx->W);
+    const size_t P = (size_t)ctx->W * ctx->H;
+    int rc = ensure(ctx, ctx->r_zbuf, P * sizeof(float));
+    if (rc) return rc;
+    if ((rc = ensure(ctx, ctx->probe_buf, (size_t)(n > 0 ? n : 1) * 3 * sizeof(int32_t)))) return rc;
+    if ((rc = run_raster(ctx, cam, 2, (float *)ctx->r_zbuf.ptr, nullptr))) return rc;
+    if (n == 0) return MVS_OK;
+    int32_t *d_rows = (int32_t *)ctx->probe_buf.ptr, *d_cols = d_rows + n;
+    float *d_out = (float *)(d_cols + n);
+    MVS_HIP(ctx, hipMemcpyAsync(d_rows, rows, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(ctx, hipMemcpyAsync(d_cols, cols, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    gather_pixels<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>((const float *)ctx->r_zbuf.ptr, ctx->W, n, d_rows, d_cols, d_out);
+    MVS_HIP(ctx, hipGetLastError());
+    MVS_HIP(ctx, hipMemcpyAsync(out, d_out, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
     MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MVS_OK;
 }

@@ -115,31 +115,61 @@ int myFind(const std::vector<int> &list, int index)
 }
 
 // heuristic.cpp:285-341
-LabelledCameras filterCameras(const Mat &viewer, const Mat &depth, const std::vector<Mat> &cameras)
+// The depth lookups are separated from the rest so that a renderer with the DepthProbe extension serves them without
+// moving the whole map to the host: pass 1 applies the tests that precede the lookup and collects (row, col), the
+// depths arrive in one call, pass 2 applies the remaining tests in the original order.  Same decisions as the one-pass form.
+LabelledCameras filterCameras(const Mat &viewer, const Render &render, int rows, int cols, const std::vector<Mat> &cameras,
+                              const std::vector<Mat> &centers)
 {
-    LabelledCameras filtered;
+    struct Candidate {
+        int index;
+        float cfv[4];
+        int row, col;
+    };
+    std::vector<Candidate> cand;
     const Mat viewerCenter = extractCameraCenter(viewer);
     for (int i = 0; i < (int)cameras.size(); i++) {
-        const Mat &camera = cameras[i];
+        Candidate c;
+        c.index = i;
+        Mat cfvM = mvs::matmul(viewer, centers[i]);  // centers[i] = extractCameraCenter(cameras[i]), hoisted out of the 200 shots
+        for (int k = 0; k < 4; k++) c.cfv[k] = cfvM.at<float>(k, 0) / cfvM.at<float>(3, 0);
+        if (c.cfv[2] > 1 || c.cfv[2] < -1) continue;  // wrong side of the face
+        c.row = (int)((c.cfv[1] + 1) * rows / 2);
+        c.col = (int)((c.cfv[0] + 1) * cols / 2);
+        if (c.row < 0 || c.row >= rows || c.col < 0 || c.col > cols) continue;  // `col > cols`, heuristic.cpp:309
+        c.col = std::min(c.col, cols - 1);                                      // the read is clamped (see the header note)
+        cand.push_back(c);
+    }
+    std::vector<float> obstacle(cand.size());
+    if (!cand.empty()) {
+        if (const DepthProbe *probe = dynamic_cast<const DepthProbe *>(&render)) {
+            std::vector<int32_t> r(cand.size()), c(cand.size());
+            for (size_t k = 0; k < cand.size(); k++) {
+                r[k] = cand[k].row;
+                c[k] = cand[k].col;
+            }
+            probe->depthAt(viewer, (int)cand.size(), r.data(), c.data(), obstacle.data());
+        } else {
+            const Mat depth = render.depth(viewer);  // the reference's path: the whole map for a handful of pixels
+            for (size_t k = 0; k < cand.size(); k++) obstacle[k] = depth.at<float>(cand[k].row, cand[k].col);
+        }
+    }
+    LabelledCameras filtered;
+    for (size_t k = 0; k < cand.size(); k++) {
+        const Candidate &c = cand[k];
+        const Mat &camera = cameras[c.index];
         CameraLabel label = dummyLabel;
-        label.index = i;
-        Mat cfvM = mvs::matmul(viewer, extractCameraCenter(camera));
-        float cfv[4];
-        for (int k = 0; k < 4; k++) cfv[k] = cfvM.at<float>(k, 0) / cfvM.at<float>(3, 0);
-        if (cfv[2] > 1 || cfv[2] < -1) continue;  // wrong side of the face
-        label.viewX = cfv[0];
-        label.viewY = cfv[1];
-        int row = (int)((cfv[1] + 1) * depth.rows / 2), col = (int)((cfv[0] + 1) * depth.cols / 2);
-        if (row < 0 || row >= depth.rows || col < 0 || col > depth.cols) continue;  // `col > cols`, heuristic.cpp:309
-        const float obstacleDepth = depth.at<float>(row, std::min(col, depth.cols - 1));
-        if (obstacleDepth != backgroundDepth && obstacleDepth <= cfv[2]) continue;
+        label.index = c.index;
+        label.viewX = c.cfv[0];
+        label.viewY = c.cfv[1];
+        if (obstacle[k] != backgroundDepth && obstacle[k] <= c.cfv[2]) continue;
         Mat vfcM = mvs::matmul(camera, viewerCenter);
         label.distance = vfcM.at<float>(3, 0) / viewerCenter.at<float>(3, 0);
         if (label.distance < 0) continue;
         const float w = vfcM.at<float>(3, 0);
         const float vfc0 = vfcM.at<float>(0, 0) / w, vfc1 = vfcM.at<float>(1, 0) / w;
         if (vfc0 < -1 || vfc0 > 1 || vfc1 < -1 || vfc1 > 1) continue;
-        label.cosFromViewer = std::sqrt(1 / (1 + (cfv[0] * cfv[0] + cfv[1] * cfv[1]) / (focal * focal)));
+        label.cosFromViewer = std::sqrt(1 / (1 + (c.cfv[0] * c.cfv[0] + c.cfv[1] * c.cfv[1]) / (focal * focal)));
         filtered.push_back(std::make_pair(label, camera));
     }
     return filtered;
@@ -223,14 +253,19 @@ int Heuristic::chooseCameras(const Mesh mesh, const std::vector<Mat> cameras, co
     const float samplingResolution = std::sqrt((float)cameras.size()) * config->width * config->height / (totalArea * config->cameraThreshold);
     const int shotCount = 200;  // heuristic.cpp:445
     std::map<unsigned, float> weights;
+    // the reference decomposes every real camera again for every shot (heuristic.cpp:293: 200 x N_cam calls); the centre
+    // of a camera does not depend on the shot, so it is computed once per call with the same function
+    std::vector<Mat> centers;
+    centers.reserve(cameras.size());
+    for (const Mat &camera : cameras) centers.push_back(extractCameraCenter(camera));
     for (int i = 0; i < shotCount; i++) {
         const float choice = rng.uniform() * totalArea;  // heuristic.cpp:450
         int chosenIdx = bisect(areaSum, choice);
         chosenIdx = std::min(std::max(chosenIdx, 0), F - 1);
         const float far = 10;  // heuristic.cpp:454
         const Mat viewer = faceCamera(mesh, chosenIdx, far, focal, rng);
-        const Mat depth = render.depth(viewer);  // the hot callee
-        const LabelledCameras filtered = filterCameras(viewer, depth, cameras);
+        // the hot callee: one depth map per shot (render.depth, or its probed form when the renderer offers it)
+        const LabelledCameras filtered = filterCameras(viewer, render, config->height, config->width, cameras, centers);
         if (filtered.size() >= 2) {
             float mainWeightSum;
             const CameraLabel mainCamera = chooseMain(weights, filtered, &mainWeightSum, config->cameraThreshold, rng);

@@ -98,6 +98,16 @@ public:
 };
 Render *spawnRender(Heuristic hint);
 
+// Optional extension a renderer may also implement (RenderHIP does): depth(camera) restricted to the n pixels the caller
+// reads.  Heuristic::chooseCameras uses it when present -- filterCameras reads one pixel per real camera out of each of
+// its 200 depth maps (heuristic.cpp:307-312, 445-456) -- and falls back to depth() otherwise.  Not part of the
+// reference's interface; a renderer that lacks it changes nothing but speed.
+class DepthProbe {
+public:
+    virtual ~DepthProbe() {}
+    virtual void depthAt(const Mat camera, int n, const int32_t *rows, const int32_t *cols, float *out) const = 0;
+};
+
 // == heuristic ==
 typedef std::pair<int, std::vector<int>> numberedVector;
 

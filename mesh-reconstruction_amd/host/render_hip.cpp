@@ -48,7 +48,7 @@ void expect(const Mat &m, int type, const char *what)
 
 }  // namespace
 
-class RenderHIP : public Render {
+class RenderHIP : public Render, public DepthProbe {
 public:
     RenderHIP(int width, int height) : w(width), h(height)
     {
@@ -85,6 +85,12 @@ public:
         Mat result(h, w, mvs::F32C1);
         if (mvs_depth(ctx, camera.ptr<float>(), result.ptr<float>())) raise(ctx, "depth");
         return result;
+    }
+
+    void depthAt(const Mat camera, int n, const int32_t *rows, const int32_t *cols, float *out) const override
+    {
+        expect(camera, mvs::F32C1, "depthAt camera");
+        if (mvs_depth_probe(ctx, camera.ptr<float>(), n, rows, cols, out)) raise(ctx, "depthAt");
     }
 
     mvs_ctx *context() const { return ctx; }

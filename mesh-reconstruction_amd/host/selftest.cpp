@@ -2,6 +2,7 @@
 //   host_selftest cpu <tracks dir>            RNG known answers, YAML reader, camera centre, filterPoints, getopt
 //   host_selftest gpu <tracks dir> <out dir>  spawnRender -> loadMesh -> depth/projected -> mixBackground ->
 //                                             compare/flowRemap, chooseCameras; raw outputs for the oracle check
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -119,9 +120,27 @@ static int run_gpu(const std::string &tracks, const std::string &out)
             for (int x = 0; x < W; x++) g.at<uint8_t>(y, x) = (uint8_t)(127 + 100 * std::sin((x + 3 * fi) / 23.0) * std::cos((y - fi) / 17.0));
         config.setFrame(fi, g);
     }
+    auto t0 = std::chrono::steady_clock::now();
     const int cameraCount = hint.chooseCameras(mesh, config.allCameras(), *render);  // recon.cpp:46
+    const double ms_probe = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     printf("chooseCameras: %d pairs, %zu main cameras\n", cameraCount, hint.chosen().size());
     CHECK(cameraCount > 0, "heuristic chose no cameras");
+    {
+        // the same 200 shots through the reference's interface only (whole depth maps): identical choices
+        struct PlainRender : Render {
+            Render *inner;
+            explicit PlainRender(Render *r) : inner(r) {}
+            void loadMesh(const Mesh m) override { inner->loadMesh(m); }
+            Mat projected(const Mat c, const Mat f, const Mat p) override { return inner->projected(c, f, p); }
+            Mat depth(const Mat c) const override { return inner->depth(c); }
+        } plain(render);
+        Heuristic hint2(&config);
+        t0 = std::chrono::steady_clock::now();
+        const int count2 = hint2.chooseCameras(mesh, config.allCameras(), plain);
+        const double ms_plain = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        CHECK(count2 == cameraCount && hint2.chosen() == hint.chosen(), "chooseCameras differs between probed and whole-map depth");
+        printf("chooseCameras (200 shots): %.1f ms with depth probes, %.1f ms with whole depth maps\n", ms_probe, ms_plain);
+    }
     std::ofstream sel(out + "/chosen.txt");
     int mains = 0, pairs = 0;
     for (int fa = hint.beginMain(); fa != Heuristic::sentinel; fa = hint.nextMain()) {  // recon.cpp:65

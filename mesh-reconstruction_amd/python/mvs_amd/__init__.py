@@ -33,6 +33,7 @@ ABI = [
     ("mvs_height", _i, [_vp]),
     ("mvs_load_mesh", _i, [_vp, _fp, _i, _i32p, _i]),
     ("mvs_depth", _i, [_vp, _fp, _fp]),
+    ("mvs_depth_probe", _i, [_vp, _fp, _i, _i32p, _i32p, _fp]),
     ("mvs_projected", _i, [_vp, _fp, _u8p, _fp, _u8p]),
     ("mvs_mix_background", _i, [_vp, _u8p, _u8p, _fp, _u8p]),
     ("mvs_compare", _i, [_vp, _u8p, _u8p, _fp]),
@@ -289,6 +290,16 @@ class Context:
         cam = _f32(cam, (4, 4))
         out = np.empty((self.H, self.W), np.float32)
         self._check(self.lib.mvs_depth(self.h, _ptr(cam, _fp), _ptr(out, _fp)))
+        return out
+
+    def depth_probe(self, cam, rows, cols):
+        cam = _f32(cam, (4, 4))
+        rows = np.ascontiguousarray(rows, np.int32).ravel()
+        cols = np.ascontiguousarray(cols, np.int32).ravel()
+        if rows.shape != cols.shape:
+            raise ValueError("rows and cols differ in length")
+        out = np.empty(rows.shape[0], np.float32)
+        self._check(self.lib.mvs_depth_probe(self.h, _ptr(cam, _fp), rows.shape[0], _ptr(rows, _i32p), _ptr(cols, _i32p), _ptr(out, _fp)))
         return out
 
     def projected(self, cam, frame, projector):

@@ -92,6 +92,26 @@ def test_empty_mesh_and_errors(oracle):
             ctx.load_mesh(np.ones((3, 4), np.float32), np.array([[0, 1, 7]], np.int32))  # bad index
 
 
+def test_depth_probe_equals_depth_map(oracle):
+    """mvs_depth_probe: the pixels Heuristic::filterCameras reads (heuristic.cpp:307-312) without moving the map"""
+    W, H = 320, 240
+    verts, faces = scenes.heightfield_mesh(48)
+    soup, ctx = _both(oracle, W, H, verts, faces)
+    cam = synth.camera_at([0.1, -0.05, 0.0], W, H)
+    rng = np.random.default_rng(4)
+    rows = np.concatenate([rng.integers(0, H, 500), [0, H - 1, 0, H - 1]]).astype(np.int32)
+    cols = np.concatenate([rng.integers(0, W, 500), [0, 0, W - 1, W - 1]]).astype(np.int32)
+    with ctx:
+        depth = ctx.depth(cam)
+        got = ctx.depth_probe(cam, rows, cols)
+        np.testing.assert_array_equal(got, depth[rows, cols])
+        np.testing.assert_array_equal(depth, oracle.depth(soup, cam, W, H))
+        assert ctx.depth_probe(cam, [], []).shape == (0,)
+        for bad in ((H, 0), (-1, 0), (0, W)):
+            with pytest.raises(mvs_amd.MvsError):
+                ctx.depth_probe(cam, [bad[0]], [bad[1]])
+
+
 def test_mix_background(oracle):
     rng = np.random.default_rng(2)
     W, H = 200, 100
