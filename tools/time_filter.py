@@ -1,0 +1,18 @@
+import sys, time, json
+sys.path.insert(0, "mesh-reconstruction_amd/python")
+import numpy as np, mvs_amd
+rng = np.random.default_rng(1)
+with mvs_amd.Context(640, 480) as ctx:
+    for n in (100_000, 500_000, 2_000_000):
+        # a noisy surface patch: points on z = f(x, y) with jitter, density ~ like triangulated pixels
+        side = int(np.sqrt(n))
+        x, y = np.meshgrid(np.linspace(-1, 1, side), np.linspace(-1, 1, side))
+        pts = np.stack([x.ravel(), y.ravel(), 0.2 * np.sin(3 * x.ravel()) + rng.normal(0, 0.002, side * side), np.ones(side * side)], 1).astype(np.float32)
+        spacing = 2.0 / side
+        alpha = 4 * 3.0 * spacing            # radius = alpha / 4 = 3 grid spacings (compared with SQUARED distances as the reference does)
+        alpha = 4 * (3.0 * spacing) ** 2
+        t0 = time.perf_counter(); keep = ctx.filter_points(pts, alpha); t1 = time.perf_counter()
+        ctx.profile_enable(True); ctx.profile_read(True)
+        t2 = time.perf_counter(); keep = ctx.filter_points(pts, alpha); t3 = time.perf_counter()
+        ms, nl = ctx.profile_read(True); ctx.profile_enable(False)
+        print(json.dumps({"points": pts.shape[0], "kept": int(len(keep)), "wall_ms": (t3 - t2) * 1e3, "first_call_ms": (t1 - t0) * 1e3, "device_ms_by_class": [round(v, 2) for v in ms]}))
