@@ -14,6 +14,8 @@
 // Quirks kept: squared distances compared with `radius` (81-89), only lower-index neighbours are penalised (152-154).
 #include "mvs_internal.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -219,6 +221,63 @@ __global__ __launch_bounds__(64) void chunk_sums(const double *__restrict__ v, i
     if (lane == 0) out256[c] = t;
 }
 
+// ---- greedy selection (heuristic.cpp:139-163) on the device -----------------------------------------------------------
+// The reference walks the points by descending density; a point whose score is still >= 0.7 is kept and lowers the score
+// of its lower-index neighbours.  That looks serial but the decision of point j depends only on the kept points i with
+// j in lower(i) -- the list up(j) -- that come BEFORE j in the order.  So: sort once (radix sort of
+// (~density bits, index) keys = density descending, index ascending: the reference's stable order), then decide in
+// rounds -- a point is decided as soon as all its earlier-ranked up-neighbours are, applying their subtractions in rank
+// order with the reference's arithmetic ((float)(score - (double)density * w)).  Exactly the sequential result; the
+// number of rounds is the longest dependency chain.
+__global__ __launch_bounds__(256) void greedy_keys(const float *__restrict__ density, int N, unsigned long long *__restrict__ keys)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float d = density[i];
+    const unsigned hi = (d != d) ? 0u : ~__builtin_bit_cast(unsigned, d);  // densities are >= +0; NaN (no neighbours at all) first, by index
+    keys[i] = ((unsigned long long)hi << 32) | (unsigned)i;
+}
+
+__global__ __launch_bounds__(256) void greedy_ranks(const unsigned long long *__restrict__ sorted, int N, int *__restrict__ rank)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < N) rank[(unsigned)sorted[p]] = p;
+}
+
+// state: 0 undecided, 1 kept, 2 dropped
+__global__ __launch_bounds__(256) void greedy_round(unsigned char *__restrict__ state, const int *__restrict__ rank,
+                                                    const float *__restrict__ density, const float *__restrict__ score0,
+                                                    const int *__restrict__ off_up, const Nb *__restrict__ up, int N, float limit,
+                                                    int *__restrict__ undecided)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N || state[j] != 0) return;
+    const int rj = rank[j], k0 = off_up[j], k1 = off_up[j + 1];
+    for (int k = k0; k < k1; k++) {
+        const int i = up[k].idx;
+        if (rank[i] < rj && state[i] == 0) {
+            atomicAdd(undecided, 1);
+            return;
+        }
+    }
+    float s = score0[j];
+    int last = -1;
+    for (;;) {  // kept earlier neighbours in rank order (lists are short: selection by repeated minimum)
+        int best = 0x7fffffff, bk = -1;
+        for (int k = k0; k < k1; k++) {
+            const int i = up[k].idx, ri = rank[i];
+            if (ri < rj && ri > last && ri < best && state[i] == 1) {
+                best = ri;
+                bk = k;
+            }
+        }
+        if (bk < 0) break;
+        s = (float)((double)s - (double)density[up[bk].idx] * (double)up[bk].w);
+        last = best;
+    }
+    state[j] = (s < limit) ? 2 : 1;
+}
+
 }  // namespace mvs
 
 using namespace mvs;
@@ -322,34 +381,45 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
     if (timing) fprintf(stderr, "filter_points[%d] power iterations: %d, neighbour pairs: %d\n", N, it, total);
     lap("power iteration");
 
-    // greedy selection on the host (heuristic.cpp:139-163): sequential by construction
-    std::vector<float> density((size_t)N), score((size_t)N);
-    std::vector<int> off((size_t)N + 1);
-    std::vector<Nb> lo((size_t)(total > 0 ? total : 1));
-    MVS_HIP(ctx, hipMemcpyAsync(density.data(), d_density, sizeof(float) * N, hipMemcpyDeviceToHost, st));
-    MVS_HIP(ctx, hipMemcpyAsync(score.data(), d_score, sizeof(float) * N, hipMemcpyDeviceToHost, st));
-    MVS_HIP(ctx, hipMemcpyAsync(off.data(), d_off_lo, sizeof(int) * ((size_t)N + 1), hipMemcpyDeviceToHost, st));
-    if (total > 0) MVS_HIP(ctx, hipMemcpyAsync(lo.data(), d_lo, sizeof(Nb) * (size_t)total, hipMemcpyDeviceToHost, st));
-    MVS_HIP(ctx, hipStreamSynchronize(st));
-    lap("download (density, score, lists)");
-    std::vector<int> order((size_t)N);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return density[a] > density[b]; });
-    lap("host sort by density");
+    // greedy selection (heuristic.cpp:139-163): order on the device, decisions in dependency rounds (see greedy_round)
+    unsigned long long *d_keys = (unsigned long long *)d_pair, *d_sorted = (unsigned long long *)d_chg;  // the f64 scratch of the power iteration
+    int *d_rank = d_fill;                                                                               // free since nb_fill
+    unsigned char *d_state = (unsigned char *)d_cnt_lo;                                                 // free since the scans
+    int *d_undecided = d_cnt_up;                                                                        // 8 counters, one per round of a batch
+    greedy_keys<<<g, 256, 0, st>>>(d_density, N, d_keys);
+    size_t cub_bytes = 0;
+    if (hipcub::DeviceRadixSort::SortKeys(nullptr, cub_bytes, d_keys, d_sorted, N, 0, 64, st) != hipSuccess)
+        return fail(ctx, MVS_EHIP, "mvs_filter_points: radix sort sizing failed");
+    if ((rc = ensure(ctx, ctx->r_tmp0, cub_bytes > 0 ? cub_bytes : 1))) return rc;
+    if (hipcub::DeviceRadixSort::SortKeys(ctx->r_tmp0.ptr, cub_bytes, d_keys, d_sorted, N, 0, 64, st) != hipSuccess)
+        return fail(ctx, MVS_EHIP, "mvs_filter_points: radix sort failed");
+    greedy_ranks<<<g, 256, 0, st>>>(d_sorted, N, d_rank);
+    MVS_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)N, st));
+    MVS_HIP(ctx, hipGetLastError());
+    lap("device sort by density");
     const float densityLimit = .7f;
-    std::vector<uint8_t> keep((size_t)N, 0);
-    for (int i = 0; i < N; i++) {
-        const int ord = order[i];
-        if (score[ord] < densityLimit) continue;
-        const double localDensity = density[ord];
-        for (int k = off[ord]; k < off[ord + 1]; k++) score[lo[k].idx] = (float)(score[lo[k].idx] - localDensity * lo[k].w);
-        keep[ord] = 1;
+    int rounds = 0;
+    for (bool done = false; !done;) {
+        int h_und[8];
+        MVS_HIP(ctx, hipMemsetAsync(d_undecided, 0, sizeof(h_und), st));
+        for (int r = 0; r < 8; r++)
+            greedy_round<<<g, 256, 0, st>>>(d_state, d_rank, d_density, d_score, d_off_up, d_up, N, densityLimit, d_undecided + r);
+        MVS_HIP(ctx, hipGetLastError());
+        MVS_HIP(ctx, hipMemcpyAsync(h_und, d_undecided, sizeof(h_und), hipMemcpyDeviceToHost, st));
+        MVS_HIP(ctx, hipStreamSynchronize(st));
+        rounds += 8;
+        for (int r = 0; r < 8; r++) done = done || h_und[r] == 0;
+        if (rounds > N + 8) return fail(ctx, MVS_EHIP, "mvs_filter_points: greedy rounds did not converge");
     }
+    if (timing) fprintf(stderr, "filter_points[%d] greedy rounds (batches of 8): %d\n", N, rounds);
+    std::vector<unsigned char> state((size_t)N);
+    MVS_HIP(ctx, hipMemcpyAsync(state.data(), d_state, (size_t)N, hipMemcpyDeviceToHost, st));
+    MVS_HIP(ctx, hipStreamSynchronize(st));
     int m = 0;
     for (int i = 0; i < N; i++)
-        if (keep[i]) keep_out[m++] = i;
+        if (state[i] == 1) keep_out[m++] = i;
     *out_count = m;
-    lap("host greedy pass + output");
+    lap("device greedy rounds + output");
     return MVS_OK;
 }
 
