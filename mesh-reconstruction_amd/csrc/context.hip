@@ -150,6 +150,9 @@ void mvs_destroy(mvs_ctx *ctx)
         if (ctx->flow_graph[i]) (void)hipGraphExecDestroy(ctx->flow_graph[i]);
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
+    if (ctx->filter_pinned) (void)hipHostFree(ctx->filter_pinned);
+    for (int e = 0; e < 2; e++)
+        if (ctx->filter_ev[e]) (void)hipEventDestroy(ctx->filter_ev[e]);
     for (auto &s : ctx->slots) {
         if (s.start) (void)hipEventDestroy(s.start);
         if (s.stop) (void)hipEventDestroy(s.stop);

@@ -92,33 +92,6 @@ __global__ __launch_bounds__(256) void nb_count(const float *__restrict__ p3, co
     cnt_lo[i] = c;
 }
 
-// exclusive scan of n ints by one workgroup (n <= a few million): per-thread contiguous chunk + LDS scan of the partials
-__global__ __launch_bounds__(1024) void exclusive_scan_1wg(const int *__restrict__ in, int n, int *__restrict__ out)
-{
-    __shared__ long long part[1024];
-    const int per = (n + 1023) / 1024;
-    const int s = threadIdx.x * per, e = min(s + per, n);
-    long long sum = 0;
-    for (int i = s; i < e; i++) sum += in[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long run = 0;
-        for (int k = 0; k < 1024; k++) {
-            const long long t = part[k];
-            part[k] = run;
-            run += t;
-        }
-    }
-    __syncthreads();
-    long long run = part[threadIdx.x];
-    for (int i = s; i < e; i++) {
-        out[i] = (int)run;
-        run += in[i];
-    }
-    if (threadIdx.x == 1023) out[n] = (int)run;
-}
-
 __global__ __launch_bounds__(256) void nb_fill(const float *__restrict__ p3, const int *__restrict__ cell3,
                                                const int *__restrict__ head, const int *__restrict__ next, unsigned mask, int N,
                                                float radius, const int *__restrict__ off_lo, const int *__restrict__ off_up,
@@ -185,40 +158,55 @@ __global__ __launch_bounds__(256) void density_score(const float *__restrict__ d
     pair_sum[i] = ps;
 }
 
-__global__ __launch_bounds__(256) void density_update(float *__restrict__ density, const float *__restrict__ score, float normalizer,
-                                                      int N, double *__restrict__ chg)
+__global__ __launch_bounds__(256) void density_update(const float *__restrict__ density, const float *__restrict__ score,
+                                                      const float *__restrict__ normalizer, int N, float *__restrict__ density_out,
+                                                      double *__restrict__ chg)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    float nd = score[i] * normalizer;
+    float nd = score[i] * normalizer[0];
     if (nd > 2.f) nd = 2.f;
     const float df = density[i] - nd;
     chg[i] = (double)(df * df);
-    density[i] = nd;
+    density_out[i] = nd;
 }
 
-// fixed-shape first level of the global sums: chunk c = sum of a contiguous range, accumulated left to right.
-// One wavefront per chunk: 64 consecutive elements are loaded coalesced, then added in index order through v_readlane
-// (every lane runs the same scalar chain).  The single-workgroup form this replaces -- thread c walking its own chunk --
-// produced the same numbers but took ~2 ms per call at 2 M points (dependent, uncoalesced loads), twice per power iteration.
-__global__ __launch_bounds__(64) void chunk_sums(const double *__restrict__ v, int N, double *__restrict__ out256)
+// second level of the global sums: the 256 chunk sums added in order by one thread, then the scalar the loop needs --
+// the normaliser (float)(N / sum) of heuristic.cpp:118, or the mean squared change of heuristic.cpp:133
+__global__ void finish_normalizer(const double *__restrict__ v256, int N, float *__restrict__ normalizer)
 {
-    const int c = blockIdx.x, lane = threadIdx.x;
+    double sum = 0.;
+    for (int c = 0; c < 256; c++) sum += v256[c];
+    normalizer[0] = (float)(N / sum);
+}
+__global__ void finish_change(const double *__restrict__ v256, int N, double *__restrict__ change)
+{
+    double sum = 0.;
+    for (int c = 0; c < 256; c++) sum += v256[c];
+    change[0] = sum / N;
+}
+
+// fixed-shape first level of the global sums: chunk c = the sum of a contiguous range of ceil(N / 256) elements, formed by a
+// reduction tree whose shape depends on N only -- thread t of the chunk's workgroup adds elements t, t + 256, ... in that
+// order, then the 256 partial sums are folded pairwise (stride 128, 64, ... 1).  Deterministic run to run and rank to rank.
+// (The oracle adds everything sequentially in double; the two meet again when N / sum is rounded to float, heuristic.cpp:118.)
+// History: one thread per chunk walking it left to right took ~2 ms per call at 2 M points, a wavefront adding in index
+// order through v_readlane 340 us; the tree takes a few microseconds.
+__global__ __launch_bounds__(256) void chunk_sums(const double *__restrict__ v, int N, double *__restrict__ out256)
+{
+    __shared__ double part[256];
+    const int c = blockIdx.x, t = threadIdx.x;
     const int per = (N + 255) / 256;
     const int s = c * per, e = min(s + per, N);
-    double t = 0.;
-    for (int base = s; base < e; base += 64) {
-        const int i = base + lane;
-        const double x = i < e ? v[i] : 0.;
-        const unsigned long long bits = __builtin_bit_cast(unsigned long long, x);
-        const int lo = (int)(unsigned)bits, hi = (int)(unsigned)(bits >> 32);
-        const int cnt = min(64, e - base);  // wave-uniform
-        for (int l = 0; l < cnt; l++) {
-            const unsigned xl = (unsigned)__builtin_amdgcn_readlane(lo, l), xh = (unsigned)__builtin_amdgcn_readlane(hi, l);
-            t += __builtin_bit_cast(double, (unsigned long long)xl | ((unsigned long long)xh << 32));
-        }
+    double acc = 0.;
+    for (int i = s + t; i < e; i += 256) acc += v[i];
+    part[t] = acc;
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if (t < stride) part[t] += part[t + stride];
+        __syncthreads();
     }
-    if (lane == 0) out256[c] = t;
+    if (t == 0) out256[c] = part[0];
 }
 
 // ---- greedy selection (heuristic.cpp:139-163) on the device -----------------------------------------------------------
@@ -315,7 +303,7 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_p4 = al(sizeof(float) * 4 * N), b_p3 = al(sizeof(float) * 3 * N), b_c3 = al(sizeof(int) * 3 * N), b_head = al(sizeof(int) * table),
                  b_n1 = al(sizeof(int) * ((size_t)N + 1));
-    int rc = ensure(ctx, ctx->flow_arena, b_p4 + b_p3 + b_c3 + b_head + 6 * b_n1 + 2 * al(sizeof(float) * N) + 2 * al(sizeof(double) * N) + 4096);
+    int rc = ensure(ctx, ctx->flow_arena, b_p4 + b_p3 + b_c3 + b_head + 6 * b_n1 + 4 * al(sizeof(float) * N) + 2 * al(sizeof(double) * N) + 8192);
     if (rc) return rc;
     char *base = (char *)ctx->flow_arena.ptr;
     float *d_p4 = (float *)base;
@@ -326,6 +314,7 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
     int *d_cnt_lo = (int *)(base += b_n1), *d_cnt_up = (int *)(base += b_n1), *d_off_lo = (int *)(base += b_n1), *d_off_up = (int *)(base += b_n1),
         *d_fill = (int *)(base += b_n1);
     float *d_density = (float *)(base += b_n1), *d_score = (float *)(base += al(sizeof(float) * N));
+    float *d_density_b = (float *)(base += al(sizeof(float) * N)), *d_score_b = (float *)(base += al(sizeof(float) * N));
     double *d_pair = (double *)(base += al(sizeof(float) * N)), *d_chg = (double *)(base += al(sizeof(double) * N));
     double *d_256 = (double *)(base += al(sizeof(double) * N));
 
@@ -338,8 +327,17 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
     dehomog_cells<<<g, 256, 0, st>>>(d_p4, N, 1.0f / cell, d_p3, d_c3);
     hash_build<<<g, 256, 0, st>>>(d_c3, N, mask, d_head, d_next);
     nb_count<<<g, 256, 0, st>>>(d_p3, d_c3, d_head, d_next, mask, N, radius, d_cnt_lo, d_cnt_up);
-    exclusive_scan_1wg<<<1, 1024, 0, st>>>(d_cnt_lo, N, d_off_lo);
-    exclusive_scan_1wg<<<1, 1024, 0, st>>>(d_cnt_up, N, d_off_up);
+    {
+        // offsets = exclusive prefix sums of the counts over N + 1 entries (count[N] = 0, so entry N is the total); integer
+        // sums are exact under any algorithm.  The single-workgroup scan this replaces took 5.7 ms per call at 2 M points.
+        size_t scan_bytes = 0;
+        if (hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_cnt_lo, d_off_lo, N + 1, st) != hipSuccess)
+            return fail(ctx, MVS_EHIP, "mvs_filter_points: scan sizing failed");
+        if ((rc = ensure(ctx, ctx->r_tmp0, scan_bytes > 0 ? scan_bytes : 1))) return rc;
+        if (hipcub::DeviceScan::ExclusiveSum(ctx->r_tmp0.ptr, scan_bytes, d_cnt_lo, d_off_lo, N + 1, st) != hipSuccess ||
+            hipcub::DeviceScan::ExclusiveSum(ctx->r_tmp0.ptr, scan_bytes, d_cnt_up, d_off_up, N + 1, st) != hipSuccess)
+            return fail(ctx, MVS_EHIP, "mvs_filter_points: scan failed");
+    }
     MVS_HIP(ctx, hipGetLastError());
     int total = 0;
     MVS_HIP(ctx, hipMemcpyAsync(&total, d_off_lo + N, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -358,26 +356,41 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
     // power iteration (heuristic.cpp:103-136)
     std::vector<float> ones((size_t)N, 1.f);
     MVS_HIP(ctx, hipMemcpyAsync(d_density, ones.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));
-    double h256[256];
-    double change;
-    int it = 0;
-    do {
-        density_score<<<g, 256, 0, st>>>(d_density, d_off_lo, d_lo, d_off_up, d_up, N, d_score, d_pair);
-        chunk_sums<<<256, 64, 0, st>>>(d_pair, N, d_256);
-        MVS_HIP(ctx, hipMemcpyAsync(h256, d_256, sizeof(h256), hipMemcpyDeviceToHost, st));
-        MVS_HIP(ctx, hipStreamSynchronize(st));
-        double sum = 0.;
-        for (int c = 0; c < 256; c++) sum += h256[c];
-        const float normalizer = (float)(N / sum);
-        density_update<<<g, 256, 0, st>>>(d_density, d_score, normalizer, N, d_chg);
-        chunk_sums<<<256, 64, 0, st>>>(d_chg, N, d_256);
-        MVS_HIP(ctx, hipMemcpyAsync(h256, d_256, sizeof(h256), hipMemcpyDeviceToHost, st));
-        MVS_HIP(ctx, hipStreamSynchronize(st));
-        change = 0.;
-        for (int c = 0; c < 256; c++) change += h256[c];
-        change /= N;
-        it++;
-    } while (change > 1e-6 && it < 200);
+    // Iteration k reads dens[k & 1], writes scor[k & 1] and dens[(k + 1) & 1]; both reductions finish on the device and
+    // only the 8-byte mean squared change comes back.  Iteration k + 1 is queued before the host looks at iteration k's
+    // value, so the GPU never waits for the host; when the loop should have stopped at k, the speculative iteration has
+    // only touched the OTHER score / density buffers and is simply ignored (same result as the one-at-a-time loop).
+    double *d_256b = d_256 + 256;
+    float *d_norm = (float *)(d_256 + 512);
+    double *d_change = d_256 + 520;
+    if (!ctx->filter_pinned) {
+        MVS_HIP(ctx, hipHostMalloc((void **)&ctx->filter_pinned, 64, hipHostMallocDefault));
+        for (int e = 0; e < 2; e++) MVS_HIP(ctx, hipEventCreateWithFlags(&ctx->filter_ev[e], hipEventDisableTiming));
+    }
+    double *h_change = ctx->filter_pinned;
+    float *dens[2] = {d_density, d_density_b}, *scor[2] = {d_score, d_score_b};
+    auto launch_iteration = [&](int k) {
+        density_score<<<g, 256, 0, st>>>(dens[k & 1], d_off_lo, d_lo, d_off_up, d_up, N, scor[k & 1], d_pair);
+        chunk_sums<<<256, 256, 0, st>>>(d_pair, N, d_256);
+        finish_normalizer<<<1, 1, 0, st>>>(d_256, N, d_norm);
+        density_update<<<g, 256, 0, st>>>(dens[k & 1], scor[k & 1], d_norm, N, dens[(k + 1) & 1], d_chg);
+        chunk_sums<<<256, 256, 0, st>>>(d_chg, N, d_256b);
+        finish_change<<<1, 1, 0, st>>>(d_256b, N, d_change + (k & 1));
+        (void)hipMemcpyAsync(h_change + (k & 1), d_change + (k & 1), sizeof(double), hipMemcpyDeviceToHost, st);
+        (void)hipEventRecord(ctx->filter_ev[k & 1], st);
+    };
+    int it = 0, k = 0;
+    launch_iteration(0);
+    for (;;) {
+        if (k + 1 < 200) launch_iteration(k + 1);
+        MVS_HIP(ctx, hipEventSynchronize(ctx->filter_ev[k & 1]));
+        it = k + 1;
+        if (!(h_change[k & 1] > 1e-6 && it < 200)) break;
+        k++;
+    }
+    MVS_HIP(ctx, hipGetLastError());
+    d_density = dens[(k + 1) & 1];  // the density after the last counted update, and the score it was computed from
+    d_score = scor[k & 1];
     if (timing) fprintf(stderr, "filter_points[%d] power iterations: %d, neighbour pairs: %d\n", N, it, total);
     lap("power iteration");
 

@@ -55,6 +55,8 @@ struct mvs_ctx {
     bool plan_forced = false;        // plan made with the 4 x 16 shape forced (timing experiments)
     mvs::DevBuf plan_stats;          // planner counters (oversize regions, regions not skipped)
     mvs::DevBuf probe_buf;           // mvs_depth_probe: pixel coordinates in, depths out
+    double *filter_pinned = nullptr; // mvs_filter_points: pinned host slots for the convergence value of two iterations in flight
+    hipEvent_t filter_ev[2] = {nullptr, nullptr};
     std::vector<float> q_host;       // V*12
     std::vector<float> z_host;       // D
 

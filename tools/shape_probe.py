@@ -1,5 +1,6 @@
 import json, os, sys, time
-sys.path.insert(0, "mesh-reconstruction_amd/python")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mesh-reconstruction_amd", "python"))
 import numpy as np, mvs_amd
 from mvs_amd import synth
 def t(ctx, V, flags, n=10):

@@ -1,5 +1,6 @@
 import sys, time, json
-sys.path.insert(0, "mesh-reconstruction_amd/python")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mesh-reconstruction_amd", "python"))
 import numpy as np, mvs_amd
 rng = np.random.default_rng(1)
 with mvs_amd.Context(640, 480) as ctx:
