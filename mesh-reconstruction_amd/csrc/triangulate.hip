@@ -265,7 +265,8 @@ __global__ __launch_bounds__(128) void tri_normals_kernel(const uint8_t *__restr
     // flag) and only then accumulated, in the reference's order, with selects: the loads of a row are independent, so they
     // overlap instead of each waiting behind a validity branch.  An invalid neighbour adds +0.0, which leaves a double
     // accumulator unchanged, so the sums are bit-identical to the branchy walk.  Measured 501 -> 485 us at 640x480: the kernel is
-    // bound by its f64 arithmetic, not by load latency (an LDS-staged variant was 2x slower and was dropped).
+    // bound by its instruction count (f64 ops issue at the f32 rate on gfx950: profiles/r01/valu_issue_microbench.txt), not by
+    // load latency (an LDS-staged variant was 2x slower and was dropped).
     constexpr int WIN = 21;
     int n = 0;
     double mean[3] = {0, 0, 0};

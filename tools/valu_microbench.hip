@@ -50,6 +50,12 @@ __global__ void probe(float *out, unsigned long long *cyc, float seed)
             if (OP == 21) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c0));
             if (OP == 22) asm volatile("v_cvt_pk_u16_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
             if (OP == 23) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(a[i]));
+            // f64 (the triangulation PCA and the Farneback box filter accumulate in double): operands are register pairs
+            if (OP == 24) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(*(double *)&a[i & ~1]) : "v"(*(double *)&b[0]), "v"(*(double *)&b[2]));
+            if (OP == 25) asm volatile("v_add_f64 %0, %0, %1" : "+v"(*(double *)&a[i & ~1]) : "v"(*(double *)&b[0]));
+            if (OP == 26) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(*(double *)&a[i & ~1]) : "v"(*(double *)&b[0]));
+            if (OP == 27) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(*(double *)&a[i & ~1]) : "v"(c0));
+            if (OP == 28) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[i]) : "v"(*(double *)&b[0]));
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -146,6 +152,11 @@ int main()
     run<21>("v_cndmask_b32", out, cyc, 64);
     run<22>("v_cvt_pk_u16_u32", out, cyc, 64);
     run<23>("v_cvt_f32_f16", out, cyc, 64);
+    run<24>("v_fma_f64", out, cyc, 64);
+    run<25>("v_add_f64", out, cyc, 64);
+    run<26>("v_mul_f64", out, cyc, 64);
+    run<27>("v_cvt_f64_f32", out, cyc, 64);
+    run<28>("v_cvt_f32_f64", out, cyc, 64);
     for (int stride : {1, 2, 3}) {
         for (int wps : {1, 2, 4}) {
             probe_lds<8><<<256 * wps, 256>>>(out, cyc, stride);
