@@ -611,9 +611,19 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
                             sample_chunk_pipelined<PC, true>(A, bx, by, bw, r_const, zc, rv.rp8, lds_minus_org8, (uint32_t)Im[j], acc[j]);
                         }
                     }
+                } else if (NPX == 2 && !(p.debug & 16)) {
+                    // general cameras in the 2 x 32 shape (no spills): the hand-pipelined reads pay here too,
+                    // 2.54 -> 2.39 ms at c3 (tools/ab_general.py; debug bit 4 of the high byte forces the loop below)
+#pragma unroll
+                    for (int j = 0; j < NPX; j++) {
+                        if (ok[j]) {
+                            const Affine A = view_affine(q, xn, yn[j]);
+                            sample_chunk_pipelined<PC, false>(A, bx, by, bw, 0.0f, zc, rv.rp8, lds_minus_org8, (uint32_t)Im[j], acc[j]);
+                        }
+                    }
                 } else {
-                    // general cameras: three more live values per pair (sw, r0, e); the hand-pipelined form measured 2 %
-                    // slower here (2.635 vs 2.58 ms at c3), so this path keeps the compiler-scheduled pair loop
+                    // general cameras in the 4 x 16 shape: three more live values per pair (sw, r0, e) on top of its spills; the
+                    // hand-pipelined form measured 2 % slower there (2.635 vs 2.58 ms at c3): compiler-scheduled pair loop
                     int negorg8 = -rv.org8;
                     asm volatile("" : "+v"(negorg8));
 #pragma unroll
