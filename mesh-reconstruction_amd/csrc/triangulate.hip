@@ -107,6 +107,11 @@ __device__ __forceinline__ void sample_point_punned(const float *__restrict__ gr
     }
 }
 
+// VMAX: compile-time capacity of the per-view arrays.  With VMAX = 32 (TRI_MAXCAM) they are indexed by a runtime loop and live
+// in scratch memory (784 B per lane), re-read on each of up to 50 Newton iterations; the reference uses 2-8 side views per main
+// frame, so the kernel is also instantiated for 4 and 8 with fully unrolled, predicated view loops (arrays in registers).
+// Same statements per view in the same order: bit-identical.
+template <int VMAX>
 __global__ __launch_bounds__(128) void tri_points_kernel(const float *const *__restrict__ flows, const CamPre *__restrict__ pre,
                                                          int V, const float *__restrict__ Minv, const float *__restrict__ depth,
                                                          const float *__restrict__ grad, int W, int H,
@@ -122,8 +127,10 @@ __global__ __launch_bounds__(128) void tri_points_kernel(const float *const *__r
     if (d0 == MVS_BACKGROUND_DEPTH) return;
     const float centerX = W / 2.0f, centerY = H / 2.0f, scaleX = 2.0f / W, scaleY = 2.0f / H;
     const float x = (col - centerX) * scaleX, y = (centerY - row) * scaleY;
-    float meas[TRI_MAXCAM][2], icov[TRI_MAXCAM][4];
-    for (int i = 0; i < V; i++) {
+    float meas[VMAX][2], icov[VMAX][4];
+#pragma unroll VMAX <= 8 ? VMAX : 1
+    for (int i = 0; i < VMAX; i++) {
+        if (i >= V) break;
         const float *fl = flows[i] + pix * 4;
         const float flx = fl[0], fly = fl[1], variance = fl[2];
         const bool gs = good_sample(depth, W, H, col + flx, row + fly);
@@ -170,7 +177,9 @@ __global__ __launch_bounds__(128) void tri_points_kernel(const float *const *__r
     float pdf = 1.0f;
     for (int iter = 0;; iter++) {
         double firstDz = 0, secondDz = 0;
-        for (int i = 0; i < V; i++) {
+#pragma unroll VMAX <= 8 ? VMAX : 1
+        for (int i = 0; i < VMAX; i++) {
+            if (i >= V) break;
             float ep[4];
             mat44_vec(pre[i].CM, k, ep);
             const float px = ep[0] / ep[3], py = ep[1] / ep[3];
@@ -188,7 +197,9 @@ __global__ __launch_bounds__(128) void tri_points_kernel(const float *const *__r
         const double delta_z = -firstDz / secondDz, eps = 1e-7;
         if (iter >= 50 || (delta_z < eps && delta_z > -eps)) {
             double exponent = 0, product_ivar = 1;
-            for (int i = 0; i < V; i++) {
+#pragma unroll VMAX <= 8 ? VMAX : 1
+            for (int i = 0; i < VMAX; i++) {
+                if (i >= V) break;
                 float ep[4];
                 mat44_vec(pre[i].CM, k, ep);
                 const float dfx = ep[0] / ep[3] - meas[i][0], dfy = ep[1] / ep[3] - meas[i][1];
@@ -552,8 +563,15 @@ int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, bo
     MVS_HIP(ctx, hipMemcpyAsync(d_mc, main_center, sizeof(main_center), hipMemcpyHostToDevice, st));
     MVS_HIP(ctx, hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(float *) * ptrs.size(), hipMemcpyHostToDevice, st));
     sobel_kernel<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, st>>>(d_depth, W, H, d_grad);
-    tri_points_kernel<<<dim3(div_up(W, 64), div_up(H, 2)), 128, 0, st>>>(d_ptrs, d_pre, V, d_minv, d_depth, d_grad, W, H, d_valid,
-                                                                         d_pts, d_xyz, d_pdf);
+    {
+        const dim3 grid(div_up(W, 64), div_up(H, 2));
+        if (V <= 4)
+            tri_points_kernel<4><<<grid, 128, 0, st>>>(d_ptrs, d_pre, V, d_minv, d_depth, d_grad, W, H, d_valid, d_pts, d_xyz, d_pdf);
+        else if (V <= 8)
+            tri_points_kernel<8><<<grid, 128, 0, st>>>(d_ptrs, d_pre, V, d_minv, d_depth, d_grad, W, H, d_valid, d_pts, d_xyz, d_pdf);
+        else
+            tri_points_kernel<TRI_MAXCAM><<<grid, 128, 0, st>>>(d_ptrs, d_pre, V, d_minv, d_depth, d_grad, W, H, d_valid, d_pts, d_xyz, d_pdf);
+    }
     tri_normals_kernel<<<dim3(div_up(W, 64), div_up(H, 2)), 128, 0, st>>>(d_valid, d_pts, d_xyz, d_pdf, d_pre, d_mc, V, W, H, d_nrm);
     // compaction in pixel scan order (the reference's pixelId, util.cpp:172,247-248) on the device: only the packed
     // rows cross PCIe, straight into the caller's buffer

@@ -64,3 +64,30 @@ def test_triangulate_edge_cases(oracle):
     assert np.array_equal(np.isfinite(got[:, 4:]), np.isfinite(ref[:, 4:]))
     ref0 = oracle.triangulate_pixels([], main, np.zeros((0, 4, 4), np.float32), depth)
     assert none.shape == ref0.shape
+
+
+@pytest.mark.parametrize("nviews", [5, 8, 11])
+def test_triangulate_view_counts(oracle, nviews):
+    """tri_points_kernel is instantiated for up to 4, up to 8 and up to 32 side views (per-view arrays in registers vs
+    scratch); 2-4 views are covered above, these counts exercise the other two instantiations against the oracle"""
+    W, H = 160, 96
+    verts, faces = scenes.heightfield_mesh(40, extent=2.2)
+    soup = oracle.load_mesh(verts, faces)
+    main = synth.camera_at([0, 0, 0], W, H)
+    rng = np.random.default_rng(nviews)
+    centres = [[0.25 * np.cos(2 * np.pi * k / nviews), 0.25 * np.sin(2 * np.pi * k / nviews), 0.03 * (k % 3 - 1)] for k in range(nviews)]
+    sides = np.stack([synth.camera_at(c, W, H) for c in centres])
+    depth = oracle.depth(soup, main, W, H)
+    flows = []
+    for _ in range(nviews):
+        f = np.zeros((H, W, 4), np.float32)
+        f[..., :2] = rng.normal(0, 1.0, (H, W, 2))
+        f[..., 2] = rng.uniform(0.5, 4.0, (H, W))
+        flows.append(f)
+    with mvs_amd.Context(W, H) as ctx:
+        got = ctx.triangulate(flows, main, sides, depth)
+    ref = oracle.triangulate_pixels(flows, main, sides, depth)
+    assert got.shape == ref.shape and got.shape[0] > 0.5 * W * H
+    np.testing.assert_array_equal(got[:, :4], ref[:, :4])
+    finite = np.isfinite(ref[:, 4:]).all(1)
+    np.testing.assert_allclose(got[finite, 4:], ref[finite, 4:], rtol=1e-5, atol=1e-9)
