@@ -150,6 +150,15 @@ void mvs_destroy(mvs_ctx *ctx)
         if (ctx->flow_graph[i]) (void)hipGraphExecDestroy(ctx->flow_graph[i]);
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
+    for (auto &lane : ctx->lanes) {
+        if (lane.stream) (void)hipStreamSynchronize(lane.stream);
+        for (int i = 0; i < 2; i++)
+            if (lane.graph[i]) (void)hipGraphExecDestroy(lane.graph[i]);
+        if (lane.arena.ptr) (void)hipFree(lane.arena.ptr);
+        if (lane.cmp.ptr) (void)hipFree(lane.cmp.ptr);
+        if (lane.stream) (void)hipStreamDestroy(lane.stream);
+    }
+    for (hipEvent_t e : ctx->lane_events) (void)hipEventDestroy(e);
     if (ctx->filter_pinned) (void)hipHostFree(ctx->filter_pinned);
     for (int e = 0; e < 2; e++)
         if (ctx->filter_ev[e]) (void)hipEventDestroy(ctx->filter_ev[e]);

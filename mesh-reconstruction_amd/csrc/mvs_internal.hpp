@@ -70,6 +70,18 @@ struct mvs_ctx {
     mvs::DevBuf best_parts;          // plane-split sweeps: partial (best cell, best index) per split and pixel
     // the launch-bound flow pipelines (~350 small kernels for Farneback) are captured once into a hipGraph per
     // algorithm and replayed; invalidated when the arena moves
+    // mvs_process_frame runs the flows of one main frame's side views concurrently: a lane is everything calculateFlow keeps
+    // per call (stream, arena, compare pyramid, cached graphs); pipeline.hip swaps a lane into the fields below for one call
+    struct FlowLane {
+        hipStream_t stream = nullptr;
+        mvs::DevBuf arena, cmp;
+        hipGraphExec_t graph[2] = {nullptr, nullptr};
+        void *graph_arena[2] = {nullptr, nullptr};
+        void *graph_tmp[2] = {nullptr, nullptr};
+    };
+    static constexpr int kFlowLanes = 4;
+    FlowLane lanes[kFlowLanes];
+    std::vector<hipEvent_t> lane_events;  // 2 per side view: inputs ready, flow done
     hipGraphExec_t flow_graph[2] = {nullptr, nullptr};
     void *flow_graph_arena[2] = {nullptr, nullptr};
     void *flow_graph_tmp[2] = {nullptr, nullptr};

@@ -12,6 +12,9 @@
 // (tests/test_pipeline_gpu.py).
 #include "mvs_internal.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 using namespace mvs;
 
 extern "C" {
@@ -27,25 +30,70 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     MVS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)ctx->W * ctx->H;
     hipStream_t st = ctx->stream;
-    // frame_buf: main u8 | side u8 | mixed u8 | out3 (3P u8) | pad to 256 | depth (P f32) | flows (nside * 4P f32)
-    const size_t bytes_u8 = (6 * P + 255) & ~(size_t)255;
+    // frame_buf: main u8 | side u8 | out3 (3P u8) | mixed u8 x nside | pad to 256 | depth (P f32) | flows (nside * 4P f32)
+    const size_t bytes_u8 = ((5 + (size_t)nside) * P + 255) & ~(size_t)255;
     int rc = ensure(ctx, ctx->frame_buf, bytes_u8 + sizeof(float) * P * (1 + 4 * (size_t)nside) + 256);
     if (rc) return rc;
-    uint8_t *d_main = (uint8_t *)ctx->frame_buf.ptr, *d_side = d_main + P, *d_mixed = d_side + P, *d_out3 = d_mixed + P;
+    uint8_t *d_main = (uint8_t *)ctx->frame_buf.ptr, *d_side = d_main + P, *d_out3 = d_side + P, *d_mixed0 = d_out3 + 3 * P;
     float *d_depth = (float *)((uint8_t *)ctx->frame_buf.ptr + bytes_u8), *d_flows = d_depth + P;
+
+    // The flows of the side views depend only on (main frame, mixed_i): each runs in a lane of its own (stream + arena +
+    // cached graph) while the main stream goes on rasterising the next view; a flow is a chain of small kernels that fills
+    // 150 of 256 CUs at best, so up to four of them overlap.  Everything joins before triangulatePixels.
+    static const bool serial = getenv("MVS_SERIAL_FLOWS") != nullptr;  // A/B: all flows in the main stream, as before
+    const int nlanes = serial ? 0 : std::min(nside, (int)mvs_ctx::kFlowLanes);
+    for (int l = 0; l < nlanes; l++)
+        if (!ctx->lanes[l].stream) MVS_HIP(ctx, hipStreamCreateWithFlags(&ctx->lanes[l].stream, hipStreamNonBlocking));
+    while ((int)ctx->lane_events.size() < 2 * nside) {
+        hipEvent_t e;
+        MVS_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->lane_events.push_back(e);
+    }
+    struct LaneScope {  // calculateFlow's per-call state <-> a lane
+        mvs_ctx *c;
+        mvs_ctx::FlowLane &l;
+        void swap()
+        {
+            std::swap(c->stream, l.stream);
+            std::swap(c->flow_arena, l.arena);
+            std::swap(c->r_tmp1, l.cmp);
+            for (int i = 0; i < 2; i++) {
+                std::swap(c->flow_graph[i], l.graph[i]);
+                std::swap(c->flow_graph_arena[i], l.graph_arena[i]);
+                std::swap(c->flow_graph_tmp[i], l.graph_tmp[i]);
+            }
+        }
+        LaneScope(mvs_ctx *ctx_, mvs_ctx::FlowLane &lane) : c(ctx_), l(lane) { swap(); }
+        ~LaneScope() { swap(); }
+    };
 
     MVS_HIP(ctx, hipMemcpyAsync(d_main, main_frame_hw, P, hipMemcpyHostToDevice, st));
     if ((rc = depth_device(ctx, main_cam, d_depth))) return rc;  // recon.cpp:70
     std::vector<const float *> flow_ptrs((size_t)(nside > 0 ? nside : 1), nullptr);
     for (int i = 0; i < nside; i++) {
         if (!side_frames_hw[i]) return fail(ctx, MVS_EINVAL, "mvs_process_frame: side_frames[%d] is null", i);
+        uint8_t *d_mixed = d_mixed0 + (size_t)i * P;
         MVS_HIP(ctx, hipMemcpyAsync(d_side, side_frames_hw[i], P, hipMemcpyHostToDevice, st));
         if ((rc = projected_device(ctx, main_cam, d_side, side_cams + 16 * i, d_out3))) return rc;   // :85
         if ((rc = mix_background_device(ctx, d_out3, d_main, d_depth, d_mixed))) return rc;           // :86
         float *fl = d_flows + (size_t)i * 4 * P;
-        if ((rc = flow_device(ctx, d_main, d_mixed, use_farneback, fl))) return rc;                   // :89
+        if (nlanes == 0) {
+            if ((rc = flow_device(ctx, d_main, d_mixed, use_farneback, fl))) return rc;               // :89
+        } else {
+            mvs_ctx::FlowLane &lane = ctx->lanes[i % nlanes];
+            hipEvent_t ready = ctx->lane_events[2 * i], done = ctx->lane_events[2 * i + 1];
+            MVS_HIP(ctx, hipEventRecord(ready, st));
+            MVS_HIP(ctx, hipStreamWaitEvent(lane.stream, ready, 0));
+            {
+                LaneScope scope(ctx, lane);
+                rc = flow_device(ctx, d_main, d_mixed, use_farneback, fl);                            // :89
+                if (rc == MVS_OK && hipEventRecord(done, ctx->stream) != hipSuccess) rc = fail(ctx, MVS_EHIP, "hipEventRecord");
+            }
+            if (rc) return rc;
+        }
         flow_ptrs[i] = fl;
     }
+    for (int i = 0; i < nside && nlanes > 0; i++) MVS_HIP(ctx, hipStreamWaitEvent(st, ctx->lane_events[2 * i + 1], 0));
     if (depth_after_hw) MVS_HIP(ctx, hipMemcpyAsync(depth_after_hw, d_depth, sizeof(float) * P, hipMemcpyDeviceToHost, st));
     return triangulate_impl(ctx, nside, flow_ptrs.data(), true, main_cam, side_cams, d_depth, out_points7, out_count);  // :114
 }
