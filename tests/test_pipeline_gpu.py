@@ -78,3 +78,30 @@ def test_process_frame_is_faster_than_stagewise():
         staged = (time.perf_counter() - t0) / 5
     print("process_frame %.2f ms vs stage-by-stage %.2f ms (640x480, 4 side views)" % (fused * 1e3, staged * 1e3))
     assert fused < staged
+
+
+@pytest.mark.parametrize("nside", [0, 1, 6, 9])
+def test_process_frame_side_view_counts(nside):
+    """the side views' flows run concurrently in up to four lanes (stream + arena + graph each): fewer views than lanes,
+    more views than lanes (lanes are reused in order) and repeated calls must all equal the stage-by-stage result"""
+    W, H = 256, 160
+    verts, faces = scenes.heightfield_mesh(48, extent=1.4)
+    sc = synth.Scene(freq_scale=0.2)
+    main_c = [0.0, 0.0, 0.0]
+    side_cs = [[0.16 * np.cos(0.7 * k), 0.14 * np.sin(0.7 * k), 0.02 * (k % 3 - 1)] for k in range(1, nside + 1)]
+    main = synth.camera_at(main_c, W, H)
+    sides = np.stack([synth.camera_at(c, W, H) for c in side_cs]) if nside else np.zeros((0, 4, 4), np.float32)
+    main_img = sc.render(main_c, W, H)
+    side_imgs = [sc.render(c, W, H) for c in side_cs]
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.load_mesh(verts, faces)
+        depth = ctx.depth(main)
+        flows = []
+        for cam, img in zip(sides, side_imgs):
+            mixed, depth = ctx.mix_background(ctx.projected(main, img, cam), main_img, depth)
+            flows.append(ctx.flow(main_img, mixed, False))
+        ref = ctx.triangulate(flows, main, sides, depth)
+        for _ in range(3):      # lanes, their graphs and events are reused from the second call on
+            pts, depth_after = ctx.process_frame(main, main_img, sides, side_imgs, False, want_depth=True)
+            np.testing.assert_array_equal(depth_after, depth)
+            np.testing.assert_array_equal(pts, ref)
