@@ -92,6 +92,9 @@ __global__ __launch_bounds__(256) void nb_count(const float *__restrict__ p3, co
     cnt_lo[i] = c;
 }
 
+// ORDERED: keep each lower list ascending by insertion while filling (short lists); otherwise append in traversal order
+// and leave the ordering to the global sort (long lists: the insertion is O(L^2) global-memory moves per point)
+template <bool ORDERED>
 __global__ __launch_bounds__(256) void nb_fill(const float *__restrict__ p3, const int *__restrict__ cell3,
                                                const int *__restrict__ head, const int *__restrict__ next, unsigned mask, int N,
                                                float radius, const int *__restrict__ off_lo, const int *__restrict__ off_up,
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) void nb_fill(const float *__restrict__ p3, con
         const float w = (float)(1. - d2 / radius);  // densityFn, heuristic.cpp:49-52
         // insertion into the ascending lower list
         int k = c++;
-        while (k > 0 && mine[k - 1].idx > j) {
+        while (ORDERED && k > 0 && mine[k - 1].idx > j) {
             mine[k] = mine[k - 1];
             k--;
         }
@@ -266,6 +269,51 @@ __global__ __launch_bounds__(256) void greedy_round(unsigned char *__restrict__ 
     state[j] = (s < limit) ? 2 : 1;
 }
 
+// Segmented ordering of the upper lists by ONE global radix sort: key = (owner point << 32) | sub-key, value = the entry
+// itself.  Segment boundaries (off_up) are unchanged because the owner is the major key.  Used when the lists are long
+// (dense clouds): the per-thread insertion sort (sort_upper) and the repeated-minimum selection in greedy_round are
+// O(L^2) per point -- 64 ms and 365 ms at 60 k points with ~100 neighbours each, against ~1 ms for the two sorts.
+__global__ __launch_bounds__(256) void list_keys(const int *__restrict__ off_up, const Nb *__restrict__ up, int N,
+                                               const int *__restrict__ rank /* nullable: sub-key = index */,
+                                               unsigned long long *__restrict__ keys)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    for (int k = off_up[j]; k < off_up[j + 1]; k++) {
+        const int i = up[k].idx;
+        keys[k] = ((unsigned long long)(unsigned)j << 32) | (unsigned)(rank ? rank[i] : i);
+    }
+}
+
+// greedy_round on lists sorted by the RANK of the neighbour: the earlier-ranked neighbours are a prefix, readiness is
+// checked from its end (the latest-ranked one is the likeliest to be undecided), the subtractions are one forward pass
+__global__ __launch_bounds__(256) void greedy_round_sorted(unsigned char *__restrict__ state, const int *__restrict__ rank,
+                                                           const float *__restrict__ density, const float *__restrict__ score0,
+                                                           const int *__restrict__ off_up, const Nb *__restrict__ up_by_rank, int N,
+                                                           float limit, int *__restrict__ undecided)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N || state[j] != 0) return;
+    const int rj = rank[j], k0 = off_up[j], k1 = off_up[j + 1];
+    int lo = k0, hi = k1;  // first entry whose rank is not earlier than rj
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (rank[up_by_rank[mid].idx] < rj)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    for (int k = lo - 1; k >= k0; k--)
+        if (state[up_by_rank[k].idx] == 0) {
+            atomicAdd(undecided, 1);
+            return;
+        }
+    float s = score0[j];
+    for (int k = k0; k < lo; k++)
+        if (state[up_by_rank[k].idx] == 1) s = (float)((double)s - (double)density[up_by_rank[k].idx] * (double)up_by_rank[k].w);
+    state[j] = (s < limit) ? 2 : 1;
+}
+
 }  // namespace mvs
 
 using namespace mvs;
@@ -348,8 +396,42 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
     // neighbour lists live in their own buffer (size known only now)
     if ((rc = ensure(ctx, ctx->r_tmp2, 2 * sizeof(Nb) * (size_t)(total > 0 ? total : 1)))) return rc;
     Nb *d_lo = (Nb *)ctx->r_tmp2.ptr, *d_up = d_lo + (total > 0 ? total : 1);
-    nb_fill<<<g, 256, 0, st>>>(d_p3, d_c3, d_head, d_next, mask, N, radius, d_off_lo, d_off_up, d_fill, d_lo, d_up);
-    sort_upper<<<g, 256, 0, st>>>(d_off_up, N, d_up);
+    // long lists (dense clouds): order them with global radix sorts instead of per-thread O(L^2) loops (see list_keys)
+    static const char *force_sorted = getenv("MVS_FILTER_SORTED_LISTS");  // test hook: "1" always, "0" never
+    const bool long_lists = (force_sorted ? force_sorted[0] == '1' : (long long)total > 24ll * N) && total > 0;
+    if (long_lists)
+        nb_fill<false><<<g, 256, 0, st>>>(d_p3, d_c3, d_head, d_next, mask, N, radius, d_off_lo, d_off_up, d_fill, d_lo, d_up);
+    else
+        nb_fill<true><<<g, 256, 0, st>>>(d_p3, d_c3, d_head, d_next, mask, N, radius, d_off_lo, d_off_up, d_fill, d_lo, d_up);
+    unsigned long long *d_skeys = nullptr, *d_skeys2 = nullptr;
+    Nb *d_up_alt = nullptr;
+    size_t pair_bytes = 0;
+    int key_bits = 33;
+    while (key_bits < 64 && (1ull << (key_bits - 32)) < (unsigned long long)N) key_bits++;
+    if (long_lists) {
+        if ((rc = ensure(ctx, ctx->filter_sort, 3 * sizeof(unsigned long long) * (size_t)total))) return rc;
+        d_skeys = (unsigned long long *)ctx->filter_sort.ptr;
+        d_skeys2 = d_skeys + total;
+        d_up_alt = (Nb *)(d_skeys2 + total);
+        if (hipcub::DeviceRadixSort::SortPairs(nullptr, pair_bytes, d_skeys, d_skeys2, (unsigned long long *)d_up, (unsigned long long *)d_up_alt,
+                                               total, 0, key_bits, st) != hipSuccess)
+            return fail(ctx, MVS_EHIP, "mvs_filter_points: list sort sizing failed");
+        if ((rc = ensure(ctx, ctx->r_tmp0, pair_bytes > 0 ? pair_bytes : 1))) return rc;
+        // lower lists by index (the order heuristic.cpp:74-92 leaves them in), sorted into the spare region and copied back
+        list_keys<<<g, 256, 0, st>>>(d_off_lo, d_lo, N, nullptr, d_skeys);
+        if (hipcub::DeviceRadixSort::SortPairs(ctx->r_tmp0.ptr, pair_bytes, d_skeys, d_skeys2, (unsigned long long *)d_lo, (unsigned long long *)d_up_alt,
+                                               total, 0, key_bits, st) != hipSuccess)
+            return fail(ctx, MVS_EHIP, "mvs_filter_points: list sort failed");
+        MVS_HIP(ctx, hipMemcpyAsync(d_lo, d_up_alt, sizeof(Nb) * (size_t)total, hipMemcpyDeviceToDevice, st));
+        // upper lists by index
+        list_keys<<<g, 256, 0, st>>>(d_off_up, d_up, N, nullptr, d_skeys);
+        if (hipcub::DeviceRadixSort::SortPairs(ctx->r_tmp0.ptr, pair_bytes, d_skeys, d_skeys2, (unsigned long long *)d_up, (unsigned long long *)d_up_alt,
+                                               total, 0, key_bits, st) != hipSuccess)
+            return fail(ctx, MVS_EHIP, "mvs_filter_points: list sort failed");
+        std::swap(d_up, d_up_alt);  // d_up: by index (what the power iteration gathers in); d_up_alt: free again
+    } else {
+        sort_upper<<<g, 256, 0, st>>>(d_off_up, N, d_up);
+    }
     MVS_HIP(ctx, hipGetLastError());
 
     lap("neighbour fill + sort");
@@ -408,26 +490,64 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
         return fail(ctx, MVS_EHIP, "mvs_filter_points: radix sort failed");
     greedy_ranks<<<g, 256, 0, st>>>(d_sorted, N, d_rank);
     MVS_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)N, st));
+    if (d_up_alt) {  // long lists: a second ordering of the upper lists, by the rank of the neighbour
+        list_keys<<<g, 256, 0, st>>>(d_off_up, d_up, N, d_rank, d_skeys);
+        if ((rc = ensure(ctx, ctx->r_tmp0, pair_bytes > 0 ? pair_bytes : 1))) return rc;  // the key sort above may have grown it
+        if (hipcub::DeviceRadixSort::SortPairs(ctx->r_tmp0.ptr, pair_bytes, d_skeys, d_skeys2, (unsigned long long *)d_up, (unsigned long long *)d_up_alt,
+                                               total, 0, key_bits, st) != hipSuccess)
+            return fail(ctx, MVS_EHIP, "mvs_filter_points: rank sort failed");
+    }
     MVS_HIP(ctx, hipGetLastError());
     lap("device sort by density");
     const float densityLimit = .7f;
+    static const int max_rounds = getenv("MVS_FILTER_MAX_ROUNDS") ? atoi(getenv("MVS_FILTER_MAX_ROUNDS")) : 2048;  // test hook
     int rounds = 0;
     for (bool done = false; !done;) {
         int h_und[8];
         MVS_HIP(ctx, hipMemsetAsync(d_undecided, 0, sizeof(h_und), st));
         for (int r = 0; r < 8; r++)
-            greedy_round<<<g, 256, 0, st>>>(d_state, d_rank, d_density, d_score, d_off_up, d_up, N, densityLimit, d_undecided + r);
+            if (d_up_alt)
+                greedy_round_sorted<<<g, 256, 0, st>>>(d_state, d_rank, d_density, d_score, d_off_up, d_up_alt, N, densityLimit, d_undecided + r);
+            else
+                greedy_round<<<g, 256, 0, st>>>(d_state, d_rank, d_density, d_score, d_off_up, d_up, N, densityLimit, d_undecided + r);
         MVS_HIP(ctx, hipGetLastError());
         MVS_HIP(ctx, hipMemcpyAsync(h_und, d_undecided, sizeof(h_und), hipMemcpyDeviceToHost, st));
         MVS_HIP(ctx, hipStreamSynchronize(st));
         rounds += 8;
         for (int r = 0; r < 8; r++) done = done || h_und[r] == 0;
-        if (rounds > N + 8) return fail(ctx, MVS_EHIP, "mvs_filter_points: greedy rounds did not converge");
+        if (!done && rounds >= max_rounds) break;
     }
     if (timing) fprintf(stderr, "filter_points[%d] greedy rounds (batches of 8): %d\n", N, rounds);
     std::vector<unsigned char> state((size_t)N);
     MVS_HIP(ctx, hipMemcpyAsync(state.data(), d_state, (size_t)N, hipMemcpyDeviceToHost, st));
     MVS_HIP(ctx, hipStreamSynchronize(st));
+    bool undecided_left = false;
+    for (int i = 0; i < N && !undecided_left; i++) undecided_left = state[i] == 0;
+    if (undecided_left) {
+        // The number of rounds is the longest dependency chain: tens for a surface-like cloud, but up to N for a
+        // pathological one (points strung along a line with monotone density).  Past max_rounds the rest is decided by the
+        // reference's sequential walk on the host, continuing from the decisions already made -- the same result, since a
+        // decided point is final and an undecided one only ever waits for earlier-ranked points.
+        std::vector<float> density((size_t)N), score((size_t)N);
+        std::vector<int> off((size_t)N + 1);
+        std::vector<Nb> lo((size_t)(total > 0 ? total : 1));
+        std::vector<unsigned long long> sorted((size_t)N);
+        MVS_HIP(ctx, hipMemcpyAsync(density.data(), d_density, sizeof(float) * N, hipMemcpyDeviceToHost, st));
+        MVS_HIP(ctx, hipMemcpyAsync(score.data(), d_score, sizeof(float) * N, hipMemcpyDeviceToHost, st));
+        MVS_HIP(ctx, hipMemcpyAsync(off.data(), d_off_lo, sizeof(int) * ((size_t)N + 1), hipMemcpyDeviceToHost, st));
+        if (total > 0) MVS_HIP(ctx, hipMemcpyAsync(lo.data(), d_lo, sizeof(Nb) * (size_t)total, hipMemcpyDeviceToHost, st));
+        MVS_HIP(ctx, hipMemcpyAsync(sorted.data(), d_sorted, sizeof(unsigned long long) * N, hipMemcpyDeviceToHost, st));
+        MVS_HIP(ctx, hipStreamSynchronize(st));
+        for (int p = 0; p < N; p++) {  // heuristic.cpp:146-163 in rank order; scores are rebuilt from the start, so every kept
+            const int ord = (int)(unsigned)sorted[p];  // point (decided on the device or here) applies its subtractions once
+            const bool keep_it = state[ord] == 1 || (state[ord] == 0 && !(score[ord] < densityLimit));
+            if (state[ord] == 0) state[ord] = keep_it ? 1 : 2;
+            if (!keep_it) continue;
+            const double localDensity = density[ord];
+            for (int k = off[ord]; k < off[ord + 1]; k++) score[lo[k].idx] = (float)(score[lo[k].idx] - localDensity * lo[k].w);
+        }
+        if (timing) fprintf(stderr, "filter_points[%d] finished on the host after %d rounds\n", N, rounds);
+    }
     int m = 0;
     for (int i = 0; i < N; i++)
         if (state[i] == 1) keep_out[m++] = i;

@@ -18,7 +18,7 @@ def _cloud(rng, N, outliers):
     return allp[rng.permutation(allp.shape[0])]
 
 
-@pytest.mark.parametrize("N,alpha", [(500, 0.02), (6000, 0.004), (20000, 0.001)])
+@pytest.mark.parametrize("N,alpha", [(500, 0.02), (6000, 0.004), (20000, 0.001), (9000, 0.05), (40000, 0.012)])  # the last two: long lists -> global-sort path
 def test_filter_points_matches_oracle(oracle, N, alpha):
     rng = np.random.default_rng(N)
     pts = _cloud(rng, N, 30)
@@ -40,3 +40,31 @@ def test_filter_points_edge_cases(oracle):
             ctx.filter_points(one, 0.0)
         same = np.tile(np.array([[0.5, 0.5, 0.5, 1.0]], np.float32), (50, 1))   # 50 coincident points
         np.testing.assert_array_equal(ctx.filter_points(same, 0.04), oracle.filter_points(same, 0.04)[0])
+
+
+def test_round_limit_fallback_gives_the_same_selection(oracle, tmp_path):
+    """the greedy pass runs in dependency rounds on the device; past a round limit the rest is decided by the reference's
+    sequential walk on the host.  With the limit forced down to 8 rounds (MVS_FILTER_MAX_ROUNDS, read once per process,
+    hence the child process) the selection must equal the unlimited one and the oracle's"""
+    import os
+    import subprocess
+    import sys
+    pts = _cloud(np.random.default_rng(11), 9000, 30)
+    alpha = 0.05           # ~350 neighbours per point: dependency chains far longer than the forced limit
+    np.save(tmp_path / "pts.npy", pts)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import mvs_amd\n"
+            "pts = np.load(%r)\n"
+            "with mvs_amd.Context(64, 64) as ctx: keep = ctx.filter_points(pts, %r)\n"
+            "np.save(%r, keep)\n") % (os.path.join(root, "mesh-reconstruction_amd", "python"), str(tmp_path / "pts.npy"), alpha,
+                                      str(tmp_path / "keep.npy"))
+    env = dict(os.environ, MVS_FILTER_MAX_ROUNDS="8", MVS_FILTER_TIMING="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert "finished on the host after 8 rounds" in out.stderr, out.stderr[-1500:]   # the fallback really ran
+    limited = np.load(tmp_path / "keep.npy")
+    with mvs_amd.Context(64, 64) as ctx:
+        full = ctx.filter_points(pts, alpha)
+    ref = oracle.filter_points(pts, alpha)[0]
+    np.testing.assert_array_equal(limited, full)
+    np.testing.assert_array_equal(full, ref)
