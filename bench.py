@@ -70,7 +70,12 @@ def pmc_traffic(kernel_prefix, config):
     FETCH_SIZE doubled for 16-byte-per-lane streams as MI355X_MICROARCH.md prescribes).  None if absent."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_%s_*.json" % config))):
+    import re
+
+    def version_key(path):  # profiles/rNN/pmc_<config>_v<K>_<tag>.json: newest round, then highest K (numeric: v12 > v9)
+        m = re.search(r"profiles[/\\]r(\d+)[/\\]pmc_[^_]+_v(\d+)", path)
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_%s_*.json" % config)), key=version_key):
         try:
             rec = json.load(open(path))
             for name, c in rec.get("kernels", {}).items():

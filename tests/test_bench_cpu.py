@@ -1,0 +1,36 @@
+"""bench.py helpers that need no GPU."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_pmc_traffic_picks_the_newest_profile_numerically(tmp_path, monkeypatch):
+    """roofline.traffic comes from the committed PMC summaries; 'v12' must win over 'v9' (a plain string sort says otherwise)"""
+    b = _bench()
+    d = tmp_path / "profiles" / "r01"
+    d.mkdir(parents=True)
+    for tag, val in (("v9_split", 9.0), ("v12_final", 12.0), ("v3_linear", 3.0)):
+        (d / ("pmc_c3_%s.json" % tag)).write_text(json.dumps({"kernels": {"sweep_tiled<2, 32, true, true>": {"hbm_bytes_per_launch": val}}}))
+    d2 = tmp_path / "profiles" / "r02"
+    d2.mkdir()
+    (d2 / "pmc_c3_v1_first.json").write_text(json.dumps({"kernels": {"sweep_tiled<2, 32, true, true>": {"hbm_bytes_per_launch": 101.0}}}))
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    got = b.pmc_traffic("sweep_tiled", "c3")
+    assert got["bytes"] == 101.0 and got["source"].endswith("pmc_c3_v1_first.json")   # a later round beats any version of an earlier one
+    (d2 / "pmc_c3_v1_first.json").unlink()
+    assert b.pmc_traffic("sweep_tiled", "c3")["bytes"] == 12.0
+    assert b.pmc_traffic("sweep_tiled", "c9") is None
+
+
+def test_committed_profiles_resolve():
+    got = _bench().pmc_traffic("sweep_tiled", "c3")
+    assert got is not None and got["bytes"] > 1.0e9 and "pmc_c3_v" in got["source"]
