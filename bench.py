@@ -57,10 +57,19 @@ def cpu_baseline(cfg, main_cam, main_img, side_cams, sides):
     o.sweep(main_cam, main_img, side_cams, sides, nplanes, z_lo, z_hi, nthreads=cores)
     dt = time.perf_counter() - t0
     samples = float(W) * H * nplanes * V
+    # the reference itself is single-threaded: the same port on ONE thread, two mid-range planes (a few seconds)
+    n1 = min(2, D)
+    d1 = (D - n1) // 2
+    t0 = time.perf_counter()
+    o.sweep(main_cam, main_img, side_cams, sides, n1, -1.0 + 2.0 * d1 / D, -1.0 + 2.0 * (d1 + n1) / D, nthreads=1)
+    dt1 = time.perf_counter() - t0
+    samples1 = float(W) * H * n1 * V
     return {
         "value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
         "sample": "%dx%d, %d views, planes %d..%d of %d (%.3g samples, %.1f s), OpenMP over rows" %
                   (W, H, V, d0, d0 + nplanes - 1, D, samples, dt),
+        "single_thread": {"value": samples1 / dt1, "unit": "samples/s", "cores": 1,
+                          "sample": "planes %d..%d of %d (%.3g samples, %.1f s)" % (d1, d1 + n1 - 1, D, samples1, dt1)},
     }
 
 
