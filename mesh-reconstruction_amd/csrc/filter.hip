@@ -1,16 +1,21 @@
 // filter.hip -- Heuristic::filterPoints (heuristic.cpp:55-176) on gfx950: the outlier / redundancy filter the reference
 // runs on the 10^5..10^6-point cloud after every iteration (recon.cpp:125).
 //
-// Reference structure -> here:
+// Reference structure -> here (everything on the device; the host only reads an 8-byte convergence value per power
+// iteration, a round counter per batch of greedy rounds, and the final keep flags):
 //   FLANN KD-tree build + one radiusSearch per point (heuristic.cpp:74-92, single thread, randomised, approximate)
-//       -> hash grid with cell = sqrt(radius): hash_build, nb_count, nb_fill (exact neighbourhood, 27 cells per point),
-//          lists sorted by index so the result does not depend on atomics' arrival order
+//       -> hash grid with cell = sqrt(radius): hash_build, nb_count, nb_fill (exact neighbourhood, 27 cells per point);
+//          every point gets its lower list (j < i) and its upper list (k > i), both ascending by index so the result does
+//          not depend on atomics' arrival order -- ordered per thread for short lists, by global radix sorts with key
+//          (owner, index) for long ones (list_keys)
 //   power iteration over the symmetric neighbour weights (103-136), scatter `score[j] += ...` on one thread
-//       -> gather form: each point owns its lower list (j < i) AND its upper list (k > i), both ascending, and adds
-//          them in exactly the order the sequential scatter would have produced (density_score); the two global
-//          sums run as fixed-shape two-level reductions (chunk_sums / final on the host) -- deterministic
-//   greedy pass by descending density (139-163) is inherently sequential: it stays on the host, on the lists copied
-//   back once.
+//       -> gather form: a point adds its lower and upper lists in exactly the order the sequential scatter would have
+//          produced (density_score); the two global sums are fixed-shape reductions finished on the device
+//          (chunk_sums, finish_normalizer / finish_change); iteration k + 1 is queued before the host sees iteration k's value
+//   greedy pass by descending density (139-163)
+//       -> the order is a radix sort of (~density bits, index) keys; the pass itself only looks serial: a point depends on the
+//          kept points earlier in the order whose lower list contains it, so it is decided in dependency rounds
+//          (greedy_round / greedy_round_sorted), exactly the sequential result; a bounded host walk finishes pathological chains
 // Quirks kept: squared distances compared with `radius` (81-89), only lower-index neighbours are penalised (152-154).
 #include "mvs_internal.hpp"
 
