@@ -7,13 +7,15 @@
 // OpenCV's organisation; the operation order is the one documented in oracle/flow_oracle.c, which these kernels
 // reproduce bit for bit (f32 ops one rounding each under -ffp-contract=off, f64 where OpenCV accumulates in double).
 //
-// Farneback, per pyramid level (coarse to fine): gauss_row/gauss_col -> resize_linear -> polyexp_vert/polyexp_horiz
-// for both frames, then update_matrices and `iterations` x [box_vert, box_horiz_solve, update_matrices].
+// Farneback, per pyramid level (coarse to fine): gauss (rows, columns) -> resize_linear -> polyexp_vert/polyexp_horiz,
+// both frames per launch (blockIdx.z), then update_matrices and `iterations` x farneback_iteration_fused (vertical box
+// sums in LDS + horizontal sums + 2x2 solve + the next update matrices; the three separate kernels remain as the A/B form).
 // Everything stays in one HBM arena per context; the reference's per-level Mat allocations and the CPU
 // round trip of every intermediate disappear.
 //
-// Variational refinement: warp_q5 -> avg_diff -> central differences -> 5 x [data_term, diffusivity,
-// smooth_gather, 5 x (sor red, sor black)] -> add increment.
+// Variational refinement: warp_q5 -> avg_diff -> central differences -> 5 x var_fixed_point_fused (data term,
+// diffusivity, smoothness gather and the 5 red-black SOR sweeps of one fixed-point iteration in ONE launch by temporal
+// blocking in LDS; the 13 separate kernels remain as the A/B form) -> add increment.
 #include "mvs_internal.hpp"
 
 #include <cmath>

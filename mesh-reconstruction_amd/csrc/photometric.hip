@@ -10,6 +10,8 @@
 //   pyr_up_add_kernel  zero-insert x2 + [1 4 6 4 1]/8, fused with the `diffPyramid[i] += upscaled` of
 //                      util.cpp:357 so the up-sampled level is never materialised
 //   absdiff_kernel     |a - b| (util.cpp:343), with the u8 -> f32 conversion of util.cpp:337-338 fused at level 0
+//   pyr_down_pair_absdiff   one level of compare(): pyrDown of both images + their absolute difference in one launch
+//   pyramid_tail       every level of <= 4096 cells, down and back up, in a single workgroup
 //   remap_cubic_kernel 1/32-pixel Q15 bicubic, BORDER_CONSTANT 0 (util.cpp:401)
 #include "mvs_internal.hpp"
 

@@ -8,8 +8,9 @@
 // Through the one-stage entry points of mvs.h each of these crosses PCIe twice (cv::Mat in, cv::Mat out), as the
 // reference's own GL path does (two glReadPixels + two uploads per pair, render_glx.cpp:286,325,359,75).  Here the
 // frames go up once, every intermediate (depth, warped image, mask, flows) stays in HBM, and only the points come
-// back.  Same kernels, same arithmetic: the result equals the stage-by-stage calls bit for bit
-// (tests/test_pipeline_gpu.py).
+// back.  The flows of the side views are independent of each other, so each runs in one of four lanes (stream + arena +
+// cached hipGraph) while the main stream rasterises the next view.  Same kernels, same arithmetic: the result equals the
+// stage-by-stage calls bit for bit (tests/test_pipeline_gpu.py).
 #include "mvs_internal.hpp"
 
 #include <algorithm>

@@ -6,6 +6,8 @@
 //   sobel_kernel       imageGradient(depth)
 //   tri_points_kernel  measured points + inverse covariances per side camera, the <= 50-step Newton solve, the pdf
 //   tri_normals_kernel 21x21-neighbourhood PCA (3x3 Jacobi in f64), orientation vote, pdf scaling
+//   compact_count / compact_scan / compact_scatter   the valid pixels in pixelId order (util.cpp:172,247-248), packed on the
+//                      device so that only the n x 7 result crosses PCIe
 // Quirks are reproduced as catalogued in oracle/triangulate_oracle.c (swapped bilinear weights, y + fly, the
 // type-punned gradient, the un-dehomogenised fallback normal).  Arithmetic mirrors the oracle statement by statement
 // (f32 storage, f64 accumulation of every matrix product); exp()/pow() come from the device math library, so pdf and
