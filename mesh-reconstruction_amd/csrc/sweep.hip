@@ -723,12 +723,14 @@ __global__ __launch_bounds__(256) void argmin_volume(const uint32_t *__restrict_
         bi[i] = -1;
     }
     int d = 0;
-    for (; d + 4 <= D; d += 4) {
-        uint32_t c[4][VEC];
+    constexpr int UNR = 8;  // planes in flight per thread: 8 x 16 B, non-temporal (the stream is read once): 4.75 -> 5.64 TB/s at c3
+    for (; d + UNR <= D; d += UNR) {
+        uint32_t c[UNR][VEC];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < UNR; u++) {
             if (VEC == 4) {
-                const uint4 t = *(const uint4 *)(vol + (size_t)(d + u) * P + base);
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 t = __builtin_nontemporal_load((const u32x4 *)(vol + (size_t)(d + u) * P + base));
                 c[u][0] = t.x;
                 c[u][1 % VEC] = t.y;
                 c[u][2 % VEC] = t.z;
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(256) void argmin_volume(const uint32_t *__restrict_
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < UNR; u++)
 #pragma unroll
             for (int i = 0; i < VEC; i++) argmin_update(c[u][i], d + u, bs[i], bc[i], bi[i]);
     }
