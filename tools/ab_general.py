@@ -15,8 +15,10 @@ W,H,D,V = 1920,1080,128,16
 mc, mi, sc, si, _ = synth.make_views(W,H,V,radius=0.15)
 with mvs_amd.Context(W,H) as ctx:
     ctx.sweep_set(mc, mi, sc, si, D)
-    r = {"wconst": t(ctx,V,both), "general_compiler": t(ctx,V,both|(4<<8)), "general_pipelined": t(ctx,V,both|((4|16)<<8)),
-         "general_compiler_again": t(ctx,V,both|(4<<8))}
+    # high-byte debug bits: 4 = never take the plane-independent-w path; 16 = general path with the compiler-scheduled pair
+    # loop instead of the hand-pipelined reads (the shipped default in the 2 x 32 shape)
+    r = {"wconst": t(ctx,V,both), "general_pipelined": t(ctx,V,both|(4<<8)), "general_compiler_loop": t(ctx,V,both|((4|16)<<8)),
+         "general_pipelined_again": t(ctx,V,both|(4<<8))}
     ctx.sweep_run(0,V,both|(4<<8)); a=[x.copy() for x in ctx.sweep_fetch()[:3]]
     ctx.sweep_run(0,V,both|((4|16)<<8)); b=ctx.sweep_fetch()[:3]
     r["identical"]=all(np.array_equal(x,y) for x,y in zip(a,b))
