@@ -125,6 +125,7 @@ __global__ __launch_bounds__(128) void tri_points_kernel(const float *const *__r
     if (col >= W || row >= H) return;
     const size_t pix = (size_t)row * W + col;
     valid[pix] = 0;
+    ((float4 *)xyz3)[pix] = make_float4(0.f, 0.f, 0.f, 0.f);  // (x, y, z, valid) per pixel, one aligned 16-byte record
     const float d0 = depth[pix];
     if (d0 == MVS_BACKGROUND_DEPTH) return;
     const float centerX = W / 2.0f, centerY = H / 2.0f, scaleX = 2.0f / W, scaleY = 2.0f / H;
@@ -220,8 +221,7 @@ __global__ __launch_bounds__(128) void tri_points_kernel(const float *const *__r
 #pragma unroll
     for (int c = 0; c < 4; c++) pts[pix * 4 + c] = out[c];
     // the normals pass visits every point up to 2 x 441 times: dehomogenise once (same f32 quotients as util.cpp:291)
-#pragma unroll
-    for (int c = 0; c < 3; c++) xyz3[pix * 3 + c] = out[c] / out[3];
+    ((float4 *)xyz3)[pix] = make_float4(out[0] / out[3], out[1] / out[3], out[2] / out[3], 1.0f);
     pdfs[pix] = pdf;
     valid[pix] = 1;
 }
@@ -292,11 +292,11 @@ __global__ __launch_bounds__(128) void tri_normals_kernel(const uint8_t *__restr
             const int nx = col - radius + k;
             const bool in = nx >= 0 && nx < W;
             const size_t p = (size_t)ny * W + (in ? nx : col);
-            ok[k] = in && valid[p];
-            const float *q = xyz3 + p * 3;
-            qx[k] = q[0];
-            qy[k] = q[1];
-            qz[k] = q[2];
+            const float4 q = ((const float4 *)xyz3)[p];  // one aligned 16-byte load instead of a 12-byte one plus a flag byte
+            ok[k] = in && q.w != 0.f;
+            qx[k] = q.x;
+            qy[k] = q.y;
+            qz[k] = q.z;
         }
 #pragma unroll
         for (int k = 0; k < WIN; k++) {
@@ -320,11 +320,11 @@ __global__ __launch_bounds__(128) void tri_normals_kernel(const uint8_t *__restr
                 const int nx = col - radius + k;
                 const bool in = nx >= 0 && nx < W;
                 const size_t p = (size_t)ny * W + (in ? nx : col);
-                ok[k] = in && valid[p];
-                const float *q = xyz3 + p * 3;
-                qx[k] = q[0];
-                qy[k] = q[1];
-                qz[k] = q[2];
+                const float4 q = ((const float4 *)xyz3)[p];
+                ok[k] = in && q.w != 0.f;
+                qx[k] = q.x;
+                qy[k] = q.y;
+                qz[k] = q.z;
             }
 #pragma unroll
             for (int k = 0; k < WIN; k++) {
@@ -532,15 +532,16 @@ int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, bo
     float main_center[3];
     host_center(main_cam, main_center);
 
-    // arena: flows (V*4P) | depth P | grad 2P | pts 4P | pdf P | normals 3P | xyz 3P | packed 7P | block counts | valid P bytes | tables
+    // arena: flows (V*4P) | xyz+valid 4P | depth P | grad 2P | pts 4P | pdf P | normals 3P | packed 7P | block counts | valid P bytes | tables
     const size_t flow_floats = on_device ? 0 : (size_t)V * 4 * P;
     const int nb = (int)((P + CP_CHUNK - 1) / CP_CHUNK);
-    const size_t floats = flow_floats + P + 2 * P + 4 * P + P + 3 * P + 3 * P + 7 * P + (size_t)nb + 2;
+    const size_t floats = flow_floats + P + 2 * P + 4 * P + P + 3 * P + 4 * P + 7 * P + (size_t)nb + 2;
     const size_t tables = sizeof(CamPre) * pre.size() + sizeof(float) * (16 + 4) + sizeof(float *) * (size_t)(V > 0 ? V : 1);
     int rc = ensure(ctx, ctx->flow_arena, floats * sizeof(float) + P + tables + 256);
     if (rc) return rc;
-    float *d_flows = (float *)ctx->flow_arena.ptr, *d_depth = d_flows + flow_floats, *d_grad = d_depth + P, *d_pts = d_grad + 2 * P,
-          *d_pdf = d_pts + 4 * P, *d_nrm = d_pdf + P, *d_xyz = d_nrm + 3 * P, *d_packed = d_xyz + 3 * P;
+    // xyz+valid first: its float4 view needs 16-byte alignment, and flow_floats (V * 4P) is a multiple of 4 floats for any P
+    float *d_flows = (float *)ctx->flow_arena.ptr, *d_xyz = d_flows + flow_floats, *d_depth = d_xyz + 4 * P, *d_grad = d_depth + P,
+          *d_pts = d_grad + 2 * P, *d_pdf = d_pts + 4 * P, *d_nrm = d_pdf + P, *d_packed = d_nrm + 3 * P;
     int *d_counts = (int *)(d_packed + 7 * P);
     uint8_t *d_valid = (uint8_t *)(d_counts + nb + 2);
     uintptr_t t = ((uintptr_t)(d_valid + P) + 63) & ~(uintptr_t)63;

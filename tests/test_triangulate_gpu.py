@@ -36,8 +36,8 @@ def test_triangulate_matches_oracle_on_the_recon_stage(oracle):
     np.testing.assert_allclose(got[:, 4:], ref[:, 4:], rtol=1e-5, atol=1e-9)
 
 
-def test_triangulate_edge_cases(oracle):
-    W, H = 200, 96
+@pytest.mark.parametrize("W,H", [(200, 96), (201, 97)])   # the second: W*H not a multiple of 4 (16-byte-aligned records in the arena)
+def test_triangulate_edge_cases(oracle, W, H):
     verts, faces = scenes.heightfield_mesh(48, extent=2.2)
     soup = oracle.load_mesh(verts, faces)
     main = synth.camera_at([0, 0, 0], W, H)
