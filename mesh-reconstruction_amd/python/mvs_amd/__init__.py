@@ -356,21 +356,27 @@ class Context:
                                              C.byref(n)))
         return out[:n.value].copy()
 
-    def process_frame(self, main_cam, main_frame, side_cams, side_frames, use_farneback=False, want_depth=False):
-        """mvs_process_frame: recon.cpp:65-117 for one main frame -> (N, 7) points [, depth after mixBackground]"""
+    def process_frame(self, main_cam, main_frame, side_cams, side_frames, use_farneback=False, want_depth=False, copy=True):
+        """mvs_process_frame: recon.cpp:65-117 for one main frame -> (N, 7) points [, depth after mixBackground].
+        The library writes into a caller-owned H*W x 7 buffer; this wrapper keeps ONE such buffer per context (a fresh 58 MB
+        numpy array per call at 1080p costs more in page faults than the whole GPU pipeline).  copy=True returns an
+        independent array; copy=False returns a view of that buffer, valid until the next call -- what a C++ caller reusing
+        its cv::Mat gets, and what the timing scripts use."""
         V = len(side_frames)
         cam = _f32(main_cam, (4, 4))
         mf = _u8(main_frame, (self.H, self.W))
         cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((1, 4, 4), np.float32)
         frames = [_u8(f, (self.H, self.W)) for f in side_frames]
         arr = (_u8p * max(V, 1))(*[_ptr(f, _u8p) for f in frames])
-        out = np.empty((self.H * self.W, 7), np.float32)
+        if getattr(self, "_pf_out", None) is None:
+            self._pf_out = np.zeros((self.H * self.W, 7), np.float32)   # zeros: touch every page once, here
+        out = self._pf_out
         depth = np.empty((self.H, self.W), np.float32) if want_depth else None
         n = C.c_int(0)
         self._check(self.lib.mvs_process_frame(self.h, _ptr(cam, _fp), _ptr(mf, _u8p), V, _ptr(cams, _fp), arr,
                                                1 if use_farneback else 0, _ptr(out, _fp), C.byref(n),
                                                _ptr(depth, _fp) if want_depth else None))
-        pts = out[:n.value].copy()
+        pts = out[:n.value].copy() if copy else out[:n.value]
         return (pts, depth) if want_depth else pts
 
     def filter_points(self, points4, alpha):

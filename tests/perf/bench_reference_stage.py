@@ -25,6 +25,9 @@ def main():
     farneback = "--farneback" in sys.argv
     t = tracks_yaml.load("koberec.yaml")
     W, H = t["width"], t["height"]
+    for a in sys.argv[1:]:   # --size=1920x1080: the projections are NDC, so the same cameras serve any frame size
+        if a.startswith("--size="):
+            W, H = (int(v) for v in a[len("--size="):].split("x"))
     cams = t["cameras"]
     main_i, side_is = 40, [30, 35, 45, 50]
     main = cams[main_i]
@@ -56,7 +59,7 @@ def main():
         samples = []
         for _ in range(reps):
             t0 = time.perf_counter()
-            ctx.process_frame(main, main_img, sides, side_imgs, farneback)
+            ctx.process_frame(main, main_img, sides, side_imgs, farneback, copy=False)   # the C ABI call into a reused buffer
             samples.append((time.perf_counter() - t0) * 1e3)
         gpu_ms = float(np.median(samples))
         info = ctx.info()
@@ -76,7 +79,7 @@ def main():
     cpu_ms = (time.perf_counter() - t0) * 1e3
     same = pts.shape == o_pts.shape and np.array_equal(pts[:, :4], o_pts[:, :4], equal_nan=True)
     n_nan = int(np.isnan(o_pts[:, :4]).any(axis=1).sum())
-    print(json.dumps({"workload": "c1 reference stage: koberec.yaml cameras, 640x480, 1 main + 4 side frames, variational flow",
+    print(json.dumps({"workload": "reference stage: koberec.yaml cameras, %dx%d, 1 main + 4 side frames, %s flow" % (W, H, "Farneback" if farneback else "variational"),
                       "points": int(pts.shape[0]), "gpu_ms_per_main_frame": gpu_ms, "gpu_ms_min_max": [min(samples), max(samples)], "gpu_reps": reps, "cpu_port_ms_per_main_frame": cpu_ms,
                       "cpu_threads": 1, "speedup": cpu_ms / gpu_ms, "positions_bit_identical": bool(same), "points_with_nan_in_both": n_nan, "device": info}))
 
