@@ -342,19 +342,22 @@ class Context:
                                       _ptr(out, _fp)))
         return out
 
-    def triangulate(self, flows, main_cam, side_cams, depth):
-        """mvs_triangulate -> (N, 7) rows (x, y, z, w, nx, ny, nz) in pixel scan order"""
+    def triangulate(self, flows, main_cam, side_cams, depth, copy=True):
+        """mvs_triangulate -> (N, 7) rows (x, y, z, w, nx, ny, nz) in pixel scan order (copy=False: a view of the context's
+        reusable output buffer, valid until the next triangulate / process_frame call -- see process_frame)"""
         V = len(flows)
         fl = [_f32(f, (self.H, self.W, 4)) for f in flows]
         arr = (_fp * max(V, 1))(*[_ptr(f, _fp) for f in fl])
         cam = _f32(main_cam, (4, 4))
         cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((1, 4, 4), np.float32)
         depth = _f32(depth, (self.H, self.W))
-        out = np.empty((self.H * self.W, 7), np.float32)
+        if getattr(self, "_pf_out", None) is None:
+            self._pf_out = np.zeros((self.H * self.W, 7), np.float32)
+        out = self._pf_out
         n = C.c_int(0)
         self._check(self.lib.mvs_triangulate(self.h, V, arr, _ptr(cam, _fp), _ptr(cams, _fp), _ptr(depth, _fp), _ptr(out, _fp),
                                              C.byref(n)))
-        return out[:n.value].copy()
+        return out[:n.value].copy() if copy else out[:n.value]
 
     def process_frame(self, main_cam, main_frame, side_cams, side_frames, use_farneback=False, want_depth=False, copy=True):
         """mvs_process_frame: recon.cpp:65-117 for one main frame -> (N, 7) points [, depth after mixBackground].

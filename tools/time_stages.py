@@ -20,7 +20,7 @@ for (W, H) in [(640, 480), (1920, 1080)]:
         tc, _ = t(lambda: ctx.compare(a, mixed))
         tf, fl = t(lambda: ctx.flow(a, mixed, True), 3)
         tv, fv = t(lambda: ctx.flow(a, mixed, False), 3)
-        tt, tri = t(lambda: ctx.triangulate([fv], main, side[None], d2), 3)
+        tt, tri = t(lambda: ctx.triangulate([fv], main, side[None], d2, copy=False), 3)   # into a reused buffer, as a C caller would
         ctx.profile_enable(True); ctx.flow(a, mixed, True); ms, n = ctx.profile_read(True); ctx.flow(a, mixed, False); ms2, n2 = ctx.profile_read(True)
         print("%dx%d (%d faces): depth %.2f ms, projected %.2f, mixBackground %.2f, compare %.2f, flow farneback %.2f (device %.2f), "
               "flow variational %.2f (device %.2f), triangulate %.2f ms (%d pts)" % (W, H, faces.shape[0], td, tp, tm, tc, tf, ms[5], tv, ms2[5], tt, tri.shape[0]))
