@@ -261,39 +261,49 @@ __device__ void smallest_eigvec3(double a[3][3], double v[3])
     for (int k = 0; k < 3; k++) v[k] = Vm[k][m];
 }
 
-__global__ __launch_bounds__(128) void tri_normals_kernel(const uint8_t *__restrict__ valid, const float *__restrict__ pts,
+constexpr int TN_W = 64, TN_H = 4, TN_R = 10, TN_RW = TN_W + 2 * TN_R, TN_RH = TN_H + 2 * TN_R;
+
+__global__ __launch_bounds__(TN_W * TN_H) void tri_normals_kernel(const uint8_t *__restrict__ valid, const float *__restrict__ pts,
                                                           const float *__restrict__ xyz3, const float *__restrict__ pdfs, const CamPre *__restrict__ pre,
                                                           const float *__restrict__ main_center, int V, int W, int H,
                                                           float *__restrict__ normals)
 {
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int row = blockIdx.y * 2 + (threadIdx.x >> 6);
+    // The 64 x 4-pixel tile and its 10-pixel apron are staged once as (x, y, z, valid) records: every pixel reads its 441
+    // neighbours twice, which through L1 is 882 16-byte loads per pixel against 8 staged records per pixel here.  Cells
+    // outside the image are staged as invalid, so the window walk needs no bounds logic at all.
+    __shared__ float4 cell[TN_RW * TN_RH];
+    const int X0 = blockIdx.x * TN_W - TN_R, Y0 = blockIdx.y * TN_H - TN_R;
+    for (int c = threadIdx.x; c < TN_RW * TN_RH; c += TN_W * TN_H) {
+        const int ry = c / TN_RW, rx = c - ry * TN_RW, gx = X0 + rx, gy = Y0 + ry;
+        cell[c] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? ((const float4 *)xyz3)[(size_t)gy * W + gx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int col = blockIdx.x * TN_W + lx;
+    const int row = blockIdx.y * TN_H + ly;
     if (col >= W || row >= H) return;
     const size_t pix = (size_t)row * W + col;
     if (!valid[pix]) return;
-    const int radius = 10;
+    const int radius = TN_R;
     float pdf = pdfs[pix];
     if (V > 1) pdf = (float)pow((double)pdf, 1.0 / V);
-    // The window is walked row by row; a row's 21 neighbours are loaded unconditionally (clamped address, validity kept as a
-    // flag) and only then accumulated, in the reference's order, with selects: the loads of a row are independent, so they
-    // overlap instead of each waiting behind a validity branch.  An invalid neighbour adds +0.0, which leaves a double
-    // accumulator unchanged, so the sums are bit-identical to the branchy walk.  Measured 501 -> 485 us at 640x480: the kernel is
-    // bound by its instruction count (f64 ops issue at the f32 rate on gfx950: profiles/r01/valu_issue_microbench.txt), not by
-    // load latency (an LDS-staged variant was 2x slower and was dropped).
+    // The window is walked row by row; a row's 21 neighbours are read unconditionally and only then accumulated, in the
+    // reference's order, with selects: an invalid neighbour adds +0.0, which leaves a double accumulator unchanged, so the sums
+    // are bit-identical to a branchy walk.  History at 640x480: branchy global loads 501 us; branch-free 485; aligned float4
+    // records 361; staged in LDS (this form) about the same at 640x480 and 1.6 % better per frame at 1080p.  f64 ops issue at
+    // the f32 rate on gfx950 (profiles/r01/valu_issue_microbench.txt): what bounds the kernel is its instruction count.
     constexpr int WIN = 21;
     int n = 0;
     double mean[3] = {0, 0, 0};
-    for (int ny = row - radius; ny <= row + radius; ny++) {
-        if (ny < 0 || ny >= H) continue;
+    for (int dy = 0; dy <= 2 * radius; dy++) {
+        if (row - radius + dy < 0 || row - radius + dy >= H) continue;  // rows outside the image hold only invalid cells
+        const float4 *rowp = cell + (ly + dy) * TN_RW + lx;
         float qx[WIN], qy[WIN], qz[WIN];
         bool ok[WIN];
 #pragma unroll
         for (int k = 0; k < WIN; k++) {
-            const int nx = col - radius + k;
-            const bool in = nx >= 0 && nx < W;
-            const size_t p = (size_t)ny * W + (in ? nx : col);
-            const float4 q = ((const float4 *)xyz3)[p];  // one aligned 16-byte load instead of a 12-byte one plus a flag byte
-            ok[k] = in && q.w != 0.f;
+            const float4 q = rowp[k];
+            ok[k] = q.w != 0.f;
             qx[k] = q.x;
             qy[k] = q.y;
             qz[k] = q.z;
@@ -311,17 +321,15 @@ __global__ __launch_bounds__(128) void tri_normals_kernel(const uint8_t *__restr
     if (n >= 3) {
         for (int c = 0; c < 3; c++) mean[c] /= n;
         double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        for (int ny = row - radius; ny <= row + radius; ny++) {
-            if (ny < 0 || ny >= H) continue;
+        for (int dy = 0; dy <= 2 * radius; dy++) {
+            if (row - radius + dy < 0 || row - radius + dy >= H) continue;
+            const float4 *rowp = cell + (ly + dy) * TN_RW + lx;
             float qx[WIN], qy[WIN], qz[WIN];
             bool ok[WIN];
 #pragma unroll
             for (int k = 0; k < WIN; k++) {
-                const int nx = col - radius + k;
-                const bool in = nx >= 0 && nx < W;
-                const size_t p = (size_t)ny * W + (in ? nx : col);
-                const float4 q = ((const float4 *)xyz3)[p];
-                ok[k] = in && q.w != 0.f;
+                const float4 q = rowp[k];
+                ok[k] = q.w != 0.f;
                 qx[k] = q.x;
                 qy[k] = q.y;
                 qz[k] = q.z;
@@ -575,7 +583,7 @@ int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, bo
         else
             tri_points_kernel<TRI_MAXCAM><<<grid, 128, 0, st>>>(d_ptrs, d_pre, V, d_minv, d_depth, d_grad, W, H, d_valid, d_pts, d_xyz, d_pdf);
     }
-    tri_normals_kernel<<<dim3(div_up(W, 64), div_up(H, 2)), 128, 0, st>>>(d_valid, d_pts, d_xyz, d_pdf, d_pre, d_mc, V, W, H, d_nrm);
+    tri_normals_kernel<<<dim3(div_up(W, TN_W), div_up(H, TN_H)), TN_W * TN_H, 0, st>>>(d_valid, d_pts, d_xyz, d_pdf, d_pre, d_mc, V, W, H, d_nrm);
     // compaction in pixel scan order (the reference's pixelId, util.cpp:172,247-248) on the device: only the packed
     // rows cross PCIe, straight into the caller's buffer
     compact_count<<<nb, 256, 0, st>>>(d_valid, P, d_counts);
