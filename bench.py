@@ -89,7 +89,10 @@ def pmc_traffic(kernel_prefix, config):
             rec = json.load(open(path))
             for name, c in rec.get("kernels", {}).items():
                 if name.startswith(kernel_prefix) and "hbm_bytes_per_launch" in c:
-                    best = {"bytes": c["hbm_bytes_per_launch"], "source": os.path.relpath(path, ROOT)}
+                    best = {"bytes": c["hbm_bytes_per_launch"], "source": os.path.relpath(path, ROOT), "valu_utilisation": None}
+                    if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
+                        # active VALU quad-cycles x 4 cycles, over 1024 SIMDs x the launch's cycles (GRBM_GUI_ACTIVE sums the 8 XCDs)
+                        best["valu_utilisation"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
         except Exception:
             pass
     return best
@@ -382,6 +385,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
                          "valu_bound_note": "VALU-issue bound, see DESIGN.md section 4 and profiles/",
+                         "valu_utilisation": traffic["valu_utilisation"] if traffic else None,   # from the same PMC summary as `traffic`
                          "bytes_per_launch": sweep_bytes, "ms_per_launch": sweep_ms},
             "kernels": {"sweep_ms": sweep_ms, "argmin_ms": argmin_ms if separate else None,
                         "argmin_GBps": argmin_bytes / (argmin_ms * 1e-3) / 1e9 if argmin_ms > 0 else None,
