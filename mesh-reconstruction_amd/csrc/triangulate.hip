@@ -113,19 +113,46 @@ __device__ __forceinline__ void sample_point_punned(const float *__restrict__ gr
 // in scratch memory (784 B per lane), re-read on each of up to 50 Newton iterations; the reference uses 2-8 side views per main
 // frame, so the kernel is also instantiated for 4 and 8 with fully unrolled, predicated view loops (arrays in registers).
 // Same statements per view in the same order: bit-identical.
-template <int VMAX>
+//
+// PHASE: the Newton solve stops when |delta z| < 1e-7 or after 50 steps.  Most pixels converge in a handful of steps, but a
+// wavefront iterates until its slowest lane is done, so a few non-converging pixels kept whole waves at the cap (275 us at
+// 640x480 where ~5 steps per pixel would take ~45).  PHASE 0 runs every pixel for at most TRI_SPLIT steps and queues the
+// unconverged ones (pixel, current z); PHASE 1 finishes the queue densely packed, one queued pixel per thread, recomputing the
+// per-view set-up (a pure function of the inputs) and continuing from step TRI_SPLIT.  The per-pixel step sequence is
+// unchanged: bit-identical.
+constexpr int TRI_SPLIT = 6;  // 4: 2.01 ms per frame at 640x480 (too many pixels queued), 6: 1.89, 9: 1.90
+struct TriQueued {
+    int pix;
+    float z;
+};
+
+template <int VMAX, int PHASE>
 __global__ __launch_bounds__(128) void tri_points_kernel(const float *const *__restrict__ flows, const CamPre *__restrict__ pre,
                                                          int V, const float *__restrict__ Minv, const float *__restrict__ depth,
                                                          const float *__restrict__ grad, int W, int H,
                                                          uint8_t *__restrict__ valid, float *__restrict__ pts,
-                                                         float *__restrict__ xyz3, float *__restrict__ pdfs)
+                                                         float *__restrict__ xyz3, float *__restrict__ pdfs,
+                                                         int *__restrict__ queue_count, TriQueued *__restrict__ queue)
 {
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int row = blockIdx.y * 2 + (threadIdx.x >> 6);
-    if (col >= W || row >= H) return;
+    int col, row;
+    float z_start = 0.f;
+    if (PHASE == 0) {
+        col = blockIdx.x * 64 + (threadIdx.x & 63);
+        row = blockIdx.y * 2 + (threadIdx.x >> 6);
+        if (col >= W || row >= H) return;
+    } else {
+        const int q = (blockIdx.y * gridDim.x + blockIdx.x) * 128 + threadIdx.x;
+        if (q >= *queue_count) return;
+        const int qp = queue[q].pix;
+        z_start = queue[q].z;
+        row = qp / W;
+        col = qp - row * W;
+    }
     const size_t pix = (size_t)row * W + col;
-    valid[pix] = 0;
-    ((float4 *)xyz3)[pix] = make_float4(0.f, 0.f, 0.f, 0.f);  // (x, y, z, valid) per pixel, one aligned 16-byte record
+    if (PHASE == 0) {
+        valid[pix] = 0;
+        ((float4 *)xyz3)[pix] = make_float4(0.f, 0.f, 0.f, 0.f);  // (x, y, z, valid) per pixel, one aligned 16-byte record
+    }
     const float d0 = depth[pix];
     if (d0 == MVS_BACKGROUND_DEPTH) return;
     const float centerX = W / 2.0f, centerY = H / 2.0f, scaleX = 2.0f / W, scaleY = 2.0f / H;
@@ -176,9 +203,15 @@ __global__ __launch_bounds__(128) void tri_points_kernel(const float *const *__r
         meas[i][0] = mp[0] / mp[3];
         meas[i][1] = mp[1] / mp[3];
     }
-    float k[4] = {x, y, d0, 1.0f};
+    float k[4] = {x, y, PHASE == 0 ? d0 : z_start, 1.0f};
     float pdf = 1.0f;
-    for (int iter = 0;; iter++) {
+    for (int iter = PHASE == 0 ? 0 : TRI_SPLIT;; iter++) {
+        if (PHASE == 0 && iter == TRI_SPLIT) {  // not converged yet: hand over to the densely packed second pass
+            const int slot = atomicAdd(queue_count, 1);
+            queue[slot].pix = (int)pix;
+            queue[slot].z = k[2];
+            return;
+        }
         double firstDz = 0, secondDz = 0;
 #pragma unroll VMAX <= 8 ? VMAX : 1
         for (int i = 0; i < VMAX; i++) {
@@ -543,14 +576,16 @@ int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, bo
     // arena: flows (V*4P) | xyz+valid 4P | depth P | grad 2P | pts 4P | pdf P | normals 3P | packed 7P | block counts | valid P bytes | tables
     const size_t flow_floats = on_device ? 0 : (size_t)V * 4 * P;
     const int nb = (int)((P + CP_CHUNK - 1) / CP_CHUNK);
-    const size_t floats = flow_floats + P + 2 * P + 4 * P + P + 3 * P + 4 * P + 7 * P + (size_t)nb + 2;
+    const size_t floats = flow_floats + P + 2 * P + 4 * P + P + 3 * P + 4 * P + 7 * P + 2 * P + 4 + (size_t)nb + 2;
     const size_t tables = sizeof(CamPre) * pre.size() + sizeof(float) * (16 + 4) + sizeof(float *) * (size_t)(V > 0 ? V : 1);
     int rc = ensure(ctx, ctx->flow_arena, floats * sizeof(float) + P + tables + 256);
     if (rc) return rc;
     // xyz+valid first: its float4 view needs 16-byte alignment, and flow_floats (V * 4P) is a multiple of 4 floats for any P
     float *d_flows = (float *)ctx->flow_arena.ptr, *d_xyz = d_flows + flow_floats, *d_depth = d_xyz + 4 * P, *d_grad = d_depth + P,
           *d_pts = d_grad + 2 * P, *d_pdf = d_pts + 4 * P, *d_nrm = d_pdf + P, *d_packed = d_nrm + 3 * P;
-    int *d_counts = (int *)(d_packed + 7 * P);
+    TriQueued *d_queue = (TriQueued *)(d_packed + 7 * P);  // unconverged pixels of the first Newton pass
+    int *d_qcount = (int *)(d_queue + P);
+    int *d_counts = d_qcount + 4;
     uint8_t *d_valid = (uint8_t *)(d_counts + nb + 2);
     uintptr_t t = ((uintptr_t)(d_valid + P) + 63) & ~(uintptr_t)63;
     CamPre *d_pre = (CamPre *)t;
@@ -576,12 +611,18 @@ int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, bo
     sobel_kernel<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, st>>>(d_depth, W, H, d_grad);
     {
         const dim3 grid(div_up(W, 64), div_up(H, 2));
-        if (V <= 4)
-            tri_points_kernel<4><<<grid, 128, 0, st>>>(d_ptrs, d_pre, V, d_minv, d_depth, d_grad, W, H, d_valid, d_pts, d_xyz, d_pdf);
-        else if (V <= 8)
-            tri_points_kernel<8><<<grid, 128, 0, st>>>(d_ptrs, d_pre, V, d_minv, d_depth, d_grad, W, H, d_valid, d_pts, d_xyz, d_pdf);
-        else
-            tri_points_kernel<TRI_MAXCAM><<<grid, 128, 0, st>>>(d_ptrs, d_pre, V, d_minv, d_depth, d_grad, W, H, d_valid, d_pts, d_xyz, d_pdf);
+        MVS_HIP(ctx, hipMemsetAsync(d_qcount, 0, sizeof(int), st));
+#define MVS_TRI_POINTS(VM, PH) tri_points_kernel<VM, PH><<<grid, 128, 0, st>>>(d_ptrs, d_pre, V, d_minv, d_depth, d_grad, W, H, d_valid, d_pts, d_xyz, d_pdf, d_qcount, d_queue)
+        for (int phase = 0; phase < 2; phase++) {  // phase 1: same grid size, threads beyond the queue length exit at once
+            if (V <= 4) {
+                if (phase == 0) MVS_TRI_POINTS(4, 0); else MVS_TRI_POINTS(4, 1);
+            } else if (V <= 8) {
+                if (phase == 0) MVS_TRI_POINTS(8, 0); else MVS_TRI_POINTS(8, 1);
+            } else {
+                if (phase == 0) MVS_TRI_POINTS(TRI_MAXCAM, 0); else MVS_TRI_POINTS(TRI_MAXCAM, 1);
+            }
+        }
+#undef MVS_TRI_POINTS
     }
     tri_normals_kernel<<<dim3(div_up(W, TN_W), div_up(H, TN_H)), TN_W * TN_H, 0, st>>>(d_valid, d_pts, d_xyz, d_pdf, d_pre, d_mc, V, W, H, d_nrm);
     // compaction in pixel scan order (the reference's pixelId, util.cpp:172,247-248) on the device: only the packed
