@@ -55,6 +55,7 @@ struct mvs_ctx {
     bool plan_forced = false;        // plan made with the 4 x 16 shape forced (timing experiments)
     mvs::DevBuf plan_stats;          // planner counters (oversize regions, regions not skipped)
     mvs::DevBuf probe_buf;           // mvs_depth_probe: pixel coordinates in, depths out
+    mvs::DevBuf raster_bins;         // face binning of large meshes: per-bin counts / offsets / lists, shared list of large faces
     mvs::DevBuf filter_sort;         // mvs_filter_points, dense clouds: keys and a second copy of the upper lists for the global sorts
     double *filter_pinned = nullptr; // mvs_filter_points: pinned host slots for the convergence value of two iterations in flight
     hipEvent_t filter_ev[2] = {nullptr, nullptr};

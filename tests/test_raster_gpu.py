@@ -79,6 +79,35 @@ def test_random_triangle_soup_and_face_camera(oracle):
         np.testing.assert_array_equal(ctx.projected(cam, frame, prj), oracle.projected(soup, cam, frame, prj))
 
 
+def test_binned_rasteriser_on_a_large_mesh(oracle):
+    """meshes of >= 16384 faces are rasterised through 64x64-pixel face bins (per-bin lists + a shared list of large faces):
+    depth, projected and a camera ON the mesh (many faces across w = 0 -> the shared list) against the oracle, ragged size"""
+    W, H = 333, 211
+    verts, faces = scenes.heightfield_mesh(150)           # 44 402 faces
+    assert faces.shape[0] >= 16384
+    soup, ctx = _both(oracle, W, H, verts, faces)
+    sc = synth.Scene(freq_scale=0.2)
+    main_c, side_c = [0.02, -0.01, 0.0], [0.25, 0.1, 0.05]
+    cam, prj = synth.camera_at(main_c, W, H), synth.camera_at(side_c, W, H)
+    side_img = sc.render(side_c, W, H)
+    with ctx:
+        _assert_depth(ctx.depth(cam), oracle.depth(soup, cam, W, H))
+        np.testing.assert_array_equal(ctx.projected(cam, side_img, prj), oracle.projected(soup, cam, side_img, prj))
+        v = verts[faces[20000, 0], :3] / verts[faces[20000, 0], 3]
+        K = np.array([[0.5, 0, 0, 0], [0, 0.5, 0, 0], [0, 0, (0.001 + 10) / (10 - 0.001), 2 * 0.001 * 10 / (0.001 - 10)],
+                      [0, 0, 1, 0]], np.float64)
+        RT = np.eye(4)
+        RT[:3, 3] = -v
+        RT = np.array([[1, 0, 0, 0], [0, 0, -1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], np.float64) @ RT   # look along the surface
+        face_cam = (K @ RT).astype(np.float32)
+        d_ref = oracle.depth(soup, face_cam, W, H)
+        _assert_depth(ctx.depth(face_cam), d_ref)
+        assert (d_ref != 1.0).sum() > 100
+        rows = np.array([0, H // 2, H - 1], np.int32)
+        cols = np.array([0, W // 2, W - 1], np.int32)
+        np.testing.assert_array_equal(ctx.depth_probe(face_cam, rows, cols), d_ref[rows, cols])
+
+
 def test_empty_mesh_and_errors(oracle):
     W, H = 64, 48
     with mvs_amd.Context(W, H) as ctx:
