@@ -101,6 +101,14 @@ int bisect(const std::vector<float> &list, float choice)
     return (int)list.size();
 }
 
+// the same on a list the caller has verified to be non-decreasing: "first entry greater than choice" is std::upper_bound.
+// chooseCameras looks its F + 1-entry cumulative-area table up 200 times (F ~ 10^6 for the later iterations' Poisson meshes).
+int bisectSorted(const std::vector<float> &list, float choice)
+{
+    const auto it = std::upper_bound(list.begin(), list.end(), choice);
+    return it == list.end() ? (int)list.size() : (int)(it - list.begin()) - 1;
+}
+
 int myFind(const std::vector<numberedVector> &list, int index)
 {
     for (int i = 0; i < (int)list.size(); i++)
@@ -258,9 +266,10 @@ int Heuristic::chooseCameras(const Mesh mesh, const std::vector<Mat> cameras, co
     std::vector<Mat> centers;
     centers.reserve(cameras.size());
     for (const Mat &camera : cameras) centers.push_back(extractCameraCenter(camera));
+    const bool areasSorted = std::is_sorted(areaSum.begin(), areaSum.end());  // false only with NaN areas: then the linear walk
     for (int i = 0; i < shotCount; i++) {
         const float choice = rng.uniform() * totalArea;  // heuristic.cpp:450
-        int chosenIdx = bisect(areaSum, choice);
+        int chosenIdx = (areasSorted && choice == choice) ? bisectSorted(areaSum, choice) : bisect(areaSum, choice);
         chosenIdx = std::min(std::max(chosenIdx, 0), F - 1);
         const float far = 10;  // heuristic.cpp:454
         const Mat viewer = faceCamera(mesh, chosenIdx, far, focal, rng);
