@@ -8,8 +8,9 @@
 // What is replaced: cv::FileStorage by a reader for exactly that YAML subset (block maps / block sequences /
 // single-line flow sequences / `!!opencv-matrix` with rows, cols, dt, data); cv::VideoCapture by setFrame() or a
 // directory of binary PGM files `<clip path>.frames/%06d.pgm` (the clips are absent from the reference checkout:
-// .MISSING_LARGE_BLOBS); exit(1) by exceptions.  estimateExposure (configuration.cpp:270-426) is not on the hot
-// path and is not built; requesting it (-e) throws.
+// .MISSING_LARGE_BLOBS) or binary PPM files `%06d.ppm` for colour; exit(1) by exceptions.  estimateExposure
+// (configuration.cpp:270-426, option -e) is a one-time host stage over the sparse bundle points and runs here on the host
+// too, with the pseudo-inverse of each frame's n x 3 sample matrix taken through its 3 x 3 normal matrix.
 #include <getopt.h>
 
 #include <cmath>
@@ -174,7 +175,118 @@ bool readPgm(const std::string &path, int w, int h, Mat &out)
     return (bool)f;
 }
 
+// binary PPM (R G B per pixel) -> the B G R order cv::VideoCapture delivers
+bool readPpm(const std::string &path, int w, int h, Mat &out)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::string magic;
+    int pw = 0, ph = 0, maxv = 0;
+    f >> magic >> pw >> ph >> maxv;
+    f.get();
+    if (magic != "P6" || pw != w || ph != h || maxv != 255) throw std::runtime_error("frame " + path + ": expected binary PPM of the clip size");
+    out.create(h, w, mvs::U8C3);
+    f.read(reinterpret_cast<char *>(out.data), (std::streamsize)w * h * 3);
+    uint8_t *p = out.ptr<uint8_t>();
+    for (size_t i = 0; i < (size_t)w * h; i++) std::swap(p[3 * i], p[3 * i + 2]);
+    return (bool)f;
+}
+
+// cv::cvtColor(BGR2GRAY) for 8-bit images: fixed point, 14 fractional bits (OpenCV 3.x color.cpp: R 4899, G 9617, B 1868)
+Mat bgrToGray(const Mat &bgr)
+{
+    Mat g(bgr.rows, bgr.cols, mvs::U8C1);
+    const uint8_t *s = bgr.ptr<uint8_t>();
+    uint8_t *d = g.ptr<uint8_t>();
+    for (size_t i = 0; i < (size_t)bgr.rows * bgr.cols; i++)
+        d[i] = (uint8_t)((s[3 * i] * 1868 + s[3 * i + 1] * 9617 + s[3 * i + 2] * 4899 + (1 << 13)) >> 14);
+    return g;
+}
+
+// configuration.cpp:248-259: radial distortion applied to cartesian points (rows), z scaled along like the reference does
+void cameraToScreen(Mat points, const std::vector<float> &lensDistortion, float aspect)
+{
+    for (int i = 0; i < points.rows; i++) {
+        float *p = points.ptr<float>(i);
+        const float radSquared = (p[0] * p[0] + p[1] * p[1] * aspect * aspect) / 4;
+        const float k = 1 + radSquared * (lensDistortion[0] + radSquared * lensDistortion[1]);
+        for (int c = 0; c < points.cols; c++) p[c] *= k;
+    }
+}
+
+// least-squares solution of A x = b of minimal norm (A: n x m row-major, m <= 3): what validSamples[i].inv(DECOMP_SVD) * b
+// computes (configuration.cpp:389), through the eigen-decomposition of the m x m normal matrix (Jacobi); directions whose
+// eigenvalue is negligible are dropped, like the zero singular values of the pseudo-inverse
+void pinvSolve(const float *A, int n, int m, const float *b, float *x)
+{
+    double N[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, r[3] = {0, 0, 0}, V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int k = 0; k < n; k++)
+        for (int a = 0; a < m; a++) {
+            r[a] += (double)A[k * m + a] * b[k];
+            for (int c = 0; c < m; c++) N[a][c] += (double)A[k * m + a] * A[k * m + c];
+        }
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = 0;
+        for (int a = 0; a < m; a++)
+            for (int c = a + 1; c < m; c++) off += std::fabs(N[a][c]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < m; p++)
+            for (int q = p + 1; q < m; q++) {
+                if (N[p][q] == 0.0) continue;
+                const double theta = (N[q][q] - N[p][p]) / (2.0 * N[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < m; k++) {
+                    const double kp = N[k][p], kq = N[k][q];
+                    N[k][p] = c * kp - sn * kq;
+                    N[k][q] = sn * kp + c * kq;
+                }
+                for (int k = 0; k < m; k++) {
+                    const double pk = N[p][k], qk = N[q][k];
+                    N[p][k] = c * pk - sn * qk;
+                    N[q][k] = sn * pk + c * qk;
+                }
+                for (int k = 0; k < m; k++) {
+                    const double vp = V[k][p], vq = V[k][q];
+                    V[k][p] = c * vp - sn * vq;
+                    V[k][q] = sn * vp + c * vq;
+                }
+            }
+    }
+    double lmax = 0;
+    for (int a = 0; a < m; a++) lmax = std::max(lmax, std::fabs(N[a][a]));
+    double sol[3] = {0, 0, 0};
+    for (int e = 0; e < m; e++) {
+        if (!(N[e][e] > 1e-12 * lmax)) continue;
+        double proj = 0;
+        for (int a = 0; a < m; a++) proj += V[a][e] * r[a];
+        for (int a = 0; a < m; a++) sol[a] += V[a][e] * proj / N[e][e];
+    }
+    for (int a = 0; a < m; a++) x[a] = (float)sol[a];
+}
+
 }  // namespace
+
+// util.cpp:408-433: mean of the unclipped values (0 < v < 255) of one channel inside a disc; -1 when there is none
+float sampleImage(const Mat image, float radiusSquared, const float x, const float y, char channel)
+{
+    const int ch = image.channels();
+    float sum = 0.f;
+    int weightSum = 0;
+    const float radius = std::sqrt(radiusSquared);
+    for (int ny = (int)std::max(0.f, y - radius); ny < std::min(y + radius + 1, (float)image.rows); ny++) {
+        const uint8_t *row = image.ptr<uint8_t>(ny);
+        for (int nx = (int)std::max(0.f, x - radius); nx < std::min(x + radius + 1, (float)image.cols); nx++) {
+            const float dx = nx - x, dy = ny - y;
+            const uint8_t val = row[nx * ch + channel];
+            if (dx * dx + dy * dy <= radiusSquared && val > 0 && val < 255) {
+                sum += val;
+                weightSum += 1;
+            }
+        }
+    }
+    return weightSum > 0 ? sum / weightSum : -1.f;
+}
 
 void Configuration::parseYaml(const std::string &path)
 {
@@ -236,12 +348,171 @@ void Configuration::parseYaml(const std::string &path)
         if (!(nearVals[kv.first] > 0 && farVals[kv.first] > 0)) throw std::runtime_error("tracks YAML: near/far must be positive");
     }
     frames.assign(trackedFrameCount, Mat());
-    // frames: optional directory of PGMs next to the clip (stands in for cv::VideoCapture, configuration.cpp:169-238)
+    colorFrames.assign(trackedFrameCount, Mat());
+    // frames: optional directory of PGMs (grey) or PPMs (colour) next to the clip (stands in for cv::VideoCapture,
+    // configuration.cpp:169-238)
     for (int fi = 0; fi < trackedFrameCount; fi++) {
         char name[64];
         snprintf(name, sizeof(name), "/%06d.pgm", fi * (int)skipFrames + 1);
         Mat g;
-        if (readPgm(clipPath + ".frames" + name, width, height, g)) frames[fi] = g;
+        if (readPgm(clipPath + ".frames" + name, width, height, g)) {
+            frames[fi] = g;
+            continue;
+        }
+        snprintf(name, sizeof(name), "/%06d.ppm", fi * (int)skipFrames + 1);
+        if (readPpm(clipPath + ".frames" + name, width, height, g)) colorFrames[fi] = g;
+    }
+    colorFramesReady();
+}
+
+// configuration.cpp:240-245: colour frames become grey ones, either through the exposure estimate (needs all of them) or by
+// cvtColor(BGR2GRAY)
+void Configuration::colorFramesReady()
+{
+    if (doEstimateExposure) {
+        for (const Mat &c : colorFrames)
+            if (c.empty()) return;  // wait until every frame has been supplied
+        if (!colorFrames.empty()) estimateExposure();
+        return;
+    }
+    for (size_t i = 0; i < colorFrames.size(); i++)
+        if (!colorFrames[i].empty()) {
+            frames[i] = bgrToGray(colorFrames[i]);
+            colorFrames[i] = Mat();
+        }
+}
+
+// configuration.cpp:262-267
+const Mat Configuration::projectPoints(const int frameNo)
+{
+    Mat projected(bundles.rows, 4, mvs::F32C1);
+    const Mat cam = camera(frameNo);
+    for (int j = 0; j < bundles.rows; j++)
+        for (int r = 0; r < 4; r++) {
+            float s = 0.f;  // (camera * bundles.t()).t(): float accumulation like cv::gemm on CV_32F
+            for (int k = 0; k < 4; k++) s += cam.at<float>(r, k) * bundles.at<float>(j, k);
+            projected.at<float>(j, r) = s;
+        }
+    Mat cartesian = dehomogenize(projected);
+    cameraToScreen(cartesian, lensDistortion, (float)height / (float)width);
+    return cartesian;
+}
+
+// configuration.cpp:270-426
+void Configuration::estimateExposure()
+{
+    const int frameCount = (int)cameras.size(), pointCount = bundles.rows;
+    if (frameCount == 0 || (int)colorFrames.size() != frameCount) throw std::runtime_error("estimateExposure: colour frames missing");
+    const int ch = colorFrames[0].channels();
+    if (lensDistortion.size() < 2) throw std::runtime_error("estimateExposure: the tracks file gives no lens distortion");
+    std::vector<float> sampledColor;                     // rows of `ch` brightness values, one per valid (frame, point) sample
+    std::vector<int> sampleIds((size_t)frameCount * pointCount, -1);
+    std::vector<int> rowBegin(frameCount + 1, 0);
+    int rowId = 0;
+    for (int i = 0; i < frameCount; i++) {
+        const Mat &image = colorFrames[i];
+        if (image.empty() || image.channels() != ch) throw std::runtime_error("estimateExposure: colour frame " + std::to_string(i) + " missing");
+        const Mat reprojected = projectPoints(i);
+        rowBegin[i] = rowId;
+        for (int j = 0; j < pointCount; j++) {
+            if (!bundlesEnabled[j].count(i)) continue;
+            const float *re = reprojected.ptr<float>(j);
+            const float imageX = centerX + re[0] * width * 0.5f, imageY = height - centerY - re[1] * height * 0.5f;
+            float sc[4];
+            bool valid = true;
+            for (int c = 0; c < ch && valid; c++) {
+                sc[c] = sampleImage(image, 16, imageX, imageY, (char)c);
+                valid = sc[c] != -1;
+            }
+            if (!valid) continue;
+            sampledColor.insert(sampledColor.end(), sc, sc + ch);
+            sampleIds[(size_t)i * pointCount + j] = rowId++;
+        }
+        if (rowId - rowBegin[i] < ch)  // `assert(false)` in the reference (configuration.cpp:318-321)
+            throw std::runtime_error("estimateExposure: frame " + std::to_string(i) + " has fewer valid samples than colour channels");
+    }
+    rowBegin[frameCount] = rowId;
+
+    double sumBrightness = 0;
+    for (size_t k = 0; k < sampledColor.size(); k++) sumBrightness += sampledColor[k];
+    sumBrightness *= 1. / ch;
+
+    exposure.create(ch, frameCount, mvs::F32C1);
+    for (int c = 0; c < ch; c++)
+        for (int i = 0; i < frameCount; i++) exposure.at<float>(c, i) = 1.f / ch;
+    std::vector<float> pointBrightness(pointCount, 1.f), valid;
+    for (int iteration = 0; iteration < 100; iteration++) {
+        double error = 0, currentSumBrightness = 0;
+        for (int j = 0; j < pointCount; j++) {  // imagine that the exposure is correct
+            float sum = 0.f;
+            int weightSum = 0;
+            for (int i = 0; i < frameCount; i++) {
+                const int row = sampleIds[(size_t)i * pointCount + j];
+                if (row == -1) continue;
+                weightSum += 1;
+                for (int c = 0; c < ch; c++) sum += sampledColor[(size_t)row * ch + c] * exposure.at<float>(c, i);
+            }
+            currentSumBrightness += sum;
+            pointBrightness[j] = weightSum > 0 ? sum / weightSum : 0.f;
+        }
+        const float scale = (float)(sumBrightness / currentSumBrightness);  // back to the original scale
+        for (float &b : pointBrightness) b *= scale;
+        for (int i = 0; i < frameCount; i++) {  // imagine that the point brightness is correct
+            valid.clear();
+            for (int j = 0; j < pointCount; j++)
+                if (sampleIds[(size_t)i * pointCount + j] >= 0) valid.push_back(pointBrightness[j]);
+            const float *A = sampledColor.data() + (size_t)rowBegin[i] * ch;
+            const int n = rowBegin[i + 1] - rowBegin[i];
+            float x[3] = {0, 0, 0};
+            pinvSolve(A, n, ch, valid.data(), x);
+            const float omega = 0.4f;  // "strongly overrelax"
+            double norm2 = 0;
+            for (int c = 0; c < ch; c++) exposure.at<float>(c, i) = x[c] * (1 + omega) - exposure.at<float>(c, i) * omega;
+            for (int k = 0; k < n; k++) {
+                float fit = 0.f;
+                for (int c = 0; c < ch; c++) fit += A[(size_t)k * ch + c] * exposure.at<float>(c, i);
+                norm2 += (double)(fit - valid[k]) * (fit - valid[k]);
+            }
+            error += std::sqrt(norm2) / n;
+        }
+        if (error / frameCount < 0.1) break;
+    }
+    if (verbosity >= 3) {  // configuration.cpp:396-416
+        if (FILE *exlog = fopen("exposure.tab", "w+")) {
+            for (int i = 0; i < frameCount; i++) {
+                double stddev = 0;
+                int weightSum = 0;
+                for (int j = 0; j < pointCount; j++) {
+                    const int row = sampleIds[(size_t)i * pointCount + j];
+                    if (row == -1) continue;
+                    for (int c = 0; c < ch; c++) {
+                        const float d = sampledColor[(size_t)row * ch + c] - exposure.at<float>(c, i) * pointBrightness[j];
+                        stddev += d * d;
+                        weightSum += 1;
+                    }
+                }
+                for (int c = 0; c < 3; c++) fprintf(exlog, "%f\t", c < ch ? exposure.at<float>(c, i) : 0.f);
+                fprintf(exlog, "%f\n", std::sqrt(stddev / weightSum));
+            }
+            fclose(exlog);
+        }
+    }
+    // normalise the frames: frames[i] = sum_c channel_c * exposure[c][i], each step saturate_cast<uchar>(cvRound(.)) like
+    // `frames[i] += channels[c] * exposure` on a CV_8U matrix (configuration.cpp:418-425)
+    for (int i = 0; i < frameCount; i++) {
+        Mat g(height, width, mvs::U8C1);
+        const uint8_t *s = colorFrames[i].ptr<uint8_t>();
+        uint8_t *d = g.ptr<uint8_t>();
+        for (size_t p = 0; p < (size_t)width * height; p++) {
+            int acc = 0;
+            for (int c = 0; c < ch; c++) {
+                const long v = std::lrint((double)((float)s[p * ch + c] * exposure.at<float>(c, i) + (float)acc));
+                acc = (int)std::min(255l, std::max(0l, v));
+            }
+            d[p] = (uint8_t)acc;
+        }
+        frames[i] = g;
+        colorFrames[i] = Mat();
     }
 }
 
@@ -289,7 +560,6 @@ Configuration::Configuration(int argc, char **argv)
     }
     if (optind < argc) inFileName = argv[optind];  // configuration.cpp:129-131
     if (!inFileName) throw std::runtime_error("No configuration YAML file given");
-    if (doEstimateExposure) throw std::runtime_error("--estimate-exposure is not part of the MI355X hot path build");
     parseYaml(inFileName);
 }
 
@@ -304,6 +574,13 @@ const Mat Configuration::frame(int frameNo) const
 
 const Mat Configuration::camera(int frameNo) const { return cameras.at(frameNo); }
 const std::vector<Mat> Configuration::allCameras() const { return cameras; }
+
+void Configuration::setFrameColor(int frameNo, const Mat bgr)
+{
+    if (bgr.type() != mvs::U8C3 || bgr.cols != width || bgr.rows != height) throw std::runtime_error("setFrameColor: frame must be H x W x 3 u8 of the clip size");
+    colorFrames.at(frameNo) = bgr;
+    colorFramesReady();
+}
 
 void Configuration::setFrame(int frameNo, const Mat gray)
 {

@@ -50,6 +50,7 @@ Mat compare(const Mat prev, const Mat next);               // util.cpp:332-361
 Mat dehomogenize(Mat points);                              // util.cpp:16-29
 Mat mixBackground(const Mat image, const Mat background, Mat &depth);  // util.cpp:366-387 (mutates depth)
 Mat flowRemap(const Mat flow, const Mat image);            // util.cpp:390-403
+float sampleImage(const Mat image, float radiusSquared, const float x, const float y, char c);  // util.cpp:408-433 (recon.hpp:47)
 
 // == configuration (configuration.cpp) ==
 class Configuration {
@@ -64,6 +65,11 @@ public:
     float farVal(int frameNo) const { return farVals.at(frameNo); }
     int frameCount() const { return (int)cameras.size(); }
     void setFrame(int frameNo, const Mat gray); // supplies a decoded frame (replaces cv::VideoCapture)
+    void setFrameColor(int frameNo, const Mat bgr); // the same for a colour frame (H x W x 3 u8, B G R): converted like
+                                               // cvtColor(BGR2GRAY) (configuration.cpp:244) unless doEstimateExposure is set
+    void estimateExposure();                   // configuration.cpp:270-426; runs by itself once every colour frame is present
+    const Mat projectPoints(int frameNo);      // configuration.cpp:262-267
+    Mat exposure;                              // channels x frames, filled by estimateExposure (the reference keeps it local)
     int iterationCount = 2;        // configuration.cpp:28
     char verbosity = 0;
     bool useFarneback = false;     // configuration.cpp:26
@@ -82,6 +88,8 @@ public:
 protected:
     void parseYaml(const std::string &path);
     std::vector<Mat> frames;
+    std::vector<Mat> colorFrames;  // kept until the exposure estimate has turned them into `frames`
+    void colorFramesReady();
     std::vector<Mat> cameras;
     std::vector<float> nearVals, farVals;
     Mat bundles;

@@ -3,6 +3,8 @@
 //   host_selftest gpu <tracks dir> <out dir>  spawnRender -> loadMesh -> depth/projected -> mixBackground ->
 //                                             compare/flowRemap, chooseCameras; raw outputs for the oracle check
 #include <chrono>
+#include <getopt.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -58,6 +60,19 @@ static int run_cpu(const std::string &tracks)
     for (int i = 0; i < 4; i++) {
         const float u = rng.uniform();
         CHECK(std::fabs(u - expect[i]) < 1e-7f, "rng[%d] = %.9g, expected %.9g", i, u, expect[i]);
+    }
+    {
+        // a colour frame without -e goes through cvtColor(BGR2GRAY) (configuration.cpp:244): OpenCV's 8-bit fixed-point weights
+        // give 29 / 150 / 76 for pure blue / green / red and leave greys unchanged
+        Configuration c(tracks + "/koule-tr.yaml");
+        Mat bgr = Mat::zeros(c.height, c.width, mvs::U8C3);
+        const uint8_t px[4][3] = {{255, 0, 0}, {0, 255, 0}, {0, 0, 255}, {200, 200, 200}};
+        for (int k = 0; k < 4; k++)
+            for (int ch = 0; ch < 3; ch++) bgr.at<uint8_t>(0, 3 * k + ch) = px[k][ch];
+        c.setFrameColor(0, bgr);
+        const Mat g = c.frame(0);
+        CHECK(g.at<uint8_t>(0, 0) == 29 && g.at<uint8_t>(0, 1) == 150 && g.at<uint8_t>(0, 2) == 76 && g.at<uint8_t>(0, 3) == 200,
+              "BGR2GRAY gave %d %d %d %d", g.at<uint8_t>(0, 0), g.at<uint8_t>(0, 1), g.at<uint8_t>(0, 2), g.at<uint8_t>(0, 3));
     }
     // YAML reader on the four bundled calibration files
     struct { const char *name; int w, h, frames, bundles; } files[] = {
@@ -237,15 +252,38 @@ static int run_gpu(const std::string &tracks, const std::string &out)
     return fails ? 1 : 0;
 }
 
+// `-e`: Configuration::estimateExposure on the colour frames found next to the clip (<clip>.frames/%06d.ppm); dumps the
+// exposure matrix (channels x frames, f32) and the normalised grey frames for tests/test_host_cpu.py
+static int run_exposure(const std::string &yaml, const std::string &out)
+{
+    std::string a0 = "recon", a1 = "-e", a2 = yaml;
+    char *argv[] = {&a0[0], &a1[0], &a2[0], nullptr};
+    optind = 1;
+    Configuration config(3, argv);
+    if (config.exposure.empty()) {
+        printf("exposure selftest: the colour frames are incomplete, nothing estimated\n");
+        return 1;
+    }
+    writeRaw(out + "/exposure.f32", config.exposure);
+    for (int i = 0; i < config.frameCount(); i++) {
+        char name[64];
+        snprintf(name, sizeof(name), "/gray_%03d.u8", i);
+        writeRaw(out + name, config.frame(i));
+    }
+    printf("exposure selftest: %d channels x %d frames\n", config.exposure.rows, config.exposure.cols);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
+        if (argc >= 4 && !strcmp(argv[1], "exposure")) return run_exposure(argv[2], argv[3]);
         if (argc >= 3 && !strcmp(argv[1], "cpu")) return run_cpu(argv[2]);
         if (argc >= 4 && !strcmp(argv[1], "gpu")) return run_gpu(argv[2], argv[3]);
     } catch (const std::exception &e) {
         printf("exception: %s\n", e.what());
         return 2;
     }
-    printf("usage: host_selftest cpu <tracks dir> | gpu <tracks dir> <out dir>\n");
+    printf("usage: host_selftest cpu <tracks dir> | gpu <tracks dir> <out dir> | exposure <tracks yaml> <out dir>\n");
     return 64;
 }
