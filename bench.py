@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--fused", action="store_true", help="also time the no-volume variant (depth only)")
     ap.add_argument("--separate-argmin", action="store_true",
                     help="single GPU: run argmin_volume as its own pass over the volume (the multi-GPU views pipeline)")
+    ap.add_argument("--collective", default="allreduce", choices=["allreduce", "reduce_scatter"],
+                    help="views sharding: all-reduce the whole volume, or reduce-scatter it by planes, select a partial best per rank "
+                         "and all-gather the 8-byte partials (half the bytes over xGMI; needs planes divisible by the rank count)")
     ap.add_argument("--plane-groups", type=int, default=4,
                     help="views sharding: all-reduce the volume in this many plane groups, overlapped with the sweep")
     ap.add_argument("--no-extras", action="store_true",
@@ -262,8 +265,30 @@ def main():
         band_cat = torch.empty((world * tallest, W), dtype=torch.float32, device="cuda")   # concatenated form: every backend
         band_all = band_cat.view(world, tallest, W)
 
+    rs = args.shard == "views" and world > 1 and args.collective == "reduce_scatter"
+    if rs:
+        if D % world:
+            raise SystemExit("--collective reduce_scatter needs the plane count (%d) divisible by the ranks (%d)" % (D, world))
+        slice_planes = D // world
+        slice_t = torch.empty(slice_planes * P, dtype=torch.int32, device="cuda")
+        part_t = torch.empty(P, dtype=torch.int64, device="cuda")
+        parts_t = torch.empty(world * P, dtype=torch.int64, device="cuda")
+
     def step():
-        if args.shard == "views" and world > 1:
+        if rs:
+            # every rank sweeps its views over all planes; the volume is reduce-scattered by plane slices (rank r receives the
+            # summed cells of planes [r D/G, (r+1) D/G)), each rank selects a partial best over its slice, the 8-byte partials are
+            # all-gathered and merged in plane order -- the same depth map as all-reduce + argmin, with half the bytes on the links
+            ctx.sweep_run(v0, vn, mvs_amd.MVS_SWEEP_VOLUME)
+            if same_device:   # gloo has no reduce-scatter: emulate it (test hook only)
+                dist.all_reduce(vol_t)
+                slice_t.copy_(vol_t[rank * slice_planes * P:(rank + 1) * slice_planes * P])
+            else:
+                dist.reduce_scatter_tensor(slice_t, vol_t)
+            ctx.sweep_argmin_partial(slice_t.data_ptr(), rank * slice_planes, slice_planes, part_t.data_ptr())
+            dist.all_gather_into_tensor(parts_t, part_t)
+            ctx.sweep_combine_partials(parts_t.data_ptr(), world)
+        elif args.shard == "views" and world > 1:
             # sweep plane group g on the compute stream while group g-1 is summed over xGMI on the comm stream
             # (RCCL, exact: packed integer cells); depth selection waits for the last group
             works = []
@@ -379,7 +404,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic (%s)" % args.data + (" [TEST HOOK: ranks share one GPU over gloo -- not a measurement]" if same_device else ""),
             "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V),
-                       "shard": args.shard, "views_per_rank": vn,
+                       "shard": args.shard, "collective": args.collective if args.shard == "views" else None, "views_per_rank": vn,
                        "rows_per_rank": [n for _, n in bands] if args.shard == "rows" else None, "device": ctx.info()},
             "roofline": {"bound": "hbm", "kernel": "sweep_tiled", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

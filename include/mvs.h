@@ -149,6 +149,14 @@ int mvs_sweep_plan_shape(const mvs_ctx *ctx);
 /* per-pixel depth selection over the packed volume (async); valid after MVS_SWEEP_VOLUME runs or
  * after the caller has reduced the volume across ranks in place */
 int mvs_sweep_argmin(mvs_ctx *ctx);
+/* The same selection in two steps, for a view-sharded job that REDUCE-SCATTERS the packed volume instead of all-reducing it
+ * (half the bytes over xGMI): rank r owns the summed cells of planes [plane_first, plane_first + plane_count) in
+ * `volume_slice_dev` ([plane_count][H][W] u32) and selects a partial best per pixel over them -- `partial_out_dev` receives
+ * H*W records of 8 bytes (packed best cell, best absolute plane index; 0xffffffff = none).  The ranks all-gather their
+ * records into [nparts][H*W] in ascending plane order and every rank merges them with mvs_sweep_combine_partials, a later part
+ * winning only if strictly better (ties -> lowest plane, like mvs_sweep_argmin).  Both are asynchronous on the context's stream. */
+int mvs_sweep_argmin_partial(mvs_ctx *ctx, const void *volume_slice_dev, int plane_first, int plane_count, void *partial_out_dev);
+int mvs_sweep_combine_partials(mvs_ctx *ctx, const void *partials_dev, int nparts);
 /* device pointer + size of the packed volume: nplanes*H*W uint32 cells (count << 16 | sum of abs
  * differences); sums and counts add exactly, so an integer sum-all-reduce across view shards is
  * bit-identical to the single-GPU result */

@@ -707,10 +707,13 @@ __global__ __launch_bounds__(256) void combine_best(SweepParams p, int nsplit, s
 // ------------------------------------------------------------------------------------------------------
 // Layout [D][P] keeps a pixel on a lane, so the reduction over planes runs in registers; each thread
 // streams 16-byte loads of 4 consecutive pixels per plane (P % 4 == 0) or single cells otherwise.
+// part != nullptr: `vol` holds planes [d_first, d_first + D) only (the slice a rank owns after a reduce-scatter) and the result
+// is the partial selection (best packed cell, best ABSOLUTE plane index) per pixel, to be merged by combine_best
 template <int VEC>
 __global__ __launch_bounds__(256) void argmin_volume(const uint32_t *__restrict__ vol, size_t P, int D,
                                                      const float *__restrict__ z, float *__restrict__ depth,
-                                                     float *__restrict__ cost, int *__restrict__ index)
+                                                     float *__restrict__ cost, int *__restrict__ index,
+                                                     uint2 *__restrict__ part = nullptr, int d_first = 0)
 {
     const size_t base = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (base >= P) return;
@@ -747,6 +750,12 @@ __global__ __launch_bounds__(256) void argmin_volume(const uint32_t *__restrict_
     for (; d < D; d++) {
 #pragma unroll
         for (int i = 0; i < VEC; i++) argmin_update(vol[(size_t)d * P + base + i], d, bs[i], bc[i], bi[i]);
+    }
+    if (part) {
+#pragma unroll
+        for (int i = 0; i < VEC; i++)
+            part[base + i] = bi[i] >= 0 ? make_uint2((bc[i] << 16) | bs[i], (uint32_t)(bi[i] + d_first)) : make_uint2(0u, 0xffffffffu);
+        return;
     }
 #pragma unroll
     for (int i = 0; i < VEC; i++) {
@@ -1059,6 +1068,42 @@ int mvs_sweep_argmin(mvs_ctx *ctx)
             ctx->volume, P, ctx->D, (const float *)ctx->ztab.ptr, (float *)ctx->depth.ptr, (float *)ctx->cost.ptr,
             (int *)ctx->index.ptr);
     }
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+int mvs_sweep_argmin_partial(mvs_ctx *ctx, const void *volume_slice_dev, int plane_first, int plane_count, void *partial_out_dev)
+{
+    if (!ctx || !volume_slice_dev || !partial_out_dev) return fail(ctx, MVS_EINVAL, "mvs_sweep_argmin_partial: null argument");
+    if (!ctx->have_planes) return fail(ctx, MVS_ESTATE, "mvs_sweep_argmin_partial: set the planes first");
+    if (plane_first < 0 || plane_count <= 0 || plane_first + plane_count > ctx->D)
+        return fail(ctx, MVS_EINVAL, "mvs_sweep_argmin_partial: planes [%d,%d) outside 0..%d", plane_first, plane_first + plane_count, ctx->D);
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->W * ctx->H;
+    ProfileScope ps(ctx, MVS_K_ARGMIN);
+    if (P % 4 == 0 && ((uintptr_t)volume_slice_dev % 16) == 0)
+        argmin_volume<4><<<(unsigned)((P / 4 + 255) / 256), 256, 0, ctx->stream>>>((const uint32_t *)volume_slice_dev, P, plane_count, nullptr, nullptr,
+                                                                                 nullptr, nullptr, (uint2 *)partial_out_dev, plane_first);
+    else
+        argmin_volume<1><<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>((const uint32_t *)volume_slice_dev, P, plane_count, nullptr, nullptr,
+                                                                              nullptr, nullptr, (uint2 *)partial_out_dev, plane_first);
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+int mvs_sweep_combine_partials(mvs_ctx *ctx, const void *partials_dev, int nparts)
+{
+    if (!ctx || !partials_dev || nparts <= 0) return fail(ctx, MVS_EINVAL, "mvs_sweep_combine_partials: bad argument");
+    if (!ctx->have_planes) return fail(ctx, MVS_ESTATE, "mvs_sweep_combine_partials: set the planes first");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_outputs(ctx, false);
+    if (rc) return rc;
+    SweepParams p;
+    fill_params(ctx, p, 0, 0, 16, 16);
+    p.part = (uint2 *)partials_dev;  // read-only here
+    const size_t P = (size_t)ctx->W * ctx->H;
+    ProfileScope ps(ctx, MVS_K_ARGMIN);
+    combine_best<<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(p, nparts, 0, P);
     MVS_HIP(ctx, hipGetLastError());
     return MVS_OK;
 }

@@ -54,6 +54,8 @@ ABI = [
     ("mvs_sweep_row_granularity", _i, []),
     ("mvs_sweep_plan_shape", _i, [_vp]),
     ("mvs_sweep_argmin", _i, [_vp]),
+    ("mvs_sweep_argmin_partial", _i, [_vp, _vp, _i, _i, _vp]),
+    ("mvs_sweep_combine_partials", _i, [_vp, _vp, _i]),
     ("mvs_sweep_volume_device", _vp, [_vp, C.POINTER(_sz)]),
     ("mvs_sweep_use_volume", _i, [_vp, _vp, _sz]),
     ("mvs_sweep_depth_device", _vp, [_vp]),
@@ -239,6 +241,13 @@ class Context:
 
     def sweep_argmin(self):
         self._check(self.lib.mvs_sweep_argmin(self.h))
+
+    def sweep_argmin_partial(self, volume_slice_ptr, plane_first, plane_count, partial_out_ptr):
+        self._check(self.lib.mvs_sweep_argmin_partial(self.h, C.c_void_p(volume_slice_ptr), int(plane_first), int(plane_count),
+                                                      C.c_void_p(partial_out_ptr)))
+
+    def sweep_combine_partials(self, partials_ptr, nparts):
+        self._check(self.lib.mvs_sweep_combine_partials(self.h, C.c_void_p(partials_ptr), int(nparts)))
 
     def sweep_volume_device(self):
         n = _sz(0)

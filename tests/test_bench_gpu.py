@@ -40,6 +40,8 @@ def test_bench_line_contract_and_two_rank_shardings():
     assert single["n_gpus"] == 1 and single["vs_baseline"] is None and single["depth_check"] is True
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in single["roofline"], key
+    rs = _bench(["--shard", "views", "--collective", "reduce_scatter"], 2)   # partial selection per plane slice + merge
+    assert rs["depth_crc32"] == single["depth_crc32"] and rs["config"]["collective"] == "reduce_scatter"
     for shard, scaling in (("views", "strong"), ("rows", "strong"), ("frames", "weak")):
         two = _bench(["--shard", shard], 2)
         assert two["n_gpus"] == 2 and two["scaling"] == scaling and two["depth_check"] is True

@@ -328,6 +328,44 @@ def test_plane_groups_reproduce_the_full_volume():
     assert mdist.plane_groups(7, 4, 16) == [(0, 7)]
 
 
+def test_partial_selection_and_merge_equal_the_one_step_argmin():
+    """mvs_sweep_argmin_partial over plane slices + mvs_sweep_combine_partials == mvs_sweep_argmin (the reduce-scatter form of the
+    view-sharded pipeline: a rank selects over the planes it owns, the 8-byte partials are merged in ascending plane order);
+    ties included (flat frames: every plane ties, the lowest must win), parts of unequal size"""
+    import torch
+    W, H, D, V = 320, 160, 40, 3
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
+    flat = np.full((H, W), 90, np.uint8)
+    P = W * H
+    for img, sd in ((main_img, sides), (flat, [flat] * V)):
+        with mvs_amd.Context(W, H) as ctx:
+            # torch fills / frees on ITS stream, the library works on its own: allocate without a fill and synchronise before
+            # handing the buffers over (bench.py shares one explicit stream instead)
+            vol_t = torch.empty(D * P, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            ctx.sweep_use_volume(vol_t.data_ptr(), vol_t.numel() * 4)
+            ctx.sweep_set(main_cam, img, side_cams, sd, D)
+            ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
+            ctx.sweep_argmin()
+            d0, c0, i0, _ = [a.copy() if a is not None else None for a in ctx.sweep_fetch()]
+            for nparts in (1, 2, 3, 8):
+                bounds = [round(k * D / nparts) for k in range(nparts + 1)]
+                parts_t = torch.empty(nparts * P, dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()
+                ctx.sweep_run(0, 0, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)            # poison depth / cost / index
+                for k in range(nparts):
+                    a, b = bounds[k], bounds[k + 1]
+                    ctx.sweep_argmin_partial(vol_t.data_ptr() + 4 * a * P, a, b - a, parts_t.data_ptr() + 8 * k * P)
+                ctx.sweep_combine_partials(parts_t.data_ptr(), nparts)
+                d, c, i, _ = ctx.sweep_fetch()                                  # synchronises the library's stream
+                np.testing.assert_array_equal(i, i0)
+                np.testing.assert_array_equal(d, d0)
+                np.testing.assert_array_equal(c, c0)
+            with pytest.raises(mvs_amd.MvsError):
+                ctx.sweep_argmin_partial(vol_t.data_ptr(), 30, 20, parts_t.data_ptr())   # planes 30..50 of 40
+            ctx.sweep_use_volume(0, 0)
+
+
 def test_row_bands_reproduce_the_full_result():
     """mvs_sweep_run_rows over the bands of mdist.row_bands == one full run, for the volume and the fused depth selection,
     tiled and generic kernels; rows outside a band are not touched (bench.py --shard rows)"""
