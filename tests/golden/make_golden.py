@@ -24,6 +24,65 @@ def main():
                         side_cams=side_cams, side_imgs=np.stack(sides), D=D, depth=depth, cost=cost, idx=idx, vol=vol,
                         gt=gt)
     print("wrote sweep_small.npz", depth.shape, vol.shape)
+    stage_small(o)
+
+
+def _crc(a):
+    import zlib
+    return np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+def stage_inputs():
+    """the reference's per-frame stage (recon.cpp:65-117) at 96x64 with two side views: deterministic inputs"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenes
+    W, H = 96, 64
+    verts, faces = scenes.heightfield_mesh(24, extent=1.4)
+    sc = synth.Scene(freq_scale=0.2)
+    main_c, side_cs = [0.0, 0.0, 0.0], [[0.15, 0.0, 0.0], [-0.1, 0.12, 0.03]]
+    main = synth.camera_at(main_c, W, H)
+    sides = np.stack([synth.camera_at(c, W, H) for c in side_cs])
+    return W, H, verts, faces, main, sides, sc.render(main_c, W, H), [sc.render(c, W, H) for c in side_cs]
+
+
+def stage_outputs(o):
+    W, H, verts, faces, main, sides, main_img, side_imgs = stage_inputs()
+    soup = o.load_mesh(verts, faces)
+    out = {}
+    d = o.depth(soup, main, W, H)
+    out["depth"] = d.copy()
+    flows = []
+    for k, (cam, img) in enumerate(zip(sides, side_imgs)):
+        proj = o.projected(soup, main, img, cam)
+        mixed, d = o.mix_background(proj, main_img, d)
+        out["projected%d_crc" % k] = _crc(proj)
+        out["mixed%d" % k] = mixed.copy()
+        fv = o.calculate_flow(main_img, mixed, False)
+        ff = o.calculate_flow(main_img, mixed, True)
+        # large float maps: a checksum of every bit plus a 1-in-16 probe (enough to see WHERE a drift starts)
+        for name, arr in (("compare", o.compare(main_img, mixed)), ("flow_var", fv), ("flow_fb", ff)):
+            out["%s%d_crc" % (name, k)] = _crc(arr)
+            out["%s%d_probe" % (name, k)] = arr[::4, ::4].copy()
+        out["remap%d" % k] = o.flow_remap(fv, mixed)
+        flows.append(fv)
+    out["depth_after"] = d.copy()
+    pts = o.triangulate_pixels(flows, main, sides, d)
+    out["points_n"] = np.int32(pts.shape[0])
+    out["points_xyzw_crc"] = _crc(pts[:, :4])
+    out["points_probe"] = pts[::16].copy()
+    cloud = pts[:, :4].copy()
+    cloud = cloud[np.isfinite(cloud).all(1)]
+    keep, _ = o.filter_points(cloud, 0.02)
+    out["filter_keep_crc"] = _crc(np.asarray(keep, np.int32))
+    out["filter_keep_n"] = np.int32(len(keep))
+    out["filter_n"] = np.int32(cloud.shape[0])
+    return out
+
+
+def stage_small(o):
+    out = stage_outputs(o)
+    np.savez_compressed(os.path.join(HERE, "stage_small.npz"), **out)
+    print("wrote stage_small.npz", {k: getattr(v, "shape", ()) for k, v in out.items()})
 
 
 if __name__ == "__main__":

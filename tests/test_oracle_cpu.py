@@ -140,3 +140,25 @@ def test_golden_sweep_fixture(oracle):
     np.testing.assert_array_equal(idx, g["idx"])
     np.testing.assert_array_equal(depth, g["depth"])
     np.testing.assert_array_equal(vol, g["vol"])
+
+
+def test_golden_stage_fixture(oracle):
+    """the reference's per-frame stage at 96x64 (raster, mixBackground, compare, flowRemap, both flows, triangulatePixels,
+    filterPoints) against the committed vectors: pins every oracle module against silent drift.  Integer / byte / f32 outputs
+    of the fixed-order C code must reproduce exactly; the triangulation's pdf-scaled normals go through exp / pow of libm and
+    get a last-ulp tolerance."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_golden
+    g = np.load(os.path.join(GOLDEN, "stage_small.npz"))
+    out = make_golden.stage_outputs(oracle)
+    assert set(out) == set(g.files)
+    for k in g.files:
+        if k == "points_probe":      # positions exact; pdf-scaled normals within a last-ulp tolerance
+            assert out[k].shape == g[k].shape
+            np.testing.assert_array_equal(out[k][:, :4], g[k][:, :4])
+            ok = np.isfinite(g[k][:, 4:]).all(1)
+            np.testing.assert_allclose(out[k][ok, 4:], g[k][ok, 4:], rtol=1e-5, atol=1e-9)
+        else:
+            np.testing.assert_array_equal(out[k], g[k], err_msg=k)
+    assert int(g["points_n"]) > 1000 and 0 < int(g["filter_keep_n"]) < int(g["filter_n"])

@@ -105,3 +105,47 @@ def test_process_frame_side_view_counts(nside):
             pts, depth_after = ctx.process_frame(main, main_img, sides, side_imgs, False, want_depth=True)
             np.testing.assert_array_equal(depth_after, depth)
             np.testing.assert_array_equal(pts, ref)
+
+
+def test_stage_matches_the_committed_golden_vectors():
+    """every stage of the reference's per-frame path, HIP through the C ABI, against tests/golden/stage_small.npz (written by the
+    oracle via tests/golden/make_golden.py and committed): no oracle runs here, so HIP and oracle cannot drift together unnoticed"""
+    import os
+    import sys
+    import zlib
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, golden)
+    import make_golden
+    g = np.load(os.path.join(golden, "stage_small.npz"))
+    W, H, verts, faces, main, sides, main_img, side_imgs = make_golden.stage_inputs()
+
+    def crc(a):
+        return np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.load_mesh(verts, faces)
+        d = ctx.depth(main)
+        np.testing.assert_array_equal(d, g["depth"])
+        flows = []
+        for k, (cam, img) in enumerate(zip(sides, side_imgs)):
+            proj = ctx.projected(main, img, cam)
+            assert crc(proj) == g["projected%d_crc" % k]
+            mixed, d = ctx.mix_background(proj, main_img, d)
+            np.testing.assert_array_equal(mixed, g["mixed%d" % k])
+            fv, ff = ctx.flow(main_img, mixed, False), ctx.flow(main_img, mixed, True)
+            for name, arr in (("compare", ctx.compare(main_img, mixed)), ("flow_var", fv), ("flow_fb", ff)):
+                np.testing.assert_array_equal(arr[::4, ::4], g["%s%d_probe" % (name, k)], err_msg=name)
+                assert crc(arr) == g["%s%d_crc" % (name, k)], name
+            np.testing.assert_array_equal(ctx.flow_remap(fv, mixed), g["remap%d" % k])
+            flows.append(fv)
+        np.testing.assert_array_equal(d, g["depth_after"])
+        pts = ctx.triangulate(flows, main, sides, d)
+        assert pts.shape[0] == int(g["points_n"]) and crc(pts[:, :4]) == g["points_xyzw_crc"]
+        probe = pts[::16]
+        ok = np.isfinite(g["points_probe"][:, 4:]).all(1)
+        np.testing.assert_allclose(probe[ok, 4:], g["points_probe"][ok, 4:], rtol=1e-5, atol=1e-9)
+        cloud = pts[:, :4][np.isfinite(pts[:, :4]).all(1)]
+        keep = ctx.filter_points(cloud, 0.02)
+        assert cloud.shape[0] == int(g["filter_n"]) and len(keep) == int(g["filter_keep_n"]) and crc(np.asarray(keep, np.int32)) == g["filter_keep_crc"]
+        # and the one-call form of the same stage
+        one = ctx.process_frame(main, main_img, sides, side_imgs, False)
+        assert one.shape[0] == int(g["points_n"]) and crc(one[:, :4]) == g["points_xyzw_crc"]
