@@ -121,6 +121,21 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
 int mvs_warp_by_depth(mvs_ctx *ctx, const float main_cam[16], const float *depth_hw, const float side_cam[16],
                       const uint8_t *frame_hw, uint8_t *out_hw2);
 
+/* Texture-fetch arithmetic of the sweep.  The reference leaves this to the OpenGL driver (GL_LINEAR on a
+ * GL_RED8 texture, render_glx.cpp:75-85, read back as RGB8, :359), which pins neither sub-texel precision nor weight width.
+ *   MVS_SAMPLER_FIXED (default): positions quantised to 1/32 texel and 8-bit weights from a 32 x 32 table -- the model of
+ *     fixed-function samplers and of OpenCV's fixed-point remap (INTER_BITS = 5, the path of the reference's flowRemap,
+ *     util.cpp:401); the warped intensity keeps the table's precision and a packed cell is count << 24 | sum |w.t - 255 I_main|
+ *     (sums in 1/255 grey levels; at most 255 views).  About half the instructions per sample on gfx950.
+ *   MVS_SAMPLER_EXACT_F32: bilinear interpolation in f32 with one rounding per operation, result rounded to u8 like the RGB8
+ *     read-back; a packed cell is count << 16 | sum |u8 - I_main| (at most 257 views).
+ * Both are restated bit for bit by the CPU oracle; they select the same plane except where two planes' costs are within the
+ * quantisation step (measured: DESIGN.md).  Changing the sampler invalidates the region plan, not the uploaded inputs. */
+#define MVS_SAMPLER_FIXED 0
+#define MVS_SAMPLER_EXACT_F32 1
+int mvs_sweep_set_sampler(mvs_ctx *ctx, int sampler);
+int mvs_sweep_sampler(const mvs_ctx *ctx);
+
 /* Staged form: inputs stay resident in HBM between runs (bench, multi-GPU view sharding). */
 int mvs_sweep_set_main(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw);
 int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames);
@@ -143,8 +158,9 @@ int mvs_sweep_plane_granularity(void);
 int mvs_sweep_run_rows(mvs_ctx *ctx, int view_first, int view_count, int row_first, int row_count, unsigned flags);
 int mvs_sweep_row_granularity(void);
 /* diagnostic: thread shape the region planner chose for the current (views, planes): 0 = no plan yet,
- * 1 = 2 pixels x 32 planes per thread (64x8-pixel tiles), 2 = 4 pixels x 16 planes (64x16 tiles).  Results are
- * bit-identical either way; the choice follows how many warped 32-plane footprints fit the LDS staging buffer. */
+ * 1 = exact sampler, 2 pixels x 32 planes per thread (64x8-pixel tiles), 2 = exact sampler, 4 pixels x 16 planes (64x16 tiles:
+ * bit-identical to 1; the choice follows how many warped 32-plane footprints fit the LDS staging buffer), 3 = fixed sampler
+ * (2 pixels x 32 planes, 64x8-pixel tiles). */
 int mvs_sweep_plan_shape(const mvs_ctx *ctx);
 /* per-pixel depth selection over the packed volume (async); valid after MVS_SWEEP_VOLUME runs or
  * after the caller has reduced the volume across ranks in place */
@@ -157,9 +173,9 @@ int mvs_sweep_argmin(mvs_ctx *ctx);
  * winning only if strictly better (ties -> lowest plane, like mvs_sweep_argmin).  Both are asynchronous on the context's stream. */
 int mvs_sweep_argmin_partial(mvs_ctx *ctx, const void *volume_slice_dev, int plane_first, int plane_count, void *partial_out_dev);
 int mvs_sweep_combine_partials(mvs_ctx *ctx, const void *partials_dev, int nparts);
-/* device pointer + size of the packed volume: nplanes*H*W uint32 cells (count << 16 | sum of abs
- * differences); sums and counts add exactly, so an integer sum-all-reduce across view shards is
- * bit-identical to the single-GPU result */
+/* device pointer + size of the packed volume: nplanes*H*W uint32 cells (count << 24 | sum with the fixed sampler,
+ * count << 16 | sum with the exact one); sums and counts add exactly, so an integer sum-all-reduce across view
+ * shards is bit-identical to the single-GPU result */
 void *mvs_sweep_volume_device(mvs_ctx *ctx, size_t *bytes);
 /* make the sweep write into caller-owned device memory (e.g. a torch tensor handed to RCCL) */
 int mvs_sweep_use_volume(mvs_ctx *ctx, void *device_ptr, size_t bytes);

@@ -142,10 +142,13 @@ void mvs_destroy(mvs_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream && ctx->own_stream != ctx->stream) (void)hipStreamSynchronize(ctx->own_stream);
+    for (auto &lane : ctx->lanes)  // before any buffer is freed: a lane may still read frame_buf or its arena
+        if (lane.stream) (void)hipStreamSynchronize(lane.stream);
     DevBuf *bufs[] = {&ctx->main_img, &ctx->side_pads, &ctx->qmats, &ctx->ztab, &ctx->plan, &ctx->upload,
                       &ctx->volume_own, &ctx->depth, &ctx->cost, &ctx->index, &ctx->soup, &ctx->r_zbuf,
                       &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2,
-                      &ctx->cubic_tab, &ctx->flow_arena, &ctx->frame_buf, &ctx->best_parts, &ctx->plan_stats, &ctx->probe_buf, &ctx->filter_sort, &ctx->raster_bins};
+                      &ctx->cubic_tab, &ctx->flow_arena, &ctx->frame_buf, &ctx->best_parts, &ctx->plan_stats, &ctx->probe_buf, &ctx->filter_sort, &ctx->raster_bins, &ctx->fx_lut};
     for (int i = 0; i < 2; i++)
         if (ctx->flow_graph[i]) (void)hipGraphExecDestroy(ctx->flow_graph[i]);
     for (DevBuf *b : bufs)

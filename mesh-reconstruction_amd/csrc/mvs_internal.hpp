@@ -51,7 +51,9 @@ struct mvs_ctx {
     float main_cam[16] = {0};
     bool have_main = false, have_views = false, have_planes = false;
     bool plan_valid = false;         // region plan matches current (views, planes)
-    int plan_shape = 2;              // thread shape the plan was made for: 1 = 2 px x 32 planes, 2 = 4 px x 16 planes
+    int sampler = MVS_SAMPLER_FIXED;  // arithmetic contract of the sweep's texture fetch (mvs_sweep_set_sampler)
+    mvs::DevBuf fx_lut;              // fixed sampler: 32 x 32 table of packed 8-bit bilinear weights
+    int plan_shape = 2;              // what the plan was made for: 1 = exact sampler, 2 px x 32 planes; 2 = exact, 4 px x 16 planes; 3 = fixed sampler
     bool plan_forced = false;        // plan made with the 4 x 16 shape forced (timing experiments)
     mvs::DevBuf plan_stats;          // planner counters (oversize regions, regions not skipped)
     mvs::DevBuf probe_buf;           // mvs_depth_probe: pixel coordinates in, depths out

@@ -68,6 +68,23 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
         ~LaneScope() { swap(); }
     };
 
+    // Any early return below leaves kernels and host-to-device copies of the caller's frames in flight on the main stream
+    // and on the lanes: the guard joins them all first, so neither the caller's buffers nor this context's arenas (which a
+    // later ensure() or mvs_destroy may free) are still in use when an error is reported.
+    struct JoinOnError {
+        mvs_ctx *c;
+        hipStream_t st;
+        int nlanes;
+        bool armed = true;
+        ~JoinOnError()
+        {
+            if (!armed) return;
+            (void)hipStreamSynchronize(st);
+            for (int l = 0; l < nlanes; l++)
+                if (c->lanes[l].stream) (void)hipStreamSynchronize(c->lanes[l].stream);
+        }
+    } join{ctx, st, nlanes};
+
     MVS_HIP(ctx, hipMemcpyAsync(d_main, main_frame_hw, P, hipMemcpyHostToDevice, st));
     if ((rc = depth_device(ctx, main_cam, d_depth))) return rc;  // recon.cpp:70
     std::vector<const float *> flow_ptrs((size_t)(nside > 0 ? nside : 1), nullptr);
@@ -96,7 +113,9 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     }
     for (int i = 0; i < nside && nlanes > 0; i++) MVS_HIP(ctx, hipStreamWaitEvent(st, ctx->lane_events[2 * i + 1], 0));
     if (depth_after_hw) MVS_HIP(ctx, hipMemcpyAsync(depth_after_hw, d_depth, sizeof(float) * P, hipMemcpyDeviceToHost, st));
-    return triangulate_impl(ctx, nside, flow_ptrs.data(), true, main_cam, side_cams, d_depth, out_points7, out_count);  // :114
+    rc = triangulate_impl(ctx, nside, flow_ptrs.data(), true, main_cam, side_cams, d_depth, out_points7, out_count);  // :114
+    if (rc == MVS_OK) join.armed = false;  // triangulate_impl synchronised the main stream, which had joined every lane
+    return rc;
 }
 
 }  // extern "C"

@@ -21,78 +21,9 @@
 //   sweep_tiled       LDS-staged side-image tiles; 64x8-pixel tiles x 32 planes or 64x16 x 16 planes per chunk
 //   sweep_generic     no tiling, global gathers; any geometry; also the in-kernel fallback
 //   argmin_volume     depth selection over the packed volume (after an optional cross-rank reduction)
-#include "mvs_internal.hpp"
+#include "sweep_shared.hpp"
 
 namespace mvs {
-
-typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-
-constexpr int TILE_W = 64;   // one wavefront spans a tile row
-// sweep_tiled is instantiated for two thread shapes with 64 accumulators each (NPX pixels x PC planes per thread, tile
-// height 4 * NPX): 2 x 32 amortises the per-(pixel, view) set-up and the staged texels over twice as many planes
-// (c3: 2.20 -> 2.09 ms) but needs the warped footprint of 32 consecutive planes to fit the LDS region; 4 x 16 is the
-// fallback when the planner reports oversize regions (wide baselines with few planes).  Chosen per plan, see sweep_run_impl.
-constexpr int PCG = 16;          // planes per accumulator batch of the un-tiled generic kernel
-constexpr int ROW_GRAN = 16;     // public row granularity: a multiple of both tile heights
-constexpr int PLANE_GRAN = 32;   // public plane granularity: a multiple of both chunk sizes
-constexpr int LDS_QUADS = 5120;  // 40 KiB of 8-byte quads per staging buffer
-constexpr int MAX_RW = 192;
-constexpr float PLAN_MARGIN = 0.0625f;
-
-enum RegionMode : unsigned { R_SKIP = 0, R_FAST = 1, R_BORDER = 2, R_GENERIC = 3 };
-
-struct SweepParams {
-    const uint8_t *__restrict__ main_img;
-    const uint8_t *__restrict__ pads;
-    size_t pad_slab;
-    int pitch;
-    int W, H, D, V;
-    int v0, vcount;
-    const float *__restrict__ Q;  // V * 12
-    const float *__restrict__ z;  // D
-    uint32_t *__restrict__ volume;
-    float *__restrict__ depth;
-    float *__restrict__ cost;
-    int *__restrict__ index;
-    float invW, invH;
-    float Wp, Hp;  // W + 0.5, H + 0.5
-    const uint2 *__restrict__ plan;
-    int tiles_x, tiles_y, nchunks;
-    int chunk0, chunk1;  // plane chunks [chunk0, chunk1) processed by this launch
-    int ty0, tyn;        // tile rows [ty0, ty0 + tyn) processed by this launch (row-band sharding)
-    int tile_h, pc;      // shape of the tiled kernel this plan was made for (tile height, planes per chunk)
-    int row_begin, row_end, plane_begin, plane_end;  // the same ranges in pixels / planes (generic kernel)
-    int *__restrict__ plan_stats;  // [0] regions too large for LDS, [1] regions not skipped (planner output)
-    int cps;             // plane chunks per workgroup: blockIdx.y selects chunks [chunk0 + y*cps, +cps) of a tile
-    uint2 *__restrict__ part;  // plane-split launches with fused depth selection: [gridDim.y][P] partial bests
-    int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: linear tile order; bit 2: never use the plane-independent-w path)
-};
-
-// ------------------------------------------------------------------------------------------------------
-// shared sample arithmetic
-// ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float rcp_rn(float w)
-{
-    // v_rcp_f32 is accurate to 1 ulp; one Newton step with FMA yields the correctly rounded
-    // reciprocal (Markstein) for every w whose significand is not all ones -- verified
-    // exhaustively on the device by tests/test_sweep_gpu.py::test_rcp_newton_exact.
-    const float r0 = __builtin_amdgcn_rcpf(w);
-    const float e = __builtin_fmaf(-w, r0, 1.0f);
-    return __builtin_fmaf(e, r0, r0);
-}
-
-struct Affine {
-    float ax, ay, aw;
-};
-
-__device__ __forceinline__ Affine view_affine(const float *__restrict__ q, float xn, float yn)
-{
-    Affine a;
-    a.ax = __builtin_fmaf(q[0], xn, __builtin_fmaf(q[1], yn, q[3]));
-    a.ay = __builtin_fmaf(q[4], xn, __builtin_fmaf(q[5], yn, q[7]));
-    a.aw = __builtin_fmaf(q[8], xn, __builtin_fmaf(q[9], yn, q[11]));
-    return a;
-}
 
 // t00h = t00 + 0.5 (exact): the rounding bias of the u8 conversion rides on the first term
 __device__ __forceinline__ int bilerp_u8(float ax, float ay, float t00h, float dxt, float dy, float dxy)
@@ -122,32 +53,6 @@ __device__ __forceinline__ uint32_t sample_global(const Affine &A, float bx, flo
     const float dxt = t01 - t00, dy = t10 - t00, dxy = (t11 - t10) - dxt;
     const int Iq = bilerp_u8(fx, fy, t00 + 0.5f, dxt, dy, dxy);
     return 65536u + (uint32_t)__builtin_abs(Iq - Im);
-}
-
-// running best plane: s/c < bs/bc  <=>  s*bc < bs*c, all factors < 2^16 (exact in u32)
-__device__ __forceinline__ void argmin_update(uint32_t cell, int d, uint32_t &bs, uint32_t &bc, int &bi)
-{
-    const uint32_t s = cell & 0xffffu, c = cell >> 16;
-    const bool better = (c != 0u) && (bi < 0 || __umul24(s, bc) < __umul24(bs, c));
-    bs = better ? s : bs;
-    bc = better ? c : bc;
-    bi = better ? d : bi;
-}
-
-// the same with the best (count, sum) kept as one packed cell: two registers of state per pixel
-__device__ __forceinline__ void argmin_update_packed(uint32_t cell, int d, uint32_t &best, int &bi)
-{
-    const uint32_t s = cell & 0xffffu, c = cell >> 16, bs = best & 0xffffu, bc = best >> 16;
-    const bool better = (c != 0u) && (bi < 0 || __umul24(s, bc) < __umul24(bs, c));
-    best = better ? cell : best;
-    bi = better ? d : bi;
-}
-
-__device__ __forceinline__ void store_best(const SweepParams &p, size_t pix, uint32_t bs, uint32_t bc, int bi)
-{
-    p.depth[pix] = bi >= 0 ? p.z[bi] : MVS_BACKGROUND_DEPTH;
-    p.cost[pix] = bi >= 0 ? (float)bs / (float)bc : __builtin_inff();
-    p.index[pix] = bi;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -337,12 +242,6 @@ __device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t acc
     return d;
 }
 
-// wave-uniform value -> SGPR
-__device__ __forceinline__ float uniform_f(float x)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
-}
-
 // Branch-free LDS sample.  FAST: the planner proved every sample of this (tile, chunk, view) in
 // frame, so no test is evaluated.  Otherwise the test of shader.frag:19 is evaluated per sample and
 // the texel address is clamped into the staged region before the (then discarded) fetch.
@@ -486,24 +385,6 @@ __device__ __forceinline__ void sample_chunk_pipelined(const Affine &A, float bx
         acc[k] = sad_u32((uint32_t)(int)res.x, Im, acc[k]);
         acc[k + 1] = sad_u32((uint32_t)(int)res.y, Im, acc[k + 1]);
     }
-}
-
-// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD, MI355X_MICROARCH.md), each with
-// its own 4 MiB L2.  Tiles are grouped 2 wide x 4 tall (128 x 64 pixels); the 8 tiles of a group get block ids
-// with equal (id % 8), so a group's overlapping side-image regions share one L2, and consecutive groups go to
-// consecutive XCDs, so border tiles (which take the slower per-sample-test path) spread evenly over the chip
-// (a contiguous band per XCD cut HBM fetches 3.2x but ran 5 % slower: profiles/r01).  Bijective onto the padded
-// group grid; ids that fall outside the image exit.  Placement affects speed and traffic only.
-constexpr int GROUP_W = 2, GROUP_H = 4;
-
-__device__ __forceinline__ int grouped_tile(int bid, int tiles_x, int tiles_y)
-{
-    const int gx = (tiles_x + GROUP_W - 1) / GROUP_W;
-    const int sb = bid >> 6, x = bid & 7, m = (bid >> 3) & 7;
-    const int g = sb * 8 + x;
-    const int tx = (g % gx) * GROUP_W + (m & (GROUP_W - 1));
-    const int ty = (g / gx) * GROUP_H + (m >> 1);
-    return (tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : -1;
 }
 
 // 3 workgroups per CU (<= 168 VGPRs): 2 per CU measured 9 % slower (not enough waves to cover the two barriers per
@@ -688,6 +569,7 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
 
 // merge of the partial bests of a plane-split launch: splits are in ascending plane order and a later split wins only
 // if strictly better, so ties still go to the lowest plane
+template <int CS>
 __global__ __launch_bounds__(256) void combine_best(SweepParams p, int nsplit, size_t pix_first, size_t pix_count)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -697,9 +579,9 @@ __global__ __launch_bounds__(256) void combine_best(SweepParams p, int nsplit, s
     int bi = -1;
     for (int s = 0; s < nsplit; s++) {
         const uint2 st = p.part[(size_t)s * P + pix];
-        argmin_update_packed(st.x, (int)st.y, best, bi);
+        argmin_update_packed<CS>(st.x, (int)st.y, best, bi);
     }
-    store_best(p, pix, best & 0xffffu, best >> 16, bi);
+    store_best<CS>(p, pix, best & ((1u << CS) - 1u), best >> CS, bi);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -709,7 +591,7 @@ __global__ __launch_bounds__(256) void combine_best(SweepParams p, int nsplit, s
 // streams 16-byte loads of 4 consecutive pixels per plane (P % 4 == 0) or single cells otherwise.
 // part != nullptr: `vol` holds planes [d_first, d_first + D) only (the slice a rank owns after a reduce-scatter) and the result
 // is the partial selection (best packed cell, best ABSOLUTE plane index) per pixel, to be merged by combine_best
-template <int VEC>
+template <int VEC, int CS>
 __global__ __launch_bounds__(256) void argmin_volume(const uint32_t *__restrict__ vol, size_t P, int D,
                                                      const float *__restrict__ z, float *__restrict__ depth,
                                                      float *__restrict__ cost, int *__restrict__ index,
@@ -745,22 +627,22 @@ __global__ __launch_bounds__(256) void argmin_volume(const uint32_t *__restrict_
 #pragma unroll
         for (int u = 0; u < UNR; u++)
 #pragma unroll
-            for (int i = 0; i < VEC; i++) argmin_update(c[u][i], d + u, bs[i], bc[i], bi[i]);
+            for (int i = 0; i < VEC; i++) argmin_update<CS>(c[u][i], d + u, bs[i], bc[i], bi[i]);
     }
     for (; d < D; d++) {
 #pragma unroll
-        for (int i = 0; i < VEC; i++) argmin_update(vol[(size_t)d * P + base + i], d, bs[i], bc[i], bi[i]);
+        for (int i = 0; i < VEC; i++) argmin_update<CS>(vol[(size_t)d * P + base + i], d, bs[i], bc[i], bi[i]);
     }
     if (part) {
 #pragma unroll
         for (int i = 0; i < VEC; i++)
-            part[base + i] = bi[i] >= 0 ? make_uint2((bc[i] << 16) | bs[i], (uint32_t)(bi[i] + d_first)) : make_uint2(0u, 0xffffffffu);
+            part[base + i] = bi[i] >= 0 ? make_uint2((bc[i] << CS) | bs[i], (uint32_t)(bi[i] + d_first)) : make_uint2(0u, 0xffffffffu);
         return;
     }
 #pragma unroll
     for (int i = 0; i < VEC; i++) {
         depth[base + i] = bi[i] >= 0 ? z[bi[i]] : MVS_BACKGROUND_DEPTH;
-        cost[base + i] = bi[i] >= 0 ? (float)bs[i] / (float)bc[i] : __builtin_inff();
+        cost[base + i] = bi[i] >= 0 ? cell_cost<CS>(bs[i], bc[i]) : __builtin_inff();
         index[base + i] = bi[i];
     }
 }
@@ -786,13 +668,14 @@ __global__ __launch_bounds__(256) void warp_by_depth_kernel(const float *__restr
     out2[2 * pix + 1] = cell ? 255 : 0;
 }
 
+template <int CS>
 __global__ void unpack_volume(const uint32_t *__restrict__ vol, float *__restrict__ out, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t cell = vol[i];
-    const uint32_t s = cell & 0xffffu, c = cell >> 16;
-    out[i] = c ? (float)s / (float)c : __builtin_inff();
+    const uint32_t s = cell & ((1u << CS) - 1u), c = cell >> CS;
+    out[i] = c ? cell_cost<CS>(s, c) : __builtin_inff();
 }
 
 // exhaustive self-check helper for the reciprocal (tests): out[0] counts w where rcp_rn(w) != 1.0f/w
@@ -809,51 +692,13 @@ __global__ void rcp_check_kernel(uint32_t exp_bits, unsigned long long *out)
     }
 }
 
+// sweep_fx.hip: the fixed-point sampler (contract v2)
+int sweep_fx_plan(mvs_ctx *ctx);
+int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool generic, unsigned flags);
+int warp_by_depth_fx_launch(mvs_ctx *ctx, const float *depth_dev, const float *q_dev, const uint8_t *pad_dev, int pitch, uint8_t *out2_dev);
+
 // defined in context.hip
 __global__ void pad_wrap_kernel(const uint8_t *__restrict__ img, uint8_t *__restrict__ pad, int W, int H, int pitch);
-
-static int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount, int tile_h, int pc)
-{
-    p.main_img = (const uint8_t *)ctx->main_img.ptr;
-    p.pads = (const uint8_t *)ctx->side_pads.ptr;
-    p.pad_slab = ctx->pad_slab;
-    p.pitch = ctx->pad_pitch;
-    p.W = ctx->W;
-    p.H = ctx->H;
-    p.D = ctx->D;
-    p.V = ctx->V;
-    p.v0 = v0;
-    p.vcount = vcount;
-    p.Q = (const float *)ctx->qmats.ptr;
-    p.z = (const float *)ctx->ztab.ptr;
-    p.volume = ctx->volume;
-    p.depth = (float *)ctx->depth.ptr;
-    p.cost = (float *)ctx->cost.ptr;
-    p.index = (int *)ctx->index.ptr;
-    p.invW = 1.0f / (float)ctx->W;
-    p.invH = 1.0f / (float)ctx->H;
-    p.Wp = (float)ctx->W + 0.5f;
-    p.Hp = (float)ctx->H + 0.5f;
-    p.plan = (const uint2 *)ctx->plan.ptr;
-    p.tiles_x = div_up(ctx->W, TILE_W);
-    p.tile_h = tile_h;
-    p.pc = pc;
-    p.tiles_y = div_up(ctx->H, tile_h);
-    p.nchunks = div_up(ctx->D, pc);
-    p.chunk0 = 0;
-    p.chunk1 = p.nchunks;
-    p.ty0 = 0;
-    p.tyn = p.tiles_y;
-    p.row_begin = 0;
-    p.row_end = ctx->H;
-    p.plane_begin = 0;
-    p.plane_end = ctx->D;
-    p.cps = p.nchunks;
-    p.part = nullptr;
-    p.plan_stats = nullptr;
-    p.debug = 0;
-    return MVS_OK;
-}
 
 }  // namespace mvs
 
@@ -919,6 +764,20 @@ int mvs_sweep_run_rows(mvs_ctx *ctx, int view_first, int view_count, int row_fir
 
 int mvs_sweep_row_granularity(void) { return ROW_GRAN; }
 
+int mvs_sweep_set_sampler(mvs_ctx *ctx, int sampler)
+{
+    if (!ctx) return MVS_EINVAL;
+    if (sampler != MVS_SAMPLER_FIXED && sampler != MVS_SAMPLER_EXACT_F32) return fail(ctx, MVS_EINVAL, "mvs_sweep_set_sampler: unknown sampler %d", sampler);
+    if (sampler != ctx->sampler) {
+        MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // queued kernels read the plan of the old sampler
+        ctx->sampler = sampler;
+        ctx->plan_valid = false;
+    }
+    return MVS_OK;
+}
+
+int mvs_sweep_sampler(const mvs_ctx *ctx) { return ctx ? ctx->sampler : MVS_EINVAL; }
+
 int mvs_sweep_plan_shape(const mvs_ctx *ctx) { return (ctx && ctx->plan_valid) ? ctx->plan_shape : 0; }
 
 int mvs_sweep_run_planes(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, unsigned flags)
@@ -952,7 +811,40 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
 
     const bool generic = (flags & MVS_SWEEP_FORCE_GENERIC) != 0;
     const int debug = (int)((flags >> 8) & 0xff);  // undocumented timing-experiment bits (bit 3: never use the 2 x 32 shape)
-    if (row_count <= 0) return MVS_OK;              // empty band: nothing to compute
+    if (row_count <= 0 || plane_count <= 0) return MVS_OK;  // empty band or empty plane group: nothing to compute
+
+    if (ctx->sampler == MVS_SAMPLER_FIXED) {
+        if (ctx->V > 255) return fail(ctx, MVS_EINVAL, "mvs_sweep_run: the fixed sampler's cells hold at most 255 views (have %d)", ctx->V);
+        if (ctx->plan_valid && ctx->plan_shape != 3) ctx->plan_valid = false;
+        if (!generic && !ctx->plan_valid && ctx->V > 0) {
+            ProfileScope ps(ctx, MVS_K_PLAN);
+            if ((rc = sweep_fx_plan(ctx))) return rc;
+            ctx->plan_shape = 3;
+            ctx->plan_valid = true;
+        }
+        SweepParams p;
+        fill_params(ctx, p, view_first, view_count, 8, 16);
+        p.debug = debug;
+        p.chunk0 = plane_first / 16;
+        p.chunk1 = div_up(plane_first + plane_count, 16);
+        p.ty0 = row_first / 8;
+        p.tyn = div_up(row_first + row_count, 8) - p.ty0;
+        p.row_begin = row_first;
+        p.row_end = min(ctx->H, row_first + row_count);
+        p.plane_begin = plane_first;
+        p.plane_end = min(ctx->D, plane_first + plane_count);
+        ProfileScope ps(ctx, MVS_K_SWEEP);
+        const int nsplit = sweep_fx_launch(ctx, p, vol, fused, generic, flags);
+        if (nsplit < 0) return nsplit;
+        if (p.part) {
+            const size_t first = (size_t)p.row_begin * ctx->W;
+            const size_t count = (size_t)(p.row_end - p.row_begin) * ctx->W;
+            combine_best<CS_FIXED><<<(unsigned)((count + 255) / 256), 256, 0, ctx->stream>>>(p, nsplit, first, count);
+            MVS_HIP(ctx, hipGetLastError());
+        }
+        return MVS_OK;
+    }
+    if (ctx->plan_valid && ctx->plan_shape == 3) ctx->plan_valid = false;  // the plan in memory belongs to the fixed sampler
 
     // thread shape of the tiled kernel (see the constants at the top): 2 pixels x 32 planes unless the planner finds
     // that more than 2 % of the regions a 32-plane chunk touches do not fit the LDS staging buffer
@@ -1040,12 +932,29 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
             if (p.part) {
                 const size_t first = (size_t)p.row_begin * ctx->W;
                 const size_t count = (size_t)(p.row_end - p.row_begin) * ctx->W;
-                combine_best<<<(unsigned)((count + 255) / 256), 256, 0, ctx->stream>>>(p, nsplit, first, count);
+                combine_best<CS_EXACT><<<(unsigned)((count + 255) / 256), 256, 0, ctx->stream>>>(p, nsplit, first, count);
             }
         }
         MVS_HIP(ctx, hipGetLastError());
     }
     return MVS_OK;
+}
+
+// depth selection over `vol` with the cell layout of the context's sampler; 16-byte loads when the pixel count and the pointer allow
+static void launch_argmin(mvs_ctx *ctx, const uint32_t *vol, size_t P, int D, const float *z, float *depth, float *cost, int *index, uint2 *part,
+                          int d_first)
+{
+    const bool wide = P % 4 == 0 && ((uintptr_t)vol % 16) == 0;
+    const unsigned blocks = (unsigned)(((wide ? P / 4 : P) + 255) / 256);
+    const bool fx = ctx->sampler == MVS_SAMPLER_FIXED;
+    if (wide && fx)
+        argmin_volume<4, CS_FIXED><<<blocks, 256, 0, ctx->stream>>>(vol, P, D, z, depth, cost, index, part, d_first);
+    else if (wide)
+        argmin_volume<4, CS_EXACT><<<blocks, 256, 0, ctx->stream>>>(vol, P, D, z, depth, cost, index, part, d_first);
+    else if (fx)
+        argmin_volume<1, CS_FIXED><<<blocks, 256, 0, ctx->stream>>>(vol, P, D, z, depth, cost, index, part, d_first);
+    else
+        argmin_volume<1, CS_EXACT><<<blocks, 256, 0, ctx->stream>>>(vol, P, D, z, depth, cost, index, part, d_first);
 }
 
 int mvs_sweep_argmin(mvs_ctx *ctx)
@@ -1058,16 +967,8 @@ int mvs_sweep_argmin(mvs_ctx *ctx)
     if (rc) return rc;
     const size_t P = (size_t)ctx->W * ctx->H;
     ProfileScope ps(ctx, MVS_K_ARGMIN);
-    if (P % 4 == 0 && ((uintptr_t)ctx->volume % 16) == 0) {
-        const size_t threads = P / 4;
-        argmin_volume<4><<<(unsigned)((threads + 255) / 256), 256, 0, ctx->stream>>>(
-            ctx->volume, P, ctx->D, (const float *)ctx->ztab.ptr, (float *)ctx->depth.ptr, (float *)ctx->cost.ptr,
-            (int *)ctx->index.ptr);
-    } else {
-        argmin_volume<1><<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(
-            ctx->volume, P, ctx->D, (const float *)ctx->ztab.ptr, (float *)ctx->depth.ptr, (float *)ctx->cost.ptr,
-            (int *)ctx->index.ptr);
-    }
+    launch_argmin(ctx, ctx->volume, P, ctx->D, (const float *)ctx->ztab.ptr, (float *)ctx->depth.ptr, (float *)ctx->cost.ptr, (int *)ctx->index.ptr,
+                  nullptr, 0);
     MVS_HIP(ctx, hipGetLastError());
     return MVS_OK;
 }
@@ -1081,12 +982,7 @@ int mvs_sweep_argmin_partial(mvs_ctx *ctx, const void *volume_slice_dev, int pla
     MVS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)ctx->W * ctx->H;
     ProfileScope ps(ctx, MVS_K_ARGMIN);
-    if (P % 4 == 0 && ((uintptr_t)volume_slice_dev % 16) == 0)
-        argmin_volume<4><<<(unsigned)((P / 4 + 255) / 256), 256, 0, ctx->stream>>>((const uint32_t *)volume_slice_dev, P, plane_count, nullptr, nullptr,
-                                                                                 nullptr, nullptr, (uint2 *)partial_out_dev, plane_first);
-    else
-        argmin_volume<1><<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>((const uint32_t *)volume_slice_dev, P, plane_count, nullptr, nullptr,
-                                                                              nullptr, nullptr, (uint2 *)partial_out_dev, plane_first);
+    launch_argmin(ctx, (const uint32_t *)volume_slice_dev, P, plane_count, nullptr, nullptr, nullptr, nullptr, (uint2 *)partial_out_dev, plane_first);
     MVS_HIP(ctx, hipGetLastError());
     return MVS_OK;
 }
@@ -1103,7 +999,10 @@ int mvs_sweep_combine_partials(mvs_ctx *ctx, const void *partials_dev, int npart
     p.part = (uint2 *)partials_dev;  // read-only here
     const size_t P = (size_t)ctx->W * ctx->H;
     ProfileScope ps(ctx, MVS_K_ARGMIN);
-    combine_best<<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(p, nparts, 0, P);
+    if (ctx->sampler == MVS_SAMPLER_FIXED)
+        combine_best<CS_FIXED><<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(p, nparts, 0, P);
+    else
+        combine_best<CS_EXACT><<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(p, nparts, 0, P);
     MVS_HIP(ctx, hipGetLastError());
     return MVS_OK;
 }
@@ -1154,7 +1053,10 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
     if (volume_dhw) {
         const size_t n = (size_t)ctx->W * ctx->H * (size_t)nplanes;
         if ((rc = ensure(ctx, ctx->r_tmp0, n * sizeof(float)))) return rc;
-        unpack_volume<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(ctx->volume, (float *)ctx->r_tmp0.ptr, n);
+        if (ctx->sampler == MVS_SAMPLER_FIXED)
+            unpack_volume<CS_FIXED><<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(ctx->volume, (float *)ctx->r_tmp0.ptr, n);
+        else
+            unpack_volume<CS_EXACT><<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(ctx->volume, (float *)ctx->r_tmp0.ptr, n);
         MVS_HIP(ctx, hipGetLastError());
         MVS_HIP(ctx, hipMemcpyAsync(volume_dhw, ctx->r_tmp0.ptr, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1183,9 +1085,15 @@ int mvs_warp_by_depth(mvs_ctx *ctx, const float main_cam[16], const float *depth
     MVS_HIP(ctx, hipMemcpyAsync(ctx->r_zbuf.ptr, depth_hw, P * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     pad_wrap_kernel<<<dim3(div_up(pitch, 256), H + 2), 256, 0, ctx->stream>>>((const uint8_t *)ctx->upload.ptr,
                                                                               (uint8_t *)ctx->r_frame.ptr, W, H, pitch);
-    warp_by_depth_kernel<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, ctx->stream>>>(
-        (const float *)ctx->r_zbuf.ptr, (const float *)ctx->r_tmp0.ptr, (const uint8_t *)ctx->r_frame.ptr, pitch, W, H,
-        1.0f / (float)W, 1.0f / (float)H, (uint8_t *)ctx->r_out3.ptr);
+    if (ctx->sampler == MVS_SAMPLER_FIXED) {
+        if ((rc = warp_by_depth_fx_launch(ctx, (const float *)ctx->r_zbuf.ptr, (const float *)ctx->r_tmp0.ptr, (const uint8_t *)ctx->r_frame.ptr, pitch,
+                                          (uint8_t *)ctx->r_out3.ptr)))
+            return rc;
+    } else {
+        warp_by_depth_kernel<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, ctx->stream>>>(
+            (const float *)ctx->r_zbuf.ptr, (const float *)ctx->r_tmp0.ptr, (const uint8_t *)ctx->r_frame.ptr, pitch, W, H,
+            1.0f / (float)W, 1.0f / (float)H, (uint8_t *)ctx->r_out3.ptr);
+    }
     MVS_HIP(ctx, hipGetLastError());
     MVS_HIP(ctx, hipMemcpyAsync(out_hw2, ctx->r_out3.ptr, 2 * P, hipMemcpyDeviceToHost, ctx->stream));
     MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -1,0 +1,578 @@
+// sweep_fx.hip -- plane-sweep cost volume + depth selection with the FIXED-POINT sampler (arithmetic contract v2) for gfx950.
+//
+// Same warp as sweep.hip (the D-plane evaluation of shader.frag:11-25); the texture unit is modelled
+// the way fixed-function samplers and OpenCV's own fixed-point remap (INTER_BITS = 5: the path the reference's flowRemap takes
+// through cv::remap, util.cpp:401) work: positions quantised to 1/32 texel, bilinear weights from a 32 x 32 table of 8-bit
+// integers that sum to 255.  Identical in oracle/sweep_oracle.c (orc_sweep_fx); DESIGN.md section 2b:
+//   s, r   as in contract v1:  s = fma(z, B, A),  r = RN(1 / s.w)  (v_rcp_f32 + one FMA Newton step)
+//   u      = RNE(s.xy * (256 r) + 4)        one rounding of the real product, done by an FMA whose addend is 1.5 * 2^23 + 4
+//   in frame <=> s.w > 0 and 132 < ux < 256 W + 132 and 132 < uy < 256 H + 132
+//   i, k   = u >> 8, (u >> 3) & 31
+//   dot    = table[ky][kx] . (t00, t01, t10, t11)                                  v_dot4_u32_u8, in [0, 65025]
+//   cell  += (1 << 24) + |dot - 255 I_main|                                         v_sad_u16; integer, order independent
+// Why: the exact-f32 sampler costs ~50 VALU cycles per sample on gfx950 (4 conversions, 2 fract, 2 address ops, 2 v_fma_mix, cvt,
+// v_sad_u32 at 4 cycles each on top of the projection); here a sample is 4 FMAs + v_perm_b32 + 2 shifts + 2 ands + v_dot4 +
+// v_sad_u16 = ~28 cycles, and the two LDS reads (weights, texel quad) hide behind it at 4 waves per SIMD
+// (tools/sweep_v2_probe.hip, profiles/r02/probe_*.txt).
+//
+// LDS image of a workgroup (32 KiB): 32 rows of 1 KiB.  Row r = [ weight table row ky = r : 32 dwords | 224 texel quads of region row r ].
+// A quad is the four u8 texels (t00, t01, t10, t11) of one bilinear footprint, so the fetch is one ds_read_b32.  With
+// P = v_perm_b32(Ty, Tx) = [iy : ix : fy8 : fx8] both addresses are a shift and a mask away:
+//   weights  (P >> 1) & 0x7c7c = ky << 10 | kx << 2          quad  ((P >> 14) & 0x7ffc) + 128 = iy << 10 | ix << 2 (+ 128)
+#include "sweep_shared.hpp"
+
+namespace mvs {
+
+constexpr int FX_ROWS = 32;       // region rows (and weight-table rows) per LDS image
+constexpr int FX_ROW_DW = 256;    // dwords per LDS row
+constexpr int FX_LUT_DW = 32;     // of which the first 32 hold the weight-table row
+constexpr int FX_MAX_RW = FX_ROW_DW - FX_LUT_DW;  // 224 quads
+constexpr float FX_MAGIC = 12582912.0f;            // 1.5 * 2^23: floats in [2^23, 2^24) have ulp 1
+constexpr int FX_TILE_H = 8, FX_PC = 16, FX_NPX = 2;  // 64x8-pixel tiles, 16 planes per chunk: 32 accumulators per thread
+constexpr int FX_GS = 8;          // samples per software-pipeline group
+constexpr int FX_WG_PER_CU = 4;   // launch bound (waves per SIMD): 128 VGPRs, 36 KiB of LDS
+
+enum FxMode : unsigned { FX_SKIP = 0, FX_FAST = 1, FX_BORDER = 2, FX_GENERIC = 3 };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc + |a.lo16 - b.lo16| + |a.hi16 - b.hi16| (v_sad_u16).  Through the builtin, NOT inline asm: the first operand comes straight
+// from v_dot4_u32_u8, and on gfx950 a VALU instruction that overwrites a dot instruction's destination needs wait states that
+// the compiler inserts only for instructions it can see -- with inline asm the sums came out wrong (and differently per run).
+__device__ __forceinline__ uint32_t sad_u16(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u16(a, b, acc); }
+
+// one sample with every check, taps and weights from global memory (planner mode GENERIC, the un-tiled kernel, warp_by_depth)
+__device__ __forceinline__ uint32_t sample_global_fx(const Affine &A, float bx, float by, float bw, float z, const uint8_t *__restrict__ pad,
+                                                     int pitch, float hix, float hiy, const uint32_t *__restrict__ lut, uint32_t Im255,
+                                                     uint32_t *dot_out = nullptr)
+{
+    const float sx = __builtin_fmaf(z, bx, A.ax);
+    const float sy = __builtin_fmaf(z, by, A.ay);
+    const float sw = __builtin_fmaf(z, bw, A.aw);
+    if (!(sw > 0.0f)) return 0u;
+    const float r256 = rcp_rn(sw) * 256.0f;
+    const float tx = __builtin_fmaf(sx, r256, FX_MAGIC + 4.0f), ty = __builtin_fmaf(sy, r256, FX_MAGIC + 4.0f);
+    if (!(tx > FX_MAGIC + 132.0f && tx < hix && ty > FX_MAGIC + 132.0f && ty < hiy)) return 0u;
+    const uint32_t ux = __builtin_bit_cast(uint32_t, tx) & 0x3fffffu, uy = __builtin_bit_cast(uint32_t, ty) & 0x3fffffu;  // tx - magic
+    const uint8_t *q = pad + (size_t)(uy >> 8) * pitch + (ux >> 8);
+    const uint32_t quad = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[pitch] << 16) | ((uint32_t)q[pitch + 1] << 24);
+    const uint32_t w = lut[(((uy >> 3) & 31u) << 5) | ((ux >> 3) & 31u)];
+    const uint32_t dot = __builtin_amdgcn_udot4(quad, w, 0u, false);
+    if (dot_out) *dot_out = dot;
+    return sad_u16(dot, Im255, 1u << 24);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// un-tiled kernel: one pixel per thread, global gathers (MVS_SWEEP_FORCE_GENERIC, V == 0)
+// ------------------------------------------------------------------------------------------------------
+template <bool WRITE_VOLUME, bool FUSED>
+__global__ __launch_bounds__(256) void sweep_fx_generic(SweepParams p, const uint32_t *__restrict__ lut)
+{
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int row = p.row_begin + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (col >= p.W || row >= p.row_end) return;
+    const size_t P = (size_t)p.W * p.H;
+    const size_t pix = (size_t)row * p.W + col;
+    const float xn = __builtin_fmaf((float)(2 * col + 1), p.invW, -1.0f);
+    const float yn = __builtin_fmaf(-(float)(2 * row + 1), p.invH, 1.0f);
+    const uint32_t Im255 = 255u * p.main_img[pix];
+    const float hix = FX_MAGIC + 132.0f + 256.0f * (float)p.W, hiy = FX_MAGIC + 132.0f + 256.0f * (float)p.H;
+    uint32_t best = 0;
+    int bi = -1;
+    for (int d0 = p.plane_begin; d0 < p.plane_end; d0 += PCG) {
+        uint32_t acc[PCG];
+#pragma unroll
+        for (int k = 0; k < PCG; k++) acc[k] = 0u;
+        for (int v = p.v0; v < p.v0 + p.vcount; v++) {
+            const float *q = p.Q + 12 * v;
+            const Affine A = view_affine(q, xn, yn);
+            const uint8_t *pad = p.pads + p.pad_slab * v;
+#pragma unroll
+            for (int k = 0; k < PCG; k++)
+                if (d0 + k < p.plane_end) acc[k] += sample_global_fx(A, q[2], q[6], q[10], p.z[d0 + k], pad, p.pitch, hix, hiy, lut, Im255);
+        }
+#pragma unroll
+        for (int k = 0; k < PCG; k++)
+            if (d0 + k < p.plane_end) {
+                if (WRITE_VOLUME) p.volume[(size_t)(d0 + k) * P + pix] = acc[k];
+                if (FUSED) argmin_update_packed<CS_FIXED>(acc[k], d0 + k, best, bi);
+            }
+    }
+    if (FUSED) store_best<CS_FIXED>(p, pix, best & 0xffffffu, best >> 24, bi);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// region planner: where does tile t land in side view v over the 16 planes of chunk c?
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plan_regions_fx(SweepParams p, uint2 *__restrict__ plan)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = p.tiles_x * p.tiles_y * p.nchunks * p.V;
+    if (tid >= total) return;
+    const int v = tid % p.V;
+    const int rest = tid / p.V;
+    const int chunk = rest % p.nchunks;
+    const int tile = rest / p.nchunks;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int c0 = tx * TILE_W, c1 = min(c0 + TILE_W, p.W) - 1;
+    const int r0 = ty * FX_TILE_H, r1 = min(r0 + FX_TILE_H, p.H) - 1;
+    const int d0 = chunk * FX_PC, d1 = min(d0 + FX_PC, p.D) - 1;
+    const float *q = p.Q + 12 * v;
+    const float bx = q[2], by = q[6], bw = q[10];
+    float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+    bool behind = false;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int col = (k & 1) ? c1 : c0;
+        const int row = (k & 2) ? r1 : r0;
+        const float z = p.z[(k & 4) ? d1 : d0];
+        const float xn = __builtin_fmaf((float)(2 * col + 1), p.invW, -1.0f);
+        const float yn = __builtin_fmaf(-(float)(2 * row + 1), p.invH, 1.0f);
+        const Affine A = view_affine(q, xn, yn);
+        const float sx = __builtin_fmaf(z, bx, A.ax);
+        const float sy = __builtin_fmaf(z, by, A.ay);
+        const float sw = __builtin_fmaf(z, bw, A.aw);
+        if (!(sw > 0.0f)) behind = true;
+        const float r = rcp_rn(sw);
+        const float cx = sx * r, cy = sy * r;
+        xmin = fminf(xmin, cx);
+        xmax = fmaxf(xmax, cx);
+        ymin = fminf(ymin, cy);
+        ymax = fmaxf(ymax, cy);
+    }
+    unsigned mode;
+    int x0 = 0, y0 = 0, rw = 0, rh = 0;
+    // the sampled position is (256 c + 4 +- 1/2) / 256 <= c + 0.018: covered by the margin like the f32 rounding of c itself
+    const float m = PLAN_MARGIN;
+    if (behind || !(xmin == xmin) || !(ymin == ymin) || !(xmax < 1.0e9f) || !(ymax < 1.0e9f) || !(xmin > -1.0e9f) || !(ymin > -1.0e9f)) {
+        mode = FX_GENERIC;  // w is affine in (col, row, z): positive at the eight corners <=> positive for every sample of the box
+    } else if (xmax < 0.5f - m || xmin > p.Wp + m || ymax < 0.5f - m || ymin > p.Hp + m) {
+        mode = FX_SKIP;  // the hull of the warped box is out of frame (projective maps keep segments: DESIGN.md)
+    } else {
+        x0 = max(0, (int)floorf(xmin - m)) & ~3;
+        const int x1 = min(p.W, (int)floorf(xmax + m));
+        y0 = max(0, (int)floorf(ymin - m));
+        const int y1 = min(p.H, (int)floorf(ymax + m));
+        rw = ((x1 - x0 + 1) + 3) & ~3;
+        rh = y1 - y0 + 1;
+        if (rw > FX_MAX_RW || rw <= 0 || rh <= 0 || rh > FX_ROWS) {
+            mode = FX_GENERIC;
+            atomicAdd(p.plan_stats, 1);
+        } else if (xmin > 0.5f + m && xmax < p.Wp - m && ymin > 0.5f + m && ymax < p.Hp - m)
+            mode = FX_FAST;
+        else
+            mode = FX_BORDER;
+    }
+    uint2 d;
+    d.x = (unsigned)x0 | ((unsigned)y0 << 16);
+    d.y = (unsigned)rw | ((unsigned)rh << 8) | (mode << 16);
+    plan[tid] = d;
+    if (mode != FX_SKIP) atomicAdd(p.plan_stats + 1, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// tiled kernel
+// ------------------------------------------------------------------------------------------------------
+// Stage quads [x0, x0+rw) x [y0, y0+rh) of the padded side image: a unit is 4 quads of one region row = two aligned dword
+// loads from each of two image rows, four byte permutes (v_alignbit_b32 for the quad that straddles the dwords) and one
+// ds_write_b128.
+__device__ __forceinline__ void stage_region_fx(const uint8_t *__restrict__ pad, int pitch, int x0, int y0, int rw, int rh, uint32_t *__restrict__ lds)
+{
+    const int units = rw >> 2;
+    const int total = units * rh;
+    const float inv_units = 1.0f / (float)units;
+    for (int u = threadIdx.x; u < total; u += 256) {
+        const int ry = (int)(((float)u + 0.5f) * inv_units);  // exact for u < 2^16 (never within rounding distance of an integer)
+        const int ux = u - ry * units;
+        const uint8_t *r0 = pad + (size_t)(y0 + ry) * pitch + x0 + 4 * ux;
+        const uint32_t d0 = *(const uint32_t *)r0, d1 = *(const uint32_t *)(r0 + 4);
+        const uint32_t e0 = *(const uint32_t *)(r0 + pitch), e1 = *(const uint32_t *)(r0 + pitch + 4);
+        uint4 q;
+        q.x = __builtin_amdgcn_perm(e0, d0, 0x05040100u);
+        q.y = __builtin_amdgcn_perm(e0, d0, 0x06050201u);
+        q.z = __builtin_amdgcn_perm(e0, d0, 0x07060302u);
+        q.w = __builtin_amdgcn_perm(__builtin_amdgcn_alignbit(e1, e0, 24), __builtin_amdgcn_alignbit(d1, d0, 24), 0x05040100u);
+        *(uint4 *)(lds + ry * FX_ROW_DW + FX_LUT_DW + 4 * ux) = q;
+    }
+}
+
+// All planes [K0, K0 + KN) of one (pixel, view) when every sample is known to be in frame, software-pipelined by hand: the two
+// LDS reads of group g + 1 are issued before the dot4 / sad of group g (inline asm reads; the wait is tied to the loaded
+// registers and to the next group's addresses so that neither consumers nor the next address stage can cross it).
+// WCONST: the view's w row does not depend on the plane (b.w == 0), so r is one number per (pixel, view).
+template <int K0, int KN, bool WCONST>
+__device__ __forceinline__ void sample_range_fx(const Affine &A, float bx, float by, float bw, float r256c, const float (&zc)[FX_PC], float offx,
+                                                float offy, uint32_t lds_base, uint32_t Im255, uint32_t (&acc)[FX_PC])
+{
+    static_assert(KN % FX_GS == 0, "plane range must be a multiple of the group size");
+    uint32_t la[2][FX_GS], ta[2][FX_GS];
+    auto address_stage = [&](int g, int buf) {
+#pragma unroll
+        for (int i = 0; i < FX_GS; i += 2) {
+            const f32x2 z = {zc[K0 + g * FX_GS + i], zc[K0 + g * FX_GS + i + 1]};
+            const f32x2 sx = __builtin_elementwise_fma(z, (f32x2)(bx), (f32x2)(A.ax));
+            const f32x2 sy = __builtin_elementwise_fma(z, (f32x2)(by), (f32x2)(A.ay));
+            f32x2 r256;
+            if (WCONST) {
+                r256 = (f32x2)(r256c);
+            } else {
+                const f32x2 sw = __builtin_elementwise_fma(z, (f32x2)(bw), (f32x2)(A.aw));
+                const f32x2 r0 = {__builtin_amdgcn_rcpf(sw.x), __builtin_amdgcn_rcpf(sw.y)};
+                const f32x2 e = __builtin_elementwise_fma(-sw, r0, (f32x2)(1.0f));
+                r256 = __builtin_elementwise_fma(e, r0, r0) * (f32x2)(256.0f);
+            }
+            const f32x2 Tx = __builtin_elementwise_fma(sx, r256, (f32x2)(offx));
+            const f32x2 Ty = __builtin_elementwise_fma(sy, r256, (f32x2)(offy));
+            // through float temporaries: __builtin_bit_cast applied directly to `vec.y` reads element 0 with this hipcc (ROCm 7.2)
+            const float tx0 = Tx.x, tx1 = Tx.y, ty0 = Ty.x, ty1 = Ty.y;
+            const uint32_t P0 = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, ty0), __builtin_bit_cast(uint32_t, tx0), 0x05010400u);
+            const uint32_t P1 = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, ty1), __builtin_bit_cast(uint32_t, tx1), 0x05010400u);
+            la[buf][i] = ((P0 >> 1) & 0x7c7cu) + lds_base;
+            ta[buf][i] = ((P0 >> 14) & 0x7ffcu) + lds_base;
+            la[buf][i + 1] = ((P1 >> 1) & 0x7c7cu) + lds_base;
+            ta[buf][i + 1] = ((P1 >> 14) & 0x7ffcu) + lds_base;
+        }
+    };
+    auto issue_reads = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < FX_GS; i++) {
+            asm volatile("ds_read_b32 %0, %0" : "+v"(la[buf][i]));
+            asm volatile("ds_read_b32 %0, %0 offset:128" : "+v"(ta[buf][i]));
+        }
+    };
+    address_stage(0, 0);
+    issue_reads(0);
+#pragma unroll
+    for (int g = 0; g < KN / FX_GS; g++) {
+        const int buf = g & 1;
+        if (g + 1 < KN / FX_GS) address_stage(g + 1, buf ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(la[buf][0]), "+v"(la[buf][1]), "+v"(la[buf][2]), "+v"(la[buf][3]), "+v"(la[buf][4]), "+v"(la[buf][5]), "+v"(la[buf][6]),
+                       "+v"(la[buf][7]), "+v"(ta[buf][0]), "+v"(ta[buf][1]), "+v"(ta[buf][2]), "+v"(ta[buf][3]), "+v"(ta[buf][4]), "+v"(ta[buf][5]),
+                       "+v"(ta[buf][6]), "+v"(ta[buf][7]), "+v"(la[buf ^ 1][0]), "+v"(ta[buf ^ 1][0]), "+v"(la[buf ^ 1][FX_GS - 1]),
+                       "+v"(ta[buf ^ 1][FX_GS - 1]));
+        if (g + 1 < KN / FX_GS) issue_reads(buf ^ 1);
+#pragma unroll
+        for (int i = 0; i < FX_GS; i++) {
+            const uint32_t dot = __builtin_amdgcn_udot4(ta[buf][i], la[buf][i], 0u, false);
+            acc[K0 + g * FX_GS + i] = sad_u16(dot, Im255, acc[K0 + g * FX_GS + i]);
+        }
+    }
+}
+
+struct FxRegion {
+    float offx, offy;            // magic + 4 - 256 * region origin: T - magic is the position relative to the region, in 1/256 texel
+    float lox, hix, loy, hiy;    // in-frame test on T (strict)
+    float cmaxx, cmaxy;          // clamp range of T for masked samples: [magic, cmax]
+};
+
+// the same planes with the in-frame test per sample (region mode BORDER, for the wavefronts that straddle the frame edge)
+template <int K0, int KN>
+__device__ __forceinline__ void sample_range_fx_checked(const Affine &A, float bx, float by, float bw, const float (&zc)[FX_PC], const FxRegion &rg,
+                                                        const uint32_t *__restrict__ lds, uint32_t Im255, uint32_t (&acc)[FX_PC])
+{
+#pragma unroll
+    for (int k = K0; k < K0 + KN; k++) {
+        const float z = zc[k];
+        const float sx = __builtin_fmaf(z, bx, A.ax), sy = __builtin_fmaf(z, by, A.ay), sw = __builtin_fmaf(z, bw, A.aw);
+        const float r256 = rcp_rn(sw) * 256.0f;
+        const float Tx = __builtin_fmaf(sx, r256, rg.offx), Ty = __builtin_fmaf(sy, r256, rg.offy);
+        const bool ok = Tx > rg.lox && Tx < rg.hix && Ty > rg.loy && Ty < rg.hiy;
+        const float Txc = __builtin_amdgcn_fmed3f(Tx, FX_MAGIC, rg.cmaxx), Tyc = __builtin_amdgcn_fmed3f(Ty, FX_MAGIC, rg.cmaxy);
+        const uint32_t P = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, Tyc), __builtin_bit_cast(uint32_t, Txc), 0x05010400u);
+        const uint32_t w = lds[((P >> 1) & 0x7c7cu) >> 2];
+        const uint32_t quad = lds[(((P >> 14) & 0x7ffcu) >> 2) + FX_LUT_DW];
+        const uint32_t dot = __builtin_amdgcn_udot4(quad, w, 0u, false);
+        const uint32_t t = sad_u16(dot, Im255, acc[k] + (1u << 24));
+        acc[k] = ok ? t : acc[k];
+    }
+}
+
+// 4 workgroups per CU (<= 128 VGPRs, 36 KiB of LDS each): at 2 per CU the LDS reads no longer hide behind the VALU work
+// (19.0 vs 14.6 ns per wave-sample, tools/sweep_v2_probe.hip).
+template <bool WRITE_VOLUME, bool FUSED>
+__global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams p, const uint32_t *__restrict__ lut_g)
+{
+    constexpr int NPX = FX_NPX, PC = FX_PC, TILE_H = FX_TILE_H;
+    // one object, so the texel image sits at LDS address 0 and its byte offsets are the ds_read addresses
+    __shared__ __attribute__((aligned(16))) uint32_t smem[FX_ROWS * FX_ROW_DW + (FUSED ? 2 * 256 * NPX : 0)];
+    uint32_t *lds = smem;
+    uint2 *best_state = (uint2 *)(smem + FX_ROWS * FX_ROW_DW);  // (packed best cell, best index) per (pixel j, thread)
+
+    const int band_tile = (p.debug & 2) ? ((int)blockIdx.x < p.tiles_x * p.tyn ? (int)blockIdx.x : -1) : grouped_tile(blockIdx.x, p.tiles_x, p.tyn);
+    if (band_tile < 0) return;
+    const int tx = band_tile % p.tiles_x, ty = band_tile / p.tiles_x + p.ty0;
+    const int tile = ty * p.tiles_x + tx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = tx * TILE_W + lane;
+    const int row0 = ty * TILE_H + wave * NPX;
+    const bool col_ok = col < p.W;
+    const size_t P = (size_t)p.W * p.H;
+    const float xn = __builtin_fmaf((float)(2 * col + 1), p.invW, -1.0f);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+
+    // the weight table goes into the first 32 dwords of every row (visible after the first staging barrier)
+    for (int i = threadIdx.x; i < FX_ROWS * FX_LUT_DW; i += 256) lds[(i >> 5) * FX_ROW_DW + (i & 31)] = lut_g[i];
+
+    float yn[NPX];
+    uint32_t Im255[NPX];
+    bool ok[NPX];
+#pragma unroll
+    for (int j = 0; j < NPX; j++) {
+        const int row = row0 + j;
+        ok[j] = col_ok && row < p.H;
+        yn[j] = __builtin_fmaf(-(float)(2 * row + 1), p.invH, 1.0f);
+        Im255[j] = ok[j] ? 255u * (uint32_t)p.main_img[(size_t)row * p.W + col] : 0u;
+        if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(0u, 0xffffffffu);  // own slot only: no barrier needed
+    }
+    const float fhix = FX_MAGIC + 132.0f + 256.0f * (float)p.W, fhiy = FX_MAGIC + 132.0f + 256.0f * (float)p.H;
+
+    const int chunk_first = p.chunk0 + (int)blockIdx.y * p.cps;
+    const int chunk_last = min(p.chunk1, chunk_first + p.cps);
+    for (int chunk = chunk_first; chunk < chunk_last; chunk++) {
+        const int d0 = chunk * PC;
+        float zc[PC];  // SGPRs; planes past D are evaluated on a clamped z and never stored
+#pragma unroll
+        for (int k = 0; k < PC; k++) zc[k] = uniform_f(p.z[min(d0 + k, p.D - 1)]);
+
+        uint32_t acc[NPX][PC];
+#pragma unroll
+        for (int j = 0; j < NPX; j++)
+#pragma unroll
+            for (int k = 0; k < PC; k++) acc[j][k] = 0u;
+        uint32_t fast_views = 0u;       // views whose whole (tile, chunk) region is in frame: one count for every cell
+        uint32_t lane_views[NPX];       // views of a BORDER region in which this pixel's whole plane range is in frame
+#pragma unroll
+        for (int j = 0; j < NPX; j++) lane_views[j] = 0u;
+        const uint2 *plan = p.plan + ((size_t)tile * p.nchunks + chunk) * p.V;
+
+        for (int v = p.v0; v < p.v0 + p.vcount; v++) {
+            const uint2 desc = plan[v];
+            const unsigned mode = (unsigned)__builtin_amdgcn_readfirstlane((int)((desc.y >> 16) & 7u));
+            if (mode == FX_SKIP) continue;
+            float q[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) q[i] = uniform_f(p.Q[12 * v + i]);
+            const float bx = q[2], by = q[6], bw = q[10];
+            const uint8_t *pad = p.pads + p.pad_slab * v;
+            if (mode == FX_GENERIC) {
+#pragma unroll
+                for (int j = 0; j < NPX; j++) {
+                    if (ok[j]) {
+                        const Affine A = view_affine(q, xn, yn[j]);
+#pragma unroll
+                        for (int k = 0; k < PC; k++) acc[j][k] += sample_global_fx(A, bx, by, bw, zc[k], pad, p.pitch, fhix, fhiy, lut_g, Im255[j]);
+                    }
+                }
+                continue;
+            }
+            const int x0 = __builtin_amdgcn_readfirstlane((int)(desc.x & 0xffffu));
+            const int y0 = __builtin_amdgcn_readfirstlane((int)(desc.x >> 16));
+            const int rw = __builtin_amdgcn_readfirstlane((int)(desc.y & 0xffu));
+            const int rh = __builtin_amdgcn_readfirstlane((int)((desc.y >> 8) & 0xffu));
+            __syncthreads();  // all reads of the previous region are done
+            if (!(p.debug & 1)) stage_region_fx(pad, p.pitch, x0, y0, rw, rh, lds);
+            __syncthreads();
+            FxRegion rg;
+            rg.offx = FX_MAGIC + 4.0f - 256.0f * (float)x0;
+            rg.offy = FX_MAGIC + 4.0f - 256.0f * (float)y0;
+            const bool wconst = bw == 0.0f && !(p.debug & 4);  // wave-uniform: plane-independent w
+#pragma unroll
+            for (int j = 0; j < NPX; j++) {
+                const Affine A = view_affine(q, xn, yn[j]);
+                bool checked = false;
+                if (mode == FX_BORDER) {
+                    rg.lox = FX_MAGIC + 132.0f - 256.0f * (float)x0;
+                    rg.loy = FX_MAGIC + 132.0f - 256.0f * (float)y0;
+                    rg.hix = rg.lox + 256.0f * (float)p.W;
+                    rg.hiy = rg.loy + 256.0f * (float)p.H;
+                    rg.cmaxx = FX_MAGIC + (float)(256 * rw - 1);
+                    rg.cmaxy = FX_MAGIC + (float)(256 * rh - 1);
+                    // A pixel's samples over the chunk lie on a segment of the side image, monotone in z (w > 0 in the whole box): if
+                    // both end planes are inside the frame by more than one 1/256-texel step (far above the f32 noise of the
+                    // coordinates), every plane between them is in frame.  One wavefront-uniform decision per (row, view).
+                    bool inside = true;
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const float z = e ? zc[PC - 1] : zc[0];
+                        const float sx = __builtin_fmaf(z, bx, A.ax), sy = __builtin_fmaf(z, by, A.ay), sw = __builtin_fmaf(z, bw, A.aw);
+                        const float r256 = rcp_rn(sw) * 256.0f;
+                        const float Tx = __builtin_fmaf(sx, r256, rg.offx), Ty = __builtin_fmaf(sy, r256, rg.offy);
+                        inside = inside && Tx > rg.lox + 2.0f && Tx < rg.hix - 2.0f && Ty > rg.loy + 2.0f && Ty < rg.hiy - 2.0f;
+                    }
+                    checked = __builtin_amdgcn_ballot_w64(!inside && ok[j]) != 0ull;
+                }
+                if (checked) {
+                    if (ok[j]) sample_range_fx_checked<0, PC>(A, bx, by, bw, zc, rg, lds, Im255[j], acc[j]);
+                    continue;
+                }
+                // every sample of this row's lanes is in frame: count once per view
+                if (mode == FX_FAST) {
+                    if (j == 0) fast_views += 1u << 24;
+                } else {
+                    lane_views[j] += 1u << 24;
+                }
+                if (wconst) {
+                    const float r256c = rcp_rn(__builtin_fmaf(zc[0], bw, A.aw)) * 256.0f;
+                    sample_range_fx<0, PC, true>(A, bx, by, bw, r256c, zc, rg.offx, rg.offy, lds_base, Im255[j], acc[j]);
+                } else {
+                    sample_range_fx<0, PC, false>(A, bx, by, bw, 0.0f, zc, rg.offx, rg.offy, lds_base, Im255[j], acc[j]);
+                }
+            }
+        }
+
+#pragma unroll
+        for (int j = 0; j < NPX; j++) {
+            if (ok[j]) {
+                const size_t pix = (size_t)(row0 + j) * p.W + col;
+                uint32_t best = 0u;
+                int bi = -1;
+                if (FUSED) {
+                    const uint2 st = best_state[j * 256 + threadIdx.x];
+                    best = st.x;
+                    bi = (int)st.y;
+                }
+                const uint32_t views = fast_views + lane_views[j];
+#pragma unroll
+                for (int k = 0; k < PC; k++) {
+                    if (d0 + k < p.D) {
+                        const uint32_t cell = acc[j][k] + views;
+                        if (WRITE_VOLUME) p.volume[(size_t)(d0 + k) * P + pix] = cell;
+                        if (FUSED) argmin_update_packed<CS_FIXED>(cell, d0 + k, best, bi);
+                    }
+                }
+                if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(best, (uint32_t)bi);
+            }
+        }
+    }
+    if (FUSED) {
+#pragma unroll
+        for (int j = 0; j < NPX; j++)
+            if (ok[j]) {
+                const uint2 st = best_state[j * 256 + threadIdx.x];
+                const size_t pix = (size_t)(row0 + j) * p.W + col;
+                if (p.part)
+                    p.part[(size_t)blockIdx.y * P + pix] = st;
+                else
+                    store_best<CS_FIXED>(p, pix, st.x & 0xffffffu, st.x >> 24, (int)st.y);
+            }
+    }
+}
+
+// the fixed sampler at one plane per pixel, z = depth[p]: (round(dot / 255), mask)
+__global__ __launch_bounds__(256) void warp_by_depth_fx_kernel(const float *__restrict__ depth, const float *__restrict__ Q, const uint8_t *__restrict__ pad,
+                                                               int pitch, int W, int H, float invW, float invH, const uint32_t *__restrict__ lut,
+                                                               uint8_t *__restrict__ out2)
+{
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (col >= W || row >= H) return;
+    const size_t pix = (size_t)row * W + col;
+    const float z = depth[pix];
+    uint32_t cell = 0u, dot = 0u;
+    if (z != MVS_BACKGROUND_DEPTH) {
+        const float xn = __builtin_fmaf((float)(2 * col + 1), invW, -1.0f);
+        const float yn = __builtin_fmaf(-(float)(2 * row + 1), invH, 1.0f);
+        const Affine A = view_affine(Q, xn, yn);
+        cell = sample_global_fx(A, Q[2], Q[6], Q[10], z, pad, pitch, FX_MAGIC + 132.0f + 256.0f * (float)W, FX_MAGIC + 132.0f + 256.0f * (float)H, lut, 0u,
+                                &dot);
+    }
+    out2[2 * pix] = cell ? (uint8_t)((dot + 127u) / 255u) : 0;
+    out2[2 * pix + 1] = cell ? 255 : 0;
+}
+
+// the 32 x 32 weight table (oracle: orc_fx_weight_table): entry [ky][kx] = (w00, w01, w10, w11) packed little-endian, sum 255
+void fx_weight_table(uint32_t *lut)
+{
+    for (int b = 0; b < 32; b++)
+        for (int a = 0; a < 32; a++) {
+            const int pr[4] = {(32 - a) * (32 - b), a * (32 - b), (32 - a) * b, a * b};
+            int w[4], sum = 0, big = 0;
+            for (int k = 0; k < 4; k++) {
+                w[k] = (255 * pr[k] + 512) >> 10;
+                sum += w[k];
+                if (pr[k] > pr[big]) big = k;
+            }
+            w[big] += 255 - sum;
+            lut[b * 32 + a] = (uint32_t)w[0] | ((uint32_t)w[1] << 8) | ((uint32_t)w[2] << 16) | ((uint32_t)w[3] << 24);
+        }
+}
+
+int ensure_fx_lut(mvs_ctx *ctx)
+{
+    if (ctx->fx_lut.ptr) return MVS_OK;
+    int rc = ensure(ctx, ctx->fx_lut, 4096);
+    if (rc) return rc;
+    uint32_t host[1024];
+    fx_weight_table(host);
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->fx_lut.ptr, host, sizeof(host), hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `host` is on this stack frame
+    return MVS_OK;
+}
+
+// launch of the fixed-sampler sweep; `p` carries the plane / row / view ranges (sweep_run_impl in sweep.hip)
+int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool generic, unsigned flags)
+{
+    int rc = ensure_fx_lut(ctx);
+    if (rc) return rc;
+    const uint32_t *lut = (const uint32_t *)ctx->fx_lut.ptr;
+    if (generic || ctx->V == 0) {
+        dim3 grid(div_up(ctx->W, 64), div_up(p.row_end - p.row_begin, 4));
+        if (vol && fused)
+            sweep_fx_generic<true, true><<<grid, 256, 0, ctx->stream>>>(p, lut);
+        else if (vol)
+            sweep_fx_generic<true, false><<<grid, 256, 0, ctx->stream>>>(p, lut);
+        else
+            sweep_fx_generic<false, true><<<grid, 256, 0, ctx->stream>>>(p, lut);
+        MVS_HIP(ctx, hipGetLastError());
+        return MVS_OK;
+    }
+    const int groups = div_up(p.tiles_x, 2) * div_up(p.tyn, 4);
+    const int nch = p.chunk1 - p.chunk0, tiles = p.tiles_x * p.tyn;
+    int want = (int)((flags >> 16) & 0xffu);  // undocumented: forced split count for timing experiments
+    if (!want) want = div_up(64 * ctx->num_cus, tiles);
+    p.cps = div_up(nch, max(1, min(want, nch)));
+    const int nsplit = div_up(nch, p.cps);
+    if (fused && nsplit > 1) {
+        if ((rc = ensure(ctx, ctx->best_parts, (size_t)nsplit * ctx->W * ctx->H * sizeof(uint2)))) return rc;
+        p.part = (uint2 *)ctx->best_parts.ptr;
+    }
+    const dim3 grid((unsigned)(div_up(groups, 8) * 64), (unsigned)nsplit);
+    if (vol && fused)
+        sweep_fx_tiled<true, true><<<grid, 256, 0, ctx->stream>>>(p, lut);
+    else if (vol)
+        sweep_fx_tiled<true, false><<<grid, 256, 0, ctx->stream>>>(p, lut);
+    else
+        sweep_fx_tiled<false, true><<<grid, 256, 0, ctx->stream>>>(p, lut);
+    MVS_HIP(ctx, hipGetLastError());
+    return nsplit;  // > 0: the caller merges the partial bests when p.part is set
+}
+
+int sweep_fx_plan(mvs_ctx *ctx)
+{
+    int rc;
+    if ((rc = ensure(ctx, ctx->plan_stats, 64))) return rc;
+    SweepParams q;
+    fill_params(ctx, q, 0, ctx->V, FX_TILE_H, FX_PC);
+    const size_t n = (size_t)q.tiles_x * q.tiles_y * q.nchunks * q.V;
+    if ((rc = ensure(ctx, ctx->plan, n * sizeof(uint2)))) return rc;
+    q.plan = (const uint2 *)ctx->plan.ptr;
+    q.plan_stats = (int *)ctx->plan_stats.ptr;
+    MVS_HIP(ctx, hipMemsetAsync(q.plan_stats, 0, 2 * sizeof(int), ctx->stream));
+    plan_regions_fx<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(q, (uint2 *)ctx->plan.ptr);
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+int warp_by_depth_fx_launch(mvs_ctx *ctx, const float *depth_dev, const float *q_dev, const uint8_t *pad_dev, int pitch, uint8_t *out2_dev)
+{
+    int rc = ensure_fx_lut(ctx);
+    if (rc) return rc;
+    const int W = ctx->W, H = ctx->H;
+    warp_by_depth_fx_kernel<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, ctx->stream>>>(depth_dev, q_dev, pad_dev, pitch, W, H, 1.0f / (float)W, 1.0f / (float)H,
+                                                                                       (const uint32_t *)ctx->fx_lut.ptr, out2_dev);
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+}  // namespace mvs

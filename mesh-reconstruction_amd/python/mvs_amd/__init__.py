@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(PKG_ROOT, "lib", "libmvs_hip.so")
 MVS_SWEEP_VOLUME = 1
 MVS_SWEEP_FUSED_ARGMIN = 2
 MVS_SWEEP_FORCE_GENERIC = 4
+MVS_SAMPLER_FIXED, MVS_SAMPLER_EXACT_F32 = 0, 1
+SAMPLERS = {"fixed": MVS_SAMPLER_FIXED, "exact": MVS_SAMPLER_EXACT_F32}
 MVS_K_SWEEP, MVS_K_ARGMIN, MVS_K_PLAN, MVS_K_RASTER, MVS_K_PROJECT, MVS_K_FLOW = 0, 1, 2, 3, 4, 5
 MVS_K_COUNT = 8
 BACKGROUND_DEPTH = np.float32(1.0)
@@ -44,6 +46,8 @@ ABI = [
     ("mvs_filter_points", _i, [_vp, _fp, _i, _f, _i32p, C.POINTER(_i)]),
     ("mvs_sweep", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _f, _f, _fp, _fp, _fp]),
     ("mvs_warp_by_depth", _i, [_vp, _fp, _fp, _fp, _u8p, _u8p]),
+    ("mvs_sweep_set_sampler", _i, [_vp, _i]),
+    ("mvs_sweep_sampler", _i, [_vp]),
     ("mvs_sweep_set_main", _i, [_vp, _fp, _u8p]),
     ("mvs_sweep_set_views", _i, [_vp, _i, _fp, C.POINTER(_u8p)]),
     ("mvs_sweep_set_planes", _i, [_vp, _i, _f, _f]),
@@ -127,12 +131,22 @@ class _DeviceArray:
 class Context:
     """One GPU context (mvs_ctx).  Mirrors the life cycle of the reference's RenderGLX (render_glx.cpp:152-227)."""
 
-    def __init__(self, width, height, device=0):
+    def __init__(self, width, height, device=0, sampler=None):
         self.lib = load_library()
         self.W, self.H = int(width), int(height)
         self.h = self.lib.mvs_create(int(device), self.W, self.H)
         if not self.h:
             raise MvsError("mvs_create failed: %s" % self.lib.mvs_last_error(None).decode())
+        if sampler is not None:
+            self.set_sampler(sampler)
+
+    def set_sampler(self, sampler):
+        """"fixed" (default of the library: 1/32-texel positions, 8-bit weight table, cells count<<24 | sum) or "exact"
+        (f32 bilinear rounded to u8, cells count<<16 | sum) -- include/mvs.h"""
+        self._check(self.lib.mvs_sweep_set_sampler(self.h, SAMPLERS[sampler] if isinstance(sampler, str) else int(sampler)))
+
+    def sampler(self):
+        return {v: k for k, v in SAMPLERS.items()}[self.lib.mvs_sweep_sampler(self.h)]
 
     def close(self):
         if getattr(self, "h", None):

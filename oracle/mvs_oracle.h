@@ -67,6 +67,17 @@ void orc_warp_by_depth(const float main_cam[16], const float *depth, const float
 void orc_argmin(const uint32_t *volume, int W, int H, int D, const float *z,
                 float *depth, float *best_cost, int32_t *best_idx);
 
+/* ---- the same sweep with the "fixed" sampler (contract v2: 1/32-texel positions, 8-bit weight table, cells count<<24 | sum of
+ * |weights.texels - 255 I_main|); see the block comment in sweep_oracle.c ---- */
+void orc_fx_weight_table(uint8_t *lut /* 32*32*4: [ky][kx][w00, w01, w10, w11], each row sums to 255 */);
+int orc_sweep_sample_fx(const float Q[12], float xn, float yn, float z, const uint8_t *pad, int pitch, int W, int H, int *dot);
+void orc_sweep_fx(const float main_cam[16], const uint8_t *main_img, int W, int H, int V, const float *side_cams,
+                  const uint8_t *const *side_imgs, int D, float z_lo, float z_hi, uint32_t *volume, float *depth, float *best_cost,
+                  int32_t *best_idx, int nthreads);
+void orc_argmin_fx(const uint32_t *volume, int W, int H, int D, const float *z, float *depth, float *best_cost, int32_t *best_idx);
+void orc_warp_by_depth_fx(const float main_cam[16], const float *depth, const float side_cam[16], const uint8_t *frame, int W, int H,
+                          uint8_t *out_hw2);
+
 /* ---- renderer (render_glx.cpp:230-397 + shader.vert/frag) ---------------------------------- */
 
 /* loadMesh: dehomogenise + expand to triangle soup; out_soup holds 9*nfaces floats. render_glx.cpp:230-258 */

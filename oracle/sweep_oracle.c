@@ -260,6 +260,181 @@ void orc_warp_by_depth(const float main_cam[16], const float *depth, const float
     free(pad);
 }
 
+
+/* ==================================================================================================================
+ * Sampler "fixed" (arithmetic contract v2): the same warp, with the texture unit modelled the way
+ * fixed-function samplers and OpenCV's own remap (INTER_BITS = 5, the fixed-point path the reference's flowRemap runs
+ * through cv::remap, util.cpp:401) work: the sampling position is quantised to 1/32 texel and the four bilinear weights
+ * come from a 32 x 32 table of 8-bit integers that sum to 255.  The warped intensity is kept at the table's precision
+ * (dot = sum of weight * texel, in [0, 65025] = 255 * grey level) instead of being re-quantised to u8 per view; the cost
+ * cell is  count << 24 | sum |dot - 255 * I_main|  (integer, order independent, all-reducible; <= 255 views).
+ *   s, r          as in the exact sampler above (s = fma(z, B, A), r = RN(1 / s.w))
+ *   u             = RNE(s.xy * (256 r) + 4)      one rounding of the real product: 1/256 texel units, +4 = half of 1/32
+ *   in frame      <=> s.w > 0  and  132 < ux < 256 W + 132  and  132 < uy < 256 H + 132
+ *   i, k          = u >> 8, (u >> 3) & 31          texel and 1/32 sub-texel position
+ *   dot           = w[ky][kx] . (t00, t01, t10, t11)
+ * ================================================================================================================== */
+void orc_fx_weight_table(uint8_t *lut /* 32*32*4 */)
+{
+    for (int b = 0; b < 32; b++)
+        for (int a = 0; a < 32; a++) {
+            const int p[4] = {(32 - a) * (32 - b), a * (32 - b), (32 - a) * b, a * b}; /* sum 1024 */
+            int w[4], sum = 0, big = 0;
+            for (int k = 0; k < 4; k++) {
+                w[k] = (255 * p[k] + 512) >> 10;
+                sum += w[k];
+                if (p[k] > p[big]) big = k; /* first of the largest */
+            }
+            w[big] += 255 - sum;
+            for (int k = 0; k < 4; k++) lut[((b * 32 + a) << 2) + k] = (uint8_t)w[k];
+        }
+}
+
+#define ORC_FX_MAGIC 12582912.0f /* 1.5 * 2^23: floats in [2^23, 2^24) have ulp 1 */
+
+static inline int sample_affine_fx(const float A[3], const float B[3], float z, const uint8_t *pad, int pitch, int W, int H,
+                                   const uint8_t *lut, int *dot)
+{
+    const float sx = fmaf(z, B[0], A[0]);
+    const float sy = fmaf(z, B[1], A[1]);
+    const float sw = fmaf(z, B[2], A[2]);
+    if (!(sw > 0.0f)) return 0;
+    const float r = 1.0f / sw;
+    const float r256 = r * 256.0f; /* exact */
+    /* RNE(product + 4) by the magic-number addition: one rounding, to an integer (the sum lies in [2^23, 2^24)) */
+    const float tx = fmaf(sx, r256, ORC_FX_MAGIC + 4.0f);
+    const float ty = fmaf(sy, r256, ORC_FX_MAGIC + 4.0f);
+    if (!(tx > ORC_FX_MAGIC + 132.0f && tx < ORC_FX_MAGIC + 132.0f + 256.0f * (float)W && ty > ORC_FX_MAGIC + 132.0f &&
+          ty < ORC_FX_MAGIC + 132.0f + 256.0f * (float)H))
+        return 0;
+    const int ux = (int)(tx - ORC_FX_MAGIC), uy = (int)(ty - ORC_FX_MAGIC); /* exact */
+    const int ix = ux >> 8, iy = uy >> 8, kx = (ux >> 3) & 31, ky = (uy >> 3) & 31;
+    const uint8_t *p = pad + (size_t)iy * pitch + ix;
+    const uint8_t *w = lut + ((ky * 32 + kx) << 2);
+    *dot = w[0] * p[0] + w[1] * p[1] + w[2] * p[pitch] + w[3] * p[pitch + 1];
+    return 1;
+}
+
+int orc_sweep_sample_fx(const float Q[12], float xn, float yn, float z, const uint8_t *pad, int pitch, int W, int H, int *dot)
+{
+    static uint8_t lut[4096];
+    static int have = 0;
+    if (!have) {
+        orc_fx_weight_table(lut);
+        have = 1;
+    }
+    float A[3], B[3];
+    view_affine(Q, xn, yn, A, B);
+    return sample_affine_fx(A, B, z, pad, pitch, W, H, lut, dot);
+}
+
+void orc_argmin_fx(const uint32_t *volume, int W, int H, int D, const float *z, float *depth, float *best_cost, int32_t *best_idx)
+{
+    const size_t P = (size_t)W * H;
+    for (size_t p = 0; p < P; p++) {
+        uint32_t bs = 0, bc = 0;
+        int bi = -1;
+        for (int d = 0; d < D; d++) {
+            const uint32_t cell = volume[(size_t)d * P + p];
+            const uint32_t s = cell & 0xffffffu, c = cell >> 24;
+            if (c == 0) continue;
+            if (bi < 0 || (uint64_t)s * bc < (uint64_t)bs * c) {
+                bs = s;
+                bc = c;
+                bi = d;
+            }
+        }
+        depth[p] = bi >= 0 ? z[bi] : ORC_BACKGROUND_DEPTH;
+        if (best_cost) best_cost[p] = bi >= 0 ? (float)bs / (float)(255u * bc) : INFINITY;
+        if (best_idx) best_idx[p] = bi;
+    }
+}
+
+void orc_sweep_fx(const float main_cam[16], const uint8_t *main_img, int W, int H, int V, const float *side_cams,
+                  const uint8_t *const *side_imgs, int D, float z_lo, float z_hi, uint32_t *volume, float *depth, float *best_cost,
+                  int32_t *best_idx, int nthreads)
+{
+    const int pitch = W + 2;
+    const size_t P = (size_t)W * H;
+    float *Q = (float *)malloc(sizeof(float) * 12 * (size_t)(V > 0 ? V : 1));
+    float *z = (float *)malloc(sizeof(float) * (size_t)D);
+    uint8_t **pads = (uint8_t **)malloc(sizeof(uint8_t *) * (size_t)(V > 0 ? V : 1));
+    uint8_t lut[4096];
+    orc_fx_weight_table(lut);
+    for (int v = 0; v < V; v++) {
+        orc_view_matrix(main_cam, side_cams + 16 * v, W, H, Q + 12 * v);
+        pads[v] = (uint8_t *)malloc((size_t)pitch * (H + 2));
+        orc_pad_image(side_imgs[v], W, H, pads[v], pitch);
+    }
+    orc_plane_table(D, z_lo, z_hi, z);
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 4)
+#endif
+    for (int row = 0; row < H; row++) {
+        uint32_t *acc = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)D);
+        const float yn = orc_pixel_yn(row, H);
+        for (int col = 0; col < W; col++) {
+            const float xn = orc_pixel_xn(col, W);
+            const int Im255 = 255 * (int)main_img[(size_t)row * W + col];
+            memset(acc, 0, sizeof(uint32_t) * (size_t)D);
+            for (int v = 0; v < V; v++) {
+                float A[3], B[3];
+                view_affine(Q + 12 * v, xn, yn, A, B);
+                for (int d = 0; d < D; d++) {
+                    int dot;
+                    if (sample_affine_fx(A, B, z[d], pads[v], pitch, W, H, lut, &dot)) {
+                        const int diff = dot > Im255 ? dot - Im255 : Im255 - dot;
+                        acc[d] += (1u << 24) + (uint32_t)diff;
+                    }
+                }
+            }
+            const size_t p = (size_t)row * W + col;
+            uint32_t bs = 0, bc = 0;
+            int bi = -1;
+            for (int d = 0; d < D; d++) {
+                const uint32_t s = acc[d] & 0xffffffu, c = acc[d] >> 24;
+                if (volume) volume[(size_t)d * P + p] = acc[d];
+                if (c == 0) continue;
+                if (bi < 0 || (uint64_t)s * bc < (uint64_t)bs * c) {
+                    bs = s;
+                    bc = c;
+                    bi = d;
+                }
+            }
+            depth[p] = bi >= 0 ? z[bi] : ORC_BACKGROUND_DEPTH;
+            if (best_cost) best_cost[p] = bi >= 0 ? (float)bs / (float)(255u * bc) : INFINITY;
+            if (best_idx) best_idx[p] = bi;
+        }
+        free(acc);
+    }
+    for (int v = 0; v < V; v++) free(pads[v]);
+    free(pads);
+    free(z);
+    free(Q);
+}
+
+/* the fixed sampler at one plane per pixel: out_hw2 = (round(dot / 255), mask) */
+void orc_warp_by_depth_fx(const float main_cam[16], const float *depth, const float side_cam[16], const uint8_t *frame, int W, int H,
+                          uint8_t *out_hw2)
+{
+    const int pitch = W + 2;
+    float Q[12];
+    orc_view_matrix(main_cam, side_cam, W, H, Q);
+    uint8_t *pad = (uint8_t *)malloc((size_t)pitch * (H + 2));
+    orc_pad_image(frame, W, H, pad, pitch);
+    for (int row = 0; row < H; row++)
+        for (int col = 0; col < W; col++) {
+            const size_t p = (size_t)row * W + col;
+            int dot = 0, ok = 0;
+            if (depth[p] != ORC_BACKGROUND_DEPTH)
+                ok = orc_sweep_sample_fx(Q, orc_pixel_xn(col, W), orc_pixel_yn(row, H), depth[p], pad, pitch, W, H, &dot);
+            out_hw2[2 * p] = ok ? (uint8_t)((dot + 127) / 255) : 0;
+            out_hw2[2 * p + 1] = ok ? 255 : 0;
+        }
+    free(pad);
+}
+
 /* util.cpp:366-387 */
 void orc_mix_background(const uint8_t *img_hw3, const uint8_t *bg_hw, float *depth_hw, uint8_t *out_hw,
                         int W, int H)

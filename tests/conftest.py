@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+try:   # before libmvs_hip.so is loaded: the library must bind to the HIP runtime torch brings along (same soname);
+    import torch  # noqa: F401  loaded the other way round, torch's own runtime finds no device ("No HIP GPUs are available")
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -74,7 +74,9 @@ class Oracle:
         return pad
 
     def sweep(self, main_cam, main_img, side_cams, side_imgs, D, z_lo=-1.0, z_hi=1.0, want_volume=False,
-              nthreads=1):
+              nthreads=1, sampler="exact"):
+        """sampler "exact": contract v1 (f32 bilinear, cells count<<16 | sum); "fixed": contract v2 (1/32-texel positions,
+        8-bit weight table, cells count<<24 | sum of |weights.texels - 255 I_main|)"""
         H, W = main_img.shape
         V = len(side_imgs)
         cam = np.ascontiguousarray(main_cam, np.float32)
@@ -86,30 +88,50 @@ class Oracle:
         cost = np.empty((H, W), np.float32)
         idx = np.empty((H, W), np.int32)
         vol = np.empty((D, H, W), np.uint32) if want_volume else None
-        self.lib.orc_sweep(self._p(cam, _fp), self._p(img, _u8p), W, H, V, self._p(cams, _fp), arr, D, z_lo, z_hi,
-                           self._p(vol, _u32p) if want_volume else None, self._p(depth, _fp), self._p(cost, _fp),
-                           self._p(idx, _i32p), nthreads)
+        fn = self.lib.orc_sweep if sampler == "exact" else self.lib.orc_sweep_fx
+        fn.argtypes = self.lib.orc_sweep.argtypes
+        fn(self._p(cam, _fp), self._p(img, _u8p), W, H, V, self._p(cams, _fp), arr, D, z_lo, z_hi,
+           self._p(vol, _u32p) if want_volume else None, self._p(depth, _fp), self._p(cost, _fp),
+           self._p(idx, _i32p), nthreads)
         return depth, cost, idx, vol
 
-    def warp_by_depth(self, main_cam, depth, side_cam, frame):
+    def fx_weight_table(self):
+        lut = np.empty((32, 32, 4), np.uint8)
+        self.lib.orc_fx_weight_table.argtypes = [_u8p]
+        self.lib.orc_fx_weight_table(self._p(lut, _u8p))
+        return lut
+
+    def sweep_sample_fx(self, q, xn, yn, z, pad):
+        q = np.ascontiguousarray(q, np.float32)
+        pad = np.ascontiguousarray(pad, np.uint8)
+        Hp, pitch = pad.shape
+        out = C.c_int(0)
+        fn = self.lib.orc_sweep_sample_fx
+        fn.argtypes = [_fp, C.c_float, C.c_float, C.c_float, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        fn.restype = C.c_int
+        ok = fn(self._p(q, _fp), xn, yn, z, self._p(pad, _u8p), pitch, pitch - 2, Hp - 2, C.byref(out))
+        return ok, out.value
+
+    def warp_by_depth(self, main_cam, depth, side_cam, frame, sampler="exact"):
         H, W = frame.shape
         m, sc = np.ascontiguousarray(main_cam, np.float32), np.ascontiguousarray(side_cam, np.float32)
         d, f = np.ascontiguousarray(depth, np.float32), np.ascontiguousarray(frame, np.uint8)
         out = np.empty((H, W, 2), np.uint8)
-        fn = self.lib.orc_warp_by_depth
+        fn = self.lib.orc_warp_by_depth if sampler == "exact" else self.lib.orc_warp_by_depth_fx
         fn.argtypes = [_fp, _fp, _fp, _u8p, C.c_int, C.c_int, _u8p]
         fn(self._p(m, _fp), self._p(d, _fp), self._p(sc, _fp), self._p(f, _u8p), W, H, self._p(out, _u8p))
         return out
 
-    def argmin(self, vol, z):
+    def argmin(self, vol, z, sampler="exact"):
         D, H, W = vol.shape
         vol = np.ascontiguousarray(vol, np.uint32)
         z = np.ascontiguousarray(z, np.float32)
         depth = np.empty((H, W), np.float32)
         cost = np.empty((H, W), np.float32)
         idx = np.empty((H, W), np.int32)
-        self.lib.orc_argmin(self._p(vol, _u32p), W, H, D, self._p(z, _fp), self._p(depth, _fp), self._p(cost, _fp),
-                            self._p(idx, _i32p))
+        fn = self.lib.orc_argmin if sampler == "exact" else self.lib.orc_argmin_fx
+        fn.argtypes = self.lib.orc_argmin.argtypes
+        fn(self._p(vol, _u32p), W, H, D, self._p(z, _fp), self._p(depth, _fp), self._p(cost, _fp), self._p(idx, _i32p))
         return depth, cost, idx
 
     def mix_background(self, img3, bg, depth):

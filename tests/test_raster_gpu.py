@@ -177,8 +177,10 @@ def test_reference_stage_per_pair(oracle):
     assert (depth2 == 1.0).mean() > 0.2 and (depth2 != 1.0).mean() > 0.1
 
 
-def test_parity_hook_warp_by_depth(oracle):
-    """mvs_warp_by_depth == oracle (bit-exact) and ~= Render::projected on unoccluded geometry (SURVEY.md section 0.2)"""
+@pytest.mark.parametrize("sampler", ["fixed", "exact"])
+def test_parity_hook_warp_by_depth(oracle, sampler):
+    """mvs_warp_by_depth == oracle (bit-exact) and ~= Render::projected on unoccluded geometry (SURVEY.md section 0.2); with the
+    fixed sampler (1/32-texel positions, 8-bit weights) the warped grey level may differ from projected()'s f32 bilinear by one"""
     W, H = 320, 240
     verts, faces = scenes.heightfield_mesh(96)
     soup, ctx = _both(oracle, W, H, verts, faces)
@@ -187,10 +189,12 @@ def test_parity_hook_warp_by_depth(oracle):
     cam, prj = synth.camera_at(main_c, W, H), synth.camera_at(side_c, W, H)
     side_img = sc.render(side_c, W, H)
     with ctx:
+        ctx.set_sampler(sampler)
         depth = ctx.depth(cam)
         warp = ctx.warp_by_depth(cam, depth, prj, side_img)
         proj = ctx.projected(cam, side_img, prj)
-    np.testing.assert_array_equal(warp, oracle.warp_by_depth(cam, depth, prj, side_img))
+    np.testing.assert_array_equal(warp, oracle.warp_by_depth(cam, depth, prj, side_img, sampler=sampler))
     both = (proj[..., 1] == 255) & (warp[..., 1] == 255)
     diff = np.abs(proj[..., 0].astype(int) - warp[..., 0].astype(int))[both]
-    assert both.mean() > 0.8 and diff.max() <= 1 and np.mean(diff == 0) > 0.97
+    print("sampler %s: |warp - projected| <= %d grey levels, equal in %.4f of the pixels" % (sampler, diff.max(), np.mean(diff == 0)))
+    assert both.mean() > 0.8 and diff.max() <= (1 if sampler == "exact" else 2) and np.mean(diff == 0) > (0.97 if sampler == "exact" else 0.80)

@@ -1,7 +1,8 @@
-"""GPU parity tests of the plane sweep: HIP kernels (through the C ABI) vs the CPU oracle.
+"""GPU parity tests of the plane sweep: HIP kernels (through the C ABI) vs the CPU oracle, for both samplers
+("fixed": contract v2, the library default; "exact": contract v1) -- each against the oracle's restatement of the same contract.
 
 Tolerances (north_star: depth RMSE < 1e-4 vs the reference path):
-  * packed volume cells (count<<16 | sum of |I_main - I_warp|): integer work -> bit-exact expected; the only
+  * packed volume cells (count<<24 | sum resp. count<<16 | sum): integer work -> bit-exact expected; the only
     admitted deviation is the Newton reciprocal's documented miss (significand all ones, probability 2^-23
     per sample), budgeted as <= 1e-6 of the cells;
   * depth maps: RMSE < 1e-4 in NDC z and identical arg-min indices except at those cells.
@@ -18,6 +19,11 @@ RMSE_TOL = 1e-4
 CELL_BUDGET = 1e-6
 
 
+@pytest.fixture(params=["fixed", "exact"])
+def sampler(request):
+    return request.param
+
+
 def _rot_cam(W, H, center, yaw, pitch, **kw):
     cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
     Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
@@ -25,8 +31,8 @@ def _rot_cam(W, H, center, yaw, pitch, **kw):
     return synth.camera_at(center, W, H, rot=Rx @ Ry, **kw)
 
 
-def _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, flags, z=(-1.0, 1.0), argmin=False, volume=True):
-    with mvs_amd.Context(W, H) as ctx:
+def _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, flags, z=(-1.0, 1.0), argmin=False, volume=True, sampler="exact"):
+    with mvs_amd.Context(W, H, sampler=sampler) as ctx:
         ctx.sweep_set(main_cam, main_img, side_cams, sides, D, z[0], z[1])
         ctx.sweep_run(0, len(sides), flags)
         if argmin:
@@ -80,63 +86,67 @@ CASES = [
 
 @pytest.mark.parametrize("W,H,D,V,radius,rot", CASES)
 @pytest.mark.parametrize("kernel", ["generic", "tiled"])
-def test_sweep_matches_oracle(oracle, W, H, D, V, radius, rot, kernel):
+def test_sweep_matches_oracle(oracle, W, H, D, V, radius, rot, kernel, sampler):
     main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=radius, freq_scale=max(W / 1920.0, 0.25))
     if rot:
         side_cams = side_cams.copy()
         side_cams[0] = _rot_cam(W, H, [radius, 0.02, 0.05], 0.05, -0.04)
         if V > 1:
             side_cams[1] = _rot_cam(W, H, [-0.9, 0.6, -0.3], -0.45, 0.3)  # partly out of frame
-    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8)
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8, sampler=sampler)
     flags = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
     if kernel == "generic":
         flags |= mvs_amd.MVS_SWEEP_FORCE_GENERIC
-    _check(_gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, flags), ref, D)
+    _check(_gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, flags, sampler=sampler), ref, D)
 
 
-def test_argmin_kernel_equals_fused_and_oracle(oracle):
+def test_argmin_kernel_equals_fused_and_oracle(oracle, sampler):
     W, H, D, V = 320, 240, 24, 3
     main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
-    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8)
-    fused = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_FUSED_ARGMIN, volume=False)
-    sep = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME, argmin=True)
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8, sampler=sampler)
+    fused = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_FUSED_ARGMIN, volume=False, sampler=sampler)
+    sep = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME, argmin=True, sampler=sampler)
     for a, b in zip(fused[:3], sep[:3]):
         np.testing.assert_array_equal(a, b)
     _check(sep, ref, D)
 
 
-def test_no_views_and_behind_camera(oracle):
+def test_no_views_and_behind_camera(oracle, sampler):
     W, H, D = 128, 64, 8
     main_cam, main_img, _, _, _ = synth.make_views(W, H, 0)
     depth, cost, idx, vol = _gpu_sweep(W, H, main_cam, main_img, np.zeros((0, 4, 4), np.float32), [], D,
-                                       mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+                                       mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN, sampler=sampler)
     assert np.all(depth == np.float32(1.0)) and np.all(idx == -1) and np.all(np.isinf(cost)) and np.all(vol == 0)
     # a side camera looking the other way: every sample has w <= 0
     back = synth.camera_at([0, 0, -6.0], W, H, rot=np.diag([-1.0, 1.0, -1.0]))
     side = np.full((H, W), 77, np.uint8)
-    ref = oracle.sweep(main_cam, main_img, back[None], [side], D, want_volume=True)
+    ref = oracle.sweep(main_cam, main_img, back[None], [side], D, want_volume=True, sampler=sampler)
     for kernel_flag in (0, mvs_amd.MVS_SWEEP_FORCE_GENERIC):
         got = _gpu_sweep(W, H, main_cam, main_img, back[None], [side], D,
-                         mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | kernel_flag)
+                         mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | kernel_flag, sampler=sampler)
         _check(got, ref, D)
 
 
-def test_one_call_form_and_float_volume(oracle):
+def test_one_call_form_and_float_volume(oracle, sampler):
     W, H, D, V = 256, 128, 16, 2
     main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
-    d_ref, c_ref, i_ref, v_ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True)
-    with mvs_amd.Context(W, H) as ctx:
+    d_ref, c_ref, i_ref, v_ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, sampler=sampler)
+    with mvs_amd.Context(W, H, sampler=sampler) as ctx:
         depth, cost, vol = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_cost=True, want_volume=True)
     np.testing.assert_array_equal(depth, d_ref)
-    cnt = (v_ref >> 16).astype(np.float32)
-    s = (v_ref & 0xffff).astype(np.float32)
+    if sampler == "exact":
+        cnt = (v_ref >> 16).astype(np.float32)
+        s = (v_ref & 0xffff).astype(np.float32)
+    else:   # sums in 1/255 grey levels: cost = sum / (255 count), one f32 division of two exactly representable integers
+        cnt = (255 * (v_ref >> 24)).astype(np.float32)
+        s = (v_ref & 0xffffff).astype(np.float32)
     with np.errstate(divide="ignore", invalid="ignore"):
         expect = np.where(cnt > 0, s / cnt, np.inf).astype(np.float32)
     np.testing.assert_array_equal(vol, expect)
     np.testing.assert_array_equal(cost, c_ref)
 
 
-def test_yaml_track_cameras(oracle):
+def test_yaml_track_cameras(oracle, sampler):
     """BASELINE config c1: cameras of tracks/koberec.yaml (640x480), 32 planes, 4 side views, synthetic frames"""
     import tracks_yaml
     t = tracks_yaml.load("koberec.yaml")
@@ -150,18 +160,18 @@ def test_yaml_track_cameras(oracle):
     main_img = big.astype(np.uint8)
     sides = [np.roll(big, (i, 2 * i), (0, 1)).astype(np.uint8) for i in range(4)]
     side_cams = np.stack([cams[i] for i in ids])
-    ref = oracle.sweep(main, main_img, side_cams, sides, 32, want_volume=True, nthreads=8)
+    ref = oracle.sweep(main, main_img, side_cams, sides, 32, want_volume=True, nthreads=8, sampler=sampler)
     for kernel_flag in (0, mvs_amd.MVS_SWEEP_FORCE_GENERIC):
         got = _gpu_sweep(W, H, main, main_img, side_cams, sides, 32,
-                         mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | kernel_flag)
+                         mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | kernel_flag, sampler=sampler)
         _check(got, ref, 32)
 
 
-def test_view_shards_sum_to_full_volume():
+def test_view_shards_sum_to_full_volume(sampler):
     """the all-reduce invariant on the device: shard volumes add (as integers) to the full volume"""
     W, H, D, V = 320, 160, 16, 4
     main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
-    with mvs_amd.Context(W, H) as ctx:
+    with mvs_amd.Context(W, H, sampler=sampler) as ctx:
         ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
         ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
         full = ctx.sweep_fetch(want_volume=True)[3].copy()
@@ -172,23 +182,23 @@ def test_view_shards_sum_to_full_volume():
     np.testing.assert_array_equal(acc, full)
 
 
-def test_c2_full_size_tiled_vs_oracle(oracle):
+def test_c2_full_size_tiled_vs_oracle(oracle, sampler):
     """BASELINE config c2 at full size (1280x720, 64 planes, 8 views): tiled kernel vs oracle"""
     W, H, D, V = 1280, 720, 64, 8
     main_cam, main_img, side_cams, sides, gt = synth.make_views(W, H, V)
-    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8)
-    got = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME, argmin=True)
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8, sampler=sampler)
+    got = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME, argmin=True, sampler=sampler)
     _check(got, ref, D)
     # the sweep recovers the analytic surface it was rendered from
     err = np.abs(got[0] - gt)[16:-16, 16:-16]
     assert np.median(err) <= 2.0 / D
 
 
-def test_c3_full_size_properties():
+def test_c3_full_size_properties(sampler):
     """BASELINE config c3 (1920x1080, 128 planes, 16 views): size-independent properties"""
     W, H, D, V = 1920, 1080, 128, 16
     main_cam, main_img, side_cams, sides, gt = synth.make_views(W, H, V)
-    with mvs_amd.Context(W, H) as ctx:
+    with mvs_amd.Context(W, H, sampler=sampler) as ctx:
         ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
         ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
         ctx.sweep_argmin()
@@ -203,9 +213,10 @@ def test_c3_full_size_properties():
         d_g, c_g, i_g, _ = ctx.sweep_fetch()
         np.testing.assert_array_equal(i_t, i_g)
         np.testing.assert_array_equal(c_t, c_g)
-        # (3) the other thread shape of the tiled kernel (the planner picks 2 x 32 here), index for index
-        assert ctx.plan_shape() == 1
-        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN | (8 << 8))
+        # (3) exact sampler: the other thread shape of the tiled kernel (the planner picks 2 x 32 here), index for index;
+        #     fixed sampler: the general-camera code path (per-sample reciprocal) on this plane-independent-w geometry
+        assert ctx.plan_shape() == (1 if sampler == "exact" else 3)
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN | ((8 if sampler == "exact" else 4) << 8))
         d_s, c_s, i_s, _ = ctx.sweep_fetch()
         np.testing.assert_array_equal(i_t, i_s)
         np.testing.assert_array_equal(c_t, c_s)
@@ -222,25 +233,25 @@ def test_c3_full_size_properties():
     assert np.mean(err <= 3.0 / D) > 0.97
 
 
-def test_c3_full_size_vs_oracle(oracle):
+def test_c3_full_size_vs_oracle(oracle, sampler):
     """BASELINE config c3 at full size against the oracle, every cell of the 1 GB volume and every depth (the oracle takes
     a couple of seconds on the GPU box's host threads -- it is bench.py's cpu_baseline on the same workload)"""
     import os
     W, H, D, V = 1920, 1080, 128, 16
     main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V)
-    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=min(256, os.cpu_count() or 8))
-    got = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=min(256, os.cpu_count() or 8), sampler=sampler)
+    got = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN, sampler=sampler)
     _check(got, ref, D)
 
 
-def test_c4_full_size_depth_vs_oracle(oracle):
+def test_c4_full_size_depth_vs_oracle(oracle, sampler):
     """BASELINE config c4 (3840x2160, 256 planes, 32 views) at full size on i.i.d. noise frames (SURVEY 8d's adversarial
     input): depth, cost and index of every pixel against the oracle; the 8.5 GB volume is not materialised"""
     import os
     W, H, D, V = 3840, 2160, 256, 32
     main_cam, main_img, side_cams, sides = synth.noise_views(W, H, V)
-    d_ref, c_ref, i_ref, _ = oracle.sweep(main_cam, main_img, side_cams, sides, D, nthreads=min(256, os.cpu_count() or 8))
-    with mvs_amd.Context(W, H) as ctx:
+    d_ref, c_ref, i_ref, _ = oracle.sweep(main_cam, main_img, side_cams, sides, D, nthreads=min(256, os.cpu_count() or 8), sampler=sampler)
+    with mvs_amd.Context(W, H, sampler=sampler) as ctx:
         ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
         ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
         depth, cost, idx, _ = ctx.sweep_fetch()
@@ -262,7 +273,7 @@ def _random_camera(rng, W, H, spread, max_angle):
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_random_geometry_stress(oracle, seed):
+def test_random_geometry_stress(oracle, seed, sampler):
     """random sizes, plane counts and wildly different side cameras (wide baselines, rotations up to 40 degrees, other
     intrinsics): exercises the planner's FAST / BORDER / SKIP / GENERIC modes and ragged tiles; tiled == generic ==
     oracle, cell for cell"""
@@ -276,10 +287,10 @@ def test_random_geometry_stress(oracle, seed):
     main_img = rng.integers(0, 256, (H, W), dtype=np.uint8)
     sides = [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(V)]
     z = (float(rng.uniform(-1.0, -0.2)), float(rng.uniform(0.2, 1.0)))
-    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, z[0], z[1], want_volume=True, nthreads=8)
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, z[0], z[1], want_volume=True, nthreads=8, sampler=sampler)
     flags = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
-    tiled = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, flags, z=z)
-    generic = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, flags | mvs_amd.MVS_SWEEP_FORCE_GENERIC, z=z)
+    tiled = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, flags, z=z, sampler=sampler)
+    generic = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, flags | mvs_amd.MVS_SWEEP_FORCE_GENERIC, z=z, sampler=sampler)
     np.testing.assert_array_equal(tiled[3], generic[3])
     np.testing.assert_array_equal(tiled[2], generic[2])
     _check(tiled, ref, D)
@@ -302,12 +313,12 @@ def test_argument_errors():
         mvs_amd.Context(1, 1)
 
 
-def test_plane_groups_reproduce_the_full_volume():
+def test_plane_groups_reproduce_the_full_volume(sampler):
     """mvs_sweep_run_planes over consecutive plane groups == one full run (the pipelined all-reduce path of bench.py)"""
     from mvs_amd import dist as mdist
     W, H, D, V = 320, 160, 40, 3
     main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
-    with mvs_amd.Context(W, H) as ctx:
+    with mvs_amd.Context(W, H, sampler=sampler) as ctx:
         ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
         ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
         ctx.sweep_argmin()
@@ -328,7 +339,7 @@ def test_plane_groups_reproduce_the_full_volume():
     assert mdist.plane_groups(7, 4, 16) == [(0, 7)]
 
 
-def test_partial_selection_and_merge_equal_the_one_step_argmin():
+def test_partial_selection_and_merge_equal_the_one_step_argmin(sampler):
     """mvs_sweep_argmin_partial over plane slices + mvs_sweep_combine_partials == mvs_sweep_argmin (the reduce-scatter form of the
     view-sharded pipeline: a rank selects over the planes it owns, the 8-byte partials are merged in ascending plane order);
     ties included (flat frames: every plane ties, the lowest must win), parts of unequal size"""
@@ -338,7 +349,7 @@ def test_partial_selection_and_merge_equal_the_one_step_argmin():
     flat = np.full((H, W), 90, np.uint8)
     P = W * H
     for img, sd in ((main_img, sides), (flat, [flat] * V)):
-        with mvs_amd.Context(W, H) as ctx:
+        with mvs_amd.Context(W, H, sampler=sampler) as ctx:
             # torch fills / frees on ITS stream, the library works on its own: allocate without a fill and synchronise before
             # handing the buffers over (bench.py shares one explicit stream instead)
             vol_t = torch.empty(D * P, dtype=torch.int32, device="cuda")
@@ -366,14 +377,14 @@ def test_partial_selection_and_merge_equal_the_one_step_argmin():
             ctx.sweep_use_volume(0, 0)
 
 
-def test_row_bands_reproduce_the_full_result():
+def test_row_bands_reproduce_the_full_result(sampler):
     """mvs_sweep_run_rows over the bands of mdist.row_bands == one full run, for the volume and the fused depth selection,
     tiled and generic kernels; rows outside a band are not touched (bench.py --shard rows)"""
     from mvs_amd import dist as mdist
     W, H, D, V = 320, 200, 24, 3            # 200 rows = 12 full tile rows + a ragged one
     main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
     both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
-    with mvs_amd.Context(W, H) as ctx:
+    with mvs_amd.Context(W, H, sampler=sampler) as ctx:
         g = ctx.row_granularity()
         ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
         ctx.sweep_run(0, V, both)
@@ -399,7 +410,7 @@ def test_row_bands_reproduce_the_full_result():
         ctx.sweep_run_rows(192, 8, 0, V, both)                   # ragged last band ends at H
 
 
-def test_plane_split_launches_are_bit_identical():
+def test_plane_split_launches_are_bit_identical(sampler):
     """launches with too few tiles to fill the chip hand each workgroup a subset of a tile's plane chunks and merge the
     partial bests (combine_best); any split count -- forced through the timing-experiment bits -- must give the
     unsplit result, ties included (noise frames produce many equal-cost planes)"""
@@ -410,7 +421,7 @@ def test_plane_split_launches_are_bit_identical():
     noise_side = rng.integers(0, 4, (H, W), dtype=np.uint8)           # 4 grey levels: many equal-cost planes
     cases = [(main_img, sides), (flat, [flat] * V), (rng.integers(0, 256, (H, W), dtype=np.uint8), [noise_side] * V)]
     both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
-    with mvs_amd.Context(W, H) as ctx:
+    with mvs_amd.Context(W, H, sampler=sampler) as ctx:
         for img, sd in cases:
             ctx.sweep_set(main_cam, img, side_cams, sd, D)
             ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
@@ -439,7 +450,7 @@ def test_both_thread_shapes_are_bit_identical(oracle):
         side_cams = side_cams.copy()
         side_cams[0] = _rot_cam(W, H, [0.0, radius, 0.03], 0.01, 0.02)        # one general camera among the ring
         ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8)
-        with mvs_amd.Context(W, H) as ctx:
+        with mvs_amd.Context(W, H, sampler="exact") as ctx:
             ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
             assert ctx.plan_shape() == 0
             ctx.sweep_run(0, V, both)
@@ -458,7 +469,7 @@ def test_both_thread_shapes_are_bit_identical(oracle):
     assert seen == {1, 2}, "the cases above are meant to exercise both shapes, got %r" % seen
 
 
-def test_plane_independent_w_path_is_bit_identical(oracle):
+def test_plane_independent_w_path_is_bit_identical(oracle, sampler):
     """ring cameras (parallel axes, centres in the main focal plane) have Q[2][2] == 0 and take the hoisted-reciprocal
     path; it must equal the general path (debug bit) and the oracle cell for cell; a rotated camera must not take it"""
     W, H, D, V = 384, 200, 32, 4
@@ -469,9 +480,9 @@ def test_plane_independent_w_path_is_bit_identical(oracle):
     rot[1] = _rot_cam(W, H, [0.0, 0.3, 0.05], 0.01, 0.02)  # pitched and displaced along the optical axis
     assert oracle.view_matrix(main_cam, rot[1], W, H)[2, 2] != 0.0
     for cams in (side_cams, rot):
-        ref = oracle.sweep(main_cam, main_img, cams, sides, D, want_volume=True, nthreads=8)
-        fast = _gpu_sweep(W, H, main_cam, main_img, cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        ref = oracle.sweep(main_cam, main_img, cams, sides, D, want_volume=True, nthreads=8, sampler=sampler)
+        fast = _gpu_sweep(W, H, main_cam, main_img, cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN, sampler=sampler)
         general = _gpu_sweep(W, H, main_cam, main_img, cams, sides, D,
-                             mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | (4 << 8))
+                             mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | (4 << 8), sampler=sampler)
         np.testing.assert_array_equal(fast[3], general[3])
         _check(fast, ref, D)
