@@ -83,6 +83,22 @@ __global__ void pad_wrap_kernel(const uint8_t *__restrict__ img, uint8_t *__rest
     pad[(size_t)r * pitch + c] = v;
 }
 
+// Quad image of a padded side view for the fixed sampler: quads[y][x] = (pad[y][x], pad[y][x+1], pad[y+1][x], pad[y+1][x+1]),
+// the four texels of the bilinear footprint whose top-left texel is (y, x), so the sweep fills its LDS image with 16-byte
+// global->LDS copies and no byte shuffling.  Row H+1 and the columns past W+1 are never sampled (zeros).
+__global__ void quad_image_kernel(const uint8_t *__restrict__ pad, uint32_t *__restrict__ quads, int W, int H, int pitch)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= pitch) return;
+    uint32_t q = 0u;
+    if (r <= H && c <= W) {
+        const uint8_t *p0 = pad + (size_t)r * pitch + c;
+        q = (uint32_t)p0[0] | ((uint32_t)p0[1] << 8) | ((uint32_t)p0[pitch] << 16) | ((uint32_t)p0[pitch + 1] << 24);
+    }
+    quads[(size_t)r * pitch + c] = q;
+}
+
 }  // namespace mvs
 
 using namespace mvs;
@@ -148,7 +164,7 @@ void mvs_destroy(mvs_ctx *ctx)
     DevBuf *bufs[] = {&ctx->main_img, &ctx->side_pads, &ctx->qmats, &ctx->ztab, &ctx->plan, &ctx->upload,
                       &ctx->volume_own, &ctx->depth, &ctx->cost, &ctx->index, &ctx->soup, &ctx->r_zbuf,
                       &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2,
-                      &ctx->cubic_tab, &ctx->flow_arena, &ctx->frame_buf, &ctx->best_parts, &ctx->plan_stats, &ctx->probe_buf, &ctx->filter_sort, &ctx->raster_bins, &ctx->fx_lut};
+                      &ctx->cubic_tab, &ctx->flow_arena, &ctx->frame_buf, &ctx->best_parts, &ctx->plan_stats, &ctx->probe_buf, &ctx->filter_sort, &ctx->raster_bins, &ctx->fx_lut, &ctx->side_quads};
     for (int i = 0; i < 2; i++)
         if (ctx->flow_graph[i]) (void)hipGraphExecDestroy(ctx->flow_graph[i]);
     for (DevBuf *b : bufs)
@@ -258,6 +274,7 @@ int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const 
         if (rc) return rc;
         if ((rc = ensure(ctx, ctx->upload, P))) return rc;
         if ((rc = ensure(ctx, ctx->qmats, sizeof(float) * 12 * nviews))) return rc;
+        if ((rc = ensure(ctx, ctx->side_quads, ctx->pad_slab * nviews * sizeof(uint32_t) + 256))) return rc;
         for (int v = 0; v < nviews; v++) {
             if (!side_frames[v]) return fail(ctx, MVS_EINVAL, "mvs_sweep_set_views: side_frames[%d] is null", v);
             view_matrix(ctx->main_cam, side_cams + 16 * v, W, H, ctx->q_host.data() + 12 * v);
@@ -266,6 +283,8 @@ int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const 
             pad_wrap_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)ctx->upload.ptr,
                                                           (uint8_t *)ctx->side_pads.ptr + ctx->pad_slab * v, W, H,
                                                           ctx->pad_pitch);
+            quad_image_kernel<<<dim3(div_up(ctx->pad_pitch, 256), H + 2), 256, 0, ctx->stream>>>(
+                (const uint8_t *)ctx->side_pads.ptr + ctx->pad_slab * v, (uint32_t *)ctx->side_quads.ptr + ctx->pad_slab * v, W, H, ctx->pad_pitch);
             MVS_HIP(ctx, hipGetLastError());
             MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging buffer is reused per view
         }

@@ -52,6 +52,7 @@ struct mvs_ctx {
     bool have_main = false, have_views = false, have_planes = false;
     bool plan_valid = false;         // region plan matches current (views, planes)
     int sampler = MVS_SAMPLER_FIXED;  // arithmetic contract of the sweep's texture fetch (mvs_sweep_set_sampler)
+    mvs::DevBuf side_quads;          // fixed sampler: quad image of every padded side view (4 bytes per texel), built by mvs_sweep_set_views
     mvs::DevBuf fx_lut;              // fixed sampler: 32 x 32 table of packed 8-bit bilinear weights
     int plan_shape = 2;              // what the plan was made for: 1 = exact sampler, 2 px x 32 planes; 2 = exact, 4 px x 16 planes; 3 = fixed sampler
     bool plan_forced = false;        // plan made with the 4 x 16 shape forced (timing experiments)

@@ -29,7 +29,8 @@ constexpr int FX_LUT_DW = 32;     // of which the first 32 hold the weight-table
 constexpr int FX_MAX_RW = FX_ROW_DW - FX_LUT_DW;  // 224 quads
 constexpr float FX_MAGIC = 12582912.0f;            // 1.5 * 2^23: floats in [2^23, 2^24) have ulp 1
 constexpr int FX_TILE_H = 8, FX_PC = 16, FX_NPX = 2;  // 64x8-pixel tiles, 16 planes per chunk: 32 accumulators per thread
-constexpr int FX_GS = 8;          // samples per software-pipeline group
+constexpr int FX_GS = 4;          // samples per software-pipeline group
+constexpr int FX_VB = 64;         // views per batch of LDS-resident per-view constants
 constexpr int FX_WG_PER_CU = 4;   // launch bound (waves per SIMD): 128 VGPRs, 36 KiB of LDS
 
 enum FxMode : unsigned { FX_SKIP = 0, FX_FAST = 1, FX_BORDER = 2, FX_GENERIC = 3 };
@@ -173,26 +174,22 @@ __global__ __launch_bounds__(256) void plan_regions_fx(SweepParams p, uint2 *__r
 // ------------------------------------------------------------------------------------------------------
 // tiled kernel
 // ------------------------------------------------------------------------------------------------------
-// Stage quads [x0, x0+rw) x [y0, y0+rh) of the padded side image: a unit is 4 quads of one region row = two aligned dword
-// loads from each of two image rows, four byte permutes (v_alignbit_b32 for the quad that straddles the dwords) and one
-// ds_write_b128.
-__device__ __forceinline__ void stage_region_fx(const uint8_t *__restrict__ pad, int pitch, int x0, int y0, int rw, int rh, uint32_t *__restrict__ lds)
+// Stage quads [x0, x0+rw) x [y0, y0+rh) of a view's quad image: one global_load_lds_dwordx4 per region row (each active lane
+// copies 4 quads = 16 bytes straight into LDS; the destination is the row's base + lane * 16, hence no register, no shuffle).
+// Rows are dealt to the four wavefronts; completion is awaited by the caller's __syncthreads() (it drains vmcnt).
+// The 32 LDS rows are a ring: region row ry lives in LDS row (base + ry) mod 32 -- the sampler's address mask wraps the same way --
+// so the NEXT view's region is requested into the rows behind the current one while the current one is being sampled.
+__device__ __forceinline__ void stage_region_fx(const uint32_t *__restrict__ quads, int pitch, int x0, int y0, int rw, int rh, int base,
+                                                uint32_t *__restrict__ lds)
 {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int units = rw >> 2;
-    const int total = units * rh;
-    const float inv_units = 1.0f / (float)units;
-    for (int u = threadIdx.x; u < total; u += 256) {
-        const int ry = (int)(((float)u + 0.5f) * inv_units);  // exact for u < 2^16 (never within rounding distance of an integer)
-        const int ux = u - ry * units;
-        const uint8_t *r0 = pad + (size_t)(y0 + ry) * pitch + x0 + 4 * ux;
-        const uint32_t d0 = *(const uint32_t *)r0, d1 = *(const uint32_t *)(r0 + 4);
-        const uint32_t e0 = *(const uint32_t *)(r0 + pitch), e1 = *(const uint32_t *)(r0 + pitch + 4);
-        uint4 q;
-        q.x = __builtin_amdgcn_perm(e0, d0, 0x05040100u);
-        q.y = __builtin_amdgcn_perm(e0, d0, 0x06050201u);
-        q.z = __builtin_amdgcn_perm(e0, d0, 0x07060302u);
-        q.w = __builtin_amdgcn_perm(__builtin_amdgcn_alignbit(e1, e0, 24), __builtin_amdgcn_alignbit(d1, d0, 24), 0x05040100u);
-        *(uint4 *)(lds + ry * FX_ROW_DW + FX_LUT_DW + 4 * ux) = q;
+    const uint32_t *src = quads + (size_t)y0 * pitch + x0 + 4 * lane;
+    for (int ry = wave; ry < rh; ry += 4) {
+        if (lane < units)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)ry * pitch),
+                                             (__attribute__((address_space(3))) void *)(lds + ((base + ry) & (FX_ROWS - 1)) * FX_ROW_DW + FX_LUT_DW), 16, 0, 0);
     }
 }
 
@@ -205,8 +202,9 @@ __device__ __forceinline__ void sample_range_fx(const Affine &A, float bx, float
                                                 float offy, uint32_t lds_base, uint32_t Im255, uint32_t (&acc)[FX_PC])
 {
     static_assert(KN % FX_GS == 0, "plane range must be a multiple of the group size");
-    uint32_t la[2][FX_GS], ta[2][FX_GS];
-    auto address_stage = [&](int g, int buf) {
+    uint32_t la[FX_GS], ta[FX_GS];      // byte addresses of the group whose reads are issued next
+    uint32_t lw[2][FX_GS], lq[2][FX_GS];  // weights and texel quads, double-buffered: group g is consumed while g + 1 is in flight
+    auto address_stage = [&](int g) {
 #pragma unroll
         for (int i = 0; i < FX_GS; i += 2) {
             const f32x2 z = {zc[K0 + g * FX_GS + i], zc[K0 + g * FX_GS + i + 1]};
@@ -227,34 +225,34 @@ __device__ __forceinline__ void sample_range_fx(const Affine &A, float bx, float
             const float tx0 = Tx.x, tx1 = Tx.y, ty0 = Ty.x, ty1 = Ty.y;
             const uint32_t P0 = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, ty0), __builtin_bit_cast(uint32_t, tx0), 0x05010400u);
             const uint32_t P1 = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, ty1), __builtin_bit_cast(uint32_t, tx1), 0x05010400u);
-            la[buf][i] = ((P0 >> 1) & 0x7c7cu) + lds_base;
-            ta[buf][i] = ((P0 >> 14) & 0x7ffcu) + lds_base;
-            la[buf][i + 1] = ((P1 >> 1) & 0x7c7cu) + lds_base;
-            ta[buf][i + 1] = ((P1 >> 14) & 0x7ffcu) + lds_base;
+            la[i] = ((P0 >> 1) & 0x7c7cu) + lds_base;
+            ta[i] = ((P0 >> 14) & 0x7ffcu) + lds_base;
+            la[i + 1] = ((P1 >> 1) & 0x7c7cu) + lds_base;
+            ta[i + 1] = ((P1 >> 14) & 0x7ffcu) + lds_base;
         }
     };
     auto issue_reads = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < FX_GS; i++) {
-            asm volatile("ds_read_b32 %0, %0" : "+v"(la[buf][i]));
-            asm volatile("ds_read_b32 %0, %0 offset:128" : "+v"(ta[buf][i]));
+            asm volatile("ds_read_b32 %0, %1" : "=v"(lw[buf][i]) : "v"(la[i]));
+            asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(lq[buf][i]) : "v"(ta[i]));
         }
     };
-    address_stage(0, 0);
+    address_stage(0);
     issue_reads(0);
 #pragma unroll
     for (int g = 0; g < KN / FX_GS; g++) {
         const int buf = g & 1;
-        if (g + 1 < KN / FX_GS) address_stage(g + 1, buf ^ 1);
+        if (g + 1 < KN / FX_GS) address_stage(g + 1);
+        // the loaded registers and the next group's addresses are operands: neither the consumers nor that address stage can cross the wait
+        static_assert(FX_GS == 4, "the operand list of the wait below names every register of a group");
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(la[buf][0]), "+v"(la[buf][1]), "+v"(la[buf][2]), "+v"(la[buf][3]), "+v"(la[buf][4]), "+v"(la[buf][5]), "+v"(la[buf][6]),
-                       "+v"(la[buf][7]), "+v"(ta[buf][0]), "+v"(ta[buf][1]), "+v"(ta[buf][2]), "+v"(ta[buf][3]), "+v"(ta[buf][4]), "+v"(ta[buf][5]),
-                       "+v"(ta[buf][6]), "+v"(ta[buf][7]), "+v"(la[buf ^ 1][0]), "+v"(ta[buf ^ 1][0]), "+v"(la[buf ^ 1][FX_GS - 1]),
-                       "+v"(ta[buf ^ 1][FX_GS - 1]));
+                     : "+v"(lw[buf][0]), "+v"(lw[buf][1]), "+v"(lw[buf][2]), "+v"(lw[buf][3]), "+v"(lq[buf][0]), "+v"(lq[buf][1]), "+v"(lq[buf][2]),
+                       "+v"(lq[buf][3]), "+v"(la[0]), "+v"(ta[0]), "+v"(la[FX_GS - 1]), "+v"(ta[FX_GS - 1]));
         if (g + 1 < KN / FX_GS) issue_reads(buf ^ 1);
 #pragma unroll
         for (int i = 0; i < FX_GS; i++) {
-            const uint32_t dot = __builtin_amdgcn_udot4(ta[buf][i], la[buf][i], 0u, false);
+            const uint32_t dot = __builtin_amdgcn_udot4(lq[buf][i], lw[buf][i], 0u, false);
             acc[K0 + g * FX_GS + i] = sad_u16(dot, Im255, acc[K0 + g * FX_GS + i]);
         }
     }
@@ -263,7 +261,7 @@ __device__ __forceinline__ void sample_range_fx(const Affine &A, float bx, float
 struct FxRegion {
     float offx, offy;            // magic + 4 - 256 * region origin: T - magic is the position relative to the region, in 1/256 texel
     float lox, hix, loy, hiy;    // in-frame test on T (strict)
-    float cmaxx, cmaxy;          // clamp range of T for masked samples: [magic, cmax]
+    float cminx, cminy, cmaxx, cmaxy;  // clamp range of T for masked samples (the staged quads, in ring coordinates)
 };
 
 // the same planes with the in-frame test per sample (region mode BORDER, for the wavefronts that straddle the frame edge)
@@ -278,7 +276,7 @@ __device__ __forceinline__ void sample_range_fx_checked(const Affine &A, float b
         const float r256 = rcp_rn(sw) * 256.0f;
         const float Tx = __builtin_fmaf(sx, r256, rg.offx), Ty = __builtin_fmaf(sy, r256, rg.offy);
         const bool ok = Tx > rg.lox && Tx < rg.hix && Ty > rg.loy && Ty < rg.hiy;
-        const float Txc = __builtin_amdgcn_fmed3f(Tx, FX_MAGIC, rg.cmaxx), Tyc = __builtin_amdgcn_fmed3f(Ty, FX_MAGIC, rg.cmaxy);
+        const float Txc = __builtin_amdgcn_fmed3f(Tx, rg.cminx, rg.cmaxx), Tyc = __builtin_amdgcn_fmed3f(Ty, rg.cminy, rg.cmaxy);
         const uint32_t P = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, Tyc), __builtin_bit_cast(uint32_t, Txc), 0x05010400u);
         const uint32_t w = lds[((P >> 1) & 0x7c7cu) >> 2];
         const uint32_t quad = lds[(((P >> 14) & 0x7ffcu) >> 2) + FX_LUT_DW];
@@ -295,9 +293,13 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
 {
     constexpr int NPX = FX_NPX, PC = FX_PC, TILE_H = FX_TILE_H;
     // one object, so the texel image sits at LDS address 0 and its byte offsets are the ds_read addresses
-    __shared__ __attribute__((aligned(16))) uint32_t smem[FX_ROWS * FX_ROW_DW + (FUSED ? 2 * 256 * NPX : 0)];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[FX_ROWS * FX_ROW_DW + FX_VB * 14 + (FUSED ? 2 * 256 * NPX : 0)];
     uint32_t *lds = smem;
-    uint2 *best_state = (uint2 *)(smem + FX_ROWS * FX_ROW_DW);  // (packed best cell, best index) per (pixel j, thread)
+    // per-view constants of a batch of up to FX_VB views: view matrix (12 floats) and this chunk's region descriptor (2 dwords).
+    // Read from here, a view's constants cost an LDS round trip (~100 cycles) instead of a dependent global load (~1 us) per region.
+    float *qtab = (float *)(smem + FX_ROWS * FX_ROW_DW);
+    uint2 *dtab = (uint2 *)(smem + FX_ROWS * FX_ROW_DW + FX_VB * 12);
+    uint2 *best_state = (uint2 *)(smem + FX_ROWS * FX_ROW_DW + FX_VB * 14);  // (packed best cell, best index) per (pixel j, thread)
 
     const int band_tile = (p.debug & 2) ? ((int)blockIdx.x < p.tiles_x * p.tyn ? (int)blockIdx.x : -1) : grouped_tile(blockIdx.x, p.tiles_x, p.tyn);
     if (band_tile < 0) return;
@@ -346,16 +348,32 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
         for (int j = 0; j < NPX; j++) lane_views[j] = 0u;
         const uint2 *plan = p.plan + ((size_t)tile * p.nchunks + chunk) * p.V;
 
-        for (int v = p.v0; v < p.v0 + p.vcount; v++) {
-            const uint2 desc = plan[v];
+        // Region pipeline of this chunk.  `base` = first LDS ring row of the region being sampled; `ahead` = the region of the view
+        // at hand was requested during the previous view (its copy is in flight or has landed).
+        int base = 0;
+        bool ahead = false;
+        const int vend = p.v0 + p.vcount;
+        for (int v = p.v0; v < vend; v++) {
+            const int vi = (v - p.v0) & (FX_VB - 1);
+            if (vi == 0) {  // next batch of per-view constants (wave-uniform branch; no region is in flight here: ahead == false)
+                __syncthreads();
+                const int nb = min(FX_VB, vend - v);
+                for (int i = threadIdx.x; i < nb * 12; i += 256) qtab[i] = p.Q[12 * v + i];
+                for (int i = threadIdx.x; i < nb; i += 256) dtab[i] = plan[v + i];
+                __syncthreads();
+            }
+            const uint2 desc = dtab[vi];
             const unsigned mode = (unsigned)__builtin_amdgcn_readfirstlane((int)((desc.y >> 16) & 7u));
             if (mode == FX_SKIP) continue;
-            float q[12];
-#pragma unroll
-            for (int i = 0; i < 12; i++) q[i] = uniform_f(p.Q[12 * v + i]);
+            float q[12];  // wave-uniform values, kept in VGPRs: they are only ever VALU operands (v_fma allows one SGPR, and that is z)
+            {
+                const float4 qa = *(const float4 *)(qtab + 12 * vi), qb = *(const float4 *)(qtab + 12 * vi + 4), qc = *(const float4 *)(qtab + 12 * vi + 8);
+                q[0] = qa.x; q[1] = qa.y; q[2] = qa.z; q[3] = qa.w; q[4] = qb.x; q[5] = qb.y; q[6] = qb.z; q[7] = qb.w;
+                q[8] = qc.x; q[9] = qc.y; q[10] = qc.z; q[11] = qc.w;
+            }
             const float bx = q[2], by = q[6], bw = q[10];
-            const uint8_t *pad = p.pads + p.pad_slab * v;
             if (mode == FX_GENERIC) {
+                const uint8_t *pad = p.pads + p.pad_slab * v;
 #pragma unroll
                 for (int j = 0; j < NPX; j++) {
                     if (ok[j]) {
@@ -370,24 +388,50 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
             const int y0 = __builtin_amdgcn_readfirstlane((int)(desc.x >> 16));
             const int rw = __builtin_amdgcn_readfirstlane((int)(desc.y & 0xffu));
             const int rh = __builtin_amdgcn_readfirstlane((int)((desc.y >> 8) & 0xffu));
-            __syncthreads();  // all reads of the previous region are done
-            if (!(p.debug & 1)) stage_region_fx(pad, p.pitch, x0, y0, rw, rh, lds);
-            __syncthreads();
+            if (!ahead) {
+                __syncthreads();  // every wavefront is done with the region these rows held
+                base = 0;
+                if (!(p.debug & 1)) stage_region_fx(p.quads + p.pad_slab * v, p.pitch, x0, y0, rw, rh, base, lds);
+            }
+            __syncthreads();  // this view's region has landed (the barrier drains vmcnt) and the previous one is no longer read
+            // Optional (debug bit 3; off by default): request the next staged view's region into the ring rows behind this one, if
+            // both fit, so its copy overlaps this view's sampling and one barrier per region goes away.  Measured 2 % SLOWER at c3
+            // (1.707 vs 1.671 ms) and neutral at c1 / c2: at 4 workgroups per CU the other workgroups already cover the copy.
+            ahead = false;
+            int nbase = 0;
+            if (p.debug & 8) {
+                for (int vn = v + 1; vn < vend && ((vn - p.v0) & (FX_VB - 1)) != 0; vn++) {  // within this batch of constants
+                    const uint2 dn = dtab[(vn - p.v0) & (FX_VB - 1)];
+                    const unsigned mn = (unsigned)__builtin_amdgcn_readfirstlane((int)((dn.y >> 16) & 7u));
+                    if (mn != FX_FAST && mn != FX_BORDER) continue;
+                    const int rhn = __builtin_amdgcn_readfirstlane((int)((dn.y >> 8) & 0xffu));
+                    if (rh + rhn <= FX_ROWS) {
+                        nbase = (base + rh) & (FX_ROWS - 1);
+                        if (!(p.debug & 1))
+                            stage_region_fx(p.quads + p.pad_slab * vn, p.pitch, __builtin_amdgcn_readfirstlane((int)(dn.x & 0xffffu)),
+                                            __builtin_amdgcn_readfirstlane((int)(dn.x >> 16)), __builtin_amdgcn_readfirstlane((int)(dn.y & 0xffu)), rhn, nbase, lds);
+                        ahead = true;
+                    }
+                    break;
+                }
+            }
             FxRegion rg;
             rg.offx = FX_MAGIC + 4.0f - 256.0f * (float)x0;
-            rg.offy = FX_MAGIC + 4.0f - 256.0f * (float)y0;
-            const bool wconst = bw == 0.0f && !(p.debug & 4);  // wave-uniform: plane-independent w
+            rg.offy = FX_MAGIC + 4.0f - 256.0f * (float)(y0 - base);  // region row ry sits in ring row base + ry (mod 32: the address mask wraps)
+            const bool wconst = uniform_f(bw) == 0.0f && !(p.debug & 4);  // wave-uniform: plane-independent w
 #pragma unroll
             for (int j = 0; j < NPX; j++) {
                 const Affine A = view_affine(q, xn, yn[j]);
                 bool checked = false;
                 if (mode == FX_BORDER) {
                     rg.lox = FX_MAGIC + 132.0f - 256.0f * (float)x0;
-                    rg.loy = FX_MAGIC + 132.0f - 256.0f * (float)y0;
+                    rg.loy = FX_MAGIC + 132.0f - 256.0f * (float)(y0 - base);
                     rg.hix = rg.lox + 256.0f * (float)p.W;
                     rg.hiy = rg.loy + 256.0f * (float)p.H;
+                    rg.cminx = FX_MAGIC;
+                    rg.cminy = FX_MAGIC + (float)(256 * base);
                     rg.cmaxx = FX_MAGIC + (float)(256 * rw - 1);
-                    rg.cmaxy = FX_MAGIC + (float)(256 * rh - 1);
+                    rg.cmaxy = rg.cminy + (float)(256 * rh - 1);
                     // A pixel's samples over the chunk lie on a segment of the side image, monotone in z (w > 0 in the whole box): if
                     // both end planes are inside the frame by more than one 1/256-texel step (far above the f32 noise of the
                     // coordinates), every plane between them is in frame.  One wavefront-uniform decision per (row, view).
@@ -419,6 +463,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                     sample_range_fx<0, PC, false>(A, bx, by, bw, 0.0f, zc, rg.offx, rg.offy, lds_base, Im255[j], acc[j]);
                 }
             }
+            base = nbase;
         }
 
 #pragma unroll

@@ -30,6 +30,7 @@ struct SweepParams {
     const uint8_t *__restrict__ pads;
     size_t pad_slab;
     int pitch;
+    const uint32_t *__restrict__ quads;  // fixed sampler: per view (H+2) x pitch packed bilinear footprints (t00, t01, t10, t11); pad_slab dwords per view
     int W, H, D, V;
     int v0, vcount;
     const float *__restrict__ Q;  // V * 12
@@ -49,7 +50,7 @@ struct SweepParams {
     int *__restrict__ plan_stats;  // [0] regions too large for LDS, [1] regions not skipped (planner output)
     int cps;             // plane chunks per workgroup: blockIdx.y selects chunks [chunk0 + y*cps, +cps) of a tile
     uint2 *__restrict__ part;  // plane-split launches with fused depth selection: [gridDim.y][P] partial bests
-    int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: linear tile order; bit 2: never use the plane-independent-w path)
+    int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: linear tile order; bit 2: never use the plane-independent-w path; bit 3: exact sampler: force the 4 x 16 shape, fixed sampler: prefetch the next region into the LDS ring)
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -146,6 +147,7 @@ inline int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount, int til
     p.main_img = (const uint8_t *)ctx->main_img.ptr;
     p.pads = (const uint8_t *)ctx->side_pads.ptr;
     p.pad_slab = ctx->pad_slab;
+    p.quads = (const uint32_t *)ctx->side_quads.ptr;
     p.pitch = ctx->pad_pitch;
     p.W = ctx->W;
     p.H = ctx->H;

@@ -1,0 +1,35 @@
+"""In-process A/B timings of the fixed-sampler sweep at c3 (timing experiments only: some variants give wrong results).
+debug bits (flags >> 8): 1 skip LDS staging, 2 linear tile order, 4 never use the plane-independent-w path; flags >> 16: forced plane splits"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
+import numpy as np
+import torch  # noqa: F401 (HIP runtime first)
+import mvs_amd
+from mvs_amd import synth
+
+cfg = {"c1": (640, 480, 32, 4), "c2": (1280, 720, 64, 8), "c3": (1920, 1080, 128, 16)}[sys.argv[1] if len(sys.argv) > 1 else "c3"]
+W, H, D, V = cfg
+mc, mi, sc, si, gt = synth.make_views(W, H, V, radius=0.15)
+both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+
+
+def timeit(ctx, flags, n=10):
+    for _ in range(3):
+        ctx.sweep_run(0, V, flags)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ctx.sweep_run(0, V, flags)
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for sampler in ("fixed", "exact"):
+    with mvs_amd.Context(W, H, sampler=sampler) as ctx:
+        ctx.sweep_set(mc, mi, sc, si, D)
+        print(sampler, "volume+fused %.3f ms" % timeit(ctx, both), " fused only %.3f" % timeit(ctx, mvs_amd.MVS_SWEEP_FUSED_ARGMIN),
+              " volume only %.3f" % timeit(ctx, mvs_amd.MVS_SWEEP_VOLUME), " no staging %.3f" % timeit(ctx, both | (1 << 8)),
+              " general %.3f" % timeit(ctx, both | (4 << 8)), " general, no staging %.3f" % timeit(ctx, both | (5 << 8)),
+              " linear tiles %.3f" % timeit(ctx, both | (2 << 8)), " with look-ahead %.3f" % timeit(ctx, both | (8 << 8)) if sampler == "fixed" else "")
+        print("   splits:", " ".join("%d: %.3f" % (s, timeit(ctx, both | (s << 16))) for s in (1, 2, 4, 8)))
