@@ -7,15 +7,18 @@ the BASELINE config already resident in HBM when the time
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--shard frames|views|rows]
 
-N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py ...`.
-Sharding (DESIGN.md "multi-GPU"):
-  frames (default): every rank processes its own main frame (the reference's independent `fa` loop,
-                    recon.cpp:65); no data-path collective; weak scaling.
-  views:            the V side views are split across ranks, the packed u32 volume is summed with an
-                    RCCL all-reduce (exact: integer cells), every rank selects depth; strong scaling.
-  rows:             the pixel rows of ONE main view are split into bands, one per rank (rows are independent,
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py ...`; without a launcher
+`--gpus N` is refused (one process drives one GPU).  The N > 1 line is STRONG scaling of ONE main view at the named config:
+  rows (default):   the pixel rows of the main view are split into bands, one per rank (rows are independent,
                     SURVEY 8e-2); each rank sweeps its band over all views, the depth bands are all-gathered
-                    (4 B per pixel in total); strong scaling without a volume exchange.
+                    (4 B per pixel in total).  `value`.
+  views:            the north_star's split: the V side views are divided over the ranks and the packed u32 volume is summed
+                    over xGMI (exact: integer cells) -- all-reduce + depth selection on every rank, or reduce-scatter by plane
+                    slices + partial selection + all-gather of 8-byte partials.  Both are timed in the same run and reported
+                    under config.alternatives with their collective bytes (or select one with --shard views --collective ...).
+  frames:           only on request: every rank processes its own main frame (the reference's independent `fa` loop,
+                    recon.cpp:65); no data-path collective; weak scaling.
+Every strong-scaling mode is checked in-process against the single-GPU depth map of the same view (CRC).
 """
 import argparse
 import json
@@ -40,7 +43,7 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(cfg, main_cam, main_img, side_cams, sides):
+def cpu_baseline(cfg, main_cam, main_img, side_cams, sides, sampler="fixed"):
     """the CPU oracle (a port: the reference itself cannot be built here) on a bounded sample of the
     same workload: all pixels and views, 8 of the D planes, all host cores"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -54,14 +57,14 @@ def cpu_baseline(cfg, main_cam, main_img, side_cams, sides):
     z_lo = -1.0 + 2.0 * d0 / D
     z_hi = -1.0 + 2.0 * (d0 + nplanes) / D
     t0 = time.perf_counter()
-    o.sweep(main_cam, main_img, side_cams, sides, nplanes, z_lo, z_hi, nthreads=cores)
+    o.sweep(main_cam, main_img, side_cams, sides, nplanes, z_lo, z_hi, nthreads=cores, sampler=sampler)
     dt = time.perf_counter() - t0
     samples = float(W) * H * nplanes * V
     # the reference itself is single-threaded: the same port on ONE thread, two mid-range planes (a few seconds)
     n1 = min(2, D)
     d1 = (D - n1) // 2
     t0 = time.perf_counter()
-    o.sweep(main_cam, main_img, side_cams, sides, n1, -1.0 + 2.0 * d1 / D, -1.0 + 2.0 * (d1 + n1) / D, nthreads=1)
+    o.sweep(main_cam, main_img, side_cams, sides, n1, -1.0 + 2.0 * d1 / D, -1.0 + 2.0 * (d1 + n1) / D, nthreads=1, sampler=sampler)
     dt1 = time.perf_counter() - t0
     samples1 = float(W) * H * n1 * V
     return {
@@ -157,8 +160,8 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
         sweep_bytes = float(P) * (V + 1) + 12.0 * P     # depth only: no volume is materialised by mvs_sweep(volume=NULL)
         achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         print(json.dumps({
-            "metric": "cost-volume samples/sec (pixels x planes x views)", "value": float(P) * D * V * args.gpus / (dt / args.steps),
-            "unit": "samples/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "metric": "cost-volume samples/sec (pixels x planes x views)", "value": float(P) * D * V * world / (dt / args.steps),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic frames on the cameras of tracks/zatisi.yaml" + (" [TEST HOOK: ranks share one GPU over gloo]" if same_device else ""),
             "config": {"workload": "c5: zatisi.yaml %d frames, 640x480, %d planes, %d side views per main frame, one main frame per step "
@@ -179,13 +182,19 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--shard", default="frames", choices=["frames", "views", "rows"])
+    ap.add_argument("--shard", default=None, choices=["frames", "views", "rows"],
+                    help="N > 1: how the work is split (default rows: strong scaling of ONE main view, depth rows all-gathered; the "
+                         "north_star's views + all-reduce and views + reduce-scatter are timed in the same run and reported under "
+                         "config.alternatives).  frames = one main frame per rank (weak scaling, no collective), only on request")
+    ap.add_argument("--sampler", default="fixed", choices=["fixed", "exact"],
+                    help="texture-fetch arithmetic (include/mvs.h): fixed = 1/32-texel positions + 8-bit weight table (library default), "
+                         "exact = f32 bilinear rounded to u8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused", action="store_true", help="also time the no-volume variant (depth only)")
     ap.add_argument("--separate-argmin", action="store_true",
                     help="single GPU: run argmin_volume as its own pass over the volume (the multi-GPU views pipeline)")
     ap.add_argument("--collective", default="allreduce", choices=["allreduce", "reduce_scatter"],
-                    help="views sharding: all-reduce the whole volume, or reduce-scatter it by planes, select a partial best per rank "
+                    help="with --shard views: all-reduce the whole volume, or reduce-scatter it by planes, select a partial best per rank "
                          "and all-gather the 8-byte partials (half the bytes over xGMI; needs planes divisible by the rank count)")
     ap.add_argument("--plane-groups", type=int, default=4,
                     help="views sharding: all-reduce the volume in this many plane groups, overlapped with the sweep")
@@ -198,126 +207,71 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world == 1 and args.gpus > 1:
+        # one process drives one GPU: without a launcher only GPU 0 would work and the line would claim N of them
+        raise SystemExit("bench.py --gpus %d needs one process per GPU: launch it as\n  python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d --steps %d --warmup %d"
+                         % (args.gpus, args.gpus, args.gpus, args.steps, args.warmup))
+    args.gpus = world   # always report the ranks that actually ran
+    same_device = os.environ.get("MVS_BENCH_SAME_DEVICE") == "1"
 
     import numpy as np
     import torch  # first: libmvs_hip.so must share torch's HIP runtime (same soname)
+    dist = None
+    if world > 1:
+        # the process group comes up before anything touches the GPU
+        import torch.distributed as dist
+        # MVS_BENCH_SAME_DEVICE=1 (test hook): all ranks share GPU 0 and talk over gloo, so the multi-rank step logic can be
+        # exercised on a one-GPU box (RCCL refuses two ranks on one device); never used for reported numbers
+        dist.init_process_group("gloo" if same_device else "nccl")
     import mvs_amd
     from mvs_amd import synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    # MVS_BENCH_SAME_DEVICE=1 (test hook): all ranks share GPU 0 and talk over gloo, so the multi-rank step logic can be
-    # exercised on a one-GPU box (RCCL refuses two ranks on one device); never used for reported numbers
-    same_device = os.environ.get("MVS_BENCH_SAME_DEVICE") == "1"
     if same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if same_device:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = CONFIGS[args.config]
     W, H, D, V = cfg
     P = W * H
     if args.config == "c5":
         return run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_device)
+    shard = args.shard or ("rows" if world > 1 else "frames")
     # every rank renders the same deterministic scene; in `frames` mode rank r uses a different main
     # frame (a ring rotated by r positions) so the ranks do not process identical data
     radius = 0.15
+    seed_off = rank if shard == "frames" else 0
     if args.data == "scene":
-        main_cam, main_img, side_cams, sides, gt = synth.make_views(W, H, V, radius=radius,
-                                                                    seed=synth.SEED_SCENE + (rank if args.shard == "frames" else 0))
+        main_cam, main_img, side_cams, sides, gt = synth.make_views(W, H, V, radius=radius, seed=synth.SEED_SCENE + seed_off)
     else:
-        main_cam, main_img, side_cams, sides = synth.noise_views(W, H, V, seed=synth.SEED_NOISE + (rank if args.shard == "frames" else 0))
+        main_cam, main_img, side_cams, sides = synth.noise_views(W, H, V, seed=synth.SEED_NOISE + seed_off)
         gt = None
 
     # one explicit (non-default) stream for kernels AND collectives: torch's default stream has handle 0, which the ABI
-    # reads as "use the context's own stream" -- the RCCL all-reduce must be ordered behind the sweep on the same stream
+    # reads as "use the context's own stream" -- the RCCL collectives must be ordered behind the sweep on the same stream
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    ctx = mvs_amd.Context(W, H, local_rank)
+    ctx = mvs_amd.Context(W, H, local_rank, sampler=args.sampler)
     ctx.set_stream(stream.cuda_stream)
     ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+    both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    sweep_kernel = "sweep_fx_tiled" if args.sampler == "fixed" else "sweep_tiled"
 
     from mvs_amd import dist as mdist
-    if args.shard == "views" and world > 1:
-        v0, vn = mdist.view_shard(V, rank, world)
-    else:
-        v0, vn = 0, V
     vol_t = torch.empty(D * P, dtype=torch.int32, device="cuda")
     ctx.sweep_use_volume(vol_t.data_ptr(), vol_t.numel() * 4)
-
     groups = mdist.plane_groups(D, args.plane_groups, ctx.plane_granularity())
     comm_stream = torch.cuda.Stream()
     bands = mdist.row_bands(H, world, ctx.row_granularity())
-    if args.shard == "rows" and world > 1:
-        r0, rn = bands[rank]
-        tallest = max(n for _, n in bands)
-        ctx.sweep_run_rows(r0, rn, 0, V, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)  # allocates the outputs
-        depth_t = torch.as_tensor(ctx.depth_device_array(), device="cuda")
-        band_pad = torch.zeros((tallest, W), dtype=torch.float32, device="cuda")
-        band_cat = torch.empty((world * tallest, W), dtype=torch.float32, device="cuda")   # concatenated form: every backend
-        band_all = band_cat.view(world, tallest, W)
+    v0, vn = mdist.view_shard(V, rank, world)
 
-    rs = args.shard == "views" and world > 1 and args.collective == "reduce_scatter"
-    if rs:
-        if D % world:
-            raise SystemExit("--collective reduce_scatter needs the plane count (%d) divisible by the ranks (%d)" % (D, world))
-        slice_planes = D // world
-        slice_t = torch.empty(slice_planes * P, dtype=torch.int32, device="cuda")
-        part_t = torch.empty(P, dtype=torch.int64, device="cuda")
-        parts_t = torch.empty(world * P, dtype=torch.int64, device="cuda")
-
-    def step():
-        if rs:
-            # every rank sweeps its views over all planes; the volume is reduce-scattered by plane slices (rank r receives the
-            # summed cells of planes [r D/G, (r+1) D/G)), each rank selects a partial best over its slice, the 8-byte partials are
-            # all-gathered and merged in plane order -- the same depth map as all-reduce + argmin, with half the bytes on the links
-            ctx.sweep_run(v0, vn, mvs_amd.MVS_SWEEP_VOLUME)
-            if same_device:   # gloo has no reduce-scatter: emulate it (test hook only)
-                dist.all_reduce(vol_t)
-                slice_t.copy_(vol_t[rank * slice_planes * P:(rank + 1) * slice_planes * P])
-            else:
-                dist.reduce_scatter_tensor(slice_t, vol_t)
-            ctx.sweep_argmin_partial(slice_t.data_ptr(), rank * slice_planes, slice_planes, part_t.data_ptr())
-            dist.all_gather_into_tensor(parts_t, part_t)
-            ctx.sweep_combine_partials(parts_t.data_ptr(), world)
-        elif args.shard == "views" and world > 1:
-            # sweep plane group g on the compute stream while group g-1 is summed over xGMI on the comm stream
-            # (RCCL, exact: packed integer cells); depth selection waits for the last group
-            works = []
-            for first, count in groups:
-                ctx.sweep_run_planes(v0, vn, first, count, mvs_amd.MVS_SWEEP_VOLUME)
-                ev = torch.cuda.Event()
-                ev.record(stream)
-                comm_stream.wait_event(ev)
-                with torch.cuda.stream(comm_stream):
-                    works.append(dist.all_reduce(vol_t[first * P:(first + count) * P], async_op=True))
-            for w in works:
-                w.wait()  # orders the current (compute) stream behind the collective
-            ctx.sweep_argmin()
-        elif args.shard == "rows" and world > 1:
-            # rows are independent: every rank sweeps its band of the SAME main view over all views and planes (volume
-            # band materialised, depth selected in the kernel); only the depth rows travel (4 B per pixel in total)
-            ctx.sweep_run_rows(r0, rn, 0, V, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
-            band_pad[:rn].copy_(depth_t[r0:r0 + rn])
-            dist.all_gather_into_tensor(band_cat, band_pad)
-            for r, (a, n) in enumerate(bands):
-                if r != rank and n:
-                    depth_t[a:a + n].copy_(band_all[r, :n])
-        elif args.separate_argmin:
-            ctx.sweep_run(v0, vn, mvs_amd.MVS_SWEEP_VOLUME)
-            ctx.sweep_argmin()
-        else:
-            # what mvs_sweep() does on one GPU: the volume is materialised AND the running best plane is kept in
-            # registers, so the volume is never read back
-            ctx.sweep_run(v0, vn, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+    # the single-GPU result of this rank's main view: the strong-scaling shardings must reproduce it bit for bit
+    ctx.sweep_run(0, V, both)
+    depth1 = ctx.sweep_fetch()[0]
+    crc1 = zlib.crc32(np.ascontiguousarray(depth1).tobytes())
+    depth_t = torch.as_tensor(ctx.depth_device_array(), device="cuda")
 
     def barrier():
         torch.cuda.synchronize()
@@ -325,23 +279,115 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ctx.profile_enable(True)
-    ctx.profile_read(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    ms_sum, launches = ctx.profile_read(reset=True)
-    ctx.profile_enable(False)
+    def make_step(mode, collective):
+        """returns (step function, views swept per rank, rows swept by rank 0, collective bytes sent+received per rank and step)"""
+        if mode == "rows" and world > 1:
+            r0, rn = bands[rank]
+            tallest = max(n for _, n in bands)
+            band_pad = torch.zeros((tallest, W), dtype=torch.float32, device="cuda")
+            band_cat = torch.empty((world * tallest, W), dtype=torch.float32, device="cuda")   # concatenated form: every backend
+            band_all = band_cat.view(world, tallest, W)
 
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+            def step():
+                # rows are independent: every rank sweeps its band of the SAME main view over all views and planes (volume band
+                # materialised, depth selected in the kernel); only the depth rows travel (4 B per pixel in total)
+                ctx.sweep_run_rows(r0, rn, 0, V, both)
+                band_pad[:rn].copy_(depth_t[r0:r0 + rn])
+                dist.all_gather_into_tensor(band_cat, band_pad)
+                for r, (a, n) in enumerate(bands):
+                    if r != rank and n:
+                        depth_t[a:a + n].copy_(band_all[r, :n])
+            return step, V, bands[0][1], 4.0 * tallest * W * (world - 1) * 2
+        if mode == "views" and world > 1 and collective == "reduce_scatter":
+            if D % world:
+                raise SystemExit("reduce_scatter needs the plane count (%d) divisible by the ranks (%d)" % (D, world))
+            slice_planes = D // world
+            slice_t = torch.empty(slice_planes * P, dtype=torch.int32, device="cuda")
+            part_t = torch.empty(P, dtype=torch.int64, device="cuda")
+            parts_t = torch.empty(world * P, dtype=torch.int64, device="cuda")
+
+            def step():
+                # every rank sweeps its views over all planes; the volume is reduce-scattered by plane slices (rank r receives the
+                # summed cells of planes [r D/G, (r+1) D/G)), each rank selects a partial best over its slice, the 8-byte partials
+                # are all-gathered and merged in plane order -- the same depth map as all-reduce + argmin, half the bytes on the links
+                ctx.sweep_run(v0, vn, mvs_amd.MVS_SWEEP_VOLUME)
+                if same_device:   # gloo has no reduce-scatter: emulate it (test hook only)
+                    dist.all_reduce(vol_t)
+                    slice_t.copy_(vol_t[rank * slice_planes * P:(rank + 1) * slice_planes * P])
+                else:
+                    dist.reduce_scatter_tensor(slice_t, vol_t)
+                ctx.sweep_argmin_partial(slice_t.data_ptr(), rank * slice_planes, slice_planes, part_t.data_ptr())
+                dist.all_gather_into_tensor(parts_t, part_t)
+                ctx.sweep_combine_partials(parts_t.data_ptr(), world)
+            ring = (world - 1) / world
+            return step, vn, H, (4.0 * P * D * ring + 8.0 * P * world * ring) * 2
+        if mode == "views" and world > 1:
+            def step():
+                # sweep plane group g on the compute stream while group g-1 is summed over xGMI on the comm stream
+                # (RCCL, exact: packed integer cells); depth selection waits for the last group
+                works = []
+                for first, count in groups:
+                    ctx.sweep_run_planes(v0, vn, first, count, mvs_amd.MVS_SWEEP_VOLUME)
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    comm_stream.wait_event(ev)
+                    with torch.cuda.stream(comm_stream):
+                        works.append(dist.all_reduce(vol_t[first * P:(first + count) * P], async_op=True))
+                for w in works:
+                    w.wait()  # orders the current (compute) stream behind the collective
+                ctx.sweep_argmin()
+            return step, vn, H, 4.0 * P * D * 2 * (world - 1) / world * 2
+        if args.separate_argmin:
+            def step():
+                ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
+                ctx.sweep_argmin()
+            return step, V, H, 0.0
+
+        def step():
+            # what mvs_sweep() does on one GPU (and what every rank does for its own main frame in `frames` mode): the volume is
+            # materialised AND the running best plane is kept in registers, so the volume is never read back
+            ctx.sweep_run(0, V, both)
+        return step, V, H, 0.0
+
+    def timed(mode, collective):
+        step, views, rows0, coll_bytes = make_step(mode, collective)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        ms_sum, launches = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        depth = ctx.sweep_fetch()[0]
+        crc = zlib.crc32(np.ascontiguousarray(depth).tobytes())
+        if mode != "frames" and crc != crc1:
+            raise SystemExit("rank %d: %s sharding produced depth crc %08x, the single-GPU sweep of the same view %08x" % (rank, mode, crc, crc1))
+        per_call = len(groups) if (mode == "views" and world > 1 and collective != "reduce_scatter") else 1
+        sweep_ms = ms_sum[mvs_amd.MVS_K_SWEEP] / (max(1, launches[mvs_amd.MVS_K_SWEEP]) / per_call)
+        argmin_ms = ms_sum[mvs_amd.MVS_K_ARGMIN] / max(1, launches[mvs_amd.MVS_K_ARGMIN]) if launches[mvs_amd.MVS_K_ARGMIN] else 0.0
+        return {"dt": dt, "ms_per_step": dt / args.steps * 1e3, "sweep_ms": sweep_ms, "argmin_ms": argmin_ms, "views": views, "rows0": rows0,
+                "collective_bytes_per_rank": coll_bytes, "depth": depth, "crc": crc, "separate": launches[mvs_amd.MVS_K_ARGMIN] > 0}
+
+    primary = timed(shard, args.collective if shard == "views" else None)
+    alternatives = None
+    if world > 1 and args.shard is None and not args.no_extras:
+        alternatives = {}
+        for name, mode, coll in (("views_allreduce", "views", "allreduce"), ("views_reduce_scatter", "views", "reduce_scatter")):
+            if coll == "reduce_scatter" and D % world:
+                continue
+            r = timed(mode, coll)
+            alternatives[name] = {"ms_per_step": r["ms_per_step"], "samples_per_s": float(P) * D * V / (r["dt"] / args.steps), "scaling": "strong",
+                                  "sweep_ms": r["sweep_ms"], "views_per_rank": r["views"], "collective_bytes_per_rank_per_step": r["collective_bytes_per_rank"],
+                                  "depth_crc32": r["crc"]}
 
     fused_ms = None
     if args.fused and world == 1:
@@ -355,10 +401,10 @@ def main():
         fused_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
     # the spec'd ring geometry (parallel axes, centres in the main focal plane) takes the plane-independent-w path
-    # of sample_lds_pair; time the general path on the same data too (undocumented debug bit 2 << 8)
+    # (reciprocal hoisted out of the plane loop); time the general path on the same data too (undocumented debug bit 2 << 8)
     general_ms = None
     if world == 1 and not args.no_extras:
-        gflags = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | (4 << 8)
+        gflags = both | (4 << 8)
         for _ in range(2):
             ctx.sweep_run(0, V, gflags)
         torch.cuda.synchronize()
@@ -367,10 +413,23 @@ def main():
             ctx.sweep_run(0, V, gflags)
         torch.cuda.synchronize()
         general_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        ctx.sweep_run(0, V, both)
+
+    # the one-call entry (host frames in, host depth out: PCIe, padding and planning inside the call) -- reported beside, never as `value`
+    onecall_ms = None
+    if world == 1 and not args.no_extras:
+        octx = mvs_amd.Context(W, H, local_rank, sampler=args.sampler)
+        for _ in range(2):
+            octx.sweep(main_cam, main_img, side_cams, sides, D)
+        t1 = time.perf_counter()
+        n1 = max(3, args.steps // 4)
+        for _ in range(n1):
+            octx.sweep(main_cam, main_img, side_cams, sides, D)
+        onecall_ms = (time.perf_counter() - t1) / n1 * 1e3
+        octx.close()
 
     # sanity: the timed path produced the surface it was rendered from
-    depth, cost, idx, _ = ctx.sweep_fetch()
+    depth = primary["depth"]
     if gt is not None:
         err = np.abs(depth - gt)[16:-16, 16:-16]
         depth_ok = bool(np.median(err) <= 2.0 / D)
@@ -378,56 +437,59 @@ def main():
         depth_ok = None
 
     if rank == 0:
-        frames_total = args.gpus if args.shard == "frames" else 1
+        frames_total = world if shard == "frames" else 1
         samples_per_step = float(P) * D * V * frames_total
-        ms_per_step = dt / args.steps * 1e3
-        sweep_launches = max(1, launches[mvs_amd.MVS_K_SWEEP]) / (len(groups) if (args.shard == "views" and world > 1) else 1)
-        sweep_ms = ms_sum[mvs_amd.MVS_K_SWEEP] / sweep_launches
-        argmin_ms = ms_sum[mvs_amd.MVS_K_ARGMIN] / max(1, launches[mvs_amd.MVS_K_ARGMIN]) if launches[mvs_amd.MVS_K_ARGMIN] else 0.0
-        separate = launches[mvs_amd.MVS_K_ARGMIN] > 0
-        # algorithmic bytes of one sweep launch: each u8 image once + the u32 volume written once (+ the three result
-        # maps when depth selection is fused into the kernel)
-        P_loc = float(bands[0][1]) * W if (args.shard == "rows" and world > 1) else float(P)   # rank 0's band
-        sweep_bytes = P_loc * (vn + 1) + 4.0 * P_loc * D + (0.0 if separate else 12.0 * P_loc)
+        sweep_ms, argmin_ms, separate = primary["sweep_ms"], primary["argmin_ms"], primary["separate"]
+        # algorithmic bytes of one sweep launch as SURVEY.md section 8(d) counts them: every u8 image once, the u32 volume written
+        # once and read once for depth selection, depth + best cost written: P (V_loc + 8 D + 9), with P = the pixels this launch
+        # covers.  (With depth selection fused into the kernel the read-back does not happen; the PMC `traffic` shows what moved.)
+        P_loc = float(primary["rows0"]) * W
+        sweep_bytes = P_loc * (primary["views"] + 8.0 * D + 9.0)
         argmin_bytes = 4.0 * P * D + 12.0 * P
         achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-        traffic = pmc_traffic("sweep_tiled", args.config) if args.gpus == 1 else None
+        traffic = pmc_traffic(sweep_kernel, args.config) if world == 1 else None
         out = {
             "metric": "cost-volume samples/sec (pixels x planes x views)",
-            "value": samples_per_step / (dt / args.steps),
+            "value": samples_per_step / (primary["dt"] / args.steps),
             "unit": "samples/s",
-            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": primary["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak" if args.shard == "frames" else "strong",
+            "scaling": "weak" if shard == "frames" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (%s)" % args.data + (" [TEST HOOK: ranks share one GPU over gloo -- not a measurement]" if same_device else ""),
             "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V),
-                       "shard": args.shard, "collective": args.collective if args.shard == "views" else None, "views_per_rank": vn,
-                       "rows_per_rank": [n for _, n in bands] if args.shard == "rows" else None, "device": ctx.info()},
-            "roofline": {"bound": "hbm", "kernel": "sweep_tiled", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                       "sampler": args.sampler, "shard": shard, "collective": args.collective if shard == "views" else ("all_gather of depth rows" if shard == "rows" and world > 1 else None),
+                       "views_per_rank": primary["views"], "rows_per_rank": [n for _, n in bands] if shard == "rows" else None,
+                       "collective_bytes_per_rank_per_step": primary["collective_bytes_per_rank"], "alternatives": alternatives, "device": ctx.info()},
+            "roofline": {"bound": "hbm", "kernel": sweep_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
                          "valu_bound_note": "VALU-issue bound, see DESIGN.md section 4 and profiles/",
                          "valu_utilisation": traffic["valu_utilisation"] if traffic else None,   # from the same PMC summary as `traffic`
-                         "bytes_per_launch": sweep_bytes, "ms_per_launch": sweep_ms},
+                         "bytes_per_launch": sweep_bytes, "bytes_formula": "P (V_loc + 8 D + 9), SURVEY.md 8(d)", "ms_per_launch": sweep_ms},
             "kernels": {"sweep_ms": sweep_ms, "argmin_ms": argmin_ms if separate else None,
                         "argmin_GBps": argmin_bytes / (argmin_ms * 1e-3) / 1e9 if argmin_ms > 0 else None,
-                        "depth_selection": "argmin_volume pass" if separate else "fused into sweep_tiled",
-                        "arithmetic": "f32 warp (one rounding per op), u8 intensities, u32 packed cost cells"},
+                        "depth_selection": "argmin_volume pass" if separate else "fused into " + sweep_kernel,
+                        "arithmetic": ("f32 projection, 1/32-texel positions, 8-bit weight table (v_dot4_u32_u8), u32 packed cost cells" if args.sampler == "fixed"
+                                       else "f32 warp (one rounding per op), u8 intensities, u32 packed cost cells")},
             "depth_check": depth_ok,
-            "depth_crc32": zlib.crc32(np.ascontiguousarray(depth).tobytes()),   # equal across N for the strong-scaling shardings
+            "depth_crc32": primary["crc"],   # equal across N for the strong-scaling shardings (asserted against the in-process single-GPU run)
+            "depth_crc32_single_gpu": crc1,
         }
         if general_ms is not None:
             out["general_camera_path"] = {
                 "ms_per_step": general_ms, "samples_per_s": float(P) * D * V / (general_ms * 1e-3),
                 "note": "same data with the plane-independent-w shortcut disabled: the rate for side cameras that are "
                         "rotated or displaced along the optical axis (DESIGN.md section 4)"}
+        if onecall_ms is not None:
+            out["one_call_mvs_sweep"] = {"ms_per_call": onecall_ms, "samples_per_s": float(P) * D * V / (onecall_ms * 1e-3),
+                                         "note": "host frames in, host depth out (PCIe, quad images and region planning inside the call); never reported as `value`"}
         if fused_ms is not None:
             out["fused_variant"] = {"ms_per_step": fused_ms, "samples_per_s": float(P) * D * V / (fused_ms * 1e-3)}
-        if not args.no_cpu_baseline and args.gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, main_cam, main_img, side_cams, sides)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, main_cam, main_img, side_cams, sides, args.sampler)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:

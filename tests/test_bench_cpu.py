@@ -34,3 +34,14 @@ def test_pmc_traffic_picks_the_newest_profile_numerically(tmp_path, monkeypatch)
 def test_committed_profiles_resolve():
     got = _bench().pmc_traffic("sweep_tiled", "c3")
     assert got is not None and got["bytes"] > 1.0e9 and "pmc_c3_v" in got["source"]
+
+
+def test_gpus_without_a_launcher_is_refused():
+    """`python bench.py --gpus 8` without torch.distributed.run would run on GPU 0 only and claim eight: it must refuse (and say how
+    to launch it) before touching any GPU"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "torch.distributed.run" in out.stderr and "--nproc-per-node 8" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

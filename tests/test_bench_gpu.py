@@ -25,7 +25,7 @@ def _bench(extra, world):
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                 "--master-port", str(port)]
     cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--config", "c1", "--steps", "2", "--warmup", "1",
-            "--no-cpu-baseline", "--no-extras"] + extra
+            "--no-cpu-baseline"] + (["--no-extras"] if "--with-extras" not in extra else []) + [e for e in extra if e != "--with-extras"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
@@ -40,6 +40,12 @@ def test_bench_line_contract_and_two_rank_shardings():
     assert single["n_gpus"] == 1 and single["vs_baseline"] is None and single["depth_check"] is True
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in single["roofline"], key
+    assert single["config"]["sampler"] == "fixed" and single["roofline"]["kernel"] == "sweep_fx_tiled"
+    assert "one_call_mvs_sweep" not in single   # --no-extras
+    # the default N > 1 line: strong scaling of one main view by row bands, the north_star's view shardings timed beside it
+    dflt = _bench([], 2)
+    assert dflt["n_gpus"] == 2 and dflt["scaling"] == "strong" and dflt["config"]["shard"] == "rows"
+    assert dflt["depth_crc32"] == single["depth_crc32"] == dflt["depth_crc32_single_gpu"]
     rs = _bench(["--shard", "views", "--collective", "reduce_scatter"], 2)   # partial selection per plane slice + merge
     assert rs["depth_crc32"] == single["depth_crc32"] and rs["config"]["collective"] == "reduce_scatter"
     for shard, scaling in (("views", "strong"), ("rows", "strong"), ("frames", "weak")):
@@ -47,3 +53,11 @@ def test_bench_line_contract_and_two_rank_shardings():
         assert two["n_gpus"] == 2 and two["scaling"] == scaling and two["depth_check"] is True
         assert "TEST HOOK" in two["data"]
         assert two["depth_crc32"] == single["depth_crc32"], shard   # rank 0's frame is the single-GPU frame in every mode
+    full = _bench(["--with-extras"], 2)   # default N = 2 with the alternatives block
+    alt = full["config"]["alternatives"]
+    assert set(alt) == {"views_allreduce", "views_reduce_scatter"}
+    for a in alt.values():
+        assert a["depth_crc32"] == single["depth_crc32"] and a["collective_bytes_per_rank_per_step"] > 0 and a["views_per_rank"] == 2
+    for s in ("exact",):
+        ex = _bench(["--sampler", s], 1)
+        assert ex["roofline"]["kernel"] == "sweep_tiled" and ex["depth_check"] is True
