@@ -188,6 +188,22 @@ int mvs_sweep_fetch(mvs_ctx *ctx, float *depth_hw, float *cost_hw, int32_t *inde
 /* read back the f32 view matrices the sweep uses (nviews*12), for parity checks */
 int mvs_sweep_view_matrices(mvs_ctx *ctx, float *q_out);
 
+/* ---- one main view on several GPUs of one node (SURVEY.md section 8b "multi-GPU", north_star) ----------------------------------
+ * A communicator owns one context per listed device and one RCCL communicator across them (librccl is loaded when the first
+ * communicator is created; the library has no link dependency on it).  mvs_sweep_sharded deals the side views to the GPUs, every
+ * GPU builds the packed volume of its views (one host thread per GPU), the volumes are summed over xGMI -- reduce-scatter by plane
+ * slices + partial selection + all-gather of the 8-byte partials when nplanes is a multiple of the GPU count, an in-place all-reduce
+ * + mvs_sweep_argmin otherwise -- and rank 0's result is returned.  Cells are integers, so depth_hw / cost_hw are bit-identical to
+ * mvs_sweep on one GPU.  The sampler of a communicator's contexts is set through mvs_comm_context(). */
+typedef struct mvs_comm mvs_comm;
+mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height); /* NULL on error: mvs_comm_last_error(NULL) */
+void mvs_comm_destroy(mvs_comm *comm);
+int mvs_comm_size(const mvs_comm *comm);
+mvs_ctx *mvs_comm_context(mvs_comm *comm, int rank); /* borrowed; NULL if rank is out of range */
+const char *mvs_comm_last_error(const mvs_comm *comm);
+int mvs_sweep_sharded(mvs_comm *comm, const float main_cam[16], const uint8_t *main_hw, int nviews, const float *side_cams /* nviews*16 */,
+                      const uint8_t *const *side_frames, int nplanes, float z_lo, float z_hi, float *depth_hw, float *cost_hw /* nullable */);
+
 /* ---- kernel timing (HIP events on the context's stream) ---------------------------------------- */
 #define MVS_K_SWEEP 0
 #define MVS_K_ARGMIN 1

@@ -67,6 +67,12 @@ ABI = [
     ("mvs_sweep_index_device", _vp, [_vp]),
     ("mvs_sweep_fetch", _i, [_vp, _fp, _fp, _i32p, _u32p]),
     ("mvs_sweep_view_matrices", _i, [_vp, _fp]),
+    ("mvs_comm_create", _vp, [C.POINTER(_i), _i, _i, _i]),
+    ("mvs_comm_destroy", None, [_vp]),
+    ("mvs_comm_size", _i, [_vp]),
+    ("mvs_comm_context", _vp, [_vp, _i]),
+    ("mvs_comm_last_error", C.c_char_p, [_vp]),
+    ("mvs_sweep_sharded", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _f, _f, _fp, _fp]),
     ("mvs_profile_enable", _i, [_vp, _i]),
     ("mvs_profile_read", _i, [_vp, _fp, C.POINTER(_i), _i]),
     ("mvs_device_info", C.c_char_p, [_vp]),
@@ -126,6 +132,59 @@ class _DeviceArray:
     def __init__(self, ptr, shape, typestr):
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
                                          "strides": None}
+
+
+class Comm:
+    """mvs_comm: one main view swept on several GPUs of one node (views dealt to the GPUs, volumes summed with RCCL)."""
+
+    def __init__(self, devices, width, height, sampler=None):
+        self.lib = load_library()
+        self.W, self.H = int(width), int(height)
+        devs = (C.c_int * max(len(devices), 1))(*devices)
+        self.h = self.lib.mvs_comm_create(devs if len(devices) else None, len(devices), self.W, self.H)
+        if not self.h:
+            raise MvsError("mvs_comm_create failed: %s" % self.lib.mvs_comm_last_error(None).decode())
+        if sampler is not None:
+            for r in range(self.size()):
+                rc = self.lib.mvs_sweep_set_sampler(self.lib.mvs_comm_context(self.h, r), SAMPLERS[sampler])
+                if rc:
+                    raise MvsError("mvs_sweep_set_sampler failed on rank %d" % r)
+
+    def size(self):
+        return self.lib.mvs_comm_size(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mvs_comm_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sweep(self, main_cam, main_img, side_cams, side_imgs, nplanes, z_lo=-1.0, z_hi=1.0):
+        W, H = self.W, self.H
+        V = len(side_imgs)
+        cam = _f32(main_cam, (4, 4))
+        img = _u8(main_img, (H, W))
+        cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((1, 4, 4), np.float32)
+        frames = [_u8(s, (H, W)) for s in side_imgs]
+        arr = (_u8p * max(V, 1))(*[_ptr(f, _u8p) for f in frames])
+        depth = np.empty((H, W), np.float32)
+        cost = np.empty((H, W), np.float32)
+        rc = self.lib.mvs_sweep_sharded(self.h, _ptr(cam, _fp), _ptr(img, _u8p), V, _ptr(cams, _fp), arr, int(nplanes), float(z_lo), float(z_hi),
+                                        _ptr(depth, _fp), _ptr(cost, _fp))
+        if rc:
+            raise MvsError("libmvs_hip error %d: %s" % (rc, self.lib.mvs_comm_last_error(self.h).decode()))
+        return depth, cost
 
 
 class Context:

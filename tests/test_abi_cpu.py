@@ -41,3 +41,22 @@ def test_create_fails_loudly_without_gpu():
     with pytest.raises(mvs_amd.MvsError) as e:
         mvs_amd.Context(64, 48)
     assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_comm_argument_errors():
+    """mvs_comm_create: argument errors are reported before any device is touched; without a GPU a valid device list fails loudly"""
+    for devs, needle in (([], "1..64"), ([0, 1, 0], "twice")):
+        with pytest.raises(mvs_amd.MvsError) as e:
+            mvs_amd.Comm(devs, 64, 48)
+        assert needle in str(e.value), str(e.value)
+    if not os.path.exists("/dev/kfd"):
+        with pytest.raises(mvs_amd.MvsError) as e:
+            mvs_amd.Comm([0], 64, 48)
+        assert "HIP" in str(e.value) or "no CPU fallback" in str(e.value)
+
+
+def test_library_has_no_link_dependency_on_rccl():
+    """RCCL is resolved with dlopen when a communicator is created (a process that already loaded one -- PyTorch -- shares it)"""
+    import subprocess
+    out = subprocess.check_output(["readelf", "-d", mvs_amd.LIB_PATH]).decode()
+    assert "rccl" not in out and "nccl" not in out
