@@ -3,8 +3,8 @@
 // recon.hpp of the reference is written against cv::Mat (recon.hpp:17-25).  OpenCV is not in this image and
 // cannot be assumed on the GPU box, so the host mirror is written against this small dense, ref-counted
 // array with the same member names and the same copy semantics (copying a Mat shares pixels, like
-// cv::Mat; clone() copies).  With -DMVS_WITH_OPENCV the mirror uses the real cv::Mat instead
-// (host/recon.hpp), which is what a maintainer linking the original recon.cpp would do.
+// cv::Mat; clone() copies).  A maintainer linking the original recon.cpp uses host/render_hip_cv.cpp instead, the same
+// calls written against the real cv::Mat.
 #pragma once
 
 #include <cassert>

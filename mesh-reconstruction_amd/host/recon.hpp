@@ -9,8 +9,8 @@
 //   calculateFlow / compare / mixBackground / flowRemap / extractCameraCenter / dehomogenize   recon.hpp:40-50
 //   class Heuristic                                   recon.hpp:104-123, heuristic.cpp
 //   class Configuration                               recon.hpp:58-90, configuration.cpp
-// Differences, all forced by the missing OpenCV: Mat is mvs::Mat (matlite.hpp)
-// unless MVS_WITH_OPENCV is defined; errors are C++ exceptions (std::runtime_error) instead of
+// Differences, all forced by the missing OpenCV: Mat is mvs::Mat (matlite.hpp) -- the same
+// seam written against the reference's own header and the real cv::Mat is host/render_hip_cv.cpp; errors are C++ exceptions (std::runtime_error) instead of
 // assert/exit(1) (recon.cpp:49, configuration.cpp:136,141,172); video decoding is replaced by a frame
 // directory (the clips are not in the reference checkout either: .MISSING_LARGE_BLOBS).
 #pragma once

@@ -2,6 +2,8 @@
 import os
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SELFTEST = os.path.join(ROOT, "mesh-reconstruction_amd", "bin", "host_selftest")
 TRACKS = os.path.join(ROOT, "tests", "data", "tracks")
@@ -89,3 +91,21 @@ def test_estimate_exposure_matches_the_numpy_restatement(tmp_path):
         spread_before.append(before.std() / before.mean())
         spread_after.append(after.std() / after.mean())
     assert np.mean(spread_after) < 0.02 and np.mean(spread_after) < 0.25 * np.mean(spread_before), (np.mean(spread_before), np.mean(spread_after))
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/recon.hpp"), reason="the reference tree is only present in the build container")
+def test_cv_mat_seam_file_compiles_against_the_reference_header(tmp_path):
+    """host/render_hip_cv.cpp is the translation unit a maintainer drops into the reference tree (class RenderHIP : public Render,
+    spawnRender, calculateFlow; with -DMVS_HIP_UTIL also compare / flowRemap / mixBackground / triangulatePixels).  OpenCV is not in
+    this image, so it is COMPILED ONLY -- against the reference's own recon.hpp and a declarations-only cv::Mat (tests/cv_decl): a
+    check of the boundary (names, signatures, virtual overrides), not parity evidence."""
+    import shutil
+    import subprocess
+    src = tmp_path / "render_hip_cv.cpp"     # away from host/recon.hpp: the quoted include must find the REFERENCE header
+    shutil.copy(os.path.join(ROOT, "mesh-reconstruction_amd", "host", "render_hip_cv.cpp"), src)
+    for extra in ([], ["-DMVS_HIP_UTIL"]):
+        subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-Werror"] + extra +
+                              ["-I", os.path.join(ROOT, "tests", "cv_decl"), "-I", "/root/reference", "-I", os.path.join(ROOT, "include"), str(src)])
+    # an abstract-class check: RenderHIP must override every pure virtual of Render, or `new RenderHIP` would not compile (it did)
+    text = open(src).read()
+    assert "class RenderHIP : public Render" in text and "Render *spawnRender(Heuristic hint)" in text
