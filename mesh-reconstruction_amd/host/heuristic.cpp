@@ -307,6 +307,29 @@ int Heuristic::nextSide(int imain)
     return chosenCameras[mainIdx].second[sideIdx];
 }
 
+// heuristic.cpp:525-545
+Mesh Heuristic::tessellate(const Mat points, const Mat normals)
+{
+    if (iteration <= 1) {
+        if (!config->inMeshFile.empty()) {
+            if (!meshers.readMesh) throw std::runtime_error("tessellate: no readMesh callback installed");
+            Mesh result = meshers.readMesh(config->inMeshFile.c_str());
+            alphaVals.push_back(1);  // "TODO: estimate some alpha value from the geometry", heuristic.cpp:530
+            return result;
+        }
+        if (!meshers.alphaShapeFaces) throw std::runtime_error("tessellate: no alphaShapeFaces callback installed");
+        float alpha = 0;
+        Mat faces = meshers.alphaShapeFaces(points, &alpha);
+        alphaVals.push_back(alpha);
+        return Mesh(points, faces);
+    }
+    if (!meshers.poissonSurface) throw std::runtime_error("tessellate: no poissonSurface callback installed");
+    if (alphaVals.empty()) throw std::runtime_error("tessellate: Poisson iteration before any alpha value was recorded");
+    Mesh result = meshers.poissonSurface(points, normals);
+    alphaVals.push_back(alphaVals.back() / 2);
+    return result;
+}
+
 // heuristic.cpp:548-551
 mvs::Size Heuristic::renderSize() { return mvs::Size(config->width, config->height); }
 

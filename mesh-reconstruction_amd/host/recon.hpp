@@ -15,6 +15,7 @@
 // directory (the clips are not in the reference checkout either: .MISSING_LARGE_BLOBS).
 #pragma once
 
+#include <functional>
 #include <list>
 #include <map>
 #include <set>
@@ -141,6 +142,16 @@ public:
     int beginSide(int mainNumber);
     int nextSide(int mainNumber);
     void filterPoints(Mat &points, Mat &normals);
+    // heuristic.cpp:525-545: first iteration -> the mesh file given with -m (alpha 1) or alpha shapes of the points (alpha from the
+    // mesher); later iterations -> Poisson surface (alpha halved).  The meshers themselves are CGAL / PCL host code outside the hot
+    // path: they are injected, the dispatch and the alphaVals bookkeeping filterPoints depends on are here.
+    struct Meshers {
+        std::function<Mat(const Mat points, float *alpha)> alphaShapeFaces;       // alpha_shapes.cpp:36-99
+        std::function<Mesh(const Mat points, const Mat normals)> poissonSurface;  // cgal_poisson.cpp:47-136 or pcl.cpp
+        std::function<Mesh(const char *fileName)> readMesh;                       // util.cpp (Wavefront OBJ)
+    };
+    Meshers meshers;
+    Mesh tessellate(const Mat points, const Mat normals);
     mvs::Size renderSize();
     static const int sentinel = -1;
     HeuristicRNG rng;  // explicit and seedable (SURVEY 8b "determinism hook")

@@ -116,6 +116,52 @@ static int run_cpu(const std::string &tracks)
         } catch (const std::exception &) { threw = true; }
         CHECK(threw, "missing YAML must throw");
     }
+    {
+        // Heuristic::tessellate: dispatch and alphaVals bookkeeping (heuristic.cpp:525-545) with stand-in meshers
+        Configuration c(tracks + "/zatisi.yaml");
+        Heuristic h(&c);
+        int alphaCalls = 0, poissonCalls = 0, readCalls = 0;
+        h.meshers.alphaShapeFaces = [&](const Mat pts, float *alpha) {
+            alphaCalls++;
+            *alpha = 0.75f;
+            Mat f(1, 3, mvs::S32C1);
+            f.at<int32_t>(0, 0) = 0; f.at<int32_t>(0, 1) = 1; f.at<int32_t>(0, 2) = 2;
+            return f;
+        };
+        h.meshers.poissonSurface = [&](const Mat pts, const Mat) {
+            poissonCalls++;
+            return Mesh(pts, Mat(0, 3, mvs::S32C1));
+        };
+        h.meshers.readMesh = [&](const char *) {
+            readCalls++;
+            return Mesh(Mat(3, 4, mvs::F32C1), Mat(1, 3, mvs::S32C1));
+        };
+        Mat pts = c.reconstructedPoints(), nrm(pts.rows, 3, mvs::F32C1);
+        bool threw = false;
+        try {
+            Mat p2 = pts.clone(), n2 = nrm.clone();
+            h.filterPoints(p2, n2);
+        } catch (const std::exception &) { threw = true; }
+        CHECK(threw, "filterPoints before tessellate must fail: no alpha value yet");
+        CHECK(h.notHappy(pts), "first iteration");                    // iteration = 1 (recon.cpp:27)
+        Mesh m1 = h.tessellate(pts, nrm);                             // alpha shapes
+        CHECK(alphaCalls == 1 && h.alphaVals.size() == 1 && h.alphaVals.back() == 0.75f && m1.faces.rows == 1 && m1.vertices.rows == pts.rows, "tessellate: alpha shapes on the first iteration");
+        CHECK(h.notHappy(pts), "second iteration");                   // iteration = 2
+        (void)h.tessellate(pts, nrm);                                 // Poisson, alpha halved
+        CHECK(poissonCalls == 1 && h.alphaVals.size() == 2 && h.alphaVals.back() == 0.375f, "tessellate: Poisson surface halves alpha");
+        Configuration c2(tracks + "/zatisi.yaml");
+        c2.inMeshFile = "some.obj";
+        Heuristic h2(&c2);
+        h2.meshers = h.meshers;
+        (void)h2.notHappy(pts);
+        (void)h2.tessellate(pts, nrm);
+        CHECK(readCalls == 1 && h2.alphaVals.size() == 1 && h2.alphaVals.back() == 1.f, "tessellate: initial mesh file gives alpha 1");
+        Heuristic h3(&c);
+        (void)h3.notHappy(pts);
+        threw = false;
+        try { (void)h3.tessellate(pts, nrm); } catch (const std::exception &) { threw = true; }
+        CHECK(threw, "tessellate without an installed mesher must fail loudly");
+    }
     printf("cpu selftest: %d failures\n", fails);
     return fails ? 1 : 0;
 }
@@ -274,10 +320,55 @@ static int run_exposure(const std::string &yaml, const std::string &out)
     return 0;
 }
 
+// host_selftest choose <tracks yaml> <verts.f32> <faces.i32> <camera threshold> <out.txt> [nodepth]
+// Heuristic::chooseCameras on a mesh from raw files, chosen schedule written as "main: side side ..." lines preceded by the pair
+// count and followed by the generator's state -- compared pair for pair with tests/policy_mirror.py.  With `nodepth` the renderer is
+// a stand-in that sees no geometry (every depth = backgroundDepth), which needs no GPU: the policy arithmetic alone.
+static int run_choose(int argc, char **argv)
+{
+    Configuration config(argv[2]);
+    config.cameraThreshold = (float)atof(argv[5]);
+    auto slurp = [](const char *path) {
+        std::ifstream f(path, std::ios::binary);
+        return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    };
+    const std::vector<char> vb = slurp(argv[3]), fb = slurp(argv[4]);
+    Mesh mesh(Mat((int)(vb.size() / 16), 4, mvs::F32C1), Mat((int)(fb.size() / 12), 3, mvs::S32C1));
+    std::memcpy(mesh.vertices.data, vb.data(), vb.size());
+    std::memcpy(mesh.faces.data, fb.data(), fb.size());
+    Heuristic hint(&config);
+    struct BlindRender : Render {
+        int w, h;
+        BlindRender(int w_, int h_) : w(w_), h(h_) {}
+        void loadMesh(const Mesh) override {}
+        Mat projected(const Mat, const Mat, const Mat) override { return Mat(); }
+        Mat depth(const Mat) const override
+        {
+            Mat d(h, w, mvs::F32C1);
+            for (size_t i = 0; i < d.total(); i++) d.ptr<float>()[i] = backgroundDepth;
+            return d;
+        }
+    };
+    Render *render = (argc > 7 && !strcmp(argv[7], "nodepth")) ? (Render *)new BlindRender(config.width, config.height) : spawnRender(hint);
+    render->loadMesh(mesh);
+    const int count = hint.chooseCameras(mesh, config.allCameras(), *render);
+    std::ofstream out(argv[6]);
+    out << count << "\n";
+    for (const auto &entry : hint.chosen()) {
+        out << entry.first << ":";
+        for (int s : entry.second) out << " " << s;
+        out << "\n";
+    }
+    out << "rng " << hint.rng.state << "\n";
+    delete render;
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
         if (argc >= 4 && !strcmp(argv[1], "exposure")) return run_exposure(argv[2], argv[3]);
+        if (argc >= 7 && !strcmp(argv[1], "choose")) return run_choose(argc, argv);
         if (argc >= 3 && !strcmp(argv[1], "cpu")) return run_cpu(argv[2]);
         if (argc >= 4 && !strcmp(argv[1], "gpu")) return run_gpu(argv[2], argv[3]);
     } catch (const std::exception &e) {

@@ -109,3 +109,48 @@ def test_cv_mat_seam_file_compiles_against_the_reference_header(tmp_path):
     # an abstract-class check: RenderHIP must override every pure virtual of Render, or `new RenderHIP` would not compile (it did)
     text = open(src).read()
     assert "class RenderHIP : public Render" in text and "Render *spawnRender(Heuristic hint)" in text
+
+
+def _choose_cpp(tmp_path, name, verts, faces, threshold, nodepth):
+    import numpy as np
+    verts.astype(np.float32).tofile(tmp_path / "v.f32")
+    faces.astype(np.int32).tofile(tmp_path / "f.i32")
+    out = tmp_path / ("chosen_%s.txt" % name)
+    cmd = [SELFTEST, "choose", os.path.join(TRACKS, name), str(tmp_path / "v.f32"), str(tmp_path / "f.i32"), repr(float(threshold)), str(out)]
+    r = subprocess.run(cmd + (["nodepth"] if nodepth else []), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(out).read().split("\n")
+    count = int(lines[0])
+    chosen = [(int(l.split(":")[0]), [int(x) for x in l.split(":")[1].split()]) for l in lines[1:] if ":" in l]
+    state = int([l for l in lines if l.startswith("rng")][0].split()[1])
+    return count, chosen, state
+
+
+def test_generator_is_opencvs_default_stream():
+    """cv::theRNG() is never seeded by the reference: the first four randu<float>() values are fixed (SURVEY.md section 8b)"""
+    import numpy as np
+    import policy_mirror
+    rng = policy_mirror.RNG()
+    got = [rng.uniform() for _ in range(4)]
+    np.testing.assert_allclose(got, [0.030282794, 0.6992592, 0.90105945, 0.3143851], rtol=0, atol=5e-8)
+
+
+@pytest.mark.parametrize("name,threshold", [("koberec.yaml", 10.0), ("koberec-.yaml", 10.0), ("zatisi.yaml", 4.0), ("koule-tr.yaml", 10.0)])
+def test_camera_selection_policy_matches_the_numpy_restatement(tmp_path, name, threshold):
+    """Heuristic::chooseCameras (host/heuristic.cpp) against tests/policy_mirror.py, an independent restatement of
+    heuristic.cpp:179-486 on the same generator: pair count, every (main, sides...) entry in order, and the generator state after
+    the 200 shots, on the cameras of each bundled tracks file with a proxy mesh through its bundle points.  No GPU here, so the
+    renderer is blind (every depth = backgroundDepth) in both: the occlusion look-up is covered by tests/test_host_gpu.py."""
+    import numpy as np
+    import policy_mirror
+    import scenes
+    import tracks_yaml
+    t = tracks_yaml.load(name)
+    cams = [np.asarray(c, np.float32) for c in t["cameras"]]
+    verts, faces = scenes.proxy_plane(t["bundles"], cams[len(cams) // 2], n=12, scale=0.6)
+    count, chosen, state = _choose_cpp(tmp_path, name, verts, faces, threshold, nodepth=True)
+    blind = lambda viewer, px: [policy_mirror.BACKGROUND] * len(px)   # noqa: E731
+    m_count, m_chosen, rng = policy_mirror.choose_cameras(verts, faces, cams, t["width"], t["height"], threshold, blind)
+    assert state == rng.state, "the two implementations drew a different number of random values"
+    assert (count, chosen) == (m_count, m_chosen)
+    assert count >= 1 and all(m not in s for m, s in chosen)

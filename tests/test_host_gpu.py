@@ -52,3 +52,42 @@ def test_recon_stage_through_cpp_mirror(oracle, tmp_path):
     mains = [int(l.split(":")[0]) for l in open(tmp_path / "chosen.txt")]
     assert mains == sorted(mains) and len(mains) >= 1
     assert (d_ref != 1.0).mean() > 0.05
+
+
+@pytest.mark.parametrize("name,threshold", [("koberec.yaml", 10.0), ("koberec-.yaml", 10.0), ("zatisi.yaml", 4.0), ("koule-tr.yaml", 10.0)])
+def test_camera_selection_with_occlusion_matches_the_numpy_restatement(oracle, tmp_path, name, threshold):
+    """Heuristic::chooseCameras through RenderHIP (depth look-ups served by mvs_depth_probe) against tests/policy_mirror.py with the
+    ORACLE's depth maps, pair for pair, on a bumpy proxy mesh that hides some cameras from some faces (heuristic.cpp:307-314)."""
+    import policy_mirror
+    import scenes
+    import tracks_yaml
+    from test_host_cpu import _choose_cpp
+    t = tracks_yaml.load(name)
+    W, H = t["width"], t["height"]
+    cams = [np.asarray(c, np.float32) for c in t["cameras"]]
+    verts, faces = scenes.proxy_plane(t["bundles"], cams[len(cams) // 2], n=20, scale=0.6)
+    # bumps along the plane normal: ridges tall enough to occlude grazing cameras
+    xyz = verts[:, :3].astype(np.float64)
+    g = xyz.mean(0)
+    a, b = xyz[1] - xyz[0], xyz[20] - xyz[0]
+    nrm = np.cross(a, b)
+    nrm /= np.linalg.norm(nrm)
+    ext = np.abs(xyz - g).max()
+    u, v = (xyz - g) @ (a / np.linalg.norm(a)), (xyz - g) @ (b / np.linalg.norm(b))
+    verts = verts.copy()
+    verts[:, :3] = (xyz + nrm[None, :] * (0.6 * ext * np.sin(7.0 * u / ext) * np.cos(5.0 * v / ext))[:, None]).astype(np.float32)
+    soup = oracle.load_mesh(verts, faces)
+    blocked = [0]
+
+    def depth_at(viewer, px):
+        d = oracle.depth(soup, viewer, W, H)
+        vals = [d[r, c] for r, c in px]
+        blocked[0] += sum(1 for x in vals if x != policy_mirror.BACKGROUND)
+        return vals
+    m_count, m_chosen, rng = policy_mirror.choose_cameras(verts, faces, cams, W, H, threshold, depth_at)
+    count, chosen, state = _choose_cpp(tmp_path, name, verts, faces, threshold, nodepth=False)
+    print("%s: %d depth look-ups hit geometry" % (name, blocked[0]))
+    if name == "koberec.yaml":
+        assert blocked[0] > 0, "this scene is meant to produce look-ups that hit geometry"
+    assert state == rng.state
+    assert (count, chosen) == (m_count, m_chosen)
