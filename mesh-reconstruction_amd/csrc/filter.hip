@@ -19,7 +19,7 @@
 // Quirks kept: squared distances compared with `radius` (81-89), only lower-index neighbours are penalised (152-154).
 #include "mvs_internal.hpp"
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -384,11 +384,11 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
         // offsets = exclusive prefix sums of the counts over N + 1 entries (count[N] = 0, so entry N is the total); integer
         // sums are exact under any algorithm.  The single-workgroup scan this replaces took 5.7 ms per call at 2 M points.
         size_t scan_bytes = 0;
-        if (hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_cnt_lo, d_off_lo, N + 1, st) != hipSuccess)
+        if (rocprim::exclusive_scan(nullptr, scan_bytes, d_cnt_lo, d_off_lo, 0, (size_t)N + 1, rocprim::plus<int>(), st) != hipSuccess)
             return fail(ctx, MVS_EHIP, "mvs_filter_points: scan sizing failed");
         if ((rc = ensure(ctx, ctx->r_tmp0, scan_bytes > 0 ? scan_bytes : 1))) return rc;
-        if (hipcub::DeviceScan::ExclusiveSum(ctx->r_tmp0.ptr, scan_bytes, d_cnt_lo, d_off_lo, N + 1, st) != hipSuccess ||
-            hipcub::DeviceScan::ExclusiveSum(ctx->r_tmp0.ptr, scan_bytes, d_cnt_up, d_off_up, N + 1, st) != hipSuccess)
+        if (rocprim::exclusive_scan(ctx->r_tmp0.ptr, scan_bytes, d_cnt_lo, d_off_lo, 0, (size_t)N + 1, rocprim::plus<int>(), st) != hipSuccess ||
+            rocprim::exclusive_scan(ctx->r_tmp0.ptr, scan_bytes, d_cnt_up, d_off_up, 0, (size_t)N + 1, rocprim::plus<int>(), st) != hipSuccess)
             return fail(ctx, MVS_EHIP, "mvs_filter_points: scan failed");
     }
     MVS_HIP(ctx, hipGetLastError());
@@ -418,20 +418,20 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
         d_skeys = (unsigned long long *)ctx->filter_sort.ptr;
         d_skeys2 = d_skeys + total;
         d_up_alt = (Nb *)(d_skeys2 + total);
-        if (hipcub::DeviceRadixSort::SortPairs(nullptr, pair_bytes, d_skeys, d_skeys2, (unsigned long long *)d_up, (unsigned long long *)d_up_alt,
-                                               total, 0, key_bits, st) != hipSuccess)
+        if (rocprim::radix_sort_pairs(nullptr, pair_bytes, d_skeys, d_skeys2, (unsigned long long *)d_up, (unsigned long long *)d_up_alt,
+                                      (size_t)total, 0u, (unsigned)key_bits, st) != hipSuccess)
             return fail(ctx, MVS_EHIP, "mvs_filter_points: list sort sizing failed");
         if ((rc = ensure(ctx, ctx->r_tmp0, pair_bytes > 0 ? pair_bytes : 1))) return rc;
         // lower lists by index (the order heuristic.cpp:74-92 leaves them in), sorted into the spare region and copied back
         list_keys<<<g, 256, 0, st>>>(d_off_lo, d_lo, N, nullptr, d_skeys);
-        if (hipcub::DeviceRadixSort::SortPairs(ctx->r_tmp0.ptr, pair_bytes, d_skeys, d_skeys2, (unsigned long long *)d_lo, (unsigned long long *)d_up_alt,
-                                               total, 0, key_bits, st) != hipSuccess)
+        if (rocprim::radix_sort_pairs(ctx->r_tmp0.ptr, pair_bytes, d_skeys, d_skeys2, (unsigned long long *)d_lo, (unsigned long long *)d_up_alt,
+                                      (size_t)total, 0u, (unsigned)key_bits, st) != hipSuccess)
             return fail(ctx, MVS_EHIP, "mvs_filter_points: list sort failed");
         MVS_HIP(ctx, hipMemcpyAsync(d_lo, d_up_alt, sizeof(Nb) * (size_t)total, hipMemcpyDeviceToDevice, st));
         // upper lists by index
         list_keys<<<g, 256, 0, st>>>(d_off_up, d_up, N, nullptr, d_skeys);
-        if (hipcub::DeviceRadixSort::SortPairs(ctx->r_tmp0.ptr, pair_bytes, d_skeys, d_skeys2, (unsigned long long *)d_up, (unsigned long long *)d_up_alt,
-                                               total, 0, key_bits, st) != hipSuccess)
+        if (rocprim::radix_sort_pairs(ctx->r_tmp0.ptr, pair_bytes, d_skeys, d_skeys2, (unsigned long long *)d_up, (unsigned long long *)d_up_alt,
+                                      (size_t)total, 0u, (unsigned)key_bits, st) != hipSuccess)
             return fail(ctx, MVS_EHIP, "mvs_filter_points: list sort failed");
         std::swap(d_up, d_up_alt);  // d_up: by index (what the power iteration gathers in); d_up_alt: free again
     } else {
@@ -488,18 +488,18 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
     int *d_undecided = d_cnt_up;                                                                        // 8 counters, one per round of a batch
     greedy_keys<<<g, 256, 0, st>>>(d_density, N, d_keys);
     size_t cub_bytes = 0;
-    if (hipcub::DeviceRadixSort::SortKeys(nullptr, cub_bytes, d_keys, d_sorted, N, 0, 64, st) != hipSuccess)
+    if (rocprim::radix_sort_keys(nullptr, cub_bytes, d_keys, d_sorted, (size_t)N, 0u, 64u, st) != hipSuccess)
         return fail(ctx, MVS_EHIP, "mvs_filter_points: radix sort sizing failed");
     if ((rc = ensure(ctx, ctx->r_tmp0, cub_bytes > 0 ? cub_bytes : 1))) return rc;
-    if (hipcub::DeviceRadixSort::SortKeys(ctx->r_tmp0.ptr, cub_bytes, d_keys, d_sorted, N, 0, 64, st) != hipSuccess)
+    if (rocprim::radix_sort_keys(ctx->r_tmp0.ptr, cub_bytes, d_keys, d_sorted, (size_t)N, 0u, 64u, st) != hipSuccess)
         return fail(ctx, MVS_EHIP, "mvs_filter_points: radix sort failed");
     greedy_ranks<<<g, 256, 0, st>>>(d_sorted, N, d_rank);
     MVS_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)N, st));
     if (d_up_alt) {  // long lists: a second ordering of the upper lists, by the rank of the neighbour
         list_keys<<<g, 256, 0, st>>>(d_off_up, d_up, N, d_rank, d_skeys);
         if ((rc = ensure(ctx, ctx->r_tmp0, pair_bytes > 0 ? pair_bytes : 1))) return rc;  // the key sort above may have grown it
-        if (hipcub::DeviceRadixSort::SortPairs(ctx->r_tmp0.ptr, pair_bytes, d_skeys, d_skeys2, (unsigned long long *)d_up, (unsigned long long *)d_up_alt,
-                                               total, 0, key_bits, st) != hipSuccess)
+        if (rocprim::radix_sort_pairs(ctx->r_tmp0.ptr, pair_bytes, d_skeys, d_skeys2, (unsigned long long *)d_up, (unsigned long long *)d_up_alt,
+                                      (size_t)total, 0u, (unsigned)key_bits, st) != hipSuccess)
             return fail(ctx, MVS_EHIP, "mvs_filter_points: rank sort failed");
     }
     MVS_HIP(ctx, hipGetLastError());

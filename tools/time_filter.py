@@ -13,7 +13,8 @@ with mvs_amd.Context(640, 480) as ctx:
         alpha = 4 * 3.0 * spacing            # radius = alpha / 4 = 3 grid spacings (compared with SQUARED distances as the reference does)
         alpha = 4 * (3.0 * spacing) ** 2
         t0 = time.perf_counter(); keep = ctx.filter_points(pts, alpha); t1 = time.perf_counter()
-        ctx.profile_enable(True); ctx.profile_read(True)
-        t2 = time.perf_counter(); keep = ctx.filter_points(pts, alpha); t3 = time.perf_counter()
-        ms, nl = ctx.profile_read(True); ctx.profile_enable(False)
-        print(json.dumps({"points": pts.shape[0], "kept": int(len(keep)), "wall_ms": (t3 - t2) * 1e3, "first_call_ms": (t1 - t0) * 1e3, "device_ms_by_class": [round(v, 2) for v in ms]}))
+        walls = []
+        for _ in range(5):      # the call speculates one power iteration ahead of the host's convergence test: its wall time is bimodal
+            t2 = time.perf_counter(); keep = ctx.filter_points(pts, alpha); walls.append((time.perf_counter() - t2) * 1e3)
+        print(json.dumps({"points": pts.shape[0], "kept": int(len(keep)), "wall_ms_min": min(walls), "wall_ms_all": [round(w, 1) for w in walls],
+                          "first_call_ms": (t1 - t0) * 1e3}))
