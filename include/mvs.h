@@ -47,6 +47,10 @@ void mvs_destroy(mvs_ctx *ctx);
 const char *mvs_last_error(const mvs_ctx *ctx);
 /* run all subsequent work of `ctx` on the caller's hipStream_t (NULL = the context's own stream) */
 int mvs_set_stream(mvs_ctx *ctx, void *hip_stream);
+/* page-locked host memory for frames / results handed to the entry points below (optional: any host pointer works; from pinned
+ * memory the one-call entries upload at the full PCIe rate and overlap with the device-side preparation).  NULL on failure. */
+void *mvs_host_alloc(size_t bytes);
+void mvs_host_free(void *p);
 /* block until all queued work of the context has finished */
 int mvs_synchronize(mvs_ctx *ctx);
 int mvs_width(const mvs_ctx *ctx);

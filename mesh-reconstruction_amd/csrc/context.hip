@@ -191,6 +191,23 @@ void mvs_destroy(mvs_ctx *ctx)
 
 const char *mvs_last_error(const mvs_ctx *ctx) { return ctx ? ctx->err : g_err; }
 
+// Page-locked host memory for frames and results: uploads from it run at the full PCIe rate and truly asynchronously (a pageable
+// buffer is first staged by the runtime, at roughly half the rate).  Plain memory to the caller (a cv::Mat can wrap it).
+void *mvs_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail(nullptr, MVS_ENOMEM, "mvs_host_alloc: hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void mvs_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int mvs_set_stream(mvs_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return MVS_EINVAL;
@@ -239,7 +256,15 @@ int mvs_profile_read(mvs_ctx *ctx, float ms_sum[MVS_K_COUNT], int launches[MVS_K
 
 // ---- sweep inputs -------------------------------------------------------------------------------------
 
-int mvs_sweep_set_main(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw)
+// The three setters share their bodies with the one-call entry mvs_sweep, which queues everything -- uploads, padding, quad
+// images, plane table -- on the stream WITHOUT intermediate synchronisation and waits once, at the depth download: a pageable
+// hipMemcpyAsync returns when the caller's bytes have been staged, so the caller's buffers are free either way, and the padding /
+// quad-image kernels of view v run while the host stages view v + 1.  Called on their own, the setters synchronise before returning.
+}  // extern "C"
+
+namespace mvs {
+
+int sweep_set_main_impl(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, bool sync)
 {
     if (!ctx || !main_cam || !main_hw) return fail(ctx, MVS_EINVAL, "mvs_sweep_set_main: null argument");
     MVS_HIP(ctx, hipSetDevice(ctx->device));
@@ -247,7 +272,7 @@ int mvs_sweep_set_main(mvs_ctx *ctx, const float main_cam[16], const uint8_t *ma
     int rc = ensure(ctx, ctx->main_img, P);
     if (rc) return rc;
     MVS_HIP(ctx, hipMemcpyAsync(ctx->main_img.ptr, main_hw, P, hipMemcpyHostToDevice, ctx->stream));
-    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // caller's buffer is not retained
+    if (sync) MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // caller's buffer is not retained
     memcpy(ctx->main_cam, main_cam, sizeof(float) * 16);
     ctx->have_main = true;
     ctx->plan_valid = false;
@@ -256,7 +281,7 @@ int mvs_sweep_set_main(mvs_ctx *ctx, const float main_cam[16], const uint8_t *ma
     return MVS_OK;
 }
 
-int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames)
+int sweep_set_views_impl(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames, bool sync)
 {
     if (!ctx || nviews < 0 || nviews > 256 || (nviews > 0 && (!side_cams || !side_frames)))
         return fail(ctx, MVS_EINVAL, "mvs_sweep_set_views: bad arguments (nviews=%d, must be 0..256)", nviews);
@@ -269,51 +294,59 @@ int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const 
     ctx->V = nviews;
     ctx->q_host.assign((size_t)nviews * 12, 0.f);
     if (nviews > 0) {
-        // + 64: the staging loads of the tiled sweep read whole dwords up to 7 bytes past a row's last used texel
+        for (int v = 0; v < nviews; v++)
+            if (!side_frames[v]) return fail(ctx, MVS_EINVAL, "mvs_sweep_set_views: side_frames[%d] is null", v);
+        // + 64: the staging loads of the exact sampler read whole dwords up to 7 bytes past a row's last used texel
         int rc = ensure(ctx, ctx->side_pads, ctx->pad_slab * nviews + 64);
         if (rc) return rc;
-        if ((rc = ensure(ctx, ctx->upload, P))) return rc;
+        if ((rc = ensure(ctx, ctx->upload, P * nviews))) return rc;  // one slot per view: no upload waits for the previous view's kernels
         if ((rc = ensure(ctx, ctx->qmats, sizeof(float) * 12 * nviews))) return rc;
         if ((rc = ensure(ctx, ctx->side_quads, ctx->pad_slab * nviews * sizeof(uint32_t) + 256))) return rc;
+        for (int v = 0; v < nviews; v++) view_matrix(ctx->main_cam, side_cams + 16 * v, W, H, ctx->q_host.data() + 12 * v);
+        MVS_HIP(ctx, hipMemcpyAsync(ctx->qmats.ptr, ctx->q_host.data(), sizeof(float) * 12 * nviews, hipMemcpyHostToDevice, ctx->stream));
         for (int v = 0; v < nviews; v++) {
-            if (!side_frames[v]) return fail(ctx, MVS_EINVAL, "mvs_sweep_set_views: side_frames[%d] is null", v);
-            view_matrix(ctx->main_cam, side_cams + 16 * v, W, H, ctx->q_host.data() + 12 * v);
-            MVS_HIP(ctx, hipMemcpyAsync(ctx->upload.ptr, side_frames[v], P, hipMemcpyHostToDevice, ctx->stream));
+            uint8_t *raw = (uint8_t *)ctx->upload.ptr + P * v;
+            MVS_HIP(ctx, hipMemcpyAsync(raw, side_frames[v], P, hipMemcpyHostToDevice, ctx->stream));
             dim3 grid(div_up(ctx->pad_pitch, 256), H + 2);
-            pad_wrap_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)ctx->upload.ptr,
-                                                          (uint8_t *)ctx->side_pads.ptr + ctx->pad_slab * v, W, H,
-                                                          ctx->pad_pitch);
-            quad_image_kernel<<<dim3(div_up(ctx->pad_pitch, 256), H + 2), 256, 0, ctx->stream>>>(
-                (const uint8_t *)ctx->side_pads.ptr + ctx->pad_slab * v, (uint32_t *)ctx->side_quads.ptr + ctx->pad_slab * v, W, H, ctx->pad_pitch);
+            pad_wrap_kernel<<<grid, 256, 0, ctx->stream>>>(raw, (uint8_t *)ctx->side_pads.ptr + ctx->pad_slab * v, W, H, ctx->pad_pitch);
+            quad_image_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)ctx->side_pads.ptr + ctx->pad_slab * v,
+                                                             (uint32_t *)ctx->side_quads.ptr + ctx->pad_slab * v, W, H, ctx->pad_pitch);
             MVS_HIP(ctx, hipGetLastError());
-            MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging buffer is reused per view
         }
-        MVS_HIP(ctx, hipMemcpyAsync(ctx->qmats.ptr, ctx->q_host.data(), sizeof(float) * 12 * nviews,
-                                    hipMemcpyHostToDevice, ctx->stream));
-        MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (sync) MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     ctx->have_views = true;
     ctx->plan_valid = false;
     return MVS_OK;
 }
 
-int mvs_sweep_set_planes(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi)
+int sweep_set_planes_impl(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi, bool sync)
 {
     if (!ctx || nplanes < 1 || nplanes > 4096)
         return fail(ctx, MVS_EINVAL, "mvs_sweep_set_planes: nplanes=%d out of range 1..4096", nplanes);
     MVS_HIP(ctx, hipSetDevice(ctx->device));
     ctx->D = nplanes;
-    ctx->z_host.resize(nplanes);
+    ctx->z_host.resize(nplanes);   // stays alive with the context: the asynchronous upload below reads it
     plane_table(nplanes, z_lo, z_hi, ctx->z_host.data());
     int rc = ensure(ctx, ctx->ztab, sizeof(float) * nplanes);
     if (rc) return rc;
-    MVS_HIP(ctx, hipMemcpyAsync(ctx->ztab.ptr, ctx->z_host.data(), sizeof(float) * nplanes, hipMemcpyHostToDevice,
-                                ctx->stream));
-    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MVS_HIP(ctx, hipMemcpyAsync(ctx->ztab.ptr, ctx->z_host.data(), sizeof(float) * nplanes, hipMemcpyHostToDevice, ctx->stream));
+    if (sync) MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_planes = true;
     ctx->plan_valid = false;
     return MVS_OK;
 }
+
+}  // namespace mvs
+
+extern "C" {
+
+int mvs_sweep_set_main(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw) { return sweep_set_main_impl(ctx, main_cam, main_hw, true); }
+int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames)
+{
+    return sweep_set_views_impl(ctx, nviews, side_cams, side_frames, true);
+}
+int mvs_sweep_set_planes(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi) { return sweep_set_planes_impl(ctx, nplanes, z_lo, z_hi, true); }
 
 int mvs_sweep_view_matrices(mvs_ctx *ctx, float *q_out)
 {

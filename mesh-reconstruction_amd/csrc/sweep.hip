@@ -1044,9 +1044,11 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
     if (!ctx) return MVS_EINVAL;
     if (!depth_hw) return fail(ctx, MVS_EINVAL, "mvs_sweep: depth_hw is null");
     int rc;
-    if ((rc = mvs_sweep_set_main(ctx, main_cam, main_hw))) return rc;
-    if ((rc = mvs_sweep_set_views(ctx, nviews, side_cams, side_frames))) return rc;
-    if ((rc = mvs_sweep_set_planes(ctx, nplanes, z_lo, z_hi))) return rc;
+    // everything below is queued on the stream without intermediate waits (the q / z host tables live in the context; pageable
+    // uploads return once staged); mvs_sweep_fetch at the end is the one synchronisation of the call
+    if ((rc = sweep_set_main_impl(ctx, main_cam, main_hw, false))) return rc;
+    if ((rc = sweep_set_views_impl(ctx, nviews, side_cams, side_frames, false))) return rc;
+    if ((rc = sweep_set_planes_impl(ctx, nplanes, z_lo, z_hi, false))) return rc;
     const unsigned flags = MVS_SWEEP_FUSED_ARGMIN | (volume_dhw ? MVS_SWEEP_VOLUME : 0u);
     if ((rc = mvs_sweep_run(ctx, 0, nviews, flags))) return rc;
     if ((rc = mvs_sweep_fetch(ctx, depth_hw, cost_hw, nullptr, nullptr))) return rc;

@@ -31,6 +31,8 @@ ABI = [
     ("mvs_last_error", C.c_char_p, [_vp]),
     ("mvs_set_stream", _i, [_vp, _vp]),
     ("mvs_synchronize", _i, [_vp]),
+    ("mvs_host_alloc", _vp, [_sz]),
+    ("mvs_host_free", None, [_vp]),
     ("mvs_width", _i, [_vp]),
     ("mvs_height", _i, [_vp]),
     ("mvs_load_mesh", _i, [_vp, _fp, _i, _i32p, _i]),
@@ -132,6 +134,21 @@ class _DeviceArray:
     def __init__(self, ptr, shape, typestr):
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
                                          "strides": None}
+
+
+def pinned_array(shape, dtype):
+    """numpy array on page-locked host memory from mvs_host_alloc (freed when the array and its views are gone)"""
+    lib = load_library()
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    ptr = lib.mvs_host_alloc(max(n, 1))
+    if not ptr:
+        raise MvsError("mvs_host_alloc(%d) failed" % n)
+    buf = (C.c_char * max(n, 1)).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    import weakref
+    weakref.finalize(buf, lib.mvs_host_free, ptr)
+    return arr
 
 
 class Comm:
@@ -248,7 +265,7 @@ class Context:
         cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((0, 4, 4), np.float32)
         frames = [_u8(s, (H, W)) for s in side_imgs]
         arr = (_u8p * max(V, 1))(*[_ptr(f, _u8p) for f in frames])
-        depth = np.empty((H, W), np.float32)
+        depth = np.empty((H, W), np.float32) if getattr(self, "_pinned_depth", None) is None else self._pinned_depth
         cost = np.empty((H, W), np.float32) if want_cost else None
         vol = np.empty((nplanes, H, W), np.float32) if want_volume else None
         self._check(self.lib.mvs_sweep(self.h, _ptr(cam, _fp), _ptr(img, _u8p), V, _ptr(cams, _fp), arr, int(nplanes),

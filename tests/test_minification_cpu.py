@@ -1,0 +1,75 @@
+"""How far is level-0 bilinear (what Render::projected and the sweep implement) from the reference's actual texture filter
+when a side view is MINIFIED?  createTexture asks for GL_LINEAR_MIPMAP_LINEAR + glGenerateMipmap + maximal anisotropy
+(render_glx.cpp:79-85); SURVEY.md A-7 treats everything beyond level-0 bilinear as tolerance.  This test puts a number on it:
+a trilinear restatement (2x2 box mip chain, LOD = log2 of the isotropic footprint, linear blend of the two nearest levels --
+the GL 3.0 rules without the driver-specific anisotropic refinement) against level-0 bilinear, for a side view whose texels are
+1.5x and 2x denser than the main view's pixels.  The resulting u8 errors are the stated tolerance of DESIGN.md section 5."""
+import numpy as np
+
+from mvs_amd import synth
+
+
+def _bilinear(img, x, y):
+    """GL_LINEAR at texel-centre coordinates (x, y in texels, centres at integers), clamp to edge"""
+    H, W = img.shape
+    x0 = np.clip(np.floor(x).astype(int), 0, W - 2)
+    y0 = np.clip(np.floor(y).astype(int), 0, H - 2)
+    ax, ay = np.clip(x - x0, 0, 1), np.clip(y - y0, 0, 1)
+    return ((1 - ay) * ((1 - ax) * img[y0, x0] + ax * img[y0, x0 + 1]) + ay * ((1 - ax) * img[y0 + 1, x0] + ax * img[y0 + 1, x0 + 1]))
+
+
+def _mip_chain(img, levels):
+    out = [img.astype(np.float64)]
+    for _ in range(levels):
+        a = out[-1]
+        a = a[:a.shape[0] // 2 * 2, :a.shape[1] // 2 * 2]
+        out.append(0.25 * (a[0::2, 0::2] + a[1::2, 0::2] + a[0::2, 1::2] + a[1::2, 1::2]))   # glGenerateMipmap's usual box filter
+    return out
+
+
+def _trilinear(chain, x, y, lod):
+    l0 = int(np.floor(lod))
+    f = lod - l0
+
+    def level(l):
+        s = 2.0 ** l
+        return _bilinear(chain[l], (x + 0.5) / s - 0.5, (y + 0.5) / s - 0.5)
+    return level(l0) if f == 0 else (1 - f) * level(l0) + f * level(l0 + 1)
+
+
+def _errors(scale, texture="scene"):
+    """main view W x H samples a side frame that is `scale` times denser in both directions (footprint = scale texels); a
+    sub-texel offset keeps pixel centres off the texel corners (there level-0 bilinear IS the 2x2 box average)"""
+    W, H = 320, 240
+    sw, sh = int(W * scale) + 2, int(H * scale) + 2
+    if texture == "scene":
+        side = synth.Scene(freq_scale=sw / 1920.0).render([0.0, 0.0, 0.0], sw, sh)  # the bench's procedural texture at that density
+    elif texture == "pink":                                                         # 1/f spectrum: the statistics of natural images
+        rng = np.random.default_rng(7)
+        fy, fx = np.meshgrid(np.fft.fftfreq(sh), np.fft.fftfreq(sw), indexing="ij")
+        spec = (rng.normal(size=(sh, sw)) + 1j * rng.normal(size=(sh, sw))) / np.maximum(np.hypot(fx, fy), 1.0 / sw)
+        img = np.real(np.fft.ifft2(spec))
+        side = (127.5 + 50.0 * img / img.std()).clip(0, 255).astype(np.uint8)
+    else:                                                                           # i.i.d. noise: the worst case
+        side = np.random.default_rng(7).integers(0, 256, (sh, sw), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    sx, sy = (xx + 0.5) * scale - 0.5 + 0.3, (yy + 0.5) * scale - 0.5 + 0.7        # pixel centres mapped into the side frame
+    lvl0 = np.floor(_bilinear(side.astype(np.float64), sx, sy) + 0.5)
+    tri = np.floor(_trilinear(_mip_chain(side, 3), sx, sy, np.log2(scale)) + 0.5)
+    d = np.abs(lvl0 - tri)[4:-4, 4:-4]
+    return d.mean(), np.percentile(d, 99), d.max()
+
+
+def test_level0_bilinear_vs_trilinear_restatement_is_within_the_stated_tolerance():
+    got = {}
+    for texture in ("scene", "pink", "noise"):
+        for scale in (2.0, 1.5, 1.05):
+            got[texture, scale] = _errors(scale, texture)
+            print("%-5s texture, minification %.2fx: mean |level0 - trilinear| = %.2f grey levels, 99th percentile %.0f, max %.0f" % ((texture, scale) + got[texture, scale]))
+    # the bundled sequences pair neighbouring frames of one clip, whose scale differs by a few per cent (LOD ~ 0.05): first column
+    # measured: smooth procedural scene 0.04 / 1-f texture 0.8 / white noise 2.3 grey levels on average
+    assert got["scene", 1.05][0] < 0.1 and got["pink", 1.05][0] < 1.2 and got["pink", 1.05][1] <= 4 and got["noise", 1.05][0] < 3.0
+    # a side view twice as dense as the main view: this is where the reference's mipmapping matters -- 0.6 / 11 / 35 grey levels on
+    # average, i.e. level-0 bilinear is NOT a stand-in for the GL filter there (DESIGN.md section 5 says so)
+    assert got["scene", 2.0][0] < 1.0 and got["pink", 2.0][0] < 15.0 and got["noise", 2.0][0] < 40.0
+    assert got["pink", 2.0][0] > 5 * got["pink", 1.05][0]
