@@ -24,6 +24,10 @@ def main():
                         side_cams=side_cams, side_imgs=np.stack(sides), D=D, depth=depth, cost=cost, idx=idx, vol=vol,
                         gt=gt)
     print("wrote sweep_small.npz", depth.shape, vol.shape)
+    # the same inputs through the fixed sampler (contract v2): only the outputs are stored
+    depth, cost, idx, vol = o.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, sampler="fixed")
+    np.savez_compressed(os.path.join(HERE, "sweep_small_fx.npz"), D=D, depth=depth, cost=cost, idx=idx, vol=vol, lut=o.fx_weight_table())
+    print("wrote sweep_small_fx.npz", depth.shape, vol.shape)
     stage_small(o)
 
 

@@ -162,3 +162,97 @@ def test_golden_stage_fixture(oracle):
         else:
             np.testing.assert_array_equal(out[k], g[k], err_msg=k)
     assert int(g["points_n"]) > 1000 and 0 < int(g["filter_keep_n"]) < int(g["filter_n"])
+
+
+# ---- the fixed sampler (contract v2) ---------------------------------------------------------------------------------
+
+def test_fixed_sampler_weight_table():
+    """32 x 32 entries of four 8-bit weights: every entry sums to 255, the texel-centre entry is (255, 0, 0, 0), symmetric under
+    x <-> y, within rounding of the exact bilinear weights"""
+    from orc import load
+    lut = load().fx_weight_table().astype(np.int64)
+    assert lut.shape == (32, 32, 4) and (lut.sum(-1) == 255).all()
+    np.testing.assert_array_equal(lut[0, 0], [255, 0, 0, 0])
+    np.testing.assert_array_equal(lut[0, 16], [127, 128, 0, 0])          # the fix-up goes to the first of the largest weights
+    np.testing.assert_array_equal(lut[:, :, 1], lut[:, :, 2].T)            # w01(kx, ky) = w10(ky, kx)
+    a = np.arange(32) / 32.0
+    exact = np.stack([np.outer(1 - a, 1 - a), np.outer(1 - a, a), np.outer(a, 1 - a), np.outer(a, a)], -1) * 255.0   # [ky][kx]
+    assert np.abs(lut - exact).max() <= 1.5 and np.abs(lut - exact).mean() < 0.35   # 1.41 where the sum fix-up lands
+
+
+def _mirror_fixed(oracle, main_cam, main_img, side_cam, side, D):
+    """numpy restatement of one view of orc_sweep_fx (float64 products are exact for f32 factors; rint = round half to even)"""
+    H, W = main_img.shape
+    f32 = np.float32
+
+    def fma32(a, b, c):
+        return (np.float64(a) * np.float64(b) + np.float64(c)).astype(f32)
+    Q = oracle.view_matrix(main_cam, side_cam, W, H).astype(f32)
+    z = oracle.plane_table(D, -1.0, 1.0)
+    pad = oracle.pad_image(side).astype(np.int64)
+    lut = oracle.fx_weight_table().astype(np.int64)
+    xn = fma32(f32(2 * np.arange(W) + 1), f32(1.0) / f32(W), f32(-1.0))
+    yn = fma32(-f32(2 * np.arange(H) + 1), f32(1.0) / f32(H), f32(1.0))
+    XN, YN = np.meshgrid(xn, yn)
+    A = [fma32(Q[r, 0], XN, fma32(Q[r, 1], YN, Q[r, 3])) for r in range(3)]
+    out = np.zeros((D, H, W), np.uint32)
+    for d in range(D):
+        sx, sy, sw = fma32(z[d], Q[0, 2], A[0]), fma32(z[d], Q[1, 2], A[1]), fma32(z[d], Q[2, 2], A[2])
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            r256 = ((f32(1.0) / sw).astype(f32) * f32(256)).astype(f32)
+            ux = np.nan_to_num(np.rint(sx.astype(np.float64) * r256.astype(np.float64) + 4.0), nan=-1, posinf=-1, neginf=-1).astype(np.int64)
+            uy = np.nan_to_num(np.rint(sy.astype(np.float64) * r256.astype(np.float64) + 4.0), nan=-1, posinf=-1, neginf=-1).astype(np.int64)
+        ok = (sw > 0) & (ux > 132) & (ux < 256 * W + 132) & (uy > 132) & (uy < 256 * H + 132)
+        ix, iy = np.clip(ux >> 8, 0, W), np.clip(uy >> 8, 0, H)
+        w = lut[(uy >> 3) & 31, (ux >> 3) & 31]
+        dot = w[..., 0] * pad[iy, ix] + w[..., 1] * pad[iy, ix + 1] + w[..., 2] * pad[iy + 1, ix] + w[..., 3] * pad[iy + 1, ix + 1]
+        out[d] = np.where(ok, (1 << 24) + np.abs(dot - 255 * main_img.astype(np.int64)), 0)
+    return out
+
+
+def test_fixed_sampler_matches_an_independent_numpy_mirror(oracle):
+    """orc_sweep_fx cell for cell against a vectorised numpy restatement of the contract (1/256-texel coordinates by one rounding of
+    the exact product, 1/32-texel table index, in-frame test on the rounded coordinate), ring and rotated cameras, ragged size"""
+    W, H, D = 90, 40, 9
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, 3, radius=0.4, freq_scale=0.3)
+    side_cams = side_cams.copy()
+    cy, sy = np.cos(0.3), np.sin(0.3)
+    side_cams[2] = synth.camera_at([-0.5, 0.3, -0.2], W, H, rot=np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]))
+    for v in range(3):
+        vol = oracle.sweep(main_cam, main_img, side_cams[v:v + 1], sides[v:v + 1], D, want_volume=True, sampler="fixed")[3]
+        np.testing.assert_array_equal(vol, _mirror_fixed(oracle, main_cam, main_img, side_cams[v], sides[v], D))
+        assert (vol >> 24).max() == 1 and (vol == 0).any() or v < 2
+
+
+def test_fixed_sampler_cells_add_over_views_and_select_like_the_exact_one(oracle):
+    """(1) shard volumes add to the full volume as integers (the all-reduce invariant); (2) orc_argmin_fx on the volume equals the
+    sweep's own selection; (3) against the exact sampler: identical in-frame counts, mean cost within a fraction of a grey level"""
+    W, H, D, V = 160, 96, 16, 4
+    main_cam, main_img, side_cams, sides, gt = synth.make_views(W, H, V, radius=0.3, freq_scale=0.3)
+    d, c, i, full = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, sampler="fixed")
+    acc = np.zeros_like(full)
+    for r in range(2):
+        acc += oracle.sweep(main_cam, main_img, side_cams[2 * r:2 * r + 2], sides[2 * r:2 * r + 2], D, want_volume=True, sampler="fixed")[3]
+    np.testing.assert_array_equal(acc, full)
+    d2, c2, i2 = oracle.argmin(full, oracle.plane_table(D, -1.0, 1.0), sampler="fixed")
+    np.testing.assert_array_equal(i2, i)
+    np.testing.assert_array_equal(d2, d)
+    np.testing.assert_array_equal(c2, c)
+    v1 = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True)[3]
+    np.testing.assert_array_equal(v1 >> 16, full >> 24)
+    cnt = np.maximum(v1 >> 16, 1)
+    diff = np.abs((v1 & 0xffff) / cnt - (full & 0xffffff) / cnt / 255.0)
+    assert diff.mean() < 0.3 and diff.max() < 2.0, (diff.mean(), diff.max())
+
+
+def test_golden_sweep_fixture_fixed_sampler(oracle):
+    """pins orc_sweep_fx and its weight table against the committed vectors (tests/golden/make_golden.py regenerates them)"""
+    g = np.load(os.path.join(GOLDEN, "sweep_small.npz"))
+    f = np.load(os.path.join(GOLDEN, "sweep_small_fx.npz"))
+    depth, cost, idx, vol = oracle.sweep(g["main_cam"], g["main_img"], g["side_cams"], list(g["side_imgs"]), int(f["D"]), want_volume=True,
+                                         sampler="fixed")
+    np.testing.assert_array_equal(oracle.fx_weight_table(), f["lut"])
+    np.testing.assert_array_equal(vol, f["vol"])
+    np.testing.assert_array_equal(idx, f["idx"])
+    np.testing.assert_array_equal(depth, f["depth"])
+    np.testing.assert_array_equal(cost, f["cost"])
