@@ -502,3 +502,20 @@ def test_fixed_sampler_region_prefetch_is_bit_identical(oracle):
         for a, b in zip(plain, ahead):
             np.testing.assert_array_equal(a, b)
         _check(ahead, ref, D)
+
+
+def test_sweep_matches_the_committed_golden_vectors(sampler):
+    """HIP through the C ABI against tests/golden/sweep_small*.npz (written by the oracle via tests/golden/make_golden.py and
+    committed): no oracle runs here, so the HIP path and the oracle cannot drift together unnoticed"""
+    import os
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(golden, "sweep_small.npz"))
+    f = g if sampler == "exact" else np.load(os.path.join(golden, "sweep_small_fx.npz"))
+    H, W = g["main_img"].shape
+    for kernel_flag in (0, mvs_amd.MVS_SWEEP_FORCE_GENERIC):
+        depth, cost, idx, vol = _gpu_sweep(W, H, g["main_cam"], g["main_img"], g["side_cams"], list(g["side_imgs"]), int(f["D"]),
+                                           mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | kernel_flag, sampler=sampler)
+        np.testing.assert_array_equal(vol, f["vol"])
+        np.testing.assert_array_equal(idx, f["idx"])
+        np.testing.assert_array_equal(depth, f["depth"])
+        np.testing.assert_array_equal(cost, f["cost"])
