@@ -43,6 +43,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t sad_u16(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u16(a, b, acc); }
 
 // one sample with every check, taps and weights from global memory (planner mode GENERIC, the un-tiled kernel, warp_by_depth)
+// WSCALED: the caller's w row (A.aw, bw) is the view matrix's divided by 256, so RN(1 / s.w) already is 256 r -- bit for bit, a
+// power of two commutes with every rounding involved (the tiled kernel keeps its view matrices in that form)
+template <bool WSCALED = false>
 __device__ __forceinline__ uint32_t sample_global_fx(const Affine &A, float bx, float by, float bw, float z, const uint8_t *__restrict__ pad,
                                                      int pitch, float hix, float hiy, const uint32_t *__restrict__ lut, uint32_t Im255,
                                                      uint32_t *dot_out = nullptr)
@@ -51,7 +54,7 @@ __device__ __forceinline__ uint32_t sample_global_fx(const Affine &A, float bx, 
     const float sy = __builtin_fmaf(z, by, A.ay);
     const float sw = __builtin_fmaf(z, bw, A.aw);
     if (!(sw > 0.0f)) return 0u;
-    const float r256 = rcp_rn(sw) * 256.0f;
+    const float r256 = WSCALED ? rcp_rn(sw) : rcp_rn(sw) * 256.0f;
     const float tx = __builtin_fmaf(sx, r256, FX_MAGIC + 4.0f), ty = __builtin_fmaf(sy, r256, FX_MAGIC + 4.0f);
     if (!(tx > FX_MAGIC + 132.0f && tx < hix && ty > FX_MAGIC + 132.0f && ty < hiy)) return 0u;
     const uint32_t ux = __builtin_bit_cast(uint32_t, tx) & 0x3fffffu, uy = __builtin_bit_cast(uint32_t, ty) & 0x3fffffu;  // tx - magic
@@ -217,7 +220,7 @@ __device__ __forceinline__ void sample_range_fx(const Affine &A, float bx, float
                 const f32x2 sw = __builtin_elementwise_fma(z, (f32x2)(bw), (f32x2)(A.aw));
                 const f32x2 r0 = {__builtin_amdgcn_rcpf(sw.x), __builtin_amdgcn_rcpf(sw.y)};
                 const f32x2 e = __builtin_elementwise_fma(-sw, r0, (f32x2)(1.0f));
-                r256 = __builtin_elementwise_fma(e, r0, r0) * (f32x2)(256.0f);
+                r256 = __builtin_elementwise_fma(e, r0, r0);  // the w row is pre-divided by 256 (see the kernel)
             }
             const f32x2 Tx = __builtin_elementwise_fma(sx, r256, (f32x2)(offx));
             const f32x2 Ty = __builtin_elementwise_fma(sy, r256, (f32x2)(offy));
@@ -273,7 +276,7 @@ __device__ __forceinline__ void sample_range_fx_checked(const Affine &A, float b
     for (int k = K0; k < K0 + KN; k++) {
         const float z = zc[k];
         const float sx = __builtin_fmaf(z, bx, A.ax), sy = __builtin_fmaf(z, by, A.ay), sw = __builtin_fmaf(z, bw, A.aw);
-        const float r256 = rcp_rn(sw) * 256.0f;
+        const float r256 = rcp_rn(sw);  // w row pre-divided by 256
         const float Tx = __builtin_fmaf(sx, r256, rg.offx), Ty = __builtin_fmaf(sy, r256, rg.offy);
         const bool ok = Tx > rg.lox && Tx < rg.hix && Ty > rg.loy && Ty < rg.hiy;
         const float Txc = __builtin_amdgcn_fmed3f(Tx, rg.cminx, rg.cmaxx), Tyc = __builtin_amdgcn_fmed3f(Ty, rg.cminy, rg.cmaxy);
@@ -358,7 +361,9 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
             if (vi == 0) {  // next batch of per-view constants (wave-uniform branch; no region is in flight here: ahead == false)
                 __syncthreads();
                 const int nb = min(FX_VB, vend - v);
-                for (int i = threadIdx.x; i < nb * 12; i += 256) qtab[i] = p.Q[12 * v + i];
+                // the w row goes in divided by 256: then RN(1 / s.w) IS 256 r, bit for bit (a power of two commutes with the roundings of
+                // fma, v_rcp_f32 and the Newton step), and the sample loop needs no multiplication by 256
+                for (int i = threadIdx.x; i < nb * 12; i += 256) qtab[i] = p.Q[12 * v + i] * ((i % 12) >= 8 ? 0.00390625f : 1.0f);
                 for (int i = threadIdx.x; i < nb; i += 256) dtab[i] = plan[v + i];
                 __syncthreads();
             }
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                     if (ok[j]) {
                         const Affine A = view_affine(q, xn, yn[j]);
 #pragma unroll
-                        for (int k = 0; k < PC; k++) acc[j][k] += sample_global_fx(A, bx, by, bw, zc[k], pad, p.pitch, fhix, fhiy, lut_g, Im255[j]);
+                        for (int k = 0; k < PC; k++) acc[j][k] += sample_global_fx<true>(A, bx, by, bw, zc[k], pad, p.pitch, fhix, fhiy, lut_g, Im255[j]);
                     }
                 }
                 continue;
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                     for (int e = 0; e < 2; e++) {
                         const float z = e ? zc[PC - 1] : zc[0];
                         const float sx = __builtin_fmaf(z, bx, A.ax), sy = __builtin_fmaf(z, by, A.ay), sw = __builtin_fmaf(z, bw, A.aw);
-                        const float r256 = rcp_rn(sw) * 256.0f;
+                        const float r256 = rcp_rn(sw);
                         const float Tx = __builtin_fmaf(sx, r256, rg.offx), Ty = __builtin_fmaf(sy, r256, rg.offy);
                         inside = inside && Tx > rg.lox + 2.0f && Tx < rg.hix - 2.0f && Ty > rg.loy + 2.0f && Ty < rg.hiy - 2.0f;
                     }
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                     lane_views[j] += 1u << 24;
                 }
                 if (wconst) {
-                    const float r256c = rcp_rn(__builtin_fmaf(zc[0], bw, A.aw)) * 256.0f;
+                    const float r256c = rcp_rn(__builtin_fmaf(zc[0], bw, A.aw));
                     sample_range_fx<0, PC, true>(A, bx, by, bw, r256c, zc, rg.offx, rg.offy, lds_base, Im255[j], acc[j]);
                 } else {
                     sample_range_fx<0, PC, false>(A, bx, by, bw, 0.0f, zc, rg.offx, rg.offy, lds_base, Im255[j], acc[j]);
