@@ -32,8 +32,10 @@ def test_pmc_traffic_picks_the_newest_profile_numerically(tmp_path, monkeypatch)
 
 
 def test_committed_profiles_resolve():
-    got = _bench().pmc_traffic("sweep_tiled", "c3")
-    assert got is not None and got["bytes"] > 1.0e9 and "pmc_c3_v" in got["source"]
+    for kernel in ("sweep_tiled", "sweep_fx_tiled"):       # exact and fixed sampler: the newest round's summary of each
+        got = _bench().pmc_traffic(kernel, "c3")
+        assert got is not None and got["bytes"] > 1.0e9 and "pmc_c3_v" in got["source"] and "r02" in got["source"], kernel
+        assert 0.3 < got["valu_utilisation"] < 1.05
 
 
 def test_gpus_without_a_launcher_is_refused():

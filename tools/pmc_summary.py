@@ -5,14 +5,15 @@ usage: tools/pmc_summary.py <config> <tag> <out.json> <dir with *_counter_collec
 FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE counts half of the bytes of wide
 (16 B per lane) streaming reads (MI355X_MICROARCH.md, HBM section), so both the raw and the doubled figure are kept;
 `hbm_bytes_per_launch` uses the doubled fetch only for kernels listed in WIDE_READERS (argmin_volume streams uint4),
-the raw one otherwise (the sweep's staging reads are 4-byte loads, uncalibrated: raw figure is the lower bound)."""
+the raw one otherwise (the exact sampler's staging reads are 4-byte loads, uncalibrated: raw figure is the lower bound)."""
 import collections
 import csv
 import glob
 import json
 import sys
 
-WIDE_READERS = ("void mvs::argmin_volume<4>",)
+# kernels whose reads are 16 bytes per lane: argmin_volume streams uint4; sweep_fx_tiled fills LDS with global_load_lds_dwordx4
+WIDE_READERS = ("void mvs::argmin_volume<4", "void mvs::sweep_fx_tiled")
 
 
 def main():
