@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
         ok[j] = col_ok && row < p.H;
         yn[j] = __builtin_fmaf(-(float)(2 * row + 1), p.invH, 1.0f);
         Im[j] = ok[j] ? (int)p.main_img[(size_t)row * p.W + col] : 0;
-        if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(0u, 0xffffffffu);  // own slot only: no barrier needed
+        if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(1u, 0xffffffffu);  // own slot only: no barrier needed
     }
 
     // plane split: a launch with too few tiles to fill the chip (a row band, a small frame) gives each workgroup only
@@ -530,23 +530,44 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
             }
         }
 
+        // chunk epilogue: as in sweep_fx_tiled (uniform plane base + 32-bit lane offset; running best started at (sum 1, count 0),
+        // so one cross-multiplied comparison per plane decides, empty cells included)
+        uint32_t *const vol_chunk = WRITE_VOLUME ? p.volume + (size_t)d0 * P : nullptr;
+        const bool whole = d0 + PC <= p.D;
 #pragma unroll
         for (int j = 0; j < NPX; j++) {
             if (ok[j]) {
-                const size_t pix = (size_t)(row0 + j) * p.W + col;
-                uint32_t best = 0u;
+                const uint32_t pix = (uint32_t)((row0 + j) * p.W + col);
+                uint32_t best = 1u;
                 int bi = -1;
                 if (FUSED) {
                     const uint2 st = best_state[j * 256 + threadIdx.x];
                     best = st.x;
                     bi = (int)st.y;
                 }
+                if (whole) {
 #pragma unroll
-                for (int k = 0; k < PC; k++) {
-                    if (d0 + k < p.D) {
+                    for (int k = 0; k < PC; k++) {
                         const uint32_t cell = acc[j][k] + fast_views;
-                        if (WRITE_VOLUME) p.volume[(size_t)(d0 + k) * P + pix] = cell;
-                        if (FUSED) argmin_update_packed(cell, d0 + k, best, bi);
+                        if (WRITE_VOLUME) (vol_chunk + (size_t)k * P)[pix] = cell;
+                        if (FUSED) {
+                            const bool better = umul24u(cell & 0xffffu, best >> 16) < umul24u(best & 0xffffu, cell >> 16);
+                            best = better ? cell : best;
+                            bi = better ? d0 + k : bi;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < PC; k++) {
+                        if (d0 + k < p.D) {
+                            const uint32_t cell = acc[j][k] + fast_views;
+                            if (WRITE_VOLUME) (vol_chunk + (size_t)k * P)[pix] = cell;
+                            if (FUSED) {
+                                const bool better = umul24u(cell & 0xffffu, best >> 16) < umul24u(best & 0xffffu, cell >> 16);
+                                best = better ? cell : best;
+                                bi = better ? d0 + k : bi;
+                            }
+                        }
                     }
                 }
                 if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(best, (uint32_t)bi);
@@ -557,7 +578,8 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
 #pragma unroll
         for (int j = 0; j < NPX; j++)
             if (ok[j]) {
-                const uint2 st = best_state[j * 256 + threadIdx.x];
+                uint2 st = best_state[j * 256 + threadIdx.x];
+                if ((int)st.y < 0) st.x = 0u;  // no plane had a view in frame: the empty cell
                 const size_t pix = (size_t)(row0 + j) * p.W + col;
                 if (p.part)
                     p.part[(size_t)blockIdx.y * P + pix] = st;

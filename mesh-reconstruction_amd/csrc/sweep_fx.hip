@@ -21,12 +21,17 @@
 //   weights  (P >> 1) & 0x7c7c = ky << 10 | kx << 2          quad  ((P >> 14) & 0x7ffc) + 128 = iy << 10 | ix << 2 (+ 128)
 #include "sweep_shared.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 namespace mvs {
 
 constexpr int FX_ROWS = 32;       // region rows (and weight-table rows) per LDS image
 constexpr int FX_ROW_DW = 256;    // dwords per LDS row
 constexpr int FX_LUT_DW = 32;     // of which the first 32 hold the weight-table row
 constexpr int FX_MAX_RW = FX_ROW_DW - FX_LUT_DW;  // 224 quads
+constexpr int FX_HALF_COL = FX_MAX_RW / 2;          // two regions of up to 112 quads side by side (region look-ahead)
 constexpr float FX_MAGIC = 12582912.0f;            // 1.5 * 2^23: floats in [2^23, 2^24) have ulp 1
 constexpr int FX_TILE_H = 8, FX_PC = 16, FX_NPX = 2;  // 64x8-pixel tiles, 16 planes per chunk: 32 accumulators per thread
 constexpr int FX_GS = 4;          // samples per software-pipeline group
@@ -180,9 +185,9 @@ __global__ __launch_bounds__(256) void plan_regions_fx(SweepParams p, uint2 *__r
 // Stage quads [x0, x0+rw) x [y0, y0+rh) of a view's quad image: one global_load_lds_dwordx4 per region row (each active lane
 // copies 4 quads = 16 bytes straight into LDS; the destination is the row's base + lane * 16, hence no register, no shuffle).
 // Rows are dealt to the four wavefronts; completion is awaited by the caller's __syncthreads() (it drains vmcnt).
-// The 32 LDS rows are a ring: region row ry lives in LDS row (base + ry) mod 32 -- the sampler's address mask wraps the same way --
-// so the NEXT view's region is requested into the rows behind the current one while the current one is being sampled.
-__device__ __forceinline__ void stage_region_fx(const uint32_t *__restrict__ quads, int pitch, int x0, int y0, int rw, int rh, int base,
+// `col` = first quad column of the LDS rows the region goes to: a row holds 224 quads and a typical region is 70-90 wide, so two
+// regions sit side by side (columns 0 and FX_HALF_COL) and the NEXT view's region is copied while the current one is sampled.
+__device__ __forceinline__ void stage_region_fx(const uint32_t *__restrict__ quads, int pitch, int x0, int y0, int rw, int rh, int col,
                                                 uint32_t *__restrict__ lds)
 {
     const int lane = threadIdx.x & 63;
@@ -192,7 +197,7 @@ __device__ __forceinline__ void stage_region_fx(const uint32_t *__restrict__ qua
     for (int ry = wave; ry < rh; ry += 4) {
         if (lane < units)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)ry * pitch),
-                                             (__attribute__((address_space(3))) void *)(lds + ((base + ry) & (FX_ROWS - 1)) * FX_ROW_DW + FX_LUT_DW), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(lds + ry * FX_ROW_DW + FX_LUT_DW + col), 16, 0, 0);
     }
 }
 
@@ -261,6 +266,11 @@ __device__ __forceinline__ void sample_range_fx(const Affine &A, float bx, float
     }
 }
 
+// FX_MAGIC + k as a float, for an integer |k| < 2^22: in the binade [2^23, 2^24) one ulp is 1, so the bit pattern is 0x4B400000 + k.
+// With a wave-uniform k this is scalar integer arithmetic (gfx950's SALU has no float unit; written with floats, every region
+// constant below cost a v_cvt + v_mul + v_add per wavefront and region: ~20 VALU instructions, 5 % of the kernel).
+__device__ __forceinline__ float magic_plus(int k) { return __builtin_bit_cast(float, 0x4B400000 + k); }
+
 struct FxRegion {
     float offx, offy;            // magic + 4 - 256 * region origin: T - magic is the position relative to the region, in 1/256 texel
     float lox, hix, loy, hiy;    // in-frame test on T (strict)
@@ -296,13 +306,13 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
 {
     constexpr int NPX = FX_NPX, PC = FX_PC, TILE_H = FX_TILE_H;
     // one object, so the texel image sits at LDS address 0 and its byte offsets are the ds_read addresses
-    __shared__ __attribute__((aligned(16))) uint32_t smem[FX_ROWS * FX_ROW_DW + FX_VB * 14 + (FUSED ? 2 * 256 * NPX : 0)];
+    __shared__ __attribute__((aligned(16))) uint32_t smem[FX_ROWS * FX_ROW_DW + FX_VB * 14 + 2 + (FUSED ? 2 * 256 * NPX : 0)];
     uint32_t *lds = smem;
     // per-view constants of a batch of up to FX_VB views: view matrix (12 floats) and this chunk's region descriptor (2 dwords).
     // Read from here, a view's constants cost an LDS round trip (~100 cycles) instead of a dependent global load (~1 us) per region.
     float *qtab = (float *)(smem + FX_ROWS * FX_ROW_DW);
     uint2 *dtab = (uint2 *)(smem + FX_ROWS * FX_ROW_DW + FX_VB * 12);
-    uint2 *best_state = (uint2 *)(smem + FX_ROWS * FX_ROW_DW + FX_VB * 14);  // (packed best cell, best index) per (pixel j, thread)
+    uint2 *best_state = (uint2 *)(smem + FX_ROWS * FX_ROW_DW + FX_VB * 14 + 2);  // (packed best cell, best index) per (pixel j, thread)
 
     const int band_tile = (p.debug & 2) ? ((int)blockIdx.x < p.tiles_x * p.tyn ? (int)blockIdx.x : -1) : grouped_tile(blockIdx.x, p.tiles_x, p.tyn);
     if (band_tile < 0) return;
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
         ok[j] = col_ok && row < p.H;
         yn[j] = __builtin_fmaf(-(float)(2 * row + 1), p.invH, 1.0f);
         Im255[j] = ok[j] ? 255u * (uint32_t)p.main_img[(size_t)row * p.W + col] : 0u;
-        if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(0u, 0xffffffffu);  // own slot only: no barrier needed
+        if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(1u, 0xffffffffu);  // (sum 1, count 0), no plane; own slot only: no barrier needed
     }
     const float fhix = FX_MAGIC + 132.0f + 256.0f * (float)p.W, fhiy = FX_MAGIC + 132.0f + 256.0f * (float)p.H;
 
@@ -351,10 +361,11 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
         for (int j = 0; j < NPX; j++) lane_views[j] = 0u;
         const uint2 *plan = p.plan + ((size_t)tile * p.nchunks + chunk) * p.V;
 
-        // Region pipeline of this chunk.  `base` = first LDS ring row of the region being sampled; `ahead` = the region of the view
-        // at hand was requested during the previous view (its copy is in flight or has landed).
-        int base = 0;
+        // Region pipeline of this chunk.  `qcol` = first quad column of the region being sampled; `ahead` = the region of the view at
+        // hand was requested while the previous staged view was being sampled (its copy is in flight or has landed).
+        int qcol = 0;
         bool ahead = false;
+        uint2 dnext = make_uint2(0u, 0u);
         const int vend = p.v0 + p.vcount;
         for (int v = p.v0; v < vend; v++) {
             const int vi = (v - p.v0) & (FX_VB - 1);
@@ -364,12 +375,18 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                 // the w row goes in divided by 256: then RN(1 / s.w) IS 256 r, bit for bit (a power of two commutes with the roundings of
                 // fma, v_rcp_f32 and the Newton step), and the sample loop needs no multiplication by 256
                 for (int i = threadIdx.x; i < nb * 12; i += 256) qtab[i] = p.Q[12 * v + i] * ((i % 12) >= 8 ? 0.00390625f : 1.0f);
-                for (int i = threadIdx.x; i < nb; i += 256) dtab[i] = plan[v + i];
+                for (int i = threadIdx.x; i <= nb; i += 256) dtab[i] = i < nb ? plan[v + i] : make_uint2(0u, 0u);  // + a SKIP sentinel
                 __syncthreads();
+                dnext = dtab[0];
             }
-            const uint2 desc = dtab[vi];
-            const unsigned mode = (unsigned)__builtin_amdgcn_readfirstlane((int)((desc.y >> 16) & 7u));
+            // the per-view bookkeeping below is a chain of dependent scalar work and LDS round trips: let it overtake the other
+            // wavefronts' sample loops on this SIMD (priority back to 0 before this wavefront's own sample loop)
+            __builtin_amdgcn_s_setprio(3);
+            const uint2 desc = dnext;
+            dnext = dtab[vi + 1];  // the next view's descriptor (or the sentinel): in flight with this view's constants, one wait for all
+            unsigned mode = (unsigned)__builtin_amdgcn_readfirstlane((int)((desc.y >> 16) & 7u));
             if (mode == FX_SKIP) continue;
+            if ((p.debug & 16) && mode == FX_BORDER) mode = FX_FAST;  // timing experiment only (wrong counts at the frame border)
             float q[12];  // wave-uniform values, kept in VGPRs: they are only ever VALU operands (v_fma allows one SGPR, and that is z)
             {
                 const float4 qa = *(const float4 *)(qtab + 12 * vi), qb = *(const float4 *)(qtab + 12 * vi + 4), qc = *(const float4 *)(qtab + 12 * vi + 8);
@@ -395,48 +412,44 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
             const int rh = __builtin_amdgcn_readfirstlane((int)((desc.y >> 8) & 0xffu));
             if (!ahead) {
                 __syncthreads();  // every wavefront is done with the region these rows held
-                base = 0;
-                if (!(p.debug & 1)) stage_region_fx(p.quads + p.pad_slab * v, p.pitch, x0, y0, rw, rh, base, lds);
+                qcol = 0;
+                if (!(p.debug & 1)) stage_region_fx(p.quads + p.pad_slab * v, p.pitch, x0, y0, rw, rh, qcol, lds);
             }
             __syncthreads();  // this view's region has landed (the barrier drains vmcnt) and the previous one is no longer read
-            // Optional (debug bit 3; off by default): request the next staged view's region into the ring rows behind this one, if
-            // both fit, so its copy overlaps this view's sampling and one barrier per region goes away.  Measured 2 % SLOWER at c3
-            // (1.707 vs 1.671 ms) and neutral at c1 / c2: at 4 workgroups per CU the other workgroups already cover the copy.
+            // Request the next staged view's region into the other half of the rows, if both regions are at most FX_HALF_COL quads
+            // wide: its copy (L2 / Infinity Cache latency, 1-2 us) then overlaps this view's sampling (0.5 us of work for the
+            // workgroup) and one barrier per region goes away.  Debug bit 3 switches it off (tests: bit-identical either way).
             ahead = false;
-            int nbase = 0;
-            if (p.debug & 8) {
-                for (int vn = v + 1; vn < vend && ((vn - p.v0) & (FX_VB - 1)) != 0; vn++) {  // within this batch of constants
-                    const uint2 dn = dtab[(vn - p.v0) & (FX_VB - 1)];
-                    const unsigned mn = (unsigned)__builtin_amdgcn_readfirstlane((int)((dn.y >> 16) & 7u));
-                    if (mn != FX_FAST && mn != FX_BORDER) continue;
-                    const int rhn = __builtin_amdgcn_readfirstlane((int)((dn.y >> 8) & 0xffu));
-                    if (rh + rhn <= FX_ROWS) {
-                        nbase = (base + rh) & (FX_ROWS - 1);
-                        if (!(p.debug & 1))
-                            stage_region_fx(p.quads + p.pad_slab * vn, p.pitch, __builtin_amdgcn_readfirstlane((int)(dn.x & 0xffffu)),
-                                            __builtin_amdgcn_readfirstlane((int)(dn.x >> 16)), __builtin_amdgcn_readfirstlane((int)(dn.y & 0xffu)), rhn, nbase, lds);
-                        ahead = true;
-                    }
-                    break;
+            int nqcol = 0;
+            if (!(p.debug & 8) && rw <= FX_HALF_COL) {
+                const unsigned mn = (unsigned)__builtin_amdgcn_readfirstlane((int)((dnext.y >> 16) & 7u));
+                const int rwn = __builtin_amdgcn_readfirstlane((int)(dnext.y & 0xffu));
+                if ((mn == FX_FAST || mn == FX_BORDER) && rwn <= FX_HALF_COL) {
+                    nqcol = qcol ? 0 : FX_HALF_COL;
+                    if (!(p.debug & 1))
+                        stage_region_fx(p.quads + p.pad_slab * (v + 1), p.pitch, __builtin_amdgcn_readfirstlane((int)(dnext.x & 0xffffu)),
+                                        __builtin_amdgcn_readfirstlane((int)(dnext.x >> 16)), rwn, __builtin_amdgcn_readfirstlane((int)((dnext.y >> 8) & 0xffu)), nqcol, lds);
+                    ahead = true;
                 }
             }
             FxRegion rg;
-            rg.offx = FX_MAGIC + 4.0f - 256.0f * (float)x0;
-            rg.offy = FX_MAGIC + 4.0f - 256.0f * (float)(y0 - base);  // region row ry sits in ring row base + ry (mod 32: the address mask wraps)
+            const int kx0 = 256 * (x0 - qcol), ky0 = 256 * y0;  // region column rx sits in quad column qcol + rx of the LDS rows
+            rg.offx = magic_plus(4 - kx0);
+            rg.offy = magic_plus(4 - ky0);
             const bool wconst = uniform_f(bw) == 0.0f && !(p.debug & 4);  // wave-uniform: plane-independent w
 #pragma unroll
             for (int j = 0; j < NPX; j++) {
                 const Affine A = view_affine(q, xn, yn[j]);
                 bool checked = false;
                 if (mode == FX_BORDER) {
-                    rg.lox = FX_MAGIC + 132.0f - 256.0f * (float)x0;
-                    rg.loy = FX_MAGIC + 132.0f - 256.0f * (float)(y0 - base);
-                    rg.hix = rg.lox + 256.0f * (float)p.W;
-                    rg.hiy = rg.loy + 256.0f * (float)p.H;
-                    rg.cminx = FX_MAGIC;
-                    rg.cminy = FX_MAGIC + (float)(256 * base);
-                    rg.cmaxx = FX_MAGIC + (float)(256 * rw - 1);
-                    rg.cmaxy = rg.cminy + (float)(256 * rh - 1);
+                    rg.lox = magic_plus(132 - kx0);
+                    rg.loy = magic_plus(132 - ky0);
+                    rg.hix = magic_plus(132 - kx0 + 256 * p.W);
+                    rg.hiy = magic_plus(132 - ky0 + 256 * p.H);
+                    rg.cminx = magic_plus(256 * qcol);
+                    rg.cminy = magic_plus(0);
+                    rg.cmaxx = magic_plus(256 * (qcol + rw) - 1);
+                    rg.cmaxy = magic_plus(256 * rh - 1);
                     // A pixel's samples over the chunk lie on a segment of the side image, monotone in z (w > 0 in the whole box): if
                     // both end planes are inside the frame by more than one 1/256-texel step (far above the f32 noise of the
                     // coordinates), every plane between them is in frame.  One wavefront-uniform decision per (row, view).
@@ -447,7 +460,8 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                         const float sx = __builtin_fmaf(z, bx, A.ax), sy = __builtin_fmaf(z, by, A.ay), sw = __builtin_fmaf(z, bw, A.aw);
                         const float r256 = rcp_rn(sw);
                         const float Tx = __builtin_fmaf(sx, r256, rg.offx), Ty = __builtin_fmaf(sy, r256, rg.offy);
-                        inside = inside && Tx > rg.lox + 2.0f && Tx < rg.hix - 2.0f && Ty > rg.loy + 2.0f && Ty < rg.hiy - 2.0f;
+                        inside = inside && Tx > magic_plus(134 - kx0) && Tx < magic_plus(130 - kx0 + 256 * p.W) && Ty > magic_plus(134 - ky0) &&
+                                 Ty < magic_plus(130 - ky0 + 256 * p.H);
                     }
                     checked = __builtin_amdgcn_ballot_w64(!inside && ok[j]) != 0ull;
                 }
@@ -461,6 +475,10 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                 } else {
                     lane_views[j] += 1u << 24;
                 }
+#ifdef MVS_FX_EXPERIMENTS
+                if (p.debug & 32) continue;  // timing experiment only: everything but the sample loop
+#endif
+                __builtin_amdgcn_s_setprio(0);
                 if (wconst) {
                     const float r256c = rcp_rn(__builtin_fmaf(zc[0], bw, A.aw));
                     sample_range_fx<0, PC, true>(A, bx, by, bw, r256c, zc, rg.offx, rg.offy, lds_base, Im255[j], acc[j]);
@@ -468,14 +486,19 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                     sample_range_fx<0, PC, false>(A, bx, by, bw, 0.0f, zc, rg.offx, rg.offy, lds_base, Im255[j], acc[j]);
                 }
             }
-            base = nbase;
+            qcol = nqcol;
         }
 
+        // Epilogue of the chunk.  The plane base is wave-uniform (SGPR pair) and the pixel a 32-bit lane offset, so a store needs no
+        // 64-bit per-lane pointer; the running best is kept as (sum, count) with the start value (1, 0), which makes
+        // "s * bc < bs * c" true for the first cell with a view in frame and false for every empty cell: no other test per plane.
+        uint32_t *const vol_chunk = WRITE_VOLUME ? p.volume + (size_t)d0 * P : nullptr;
+        const bool whole = d0 + PC <= p.D;  // uniform: every plane of the chunk exists
 #pragma unroll
         for (int j = 0; j < NPX; j++) {
             if (ok[j]) {
-                const size_t pix = (size_t)(row0 + j) * p.W + col;
-                uint32_t best = 0u;
+                const uint32_t pix = (uint32_t)((row0 + j) * p.W + col);
+                uint32_t best = 1u;
                 int bi = -1;
                 if (FUSED) {
                     const uint2 st = best_state[j * 256 + threadIdx.x];
@@ -483,12 +506,29 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                     bi = (int)st.y;
                 }
                 const uint32_t views = fast_views + lane_views[j];
+                if (whole) {
 #pragma unroll
-                for (int k = 0; k < PC; k++) {
-                    if (d0 + k < p.D) {
+                    for (int k = 0; k < PC; k++) {
                         const uint32_t cell = acc[j][k] + views;
-                        if (WRITE_VOLUME) p.volume[(size_t)(d0 + k) * P + pix] = cell;
-                        if (FUSED) argmin_update_packed<CS_FIXED>(cell, d0 + k, best, bi);
+                        if (WRITE_VOLUME) (vol_chunk + (size_t)k * P)[pix] = cell;
+                        if (FUSED) {
+                            const bool better = umul24u(cell & 0xffffffu, best >> 24) < umul24u(best & 0xffffffu, cell >> 24);
+                            best = better ? cell : best;
+                            bi = better ? d0 + k : bi;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < PC; k++) {
+                        if (d0 + k < p.D) {
+                            const uint32_t cell = acc[j][k] + views;
+                            if (WRITE_VOLUME) (vol_chunk + (size_t)k * P)[pix] = cell;
+                            if (FUSED) {
+                                const bool better = umul24u(cell & 0xffffffu, best >> 24) < umul24u(best & 0xffffffu, cell >> 24);
+                                best = better ? cell : best;
+                                bi = better ? d0 + k : bi;
+                            }
+                        }
                     }
                 }
                 if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(best, (uint32_t)bi);
@@ -499,7 +539,8 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
 #pragma unroll
         for (int j = 0; j < NPX; j++)
             if (ok[j]) {
-                const uint2 st = best_state[j * 256 + threadIdx.x];
+                uint2 st = best_state[j * 256 + threadIdx.x];
+                if ((int)st.y < 0) st.x = 0u;  // no plane had a view in frame: the empty cell, as argmin_update_packed leaves it
                 const size_t pix = (size_t)(row0 + j) * p.W + col;
                 if (p.part)
                     p.part[(size_t)blockIdx.y * P + pix] = st;
@@ -611,6 +652,17 @@ int sweep_fx_plan(mvs_ctx *ctx)
     MVS_HIP(ctx, hipMemsetAsync(q.plan_stats, 0, 2 * sizeof(int), ctx->stream));
     plan_regions_fx<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(q, (uint2 *)ctx->plan.ptr);
     MVS_HIP(ctx, hipGetLastError());
+    if (const char *path = getenv("MVS_PLAN_DUMP")) {  // diagnostic (tools/plan_hist.py): header {tiles_x, tiles_y, nchunks, V}, then the descriptors
+        std::vector<uint2> host(n);
+        MVS_HIP(ctx, hipMemcpyAsync(host.data(), ctx->plan.ptr, n * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
+        MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (FILE *f = fopen(path, "wb")) {
+            const int hdr[4] = {q.tiles_x, q.tiles_y, q.nchunks, q.V};
+            fwrite(hdr, sizeof(int), 4, f);
+            fwrite(host.data(), sizeof(uint2), n, f);
+            fclose(f);
+        }
+    }
     return MVS_OK;
 }
 

@@ -50,7 +50,7 @@ struct SweepParams {
     int *__restrict__ plan_stats;  // [0] regions too large for LDS, [1] regions not skipped (planner output)
     int cps;             // plane chunks per workgroup: blockIdx.y selects chunks [chunk0 + y*cps, +cps) of a tile
     uint2 *__restrict__ part;  // plane-split launches with fused depth selection: [gridDim.y][P] partial bests
-    int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: linear tile order; bit 2: never use the plane-independent-w path; bit 3: exact sampler: force the 4 x 16 shape, fixed sampler: prefetch the next region into the LDS ring)
+    int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: linear tile order; bit 2: never use the plane-independent-w path; bit 3: exact sampler: force the 4 x 16 shape, fixed sampler: no region look-ahead; fixed sampler only: bit 4: BORDER regions as FAST, bit 5: skip the sample loop)
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -79,12 +79,15 @@ __device__ __forceinline__ Affine view_affine(const float *__restrict__ q, float
     return a;
 }
 
-// running best plane: s/c < bs/bc  <=>  s*bc < bs*c, all factors < 2^16 (exact in u32)
+// HIP declares __umul24 as returning int: compared as such, products >= 2^31 (fixed sampler, > 181 views at maximal cost) would order wrongly
+__device__ __forceinline__ uint32_t umul24u(uint32_t a, uint32_t b) { return (uint32_t)__umul24(a, b); }
+
+// running best plane: s/c < bs/bc  <=>  s*bc < bs*c; the products stay below 2^32 (s < 2^16, c < 2^16 or s < 2^24, c < 2^8)
 template <int CS = CS_EXACT>
 __device__ __forceinline__ void argmin_update(uint32_t cell, int d, uint32_t &bs, uint32_t &bc, int &bi)
 {
     const uint32_t s = cell & ((1u << CS) - 1u), c = cell >> CS;  // s < 2^24, c < 2^16: the 24-bit multiplies below are exact
-    const bool better = (c != 0u) && (bi < 0 || __umul24(s, bc) < __umul24(bs, c));
+    const bool better = (c != 0u) && (bi < 0 || umul24u(s, bc) < umul24u(bs, c));
     bs = better ? s : bs;
     bc = better ? c : bc;
     bi = better ? d : bi;
@@ -96,7 +99,7 @@ __device__ __forceinline__ void argmin_update_packed(uint32_t cell, int d, uint3
 {
     constexpr uint32_t M = (1u << CS) - 1u;
     const uint32_t s = cell & M, c = cell >> CS, bs = best & M, bc = best >> CS;
-    const bool better = (c != 0u) && (bi < 0 || __umul24(s, bc) < __umul24(bs, c));
+    const bool better = (c != 0u) && (bi < 0 || umul24u(s, bc) < umul24u(bs, c));
     best = better ? cell : best;
     bi = better ? d : bi;
 }

@@ -489,16 +489,17 @@ def test_plane_independent_w_path_is_bit_identical(oracle, sampler):
 
 
 def test_fixed_sampler_region_prefetch_is_bit_identical(oracle):
-    """the fixed sampler's optional look-ahead (debug bit 3: the next view's region is copied into the LDS ring rows behind the
-    current one while that is being sampled) must not change a cell; general cameras, border tiles, ragged sizes"""
+    """the fixed sampler's region look-ahead (the next view's region is copied into the other half of the LDS rows while the current
+    one is being sampled; debug bit 3 switches it off) must not change a cell; general cameras, border tiles, ragged sizes, and a
+    wide-baseline case whose regions are too wide for a half row (falls back to one region at a time)"""
     both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
-    for (W, H, D, V, radius) in [(384, 200, 48, 5, 0.15), (330, 130, 70, 3, 0.4)]:
+    for (W, H, D, V, radius) in [(384, 200, 48, 5, 0.15), (330, 130, 70, 3, 0.4), (640, 96, 16, 4, 0.9)]:
         main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=radius)
         side_cams = side_cams.copy()
         side_cams[0] = _rot_cam(W, H, [0.0, radius, 0.03], 0.01, 0.02)
         ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8, sampler="fixed")
-        plain = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, both, sampler="fixed")
-        ahead = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, both | (8 << 8), sampler="fixed")
+        ahead = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, both, sampler="fixed")
+        plain = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, both | (8 << 8), sampler="fixed")
         for a, b in zip(plain, ahead):
             np.testing.assert_array_equal(a, b)
         _check(ahead, ref, D)

@@ -1,5 +1,5 @@
 """In-process A/B timings of the fixed-sampler sweep at c3 (timing experiments only: some variants give wrong results).
-debug bits (flags >> 8): 1 skip LDS staging, 2 linear tile order, 4 never use the plane-independent-w path; flags >> 16: forced plane splits"""
+debug bits (flags >> 8): 1 skip LDS staging, 2 linear tile order, 4 never use the plane-independent-w path, 8 no region look-ahead, 16 treat BORDER regions as FAST, 32 skip the sample loop; flags >> 16: forced plane splits"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
@@ -28,8 +28,13 @@ def timeit(ctx, flags, n=10):
 for sampler in ("fixed", "exact"):
     with mvs_amd.Context(W, H, sampler=sampler) as ctx:
         ctx.sweep_set(mc, mi, sc, si, D)
+        timeit(ctx, both, 30)  # clocks up
         print(sampler, "volume+fused %.3f ms" % timeit(ctx, both), " fused only %.3f" % timeit(ctx, mvs_amd.MVS_SWEEP_FUSED_ARGMIN),
               " volume only %.3f" % timeit(ctx, mvs_amd.MVS_SWEEP_VOLUME), " no staging %.3f" % timeit(ctx, both | (1 << 8)),
               " general %.3f" % timeit(ctx, both | (4 << 8)), " general, no staging %.3f" % timeit(ctx, both | (5 << 8)),
-              " linear tiles %.3f" % timeit(ctx, both | (2 << 8)), " with look-ahead %.3f" % timeit(ctx, both | (8 << 8)) if sampler == "fixed" else "")
+              " linear tiles %.3f" % timeit(ctx, both | (2 << 8)), (" without look-ahead %.3f" % timeit(ctx, both | (8 << 8)) + " border as fast %.3f" % timeit(ctx, both | (16 << 8)) + " no sample loop %.3f" % timeit(ctx, both | (32 << 8)) + " no loop, no staging %.3f" % timeit(ctx, both | (33 << 8)) + " setprio %.3f" % timeit(ctx, both | (64 << 8))) if sampler == "fixed" else "")
+        if sampler == "fixed":
+            fo, vo = mvs_amd.MVS_SWEEP_FUSED_ARGMIN, mvs_amd.MVS_SWEEP_VOLUME
+            print("   no sample loop: fused only %.3f  volume only %.3f  | no loop, no staging: fused only %.3f  volume only %.3f | no loop, no look-ahead %.3f" %
+                  (timeit(ctx, fo | (32 << 8)), timeit(ctx, vo | (32 << 8)), timeit(ctx, fo | (33 << 8)), timeit(ctx, vo | (33 << 8)), timeit(ctx, both | (40 << 8))))
         print("   splits:", " ".join("%d: %.3f" % (s, timeit(ctx, both | (s << 16))) for s in (1, 2, 4, 8)))
