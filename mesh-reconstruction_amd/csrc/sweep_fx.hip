@@ -34,7 +34,7 @@ constexpr int FX_MAX_RW = FX_ROW_DW - FX_LUT_DW;  // 224 quads
 constexpr int FX_HALF_COL = FX_MAX_RW / 2;          // two regions of up to 112 quads side by side (region look-ahead)
 constexpr float FX_MAGIC = 12582912.0f;            // 1.5 * 2^23: floats in [2^23, 2^24) have ulp 1
 constexpr int FX_TILE_H = 8, FX_PC = 16, FX_NPX = 2;  // 64x8-pixel tiles, 16 planes per chunk: 32 accumulators per thread
-constexpr int FX_GS = 4;          // samples per software-pipeline group
+constexpr int FX_GS = 2;          // samples per software-pipeline group
 constexpr int FX_VB = 64;         // views per batch of LDS-resident per-view constants
 constexpr int FX_WG_PER_CU = 4;   // launch bound (waves per SIMD): 128 VGPRs, 36 KiB of LDS
 
@@ -253,10 +253,13 @@ __device__ __forceinline__ void sample_range_fx(const Affine &A, float bx, float
         const int buf = g & 1;
         if (g + 1 < KN / FX_GS) address_stage(g + 1);
         // the loaded registers and the next group's addresses are operands: neither the consumers nor that address stage can cross the wait
-        static_assert(FX_GS == 4, "the operand list of the wait below names every register of a group");
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(lw[buf][0]), "+v"(lw[buf][1]), "+v"(lw[buf][2]), "+v"(lw[buf][3]), "+v"(lq[buf][0]), "+v"(lq[buf][1]), "+v"(lq[buf][2]),
-                       "+v"(lq[buf][3]), "+v"(la[0]), "+v"(ta[0]), "+v"(la[FX_GS - 1]), "+v"(ta[FX_GS - 1]));
+        static_assert(FX_GS == 4 || FX_GS == 2, "the operand list of the wait below names every register of a group");
+        if constexpr (FX_GS == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(lw[buf][0]), "+v"(lw[buf][1]), "+v"(lw[buf][2]), "+v"(lw[buf][3]), "+v"(lq[buf][0]), "+v"(lq[buf][1]), "+v"(lq[buf][2]),
+                           "+v"(lq[buf][3]), "+v"(la[0]), "+v"(ta[0]), "+v"(la[FX_GS - 1]), "+v"(ta[FX_GS - 1]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lw[buf][0]), "+v"(lw[buf][1]), "+v"(lq[buf][0]), "+v"(lq[buf][1]), "+v"(la[0]), "+v"(ta[0]), "+v"(la[1]), "+v"(ta[1]));
         if (g + 1 < KN / FX_GS) issue_reads(buf ^ 1);
 #pragma unroll
         for (int i = 0; i < FX_GS; i++) {
@@ -274,10 +277,12 @@ __device__ __forceinline__ float magic_plus(int k) { return __builtin_bit_cast(f
 struct FxRegion {
     float offx, offy;            // magic + 4 - 256 * region origin: T - magic is the position relative to the region, in 1/256 texel
     float lox, hix, loy, hiy;    // in-frame test on T (strict)
-    float cminx, cminy, cmaxx, cmaxy;  // clamp range of T for masked samples (the staged quads, in ring coordinates)
 };
 
-// the same planes with the in-frame test per sample (region mode BORDER, for the wavefronts that straddle the frame edge)
+// the same planes with the in-frame test per sample (region mode BORDER, for the wavefronts that straddle the frame edge).
+// A sample outside the frame reads whatever its masked address holds (the masks keep every address inside the LDS image, so no
+// clamp is needed) and is then dropped by the select.  (A variant with the hoisted reciprocal of the plane-independent-w case
+// doubles the instantiations and made the register allocator spill 29 VGPRs in the whole kernel: not worth 1 % of the samples.)
 template <int K0, int KN>
 __device__ __forceinline__ void sample_range_fx_checked(const Affine &A, float bx, float by, float bw, const float (&zc)[FX_PC], const FxRegion &rg,
                                                         const uint32_t *__restrict__ lds, uint32_t Im255, uint32_t (&acc)[FX_PC])
@@ -289,8 +294,7 @@ __device__ __forceinline__ void sample_range_fx_checked(const Affine &A, float b
         const float r256 = rcp_rn(sw);  // w row pre-divided by 256
         const float Tx = __builtin_fmaf(sx, r256, rg.offx), Ty = __builtin_fmaf(sy, r256, rg.offy);
         const bool ok = Tx > rg.lox && Tx < rg.hix && Ty > rg.loy && Ty < rg.hiy;
-        const float Txc = __builtin_amdgcn_fmed3f(Tx, rg.cminx, rg.cmaxx), Tyc = __builtin_amdgcn_fmed3f(Ty, rg.cminy, rg.cmaxy);
-        const uint32_t P = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, Tyc), __builtin_bit_cast(uint32_t, Txc), 0x05010400u);
+        const uint32_t P = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, Ty), __builtin_bit_cast(uint32_t, Tx), 0x05010400u);
         const uint32_t w = lds[((P >> 1) & 0x7c7cu) >> 2];
         const uint32_t quad = lds[(((P >> 14) & 0x7ffcu) >> 2) + FX_LUT_DW];
         const uint32_t dot = __builtin_amdgcn_udot4(quad, w, 0u, false);
@@ -301,6 +305,18 @@ __device__ __forceinline__ void sample_range_fx_checked(const Affine &A, float b
 
 // 4 workgroups per CU (<= 128 VGPRs, 36 KiB of LDS each): at 2 per CU the LDS reads no longer hide behind the VALU work
 // (19.0 vs 14.6 ns per wave-sample, tools/sweep_v2_probe.hip).
+// Timing experiments (tools/exp_fx.py, tools/fx_sections.py) are compiled in with -DMVS_FX_EXPERIMENTS only: even never-taken
+// branches on p.debug change register allocation enough to cost the production kernel a few per cent.
+#ifdef MVS_FX_EXPERIMENTS
+#define FX_PROF_DECL unsigned long long pt_prev = 0, pt_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_iter = 0, pt_chunks = 0; const bool pt_on = p.plan_stats != nullptr && threadIdx.x < 64
+#define FX_PROF_START() do { if (pt_on) pt_prev = __builtin_amdgcn_s_memtime(); } while (0)
+#define FX_PROF_MARK(i) do { if (pt_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt_sum[i] += t_ - pt_prev; pt_prev = t_; } } while (0)
+#else
+#define FX_PROF_DECL
+#define FX_PROF_START()
+#define FX_PROF_MARK(i)
+#endif
+
 template <bool WRITE_VOLUME, bool FUSED>
 __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams p, const uint32_t *__restrict__ lut_g)
 {
@@ -344,6 +360,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
 
     const int chunk_first = p.chunk0 + (int)blockIdx.y * p.cps;
     const int chunk_last = min(p.chunk1, chunk_first + p.cps);
+    FX_PROF_DECL;
     for (int chunk = chunk_first; chunk < chunk_last; chunk++) {
         const int d0 = chunk * PC;
         float zc[PC];  // SGPRs; planes past D are evaluated on a clamped z and never stored
@@ -370,6 +387,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
         for (int v = p.v0; v < vend; v++) {
             const int vi = (v - p.v0) & (FX_VB - 1);
             if (vi == 0) {  // next batch of per-view constants (wave-uniform branch; no region is in flight here: ahead == false)
+                FX_PROF_START();
                 __syncthreads();
                 const int nb = min(FX_VB, vend - v);
                 // the w row goes in divided by 256: then RN(1 / s.w) IS 256 r, bit for bit (a power of two commutes with the roundings of
@@ -378,7 +396,9 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                 for (int i = threadIdx.x; i <= nb; i += 256) dtab[i] = i < nb ? plan[v + i] : make_uint2(0u, 0u);  // + a SKIP sentinel
                 __syncthreads();
                 dnext = dtab[0];
+                FX_PROF_MARK(7);
             }
+            FX_PROF_START();
             // the per-view bookkeeping below is a chain of dependent scalar work and LDS round trips: let it overtake the other
             // wavefronts' sample loops on this SIMD (priority back to 0 before this wavefront's own sample loop)
             __builtin_amdgcn_s_setprio(3);
@@ -394,6 +414,10 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                 q[8] = qc.x; q[9] = qc.y; q[10] = qc.z; q[11] = qc.w;
             }
             const float bx = q[2], by = q[6], bw = q[10];
+#ifdef MVS_FX_EXPERIMENTS
+            if (pt_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            FX_PROF_MARK(0);
+#endif
             if (mode == FX_GENERIC) {
                 const uint8_t *pad = p.pads + p.pad_slab * v;
 #pragma unroll
@@ -415,10 +439,16 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                 qcol = 0;
                 if (!(p.debug & 1)) stage_region_fx(p.quads + p.pad_slab * v, p.pitch, x0, y0, rw, rh, qcol, lds);
             }
+#ifdef MVS_FX_EXPERIMENTS
+            if (p.debug & 64)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // timing experiment only (racy): what the per-view barrier costs
+            else
+#endif
             __syncthreads();  // this view's region has landed (the barrier drains vmcnt) and the previous one is no longer read
             // Request the next staged view's region into the other half of the rows, if both regions are at most FX_HALF_COL quads
             // wide: its copy (L2 / Infinity Cache latency, 1-2 us) then overlaps this view's sampling (0.5 us of work for the
             // workgroup) and one barrier per region goes away.  Debug bit 3 switches it off (tests: bit-identical either way).
+            FX_PROF_MARK(1);
             ahead = false;
             int nqcol = 0;
             if (!(p.debug & 8) && rw <= FX_HALF_COL) {
@@ -432,6 +462,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                     ahead = true;
                 }
             }
+            FX_PROF_MARK(2);
             FxRegion rg;
             const int kx0 = 256 * (x0 - qcol), ky0 = 256 * y0;  // region column rx sits in quad column qcol + rx of the LDS rows
             rg.offx = magic_plus(4 - kx0);
@@ -446,10 +477,6 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                     rg.loy = magic_plus(132 - ky0);
                     rg.hix = magic_plus(132 - kx0 + 256 * p.W);
                     rg.hiy = magic_plus(132 - ky0 + 256 * p.H);
-                    rg.cminx = magic_plus(256 * qcol);
-                    rg.cminy = magic_plus(0);
-                    rg.cmaxx = magic_plus(256 * (qcol + rw) - 1);
-                    rg.cmaxy = magic_plus(256 * rh - 1);
                     // A pixel's samples over the chunk lie on a segment of the side image, monotone in z (w > 0 in the whole box): if
                     // both end planes are inside the frame by more than one 1/256-texel step (far above the f32 noise of the
                     // coordinates), every plane between them is in frame.  One wavefront-uniform decision per (row, view).
@@ -479,19 +506,29 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                 if (p.debug & 32) continue;  // timing experiment only: everything but the sample loop
 #endif
                 __builtin_amdgcn_s_setprio(0);
+                if (j == 0) FX_PROF_MARK(3);
                 if (wconst) {
                     const float r256c = rcp_rn(__builtin_fmaf(zc[0], bw, A.aw));
                     sample_range_fx<0, PC, true>(A, bx, by, bw, r256c, zc, rg.offx, rg.offy, lds_base, Im255[j], acc[j]);
                 } else {
                     sample_range_fx<0, PC, false>(A, bx, by, bw, 0.0f, zc, rg.offx, rg.offy, lds_base, Im255[j], acc[j]);
                 }
+                if (j == 0) FX_PROF_MARK(4);
             }
             qcol = nqcol;
+#ifdef MVS_FX_EXPERIMENTS
+            FX_PROF_MARK(5);
+            pt_iter++;
+#endif
         }
 
         // Epilogue of the chunk.  The plane base is wave-uniform (SGPR pair) and the pixel a 32-bit lane offset, so a store needs no
         // 64-bit per-lane pointer; the running best is kept as (sum, count) with the start value (1, 0), which makes
         // "s * bc < bs * c" true for the first cell with a view in frame and false for every empty cell: no other test per plane.
+#ifdef MVS_FX_EXPERIMENTS
+        if (p.debug & 128) continue;  // timing experiment only: no chunk epilogue
+        FX_PROF_START();
+#endif
         uint32_t *const vol_chunk = WRITE_VOLUME ? p.volume + (size_t)d0 * P : nullptr;
         const bool whole = d0 + PC <= p.D;  // uniform: every plane of the chunk exists
 #pragma unroll
@@ -534,7 +571,19 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                 if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(best, (uint32_t)bi);
             }
         }
+#ifdef MVS_FX_EXPERIMENTS
+        FX_PROF_MARK(6);
+        pt_chunks++;
+#endif
     }
+#ifdef MVS_FX_EXPERIMENTS
+    if (pt_on && threadIdx.x == 0) {
+        unsigned long long *out = (unsigned long long *)((char *)p.plan_stats + 64);
+        for (int i = 0; i < 8; i++) atomicAdd(out + i, pt_sum[i]);
+        atomicAdd(out + 8, pt_iter);
+        atomicAdd(out + 9, pt_chunks);
+    }
+#endif
     if (FUSED) {
 #pragma unroll
         for (int j = 0; j < NPX; j++)
@@ -629,6 +678,14 @@ int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool gen
         p.part = (uint2 *)ctx->best_parts.ptr;
     }
     const dim3 grid((unsigned)(div_up(groups, 8) * 64), (unsigned)nsplit);
+#ifdef MVS_FX_EXPERIMENTS
+    const bool prof = getenv("MVS_FX_PROF") != nullptr;
+    if (prof) {  // per-section cycle sums of wavefront 0 of every workgroup (s_memtime), printed after the launch
+        if ((rc = ensure(ctx, ctx->plan_stats, 256))) return rc;
+        p.plan_stats = (int *)ctx->plan_stats.ptr;
+        MVS_HIP(ctx, hipMemsetAsync(ctx->plan_stats.ptr, 0, 256, ctx->stream));
+    }
+#endif
     if (vol && fused)
         sweep_fx_tiled<true, true><<<grid, 256, 0, ctx->stream>>>(p, lut);
     else if (vol)
@@ -636,6 +693,18 @@ int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool gen
     else
         sweep_fx_tiled<false, true><<<grid, 256, 0, ctx->stream>>>(p, lut);
     MVS_HIP(ctx, hipGetLastError());
+#ifdef MVS_FX_EXPERIMENTS
+    if (prof) {
+        unsigned long long h[16];
+        MVS_HIP(ctx, hipMemcpyAsync(h, (char *)ctx->plan_stats.ptr + 64, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        static const char *names[8] = {"top->tables read", "->barrier passed", "->look-ahead issued", "->first loop", "loop j=0", "loop j=1 + end", "epilogue", "batch load"};
+        fprintf(stderr, "fx prof: iterations %llu chunks %llu;", h[8], h[9]);
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.0f |", names[i], (double)h[i] / (double)(i < 6 ? (h[8] ? h[8] : 1) : (h[9] ? h[9] : 1)));
+        fprintf(stderr, " s_memtime ticks per iteration / chunk\n");
+        p.plan_stats = nullptr;
+    }
+#endif
     return nsplit;  // > 0: the caller merges the partial bests when p.part is set
 }
 

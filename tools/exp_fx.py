@@ -32,9 +32,11 @@ for sampler in ("fixed", "exact"):
         print(sampler, "volume+fused %.3f ms" % timeit(ctx, both), " fused only %.3f" % timeit(ctx, mvs_amd.MVS_SWEEP_FUSED_ARGMIN),
               " volume only %.3f" % timeit(ctx, mvs_amd.MVS_SWEEP_VOLUME), " no staging %.3f" % timeit(ctx, both | (1 << 8)),
               " general %.3f" % timeit(ctx, both | (4 << 8)), " general, no staging %.3f" % timeit(ctx, both | (5 << 8)),
-              " linear tiles %.3f" % timeit(ctx, both | (2 << 8)), (" without look-ahead %.3f" % timeit(ctx, both | (8 << 8)) + " border as fast %.3f" % timeit(ctx, both | (16 << 8)) + " no sample loop %.3f" % timeit(ctx, both | (32 << 8)) + " no loop, no staging %.3f" % timeit(ctx, both | (33 << 8)) + " setprio %.3f" % timeit(ctx, both | (64 << 8))) if sampler == "fixed" else "")
+              " linear tiles %.3f" % timeit(ctx, both | (2 << 8)), (" without look-ahead %.3f" % timeit(ctx, both | (8 << 8)) + " border as fast %.3f" % timeit(ctx, both | (16 << 8)) + " no sample loop %.3f" % timeit(ctx, both | (32 << 8)) + " no loop, no staging %.3f" % timeit(ctx, both | (33 << 8)) + " no per-view barrier %.3f" % timeit(ctx, both | (64 << 8))) if sampler == "fixed" else "")
         if sampler == "fixed":
             fo, vo = mvs_amd.MVS_SWEEP_FUSED_ARGMIN, mvs_amd.MVS_SWEEP_VOLUME
             print("   no sample loop: fused only %.3f  volume only %.3f  | no loop, no staging: fused only %.3f  volume only %.3f | no loop, no look-ahead %.3f" %
                   (timeit(ctx, fo | (32 << 8)), timeit(ctx, vo | (32 << 8)), timeit(ctx, fo | (33 << 8)), timeit(ctx, vo | (33 << 8)), timeit(ctx, both | (40 << 8))))
+            print("   skeleton (no loop, no staging, fused only) %.3f: border as fast %.3f  + no epilogue %.3f  + no per-view barrier %.3f" %
+                  (timeit(ctx, fo | (33 << 8)), timeit(ctx, fo | ((33 + 16) << 8)), timeit(ctx, fo | ((33 + 16 + 128) << 8)), timeit(ctx, fo | ((33 + 16 + 128 + 64) << 8))))
         print("   splits:", " ".join("%d: %.3f" % (s, timeit(ctx, both | (s << 16))) for s in (1, 2, 4, 8)))

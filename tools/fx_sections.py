@@ -1,0 +1,21 @@
+"""Per-section cycle counts of the fixed-sampler sweep's view loop (s_memtime, wavefront 0 of every workgroup).  Needs a library built
+with -DMVS_FX_EXPERIMENTS (make CXXFLAGS="... -DMVS_FX_EXPERIMENTS"); the production build ignores MVS_FX_PROF."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
+import torch  # noqa: F401 (HIP runtime first)
+os.environ["MVS_FX_PROF"] = "1"
+import mvs_amd
+from mvs_amd import synth
+
+cfg = {"c1": (640, 480, 32, 4), "c2": (1280, 720, 64, 8), "c3": (1920, 1080, 128, 16)}[sys.argv[1] if len(sys.argv) > 1 else "c3"]
+W, H, D, V = cfg
+mc, mi, sc, si, gt = synth.make_views(W, H, V, radius=0.15)
+both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+with mvs_amd.Context(W, H, sampler="fixed") as ctx:
+    ctx.sweep_set(mc, mi, sc, si, D)
+    for flags in (both, both, both, both | (32 << 8), both | (33 << 8)):
+        sys.stderr.write("flags %#x: " % flags)
+        sys.stderr.flush()
+        ctx.sweep_run(0, V, flags)
+        ctx.synchronize()
