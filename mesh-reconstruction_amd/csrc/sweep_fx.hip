@@ -361,6 +361,23 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
     const int chunk_first = p.chunk0 + (int)blockIdx.y * p.cps;
     const int chunk_last = min(p.chunk1, chunk_first + p.cps);
     FX_PROF_DECL;
+    // Region pipeline.  `qcol` = first quad column of the region being sampled; `ahead` = the region of the view at hand was requested
+    // while the previous staged view was being sampled (its copy is in flight or has landed).  When the descriptors of ALL this
+    // workgroup's (chunk, view) regions fit the table (`whole_wg`: c3 has 4 chunks x 16 views), they and the view constants are loaded
+    // once, and the pipeline runs on across chunk boundaries: no table reload and no cold first region per chunk.
+    int qcol = 0;
+    bool ahead = false;
+    uint2 dnext = make_uint2(0u, 0u);
+    const int vend = p.v0 + p.vcount;
+    const bool whole_wg = p.vcount > 0 && (chunk_last - chunk_first) * p.vcount <= FX_VB;
+    if (whole_wg) {
+        const int nd = (chunk_last - chunk_first) * p.vcount;
+        const uint2 *plan0 = p.plan + ((size_t)tile * p.nchunks + chunk_first) * p.V;
+        for (int i = threadIdx.x; i < p.vcount * 12; i += 256) qtab[i] = p.Q[12 * p.v0 + i] * ((i % 12) >= 8 ? 0.00390625f : 1.0f);
+        for (int i = threadIdx.x; i <= nd; i += 256) dtab[i] = i < nd ? plan0[(size_t)(i / p.vcount) * p.V + p.v0 + i % p.vcount] : make_uint2(0u, 0u);
+        __syncthreads();
+        dnext = dtab[0];
+    }
     for (int chunk = chunk_first; chunk < chunk_last; chunk++) {
         const int d0 = chunk * PC;
         float zc[PC];  // SGPRs; planes past D are evaluated on a clamped z and never stored
@@ -378,15 +395,10 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
         for (int j = 0; j < NPX; j++) lane_views[j] = 0u;
         const uint2 *plan = p.plan + ((size_t)tile * p.nchunks + chunk) * p.V;
 
-        // Region pipeline of this chunk.  `qcol` = first quad column of the region being sampled; `ahead` = the region of the view at
-        // hand was requested while the previous staged view was being sampled (its copy is in flight or has landed).
-        int qcol = 0;
-        bool ahead = false;
-        uint2 dnext = make_uint2(0u, 0u);
-        const int vend = p.v0 + p.vcount;
+        const int dbase = whole_wg ? (chunk - chunk_first) * p.vcount : 0;  // this chunk's first descriptor in the table
         for (int v = p.v0; v < vend; v++) {
             const int vi = (v - p.v0) & (FX_VB - 1);
-            if (vi == 0) {  // next batch of per-view constants (wave-uniform branch; no region is in flight here: ahead == false)
+            if (vi == 0 && !whole_wg) {  // next batch of per-view constants (wave-uniform branch; no region is in flight here: ahead == false)
                 FX_PROF_START();
                 __syncthreads();
                 const int nb = min(FX_VB, vend - v);
@@ -403,7 +415,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
             // wavefronts' sample loops on this SIMD (priority back to 0 before this wavefront's own sample loop)
             __builtin_amdgcn_s_setprio(3);
             const uint2 desc = dnext;
-            dnext = dtab[vi + 1];  // the next view's descriptor (or the sentinel): in flight with this view's constants, one wait for all
+            dnext = dtab[dbase + vi + 1];  // the next region's descriptor (or the sentinel): in flight with this view's constants, one wait for all
             unsigned mode = (unsigned)__builtin_amdgcn_readfirstlane((int)((desc.y >> 16) & 7u));
             if (mode == FX_SKIP) continue;
             if ((p.debug & 16) && mode == FX_BORDER) mode = FX_FAST;  // timing experiment only (wrong counts at the frame border)
@@ -455,9 +467,10 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                 const unsigned mn = (unsigned)__builtin_amdgcn_readfirstlane((int)((dnext.y >> 16) & 7u));
                 const int rwn = __builtin_amdgcn_readfirstlane((int)(dnext.y & 0xffu));
                 if ((mn == FX_FAST || mn == FX_BORDER) && rwn <= FX_HALF_COL) {
+                    const int vn = v + 1 == vend ? p.v0 : v + 1;  // after the last view: the first view of the workgroup's next chunk
                     nqcol = qcol ? 0 : FX_HALF_COL;
                     if (!(p.debug & 1))
-                        stage_region_fx(p.quads + p.pad_slab * (v + 1), p.pitch, __builtin_amdgcn_readfirstlane((int)(dnext.x & 0xffffu)),
+                        stage_region_fx(p.quads + p.pad_slab * vn, p.pitch, __builtin_amdgcn_readfirstlane((int)(dnext.x & 0xffffu)),
                                         __builtin_amdgcn_readfirstlane((int)(dnext.x >> 16)), rwn, __builtin_amdgcn_readfirstlane((int)((dnext.y >> 8) & 0xffu)), nqcol, lds);
                     ahead = true;
                 }
