@@ -505,6 +505,19 @@ def test_fixed_sampler_region_prefetch_is_bit_identical(oracle):
         _check(ahead, ref, D)
 
 
+def test_many_views_use_batched_tables(oracle, sampler):
+    """70 views: more than the fixed sampler's 64-entry constant tables, so they are reloaded in batches within a chunk (no look-ahead
+    across a batch boundary), and more than fit one per-workgroup descriptor table; 16 views x 3 chunks in ONE workgroup (forced
+    split count 1) is the opposite case, the table loaded once and the look-ahead running across chunk boundaries"""
+    both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    for (W, H, D, V, splits) in [(128, 40, 40, 70, 0), (128, 40, 40, 70, 1), (192, 48, 44, 16, 1), (192, 48, 44, 16, 3)]:
+        main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.2, freq_scale=0.25)
+        side_cams = side_cams.copy()
+        side_cams[V // 2] = _rot_cam(W, H, [-0.9, 0.6, -0.3], -0.45, 0.3)   # partly out of frame: SKIP / BORDER regions in the sequence
+        ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8, sampler=sampler)
+        _check(_gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, both | (splits << 16), sampler=sampler), ref, D)
+
+
 def test_sweep_matches_the_committed_golden_vectors(sampler):
     """HIP through the C ABI against tests/golden/sweep_small*.npz (written by the oracle via tests/golden/make_golden.py and
     committed): no oracle runs here, so the HIP path and the oracle cannot drift together unnoticed"""
