@@ -40,6 +40,8 @@ CONFIGS = {
     # one main frame through the one-call entry mvs_sweep (upload, pad, plan, sweep, depth download).  Not the default.
     "c5": (640, 480, 128, 4),
 }
+# the arithmetic the sweep computes in: f32 projection in both samplers; texel fetch and cost in u8 x u8 -> u32 (fixed) or f32 (exact)
+DTYPE = {"fixed": "u8", "exact": "f32"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -127,7 +129,7 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
         return ids
     mine = mdist.frame_shard(nframes, rank, world) or [0]
     side_cams = [np.stack([cams[j] for j in sides_of(f)]) for f in range(nframes)]
-    ctx = mvs_amd.Context(W, H, local_rank)
+    ctx = mvs_amd.Context(W, H, local_rank, sampler=args.sampler)
 
     def step(i):
         f = mine[i % len(mine)]
@@ -157,17 +159,20 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
         dt = float(tt.item())
     if rank == 0:
         sweep_ms = ms_sum[mvs_amd.MVS_K_SWEEP] / max(1, launches[mvs_amd.MVS_K_SWEEP])
-        sweep_bytes = float(P) * (V + 1) + 12.0 * P     # depth only: no volume is materialised by mvs_sweep(volume=NULL)
+        # SURVEY 8(d) bytes, the same formula as the resident bench (the read-back of the volume is in it although mvs_sweep with
+        # volume = NULL selects the depth in the sweep kernel and writes no volume at all: the figure is algorithmic, not traffic)
+        sweep_bytes = float(P) * (V + 8.0 * D + 9.0)
         achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         print(json.dumps({
             "metric": "cost-volume samples/sec (pixels x planes x views)", "value": float(P) * D * V * world / (dt / args.steps),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPE[args.sampler],
             "data": "synthetic frames on the cameras of tracks/zatisi.yaml" + (" [TEST HOOK: ranks share one GPU over gloo]" if same_device else ""),
             "config": {"workload": "c5: zatisi.yaml %d frames, 640x480, %d planes, %d side views per main frame, one main frame per step "
                                    "through mvs_sweep (host frames in, host depth out: PCIe and per-frame planning included)" % (nframes, D, V),
-                       "shard": "frames", "frames_per_rank": len(mine), "plan_shape": shape, "device": ctx.info()},
-            "roofline": {"bound": "hbm", "kernel": "sweep_tiled", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "sampler": args.sampler, "shard": "frames", "frames_per_rank": len(mine), "plan_shape": shape, "device": ctx.info()},
+            "roofline": {"bound": "hbm", "kernel": "sweep_fx_tiled" if args.sampler == "fixed" else "sweep_tiled", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": sweep_bytes, "ms_per_launch": sweep_ms,
                          "valu_bound_note": "VALU-issue bound, see DESIGN.md section 4"},
             "depth_in_frame_fraction": float((depth != 1.0).mean())}), flush=True)
@@ -457,7 +462,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak" if shard == "frames" else "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE[args.sampler],
             "data": "synthetic (%s)" % args.data + (" [TEST HOOK: ranks share one GPU over gloo -- not a measurement]" if same_device else ""),
             "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V),
                        "sampler": args.sampler, "shard": shard, "collective": args.collective if shard == "views" else ("all_gather of depth rows" if shard == "rows" and world > 1 else None),
