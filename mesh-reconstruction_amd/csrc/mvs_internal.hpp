@@ -130,7 +130,8 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
 // the sweep's input setters with the final synchronisation optional (context.hip; mvs_sweep queues all of them and waits once)
 int sweep_set_main_impl(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, bool sync);
-int sweep_set_views_impl(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames, bool sync);
+int sweep_set_views_impl(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames, bool sync, bool defer_frames = false);
+int sweep_upload_frames_impl(mvs_ctx *ctx, const uint8_t *const *side_frames);  // the deferred half of sweep_set_views_impl
 int sweep_set_planes_impl(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi, bool sync);
 
 // device-buffer forms used by the flow stage (photometric.hip)

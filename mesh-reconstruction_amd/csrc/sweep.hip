@@ -1069,8 +1069,16 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
     // everything below is queued on the stream without intermediate waits (the q / z host tables live in the context; pageable
     // uploads return once staged); mvs_sweep_fetch at the end is the one synchronisation of the call
     if ((rc = sweep_set_main_impl(ctx, main_cam, main_hw, false))) return rc;
-    if ((rc = sweep_set_views_impl(ctx, nviews, side_cams, side_frames, false))) return rc;
+    if ((rc = sweep_set_views_impl(ctx, nviews, side_cams, side_frames, false, true))) return rc;  // tables only: the frames follow below
     if ((rc = sweep_set_planes_impl(ctx, nplanes, z_lo, z_hi, false))) return rc;
+    // the region plan needs the cameras and the planes, not the frames: queued first, it runs while the host stages the uploads
+    if (ctx->sampler == MVS_SAMPLER_FIXED && nviews > 0 && nviews <= 255) {
+        ProfileScope ps(ctx, MVS_K_PLAN);
+        if ((rc = sweep_fx_plan(ctx))) return rc;
+        ctx->plan_shape = 3;
+        ctx->plan_valid = true;
+    }
+    if ((rc = sweep_upload_frames_impl(ctx, side_frames))) return rc;
     const unsigned flags = MVS_SWEEP_FUSED_ARGMIN | (volume_dhw ? MVS_SWEEP_VOLUME : 0u);
     if ((rc = mvs_sweep_run(ctx, 0, nviews, flags))) return rc;
     if ((rc = mvs_sweep_fetch(ctx, depth_hw, cost_hw, nullptr, nullptr))) return rc;
