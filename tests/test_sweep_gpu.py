@@ -518,6 +518,28 @@ def test_many_views_use_batched_tables(oracle, sampler):
         _check(_gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, both | (splits << 16), sampler=sampler), ref, D)
 
 
+def test_255_views_at_maximal_cost(oracle, sampler):
+    """the fixed sampler's cell limit: 255 views, a black main frame against nearly white side frames -- sums of 1.6e7 (24 bits) and
+    cross products above 2^31 in the depth selection (they are compared unsigned: HIP's __umul24 returns int)"""
+    W, H, D, V = 64, 16, 16, 255
+    rng = np.random.default_rng(77)
+    main_cam, _, side_cams, _, _ = synth.make_views(W, H, V, radius=0.05, freq_scale=0.25)
+    main_img = np.zeros((H, W), np.uint8)
+    sides = [rng.integers(250, 256, (H, W), dtype=np.uint8) for _ in range(V)]
+    both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8, sampler=sampler)
+    gpu = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, both, sampler=sampler)
+    _check(gpu, ref, D)
+    shift = 24 if sampler == "fixed" else 16
+    full = (gpu[3] >> shift) == V
+    assert full.any()
+    if sampler == "fixed":
+        s = (gpu[3][full] & 0xffffff).astype(np.uint64)
+        assert (s * V).max() > 2**31, "the case must reach products the signed comparison would have ordered wrongly"
+    sep = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME, argmin=True, sampler=sampler)
+    np.testing.assert_array_equal(sep[2], gpu[2])   # the separate depth-selection kernel agrees with the fused one
+
+
 def test_sweep_matches_the_committed_golden_vectors(sampler):
     """HIP through the C ABI against tests/golden/sweep_small*.npz (written by the oracle via tests/golden/make_golden.py and
     committed): no oracle runs here, so the HIP path and the oracle cannot drift together unnoticed"""
