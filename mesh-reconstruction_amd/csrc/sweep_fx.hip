@@ -210,6 +210,28 @@ __device__ __forceinline__ void sample_range_fx(const Affine &A, float bx, float
                                                 float offy, uint32_t lds_base, uint32_t Im255, uint32_t (&acc)[FX_PC])
 {
     static_assert(KN % FX_GS == 0, "plane range must be a multiple of the group size");
+#ifdef MVS_FX_NO_ASM
+    // Build-time fallback without inline asm (make CXXFLAGS+=-DMVS_FX_NO_ASM): the same arithmetic with compiler-managed LDS reads and
+    // waits, bit-identical and slower.  The pipelined form below issues ds_read_b32 from inline asm and places its own s_waitcnt, which
+    // the compiler's wait-count insertion does not model: should a future hipcc copy or spill the loaded registers between issue and
+    // wait, this is the path to ship until the asm is revisited (the GPU parity suite is the gate either way).
+#pragma unroll
+    for (int k = 0; k < KN; k++) {
+        const float z = zc[K0 + k];
+        const float sx = __builtin_fmaf(z, bx, A.ax), sy = __builtin_fmaf(z, by, A.ay);
+        const float r256 = WCONST ? r256c : rcp_rn(__builtin_fmaf(z, bw, A.aw));
+        const float Tx = __builtin_fmaf(sx, r256, offx), Ty = __builtin_fmaf(sy, r256, offy);
+        const uint32_t P = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, Ty), __builtin_bit_cast(uint32_t, Tx), 0x05010400u);
+        typedef const __attribute__((address_space(3))) uint32_t *lds_ptr;  // lds_base is an LDS byte address, not a flat one
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"  // the host pass sees a 64-bit pointer type here; LDS pointers are 32 bits wide
+        const uint32_t w = *(lds_ptr)(lds_base + ((P >> 1) & 0x7c7cu));
+        const uint32_t quad = *(lds_ptr)(lds_base + ((P >> 14) & 0x7ffcu) + 4u * FX_LUT_DW);
+#pragma clang diagnostic pop
+        acc[K0 + k] = sad_u16(__builtin_amdgcn_udot4(quad, w, 0u, false), Im255, acc[K0 + k]);
+    }
+    return;
+#endif
     uint32_t la[FX_GS], ta[FX_GS];      // byte addresses of the group whose reads are issued next
     uint32_t lw[2][FX_GS], lq[2][FX_GS];  // weights and texel quads, double-buffered: group g is consumed while g + 1 is in flight
     auto address_stage = [&](int g) {
