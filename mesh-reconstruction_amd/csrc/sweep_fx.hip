@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
 #pragma unroll
                     for (int k = 0; k < PC; k++) {
                         const uint32_t cell = acc[j][k] + views;
-                        if (WRITE_VOLUME) (vol_chunk + (size_t)k * P)[pix] = cell;
+                        if (WRITE_VOLUME) __builtin_nontemporal_store(cell, vol_chunk + (size_t)k * P + pix);  // written once, read by a later kernel: keep it out of the L2 the quad images live in
                         if (FUSED) {
                             const bool better = umul24u(cell & 0xffffffu, best >> 24) < umul24u(best & 0xffffffu, cell >> 24);
                             best = better ? cell : best;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                     for (int k = 0; k < PC; k++) {
                         if (d0 + k < p.D) {
                             const uint32_t cell = acc[j][k] + views;
-                            if (WRITE_VOLUME) (vol_chunk + (size_t)k * P)[pix] = cell;
+                            if (WRITE_VOLUME) __builtin_nontemporal_store(cell, vol_chunk + (size_t)k * P + pix);  // written once, read by a later kernel: keep it out of the L2 the quad images live in
                             if (FUSED) {
                                 const bool better = umul24u(cell & 0xffffffu, best >> 24) < umul24u(best & 0xffffffu, cell >> 24);
                                 best = better ? cell : best;
