@@ -403,6 +403,9 @@ __global__ void lds_gather(float *out, int seed)
     if (PATTERN == 2) addr = ((lane * 2654435761u) >> 17) & 0x7ffc;   // random
     if (PATTERN == 3) addr = (lane >> 3) * 4;                         // 8 distinct addresses
     if (PATTERN == 4) addr = (lane & 31) * 4 + ((lane & 31) > 20 ? 1024 : 0) + (lane >> 5) * 2048;  // a row step inside the half wave
+    if (PATTERN == 5) addr = lane * 2;                                // 2-byte stride, overlapping dwords (a u16 column-pair layout)
+    if (PATTERN == 6) addr = lane * 2 + 2;                            // the same, odd start
+    if (PATTERN == 7) addr = lane * 4 + 2;                            // dword stride, every read misaligned by 2
     addr += seed;
     uint32_t acc = 0;
     for (int it = 0; it < ITERS; it++) {
@@ -644,6 +647,13 @@ int main(int argc, char **argv)
     float *out; unsigned long long *cyc;
     CHECK(hipMalloc(&out, 256 * 64 * 256 * 4));
     CHECK(hipMalloc(&cyc, 256 * 8 * 8));
+    if (argc > 1 && argv[1][0] == 'g') {  // LDS gather patterns only
+        run_gather<1>("consecutive per half wave", out);
+        run_gather<5>("2-byte stride, even start", out);
+        run_gather<6>("2-byte stride, odd start", out);
+        run_gather<7>("dword stride, misaligned by 2", out);
+        return 0;
+    }
     {
         char *glut;
         CHECK(hipMalloc(&glut, 65536));
@@ -676,6 +686,10 @@ int main(int argc, char **argv)
         run_gather<2>("random", out);
         run_gather<3>("8 distinct", out);
         run_gather<4>("row step in half wave", out);
+        run_gather<5>("2-byte stride, even start", out);
+        run_gather<6>("2-byte stride, odd start", out);
+        run_gather<7>("dword stride, misaligned by 2", out);
+        if (argc > 1 && argv[1][0] == 'g') return 0;
         if (argc > 1) return 0;
     }
     test_mfma_semantics();
