@@ -184,8 +184,8 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--shard", default=None, choices=["frames", "views", "rows"],
                     help="N > 1: how the work is split (default rows: strong scaling of ONE main view, depth rows all-gathered; the "
