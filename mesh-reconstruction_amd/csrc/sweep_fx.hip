@@ -15,7 +15,8 @@
 // v_sad_u16 = ~28 cycles, and the two LDS reads (weights, texel quad) hide behind it at 4 waves per SIMD
 // (tools/sweep_v2_probe.hip, profiles/r02/probe_*.txt).
 //
-// LDS image of a workgroup (32 KiB): 32 rows of 1 KiB.  Row r = [ weight table row ky = r : 32 dwords | 224 texel quads of region row r ].
+// LDS image of a workgroup (32 KiB): 32 rows of 1 KiB.  Row r = [ weight table row ky = r : 32 dwords | 224 texel quads: row r of one region in
+// columns 0..111 and of the next view's region in columns 112..223, or of one wide region ].
 // A quad is the four u8 texels (t00, t01, t10, t11) of one bilinear footprint, so the fetch is one ds_read_b32.  With
 // P = v_perm_b32(Ty, Tx) = [iy : ix : fy8 : fx8] both addresses are a shift and a mask away:
 //   weights  (P >> 1) & 0x7c7c = ky << 10 | kx << 2          quad  ((P >> 14) & 0x7ffc) + 128 = iy << 10 | ix << 2 (+ 128)
@@ -34,9 +35,9 @@ constexpr int FX_MAX_RW = FX_ROW_DW - FX_LUT_DW;  // 224 quads
 constexpr int FX_HALF_COL = FX_MAX_RW / 2;          // two regions of up to 112 quads side by side (region look-ahead)
 constexpr float FX_MAGIC = 12582912.0f;            // 1.5 * 2^23: floats in [2^23, 2^24) have ulp 1
 constexpr int FX_TILE_H = 8, FX_PC = 16, FX_NPX = 2;  // 64x8-pixel tiles, 16 planes per chunk: 32 accumulators per thread
-constexpr int FX_GS = 2;          // samples per software-pipeline group
+constexpr int FX_GS = 2;          // samples per software-pipeline group (4: 12 more VGPRs, spills, 1.505 vs 1.479 ms at c3)
 constexpr int FX_VB = 64;         // views per batch of LDS-resident per-view constants
-constexpr int FX_WG_PER_CU = 4;   // launch bound (waves per SIMD): 128 VGPRs, 36 KiB of LDS
+constexpr int FX_WG_PER_CU = 4;   // launch bound (waves per SIMD): 128 VGPRs, 39.5 KiB of LDS (5 would need <= 96 VGPRs: the kernel needs ~125)
 
 enum FxMode : unsigned { FX_SKIP = 0, FX_FAST = 1, FX_BORDER = 2, FX_GENERIC = 3 };
 
@@ -325,7 +326,7 @@ __device__ __forceinline__ void sample_range_fx_checked(const Affine &A, float b
     }
 }
 
-// 4 workgroups per CU (<= 128 VGPRs, 36 KiB of LDS each): at 2 per CU the LDS reads no longer hide behind the VALU work
+// 4 workgroups per CU (<= 128 VGPRs, 39.5 KiB of LDS each): at 2 per CU the LDS reads no longer hide behind the VALU work
 // (19.0 vs 14.6 ns per wave-sample, tools/sweep_v2_probe.hip).
 // Timing experiments (tools/exp_fx.py, tools/fx_sections.py) are compiled in with -DMVS_FX_EXPERIMENTS only: even never-taken
 // branches on p.debug change register allocation enough to cost the production kernel a few per cent.
