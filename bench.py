@@ -269,7 +269,7 @@ def main():
     ctx.sweep_use_volume(vol_t.data_ptr(), vol_t.numel() * 4)
     groups = mdist.plane_groups(D, args.plane_groups, ctx.plane_granularity())
     comm_stream = torch.cuda.Stream()
-    bands = mdist.row_bands(H, world, ctx.row_granularity())
+    bands = mdist.equal_row_bands(H, world, ctx.row_granularity())   # every band but the last `tallest` rows: gathered bands are contiguous
     v0, vn = mdist.view_shard(V, rank, world)
 
     # the single-GPU result of this rank's main view: the strong-scaling shardings must reproduce it bit for bit
@@ -289,20 +289,21 @@ def main():
         if mode == "rows" and world > 1:
             r0, rn = bands[rank]
             tallest = max(n for _, n in bands)
+            # band r is rows [r * tallest, ...) of the main view, so the gathered bands ARE the depth map (its first H rows): the
+            # collective reads a full band straight from the context's depth buffer and no row is copied afterwards; only a band
+            # shorter than `tallest` (the last one) goes through a padded staging buffer
             band_pad = torch.zeros((tallest, W), dtype=torch.float32, device="cuda")
             band_cat = torch.empty((world * tallest, W), dtype=torch.float32, device="cuda")   # concatenated form: every backend
-            band_all = band_cat.view(world, tallest, W)
+            mine = depth_t[r0:r0 + tallest] if rn == tallest else band_pad
 
             def step():
                 # rows are independent: every rank sweeps its band of the SAME main view over all views and planes (volume band
                 # materialised, depth selected in the kernel); only the depth rows travel (4 B per pixel in total)
                 ctx.sweep_run_rows(r0, rn, 0, V, both)
-                band_pad[:rn].copy_(depth_t[r0:r0 + rn])
-                dist.all_gather_into_tensor(band_cat, band_pad)
-                for r, (a, n) in enumerate(bands):
-                    if r != rank and n:
-                        depth_t[a:a + n].copy_(band_all[r, :n])
-            return step, V, bands[0][1], 4.0 * tallest * W * (world - 1) * 2
+                if rn != tallest and rn:
+                    band_pad[:rn].copy_(depth_t[r0:r0 + rn])
+                dist.all_gather_into_tensor(band_cat, mine)
+            return step, V, bands[0][1], 4.0 * tallest * W * (world - 1) * 2, lambda: band_cat[:H].cpu().numpy()
         if mode == "views" and world > 1 and collective == "reduce_scatter":
             if D % world:
                 raise SystemExit("reduce_scatter needs the plane count (%d) divisible by the ranks (%d)" % (D, world))
@@ -325,7 +326,7 @@ def main():
                 dist.all_gather_into_tensor(parts_t, part_t)
                 ctx.sweep_combine_partials(parts_t.data_ptr(), world)
             ring = (world - 1) / world
-            return step, vn, H, (4.0 * P * D * ring + 8.0 * P * world * ring) * 2
+            return step, vn, H, (4.0 * P * D * ring + 8.0 * P * world * ring) * 2, None
         if mode == "views" and world > 1:
             def step():
                 # sweep plane group g on the compute stream while group g-1 is summed over xGMI on the comm stream
@@ -341,21 +342,21 @@ def main():
                 for w in works:
                     w.wait()  # orders the current (compute) stream behind the collective
                 ctx.sweep_argmin()
-            return step, vn, H, 4.0 * P * D * 2 * (world - 1) / world * 2
+            return step, vn, H, 4.0 * P * D * 2 * (world - 1) / world * 2, None
         if args.separate_argmin:
             def step():
                 ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
                 ctx.sweep_argmin()
-            return step, V, H, 0.0
+            return step, V, H, 0.0, None
 
         def step():
             # what mvs_sweep() does on one GPU (and what every rank does for its own main frame in `frames` mode): the volume is
             # materialised AND the running best plane is kept in registers, so the volume is never read back
             ctx.sweep_run(0, V, both)
-        return step, V, H, 0.0
+        return step, V, H, 0.0, None
 
     def timed(mode, collective):
-        step, views, rows0, coll_bytes = make_step(mode, collective)
+        step, views, rows0, coll_bytes, gathered_depth = make_step(mode, collective)
         for _ in range(args.warmup):
             step()
         barrier()
@@ -372,7 +373,7 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        depth = ctx.sweep_fetch()[0]
+        depth = gathered_depth() if gathered_depth else ctx.sweep_fetch()[0]
         crc = zlib.crc32(np.ascontiguousarray(depth).tobytes())
         if mode != "frames" and crc != crc1:
             raise SystemExit("rank %d: %s sharding produced depth crc %08x, the single-GPU sweep of the same view %08x" % (rank, mode, crc, crc1))

@@ -68,6 +68,19 @@ def row_bands(H, world, granularity):
     return out
 
 
+def equal_row_bands(H, world, granularity):
+    """as row_bands, but every band has the same height `tallest` (a multiple of `granularity`) except the last non-empty one, which
+    takes the remainder: band r starts at row r * tallest, so bands gathered at a fixed stride are contiguous rows of the image.
+    The tallest band is as tall as row_bands' tallest (the step time is the same), the last one is shorter."""
+    units = (H + granularity - 1) // granularity
+    tallest = ((units + world - 1) // world) * granularity
+    out = []
+    for r in range(world):
+        first = min(H, r * tallest)
+        out.append((first, min(H, first + tallest) - first))
+    return out
+
+
 def gather_rows(dist, torch, local_rows, bands, W):
     """all-gather row bands of unequal height: every rank contributes its [count, W] band (padded to the tallest band),
     returns the assembled [H, W] map on every rank"""

@@ -114,3 +114,19 @@ def test_shard_bookkeeping():
             sizes = [n for _, n in bands if n]
             assert max(sizes) - min(sizes) <= 16 + 15      # balanced to one unit (the last band may be ragged)
     assert mdist.row_bands(1080, 8, 16) == [(0, 144), (144, 144), (288, 144), (432, 144), (576, 128), (704, 128), (832, 128), (960, 120)]
+
+
+def test_equal_row_bands_are_contiguous_at_a_fixed_stride():
+    """bench.py's rows sharding gathers the bands at a fixed stride and reads the depth map from the gathered buffer: band r must
+    start at r * tallest, only the last non-empty band may be shorter, and the tallest band is no taller than row_bands' tallest"""
+    from mvs_amd import dist as mdist
+    for H in (1, 16, 40, 480, 1080, 2160):
+        for world in (1, 2, 3, 4, 8, 100):
+            bands = mdist.equal_row_bands(H, world, 16)
+            tallest = max(n for _, n in bands)
+            assert len(bands) == world and (tallest % 16 == 0 or tallest == H)
+            assert [r for a, n in bands for r in range(a, a + n)] == list(range(H))
+            for r, (a, n) in enumerate(bands):
+                assert a == min(H, r * tallest) and (n == tallest or a + n == H)
+            assert tallest <= max(n for _, n in mdist.row_bands(H, world, 16)) + 15   # same number of units; only a ragged last band differs
+    assert mdist.equal_row_bands(1080, 8, 16) == [(0, 144)] + [(144 * r, 144) for r in range(1, 7)] + [(1008, 72)]
