@@ -29,7 +29,7 @@ def run(name, W, H, D, V, world, data):
         full_depth = ctx.sweep_fetch()[0].copy()
         alias = torch.as_tensor(ctx.depth_device_array(), device="cuda")
         alias_ok = bool(np.array_equal(alias.cpu().numpy(), full_depth))
-        bands = mdist.row_bands(H, world, ctx.row_granularity())
+        bands = mdist.equal_row_bands(H, world, ctx.row_granularity())
         band_ms = []
         for a, n in bands:
             for _ in range(3):
