@@ -160,7 +160,8 @@ int mvs_sweep_plane_granularity(void);
  * so G ranks sweep one band each of the SAME main view and exchange only the depth rows (bench.py --shard rows).
  * Volume cells and depth / cost / index outside the band are left untouched. */
 int mvs_sweep_run_rows(mvs_ctx *ctx, int view_first, int view_count, int row_first, int row_count, unsigned flags);
-int mvs_sweep_row_granularity(void);
+int mvs_sweep_row_granularity(void);                    /* valid for either sampler (16) */
+int mvs_sweep_row_granularity_of(const mvs_ctx *ctx);   /* what the context's current sampler needs (fixed sampler: 8): finer bands balance better */
 /* diagnostic: thread shape the region planner chose for the current (views, planes): 0 = no plan yet,
  * 1 = exact sampler, 2 pixels x 32 planes per thread (64x8-pixel tiles), 2 = exact sampler, 4 pixels x 16 planes (64x16 tiles:
  * bit-identical to 1; the choice follows how many warped 32-plane footprints fit the LDS staging buffer), 3 = fixed sampler

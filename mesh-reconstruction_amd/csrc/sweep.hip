@@ -777,14 +777,18 @@ int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags)
 int mvs_sweep_run_rows(mvs_ctx *ctx, int view_first, int view_count, int row_first, int row_count, unsigned flags)
 {
     if (!ctx) return MVS_EINVAL;
-    if (row_first < 0 || row_count < 0 || row_first + row_count > ctx->H || (row_first % ROW_GRAN) != 0 ||
-        ((row_first + row_count) % ROW_GRAN != 0 && row_first + row_count != ctx->H))
+    const int gran = mvs_sweep_row_granularity_of(ctx);
+    if (row_first < 0 || row_count < 0 || row_first + row_count > ctx->H || (row_first % gran) != 0 ||
+        ((row_first + row_count) % gran != 0 && row_first + row_count != ctx->H))
         return fail(ctx, MVS_EINVAL, "mvs_sweep_run_rows: row range [%d,%d) must lie in 0..%d and start/end on multiples of %d",
-                    row_first, row_first + row_count, ctx->H, ROW_GRAN);
+                    row_first, row_first + row_count, ctx->H, gran);
     return sweep_run_impl(ctx, view_first, view_count, 0, ctx->D, row_first, row_count, flags);
 }
 
 int mvs_sweep_row_granularity(void) { return ROW_GRAN; }
+
+// the fixed sampler's tiles are 8 rows tall whatever the plan; the exact sampler's 8 or 16 (hence 16)
+int mvs_sweep_row_granularity_of(const mvs_ctx *ctx) { return (ctx && ctx->sampler == MVS_SAMPLER_FIXED) ? 8 : ROW_GRAN; }
 
 int mvs_sweep_set_sampler(mvs_ctx *ctx, int sampler)
 {

@@ -58,6 +58,7 @@ ABI = [
     ("mvs_sweep_plane_granularity", _i, []),
     ("mvs_sweep_run_rows", _i, [_vp, _i, _i, _i, _i, C.c_uint]),
     ("mvs_sweep_row_granularity", _i, []),
+    ("mvs_sweep_row_granularity_of", _i, [_vp]),
     ("mvs_sweep_plan_shape", _i, [_vp]),
     ("mvs_sweep_argmin", _i, [_vp]),
     ("mvs_sweep_argmin_partial", _i, [_vp, _vp, _i, _i, _vp]),
@@ -316,7 +317,8 @@ class Context:
         self._check(self.lib.mvs_sweep_run_rows(self.h, int(view_first), int(view_count), int(row_first), int(row_count), int(flags)))
 
     def row_granularity(self):
-        return self.lib.mvs_sweep_row_granularity()
+        """row-band boundaries must be multiples of this (depends on the sampler set on the context)"""
+        return self.lib.mvs_sweep_row_granularity_of(self.h)
 
     def plan_shape(self):
         return self.lib.mvs_sweep_plan_shape(self.h)

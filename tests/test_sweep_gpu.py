@@ -404,7 +404,7 @@ def test_row_bands_reproduce_the_full_result(sampler):
                 np.testing.assert_array_equal(i, i_full)
                 np.testing.assert_array_equal(c, c_full)
         ctx.sweep_run_rows(0, 0, 0, V, both)                     # an empty band is legal (rank beyond the units)
-        for bad in ((8, 16), (0, 24), (192, 16), (-16, 16)):
+        for bad in ((g // 2, g), (0, g + g // 2), (192, 16), (-g, g)):   # boundaries off the granularity (8 fixed, 16 exact), past H, negative
             with pytest.raises(mvs_amd.MvsError):
                 ctx.sweep_run_rows(bad[0], bad[1], 0, V, both)
         ctx.sweep_run_rows(192, 8, 0, V, both)                   # ragged last band ends at H
