@@ -161,6 +161,15 @@ int mvs_sweep_sharded(mvs_comm *c, const float main_cam[16], const uint8_t *main
     if (!main_cam || !main_hw || !depth_hw || nviews < 0 || (nviews > 0 && (!side_cams || !side_frames)))
         return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: null argument");
     if (nplanes < 1 || nplanes > 4096) return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: nplanes=%d out of range 1..4096", nplanes);
+    // Everything a rank could reject is checked HERE, before any rank enters a collective: a rank that returned early would leave the
+    // others waiting in RCCL for ever.  (A HIP or RCCL failure in the middle of the exchange is not recoverable either way.)
+    for (int v = 0; v < nviews; v++)
+        if (!side_frames[v]) return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: side_frames[%d] is null", v);
+    const int view_limit = mvs_sweep_sampler(c->ctx[0]) == MVS_SAMPLER_FIXED ? 255 : 256;  // the SUMMED cells must hold every view's count
+    if (nviews > view_limit) return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: %d views, the sampler's cells hold at most %d", nviews, view_limit);
+    for (int r = 1; r < c->n; r++)
+        if (mvs_sweep_sampler(c->ctx[r]) != mvs_sweep_sampler(c->ctx[0]))
+            return comm_fail(c, MVS_ESTATE, "mvs_sweep_sharded: rank %d uses another sampler than rank 0 (cells of different formats cannot be summed)", r);
     const int n = c->n;
     const size_t P = (size_t)c->W * c->H;
     // plane slices of equal size: reduce-scatter; otherwise (or with the test hook MVS_COMM_ALLREDUCE set) all-reduce in place

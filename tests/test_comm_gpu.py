@@ -42,6 +42,10 @@ def test_single_device_comm_equals_one_call_sweep(oracle, sampler, monkeypatch):
         np.testing.assert_array_equal(c, c1)
         with pytest.raises(mvs_amd.MvsError):
             comm.sweep(main_cam, main_img, side_cams, sides, 0)
+        # more views than a summed cell can count: refused before any rank enters a collective (a late refusal would hang the others)
+        too_many = 256 if sampler == "fixed" else 257
+        with pytest.raises(mvs_amd.MvsError, match="views"):
+            comm.sweep(main_cam, main_img, np.repeat(side_cams[:1], too_many, 0), [sides[0]] * too_many, D)
 
 
 def test_comm_create_errors_on_the_gpu_box():
