@@ -72,6 +72,24 @@ __device__ __forceinline__ uint32_t sample_global_fx(const Affine &A, float bx, 
     return sad_u16(dot, Im255, 1u << 24);
 }
 
+// The same sample for the tiled kernel's GENERIC regions (warped footprint larger than the LDS image): the texel quad is ONE dword
+// of the view's quad image (instead of four byte gathers from the padded frame) and the weights come from the table rows the LDS
+// image carries anyway (instead of a gather from global memory); no divergent branch -- a sample outside the frame reads quad 0 and
+// is dropped by the select.  The w row is pre-divided by 256 (see the kernel).
+__device__ __forceinline__ uint32_t sample_quads_fx(const Affine &A, float bx, float by, float bw, float z, const uint32_t *__restrict__ quads, int pitch,
+                                                   float hix, float hiy, const uint32_t *__restrict__ lds, uint32_t Im255)
+{
+    const float sx = __builtin_fmaf(z, bx, A.ax), sy = __builtin_fmaf(z, by, A.ay), sw = __builtin_fmaf(z, bw, A.aw);
+    const float r256 = rcp_rn(sw);
+    const float tx = __builtin_fmaf(sx, r256, FX_MAGIC + 4.0f), ty = __builtin_fmaf(sy, r256, FX_MAGIC + 4.0f);
+    const bool ok = sw > 0.0f && tx > FX_MAGIC + 132.0f && tx < hix && ty > FX_MAGIC + 132.0f && ty < hiy;
+    const uint32_t ux = __builtin_bit_cast(uint32_t, tx) & 0x3fffffu, uy = __builtin_bit_cast(uint32_t, ty) & 0x3fffffu;  // t - magic
+    const uint32_t quad = quads[ok ? (uy >> 8) * (uint32_t)pitch + (ux >> 8) : 0u];
+    const uint32_t w = lds[(((uy >> 3) & 31u) << 8) | ((ux >> 3) & 31u)];  // table row ky is the first 32 dwords of LDS row ky
+    const uint32_t cell = sad_u16(__builtin_amdgcn_udot4(quad, w, 0u, false), Im255, 1u << 24);
+    return ok ? cell : 0u;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // un-tiled kernel: one pixel per thread, global gathers (MVS_SWEEP_FORCE_GENERIC, V == 0)
 // ------------------------------------------------------------------------------------------------------
@@ -453,14 +471,14 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
             if (pt_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             FX_PROF_MARK(0);
 #endif
-            if (mode == FX_GENERIC) {
-                const uint8_t *pad = p.pads + p.pad_slab * v;
+            if (__builtin_expect(mode == FX_GENERIC, 0)) {
+                const uint32_t *qv = p.quads + p.pad_slab * v;
 #pragma unroll
                 for (int j = 0; j < NPX; j++) {
                     if (ok[j]) {
                         const Affine A = view_affine(q, xn, yn[j]);
 #pragma unroll
-                        for (int k = 0; k < PC; k++) acc[j][k] += sample_global_fx<true>(A, bx, by, bw, zc[k], pad, p.pitch, fhix, fhiy, lut_g, Im255[j]);
+                        for (int k = 0; k < PC; k++) acc[j][k] += sample_quads_fx(A, bx, by, bw, zc[k], qv, p.pitch, fhix, fhiy, lds, Im255[j]);
                     }
                 }
                 continue;
