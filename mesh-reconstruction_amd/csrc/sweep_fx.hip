@@ -213,8 +213,8 @@ __device__ __forceinline__ void stage_region_fx(const uint32_t *__restrict__ qua
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int units = rw >> 2;
     const uint32_t *src = quads + (size_t)y0 * pitch + x0 + 4 * lane;
-    for (int ry = wave; ry < rh; ry += 4) {
-        if (lane < units)
+    if (lane < units) {  // one exec-mask change around the whole loop, not one per row
+        for (int ry = wave; ry < rh; ry += 4)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)ry * pitch),
                                              (__attribute__((address_space(3))) void *)(lds + ry * FX_ROW_DW + FX_LUT_DW + col), 16, 0, 0);
     }
