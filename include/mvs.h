@@ -130,7 +130,7 @@ int mvs_warp_by_depth(mvs_ctx *ctx, const float main_cam[16], const float *depth
  *   MVS_SAMPLER_FIXED (default): positions quantised to 1/32 texel and 8-bit weights from a 32 x 32 table -- the model of
  *     fixed-function samplers and of OpenCV's fixed-point remap (INTER_BITS = 5, the path of the reference's flowRemap,
  *     util.cpp:401); the warped intensity keeps the table's precision and a packed cell is count << 24 | sum |w.t - 255 I_main|
- *     (sums in 1/255 grey levels; at most 255 views).  About half the instructions per sample on gfx950.
+ *     (sums in 1/255 grey levels; at most 255 views; images of up to 16383 x 16383).  About 30 % fewer instructions per sample on gfx950.
  *   MVS_SAMPLER_EXACT_F32: bilinear interpolation in f32 with one rounding per operation, result rounded to u8 like the RGB8
  *     read-back; a packed cell is count << 16 | sum |u8 - I_main| (at most 257 views).
  * Both are restated bit for bit by the CPU oracle; they select the same plane except where two planes' costs are within the

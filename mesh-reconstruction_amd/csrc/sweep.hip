@@ -841,6 +841,10 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
 
     if (ctx->sampler == MVS_SAMPLER_FIXED) {
         if (ctx->V > 255) return fail(ctx, MVS_EINVAL, "mvs_sweep_run: the fixed sampler's cells hold at most 255 views (have %d)", ctx->V);
+        // 1/256-texel coordinates live in the low 22 mantissa bits of a float in [2^23, 2^24): 256 * size + 132 must stay below 2^22
+        if (ctx->W > 16383 || ctx->H > 16383)
+            return fail(ctx, MVS_EINVAL, "mvs_sweep_run: the fixed sampler addresses images of up to 16383 x 16383 (have %d x %d); use MVS_SAMPLER_EXACT_F32",
+                        ctx->W, ctx->H);
         if (ctx->plan_valid && ctx->plan_shape != 3) ctx->plan_valid = false;
         if (!generic && !ctx->plan_valid && ctx->V > 0) {
             ProfileScope ps(ctx, MVS_K_PLAN);

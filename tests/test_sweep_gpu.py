@@ -311,6 +311,17 @@ def test_argument_errors():
             ctx.sweep_set(main_cam, main_img, side_cams, sides, 0)  # zero planes
     with pytest.raises(mvs_amd.MvsError):
         mvs_amd.Context(1, 1)
+    # the widest frame the library accepts: the fixed sampler's 1/256-texel coordinates stop at 16383, the exact sampler takes it
+    W, H = 16384, 2
+    cam = synth.camera_at([0.0, 0.0, 0.0], W, H)
+    img = np.zeros((H, W), np.uint8)
+    with mvs_amd.Context(W, H, sampler="fixed") as ctx:
+        ctx.sweep_set(cam, img, cam[None], [img], 2)
+        with pytest.raises(mvs_amd.MvsError, match="16383"):
+            ctx.sweep_run(0, 1, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        ctx.set_sampler("exact")
+        ctx.sweep_run(0, 1, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        assert (ctx.sweep_fetch()[2] == 0).all()                   # identical black frames: every plane costs 0, the first one wins
 
 
 def test_plane_groups_reproduce_the_full_volume(sampler):
