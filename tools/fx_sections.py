@@ -8,7 +8,7 @@ os.environ["MVS_FX_PROF"] = "1"
 import mvs_amd
 from mvs_amd import synth
 
-cfg = {"c1": (640, 480, 32, 4), "c2": (1280, 720, 64, 8), "c3": (1920, 1080, 128, 16)}[sys.argv[1] if len(sys.argv) > 1 else "c3"]
+cfg = {"c1": (640, 480, 32, 4), "c2": (1280, 720, 64, 8), "c3": (1920, 1080, 128, 16), "c5": (640, 480, 128, 4)}[sys.argv[1] if len(sys.argv) > 1 else "c3"]
 W, H, D, V = cfg
 mc, mi, sc, si, gt = synth.make_views(W, H, V, radius=0.15)
 both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
