@@ -119,9 +119,45 @@ __global__ void quad_image_views_kernel(const uint8_t *__restrict__ pads, uint32
     quads[pad_slab * blockIdx.z + (size_t)r * pitch + c] = q;
 }
 
+// The exact sampler's LDS quad {t00 + 0.5, t01 - t00, t10 - t00, (t11 - t10) - (t01 - t00)} as four f16 (all exactly representable),
+// precomputed per texel of a padded side view: the sweep then fills its LDS region with global->LDS copies instead of building the
+// quads from bytes on the VALU for every (tile, chunk, view).  8 bytes per texel; built on demand (mvs_sweep_run with that sampler).
+__global__ void quad16_image_views_kernel(const uint8_t *__restrict__ pads, uint2 *__restrict__ q16, int W, int H, int pitch, size_t pad_slab)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= pitch) return;
+    uint2 q = make_uint2(0u, 0u);
+    if (r <= H && c <= W) {
+        const uint8_t *p0 = pads + pad_slab * blockIdx.z + (size_t)r * pitch + c;
+        const float t00 = (float)p0[0], t01 = (float)p0[1], t10 = (float)p0[pitch], t11 = (float)p0[pitch + 1];
+        const _Float16 h0 = (_Float16)(t00 + 0.5f), h1 = (_Float16)(t01 - t00), h2 = (_Float16)(t10 - t00), h3 = (_Float16)((t11 - t10) - (t01 - t00));
+        q.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+        q.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
+    }
+    q16[pad_slab * blockIdx.z + (size_t)r * pitch + c] = q;
+}
+
 }  // namespace mvs
 
 using namespace mvs;
+
+namespace mvs {
+
+int ensure_quads16(mvs_ctx *ctx)
+{
+    if (ctx->quads16_valid || ctx->V <= 0) return MVS_OK;
+    int rc = ensure(ctx, ctx->side_quads16, ctx->pad_slab * ctx->V * sizeof(uint2) + 256);
+    if (rc) return rc;
+    const dim3 grid(div_up(ctx->pad_pitch, 256), ctx->H + 2, ctx->V);
+    quad16_image_views_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)ctx->side_pads.ptr, (uint2 *)ctx->side_quads16.ptr, ctx->W, ctx->H, ctx->pad_pitch,
+                                                             ctx->pad_slab);
+    MVS_HIP(ctx, hipGetLastError());
+    ctx->quads16_valid = true;
+    return MVS_OK;
+}
+
+}  // namespace mvs
 
 extern "C" {
 
@@ -184,7 +220,7 @@ void mvs_destroy(mvs_ctx *ctx)
     DevBuf *bufs[] = {&ctx->main_img, &ctx->side_pads, &ctx->qmats, &ctx->ztab, &ctx->plan, &ctx->upload,
                       &ctx->volume_own, &ctx->depth, &ctx->cost, &ctx->index, &ctx->soup, &ctx->r_zbuf,
                       &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2,
-                      &ctx->cubic_tab, &ctx->flow_arena, &ctx->frame_buf, &ctx->best_parts, &ctx->plan_stats, &ctx->probe_buf, &ctx->filter_sort, &ctx->raster_bins, &ctx->fx_lut, &ctx->side_quads};
+                      &ctx->cubic_tab, &ctx->flow_arena, &ctx->frame_buf, &ctx->best_parts, &ctx->plan_stats, &ctx->probe_buf, &ctx->filter_sort, &ctx->raster_bins, &ctx->fx_lut, &ctx->side_quads, &ctx->side_quads16};
     for (int i = 0; i < 2; i++)
         if (ctx->flow_graph[i]) (void)hipGraphExecDestroy(ctx->flow_graph[i]);
     for (DevBuf *b : bufs)
@@ -315,6 +351,7 @@ int sweep_upload_frames_impl(mvs_ctx *ctx, const uint8_t *const *side_frames)
     quad_image_views_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)ctx->side_pads.ptr, (uint32_t *)ctx->side_quads.ptr, W, H, ctx->pad_pitch,
                                                            ctx->pad_slab);
     MVS_HIP(ctx, hipGetLastError());
+    ctx->quads16_valid = false;  // the exact sampler's quad image is rebuilt from the new pads when that sampler next runs
     return MVS_OK;
 }
 

@@ -53,6 +53,8 @@ struct mvs_ctx {
     bool plan_valid = false;         // region plan matches current (views, planes)
     int sampler = MVS_SAMPLER_FIXED;  // arithmetic contract of the sweep's texture fetch (mvs_sweep_set_sampler)
     mvs::DevBuf side_quads;          // fixed sampler: quad image of every padded side view (4 bytes per texel), built by mvs_sweep_set_views
+    mvs::DevBuf side_quads16;        // exact sampler: f16 quad image (8 bytes per texel), built on demand by ensure_quads16
+    bool quads16_valid = false;
     mvs::DevBuf fx_lut;              // fixed sampler: 32 x 32 table of packed 8-bit bilinear weights
     int plan_shape = 2;              // what the plan was made for: 1 = exact sampler, 2 px x 32 planes; 2 = exact, 4 px x 16 planes; 3 = fixed sampler
     bool plan_forced = false;        // plan made with the 4 x 16 shape forced (timing experiments)
@@ -131,7 +133,8 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // the sweep's input setters with the final synchronisation optional (context.hip; mvs_sweep queues all of them and waits once)
 int sweep_set_main_impl(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, bool sync);
 int sweep_set_views_impl(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames, bool sync, bool defer_frames = false);
-int sweep_upload_frames_impl(mvs_ctx *ctx, const uint8_t *const *side_frames);  // the deferred half of sweep_set_views_impl
+int sweep_upload_frames_impl(mvs_ctx *ctx, const uint8_t *const *side_frames);
+int ensure_quads16(mvs_ctx *ctx);  // exact sampler's f16 quad image of the current side views  // the deferred half of sweep_set_views_impl
 int sweep_set_planes_impl(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi, bool sync);
 
 // device-buffer forms used by the flow stage (photometric.hip)

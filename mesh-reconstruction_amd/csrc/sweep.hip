@@ -173,63 +173,24 @@ __global__ __launch_bounds__(256) void plan_regions(SweepParams p, uint2 *__rest
 // LDS region format: one 8-byte quad per texel position (y, x) of the padded side image:
 //   { t00 + 0.5, t01 - t00, t10 - t00, (t11 - t10) - (t01 - t00) } as four f16 (all exactly representable),
 // so the bilinear fetch is one ds_read_b64 and three v_fma_mix_f32.
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// two adjacent bytes -> packed f16 (1024 + b_lo, 1024 + b_hi): v_perm_b32 places the bytes in the low byte of
-// each half, OR-ing 0x6400 turns each half into the f16 with exponent 2^10 whose mantissa is the byte.
-__device__ __forceinline__ f16x2 bytes_to_f16x2(uint32_t hi_word, uint32_t lo_word, uint32_t sel)
+// Stage the region [x0, x0+rw) x [y0, y0+rh) of a view into LDS from its precomputed f16 quad image (context.hip:
+// quad16_image_views_kernel): global->LDS copies, 16 bytes = 2 quads per lane, one or two instructions per region row (rw <= 192
+// quads), rows dealt to the four wavefronts; no VALU work and no registers.  The caller's __syncthreads() awaits the copies (it
+// drains vmcnt).  (Round 1 built the quads from the padded bytes with permutes and packed-f16 subtractions for every (tile, chunk,
+// view): 1.1 VALU instructions per sample; 2.04 -> 1.95 ms at c3.)
+__device__ __forceinline__ void stage_region_q16(const uint2 *__restrict__ q16, int pitch, int x0, int y0, int rw, int rh, int rp,
+                                                 uint2 *__restrict__ lds)
 {
-    return __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(hi_word, lo_word, sel) | 0x64006400u);
-}
-
-__device__ __forceinline__ uint32_t interleave_lo(f16x2 hi, f16x2 lo)  // (lo.x, hi.x)
-{
-    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x05040100u);
-}
-__device__ __forceinline__ uint32_t interleave_hi(f16x2 hi, f16x2 lo)  // (lo.y, hi.y)
-{
-    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x07060302u);
-}
-
-// Stage the region [x0, x0+rw) x [y0, y0+rh) of the padded side image into LDS quads.  A unit is 4 quads of one
-// region row: 4 aligned dword loads (two image rows), then byte permutes and packed-f16 subtractions only --
-// every value is a small integer (or integer + 0.5), so all of it is exact:
-//   T = (b_k, b_k+1) - 1023.5 -> t00 + 0.5     X  = (b_k+1, b_k+2) - (b_k, b_k+1)   -> t01 - t00
-//   DY = (c_k, c_k+1) - (b_k, b_k+1)           DXY = ((c_k+1, c_k+2) - (c_k, c_k+1)) - X
-__device__ __forceinline__ void stage_region(const uint8_t *__restrict__ pad, int pitch, int x0, int y0, int rw,
-                                             int rh, int rp, uint2 *__restrict__ lds)
-{
-    // units (4 quads each) are dealt to the 256 threads in row-major order; (row, unit-in-row) by an exact
-    // float division: (u + 0.5) / units never lands within rounding distance of an integer for u < 2^16
-    const int units = rw >> 2;
-    const int total = units * rh;
-    const float inv_units = 1.0f / (float)units;
-    const f16x2 bias = {(_Float16)-1023.5f, (_Float16)-1023.5f};
-    for (int u = threadIdx.x; u < total; u += 256) {
-        {
-            const int ry = (int)(((float)u + 0.5f) * inv_units);
-            const int tx = u - ry * units;
-            const uint8_t *r0 = pad + (size_t)(y0 + ry) * pitch + x0 + 4 * tx;
-            const uint32_t d0 = *(const uint32_t *)r0, d1 = *(const uint32_t *)(r0 + 4);
-            const uint32_t e0 = *(const uint32_t *)(r0 + pitch), e1 = *(const uint32_t *)(r0 + pitch + 4);
-            const f16x2 B01 = bytes_to_f16x2(d1, d0, 0x0c010c00u), B12 = bytes_to_f16x2(d1, d0, 0x0c020c01u),
-                        B23 = bytes_to_f16x2(d1, d0, 0x0c030c02u), B34 = bytes_to_f16x2(d1, d0, 0x0c040c03u);
-            const f16x2 C01 = bytes_to_f16x2(e1, e0, 0x0c010c00u), C12 = bytes_to_f16x2(e1, e0, 0x0c020c01u),
-                        C23 = bytes_to_f16x2(e1, e0, 0x0c030c02u), C34 = bytes_to_f16x2(e1, e0, 0x0c040c03u);
-            const f16x2 Ta = B01 + bias, Xa = B12 - B01, DYa = C01 - B01, DXYa = (C12 - C01) - Xa;
-            const f16x2 Tb = B23 + bias, Xb = B34 - B23, DYb = C23 - B23, DXYb = (C34 - C23) - Xb;
-            uint4 q01, q23;
-            q01.x = interleave_lo(Xa, Ta);
-            q01.y = interleave_lo(DXYa, DYa);
-            q01.z = interleave_hi(Xa, Ta);
-            q01.w = interleave_hi(DXYa, DYa);
-            q23.x = interleave_lo(Xb, Tb);
-            q23.y = interleave_lo(DXYb, DYb);
-            q23.z = interleave_hi(Xb, Tb);
-            q23.w = interleave_hi(DXYb, DYb);
-            uint4 *dst = (uint4 *)(lds + ry * rp + 4 * tx);
-            dst[0] = q01;
-            dst[1] = q23;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pairs = rw >> 1;  // lanes a row needs
+    const uint2 *src = q16 + (uint32_t)(y0 * pitch + x0) + 2 * lane;
+    for (int blk = 0; blk * 64 < pairs; blk++) {
+        if (lane + blk * 64 < pairs) {
+            for (int ry = wave; ry < rh; ry += 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)ry * pitch + blk * 128),
+                                                 (__attribute__((address_space(3))) void *)(lds + ry * rp + blk * 128), 16, 0, 0);
         }
     }
 }
@@ -468,7 +429,7 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
             const int rh = __builtin_amdgcn_readfirstlane((int)((desc.y >> 8) & 0xffu));
             const int rp = __builtin_amdgcn_readfirstlane((int)(desc.y >> 24) << 5);
             __syncthreads();  // all reads of the previous region are done
-            if (!(p.debug & 1)) stage_region(pad, p.pitch, x0, y0, rw, rh, rp, lds);
+            if (!(p.debug & 1)) stage_region_q16(p.quads16 + p.pad_slab * v, p.pitch, x0, y0, rw, rh, rp, lds);
             __syncthreads();
             RegionView rv;
             rv.lds_bytes = (const char *)lds;
@@ -875,6 +836,7 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
         return MVS_OK;
     }
     if (ctx->plan_valid && ctx->plan_shape == 3) ctx->plan_valid = false;  // the plan in memory belongs to the fixed sampler
+    if (!generic && (rc = ensure_quads16(ctx))) return rc;
 
     // thread shape of the tiled kernel (see the constants at the top): 2 pixels x 32 planes unless the planner finds
     // that more than 2 % of the regions a 32-plane chunk touches do not fit the LDS staging buffer

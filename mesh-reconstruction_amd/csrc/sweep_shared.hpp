@@ -31,6 +31,7 @@ struct SweepParams {
     size_t pad_slab;
     int pitch;
     const uint32_t *__restrict__ quads;  // fixed sampler: per view (H+2) x pitch packed bilinear footprints (t00, t01, t10, t11); pad_slab dwords per view
+    const uint2 *__restrict__ quads16;   // exact sampler: per view (H+2) x pitch f16 quads {t00 + 0.5, t01 - t00, t10 - t00, dxy}; pad_slab quads per view
     int W, H, D, V;
     int v0, vcount;
     const float *__restrict__ Q;  // V * 12
@@ -151,6 +152,7 @@ inline int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount, int til
     p.pads = (const uint8_t *)ctx->side_pads.ptr;
     p.pad_slab = ctx->pad_slab;
     p.quads = (const uint32_t *)ctx->side_quads.ptr;
+    p.quads16 = (const uint2 *)ctx->side_quads16.ptr;
     p.pitch = ctx->pad_pitch;
     p.W = ctx->W;
     p.H = ctx->H;
