@@ -5,7 +5,8 @@ usage: tools/pmc_summary.py <config> <tag> <out.json> <dir with *_counter_collec
 FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE counts half of the bytes of wide
 (16 B per lane) streaming reads (MI355X_MICROARCH.md, HBM section), so both the raw and the doubled figure are kept;
 `hbm_bytes_per_launch` uses the doubled fetch only for kernels listed in WIDE_READERS (argmin_volume streams uint4),
-the raw one otherwise (the exact sampler's staging reads are 4-byte loads, uncalibrated: raw figure is the lower bound)."""
+the raw one otherwise.  Both tiled sweep kernels fill LDS with 16-byte-per-lane global->LDS copies (the exact sampler since round 2's
+v23; its round-1 staging used 4-byte loads and is summarised undoubled in the older files)."""
 import collections
 import csv
 import glob
@@ -13,7 +14,7 @@ import json
 import sys
 
 # kernels whose reads are 16 bytes per lane: argmin_volume streams uint4; sweep_fx_tiled fills LDS with global_load_lds_dwordx4
-WIDE_READERS = ("void mvs::argmin_volume<4", "void mvs::sweep_fx_tiled")
+WIDE_READERS = ("void mvs::argmin_volume<4", "void mvs::sweep_fx_tiled", "void mvs::sweep_tiled")
 
 
 def main():
