@@ -893,12 +893,12 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
         } else {
             // padded group grid: 8 tiles per group, 8 groups per 64-id super block
             const int groups = div_up(p.tiles_x, 2) * div_up(p.tyn, 4);
-            // plane split: aim at ~64 workgroups per CU.  Finer work units smooth the tail of the launch and keep small
+            // plane split: aim at ~32 workgroups per CU (64 in round 1).  Finer work units smooth the tail of the launch and keep small
             // frames / row bands from leaving CUs idle: c3 2.50 -> 2.31 ms, c2 0.414 -> 0.333 ms, c1 0.080 -> 0.055 ms,
             // a 1/8 row band of c3 0.86 -> 0.4 ms; flat at c4 (8100 tiles) -- profiles/r01/exp_split.json
             const int nch = p.chunk1 - p.chunk0, tiles = p.tiles_x * p.tyn;
             int want = (int)((flags >> 16) & 0xffu);  // undocumented: forced split count for timing experiments
-            if (!want) want = div_up(64 * ctx->num_cus, tiles);
+            if (!want) want = div_up(32 * ctx->num_cus, tiles);  // round 2: 32 instead of 64 workgroups per CU (c3: 2 splits 1.92 ms, 4 splits 1.94)
             p.cps = div_up(nch, max(1, min(want, nch)));
             const int nsplit = div_up(nch, p.cps);
             if (fused && nsplit > 1) {
