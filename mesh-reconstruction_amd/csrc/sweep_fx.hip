@@ -212,7 +212,7 @@ __device__ __forceinline__ void stage_region_fx(const uint32_t *__restrict__ qua
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int units = rw >> 2;
-    const uint32_t *src = quads + (size_t)y0 * pitch + x0 + 4 * lane;
+    const uint32_t *src = quads + (uint32_t)(y0 * pitch + x0) + 4 * lane;  // a slab has fewer than 2^32 quads
     if (lane < units) {  // one exec-mask change around the whole loop, not one per row
         for (int ry = wave; ry < rh; ry += 4)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)ry * pitch),
@@ -459,7 +459,9 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
             dnext = dtab[dbase + vi + 1];  // the next region's descriptor (or the sentinel): in flight with this view's constants, one wait for all
             unsigned mode = (unsigned)__builtin_amdgcn_readfirstlane((int)((desc.y >> 16) & 7u));
             if (mode == FX_SKIP) continue;
+#ifdef MVS_FX_EXPERIMENTS
             if ((p.debug & 16) && mode == FX_BORDER) mode = FX_FAST;  // timing experiment only (wrong counts at the frame border)
+#endif
             float q[12];  // wave-uniform values, kept in VGPRs: they are only ever VALU operands (v_fma allows one SGPR, and that is z)
             {
                 const float4 qa = *(const float4 *)(qtab + 12 * vi), qb = *(const float4 *)(qtab + 12 * vi + 4), qc = *(const float4 *)(qtab + 12 * vi + 8);
@@ -490,7 +492,10 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
             if (!ahead) {
                 __syncthreads();  // every wavefront is done with the region these rows held
                 qcol = 0;
-                if (!(p.debug & 1)) stage_region_fx(p.quads + p.pad_slab * v, p.pitch, x0, y0, rw, rh, qcol, lds);
+#ifdef MVS_FX_EXPERIMENTS
+                if (!(p.debug & 1))  // timing experiment only: no copies
+#endif
+                stage_region_fx(p.quads + p.pad_slab * v, p.pitch, x0, y0, rw, rh, qcol, lds);
             }
 #ifdef MVS_FX_EXPERIMENTS
             if (p.debug & 64)
@@ -510,7 +515,9 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                 if ((mn == FX_FAST || mn == FX_BORDER) && rwn <= FX_HALF_COL) {
                     const int vn = v + 1 == vend ? p.v0 : v + 1;  // after the last view: the first view of the workgroup's next chunk
                     nqcol = qcol ? 0 : FX_HALF_COL;
+#ifdef MVS_FX_EXPERIMENTS
                     if (!(p.debug & 1))
+#endif
                         stage_region_fx(p.quads + p.pad_slab * vn, p.pitch, __builtin_amdgcn_readfirstlane((int)(dnext.x & 0xffffu)),
                                         __builtin_amdgcn_readfirstlane((int)(dnext.x >> 16)), rwn, __builtin_amdgcn_readfirstlane((int)((dnext.y >> 8) & 0xffu)), nqcol, lds);
                     ahead = true;
