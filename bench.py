@@ -476,6 +476,8 @@ def main():
                          "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
                          "valu_bound_note": "VALU-issue bound, see DESIGN.md section 4 and profiles/",
                          "valu_utilisation": traffic["valu_utilisation"] if traffic else None,   # from the same PMC summary as `traffic`
+                         "valu_utilisation_note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel cycles): the counter charges every VALU instruction a "
+                                                  "4-cycle slot; with the measured 2- and 4-cycle instruction classes the VALU is busy ~60 % (DESIGN.md section 4)",
                          "bytes_per_launch": sweep_bytes, "bytes_formula": "P (V_loc + 8 D + 9), SURVEY.md 8(d)", "ms_per_launch": sweep_ms},
             "kernels": {"sweep_ms": sweep_ms, "argmin_ms": argmin_ms if separate else None,
                         "argmin_GBps": argmin_bytes / (argmin_ms * 1e-3) / 1e9 if argmin_ms > 0 else None,
