@@ -77,3 +77,34 @@ def test_build_time_variants_of_the_fixed_sampler_compile(tmp_path, define):
                           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), "-c", "-o", str(tmp_path / "v.o"), src],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
+
+
+def test_header_and_library_are_usable_from_plain_c(tmp_path):
+    """include/mvs.h is the drop-in boundary: it must compile as C99 (not only as C++), and a C program must link against
+    libmvs_hip.so and get an error code -- not an abort -- when there is no GPU"""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text("""
+#include <stdio.h>
+#include <string.h>
+#include <mvs.h>
+int main(void)
+{
+    mvs_ctx *ctx = mvs_create(0, 64, 48);
+    if (ctx) { mvs_destroy(ctx); puts("created"); return 0; }          /* a GPU box */
+    const char *msg = mvs_last_error(NULL);
+    printf("refused: %s\\n", msg ? msg : "(null)");
+    return (msg && strlen(msg) > 0 && mvs_sweep_row_granularity() == 16 && mvs_comm_size(NULL) < 0) ? 0 : 1;
+}
+""")
+    lib = os.path.join(ROOT, "mesh-reconstruction_amd", "lib")
+    exe = tmp_path / "abi"
+    out = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                          "-L" + lib, "-lmvs_hip", "-Wl,-rpath," + lib, "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and ("refused:" in run.stdout or "created" in run.stdout), run.stdout + run.stderr
