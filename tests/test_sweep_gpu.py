@@ -244,6 +244,29 @@ def test_c3_full_size_vs_oracle(oracle, sampler):
     _check(got, ref, D)
 
 
+def test_c3_full_size_general_cameras_vs_oracle(oracle, sampler):
+    """the same size with cameras that are NOT in the main camera's focal plane (every view rotated a little, two of them strongly and
+    partly out of frame): the reciprocal-per-sample path that the bundled tracks take, BORDER and SKIP regions in every chunk; depth,
+    cost and index of every pixel and every cell of the volume"""
+    import os
+    W, H, D, V = 1920, 1080, 128, 16
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V)
+    side_cams = side_cams.copy()
+    rng = np.random.default_rng(11)
+    for v in range(V):
+        a = 2.0 * np.pi * v / V
+        side_cams[v] = _rot_cam(W, H, [0.15 * np.cos(a), 0.15 * np.sin(a), float(rng.uniform(-0.05, 0.05))], float(rng.uniform(-0.03, 0.03)),
+                                float(rng.uniform(-0.03, 0.03)))
+    side_cams[5] = _rot_cam(W, H, [-0.9, 0.6, -0.3], -0.45, 0.3)
+    side_cams[11] = _rot_cam(W, H, [0.5, -0.2, 0.1], 0.25, -0.1)
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=min(256, os.cpu_count() or 8), sampler=sampler)
+    got = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN, sampler=sampler)
+    _check(got, ref, D)
+    shift = 24 if sampler == "fixed" else 16
+    counts = got[3] >> shift
+    assert counts.max() >= V - 2 and counts.mean() > V / 4 and (counts < counts.max()).mean() > 0.05, "views must overlap, and some cells must miss some"
+
+
 def test_c4_full_size_depth_vs_oracle(oracle, sampler):
     """BASELINE config c4 (3840x2160, 256 planes, 32 views) at full size on i.i.d. noise frames (SURVEY 8d's adversarial
     input): depth, cost and index of every pixel against the oracle; the 8.5 GB volume is not materialised"""
