@@ -1,6 +1,6 @@
 """Randomised hunt for disagreements between the fixed sampler's tiled kernel, its un-tiled kernel and the oracle: random sizes, plane
 counts, view counts (sequences mixing SKIP / FAST / BORDER / GENERIC / wide regions), forced plane splits.  Not part of the test
-suite proper (minutes of GPU time; it lives under tests/ because it uses the oracle): python tests/perf/stress_fx.py [first_seed] [count]"""
+suite proper (minutes of GPU time; it lives under tests/ because it uses the oracle): python tests/perf/stress_fx.py [first_seed] [count] [fixed|exact]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
@@ -14,6 +14,7 @@ import orc
 oracle = orc.load()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+sampler = sys.argv[3] if len(sys.argv) > 3 else "fixed"
 both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
 
 
@@ -36,9 +37,9 @@ for seed in range(first, first + count):
     main_img = rng.integers(0, 256, (H, W), dtype=np.uint8)
     sides = [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(V)]
     z = (float(rng.uniform(-1.0, -0.2)), float(rng.uniform(0.2, 1.0)))
-    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, z[0], z[1], want_volume=True, nthreads=8, sampler="fixed")
-    seen.append(float(((ref[3] >> 24) > 0).mean()))
-    with mvs_amd.Context(W, H, sampler="fixed") as ctx:
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, z[0], z[1], want_volume=True, nthreads=8, sampler=sampler)
+    seen.append(float(((ref[3] >> (24 if sampler == "fixed" else 16)) > 0).mean()))
+    with mvs_amd.Context(W, H, sampler=sampler) as ctx:
         ctx.sweep_set(main_cam, main_img, side_cams, sides, D, z[0], z[1])
         for flags in (both, both | (1 << 16), both | (8 << 8), both | mvs_amd.MVS_SWEEP_FORCE_GENERIC):
             ctx.sweep_run(0, V, flags)
@@ -47,5 +48,5 @@ for seed in range(first, first + count):
             if nv > max(1, vol.size * 1e-6) or ni > max(1, idx.size * 1e-5):
                 bad += 1
                 print("seed %d %dx%d D=%d V=%d flags=%#x: %d cells, %d indices differ" % (seed, W, H, D, V, flags, nv, ni), flush=True)
-print("stress: seeds %d..%d, %d disagreements; cells with a view in frame: mean %.2f, cases above 0.5: %d, all empty: %d" %
-      (first, first + count - 1, bad, float(np.mean(seen)), int(np.sum(np.array(seen) > 0.5)), int(np.sum(np.array(seen) == 0.0))))
+print("stress (%s sampler): seeds %d..%d, %d disagreements; cells with a view in frame: mean %.2f, cases above 0.5: %d, all empty: %d" %
+      (sampler, first, first + count - 1, bad, float(np.mean(seen)), int(np.sum(np.array(seen) > 0.5)), int(np.sum(np.array(seen) == 0.0))))
