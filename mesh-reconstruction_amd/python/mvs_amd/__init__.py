@@ -299,6 +299,20 @@ class Context:
         self._check(self.lib.mvs_sweep_set_planes(self.h, int(nplanes), float(z_lo), float(z_hi)))
         self.V, self.D = V, int(nplanes)
 
+    def sweep_set_views(self, side_cams, side_imgs):
+        """mvs_sweep_set_views alone (new side views for the main view already set)"""
+        W, H = self.W, self.H
+        V = len(side_imgs)
+        cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((0, 4, 4), np.float32)
+        frames = [_u8(s, (H, W)) for s in side_imgs]
+        arr = (_u8p * max(V, 1))(*[_ptr(f, _u8p) for f in frames])
+        self._check(self.lib.mvs_sweep_set_views(self.h, V, _ptr(cams, _fp), arr))
+        self.V = V
+
+    def sweep_set_planes(self, nplanes, z_lo=-1.0, z_hi=1.0):
+        self._check(self.lib.mvs_sweep_set_planes(self.h, int(nplanes), float(z_lo), float(z_hi)))
+        self.D = int(nplanes)
+
     def sweep_run(self, view_first=0, view_count=None, flags=MVS_SWEEP_VOLUME):
         if view_count is None:
             view_count = self.V - view_first

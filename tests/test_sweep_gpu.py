@@ -552,6 +552,37 @@ def test_many_views_use_batched_tables(oracle, sampler):
         _check(_gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, both | (splits << 16), sampler=sampler), ref, D)
 
 
+def test_one_context_through_sampler_and_view_changes(oracle):
+    """state carried by a context: the region plan, the quad images of both samplers (the exact sampler's is built on demand and must be
+    rebuilt after new frames), plane tables -- a sequence of sampler switches, new views, new planes and a new main view, each sweep
+    compared with the oracle"""
+    W, H = 320, 136
+    rng = np.random.default_rng(3)
+    main_cam, main_img, cams_a, imgs_a, _ = synth.make_views(W, H, 5, radius=0.25, freq_scale=0.3)
+    _, main_img_b, cams_b, imgs_b, _ = synth.make_views(W, H, 3, radius=0.4, freq_scale=0.5)
+    imgs_c = [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(5)]
+    both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    with mvs_amd.Context(W, H, sampler="fixed") as ctx:
+        def sweep_and_check(smp, main, cams, imgs, D, z=(-1.0, 1.0)):
+            ref = oracle.sweep(main_cam, main, cams, imgs, D, z[0], z[1], want_volume=True, nthreads=8, sampler=smp)
+            ctx.sweep_run(0, len(imgs), both)
+            _check(ctx.sweep_fetch(want_volume=True), ref, D)
+        ctx.sweep_set(main_cam, main_img, cams_a, imgs_a, 24)
+        sweep_and_check("fixed", main_img, cams_a, imgs_a, 24)
+        ctx.set_sampler("exact")                                   # same inputs: new plan, f16 quad image built now
+        sweep_and_check("exact", main_img, cams_a, imgs_a, 24)
+        ctx.sweep_set_views(cams_a, imgs_c)                        # new frames under the exact sampler: its quad image is stale
+        sweep_and_check("exact", main_img, cams_a, imgs_c, 24)
+        ctx.set_sampler("fixed")
+        sweep_and_check("fixed", main_img, cams_a, imgs_c, 24)
+        ctx.sweep_set_planes(40, -0.8, 0.9)                        # new planes: new plan, same images
+        sweep_and_check("fixed", main_img, cams_a, imgs_c, 40, (-0.8, 0.9))
+        ctx.sweep_set(main_cam, main_img_b, cams_b, imgs_b, 40, -0.8, 0.9)   # fewer views, another main frame
+        sweep_and_check("fixed", main_img_b, cams_b, imgs_b, 40, (-0.8, 0.9))
+        ctx.set_sampler("exact")
+        sweep_and_check("exact", main_img_b, cams_b, imgs_b, 40, (-0.8, 0.9))
+
+
 def test_255_views_at_maximal_cost(oracle, sampler):
     """the fixed sampler's cell limit: 255 views, a black main frame against nearly white side frames -- sums of 1.6e7 (24 bits) and
     cross products above 2^31 in the depth selection (they are compared unsigned: HIP's __umul24 returns int)"""
