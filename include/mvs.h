@@ -148,6 +148,7 @@ int mvs_sweep_set_planes(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi);
 #define MVS_SWEEP_VOLUME 1u       /* materialise the packed cost volume in HBM */
 #define MVS_SWEEP_FUSED_ARGMIN 2u /* select depth inside the sweep kernel (no volume read-back pass) */
 #define MVS_SWEEP_FORCE_GENERIC 4u /* use the un-tiled global-gather kernel (test / fallback path) */
+#define MVS_SWEEP_NO_RECT 8u       /* fixed sampler: never take the rectified-view kernel (sweep_fx_rect); results are bit-identical either way */
 /* accumulate views [view_first, view_first + view_count) into the packed volume / fused outputs (async) */
 int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags);
 /* the same for planes [plane_first, plane_first + plane_count) only (MVS_SWEEP_VOLUME; boundaries on multiples of
@@ -165,7 +166,9 @@ int mvs_sweep_row_granularity_of(const mvs_ctx *ctx);   /* what the context's cu
 /* diagnostic: thread shape the region planner chose for the current (views, planes): 0 = no plan yet,
  * 1 = exact sampler, 2 pixels x 32 planes per thread (64x8-pixel tiles), 2 = exact sampler, 4 pixels x 16 planes (64x16 tiles:
  * bit-identical to 1; the choice follows how many warped 32-plane footprints fit the LDS staging buffer), 3 = fixed sampler
- * (2 pixels x 32 planes, 64x8-pixel tiles). */
+ * (2 pixels x 16 planes, 64x8-pixel tiles), 4 = fixed sampler, every side view rectified against the main view (pure translation
+ * in its focal plane, equal intrinsics): the kernel sweep_fx_rect (8 pixels x 4 planes per thread, wave-uniform sampling
+ * positions; bit-identical to 3, which MVS_SWEEP_NO_RECT selects). */
 int mvs_sweep_plan_shape(const mvs_ctx *ctx);
 /* per-pixel depth selection over the packed volume (async); valid after MVS_SWEEP_VOLUME runs or
  * after the caller has reduced the volume across ranks in place */

@@ -58,7 +58,11 @@ struct mvs_ctx {
     mvs::DevBuf fx_lut;              // fixed sampler: 32 x 32 table of packed 8-bit bilinear weights
     int plan_shape = 2;              // what the plan was made for: 1 = exact sampler, 2 px x 32 planes; 2 = exact, 4 px x 16 planes; 3 = fixed sampler
     bool plan_forced = false;        // plan made with the 4 x 16 shape forced (timing experiments)
-    mvs::DevBuf plan_stats;          // planner counters (oversize regions, regions not skipped)
+    mvs::DevBuf plan_stats;          // planner counters (oversize regions, regions not skipped, widest / tallest staged region)
+    // rectified fast path of the fixed sampler (sweep_rect.hip): per (tile column | tile row, view, plane) texel + phase + certificates
+    mvs::DevBuf rect_tab;
+    bool rect_ok = false;            // the current plan can be served by sweep_fx_rect
+    int rect_rs = 0, rect_ni = 0, rect_instrs = 0, rect_slot_dw = 0, rect_dpad = 0;
     mvs::DevBuf probe_buf;           // mvs_depth_probe: pixel coordinates in, depths out
     mvs::DevBuf raster_bins;         // face binning of large meshes: per-bin counts / offsets / lists, shared list of large faces
     mvs::DevBuf filter_sort;         // mvs_filter_points, dense clouds: keys and a second copy of the upper lists for the global sorts
@@ -134,6 +138,8 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 int sweep_set_main_impl(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, bool sync);
 int sweep_set_views_impl(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames, bool sync, bool defer_frames = false);
 int sweep_upload_frames_impl(mvs_ctx *ctx, const uint8_t *const *side_frames);
+int sweep_rect_plan(mvs_ctx *ctx);   // sweep_rect.hip: tables + eligibility of the rectified kernel for the current fixed-sampler plan
+struct SweepParams;
 int ensure_quads16(mvs_ctx *ctx);  // exact sampler's f16 quad image of the current side views  // the deferred half of sweep_set_views_impl
 int sweep_set_planes_impl(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi, bool sync);
 

@@ -678,6 +678,7 @@ __global__ void rcp_check_kernel(uint32_t exp_bits, unsigned long long *out)
 // sweep_fx.hip: the fixed-point sampler (contract v2)
 int sweep_fx_plan(mvs_ctx *ctx);
 int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool generic, unsigned flags);
+int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsigned flags);
 int warp_by_depth_fx_launch(mvs_ctx *ctx, const float *depth_dev, const float *q_dev, const uint8_t *pad_dev, int pitch, uint8_t *out2_dev);
 
 // defined in context.hip
@@ -765,7 +766,7 @@ int mvs_sweep_set_sampler(mvs_ctx *ctx, int sampler)
 
 int mvs_sweep_sampler(const mvs_ctx *ctx) { return ctx ? ctx->sampler : MVS_EINVAL; }
 
-int mvs_sweep_plan_shape(const mvs_ctx *ctx) { return (ctx && ctx->plan_valid) ? ctx->plan_shape : 0; }
+int mvs_sweep_plan_shape(const mvs_ctx *ctx) { return (ctx && ctx->plan_valid) ? ((ctx->plan_shape == 3 && ctx->rect_ok) ? 4 : ctx->plan_shape) : 0; }
 
 int mvs_sweep_run_planes(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, unsigned flags)
 {
@@ -825,7 +826,8 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
         p.plane_begin = plane_first;
         p.plane_end = min(ctx->D, plane_first + plane_count);
         ProfileScope ps(ctx, MVS_K_SWEEP);
-        const int nsplit = sweep_fx_launch(ctx, p, vol, fused, generic, flags);
+        const bool rect = ctx->rect_ok && !generic && ctx->V > 0 && !(flags & MVS_SWEEP_NO_RECT);
+        const int nsplit = rect ? sweep_rect_launch(ctx, p, vol, fused, flags) : sweep_fx_launch(ctx, p, vol, fused, generic, flags);
         if (nsplit < 0) return nsplit;
         if (p.part) {
             const size_t first = (size_t)p.row_begin * ctx->W;

@@ -186,10 +186,11 @@ __global__ __launch_bounds__(256) void plan_regions_fx(SweepParams p, uint2 *__r
         if (rw > FX_MAX_RW || rw <= 0 || rh <= 0 || rh > FX_ROWS) {
             mode = FX_GENERIC;
             atomicAdd(p.plan_stats, 1);
-        } else if (xmin > 0.5f + m && xmax < p.Wp - m && ymin > 0.5f + m && ymax < p.Hp - m)
-            mode = FX_FAST;
-        else
-            mode = FX_BORDER;
+        } else {
+            mode = (xmin > 0.5f + m && xmax < p.Wp - m && ymin > 0.5f + m && ymax < p.Hp - m) ? FX_FAST : FX_BORDER;
+            atomicMax(p.plan_stats + 2, rw);  // largest staged region: the rectified kernel sizes its LDS slots by it (sweep_rect.hip)
+            atomicMax(p.plan_stats + 3, rh);
+        }
     }
     uint2 d;
     d.x = (unsigned)x0 | ((unsigned)y0 << 16);
@@ -779,7 +780,7 @@ int sweep_fx_plan(mvs_ctx *ctx)
     if ((rc = ensure(ctx, ctx->plan, n * sizeof(uint2)))) return rc;
     q.plan = (const uint2 *)ctx->plan.ptr;
     q.plan_stats = (int *)ctx->plan_stats.ptr;
-    MVS_HIP(ctx, hipMemsetAsync(q.plan_stats, 0, 2 * sizeof(int), ctx->stream));
+    MVS_HIP(ctx, hipMemsetAsync(q.plan_stats, 0, 4 * sizeof(int), ctx->stream));
     plan_regions_fx<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(q, (uint2 *)ctx->plan.ptr);
     MVS_HIP(ctx, hipGetLastError());
     if (const char *path = getenv("MVS_PLAN_DUMP")) {  // diagnostic (tools/plan_hist.py): header {tiles_x, tiles_y, nchunks, V}, then the descriptors
@@ -793,7 +794,7 @@ int sweep_fx_plan(mvs_ctx *ctx)
             fclose(f);
         }
     }
-    return MVS_OK;
+    return sweep_rect_plan(ctx);  // rectified views: tables for sweep_fx_rect (sweep_rect.hip)
 }
 
 int warp_by_depth_fx_launch(mvs_ctx *ctx, const float *depth_dev, const float *q_dev, const uint8_t *pad_dev, int pitch, uint8_t *out2_dev)

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(PKG_ROOT, "lib", "libmvs_hip.so")
 MVS_SWEEP_VOLUME = 1
 MVS_SWEEP_FUSED_ARGMIN = 2
 MVS_SWEEP_FORCE_GENERIC = 4
+MVS_SWEEP_NO_RECT = 8
 MVS_SAMPLER_FIXED, MVS_SAMPLER_EXACT_F32 = 0, 1
 SAMPLERS = {"fixed": MVS_SAMPLER_FIXED, "exact": MVS_SAMPLER_EXACT_F32}
 MVS_K_SWEEP, MVS_K_ARGMIN, MVS_K_PLAN, MVS_K_RASTER, MVS_K_PROJECT, MVS_K_FLOW = 0, 1, 2, 3, 4, 5
