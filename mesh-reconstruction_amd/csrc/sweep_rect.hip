@@ -31,8 +31,10 @@
 // region ahead.  LDS reads in the sample loop are inline asm (the compiler would order every ds_read behind ALL pending LDS-DMA).
 #include "sweep_shared.hpp"
 
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace mvs {
@@ -56,6 +58,8 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) u32x2 *cu2;
 typedef const __attribute__((address_space(4))) u32x4 *cu4;
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) u32x8 *cu8;
 typedef const __attribute__((address_space(4))) float *cf32;
 template <typename T, typename U>
 __device__ __forceinline__ T as_const(const U *p) { return (T)(uintptr_t)p; }
@@ -94,7 +98,7 @@ __device__ __forceinline__ void wait_vmcnt(int n)
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------
-// planner: X / Y / W tables
+// planner: per-axis tables
 // ------------------------------------------------------------------------------------------------------
 // A view is eligible when Tx does not depend on the row, Ty not on the column and w on nothing (and w > 0).
 template <typename Q>
@@ -120,7 +124,18 @@ __device__ __forceinline__ float rect_ty(Q q, float r256, float z, int r, float 
     return __builtin_fmaf(__builtin_fmaf(z, q[6], ay), r256, RX_MAGIC + 4.0f);
 }
 
-// One thread per (tile column or tile row, view, plane), evaluating every pixel of the tile.  Entry:
+// Table set of one plan (device pointers into ctx->rect_tab).  T = tiles_x resp. tiles_y, NC = plane chunks, dpad = 16 NC.
+struct RectTables {
+    uint32_t *xt, *yt;    // [T][V][dpad]   full entries (below)
+    uint32_t *xmm, *ymm;  // [T][V][dpad]   lowest | highest << 16 integer texel over the tile's in-frame pixels, 0xffffffff if none
+    uint32_t *wt;         // [V][dpad]      weight word of the view's nominal phase pair at that plane
+    uint32_t *xw;         // [tiles_x][V][NC][4 wavefronts][8]  {xb, W0, W1, W2, W3, xdesc, 0, 0}
+    uint32_t *yr;         // [tiles_y][V][NC][4 wavefronts][2]  {yb, ydesc}
+    int *stats;           // [0] widest region (quads), [1] tallest region (rows), [2] planes that are not FULL (diagnostic)
+    int dpad;
+};
+
+// Pass A.  One thread per (tile column or tile row, view, plane), evaluating every pixel of the tile.  Full entry:
 //   bits  0-19  t0 + RX_BIAS, t0 = (u >> 3) - 32 i of the in-frame pixels (i = index in the tile, u = 1/256-texel coordinate):
 //               phase in the low 5 bits, integer texel of the tile's pixel 0 (extrapolated, possibly left of the image) above
 //   bits 20-26  n = pixels of the tile that are out of frame (all of the tile's pixels: 64 resp. 8)
@@ -128,9 +143,9 @@ __device__ __forceinline__ float rect_ty(Q q, float r256, float z, int r, float 
 //   bit  30     certificate: the out-of-frame pixels are exactly those n, every other pixel has (u >> 3) - 32 i == t0, and
 //               the phase is the view's nominal one for this plane (the phase at the image centre: the W table's)
 // Pixels past the image edge (ragged last tile) count as matching.
-__global__ __launch_bounds__(256) void plan_rect_axis(SweepParams p, int dpad, uint32_t *__restrict__ xt, uint32_t *__restrict__ yt, uint32_t *__restrict__ wt,
-                                                      const uint32_t *__restrict__ lut)
+__global__ __launch_bounds__(256) void plan_rect_axis(SweepParams p, RectTables rt, const uint32_t *__restrict__ lut)
 {
+    const int dpad = rt.dpad;
     const int nx = p.tiles_x * p.V * dpad, ny = p.tiles_y * p.V * dpad, nw = p.V * dpad;
     int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= nx + ny + nw) return;
@@ -146,7 +161,7 @@ __global__ __launch_bounds__(256) void plan_rect_axis(SweepParams p, int dpad, u
     const uint32_t nomx = (__builtin_bit_cast(uint32_t, rect_tx(q, r256, z, p.W / 2, p.invW)) >> 3) & 31u;
     const uint32_t nomy = (__builtin_bit_cast(uint32_t, rect_ty(q, r256, z, p.H / 2, p.invH)) >> 3) & 31u;
     if (which == 2) {
-        wt[tid] = lut[nomy * 32u + nomx];
+        rt.wt[tid] = lut[nomy * 32u + nomx];
         return;
     }
     const int size = which == 0 ? TILE_W : RX_TILE_H;
@@ -154,16 +169,20 @@ __global__ __launch_bounds__(256) void plan_rect_axis(SweepParams p, int dpad, u
     const int count = min(first + size, which == 0 ? p.W : p.H) - first;  // pixels of the tile inside the image
     int nin = 0, first_in = -1, last_in = -1;
     int t0 = 0;
+    uint32_t lo = 0xffffu, hi = 0u;
     bool uniform = elig;
     for (int i = 0; i < count; i++) {
         const float T = which == 0 ? rect_tx(q, r256, z, first + i, p.invW) : rect_ty(q, r256, z, first + i, p.invH);
         if (!(T > RX_MAGIC + 132.0f && T < (which == 0 ? hix : hiy))) continue;
-        const int ti = (int)((__builtin_bit_cast(uint32_t, T) & 0x3fffffu) >> 3) - 32 * i;
+        const uint32_t u = __builtin_bit_cast(uint32_t, T) & 0x3fffffu;
+        const int ti = (int)(u >> 3) - 32 * i;
         if (nin == 0) {
             t0 = ti;
             first_in = i;
         }
         uniform = uniform && ti == t0;
+        lo = min(lo, u >> 8);
+        hi = max(hi, u >> 8);
         last_in = i;
         nin++;
     }
@@ -181,102 +200,183 @@ __global__ __launch_bounds__(256) void plan_rect_axis(SweepParams p, int dpad, u
         uniform = uniform && (uint32_t)(t0 & 31) == (which == 0 ? nomx : nomy) && t0 + RX_BIAS >= 0 && t0 + RX_BIAS < (1 << 20);
     }
     // (no pixel in frame: n = the whole tile and the certificate as computed so far -- nothing to sample)
-    (which == 0 ? xt : yt)[tid] = ((uint32_t)(t0 + RX_BIAS) & 0xfffffu) | ((uint32_t)nout << 20) | ((uint32_t)side << 27) | (uniform ? RX_UNIFORM : 0u);
+    (which == 0 ? rt.xt : rt.yt)[tid] = ((uint32_t)(t0 + RX_BIAS) & 0xfffffu) | ((uint32_t)nout << 20) | ((uint32_t)side << 27) | (uniform ? RX_UNIFORM : 0u);
+    (which == 0 ? rt.xmm : rt.ymm)[tid] = nin > 0 ? (lo | (hi << 16)) : 0xffffffffu;
+}
+
+// Pass B.  One thread per (tile column or tile row, view, chunk): the box of the view's quad image the chunk's 16 planes touch
+// (x0 a multiple of 4 quads: the copies move 16-byte units), and for each of the four wavefronts one record with a byte per plane:
+// the plane's texel offset inside the box (FULL planes: certificate, nothing out of frame), or 0x80 = look at the full entry.
+//   xdesc = x0 | width << 16 | any << 31        ydesc = y0 | rows << 16 | any << 31        (any: some pixel of some plane in frame)
+__global__ __launch_bounds__(256) void plan_rect_pack(SweepParams p, RectTables rt)
+{
+    const int NC = p.nchunks, dpad = rt.dpad;
+    const int nx = p.tiles_x * p.V * NC, ny = p.tiles_y * p.V * NC;
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= nx + ny) return;
+    const int which = tid < nx ? 0 : 1;
+    if (which == 1) tid -= nx;
+    const int chunk = tid % NC, v = (tid / NC) % p.V, t = tid / (NC * p.V);
+    const uint32_t *ent = (which == 0 ? rt.xt : rt.yt) + ((size_t)t * p.V + v) * dpad + chunk * RX_PC;
+    const uint32_t *mm = (which == 0 ? rt.xmm : rt.ymm) + ((size_t)t * p.V + v) * dpad + chunk * RX_PC;
+    uint32_t lo = 0xffffu, hi = 0u;
+    bool any = false;
+    for (int k = 0; k < RX_PC; k++) {
+        const uint32_t m = mm[k];
+        if (m == 0xffffffffu) continue;
+        any = true;
+        lo = min(lo, m & 0xffffu);
+        hi = max(hi, m >> 16);
+    }
+    const uint32_t org = any ? (which == 0 ? (lo & ~3u) : lo) : 0u;
+    const uint32_t ext = any ? hi + 1u - org : 0u;
+    if (any) atomicMax(rt.stats + which, (int)ext);
+    const uint32_t desc = org | (min(ext, 255u) << 16) | (any ? 1u << 31 : 0u);
+    for (int w = 0; w < 4; w++) {
+        uint32_t bytes = 0u;
+        for (int k = 0; k < RX_KW; k++) {
+            const uint32_t e = ent[w * RX_KW + k];
+            const int tex = ((int)(e & 0xfffffu) - RX_BIAS) >> 5;
+            const bool full = (e & RX_UNIFORM) && ((e >> 20) & 127u) == 0u && any && tex >= (int)org && tex - (int)org < (which == 0 ? 128 : 32);
+            bytes |= (full ? (uint32_t)(tex - (int)org) : 0x80u) << (8 * k);
+            if (!full) atomicAdd(rt.stats + 2, 1);
+        }
+        if (which == 0) {
+            uint32_t *rec = rt.xw + ((((size_t)t * p.V + v) * NC + chunk) * 4 + w) * 8;
+            const uint32_t *wv = rt.wt + (size_t)v * dpad + chunk * RX_PC + w * RX_KW;
+            rec[0] = bytes;
+            rec[1] = wv[0];
+            rec[2] = wv[1];
+            rec[3] = wv[2];
+            rec[4] = wv[3];
+            rec[5] = desc;
+            rec[6] = 0u;
+            rec[7] = 0u;
+        } else {
+            uint32_t *rec = rt.yr + ((((size_t)t * p.V + v) * NC + chunk) * 4 + w) * 2;
+            rec[0] = bytes;
+            rec[1] = desc;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // sweep kernel
 // ------------------------------------------------------------------------------------------------------
-struct RectParams {
-    const uint32_t *__restrict__ xt;   // [tiles_x][V][dpad]
-    const uint32_t *__restrict__ yt;   // [tiles_y][V][dpad]
-    const uint32_t *__restrict__ wt;   // [V][dpad]
-    const uint32_t *__restrict__ lut;  // 32 x 32 weight table (slow path)
-    int dpad;
-    int slot_dw;   // dwords per LDS slot = 256 x instrs (one copy instruction fills 256 dwords); after the S slots: 256 dwords nobody reads
-    int nslots;    // S
-    int instrs;    // copy instructions per region (all four wavefronts together)
-    int ni;        // copy instructions per wavefront and region = ceil(instrs / 4), the ones past `instrs` going to the unread dwords
+// What the sweep kernel reads on every region comes in as kernel arguments (SGPRs); what only its rare paths, its prologue and its
+// last lines need sits behind one pointer (RectCold, in device memory) and is fetched where it is used: the view loop is short of
+// SGPRs, and a spilled SGPR costs vector instructions (v_readlane / v_writelane) in the loop.
+struct RectCold {
+    const uint8_t *main_img;
+    const uint32_t *xt, *yt, *lut;
+    const float *Q, *z;
+    float *depth, *cost;
+    int *index;
+    float invW, invH;
+    int dpad, pad_;
 };
 
-// Everything a plane's fast paths need, decoded from one X and one Y entry (wave-uniform)
-enum PlaneKind : int { PK_NONE = 0, PK_FULL = 1, PK_MASKED = 2, PK_SEMI = 3 };
+struct RectArgs {
+    const uint32_t *__restrict__ quads;  // quad images of the side views, pad_slab dwords each
+    const uint32_t *__restrict__ xw;
+    const uint32_t *__restrict__ yr;
+    uint32_t *__restrict__ volume;
+    const RectCold *__restrict__ cold;
+    uint2 *__restrict__ part;            // plane-split launches: partial bests [gridDim.y][P]
+    size_t pad_slab;
+    int pitch, W, H, D, V, v0, vcount, nchunks, chunk0, chunk1, cps, ty0, tyn, tiles_x;
+    int slot_dw;   // dwords per LDS slot = 256 x copy instructions per region (one instruction fills 256 dwords); two slots
+};
+
+template <typename T>
+__device__ __forceinline__ T cold_get(uintptr_t c, size_t off)
+{
+    return *(const __attribute__((address_space(4))) T *)(c + off);
+}
+#define RX_COLD(c, T, field) cold_get<T>((uintptr_t)(c), offsetof(RectCold, field))
+
+// raw buffer resource over `bytes` bytes at p (gfx950: dword 3 = 0x00020000, 32-bit data format): buffer instructions take a
+// wave-uniform resource + a 32-bit per-lane offset + a wave-uniform offset, so no access of the view loop needs a 64-bit per-lane
+// address (through plain pointers the compiler forms one for every load, store and LDS copy: 2 VGPRs and 1-2 VALU instructions each).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, 0x00020000);
+}
 
 template <int RS, bool WRITE_VOLUME, bool FUSED>
-__global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(SweepParams p, RectParams rp)
+__global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs a)
 {
     constexpr int UNITS = RS / 4;  // 16-byte units per region row
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
 
-    const int band_tile = grouped_tile(blockIdx.x, p.tiles_x, p.tyn);
+    const int band_tile = grouped_tile(blockIdx.x, a.tiles_x, a.tyn);
     if (band_tile < 0) return;
-    const int tx = band_tile % p.tiles_x, ty = band_tile / p.tiles_x + p.ty0;
-    const int tile = ty * p.tiles_x + tx;
+    const int tx = band_tile % a.tiles_x, ty = band_tile / a.tiles_x + a.ty0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int col = tx * TILE_W + lane;
     const int row0 = ty * RX_TILE_H;
-    const bool col_ok = col < p.W;
-    const size_t P = (size_t)p.W * p.H;
+    const bool col_ok = col < a.W;
+    const int NC = a.nchunks;
 
     uint32_t Im255[8];
+    {
+        const uint8_t *img = RX_COLD(a.cold, const uint8_t *, main_img);
 #pragma unroll
-    for (int j = 0; j < 8; j++) Im255[j] = (col_ok && row0 + j < p.H) ? 255u * (uint32_t)p.main_img[(size_t)(row0 + j) * p.W + col] : 0u;
+        for (int j = 0; j < 8; j++) Im255[j] = (col_ok && row0 + j < a.H) ? 255u * (uint32_t)img[(size_t)(row0 + j) * a.W + col] : 0u;
+    }
 
-    // per-lane source offsets (dwords) of this wavefront's copy instructions: instruction i = wave + 4 t fills LDS dwords
+    // per-lane source offsets (bytes) of this wavefront's copy instructions: instruction i = wave + 4 t fills LDS dwords
     // [256 i, 256 i + 256) of the slot = 16-byte units g = 64 i + lane of the dense [row][RS] region image
     uint32_t srcoff[RX_MAX_NI];
 #pragma unroll
     for (int t = 0; t < RX_MAX_NI; t++) {
         const int g = (wave + 4 * t) * 64 + lane;
-        srcoff[t] = (uint32_t)((g / UNITS) * p.pitch + (g % UNITS) * 4);
+        srcoff[t] = 4u * (uint32_t)((g / UNITS) * a.pitch + (g % UNITS) * 4);
     }
 
-    const int chunk_first = p.chunk0 + (int)blockIdx.y * p.cps;
-    const int chunk_last = min(p.chunk1, chunk_first + p.cps);
-    const int nreg = (chunk_last - chunk_first) * p.vcount;
-    const int S = rp.nslots, L = S - 1;
-    const int ni = rp.ni;
+    const int chunk_first = a.chunk0 + (int)blockIdx.y * a.cps;
+    const int chunk_last = min(a.chunk1, chunk_first + a.cps);
+    const int vend = a.v0 + a.vcount;
+    const int nreg = (chunk_last - chunk_first) * a.vcount;
 
-    // request region (chunk, v) into `slot`: always exactly `ni` copy instructions per wavefront, so that a counted vmcnt wait
-    // can name a region; an instruction with no unit of the region to copy (short regions, SKIP mode) copies one
-    // harmless unit from the head of the view's image with lane 0 (into slot space the region does not use, or past the slots)
-    auto issue_copy = [&](int chunk, int v, int slot) {
-        const u32x2 d = as_const<cu2>(p.plan)[((size_t)tile * p.nchunks + chunk) * p.V + v];
-        const unsigned mode = (d.y >> 16) & 7u;
-        const bool staged = mode == RX_FAST || mode == RX_BORDER;
-        const int x0 = min((int)(d.x & 0xffffu), p.pitch - RS), y0 = (int)(d.x >> 16), rh = (int)((d.y >> 8) & 0xffu);
-        const int n = staged ? rh * UNITS : 0;
-        const uint32_t *src = p.quads + p.pad_slab * v + (staged ? (uint32_t)(y0 * p.pitch + x0) : 0u);
+    // this wavefront's records of region (chunk, v), e = v NC + chunk: 8 dwords at xw_wg + 128 e bytes, 2 dwords at yr_wg + 32 e bytes;
+    // both tables live in one allocation (a.xw < a.yr): one resource, two wave-uniform offsets
+    const __amdgpu_buffer_rsrc_t rtab = make_rsrc(a.xw, 0xffffffffu);
+    const uint32_t xw_wg = (uint32_t)(((size_t)tx * a.V * NC * 4 + wave) * 32);
+    const uint32_t yr_wg = (uint32_t)((size_t)((const char *)a.yr - (const char *)a.xw) + ((size_t)ty * a.V * NC * 4 + wave) * 8);
+    const __amdgpu_buffer_rsrc_t rquads = make_rsrc(a.quads, 0xffffffffu);
+
+    // request the region with descriptors (xd, yd) of view v into `slot`: rows of RS quads, 64 16-byte units per instruction
+    auto issue_copy = [&](uint32_t xd, uint32_t yd, int v, int slot) {
+        const int n = ((xd & yd) >> 31) ? (int)((yd >> 16) & 0xffu) * UNITS : 0;
+        const uint32_t src = 4u * ((uint32_t)a.pad_slab * (uint32_t)v + (uint32_t)((int)(yd & 0xffffu) * a.pitch + (int)(xd & 0xffffu)));
+        uint32_t *dst = smem + slot * a.slot_dw + wave * 256;
 #pragma unroll
         for (int t = 0; t < RX_MAX_NI; t++) {
-            if (t < ni) {
-                const int i = wave + 4 * t;
-                const int left = n - i * 64;  // units of the region this instruction still has to copy (wave-uniform)
-                const bool act = lane < left;
-                const bool dummy = left <= 0 && lane == 0;
-                uint32_t *dst = smem + (i < rp.instrs ? slot * rp.slot_dw + i * 256 : S * rp.slot_dw);
-                if (act || dummy)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (act ? srcoff[t] : 0u)),
-                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-            }
+            const int left = n - (wave + 4 * t) * 64;  // units of the region this instruction still has to copy (wave-uniform)
+            if (left > 0 && lane < left)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rquads, (__attribute__((address_space(3))) void *)(dst + t * 1024), 16, srcoff[t], src, 0, 0);
         }
     };
 
-    // the table entries and the descriptor of region (chunk, v) for this wavefront's four planes
-    struct RegionInfo {
-        u32x4 x, y, w;
-        u32x2 d;
-    };
-    auto load_info = [&](int chunk, int v) {
-        RegionInfo r;
-        const int dk = chunk * RX_PC + wave * RX_KW;
-        r.x = *as_const<cu4>(rp.xt + ((size_t)tx * p.V + v) * rp.dpad + dk);
-        r.y = *as_const<cu4>(rp.yt + ((size_t)ty * p.V + v) * rp.dpad + dk);
-        r.w = *as_const<cu4>(rp.wt + (size_t)v * rp.dpad + dk);
-        r.d = as_const<cu2>(p.plan)[((size_t)tile * p.nchunks + chunk) * p.V + v];
-        return r;
+    // The records of the coming regions travel through VECTOR registers (lane l holds dword l of the record; one v_readlane each when
+    // the region's turn comes): as scalar loads they would have to stay in SGPRs across a whole region's sampling, and the compiler
+    // spills them right after the load (a wait for the load, then v_writelane / v_readlane pairs) -- measured: 0.65 ms of loop skeleton.
+    const uint32_t lane8 = 4u * (uint32_t)(lane & 7);
+    auto load_x = [&](int e) { return __builtin_amdgcn_raw_buffer_load_b32(rtab, lane8, xw_wg + 128u * (uint32_t)e, 0); };  // xb, W0, W1, W2, W3, xdesc
+    auto load_y = [&](int e) { return __builtin_amdgcn_raw_buffer_load_b32(rtab, lane8, yr_wg + 32u * (uint32_t)e, 0); };   // yb, ydesc
+    auto rdl = [](uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); };
+    // region order of this workgroup: chunks outer, views inner; e = v NC + chunk indexes the record tables
+    auto advance = [&](int &chunk, int &v, int &e) {
+        v++;
+        e += NC;
+        if (v == vend) {
+            v = a.v0;
+            chunk++;
+            e = a.v0 * NC + chunk;
+        }
     };
 
     uint32_t acc[8][RX_KW];
@@ -291,112 +391,104 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(SweepPar
     }
     uint32_t cnt[RX_KW] = {0u, 0u, 0u, 0u};  // views counted once for every cell of a plane (wave-uniform)
 
-    // prologue: the first L regions
-    {
-        int c = chunk_first, v = p.v0;
-        for (int i = 0; i < L && i < nreg; i++) {
-            issue_copy(c, v, i);
-            if (++v == p.v0 + p.vcount) {
-                v = p.v0;
-                c++;
-            }
-        }
-    }
-    int ca = chunk_first, va = p.v0;  // region r + L (the next one to request)
-    for (int i = 0; i < L; i++)
-        if (++va == p.v0 + p.vcount) {
-            va = p.v0;
-            ca++;
-        }
-    int slot_a = L % S, slot_c = 0;
-    int chunk = chunk_first, v = p.v0;
-    RegionInfo cur = nreg > 0 ? load_info(chunk, v) : RegionInfo{};
+    const int e_last = (vend - 1) * NC + chunk_last - 1;  // the workgroup's last region: prefetches past it re-read it
+    int chunk = chunk_first, v = a.v0, e = a.v0 * NC + chunk_first;
+    int cn = chunk, vn = v, en = e;  // the region after the current one
+    advance(cn, vn, en);
+    // prologue: the records of regions 0 and 1, the copy of region 0
+    uint32_t x0r = load_x(min(e, e_last)), y0r = load_y(min(e, e_last));    // region r
+    uint32_t x1r = load_x(min(en, e_last)), y1r = load_y(min(en, e_last));  // region r + 1
+    if (nreg > 0) issue_copy(rdl(x0r, 5), rdl(y0r, 1), v, 0);
+    int slot_c = 0;
     const uint32_t lane4 = lds_base + 4u * (uint32_t)lane;
-    const uint32_t lo_bits = __builtin_bit_cast(uint32_t, RX_MAGIC + 132.0f);
-    const uint32_t hix_bits = lo_bits + 256u * (uint32_t)p.W, hiy_bits = lo_bits + 256u * (uint32_t)p.H;  // floats in [2^23, 2^24): ulp 1
 
     for (int r = 0; r < nreg; r++) {
-        // next region's table entries: in flight during this region's sampling
-        int cn = chunk, vn = v + 1;
-        if (vn == p.v0 + p.vcount) {
-            vn = p.v0;
-            cn++;
-        }
-        RegionInfo nxt = cur;
-        if (r + 1 < nreg) nxt = load_info(cn, vn);
-
-        // this wavefront's copies of region r have landed (the copies of regions r + 1 .. r + L - 1 stay in flight) ...
-        wait_vmcnt(r + L - 1 < nreg ? (L - 1) * ni : 0);
+        // every copy and every record this wavefront asked for has landed ...
+        wait_vm<0>();
         // ... and so have every other wavefront's; nobody reads region r - 1 any more
         __builtin_amdgcn_s_barrier();
-        if (r + L < nreg) {
-            issue_copy(ca, va, slot_a);
-            if (++va == p.v0 + p.vcount) {
-                va = p.v0;
-                ca++;
-            }
-            if (++slot_a == S) slot_a = 0;
-        }
+        // request region r + 1 into the other slot and the records of region r + 2: in flight during this region's sampling
+        if (r + 1 < nreg) issue_copy(rdl(x1r, 5), rdl(y1r, 1), vn, slot_c ^ 1);
+        int c2 = cn, v2 = vn, e2 = en;
+        advance(c2, v2, e2);
+        const uint32_t x2r = load_x(min(e2, e_last)), y2r = load_y(min(e2, e_last));
+        const uint32_t xb = rdl(x0r, 0), yb = rdl(y0r, 0);
+        const uint32_t we[RX_KW] = {rdl(x0r, 1), rdl(x0r, 2), rdl(x0r, 3), rdl(x0r, 4)};
 
         // ---- sample region r ----
-        const unsigned mode = (cur.d.y >> 16) & 7u;
-        if (mode == RX_FAST || mode == RX_BORDER) {
-            const int x0 = min((int)(cur.d.x & 0xffffu), p.pitch - RS), y0 = (int)(cur.d.x >> 16);
-            const uint32_t xe[RX_KW] = {cur.x.x, cur.x.y, cur.x.z, cur.x.w}, ye[RX_KW] = {cur.y.x, cur.y.y, cur.y.z, cur.y.w};
-            const uint32_t we[RX_KW] = {cur.w.x, cur.w.y, cur.w.z, cur.w.w};
-            const uint32_t slot_byte = (uint32_t)(slot_c * rp.slot_dw) * 4u;
+        const uint32_t special = (xb | yb) & 0x80808080u;
+        {
+            const uint32_t slot_byte = (uint32_t)(slot_c * a.slot_dw) * 4u;
             uint32_t qd[2][8];
-            int kind[RX_KW];
-#pragma unroll
-            for (int k = 0; k < RX_KW; k++) {
-                const int nx = (int)((xe[k] >> 20) & 127u), ny = (int)((ye[k] >> 20) & 127u);
-                kind[k] = !((xe[k] & ye[k]) & RX_UNIFORM) ? PK_SEMI : (nx >= TILE_W || ny >= RX_TILE_H) ? PK_NONE : (nx | ny) ? PK_MASKED : PK_FULL;
-            }
+            // FULL planes (certificates hold, nothing out of frame): wave-uniform LDS base and weight word, software-pipelined over the planes
 #pragma unroll
             for (int k = 0; k <= RX_KW; k++) {
-                if (k < RX_KW && (kind[k] == PK_FULL || kind[k] == PK_MASKED)) {
-                    const int tx0 = (int)(xe[k] & 0xfffffu) - RX_BIAS, ty0 = (int)(ye[k] & 0xfffffu) - RX_BIAS;
-                    const uint32_t addr = lane4 + slot_byte + 4u * (uint32_t)(((ty0 >> 5) - y0) * RS + ((tx0 >> 5) - x0));
-                    if (kind[k] == PK_FULL) cnt[k] += 1u << 24;
+                const bool fk = k < RX_KW && !((special >> (8 * k)) & 0x80u), fp = k > 0 && !((special >> (8 * (k - 1))) & 0x80u);
+                if (fk) {
+                    const uint32_t addr = lane4 + slot_byte + 4u * (((yb >> (8 * k)) & 0x7fu) * RS + ((xb >> (8 * k)) & 0x7fu));
+                    cnt[k] += 1u << 24;
 #pragma unroll
                     for (int j = 0; j < 8; j++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(qd[k & 1][j]) : "v"(addr), "n"(j * RS * 4));
                 }
-                if (k > 0 && (kind[k - 1] == PK_FULL || kind[k - 1] == PK_MASKED)) {
+                if (fp) {
                     const int b = (k - 1) & 1;
                     // LDS reads return in order: at most the 8 reads of plane k outstanding <=> plane k - 1's have landed.  The loaded
                     // registers are operands of the wait, so their consumers cannot be scheduled above it.
-                    if (k < RX_KW && (kind[k] == PK_FULL || kind[k] == PK_MASKED))
+                    if (fk)
                         asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(qd[b][0]), "+v"(qd[b][1]), "+v"(qd[b][2]), "+v"(qd[b][3]), "+v"(qd[b][4]), "+v"(qd[b][5]), "+v"(qd[b][6]), "+v"(qd[b][7]));
                     else
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qd[b][0]), "+v"(qd[b][1]), "+v"(qd[b][2]), "+v"(qd[b][3]), "+v"(qd[b][4]), "+v"(qd[b][5]), "+v"(qd[b][6]), "+v"(qd[b][7]));
-                    if (kind[k - 1] == PK_FULL) {
 #pragma unroll
-                        for (int j = 0; j < 8; j++) acc[j][k - 1] = sad_u16(__builtin_amdgcn_udot4(qd[b][j], we[k - 1], 0u, false), Im255[j], acc[j][k - 1]);
-                    } else {
-                        // part of the tile is out of frame in this plane: a lane range (from the X entry) and a row range (from the Y entry)
-                        const int nx = (int)((xe[k - 1] >> 20) & 127u), ny = (int)((ye[k - 1] >> 20) & 127u);
-                        const bool lane_in = ((xe[k - 1] >> 27) & 1u) ? lane < TILE_W - nx : lane >= nx;
-                        const int jlo = ((ye[k - 1] >> 27) & 1u) ? 0 : ny, jhi = ((ye[k - 1] >> 27) & 1u) ? RX_TILE_H - ny : RX_TILE_H;
+                    for (int j = 0; j < 8; j++) acc[j][k - 1] = sad_u16(__builtin_amdgcn_udot4(qd[b][j], we[k - 1], 0u, false), Im255[j], acc[j][k - 1]);
+                }
+            }
+            // the other planes: part of the tile out of frame (MASKED), nothing in frame, or a certificate failed (SEMI)
+            if (special) {
+                uintptr_t coldp = (uintptr_t)a.cold;
+                asm volatile("" : "+s"(coldp));  // not loop-invariant for the optimiser: fetched here, not held in SGPRs over the loop
+                const int dpad = RX_COLD(coldp, int, dpad);
+                const cu32 xt = as_const<cu32>(RX_COLD(coldp, const uint32_t *, xt) + ((size_t)tx * a.V + v) * dpad + chunk * RX_PC + wave * RX_KW);
+                const cu32 yt = as_const<cu32>(RX_COLD(coldp, const uint32_t *, yt) + ((size_t)ty * a.V + v) * dpad + chunk * RX_PC + wave * RX_KW);
+                const uint32_t xdesc = rdl(x0r, 5), ydesc = rdl(y0r, 1);
+                const int x0 = (int)(xdesc & 0xffffu), y0 = (int)(ydesc & 0xffffu);
+                const bool staged = ((xdesc & ydesc) >> 31) != 0u;
+#pragma unroll
+                for (int k = 0; k < RX_KW; k++) {
+                    if (!((special >> (8 * k)) & 0x80u) || !staged) continue;
+                    const uint32_t xe = xt[k], ye = yt[k];
+                    const int nx = (int)((xe >> 20) & 127u), ny = (int)((ye >> 20) & 127u);
+                    if ((xe & ye) & RX_UNIFORM) {
+                        if (nx >= TILE_W || ny >= RX_TILE_H) continue;  // nothing in frame
+                        // a lane range (from the X entry) and a row range (from the Y entry) are in frame: the fast path under a mask,
+                        // the in-frame count per cell
+                        const int tx0 = (int)(xe & 0xfffffu) - RX_BIAS, ty0 = (int)(ye & 0xfffffu) - RX_BIAS;
+                        const uint32_t addr = lane4 + slot_byte + 4u * (uint32_t)(((ty0 >> 5) - y0) * RS + ((tx0 >> 5) - x0));
+                        const bool lane_in = ((xe >> 27) & 1u) ? lane < TILE_W - nx : lane >= nx;
+                        const int jlo = ((ye >> 27) & 1u) ? 0 : ny, jhi = ((ye >> 27) & 1u) ? RX_TILE_H - ny : RX_TILE_H;
                         if (lane_in) {
 #pragma unroll
+                            for (int j = 0; j < 8; j++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(qd[0][j]) : "v"(addr), "n"(j * RS * 4));
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qd[0][0]), "+v"(qd[0][1]), "+v"(qd[0][2]), "+v"(qd[0][3]), "+v"(qd[0][4]), "+v"(qd[0][5]), "+v"(qd[0][6]), "+v"(qd[0][7]));
+#pragma unroll
                             for (int j = 0; j < 8; j++)
-                                if (j >= jlo && j < jhi)
-                                    acc[j][k - 1] = sad_u16(__builtin_amdgcn_udot4(qd[b][j], we[k - 1], 0u, false), Im255[j], acc[j][k - 1] + (1u << 24));
+                                if (j >= jlo && j < jhi) acc[j][k] = sad_u16(__builtin_amdgcn_udot4(qd[0][j], we[k], 0u, false), Im255[j], acc[j][k] + (1u << 24));
                         }
+                        continue;
                     }
-                }
-                if (k < RX_KW && kind[k] == PK_SEMI) {
-                    // A certificate failed (a rounding boundary inside the tile, ~0.3 % of the planes; or a view that is not rectified):
-                    // the contract's expression per lane (columns) and per row, then one pass per group of lanes that share a phase and
-                    // a texel offset (usually two groups), each with wave-uniform weights and LDS bases like the fast path.
-                    const cf32 q = as_const<cf32>(p.Q + 12 * v);
-                    const float z = as_const<cf32>(p.z)[min(chunk * RX_PC + wave * RX_KW + k, p.D - 1)];
+                    // A certificate failed (a rounding boundary inside the tile: ~0.3 % of the planes on the SURVEY 8d ring): the contract's
+                    // expression per lane (columns) and per row, then one pass per group of lanes that share a phase and a texel offset
+                    // (usually two groups), each with wave-uniform weights and LDS bases like the fast path.
+                    const cf32 q = as_const<cf32>(RX_COLD(coldp, const float *, Q) + 12 * v);
+                    const float z = as_const<cf32>(RX_COLD(coldp, const float *, z))[min(chunk * RX_PC + wave * RX_KW + k, a.D - 1)];
+                    const float invW = RX_COLD(coldp, float, invW), invH = RX_COLD(coldp, float, invH);
+                    const cu32 lut = as_const<cu32>(RX_COLD(coldp, const uint32_t *, lut));
+                    const uint32_t lo_bits = __builtin_bit_cast(uint32_t, RX_MAGIC + 132.0f);
+                    const uint32_t hix_bits = lo_bits + 256u * (uint32_t)a.W, hiy_bits = lo_bits + 256u * (uint32_t)a.H;  // floats in [2^23, 2^24): ulp 1
                     const float r256 = rect_r256(q);
-                    const float Tx = rect_tx(q, r256, z, col, p.invW);
-                    const uint32_t txb = __builtin_bit_cast(uint32_t, Tx);
+                    const uint32_t txb = __builtin_bit_cast(uint32_t, rect_tx(q, r256, z, col, invW));
                     const bool inx = col_ok && txb > lo_bits && txb < hix_bits;
                     const int tx3 = (int)((txb & 0x3fffffu) >> 3) - 32 * lane;
-                    const uint32_t tyv = __builtin_bit_cast(uint32_t, rect_ty(q, r256, z, row0 + (lane & 7), p.invH));
+                    const uint32_t tyv = __builtin_bit_cast(uint32_t, rect_ty(q, r256, z, row0 + (lane & 7), invH));
                     unsigned long long remaining = __builtin_amdgcn_ballot_w64(inx);
                     while (remaining) {
                         const int t = __builtin_amdgcn_readlane(tx3, (int)__builtin_ctzll(remaining));
@@ -407,9 +499,9 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(SweepPar
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
                             const uint32_t tyb = (uint32_t)__builtin_amdgcn_readlane((int)tyv, j);
-                            if (tyb > lo_bits && tyb < hiy_bits && row0 + j < p.H) {
+                            if (tyb > lo_bits && tyb < hiy_bits && row0 + j < a.H) {
                                 const uint32_t uy = tyb & 0x3fffffu;
-                                const uint32_t w = as_const<cu32>(rp.lut)[((uy >> 3) & 31u) * 32u + kx];
+                                const uint32_t w = lut[((uy >> 3) & 31u) * 32u + kx];
                                 const uint32_t addr = lane4 + slot_byte + 4u * (uint32_t)(((int)(uy >> 8) - y0) * RS + ixrel);
                                 if (mine) {
                                     uint32_t quad;
@@ -424,17 +516,20 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(SweepPar
         }
 
         // ---- chunk epilogue ----
-        if (v + 1 == p.v0 + p.vcount) {
+        if (v + 1 == vend) {
             const int d0 = chunk * RX_PC + wave * RX_KW;
+            const size_t P = (size_t)a.W * a.H;
+            const uint32_t pix0 = 4u * (uint32_t)(row0 * a.W + col);  // byte offset of this lane's first pixel inside a plane
 #pragma unroll
             for (int k = 0; k < RX_KW; k++) {
-                if (d0 + k < p.D) {
-                    uint32_t *const vol_plane = WRITE_VOLUME ? p.volume + (size_t)(d0 + k) * P : nullptr;
+                if (d0 + k < a.D) {
+                    // one resource per plane (a volume can exceed the 4 GiB a resource spans), rows by the wave-uniform offset
+                    const __amdgpu_buffer_rsrc_t rvol = make_rsrc(WRITE_VOLUME ? a.volume + (size_t)(d0 + k) * P : nullptr, 0xffffffffu);
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
-                        if (col_ok && row0 + j < p.H) {
+                        if (col_ok && row0 + j < a.H) {
                             const uint32_t cell = acc[j][k] + cnt[k];
-                            if (WRITE_VOLUME) __builtin_nontemporal_store(cell, vol_plane + (uint32_t)((row0 + j) * p.W + col));
+                            if (WRITE_VOLUME) __builtin_amdgcn_raw_buffer_store_b32(cell, rvol, pix0, 4u * (uint32_t)(j * a.W), 2);  // nt: written once, read by a later kernel
                             if (FUSED) {
                                 const bool better = umul24u(cell & 0xffffffu, best[j] >> 24) < umul24u(best[j] & 0xffffffu, cell >> 24);
                                 best[j] = better ? cell : best[j];
@@ -449,10 +544,16 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(SweepPar
             }
         }
 
-        cur = nxt;
         chunk = cn;
         v = vn;
-        if (++slot_c == S) slot_c = 0;
+        cn = c2;
+        vn = v2;
+        en = e2;
+        x0r = x1r;
+        y0r = y1r;
+        x1r = x2r;
+        y1r = y2r;
+        slot_c ^= 1;
     }
 
     // ---- depth selection across the four wavefronts (each holds the best of its own planes): lowest cost, ties -> lowest plane ----
@@ -462,11 +563,15 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(SweepPar
 #pragma unroll
         for (int j = 0; j < 8; j++) ex[(wave * 8 + j) * 64 + lane] = make_uint2(best[j], (uint32_t)bi[j]);
         __syncthreads();
+        const size_t P = (size_t)a.W * a.H;
+        float *depth = RX_COLD(a.cold, float *, depth), *cost = RX_COLD(a.cold, float *, cost);
+        int *index = RX_COLD(a.cold, int *, index);
+        const float *zt = RX_COLD(a.cold, const float *, z);
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) {
             const int j = wave * 2 + jj;
             const int row = row0 + j;
-            if (col_ok && row < p.H) {
+            if (col_ok && row < a.H) {
                 uint32_t b = 1u;
                 int bidx = -1;
 #pragma unroll
@@ -480,11 +585,14 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(SweepPar
                     }
                 }
                 if (bidx < 0) b = 0u;  // no plane had a view in frame: the empty cell, as argmin_update_packed leaves it
-                const size_t pix = (size_t)row * p.W + col;
-                if (p.part)
-                    p.part[(size_t)blockIdx.y * P + pix] = make_uint2(b, (uint32_t)bidx);
-                else
-                    store_best<CS_FIXED>(p, pix, b & 0xffffffu, b >> 24, bidx);
+                const size_t pix = (size_t)row * a.W + col;
+                if (a.part) {
+                    a.part[(size_t)blockIdx.y * P + pix] = make_uint2(b, (uint32_t)bidx);
+                } else {  // store_best<CS_FIXED>
+                    depth[pix] = bidx >= 0 ? zt[bidx] : MVS_BACKGROUND_DEPTH;
+                    cost[pix] = bidx >= 0 ? cell_cost<CS_FIXED>(b & 0xffffffu, b >> 24) : __builtin_inff();
+                    index[pix] = bidx;
+                }
             }
         }
     }
@@ -497,58 +605,102 @@ int ensure_fx_lut(mvs_ctx *ctx);  // sweep_fx.hip
 
 bool rect_view_host(const float *q) { return q[1] == 0.0f && q[4] == 0.0f && q[8] == 0.0f && q[9] == 0.0f && q[10] == 0.0f && q[11] > 0.0f; }
 
-// Builds the X / Y / W tables for the current (views, planes) and decides whether the rectified kernel serves this plan: every
-// view eligible and every staged region of the fixed-sampler plan within a slot shape the kernel is compiled for.
-// Called after plan_regions_fx (whose counters it reads back: one stream synchronisation per plan).
+static void rect_tables(mvs_ctx *ctx, const SweepParams &q, RectTables &rt)
+{
+    const int dpad = q.nchunks * RX_PC;
+    const size_t nx = (size_t)q.tiles_x * q.V * dpad, ny = (size_t)q.tiles_y * q.V * dpad, nw = (size_t)q.V * dpad;
+    const size_t nxw = (size_t)q.tiles_x * q.V * q.nchunks * 32, nyr = (size_t)q.tiles_y * q.V * q.nchunks * 8;
+    uint32_t *base = (uint32_t *)ctx->rect_tab.ptr;
+    rt.dpad = dpad;
+    rt.stats = (int *)base;  // 16 dwords
+    rt.xw = base + 16;
+    rt.yr = rt.xw + nxw;
+    rt.xt = rt.yr + nyr;
+    rt.yt = rt.xt + nx;
+    rt.wt = rt.yt + ny;
+    rt.xmm = rt.wt + nw;
+    rt.ymm = rt.xmm + nx;
+}
+
+static size_t rect_table_dwords(const SweepParams &q)
+{
+    const int dpad = q.nchunks * RX_PC;
+    const size_t nx = (size_t)q.tiles_x * q.V * dpad, ny = (size_t)q.tiles_y * q.V * dpad, nw = (size_t)q.V * dpad;
+    return 16 + (size_t)q.tiles_x * q.V * q.nchunks * 32 + (size_t)q.tiles_y * q.V * q.nchunks * 8 + 2 * nx + 2 * ny + nw + 16;
+}
+
+// Builds the tables for the current (views, planes) and decides whether the rectified kernel serves this plan: every view
+// eligible (host check on the f32 view matrices) and every region box within a slot shape the kernel is compiled for (counters of
+// pass B: one stream synchronisation per plan).  Called from sweep_fx_plan.
 int sweep_rect_plan(mvs_ctx *ctx)
 {
     ctx->rect_ok = false;
+    ctx->rect_cold_sent = false;  // the tables (and the cold block behind them) may move
     if (getenv("MVS_NO_RECT")) return MVS_OK;
-    int elig = 0;
-    for (int v = 0; v < ctx->V; v++) elig += rect_view_host(ctx->q_host.data() + 12 * v) ? 1 : 0;
-    if (ctx->V == 0 || elig < ctx->V) return MVS_OK;  // a view that is not rectified would take the kernel's slowest path for all its planes
+    if (ctx->V == 0) return MVS_OK;
+    for (int v = 0; v < ctx->V; v++)
+        if (!rect_view_host(ctx->q_host.data() + 12 * v)) return MVS_OK;  // a view that is not rectified: the general kernel
+    SweepParams q;
+    fill_params(ctx, q, 0, ctx->V, RX_TILE_H, RX_PC);
+    int rc;
+    if ((rc = ensure(ctx, ctx->rect_tab, rect_table_dwords(q) * sizeof(uint32_t) + sizeof(RectCold) + 256))) return rc;
+    if ((rc = ensure_fx_lut(ctx))) return rc;
+    RectTables rt;
+    rect_tables(ctx, q, rt);
+    MVS_HIP(ctx, hipMemsetAsync(rt.stats, 0, 64, ctx->stream));
+    const size_t na = (size_t)(q.tiles_x + q.tiles_y + 1) * q.V * rt.dpad;
+    plan_rect_axis<<<(unsigned)((na + 255) / 256), 256, 0, ctx->stream>>>(q, rt, (const uint32_t *)ctx->fx_lut.ptr);
+    const size_t nb = (size_t)(q.tiles_x + q.tiles_y) * q.V * q.nchunks;
+    plan_rect_pack<<<(unsigned)((nb + 255) / 256), 256, 0, ctx->stream>>>(q, rt);
+    MVS_HIP(ctx, hipGetLastError());
     int stats[4] = {0, 0, 0, 0};
-    MVS_HIP(ctx, hipMemcpyAsync(stats, ctx->plan_stats.ptr, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipMemcpyAsync(stats, rt.stats, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream));
     MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int max_rw = stats[2], max_rh = stats[3];
-    if (stats[0] > 0) return MVS_OK;  // regions beyond the LDS image of the general kernel: wide baselines, not this kernel's case
+    const int max_rw = stats[0], max_rh = stats[1];
     int rs = 0;
     for (int cand : {96, 128})
-        if (max_rw <= cand && ctx->pad_pitch >= cand) {
+        if (max_rw <= cand) {
             rs = cand;
             break;
         }
-    if (!rs || max_rh <= 0 || max_rh > 32) return MVS_OK;
+    if (!rs || max_rw <= 0 || max_rh <= 0 || max_rh > 32) return MVS_OK;  // wide baselines / few planes: boxes too large for the slots
     const int units = rs / 4;
-    const int instrs = div_up(max_rh * units, 64);         // 1 KiB copy instructions per region
+    const int instrs = div_up(max_rh * units, 64);  // 1 KiB copy instructions per region
     const int ni = div_up(instrs, 4);
     if (ni > RX_MAX_NI) return MVS_OK;
     ctx->rect_rs = rs;
     ctx->rect_ni = ni;
     ctx->rect_instrs = instrs;
     ctx->rect_slot_dw = instrs * 256;
-
-    SweepParams q;
-    fill_params(ctx, q, 0, ctx->V, RX_TILE_H, RX_PC);
-    const int dpad = q.nchunks * RX_PC;
-    const size_t nx = (size_t)q.tiles_x * q.V * dpad, ny = (size_t)q.tiles_y * q.V * dpad, nw = (size_t)q.V * dpad;
-    int rc;
-    if ((rc = ensure(ctx, ctx->rect_tab, (nx + ny + nw) * sizeof(uint32_t) + 64))) return rc;
-    if ((rc = ensure_fx_lut(ctx))) return rc;
-    uint32_t *xt = (uint32_t *)ctx->rect_tab.ptr, *yt = xt + nx, *wt = yt + ny;
-    plan_rect_axis<<<(unsigned)((nx + ny + nw + 255) / 256), 256, 0, ctx->stream>>>(q, dpad, xt, yt, wt, (const uint32_t *)ctx->fx_lut.ptr);
-    MVS_HIP(ctx, hipGetLastError());
-    ctx->rect_dpad = dpad;
+    ctx->rect_dpad = rt.dpad;
+    ctx->rect_special = stats[2];
+    // the cold block (device memory, after the tables)
+    RectCold cold;
+    cold.main_img = (const uint8_t *)ctx->main_img.ptr;
+    cold.xt = rt.xt;
+    cold.yt = rt.yt;
+    cold.lut = (const uint32_t *)ctx->fx_lut.ptr;
+    cold.Q = (const float *)ctx->qmats.ptr;
+    cold.z = (const float *)ctx->ztab.ptr;
+    cold.depth = (float *)ctx->depth.ptr;
+    cold.cost = (float *)ctx->cost.ptr;
+    cold.index = (int *)ctx->index.ptr;
+    cold.invW = q.invW;
+    cold.invH = q.invH;
+    cold.dpad = rt.dpad;
+    cold.pad_ = 0;
+    ctx->rect_cold_host.resize(sizeof(RectCold));
+    memcpy(ctx->rect_cold_host.data(), &cold, sizeof(RectCold));
     ctx->rect_ok = true;
     return MVS_OK;
 }
 
 template <int RS>
-static int launch_rect(mvs_ctx *ctx, const SweepParams &p, const RectParams &rp, dim3 grid, size_t lds, bool vol, bool fused)
+static int launch_rect(mvs_ctx *ctx, const RectArgs &a, dim3 grid, size_t lds, bool vol, bool fused)
 {
     auto go = [&](auto kernel) -> int {
         MVS_HIP(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        kernel<<<grid, 256, lds, ctx->stream>>>(p, rp);
+        kernel<<<grid, 256, lds, ctx->stream>>>(a);
         MVS_HIP(ctx, hipGetLastError());
         return MVS_OK;
     };
@@ -560,22 +712,44 @@ static int launch_rect(mvs_ctx *ctx, const SweepParams &p, const RectParams &rp,
 // launch of the rectified sweep; `p` carries the plane / row / view ranges.  Returns the split count like sweep_fx_launch.
 int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsigned flags)
 {
-    RectParams rp;
-    const int dpad = ctx->rect_dpad;
-    const size_t nx = (size_t)p.tiles_x * p.V * dpad, ny = (size_t)p.tiles_y * p.V * dpad;
-    rp.xt = (const uint32_t *)ctx->rect_tab.ptr;
-    rp.yt = rp.xt + nx;
-    rp.wt = rp.yt + ny;
-    rp.lut = (const uint32_t *)ctx->fx_lut.ptr;
-    rp.dpad = dpad;
-    rp.slot_dw = ctx->rect_slot_dw;
-    rp.ni = ctx->rect_ni;
-    rp.instrs = ctx->rect_instrs;
-    int slots = 3;
-    if (const char *e = getenv("MVS_RECT_SLOTS")) slots = atoi(e);
-    slots = max(2, min(slots, 8));
-    rp.nslots = slots;
-    size_t lds = (size_t)slots * rp.slot_dw * 4 + 1024;
+    RectTables rt;
+    rect_tables(ctx, p, rt);
+    // the cold block follows the tables; its output pointers can change between plan and launch (ensure_outputs): re-sent when they do
+    RectCold *cold_dev = (RectCold *)((uint32_t *)ctx->rect_tab.ptr + rect_table_dwords(p));
+    RectCold cold;
+    memcpy(&cold, ctx->rect_cold_host.data(), sizeof(RectCold));
+    cold.main_img = (const uint8_t *)ctx->main_img.ptr;
+    cold.depth = (float *)ctx->depth.ptr;
+    cold.cost = (float *)ctx->cost.ptr;
+    cold.index = (int *)ctx->index.ptr;
+    if (!ctx->rect_cold_sent || memcmp(&cold, ctx->rect_cold_host.data(), sizeof(RectCold)) != 0) {
+        memcpy(ctx->rect_cold_host.data(), &cold, sizeof(RectCold));
+        MVS_HIP(ctx, hipMemcpyAsync(cold_dev, ctx->rect_cold_host.data(), sizeof(RectCold), hipMemcpyHostToDevice, ctx->stream));
+        ctx->rect_cold_sent = true;
+    }
+    RectArgs a;
+    a.quads = p.quads;
+    a.xw = rt.xw;
+    a.yr = rt.yr;
+    a.volume = p.volume;
+    a.cold = cold_dev;
+    a.part = nullptr;
+    a.pad_slab = p.pad_slab;
+    a.pitch = p.pitch;
+    a.W = p.W;
+    a.H = p.H;
+    a.D = p.D;
+    a.V = p.V;
+    a.v0 = p.v0;
+    a.vcount = p.vcount;
+    a.nchunks = p.nchunks;
+    a.chunk0 = p.chunk0;
+    a.chunk1 = p.chunk1;
+    a.ty0 = p.ty0;
+    a.tyn = p.tyn;
+    a.tiles_x = p.tiles_x;
+    a.slot_dw = ctx->rect_slot_dw;
+    size_t lds = (size_t)2 * a.slot_dw * 4;
     if (fused) lds = lds < 16384 ? 16384 : lds;  // the cross-wavefront depth selection borrows 16 KiB
     if (lds > 160 * 1024) return fail(ctx, MVS_EINVAL, "sweep_rect_launch: %zu bytes of LDS", lds);
 
@@ -584,14 +758,16 @@ int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsign
     int want = (int)((flags >> 16) & 0xffu);
     if (!want) want = div_up(16 * ctx->num_cus, tiles);
     p.cps = div_up(nch, max(1, min(want, nch)));
+    a.cps = p.cps;
     const int nsplit = div_up(nch, p.cps);
     int rc;
     if (fused && nsplit > 1) {
         if ((rc = ensure(ctx, ctx->best_parts, (size_t)nsplit * ctx->W * ctx->H * sizeof(uint2)))) return rc;
         p.part = (uint2 *)ctx->best_parts.ptr;
+        a.part = p.part;
     }
     const dim3 grid((unsigned)(div_up(groups, 8) * 64), (unsigned)nsplit);
-    rc = ctx->rect_rs == 96 ? launch_rect<96>(ctx, p, rp, grid, lds, vol, fused) : launch_rect<128>(ctx, p, rp, grid, lds, vol, fused);
+    rc = ctx->rect_rs == 96 ? launch_rect<96>(ctx, a, grid, lds, vol, fused) : launch_rect<128>(ctx, a, grid, lds, vol, fused);
     if (rc) return rc;
     return nsplit;
 }
