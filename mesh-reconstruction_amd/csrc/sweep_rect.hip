@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
 #pragma unroll
         for (int k = 0; k < RX_KW; k++) acc[j][k] = 0u;
     }
-    uint32_t cnt[RX_KW] = {0u, 0u, 0u, 0u};  // views counted once for every cell of a plane (wave-uniform)
+    uint32_t spacc = 0u;  // per plane of this wavefront (one byte each): views of the current chunk whose plane was NOT counted as a whole
 
     const int e_last = (vend - 1) * NC + chunk_last - 1;  // the workgroup's last region: prefetches past it re-read it
     int chunk = chunk_first, v = a.v0, e = a.v0 * NC + chunk_first;
@@ -400,7 +400,6 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     uint32_t x1r = load_x(min(en, e_last)), y1r = load_y(min(en, e_last));  // region r + 1
     if (nreg > 0) issue_copy(rdl(x0r, 5), rdl(y0r, 1), v, 0);
     int slot_c = 0;
-    const uint32_t lane4 = lds_base + 4u * (uint32_t)lane;
 
     for (int r = 0; r < nreg; r++) {
         // every copy and every record this wavefront asked for has landed ...
@@ -417,31 +416,46 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
 
         // ---- sample region r ----
         const uint32_t special = (xb | yb) & 0x80808080u;
+        spacc += special >> 7;  // per plane (one byte each): views whose plane was not FULL in this chunk
         {
-            const uint32_t slot_byte = (uint32_t)(slot_c * a.slot_dw) * 4u;
+            const uint32_t slot_byte = lds_base + (uint32_t)(slot_c * a.slot_dw) * 4u;
             uint32_t qd[2][8];
-            // FULL planes (certificates hold, nothing out of frame): wave-uniform LDS base and weight word, software-pipelined over the planes
+            // FULL planes (certificates hold, nothing out of frame): LDS base in M0 (ds_read_addtid_b32: M0 + offset + 4 lane, no
+            // address register) and weight word in an SGPR; the reads of plane k + 1 are in flight while plane k is consumed.  LDS reads
+            // return in order, so "at most 8 outstanding" means the older plane has landed; the loaded registers are operands of the
+            // wait, so their consumers cannot be scheduled above it.  A plane that is not FULL is read as well (from the slot's first
+            // row: harmless) and skipped at the compute stage: no second shape of the pipeline.
+            auto issue = [&](int k, int buf) {
+                const uint32_t off = ((special >> (8 * k)) & 0x80u) ? 0u : ((yb >> (8 * k)) & 0x7fu) * RS + ((xb >> (8 * k)) & 0x7fu);
+                const uint32_t m0v = slot_byte + 4u * off;
+                asm volatile("s_mov_b32 m0, %8\n\ts_nop 0\n\t"
+                             "ds_read_addtid_b32 %0 offset:%9\n\tds_read_addtid_b32 %1 offset:%10\n\tds_read_addtid_b32 %2 offset:%11\n\tds_read_addtid_b32 %3 offset:%12\n\t"
+                             "ds_read_addtid_b32 %4 offset:%13\n\tds_read_addtid_b32 %5 offset:%14\n\tds_read_addtid_b32 %6 offset:%15\n\tds_read_addtid_b32 %7 offset:%16"
+                             : "=v"(qd[buf][0]), "=v"(qd[buf][1]), "=v"(qd[buf][2]), "=v"(qd[buf][3]), "=v"(qd[buf][4]), "=v"(qd[buf][5]), "=v"(qd[buf][6]), "=v"(qd[buf][7])
+                             : "s"(m0v), "n"(0), "n"(RS * 4), "n"(RS * 8), "n"(RS * 12), "n"(RS * 16), "n"(RS * 20), "n"(RS * 24), "n"(RS * 28)
+                             : "m0");
+            };
+            auto consume = [&](int k, int buf, bool more_in_flight) {
+                if (more_in_flight)
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(qd[buf][0]), "+v"(qd[buf][1]), "+v"(qd[buf][2]), "+v"(qd[buf][3]), "+v"(qd[buf][4]), "+v"(qd[buf][5]), "+v"(qd[buf][6]), "+v"(qd[buf][7]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qd[buf][0]), "+v"(qd[buf][1]), "+v"(qd[buf][2]), "+v"(qd[buf][3]), "+v"(qd[buf][4]), "+v"(qd[buf][5]), "+v"(qd[buf][6]), "+v"(qd[buf][7]));
+                if (!((special >> (8 * k)) & 0x80u)) {
+                    // all dot products, then all differences: a v_sad right behind the v_dot4 it consumes costs three wait states
 #pragma unroll
-            for (int k = 0; k <= RX_KW; k++) {
-                const bool fk = k < RX_KW && !((special >> (8 * k)) & 0x80u), fp = k > 0 && !((special >> (8 * (k - 1))) & 0x80u);
-                if (fk) {
-                    const uint32_t addr = lane4 + slot_byte + 4u * (((yb >> (8 * k)) & 0x7fu) * RS + ((xb >> (8 * k)) & 0x7fu));
-                    cnt[k] += 1u << 24;
+                    for (int j = 0; j < 8; j++) qd[buf][j] = __builtin_amdgcn_udot4(qd[buf][j], we[k], 0u, false);
 #pragma unroll
-                    for (int j = 0; j < 8; j++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(qd[k & 1][j]) : "v"(addr), "n"(j * RS * 4));
+                    for (int j = 0; j < 8; j++) acc[j][k] = sad_u16(qd[buf][j], Im255[j], acc[j][k]);
                 }
-                if (fp) {
-                    const int b = (k - 1) & 1;
-                    // LDS reads return in order: at most the 8 reads of plane k outstanding <=> plane k - 1's have landed.  The loaded
-                    // registers are operands of the wait, so their consumers cannot be scheduled above it.
-                    if (fk)
-                        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(qd[b][0]), "+v"(qd[b][1]), "+v"(qd[b][2]), "+v"(qd[b][3]), "+v"(qd[b][4]), "+v"(qd[b][5]), "+v"(qd[b][6]), "+v"(qd[b][7]));
-                    else
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qd[b][0]), "+v"(qd[b][1]), "+v"(qd[b][2]), "+v"(qd[b][3]), "+v"(qd[b][4]), "+v"(qd[b][5]), "+v"(qd[b][6]), "+v"(qd[b][7]));
-#pragma unroll
-                    for (int j = 0; j < 8; j++) acc[j][k - 1] = sad_u16(__builtin_amdgcn_udot4(qd[b][j], we[k - 1], 0u, false), Im255[j], acc[j][k - 1]);
-                }
-            }
+            };
+            issue(0, 0);
+            issue(1, 1);
+            consume(0, 0, true);
+            issue(2, 0);
+            consume(1, 1, true);
+            issue(3, 1);
+            consume(2, 0, true);
+            consume(3, 1, false);
             // the other planes: part of the tile out of frame (MASKED), nothing in frame, or a certificate failed (SEMI)
             if (special) {
                 uintptr_t coldp = (uintptr_t)a.cold;
@@ -462,7 +476,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                         // a lane range (from the X entry) and a row range (from the Y entry) are in frame: the fast path under a mask,
                         // the in-frame count per cell
                         const int tx0 = (int)(xe & 0xfffffu) - RX_BIAS, ty0 = (int)(ye & 0xfffffu) - RX_BIAS;
-                        const uint32_t addr = lane4 + slot_byte + 4u * (uint32_t)(((ty0 >> 5) - y0) * RS + ((tx0 >> 5) - x0));
+                        const uint32_t addr = 4u * (uint32_t)lane + slot_byte + 4u * (uint32_t)(((ty0 >> 5) - y0) * RS + ((tx0 >> 5) - x0));
                         const bool lane_in = ((xe >> 27) & 1u) ? lane < TILE_W - nx : lane >= nx;
                         const int jlo = ((ye >> 27) & 1u) ? 0 : ny, jhi = ((ye >> 27) & 1u) ? RX_TILE_H - ny : RX_TILE_H;
                         if (lane_in) {
@@ -502,7 +516,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                             if (tyb > lo_bits && tyb < hiy_bits && row0 + j < a.H) {
                                 const uint32_t uy = tyb & 0x3fffffu;
                                 const uint32_t w = lut[((uy >> 3) & 31u) * 32u + kx];
-                                const uint32_t addr = lane4 + slot_byte + 4u * (uint32_t)(((int)(uy >> 8) - y0) * RS + ixrel);
+                                const uint32_t addr = 4u * (uint32_t)lane + slot_byte + 4u * (uint32_t)(((int)(uy >> 8) - y0) * RS + ixrel);
                                 if (mine) {
                                     uint32_t quad;
                                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(quad) : "v"(addr));
@@ -522,13 +536,14 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
             const uint32_t pix0 = 4u * (uint32_t)(row0 * a.W + col);  // byte offset of this lane's first pixel inside a plane
 #pragma unroll
             for (int k = 0; k < RX_KW; k++) {
+                const uint32_t cntk = ((uint32_t)a.vcount - ((spacc >> (8 * k)) & 0xffu)) << 24;  // FULL planes: every cell gets the view's count
                 if (d0 + k < a.D) {
                     // one resource per plane (a volume can exceed the 4 GiB a resource spans), rows by the wave-uniform offset
                     const __amdgpu_buffer_rsrc_t rvol = make_rsrc(WRITE_VOLUME ? a.volume + (size_t)(d0 + k) * P : nullptr, 0xffffffffu);
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
                         if (col_ok && row0 + j < a.H) {
-                            const uint32_t cell = acc[j][k] + cnt[k];
+                            const uint32_t cell = acc[j][k] + cntk;
                             if (WRITE_VOLUME) __builtin_amdgcn_raw_buffer_store_b32(cell, rvol, pix0, 4u * (uint32_t)(j * a.W), 2);  // nt: written once, read by a later kernel
                             if (FUSED) {
                                 const bool better = umul24u(cell & 0xffffffu, best[j] >> 24) < umul24u(best[j] & 0xffffffu, cell >> 24);
@@ -538,10 +553,10 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                         }
                     }
                 }
-                cnt[k] = 0u;
 #pragma unroll
                 for (int j = 0; j < 8; j++) acc[j][k] = 0u;
             }
+            spacc = 0u;
         }
 
         chunk = cn;
