@@ -129,8 +129,9 @@ struct RectTables {
     uint32_t *xt, *yt;    // [T][V][dpad]   full entries (below)
     uint32_t *xmm, *ymm;  // [T][V][dpad]   lowest | highest << 16 integer texel over the tile's in-frame pixels, 0xffffffff if none
     uint32_t *wt;         // [V][dpad]      weight word of the view's nominal phase pair at that plane
-    uint32_t *xw;         // [tiles_x][V][NC][4 wavefronts][8]  {xb, W0, W1, W2, W3, xdesc, 0, 0}
-    uint32_t *yr;         // [tiles_y][V][NC][4 wavefronts][2]  {yb, ydesc}
+    uint32_t *xw;         // [tiles_x][V][NC][4 wavefronts][8]  X records (pass C)
+    uint32_t *yr;         // [tiles_y][V][NC][4 wavefronts][4]  Y records
+    uint32_t *xbox, *ybox;  // [T][V][NC]   region boxes (pass B)
     int *stats;           // [0] widest region (quads), [1] tallest region (rows), [2] planes that are not FULL (diagnostic)
     int dpad;
 };
@@ -205,10 +206,9 @@ __global__ __launch_bounds__(256) void plan_rect_axis(SweepParams p, RectTables 
 }
 
 // Pass B.  One thread per (tile column or tile row, view, chunk): the box of the view's quad image the chunk's 16 planes touch
-// (x0 a multiple of 4 quads: the copies move 16-byte units), and for each of the four wavefronts one record with a byte per plane:
-// the plane's texel offset inside the box (FULL planes: certificate, nothing out of frame), or 0x80 = look at the full entry.
-//   xdesc = x0 | width << 16 | any << 31        ydesc = y0 | rows << 16 | any << 31        (any: some pixel of some plane in frame)
-__global__ __launch_bounds__(256) void plan_rect_pack(SweepParams p, RectTables rt)
+// (x origin a multiple of 4 quads: the copies move 16-byte units):  box = origin | extent << 16 | any << 31
+// (any: some pixel of some plane is in frame).  Counters: widest / tallest box.
+__global__ __launch_bounds__(256) void plan_rect_box(SweepParams p, RectTables rt)
 {
     const int NC = p.nchunks, dpad = rt.dpad;
     const int nx = p.tiles_x * p.V * NC, ny = p.tiles_y * p.V * NC;
@@ -217,7 +217,6 @@ __global__ __launch_bounds__(256) void plan_rect_pack(SweepParams p, RectTables 
     const int which = tid < nx ? 0 : 1;
     if (which == 1) tid -= nx;
     const int chunk = tid % NC, v = (tid / NC) % p.V, t = tid / (NC * p.V);
-    const uint32_t *ent = (which == 0 ? rt.xt : rt.yt) + ((size_t)t * p.V + v) * dpad + chunk * RX_PC;
     const uint32_t *mm = (which == 0 ? rt.xmm : rt.ymm) + ((size_t)t * p.V + v) * dpad + chunk * RX_PC;
     uint32_t lo = 0xffffu, hi = 0u;
     bool any = false;
@@ -231,32 +230,54 @@ __global__ __launch_bounds__(256) void plan_rect_pack(SweepParams p, RectTables 
     const uint32_t org = any ? (which == 0 ? (lo & ~3u) : lo) : 0u;
     const uint32_t ext = any ? hi + 1u - org : 0u;
     if (any) atomicMax(rt.stats + which, (int)ext);
-    const uint32_t desc = org | (min(ext, 255u) << 16) | (any ? 1u << 31 : 0u);
-    for (int w = 0; w < 4; w++) {
-        uint32_t bytes = 0u;
-        for (int k = 0; k < RX_KW; k++) {
-            const uint32_t e = ent[w * RX_KW + k];
-            const int tex = ((int)(e & 0xfffffu) - RX_BIAS) >> 5;
-            const bool full = (e & RX_UNIFORM) && ((e >> 20) & 127u) == 0u && any && tex >= (int)org && tex - (int)org < (which == 0 ? 128 : 32);
-            bytes |= (full ? (uint32_t)(tex - (int)org) : 0x80u) << (8 * k);
-            if (!full) atomicAdd(rt.stats + 2, 1);
-        }
-        if (which == 0) {
-            uint32_t *rec = rt.xw + ((((size_t)t * p.V + v) * NC + chunk) * 4 + w) * 8;
-            const uint32_t *wv = rt.wt + (size_t)v * dpad + chunk * RX_PC + w * RX_KW;
-            rec[0] = bytes;
-            rec[1] = wv[0];
-            rec[2] = wv[1];
-            rec[3] = wv[2];
-            rec[4] = wv[3];
-            rec[5] = desc;
-            rec[6] = 0u;
-            rec[7] = 0u;
-        } else {
-            uint32_t *rec = rt.yr + ((((size_t)t * p.V + v) * NC + chunk) * 4 + w) * 2;
-            rec[0] = bytes;
-            rec[1] = desc;
-        }
+    (which == 0 ? rt.xbox : rt.ybox)[tid] = org | (min(ext, 0x7fffu) << 16) | (any ? 1u << 31 : 0u);
+}
+
+// Pass C (after the host has chosen the row stride RS of the LDS slots from pass B's counters).  One thread per (tile column or
+// tile row, view, chunk, wavefront): that wavefront's record of the region -- per plane a 16-bit field with the plane's share of
+// the LDS byte offset of its first texel quad (x: 4 (ix - x0); y: 4 RS (iy - y0); their sum stays below 2^14), or a flag (x: bit
+// 14, y: bit 15) = not a FULL plane, look at the full entry.  The sum of an x and a y field is the plane's whole offset, or has a
+// flag bit set; fields do not carry into each other.
+//   X record (8 dwords): x01, x23, W0, W1, W2, W3, 4 x0 | (any ? RS / 4 : 0) << 16, 0
+//   Y record (4 dwords): y01, y23, 4 (pad_slab v + y0 pitch), (any ? rows : 0) | y0 << 8
+__global__ __launch_bounds__(256) void plan_rect_pack(SweepParams p, RectTables rt, int RS)
+{
+    const int NC = p.nchunks, dpad = rt.dpad;
+    const int nx = p.tiles_x * p.V * NC * 4, ny = p.tiles_y * p.V * NC * 4;
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= nx + ny) return;
+    const int which = tid < nx ? 0 : 1;
+    if (which == 1) tid -= nx;
+    const int w = tid & 3, chunk = (tid >> 2) % NC, v = ((tid >> 2) / NC) % p.V, t = (tid >> 2) / (NC * p.V);
+    const uint32_t *ent = (which == 0 ? rt.xt : rt.yt) + ((size_t)t * p.V + v) * dpad + chunk * RX_PC + w * RX_KW;
+    const uint32_t box = (which == 0 ? rt.xbox : rt.ybox)[tid >> 2];
+    const int org = (int)(box & 0xffffu), ext = (int)((box >> 16) & 0x7fffu);
+    const bool any = (box >> 31) != 0u;
+    uint32_t f[RX_KW];
+    for (int k = 0; k < RX_KW; k++) {
+        const uint32_t e = ent[k];
+        const int tex = ((int)(e & 0xfffffu) - RX_BIAS) >> 5;
+        const bool full = (e & RX_UNIFORM) && ((e >> 20) & 127u) == 0u && any && tex >= org && tex - org < ext;
+        f[k] = full ? (uint32_t)(tex - org) * (which == 0 ? 4u : 4u * (uint32_t)RS) : (which == 0 ? 0x4000u : 0x8000u);
+        if (!full) atomicAdd(rt.stats + 2, 1);
+    }
+    if (which == 0) {
+        uint32_t *rec = rt.xw + (size_t)tid * 8;
+        const uint32_t *wv = rt.wt + (size_t)v * dpad + chunk * RX_PC + w * RX_KW;
+        rec[0] = f[0] | (f[1] << 16);
+        rec[1] = f[2] | (f[3] << 16);
+        rec[2] = wv[0];
+        rec[3] = wv[1];
+        rec[4] = wv[2];
+        rec[5] = wv[3];
+        rec[6] = 4u * (uint32_t)org | ((any ? (uint32_t)RS / 4u : 0u) << 16);
+        rec[7] = 0u;
+    } else {
+        uint32_t *rec = rt.yr + (size_t)tid * 4;
+        rec[0] = f[0] | (f[1] << 16);
+        rec[1] = f[2] | (f[3] << 16);
+        rec[2] = 4u * ((uint32_t)p.pad_slab * (uint32_t)v + (uint32_t)(org * p.pitch));
+        rec[3] = (any ? (uint32_t)ext : 0u) | ((uint32_t)org << 8);
     }
 }
 
@@ -341,23 +362,28 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     const int vend = a.v0 + a.vcount;
     const int nreg = (chunk_last - chunk_first) * a.vcount;
 
-    // this wavefront's records of region (chunk, v), e = v NC + chunk: 8 dwords at xw_wg + 128 e bytes, 2 dwords at yr_wg + 32 e bytes;
+    // this wavefront's records of region (chunk, v), e = v NC + chunk: 8 dwords at xw_wg + 128 e bytes, 4 dwords at yr_wg + 64 e bytes;
     // both tables live in one allocation (a.xw < a.yr): one resource, two wave-uniform offsets
     const __amdgpu_buffer_rsrc_t rtab = make_rsrc(a.xw, 0xffffffffu);
     const uint32_t xw_wg = (uint32_t)(((size_t)tx * a.V * NC * 4 + wave) * 32);
-    const uint32_t yr_wg = (uint32_t)((size_t)((const char *)a.yr - (const char *)a.xw) + ((size_t)ty * a.V * NC * 4 + wave) * 8);
+    const uint32_t yr_wg = (uint32_t)((size_t)((const char *)a.yr - (const char *)a.xw) + ((size_t)ty * a.V * NC * 4 + wave) * 16);
     const __amdgpu_buffer_rsrc_t rquads = make_rsrc(a.quads, 0xffffffffu);
 
-    // request the region with descriptors (xd, yd) of view v into `slot`: rows of RS quads, 64 16-byte units per instruction
-    auto issue_copy = [&](uint32_t xd, uint32_t yd, int v, int slot) {
-        const int n = ((xd & yd) >> 31) ? (int)((yd >> 16) & 0xffu) * UNITS : 0;
-        const uint32_t src = 4u * ((uint32_t)a.pad_slab * (uint32_t)v + (uint32_t)((int)(yd & 0xffffu) * a.pitch + (int)(xd & 0xffffu)));
-        uint32_t *dst = smem + slot * a.slot_dw + wave * 256;
+    // request a region into the slot at LDS dword `slot_dw0`: xsx = X record dword 6 (4 x0 | units per row << 16, 0 units if the box is
+    // empty), ysrc / yn = Y record dwords 2 / 3 (byte offset of the box's first row in the quad images; rows | y0 << 8).  Rows of RS
+    // quads, 64 16-byte units per instruction; only the last instruction of a region runs under a lane mask.
+    auto issue_copy = [&](uint32_t xsx, uint32_t ysrc, uint32_t yn, uint32_t slot_dw0) {
+        const int n = (int)((yn & 0xffu) * (xsx >> 16));
+        const uint32_t src = (xsx & 0xffffu) + ysrc;
+        uint32_t *dst = smem + slot_dw0 + wave * 256;
 #pragma unroll
         for (int t = 0; t < RX_MAX_NI; t++) {
             const int left = n - (wave + 4 * t) * 64;  // units of the region this instruction still has to copy (wave-uniform)
-            if (left > 0 && lane < left)
+            if (left >= 64) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rquads, (__attribute__((address_space(3))) void *)(dst + t * 1024), 16, srcoff[t], src, 0, 0);
+            } else if (left > 0) {
+                if (lane < left) __builtin_amdgcn_raw_ptr_buffer_load_lds(rquads, (__attribute__((address_space(3))) void *)(dst + t * 1024), 16, srcoff[t], src, 0, 0);
+            }
         }
     };
 
@@ -365,18 +391,24 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     // the region's turn comes): as scalar loads they would have to stay in SGPRs across a whole region's sampling, and the compiler
     // spills them right after the load (a wait for the load, then v_writelane / v_readlane pairs) -- measured: 0.65 ms of loop skeleton.
     const uint32_t lane8 = 4u * (uint32_t)(lane & 7);
-    auto load_x = [&](int e) { return __builtin_amdgcn_raw_buffer_load_b32(rtab, lane8, xw_wg + 128u * (uint32_t)e, 0); };  // xb, W0, W1, W2, W3, xdesc
-    auto load_y = [&](int e) { return __builtin_amdgcn_raw_buffer_load_b32(rtab, lane8, yr_wg + 32u * (uint32_t)e, 0); };   // yb, ydesc
+    auto load_x = [&](uint32_t xo) { return __builtin_amdgcn_raw_buffer_load_b32(rtab, lane8, xo, 0); };
+    auto load_y = [&](uint32_t yo) { return __builtin_amdgcn_raw_buffer_load_b32(rtab, lane8, yo, 0); };
     auto rdl = [](uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); };
-    // region order of this workgroup: chunks outer, views inner; e = v NC + chunk indexes the record tables
-    auto advance = [&](int &chunk, int &v, int &e) {
-        v++;
-        e += NC;
-        if (v == vend) {
-            v = a.v0;
-            chunk++;
-            e = a.v0 * NC + chunk;
-        }
+    // Region order of this workgroup: chunks outer, views inner.  A cursor = (views left in the chunk, byte offsets of the region's
+    // X and Y records); past the workgroup's last region it stays there (prefetches re-read the last records).
+    struct Cursor {
+        int vleft, left;  // views left in this chunk after this one; regions left after this one
+        uint32_t xo, yo;
+    };
+    const uint32_t xstep = 128u * (uint32_t)NC, ystep = 64u * (uint32_t)NC;          // next view, same chunk
+    const uint32_t xwrap = 128u - xstep * (uint32_t)(a.vcount - 1), ywrap = 64u - ystep * (uint32_t)(a.vcount - 1);  // first view of the next chunk
+    auto advance = [&](Cursor &c) {
+        if (c.left <= 0) return;
+        c.left--;
+        const bool wrap = c.vleft == 0;
+        c.xo += wrap ? xwrap : xstep;
+        c.yo += wrap ? ywrap : ystep;
+        c.vleft = wrap ? a.vcount - 1 : c.vleft - 1;
     };
 
     uint32_t acc[8][RX_KW];
@@ -391,15 +423,19 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     }
     uint32_t spacc = 0u;  // per plane of this wavefront (one byte each): views of the current chunk whose plane was NOT counted as a whole
 
-    const int e_last = (vend - 1) * NC + chunk_last - 1;  // the workgroup's last region: prefetches past it re-read it
-    int chunk = chunk_first, v = a.v0, e = a.v0 * NC + chunk_first;
-    int cn = chunk, vn = v, en = e;  // the region after the current one
-    advance(cn, vn, en);
+    Cursor c2;  // region r + 2: the one whose records are fetched next
+    c2.vleft = a.vcount - 1;
+    c2.left = nreg - 1;
+    c2.xo = xw_wg + 128u * (uint32_t)(a.v0 * NC + chunk_first);
+    c2.yo = yr_wg + 64u * (uint32_t)(a.v0 * NC + chunk_first);
     // prologue: the records of regions 0 and 1, the copy of region 0
-    uint32_t x0r = load_x(min(e, e_last)), y0r = load_y(min(e, e_last));    // region r
-    uint32_t x1r = load_x(min(en, e_last)), y1r = load_y(min(en, e_last));  // region r + 1
-    if (nreg > 0) issue_copy(rdl(x0r, 5), rdl(y0r, 1), v, 0);
-    int slot_c = 0;
+    uint32_t x0r = load_x(c2.xo), y0r = load_y(c2.yo);  // region r
+    advance(c2);
+    uint32_t x1r = load_x(c2.xo), y1r = load_y(c2.yo);  // region r + 1
+    advance(c2);
+    uint32_t slot_cur = 0u, slot_nxt = (uint32_t)a.slot_dw;  // LDS dword offsets of the two slots
+    if (nreg > 0) issue_copy(rdl(x0r, 6), rdl(y0r, 2), rdl(y0r, 3), slot_cur);
+    int chunk = chunk_first, v = a.v0;
 
     for (int r = 0; r < nreg; r++) {
         // every copy and every record this wavefront asked for has landed ...
@@ -407,40 +443,39 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
         // ... and so have every other wavefront's; nobody reads region r - 1 any more
         __builtin_amdgcn_s_barrier();
         // request region r + 1 into the other slot and the records of region r + 2: in flight during this region's sampling
-        if (r + 1 < nreg) issue_copy(rdl(x1r, 5), rdl(y1r, 1), vn, slot_c ^ 1);
-        int c2 = cn, v2 = vn, e2 = en;
-        advance(c2, v2, e2);
-        const uint32_t x2r = load_x(min(e2, e_last)), y2r = load_y(min(e2, e_last));
-        const uint32_t xb = rdl(x0r, 0), yb = rdl(y0r, 0);
-        const uint32_t we[RX_KW] = {rdl(x0r, 1), rdl(x0r, 2), rdl(x0r, 3), rdl(x0r, 4)};
+        if (r + 1 < nreg) issue_copy(rdl(x1r, 6), rdl(y1r, 2), rdl(y1r, 3), slot_nxt);
+        const uint32_t x2r = load_x(c2.xo), y2r = load_y(c2.yo);
+        advance(c2);
+        const uint32_t sum01 = rdl(x0r, 0) + rdl(y0r, 0), sum23 = rdl(x0r, 1) + rdl(y0r, 1);  // per plane: LDS byte offset, or a flag bit
+        const uint32_t we[RX_KW] = {rdl(x0r, 2), rdl(x0r, 3), rdl(x0r, 4), rdl(x0r, 5)};
+        const uint32_t fld[RX_KW] = {sum01 & 0xffffu, sum01 >> 16, sum23 & 0xffffu, sum23 >> 16};
 
         // ---- sample region r ----
-        const uint32_t special = (xb | yb) & 0x80808080u;
-        spacc += special >> 7;  // per plane (one byte each): views whose plane was not FULL in this chunk
+        const uint32_t special = (sum01 | sum23) & 0xc000c000u;
         {
-            const uint32_t slot_byte = lds_base + (uint32_t)(slot_c * a.slot_dw) * 4u;
+            const uint32_t slot_byte = lds_base + slot_cur * 4u;
             uint32_t qd[2][8];
             // FULL planes (certificates hold, nothing out of frame): LDS base in M0 (ds_read_addtid_b32: M0 + offset + 4 lane, no
             // address register) and weight word in an SGPR; the reads of plane k + 1 are in flight while plane k is consumed.  LDS reads
             // return in order, so "at most 8 outstanding" means the older plane has landed; the loaded registers are operands of the
-            // wait, so their consumers cannot be scheduled above it.  A plane that is not FULL is read as well (from the slot's first
-            // row: harmless) and skipped at the compute stage: no second shape of the pipeline.
+            // wait, so their consumers cannot be scheduled above it.  A plane that is not FULL is read as well (somewhere in or past
+            // the LDS: harmless) and skipped at the compute stage: no second shape of the pipeline.
             auto issue = [&](int k, int buf) {
-                const uint32_t off = ((special >> (8 * k)) & 0x80u) ? 0u : ((yb >> (8 * k)) & 0x7fu) * RS + ((xb >> (8 * k)) & 0x7fu);
-                const uint32_t m0v = slot_byte + 4u * off;
-                asm volatile("s_mov_b32 m0, %8\n\ts_nop 0\n\t"
-                             "ds_read_addtid_b32 %0 offset:%9\n\tds_read_addtid_b32 %1 offset:%10\n\tds_read_addtid_b32 %2 offset:%11\n\tds_read_addtid_b32 %3 offset:%12\n\t"
-                             "ds_read_addtid_b32 %4 offset:%13\n\tds_read_addtid_b32 %5 offset:%14\n\tds_read_addtid_b32 %6 offset:%15\n\tds_read_addtid_b32 %7 offset:%16"
+                asm volatile("s_add_u32 m0, %8, %9\n\ts_nop 0\n\t"
+                             "ds_read_addtid_b32 %0 offset:%10\n\tds_read_addtid_b32 %1 offset:%11\n\tds_read_addtid_b32 %2 offset:%12\n\tds_read_addtid_b32 %3 offset:%13\n\t"
+                             "ds_read_addtid_b32 %4 offset:%14\n\tds_read_addtid_b32 %5 offset:%15\n\tds_read_addtid_b32 %6 offset:%16\n\tds_read_addtid_b32 %7 offset:%17"
                              : "=v"(qd[buf][0]), "=v"(qd[buf][1]), "=v"(qd[buf][2]), "=v"(qd[buf][3]), "=v"(qd[buf][4]), "=v"(qd[buf][5]), "=v"(qd[buf][6]), "=v"(qd[buf][7])
-                             : "s"(m0v), "n"(0), "n"(RS * 4), "n"(RS * 8), "n"(RS * 12), "n"(RS * 16), "n"(RS * 20), "n"(RS * 24), "n"(RS * 28)
-                             : "m0");
+                             : "s"(slot_byte), "s"(fld[k]), "n"(0), "n"(RS * 4), "n"(RS * 8), "n"(RS * 12), "n"(RS * 16), "n"(RS * 20), "n"(RS * 24), "n"(RS * 28)
+                             : "m0", "scc");
             };
             auto consume = [&](int k, int buf, bool more_in_flight) {
                 if (more_in_flight)
                     asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(qd[buf][0]), "+v"(qd[buf][1]), "+v"(qd[buf][2]), "+v"(qd[buf][3]), "+v"(qd[buf][4]), "+v"(qd[buf][5]), "+v"(qd[buf][6]), "+v"(qd[buf][7]));
                 else
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qd[buf][0]), "+v"(qd[buf][1]), "+v"(qd[buf][2]), "+v"(qd[buf][3]), "+v"(qd[buf][4]), "+v"(qd[buf][5]), "+v"(qd[buf][6]), "+v"(qd[buf][7]));
-                if (!((special >> (8 * k)) & 0x80u)) {
+                if (__builtin_expect((fld[k] & 0xc000u) != 0u, 0)) {
+                    spacc += 1u << (8 * k);  // not FULL: this view's count does not go to every cell of the plane
+                } else {
                     // all dot products, then all differences: a v_sad right behind the v_dot4 it consumes costs three wait states
 #pragma unroll
                     for (int j = 0; j < 8; j++) qd[buf][j] = __builtin_amdgcn_udot4(qd[buf][j], we[k], 0u, false);
@@ -463,12 +498,12 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                 const int dpad = RX_COLD(coldp, int, dpad);
                 const cu32 xt = as_const<cu32>(RX_COLD(coldp, const uint32_t *, xt) + ((size_t)tx * a.V + v) * dpad + chunk * RX_PC + wave * RX_KW);
                 const cu32 yt = as_const<cu32>(RX_COLD(coldp, const uint32_t *, yt) + ((size_t)ty * a.V + v) * dpad + chunk * RX_PC + wave * RX_KW);
-                const uint32_t xdesc = rdl(x0r, 5), ydesc = rdl(y0r, 1);
-                const int x0 = (int)(xdesc & 0xffffu), y0 = (int)(ydesc & 0xffffu);
-                const bool staged = ((xdesc & ydesc) >> 31) != 0u;
+                const uint32_t xsx = rdl(x0r, 6), yn = rdl(y0r, 3);
+                const int x0 = (int)((xsx & 0xffffu) >> 2), y0 = (int)((yn >> 8) & 0x3fffu);
+                const bool staged = (xsx >> 16) != 0u && (yn & 0xffu) != 0u;
 #pragma unroll
                 for (int k = 0; k < RX_KW; k++) {
-                    if (!((special >> (8 * k)) & 0x80u) || !staged) continue;
+                    if (!(fld[k] & 0xc000u) || !staged) continue;
                     const uint32_t xe = xt[k], ye = yt[k];
                     const int nx = (int)((xe >> 20) & 127u), ny = (int)((ye >> 20) & 127u);
                     if ((xe & ye) & RX_UNIFORM) {
@@ -559,16 +594,17 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
             spacc = 0u;
         }
 
-        chunk = cn;
-        v = vn;
-        cn = c2;
-        vn = v2;
-        en = e2;
+        if (++v == vend) {
+            v = a.v0;
+            chunk++;
+        }
         x0r = x1r;
         y0r = y1r;
         x1r = x2r;
         y1r = y2r;
-        slot_c ^= 1;
+        const uint32_t sw = slot_cur;
+        slot_cur = slot_nxt;
+        slot_nxt = sw;
     }
 
     // ---- depth selection across the four wavefronts (each holds the best of its own planes): lowest cost, ties -> lowest plane ----
@@ -620,29 +656,43 @@ int ensure_fx_lut(mvs_ctx *ctx);  // sweep_fx.hip
 
 bool rect_view_host(const float *q) { return q[1] == 0.0f && q[4] == 0.0f && q[8] == 0.0f && q[9] == 0.0f && q[10] == 0.0f && q[11] > 0.0f; }
 
-static void rect_tables(mvs_ctx *ctx, const SweepParams &q, RectTables &rt)
+struct RectSizes {
+    size_t nx, ny, nw, nxw, nyr, nxb, nyb, total;
+};
+
+static RectSizes rect_sizes(const SweepParams &q)
 {
-    const int dpad = q.nchunks * RX_PC;
-    const size_t nx = (size_t)q.tiles_x * q.V * dpad, ny = (size_t)q.tiles_y * q.V * dpad, nw = (size_t)q.V * dpad;
-    const size_t nxw = (size_t)q.tiles_x * q.V * q.nchunks * 32, nyr = (size_t)q.tiles_y * q.V * q.nchunks * 8;
-    uint32_t *base = (uint32_t *)ctx->rect_tab.ptr;
-    rt.dpad = dpad;
-    rt.stats = (int *)base;  // 16 dwords
-    rt.xw = base + 16;
-    rt.yr = rt.xw + nxw;
-    rt.xt = rt.yr + nyr;
-    rt.yt = rt.xt + nx;
-    rt.wt = rt.yt + ny;
-    rt.xmm = rt.wt + nw;
-    rt.ymm = rt.xmm + nx;
+    RectSizes z;
+    const size_t dpad = (size_t)q.nchunks * RX_PC;
+    z.nx = (size_t)q.tiles_x * q.V * dpad;
+    z.ny = (size_t)q.tiles_y * q.V * dpad;
+    z.nw = (size_t)q.V * dpad;
+    z.nxb = (size_t)q.tiles_x * q.V * q.nchunks;
+    z.nyb = (size_t)q.tiles_y * q.V * q.nchunks;
+    z.nxw = z.nxb * 32;
+    z.nyr = z.nyb * 16;
+    z.total = 16 + z.nxw + z.nyr + 2 * z.nx + 2 * z.ny + z.nw + z.nxb + z.nyb + 64;  // + slack: prefetches read whole 8-dword lanes past a Y record
+    return z;
 }
 
-static size_t rect_table_dwords(const SweepParams &q)
+static void rect_tables(mvs_ctx *ctx, const SweepParams &q, RectTables &rt)
 {
-    const int dpad = q.nchunks * RX_PC;
-    const size_t nx = (size_t)q.tiles_x * q.V * dpad, ny = (size_t)q.tiles_y * q.V * dpad, nw = (size_t)q.V * dpad;
-    return 16 + (size_t)q.tiles_x * q.V * q.nchunks * 32 + (size_t)q.tiles_y * q.V * q.nchunks * 8 + 2 * nx + 2 * ny + nw + 16;
+    const RectSizes z = rect_sizes(q);
+    uint32_t *base = (uint32_t *)ctx->rect_tab.ptr;
+    rt.dpad = q.nchunks * RX_PC;
+    rt.stats = (int *)base;  // 16 dwords
+    rt.xw = base + 16;
+    rt.yr = rt.xw + z.nxw;
+    rt.xt = rt.yr + z.nyr;
+    rt.yt = rt.xt + z.nx;
+    rt.wt = rt.yt + z.ny;
+    rt.xmm = rt.wt + z.nw;
+    rt.ymm = rt.xmm + z.nx;
+    rt.xbox = rt.ymm + z.ny;
+    rt.ybox = rt.xbox + z.nxb;
 }
+
+static size_t rect_table_dwords(const SweepParams &q) { return rect_sizes(q).total; }
 
 // Builds the tables for the current (views, planes) and decides whether the rectified kernel serves this plan: every view
 // eligible (host check on the f32 view matrices) and every region box within a slot shape the kernel is compiled for (counters of
@@ -666,7 +716,7 @@ int sweep_rect_plan(mvs_ctx *ctx)
     const size_t na = (size_t)(q.tiles_x + q.tiles_y + 1) * q.V * rt.dpad;
     plan_rect_axis<<<(unsigned)((na + 255) / 256), 256, 0, ctx->stream>>>(q, rt, (const uint32_t *)ctx->fx_lut.ptr);
     const size_t nb = (size_t)(q.tiles_x + q.tiles_y) * q.V * q.nchunks;
-    plan_rect_pack<<<(unsigned)((nb + 255) / 256), 256, 0, ctx->stream>>>(q, rt);
+    plan_rect_box<<<(unsigned)((nb + 255) / 256), 256, 0, ctx->stream>>>(q, rt);
     MVS_HIP(ctx, hipGetLastError());
     int stats[4] = {0, 0, 0, 0};
     MVS_HIP(ctx, hipMemcpyAsync(stats, rt.stats, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream));
@@ -681,14 +731,12 @@ int sweep_rect_plan(mvs_ctx *ctx)
     if (!rs || max_rw <= 0 || max_rh <= 0 || max_rh > 32) return MVS_OK;  // wide baselines / few planes: boxes too large for the slots
     const int units = rs / 4;
     const int instrs = div_up(max_rh * units, 64);  // 1 KiB copy instructions per region
-    const int ni = div_up(instrs, 4);
-    if (ni > RX_MAX_NI) return MVS_OK;
+    if (instrs > 4 * RX_MAX_NI || instrs * 1024 >= 16384) return MVS_OK;  // (the records hold 14-bit LDS offsets)
     ctx->rect_rs = rs;
-    ctx->rect_ni = ni;
-    ctx->rect_instrs = instrs;
     ctx->rect_slot_dw = instrs * 256;
     ctx->rect_dpad = rt.dpad;
-    ctx->rect_special = stats[2];
+    plan_rect_pack<<<(unsigned)((4 * nb + 255) / 256), 256, 0, ctx->stream>>>(q, rt, rs);
+    MVS_HIP(ctx, hipGetLastError());
     // the cold block (device memory, after the tables)
     RectCold cold;
     cold.main_img = (const uint8_t *)ctx->main_img.ptr;
