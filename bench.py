@@ -263,8 +263,6 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
     both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
-    sweep_kernel = "sweep_fx_tiled" if args.sampler == "fixed" else "sweep_tiled"
-
     from mvs_amd import dist as mdist
     vol_t = torch.empty(D * P, dtype=torch.int32, device="cuda")
     ctx.sweep_use_volume(vol_t.data_ptr(), vol_t.numel() * 4)
@@ -276,6 +274,8 @@ def main():
     # the single-GPU result of this rank's main view: the strong-scaling shardings must reproduce it bit for bit
     ctx.sweep_run(0, V, both)
     depth1 = ctx.sweep_fetch()[0]
+    # the kernel that serves this plan: the SURVEY 8d ring is rectified (plan shape 4: sweep_fx_rect), anything else the general tiled kernel
+    sweep_kernel = {1: "sweep_tiled", 2: "sweep_tiled", 3: "sweep_fx_tiled", 4: "sweep_fx_rect"}.get(ctx.plan_shape(), "sweep_fx_tiled")
     crc1 = zlib.crc32(np.ascontiguousarray(depth1).tobytes())
     depth_t = torch.as_tensor(ctx.depth_device_array(), device="cuda")
 

@@ -23,6 +23,8 @@
 //   argmin_volume     depth selection over the packed volume (after an optional cross-rank reduction)
 #include "sweep_shared.hpp"
 
+#include <cstdlib>
+
 namespace mvs {
 
 // t00h = t00 + 0.5 (exact): the rounding bias of the u8 conversion rides on the first term
@@ -791,6 +793,11 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
     if (view_first < 0 || view_count < 0 || view_first + view_count > ctx->V)
         return fail(ctx, MVS_EINVAL, "mvs_sweep_run: view range [%d,%d) outside 0..%d", view_first,
                     view_first + view_count, ctx->V);
+    // Only the documented bits of `flags` reach the kernels.  Bits 8-23 carry timing-experiment switches (debug bits, forced plane-split
+    // count: tools/exp_*.py, tests) and are honoured only when the process sets MVS_DEBUG_FLAGS=1: a caller's stray high bits must not
+    // change tile order, look-ahead or split counts silently.
+    static const bool debug_flags = getenv("MVS_DEBUG_FLAGS") != nullptr && atoi(getenv("MVS_DEBUG_FLAGS")) != 0;
+    if (!debug_flags) flags &= (MVS_SWEEP_VOLUME | MVS_SWEEP_FUSED_ARGMIN | MVS_SWEEP_FORCE_GENERIC | MVS_SWEEP_NO_RECT);
     const bool vol = flags & MVS_SWEEP_VOLUME, fused = flags & MVS_SWEEP_FUSED_ARGMIN;
     if (!vol && !fused) return fail(ctx, MVS_EINVAL, "mvs_sweep_run: flags select neither volume nor fused argmin");
     MVS_HIP(ctx, hipSetDevice(ctx->device));

@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace mvs {
@@ -44,7 +45,13 @@ namespace {
 constexpr float RX_MAGIC = 12582912.0f;  // 1.5 * 2^23 (FX_MAGIC of sweep_fx.hip)
 constexpr int RX_TILE_H = 8, RX_PC = 16, RX_KW = 4;  // tile rows, planes per chunk, planes per wavefront
 constexpr int RX_MAX_NI = 3;                          // copy instructions per wavefront and region, at most
-constexpr int RX_WAVES_PER_SIMD = 4;                  // launch bound: <= 128 VGPRs
+#ifndef RX_DOUBLE_BUFFER
+#define RX_DOUBLE_BUFFER 0
+#endif
+#ifndef RX_WAVES
+#define RX_WAVES 5
+#endif
+constexpr int RX_WAVES_PER_SIMD = RX_WAVES;                  // launch bound: <= 128 VGPRs
 
 enum RxMode : unsigned { RX_SKIP = 0, RX_FAST = 1, RX_BORDER = 2, RX_GENERIC = 3 };  // = FxMode (the plan is plan_regions_fx's)
 
@@ -416,11 +423,12 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     int bi[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        best[j] = 1u;  // (sum 1, count 0): "s * bc < bs * c" holds for the first cell with a view in frame, never for an empty one
+        best[j] = 0xffffffffu;  // plain comparison (chunk epilogue); the cross-multiplied one starts from (sum 1, count 0)
         bi[j] = -1;
 #pragma unroll
         for (int k = 0; k < RX_KW; k++) acc[j][k] = 0u;
     }
+    bool plain = true;    // depth selection: every cell so far carries the same count (see the chunk epilogue)
     uint32_t spacc = 0u;  // per plane of this wavefront (one byte each): views of the current chunk whose plane was NOT counted as a whole
 
     Cursor c2;  // region r + 2: the one whose records are fetched next
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
         const uint32_t special = (sum01 | sum23) & 0xc000c000u;
         {
             const uint32_t slot_byte = lds_base + slot_cur * 4u;
-            uint32_t qd[2][8];
+            uint32_t qd[RX_DOUBLE_BUFFER ? 2 : 1][8];
             // FULL planes (certificates hold, nothing out of frame): LDS base in M0 (ds_read_addtid_b32: M0 + offset + 4 lane, no
             // address register) and weight word in an SGPR; the reads of plane k + 1 are in flight while plane k is consumed.  LDS reads
             // return in order, so "at most 8 outstanding" means the older plane has landed; the loaded registers are operands of the
@@ -483,14 +491,22 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                     for (int j = 0; j < 8; j++) acc[j][k] = sad_u16(qd[buf][j], Im255[j], acc[j][k]);
                 }
             };
-            issue(0, 0);
-            issue(1, 1);
-            consume(0, 0, true);
-            issue(2, 0);
-            consume(1, 1, true);
-            issue(3, 1);
-            consume(2, 0, true);
-            consume(3, 1, false);
+            if (RX_DOUBLE_BUFFER) {
+                issue(0, 0);
+                issue(1, 1);
+                consume(0, 0, true);
+                issue(2, 0);
+                consume(1, 1, true);
+                issue(3, 1);
+                consume(2, 0, true);
+                consume(3, 1, false);
+            } else {  // 8 registers less; the other wavefronts of the SIMD cover the LDS latency
+#pragma unroll
+                for (int k = 0; k < RX_KW; k++) {
+                    issue(k, 0);
+                    consume(k, 0, false);
+                }
+            }
             // the other planes: part of the tile out of frame (MASKED), nothing in frame, or a certificate failed (SEMI)
             if (special) {
                 uintptr_t coldp = (uintptr_t)a.cold;
@@ -569,28 +585,51 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
             const int d0 = chunk * RX_PC + wave * RX_KW;
             const size_t P = (size_t)a.W * a.H;
             const uint32_t pix0 = 4u * (uint32_t)(row0 * a.W + col);  // byte offset of this lane's first pixel inside a plane
+            const int nrows = min(8, a.H - row0);
+            // While every plane of every chunk so far was FULL for every view, every cell carries the same count and the packed cells
+            // compare like their sums: "cell < best" (best starts at 0xffffffff) instead of the cross-multiplied comparison.  The
+            // first chunk with a plane that is not FULL ends that for the rest of the workgroup (same packed cells, start value 1).
+            if (FUSED && plain && spacc != 0u) {
+                plain = false;
 #pragma unroll
-            for (int k = 0; k < RX_KW; k++) {
-                const uint32_t cntk = ((uint32_t)a.vcount - ((spacc >> (8 * k)) & 0xffu)) << 24;  // FULL planes: every cell gets the view's count
-                if (d0 + k < a.D) {
-                    // one resource per plane (a volume can exceed the 4 GiB a resource spans), rows by the wave-uniform offset
-                    const __amdgpu_buffer_rsrc_t rvol = make_rsrc(WRITE_VOLUME ? a.volume + (size_t)(d0 + k) * P : nullptr, 0xffffffffu);
+                for (int j = 0; j < 8; j++) best[j] = bi[j] < 0 ? 1u : best[j];
+            }
+            auto finish = [&](auto checked_rows, auto plain_compare) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        if (col_ok && row0 + j < a.H) {
-                            const uint32_t cell = acc[j][k] + cntk;
-                            if (WRITE_VOLUME) __builtin_amdgcn_raw_buffer_store_b32(cell, rvol, pix0, 4u * (uint32_t)(j * a.W), 2);  // nt: written once, read by a later kernel
-                            if (FUSED) {
-                                const bool better = umul24u(cell & 0xffffffu, best[j] >> 24) < umul24u(best[j] & 0xffffffu, cell >> 24);
-                                best[j] = better ? cell : best[j];
-                                bi[j] = better ? d0 + k : bi[j];
+                for (int k = 0; k < RX_KW; k++) {
+                    const uint32_t cntk = ((uint32_t)a.vcount - ((spacc >> (8 * k)) & 0xffu)) << 24;  // FULL planes: every cell gets the view's count
+                    if (d0 + k < a.D) {
+                        // one resource per plane (a volume can exceed the 4 GiB a resource spans), rows by the wave-uniform offset
+                        const __amdgpu_buffer_rsrc_t rvol = make_rsrc(WRITE_VOLUME ? a.volume + (size_t)(d0 + k) * P : nullptr, 0xffffffffu);
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            if (!checked_rows.value || j < nrows) {
+                                const uint32_t cell = acc[j][k] + cntk;
+                                if (WRITE_VOLUME) __builtin_amdgcn_raw_buffer_store_b32(cell, rvol, pix0, 4u * (uint32_t)(j * a.W), 2);  // nt: written once, read by a later kernel
+                                if (FUSED) {
+                                    const bool better = plain_compare.value ? cell < best[j] : umul24u(cell & 0xffffffu, best[j] >> 24) < umul24u(best[j] & 0xffffffu, cell >> 24);
+                                    best[j] = better ? cell : best[j];
+                                    bi[j] = better ? d0 + k : bi[j];
+                                }
                             }
                         }
                     }
                 }
+            };
+            if (col_ok) {
+                if (nrows == 8 && plain)
+                    finish(std::false_type{}, std::true_type{});
+                else if (nrows == 8)
+                    finish(std::false_type{}, std::false_type{});
+                else if (plain)
+                    finish(std::true_type{}, std::true_type{});
+                else
+                    finish(std::true_type{}, std::false_type{});
+            }
+#pragma unroll
+            for (int k = 0; k < RX_KW; k++)
 #pragma unroll
                 for (int j = 0; j < 8; j++) acc[j][k] = 0u;
-            }
             spacc = 0u;
         }
 

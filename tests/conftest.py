@@ -9,6 +9,10 @@ try:   # before libmvs_hip.so is loaded: the library must bind to the HIP runtim
 except ImportError:
     pass
 
+# the sweep's timing-experiment flag bits (flags >> 8: debug switches, forced plane-split counts) are masked off by the library unless
+# this is set; several parity tests drive the kernels through them (bit-identical results are the point of those tests)
+os.environ.setdefault("MVS_DEBUG_FLAGS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

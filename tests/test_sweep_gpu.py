@@ -215,11 +215,14 @@ def test_c3_full_size_properties(sampler):
         np.testing.assert_array_equal(c_t, c_g)
         # (3) exact sampler: the other thread shape of the tiled kernel (the planner picks 2 x 32 here), index for index;
         #     fixed sampler: the general-camera code path (per-sample reciprocal) on this plane-independent-w geometry
-        assert ctx.plan_shape() == (1 if sampler == "exact" else 3)
-        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN | ((8 if sampler == "exact" else 4) << 8))
-        d_s, c_s, i_s, _ = ctx.sweep_fetch()
-        np.testing.assert_array_equal(i_t, i_s)
-        np.testing.assert_array_equal(c_t, c_s)
+        #     (the ring is rectified: the fixed sampler's runs above took sweep_fx_rect, plan shape 4; here the general tiled kernel,
+        #     with and without its plane-independent-w shortcut)
+        assert ctx.plan_shape() == (1 if sampler == "exact" else 4)
+        for extra in ((8 << 8,) if sampler == "exact" else (mvs_amd.MVS_SWEEP_NO_RECT, mvs_amd.MVS_SWEEP_NO_RECT | (4 << 8))):
+            ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN | extra)
+            d_s, c_s, i_s, _ = ctx.sweep_fetch()
+            np.testing.assert_array_equal(i_t, i_s)
+            np.testing.assert_array_equal(c_t, c_s)
         # (4) linearity over views, as a checksum of the packed cells: shards [0,8) and [8,16) add up to the full volume
         ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME)
         full = int(ctx.sweep_fetch(want_volume=True)[3].sum(dtype=np.uint64))
@@ -462,7 +465,8 @@ def test_plane_split_launches_are_bit_identical(sampler):
             ctx.sweep_argmin()                                   # reference: separate pass over the volume
             d0, c0, i0, v0 = [a.copy() for a in ctx.sweep_fetch(want_volume=True)]
             for forced in (1, 2, 3, 5, 9):
-                for flags in (both, mvs_amd.MVS_SWEEP_FUSED_ARGMIN):
+                # (the ring is rectified: with the fixed sampler `both` takes sweep_fx_rect; NO_RECT keeps the general tiled kernel covered)
+                for flags in (both, mvs_amd.MVS_SWEEP_FUSED_ARGMIN, both | mvs_amd.MVS_SWEEP_NO_RECT, mvs_amd.MVS_SWEEP_FUSED_ARGMIN | mvs_amd.MVS_SWEEP_NO_RECT):
                     ctx.sweep_run(0, 0, both)
                     ctx.sweep_run(0, V, flags | (forced << 16))
                     d, c, i, v = ctx.sweep_fetch(want_volume=bool(flags & mvs_amd.MVS_SWEEP_VOLUME))
@@ -517,8 +521,12 @@ def test_plane_independent_w_path_is_bit_identical(oracle, sampler):
         ref = oracle.sweep(main_cam, main_img, cams, sides, D, want_volume=True, nthreads=8, sampler=sampler)
         fast = _gpu_sweep(W, H, main_cam, main_img, cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN, sampler=sampler)
         general = _gpu_sweep(W, H, main_cam, main_img, cams, sides, D,
-                             mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | (4 << 8), sampler=sampler)
+                             mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | mvs_amd.MVS_SWEEP_NO_RECT | (4 << 8), sampler=sampler)
         np.testing.assert_array_equal(fast[3], general[3])
+        # (fixed sampler, ring cameras: `fast` above is the rectified kernel; the general kernel's hoisted-reciprocal path on its own)
+        shortcut = _gpu_sweep(W, H, main_cam, main_img, cams, sides, D,
+                              mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN | mvs_amd.MVS_SWEEP_NO_RECT, sampler=sampler)
+        np.testing.assert_array_equal(shortcut[3], general[3])
         _check(fast, ref, D)
 
 

@@ -1,7 +1,9 @@
 """In-process timings of the rectified-view kernel (sweep_fx_rect) against the general tiled kernel on the SURVEY 8d ring.
     python tools/exp_rect.py [c1|c2|c3|c4|c5] [--check]
 Environment: MVS_RECT_SLOTS=S (LDS slots = look-ahead + 1)."""
-import sys, os, time
+import sys, os
+os.environ.setdefault("MVS_DEBUG_FLAGS", "1")  # the library masks the experiment bits of `flags` otherwise
+import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
 import numpy as np

@@ -1,6 +1,7 @@
 """One table of resident sweep times (volume + fused depth selection, frames in HBM) for the BASELINE shapes and both samplers, ring geometry
 (plane-independent w) and the same with that shortcut disabled (the path general cameras take): python tools/perf_snapshot.py > out.json"""
 import json, os, sys, time
+os.environ.setdefault("MVS_DEBUG_FLAGS", "1")  # the library masks the experiment bits of `flags` otherwise
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
 import numpy as np
@@ -32,7 +33,7 @@ for name, (W, H, D, V) in SHAPES.items():
         with mvs_amd.Context(W, H, sampler=sampler) as ctx:
             ctx.sweep_set(mc, mi, sc, si, D)
             timeit(ctx, V, both, n)  # clocks
-            ms, ms_general, ms_fused = timeit(ctx, V, both, n), timeit(ctx, V, both | (4 << 8), n), timeit(ctx, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN, n)
+            ms, ms_general, ms_fused = timeit(ctx, V, both, n), timeit(ctx, V, both | mvs_amd.MVS_SWEEP_NO_RECT | (4 << 8), n), timeit(ctx, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN, n)
         samples = float(W) * H * D * V
         out["%s %s" % (name, sampler)] = {"shape": [W, H, D, V], "ms": round(ms, 4), "T_samples_per_s": round(samples / ms / 1e9, 3),
                                           "ms_general_cameras": round(ms_general, 4), "ms_depth_only_no_volume": round(ms_fused, 4)}
