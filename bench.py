@@ -160,22 +160,22 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
         dt = float(tt.item())
     if rank == 0:
         sweep_ms = ms_sum[mvs_amd.MVS_K_SWEEP] / max(1, launches[mvs_amd.MVS_K_SWEEP])
-        # SURVEY 8(d) bytes, the same formula as the resident bench (the read-back of the volume is in it although mvs_sweep with
-        # volume = NULL selects the depth in the sweep kernel and writes no volume at all: the figure is algorithmic, not traffic)
-        sweep_bytes = float(P) * (V + 8.0 * D + 9.0)
+        # this entry writes no volume (depth selection inside the sweep kernel): the fused lower bound of SURVEY 8(d), P (V + 1) image
+        # bytes + 8 P of depth and best cost -- not the P (V + 8 D + 9) of the resident bench, which would overstate this path's rate
+        sweep_bytes = float(P) * (V + 1.0) + 8.0 * P
         achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         print(json.dumps({
             "metric": "cost-volume samples/sec (pixels x planes x views)", "value": float(P) * D * V * world / (dt / args.steps),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": None if world == 1 else "weak", "vs_baseline": None,
             "dtype": DTYPE[args.sampler],
             "data": "synthetic frames on the cameras of tracks/zatisi.yaml" + (" [TEST HOOK: ranks share one GPU over gloo]" if same_device else ""),
             "config": {"workload": "c5: zatisi.yaml %d frames, 640x480, %d planes, %d side views per main frame, one main frame per step "
                                    "through mvs_sweep (host frames in, host depth out: PCIe and per-frame planning included)" % (nframes, D, V),
-                       "sampler": args.sampler, "shard": "frames", "frames_per_rank": len(mine), "plan_shape": shape, "device": ctx.info()},
-            "roofline": {"bound": "hbm", "kernel": "sweep_fx_tiled" if args.sampler == "fixed" else "sweep_tiled", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "sampler": args.sampler, "shard": None if world == 1 else "frames", "frames_per_rank": len(mine), "plan_shape": shape, "device": ctx.info()},
+            "roofline": {"bound": "hbm", "kernel": {1: "sweep_tiled", 2: "sweep_tiled", 3: "sweep_fx_tiled", 4: "sweep_fx_rect"}.get(shape), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": sweep_bytes, "ms_per_launch": sweep_ms,
-                         "valu_bound_note": "VALU-issue bound, see DESIGN.md section 4"},
+                         "bytes_formula": "P (V + 1) + 8 P: no volume is materialised on this path (SURVEY.md 8d, fused lower bound)"},
             "depth_in_frame_fraction": float((depth != 1.0).mean())}), flush=True)
     ctx.close()
     if dist is not None:
@@ -408,20 +408,82 @@ def main():
         torch.cuda.synchronize()
         fused_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
-    # the spec'd ring geometry (parallel axes, centres in the main focal plane) takes the plane-independent-w path
-    # (reciprocal hoisted out of the plane loop); time the general path on the same data too (undocumented debug bit 2 << 8)
-    general_ms = None
-    if world == 1 and not args.no_extras:
-        gflags = both | (4 << 8)
-        for _ in range(2):
-            ctx.sweep_run(0, V, gflags)
+    def time_resident(c, flags, n):
+        for _ in range(3):
+            c.sweep_run(0, V, flags)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            ctx.sweep_run(0, V, gflags)
+        for _ in range(n):
+            c.sweep_run(0, V, flags)
         torch.cuda.synchronize()
-        general_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        ctx.sweep_run(0, V, both)
+        return (time.perf_counter() - t1) / n * 1e3
+
+    def general_cameras():
+        """the ring's cameras, each turned by a few milliradians about two axes (yaw = 0.012 cos a, pitch = 0.012 sin a): no view is
+        rectified against the main view any more, so the sweep takes the general tiled kernel with its per-sample reciprocal -- the
+        rate for rotated / forward-moving cameras such as the bundled tracks.  Timing only: the frames stay those of the ring."""
+        cams = []
+        for vi in range(V):
+            ang = 2.0 * np.pi * vi / max(V, 1)
+            yaw, pitch = 0.012 * np.cos(ang), 0.012 * np.sin(ang)
+            cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+            rot = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+            cams.append(synth.camera_at([radius * np.cos(ang), radius * np.sin(ang), 0.0], W, H, rot=rot))
+        return np.stack(cams)
+
+    # co-headline: the same frames under general (rotated) cameras; and the exact-f32 sampler on both geometries
+    general_ms = exact = disagreement = sustained = None
+    if world == 1 and not args.no_extras:
+        other = "exact" if args.sampler == "fixed" else "fixed"
+        gcams = general_cameras()
+        with mvs_amd.Context(W, H, local_rank, sampler=args.sampler) as gctx:
+            gctx.set_stream(stream.cuda_stream)
+            gctx.sweep_set(main_cam, main_img, gcams, sides, D)
+            time_resident(gctx, both, 20)
+            general_ms = time_resident(gctx, both, args.steps)
+            general_kernel = {1: "sweep_tiled", 2: "sweep_tiled", 3: "sweep_fx_tiled", 4: "sweep_fx_rect"}.get(gctx.plan_shape())
+            gctx.set_sampler(other)
+            other_general_ms = time_resident(gctx, both, args.steps)
+        with mvs_amd.Context(W, H, local_rank, sampler=other) as octx2:
+            octx2.set_stream(stream.cuda_stream)
+            octx2.sweep_set(main_cam, main_img, side_cams, sides, D)
+            time_resident(octx2, both, 20)
+            other_ms = time_resident(octx2, both, args.steps)
+            octx2.sweep_run(0, V, both)
+            d_o, c_o, i_o, _ = octx2.sweep_fetch()
+        d_p, c_p, i_p, _ = ctx.sweep_fetch()
+        other_block = {"sampler": other, "ms_per_step": other_ms, "samples_per_s": float(P) * D * V / (other_ms * 1e-3),
+                       "roofline_frac": float(P) * (V + 8.0 * D + 9.0) / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "general_cameras_ms_per_step": other_general_ms}
+        exact = other_block if other == "exact" else {"sampler": "exact", "ms_per_step": primary["ms_per_step"], "note": "this run's primary sampler"}
+        # how far the two samplers are apart on the bench's own inputs (depth maps of the two contexts, both resident-path results)
+        valid = (i_p >= 0) & (i_o >= 0)
+        flips = valid & (i_p != i_o)
+        dd = (d_p.astype(np.float64) - d_o.astype(np.float64))[valid]
+        both_fin = np.isfinite(c_p) & np.isfinite(c_o)
+        disagreement = {
+            "samplers": [args.sampler, other], "pixels": int(valid.sum()),
+            "plane_flip_rate": float(flips.sum()) / max(1, int(valid.sum())),
+            "plane_flip_rate_more_than_one_plane": float((valid & (np.abs(i_p - i_o) > 1)).sum()) / max(1, int(valid.sum())),
+            "depth_rmse_between_samplers": float(np.sqrt(np.mean(dd * dd))) if dd.size else 0.0,
+            "mean_abs_best_cost_difference_grey_levels": float(np.mean(np.abs(c_p[both_fin].astype(np.float64) - c_o[both_fin].astype(np.float64)))),
+            "plane_step": 2.0 / D,
+            "note": "both samplers are bit-exact against their own CPU oracle (tests/); this block is what choosing one over the other costs (DESIGN.md section 2)"}
+        if gt is not None:
+            inner = np.s_[16:-16, 16:-16]
+            disagreement["depth_rmse_vs_ground_truth"] = {args.sampler: float(np.sqrt(np.mean((d_p[inner].astype(np.float64) - gt[inner]) ** 2))),
+                                                           other: float(np.sqrt(np.mean((d_o[inner].astype(np.float64) - gt[inner]) ** 2)))}
+        # throttling check beside the short timed window: the same step back to back for >= 2 s
+        n_sus = int(max(300, np.ceil(2000.0 / max(primary["ms_per_step"], 1e-3))))
+        torch.cuda.synchronize()
+        marks = [time.perf_counter()]
+        for lo, hi in ((0, 100), (100, n_sus - 100), (n_sus - 100, n_sus)):
+            for _ in range(lo, hi):
+                ctx.sweep_run(0, V, both)
+            torch.cuda.synchronize()
+            marks.append(time.perf_counter())
+        sustained = {"steps": n_sus, "seconds": marks[-1] - marks[0], "ms_per_step": (marks[-1] - marks[0]) / n_sus * 1e3,
+                     "first_100_steps_ms": (marks[1] - marks[0]) / 100 * 1e3, "last_100_steps_ms": (marks[3] - marks[2]) / 100 * 1e3}
 
     # the one-call entry (host frames in, host depth out: PCIe, padding and planning inside the call) -- reported beside, never as `value`
     onecall_ms = None
@@ -463,21 +525,20 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_ramp_steps": CLOCK_RAMP_STEPS,
             "ms_per_step": primary["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak" if shard == "frames" else "strong",
+            "scaling": None if world == 1 else ("weak" if shard == "frames" else "strong"),
             "vs_baseline": None,
             "dtype": DTYPE[args.sampler],
             "data": "synthetic (%s)" % args.data + (" [TEST HOOK: ranks share one GPU over gloo -- not a measurement]" if same_device else ""),
             "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V),
-                       "sampler": args.sampler, "shard": shard, "collective": args.collective if shard == "views" else ("all_gather of depth rows" if shard == "rows" and world > 1 else None),
+                       "sampler": args.sampler, "shard": None if world == 1 else shard, "collective": args.collective if shard == "views" else ("all_gather of depth rows" if shard == "rows" and world > 1 else None),
                        "views_per_rank": primary["views"], "rows_per_rank": [n for _, n in bands] if shard == "rows" else None,
                        "collective_bytes_per_rank_per_step": primary["collective_bytes_per_rank"], "alternatives": alternatives, "device": ctx.info()},
             "roofline": {"bound": "hbm", "kernel": sweep_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
-                         "valu_bound_note": "VALU-issue bound, see DESIGN.md section 4 and profiles/",
+                         "bound_note": "the rectified-view kernel issues ~3.4 vector and ~3.3 scalar instructions per wave-sample; what bounds it is in DESIGN.md section 4 and profiles/",
                          "valu_utilisation": traffic["valu_utilisation"] if traffic else None,   # from the same PMC summary as `traffic`
-                         "valu_utilisation_note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel cycles): the counter charges every VALU instruction a "
-                                                  "4-cycle slot; with the measured 2- and 4-cycle instruction classes the VALU is busy ~60 % (DESIGN.md section 4)",
+                         "valu_utilisation_note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel cycles) from the PMC summary named in traffic_source",
                          "bytes_per_launch": sweep_bytes, "bytes_formula": "P (V_loc + 8 D + 9), SURVEY.md 8(d)", "ms_per_launch": sweep_ms},
             "kernels": {"sweep_ms": sweep_ms, "argmin_ms": argmin_ms if separate else None,
                         "argmin_GBps": argmin_bytes / (argmin_ms * 1e-3) / 1e9 if argmin_ms > 0 else None,
@@ -490,9 +551,17 @@ def main():
         }
         if general_ms is not None:
             out["general_camera_path"] = {
-                "ms_per_step": general_ms, "samples_per_s": float(P) * D * V / (general_ms * 1e-3),
-                "note": "same data with the plane-independent-w shortcut disabled: the rate for side cameras that are "
-                        "rotated or displaced along the optical axis (DESIGN.md section 4)"}
+                "ms_per_step": general_ms, "samples_per_s": float(P) * D * V / (general_ms * 1e-3), "kernel": general_kernel,
+                "roofline_frac": sweep_bytes / (general_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "same frames, side cameras turned by 12 mrad about two axes: no view is rectified any more, the general tiled kernel "
+                        "with its per-sample reciprocal runs -- the rate for rotated / forward-moving cameras such as the bundled tracks "
+                        "(timing only; DESIGN.md section 4)"}
+        if exact is not None:
+            out["exact_sampler"] = exact
+        if disagreement is not None:
+            out["sampler_disagreement"] = disagreement
+        if sustained is not None:
+            out["sustained"] = sustained
         if onecall_ms is not None:
             out["one_call_mvs_sweep"] = {"ms_per_call": onecall_ms, "samples_per_s": float(P) * D * V / (onecall_ms * 1e-3),
                                          "note": "host frames in, host depth out (PCIe, quad images and region planning inside the call); never reported as `value`"}

@@ -267,7 +267,7 @@ class Context:
         cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((0, 4, 4), np.float32)
         frames = [_u8(s, (H, W)) for s in side_imgs]
         arr = (_u8p * max(V, 1))(*[_ptr(f, _u8p) for f in frames])
-        depth = np.empty((H, W), np.float32) if getattr(self, "_pinned_depth", None) is None else self._pinned_depth
+        depth = np.empty((H, W), np.float32)
         cost = np.empty((H, W), np.float32) if want_cost else None
         vol = np.empty((nplanes, H, W), np.float32) if want_volume else None
         self._check(self.lib.mvs_sweep(self.h, _ptr(cam, _fp), _ptr(img, _u8p), V, _ptr(cams, _fp), arr, int(nplanes),
