@@ -14,7 +14,7 @@ import json
 import sys
 
 # kernels whose reads are 16 bytes per lane: argmin_volume streams uint4; sweep_fx_tiled fills LDS with global_load_lds_dwordx4
-WIDE_READERS = ("void mvs::argmin_volume<4", "void mvs::sweep_fx_tiled", "void mvs::sweep_tiled")
+WIDE_READERS = ("void mvs::argmin_volume<4", "void mvs::sweep_fx_tiled", "void mvs::sweep_tiled", "void mvs::sweep_fx_rect")
 
 
 def main():
