@@ -131,35 +131,60 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
     mine = mdist.frame_shard(nframes, rank, world) or [0]
     side_cams = [np.stack([cams[j] for j in sides_of(f)]) for f in range(nframes)]
     ctx = mvs_amd.Context(W, H, local_rank, sampler=args.sampler)
+    batch = max(1, args.batch)
+    batched = args.sampler == "fixed" and not args.onecall
 
-    def step(i):
-        f = mine[i % len(mine)]
-        ids = sides_of(f)
-        return ctx.sweep(cams[f], frame(f), side_cams[f], [frame(j) for j in ids], D)
+    def run_frames(mains):
+        """the main frames `mains` of this rank: batched = the frames they touch go up once (frame store), then mvs_sweep_batch over
+        `batch` main frames per launch; one-call = mvs_sweep per main frame (every frame re-uploaded by each main frame that uses it)"""
+        depth = None
+        if batched:
+            need = sorted(set(mains) | set(j for f in mains for j in sides_of(f)))
+            for j in need:
+                ctx.frame_upload(j, frame(j))
+            for i in range(0, len(mains), batch):
+                mb = mains[i:i + batch]
+                depth = ctx.sweep_batch(mb, np.stack([cams[f] for f in mb]), np.array([sides_of(f) for f in mb], np.int32),
+                                        np.stack([side_cams[f] for f in mb]), D, out=out_pinned[:len(mb)])[len(mb) - 1]
+        else:
+            for f in mains:
+                depth = ctx.sweep(cams[f], frame(f), side_cams[f], [frame(j) for j in sides_of(f)], D)
+        return depth
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-    for i in range(CLOCK_RAMP_STEPS + args.warmup):   # untimed: clock ramp, then the warm-up steps asked for
-        step(i)
+    out_pinned = None
+    if batched:
+        ctx.frame_store(nframes)
+        out_pinned = mvs_amd.pinned_array((batch, H, W), np.float32)   # page-locked result buffer (mvs_host_alloc), reused by every batch
+    seq = [mine[i % len(mine)] for i in range(CLOCK_RAMP_STEPS + args.warmup + args.steps)]
+    run_frames(seq[:CLOCK_RAMP_STEPS + args.warmup])   # untimed: clock ramp, then the warm-up steps asked for
     barrier()
     ctx.profile_enable(True)
     ctx.profile_read(reset=True)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        depth = step(CLOCK_RAMP_STEPS + args.warmup + i)
+    depth = run_frames(seq[CLOCK_RAMP_STEPS + args.warmup:])
     barrier()
     dt = time.perf_counter() - t0
     ms_sum, launches = ctx.profile_read(reset=True)
     shape = ctx.plan_shape()
+    onecall_ms = None
+    if batched and world == 1 and not args.no_extras:   # the same main frames through the one-call entry, for comparison
+        some = seq[CLOCK_RAMP_STEPS + args.warmup:][:min(args.steps, 30)]
+        t1 = time.perf_counter()
+        for f in some:
+            ctx.sweep(cams[f], frame(f), side_cams[f], [frame(j) for j in sides_of(f)], D)
+        onecall_ms = (time.perf_counter() - t1) / len(some) * 1e3
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank == 0:
-        sweep_ms = ms_sum[mvs_amd.MVS_K_SWEEP] / max(1, launches[mvs_amd.MVS_K_SWEEP])
+        per_launch = batch if batched else 1
+        sweep_ms = ms_sum[mvs_amd.MVS_K_SWEEP] / max(1, launches[mvs_amd.MVS_K_SWEEP]) / per_launch   # per main frame
         # this entry writes no volume (depth selection inside the sweep kernel): the fused lower bound of SURVEY 8(d), P (V + 1) image
         # bytes + 8 P of depth and best cost -- not the P (V + 8 D + 9) of the resident bench, which would overstate this path's rate
         sweep_bytes = float(P) * (V + 1.0) + 8.0 * P
@@ -170,10 +195,13 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": None if world == 1 else "weak", "vs_baseline": None,
             "dtype": DTYPE[args.sampler],
             "data": "synthetic frames on the cameras of tracks/zatisi.yaml" + (" [TEST HOOK: ranks share one GPU over gloo]" if same_device else ""),
-            "config": {"workload": "c5: zatisi.yaml %d frames, 640x480, %d planes, %d side views per main frame, one main frame per step "
-                                   "through mvs_sweep (host frames in, host depth out: PCIe and per-frame planning included)" % (nframes, D, V),
+            "config": {"workload": "c5: zatisi.yaml %d frames, 640x480, %d planes, %d side views per main frame, one main frame per step; " % (nframes, D, V) +
+                                   ("frame store + mvs_sweep_batch, %d main frames per launch (host frames in once, host depth out: PCIe and per-frame planning included)" % batch
+                                    if batched else "mvs_sweep per main frame (host frames in, host depth out: PCIe and per-frame planning included)"),
+                       "entry": "mvs_sweep_batch" if batched else "mvs_sweep", "main_frames_per_launch": batch if batched else 1,
+                       "one_call_mvs_sweep_ms_per_main_frame": onecall_ms,
                        "sampler": args.sampler, "shard": None if world == 1 else "frames", "frames_per_rank": len(mine), "plan_shape": shape, "device": ctx.info()},
-            "roofline": {"bound": "hbm", "kernel": {1: "sweep_tiled", 2: "sweep_tiled", 3: "sweep_fx_tiled", 4: "sweep_fx_rect"}.get(shape), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "sweep_fx_tiled_batch" if batched else {1: "sweep_tiled", 2: "sweep_tiled", 3: "sweep_fx_tiled", 4: "sweep_fx_rect"}.get(shape), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": sweep_bytes, "ms_per_launch": sweep_ms,
                          "bytes_formula": "P (V + 1) + 8 P: no volume is materialised on this path (SURVEY.md 8d, fused lower bound)"},
             "depth_in_frame_fraction": float((depth != 1.0).mean())}), flush=True)
@@ -195,6 +223,8 @@ def main():
     ap.add_argument("--sampler", default="fixed", choices=["fixed", "exact"],
                     help="texture-fetch arithmetic (include/mvs.h): fixed = 1/32-texel positions + 8-bit weight table (library default), "
                          "exact = f32 bilinear rounded to u8")
+    ap.add_argument("--batch", type=int, default=8, help="--config c5: main frames per mvs_sweep_batch launch")
+    ap.add_argument("--onecall", action="store_true", help="--config c5: mvs_sweep per main frame instead of the frame store + mvs_sweep_batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused", action="store_true", help="also time the no-volume variant (depth only)")
     ap.add_argument("--separate-argmin", action="store_true",

@@ -196,6 +196,23 @@ int mvs_sweep_fetch(mvs_ctx *ctx, float *depth_hw, float *cost_hw, int32_t *inde
 /* read back the f32 view matrices the sweep uses (nviews*12), for parity checks */
 int mvs_sweep_view_matrices(mvs_ctx *ctx, float *q_out);
 
+/* ---- a sequence on one GPU: frames uploaded once, several main frames per launch (recon.cpp:65-117) -------------------------
+ * The reference sweeps every chosen main frame against a handful of neighbouring frames; through mvs_sweep each frame of the
+ * sequence crosses PCIe once per main frame that uses it, and a 640 x 480 frame leaves most of the chip idle.  The frame store keeps
+ * every frame of the sequence resident (raw, wrap-padded and as quad image: 9 bytes per pixel); mvs_sweep_batch then sweeps nmain
+ * main frames, each against its own nside side views -- all of them slots of the store -- in ONE launch of the general tiled kernel
+ * (fixed sampler) and returns the nmain depth maps (and best costs) tightly packed.  Results are bit-identical to mvs_sweep on the
+ * same frames and cameras.
+ *   mvs_frame_store(ctx, capacity)   sizes the store (1..8191 frames); re-sizing empties it
+ *   mvs_frame_upload(ctx, slot, f)   copies frame f (H*W u8) into a slot and prepares it (asynchronous; `f` must stay valid until the
+ *                                    next synchronising call on the context, e.g. mvs_sweep_batch or mvs_synchronize)
+ *   mvs_sweep_batch(...)             main_slots[nmain], main_cams[nmain*16], side_slots[nmain*nside], side_cams[nmain*nside*16];
+ *                                    depth_out[nmain*H*W], cost_out nullable; synchronises */
+int mvs_frame_store(mvs_ctx *ctx, int capacity);
+int mvs_frame_upload(mvs_ctx *ctx, int slot, const uint8_t *frame_hw);
+int mvs_sweep_batch(mvs_ctx *ctx, int nmain, const int *main_slots, const float *main_cams, int nside, const int *side_slots,
+                    const float *side_cams, int nplanes, float z_lo, float z_hi, float *depth_out, float *cost_out);
+
 /* ---- one main view on several GPUs of one node (SURVEY.md section 8b "multi-GPU", north_star) ----------------------------------
  * A communicator owns one context per listed device and one RCCL communicator across them (librccl is loaded when the first
  * communicator is created; the library has no link dependency on it).  mvs_sweep_sharded deals the side views to the GPUs, every

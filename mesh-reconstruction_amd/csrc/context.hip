@@ -220,7 +220,8 @@ void mvs_destroy(mvs_ctx *ctx)
     DevBuf *bufs[] = {&ctx->main_img, &ctx->side_pads, &ctx->qmats, &ctx->ztab, &ctx->plan, &ctx->upload,
                       &ctx->volume_own, &ctx->depth, &ctx->cost, &ctx->index, &ctx->soup, &ctx->r_zbuf,
                       &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2,
-                      &ctx->cubic_tab, &ctx->flow_arena, &ctx->frame_buf, &ctx->best_parts, &ctx->plan_stats, &ctx->probe_buf, &ctx->filter_sort, &ctx->raster_bins, &ctx->fx_lut, &ctx->side_quads, &ctx->side_quads16};
+                      &ctx->cubic_tab, &ctx->flow_arena, &ctx->frame_buf, &ctx->best_parts, &ctx->plan_stats, &ctx->probe_buf, &ctx->filter_sort, &ctx->raster_bins, &ctx->fx_lut, &ctx->side_quads, &ctx->side_quads16,
+                      &ctx->rect_tab, &ctx->store_raw, &ctx->store_pads, &ctx->store_quads, &ctx->batch_buf};
     for (int i = 0; i < 2; i++)
         if (ctx->flow_graph[i]) (void)hipGraphExecDestroy(ctx->flow_graph[i]);
     for (DevBuf *b : bufs)
@@ -355,6 +356,44 @@ int sweep_upload_frames_impl(mvs_ctx *ctx, const uint8_t *const *side_frames)
     return MVS_OK;
 }
 
+// ---- frame store ---------------------------------------------------------------------------------------------------------------
+int frame_store_impl(mvs_ctx *ctx, int capacity)
+{
+    if (!ctx || capacity < 1 || capacity > 8191) return fail(ctx, MVS_EINVAL, "mvs_frame_store: capacity %d out of range 1..8191", capacity);
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->W, H = ctx->H;
+    const size_t P = (size_t)W * H;
+    const int pitch = ((W + 2 + 63) / 64) * 64;
+    const size_t slab = (size_t)pitch * (H + 2);
+    if (ctx->have_views && (ctx->pad_pitch != pitch || ctx->pad_slab != slab)) return fail(ctx, MVS_ESTATE, "mvs_frame_store: inconsistent padding geometry");
+    int rc;
+    if ((rc = ensure(ctx, ctx->store_raw, P * capacity))) return rc;
+    if ((rc = ensure(ctx, ctx->store_pads, slab * capacity + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->store_quads, slab * capacity * sizeof(uint32_t) + 4096))) return rc;
+    ctx->store_cap = capacity;
+    ctx->store_have.assign((size_t)capacity, 0);  // (a growing store starts empty: the buffers may have moved)
+    return MVS_OK;
+}
+
+int frame_upload_impl(mvs_ctx *ctx, int slot, const uint8_t *frame_hw)
+{
+    if (!ctx || !frame_hw) return fail(ctx, MVS_EINVAL, "mvs_frame_upload: null argument");
+    if (slot < 0 || slot >= ctx->store_cap) return fail(ctx, MVS_EINVAL, "mvs_frame_upload: slot %d outside the store (capacity %d: mvs_frame_store first)", slot, ctx->store_cap);
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->W, H = ctx->H;
+    const size_t P = (size_t)W * H;
+    const int pitch = ((W + 2 + 63) / 64) * 64;
+    const size_t slab = (size_t)pitch * (H + 2);
+    uint8_t *raw = (uint8_t *)ctx->store_raw.ptr + P * slot;
+    MVS_HIP(ctx, hipMemcpyAsync(raw, frame_hw, P, hipMemcpyHostToDevice, ctx->stream));
+    const dim3 grid(div_up(pitch, 256), H + 2, 1);
+    pad_wrap_views_kernel<<<grid, 256, 0, ctx->stream>>>(raw, (uint8_t *)ctx->store_pads.ptr + slab * slot, W, H, pitch, P, slab);
+    quad_image_views_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)ctx->store_pads.ptr + slab * slot, (uint32_t *)ctx->store_quads.ptr + slab * slot, W, H, pitch, slab);
+    MVS_HIP(ctx, hipGetLastError());
+    ctx->store_have[slot] = 1;
+    return MVS_OK;
+}
+
 int sweep_set_views_impl(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames, bool sync, bool defer_frames)
 {
     if (!ctx || nviews < 0 || nviews > 256 || (nviews > 0 && (!side_cams || !side_frames)))
@@ -413,6 +452,9 @@ int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const 
     return sweep_set_views_impl(ctx, nviews, side_cams, side_frames, true, false);
 }
 int mvs_sweep_set_planes(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi) { return sweep_set_planes_impl(ctx, nplanes, z_lo, z_hi, true); }
+
+int mvs_frame_store(mvs_ctx *ctx, int capacity) { return frame_store_impl(ctx, capacity); }
+int mvs_frame_upload(mvs_ctx *ctx, int slot, const uint8_t *frame_hw) { return frame_upload_impl(ctx, slot, frame_hw); }
 
 int mvs_sweep_view_matrices(mvs_ctx *ctx, float *q_out)
 {

@@ -81,6 +81,11 @@ struct mvs_ctx {
     mvs::DevBuf flow_arena;          // optical-flow pyramids and work buffers
     mvs::DevBuf frame_buf;           // mvs_process_frame: frames, depth, warped image, flows of one main frame
     mvs::DevBuf best_parts;          // plane-split sweeps: partial (best cell, best index) per split and pixel
+    // frame store (mvs_frame_store / mvs_frame_upload / mvs_sweep_batch): the frames of a sequence, uploaded once, each as raw frame,
+    // wrap-padded frame and quad image; main and side views of the batched sweep are slots of it
+    mvs::DevBuf store_raw, store_pads, store_quads, batch_buf;
+    int store_cap = 0;
+    std::vector<unsigned char> store_have;
     // the launch-bound flow pipelines (~350 small kernels for Farneback) are captured once into a hipGraph per
     // algorithm and replayed; invalidated when the arena moves
     // mvs_process_frame runs the flows of one main frame's side views concurrently: a lane is everything calculateFlow keeps

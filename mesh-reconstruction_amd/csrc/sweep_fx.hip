@@ -24,6 +24,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace mvs {
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void sweep_fx_generic(SweepParams p, const uin
         for (int v = p.v0; v < p.v0 + p.vcount; v++) {
             const float *q = p.Q + 12 * v;
             const Affine A = view_affine(q, xn, yn);
-            const uint8_t *pad = p.pads + p.pad_slab * v;
+            const uint8_t *pad = p.pads + p.pad_slab * (p.view_slot ? p.view_slot[v] : v);
 #pragma unroll
             for (int k = 0; k < PCG; k++)
                 if (d0 + k < p.plane_end) acc[k] += sample_global_fx(A, q[2], q[6], q[10], p.z[d0 + k], pad, p.pitch, hix, hiy, lut, Im255);
@@ -132,7 +133,22 @@ __global__ __launch_bounds__(256) void sweep_fx_generic(SweepParams p, const uin
 // ------------------------------------------------------------------------------------------------------
 // region planner: where does tile t land in side view v over the 16 planes of chunk c?
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void plan_regions_fx(SweepParams p, uint2 *__restrict__ plan)
+// A workgroup's parameter block out of an array of them, through the constant address space: scalar loads into SGPRs (a per-thread
+// copy of the 280-byte block from global memory lands in scratch: the planner of 8 frames took 5 ms that way).
+__device__ __forceinline__ SweepParams load_params(const SweepParams *src)
+{
+    static_assert(sizeof(SweepParams) % 4 == 0, "copied dword by dword");
+    SweepParams p;
+    const __attribute__((address_space(4))) uint32_t *s = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)src;
+    uint32_t *d = (uint32_t *)&p;
+#pragma unroll
+    for (size_t i = 0; i < sizeof(SweepParams) / 4; i++) d[i] = s[i];
+    return p;
+}
+
+// (bits 19-31 of a descriptor's second word: the slab of the view's quad image -- the view's own index, or its slot in the frame
+// store when the views are given by slots, mvs_sweep_batch)
+__device__ __forceinline__ void plan_regions_fx_body(const SweepParams &p, uint2 *__restrict__ plan)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = p.tiles_x * p.tiles_y * p.nchunks * p.V;
@@ -185,18 +201,31 @@ __global__ __launch_bounds__(256) void plan_regions_fx(SweepParams p, uint2 *__r
         rh = y1 - y0 + 1;
         if (rw > FX_MAX_RW || rw <= 0 || rh <= 0 || rh > FX_ROWS) {
             mode = FX_GENERIC;
-            atomicAdd(p.plan_stats, 1);
+            if (p.plan_stats) atomicAdd(p.plan_stats, 1);
         } else {
             mode = (xmin > 0.5f + m && xmax < p.Wp - m && ymin > 0.5f + m && ymax < p.Hp - m) ? FX_FAST : FX_BORDER;
-            atomicMax(p.plan_stats + 2, rw);  // largest staged region: the rectified kernel sizes its LDS slots by it (sweep_rect.hip)
-            atomicMax(p.plan_stats + 3, rh);
+            if (p.plan_stats) {
+                atomicMax(p.plan_stats + 2, rw);  // largest staged region (diagnostic)
+                atomicMax(p.plan_stats + 3, rh);
+            }
         }
     }
     uint2 d;
     d.x = (unsigned)x0 | ((unsigned)y0 << 16);
-    d.y = (unsigned)rw | ((unsigned)rh << 8) | (mode << 16);
+    d.y = (unsigned)rw | ((unsigned)rh << 8) | (mode << 16) | ((unsigned)(p.view_slot ? p.view_slot[v] : v) << 19);
     plan[tid] = d;
-    if (mode != FX_SKIP) atomicAdd(p.plan_stats + 1, 1);
+    if (mode != FX_SKIP && p.plan_stats) atomicAdd(p.plan_stats + 1, 1);
+}
+
+__global__ __launch_bounds__(256) void plan_regions_fx(SweepParams p, uint2 *__restrict__ plan) { plan_regions_fx_body(p, plan); }
+
+// one main frame per blockIdx.y, each with its own parameter block (mvs_sweep_batch)
+__global__ __launch_bounds__(256) void plan_regions_fx_batch(const SweepParams *__restrict__ pp)
+{
+    // the block's parameters through the constant address space: scalar loads into SGPRs (a per-thread copy of the 280-byte block from
+    // global memory lands in scratch: the planner of 8 frames took 5 ms that way)
+    const SweepParams p = load_params(pp + blockIdx.y);
+    plan_regions_fx_body(p, (uint2 *)p.plan);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -360,7 +389,7 @@ __device__ __forceinline__ void sample_range_fx_checked(const Affine &A, float b
 #endif
 
 template <bool WRITE_VOLUME, bool FUSED>
-__global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams p, const uint32_t *__restrict__ lut_g)
+__device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const uint32_t *__restrict__ lut_g)
 {
     constexpr int NPX = FX_NPX, PC = FX_PC, TILE_H = FX_TILE_H;
     // one object, so the texel image sits at LDS address 0 and its byte offsets are the ds_read addresses
@@ -475,7 +504,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
             FX_PROF_MARK(0);
 #endif
             if (__builtin_expect(mode == FX_GENERIC, 0)) {
-                const uint32_t *qv = p.quads + p.pad_slab * v;
+                const uint32_t *qv = p.quads + p.pad_slab * (size_t)__builtin_amdgcn_readfirstlane((int)(desc.y >> 19));
 #pragma unroll
                 for (int j = 0; j < NPX; j++) {
                     if (ok[j]) {
@@ -496,7 +525,7 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
 #ifdef MVS_FX_EXPERIMENTS
                 if (!(p.debug & 1))  // timing experiment only: no copies
 #endif
-                stage_region_fx(p.quads + p.pad_slab * v, p.pitch, x0, y0, rw, rh, qcol, lds);
+                stage_region_fx(p.quads + p.pad_slab * (size_t)__builtin_amdgcn_readfirstlane((int)(desc.y >> 19)), p.pitch, x0, y0, rw, rh, qcol, lds);
             }
 #ifdef MVS_FX_EXPERIMENTS
             if (p.debug & 64)
@@ -514,12 +543,11 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                 const unsigned mn = (unsigned)__builtin_amdgcn_readfirstlane((int)((dnext.y >> 16) & 7u));
                 const int rwn = __builtin_amdgcn_readfirstlane((int)(dnext.y & 0xffu));
                 if ((mn == FX_FAST || mn == FX_BORDER) && rwn <= FX_HALF_COL) {
-                    const int vn = v + 1 == vend ? p.v0 : v + 1;  // after the last view: the first view of the workgroup's next chunk
-                    nqcol = qcol ? 0 : FX_HALF_COL;
+                    nqcol = qcol ? 0 : FX_HALF_COL;  // (the next view, or after the last view the first view of the workgroup's next chunk: its slab is in the descriptor)
 #ifdef MVS_FX_EXPERIMENTS
                     if (!(p.debug & 1))
 #endif
-                        stage_region_fx(p.quads + p.pad_slab * vn, p.pitch, __builtin_amdgcn_readfirstlane((int)(dnext.x & 0xffffu)),
+                        stage_region_fx(p.quads + p.pad_slab * (size_t)__builtin_amdgcn_readfirstlane((int)(dnext.y >> 19)), p.pitch, __builtin_amdgcn_readfirstlane((int)(dnext.x & 0xffffu)),
                                         __builtin_amdgcn_readfirstlane((int)(dnext.x >> 16)), rwn, __builtin_amdgcn_readfirstlane((int)((dnext.y >> 8) & 0xffu)), nqcol, lds);
                     ahead = true;
                 }
@@ -659,6 +687,19 @@ __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams 
                     store_best<CS_FIXED>(p, pix, st.x & 0xffffffu, st.x >> 24, (int)st.y);
             }
     }
+}
+
+template <bool WRITE_VOLUME, bool FUSED>
+__global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams p, const uint32_t *__restrict__ lut_g)
+{
+    sweep_fx_tiled_body<WRITE_VOLUME, FUSED>(p, lut_g);
+}
+
+// several main frames in one launch (mvs_sweep_batch): blockIdx.z selects the frame's parameter block; depth selection only
+__global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled_batch(const SweepParams *__restrict__ pp, const uint32_t *__restrict__ lut_g)
+{
+    const SweepParams p = load_params(pp + blockIdx.z);
+    sweep_fx_tiled_body<false, true>(p, lut_g);
 }
 
 // the fixed sampler at one plane per pixel, z = depth[p]: (round(dot / 255), mask)
@@ -808,4 +849,119 @@ int warp_by_depth_fx_launch(mvs_ctx *ctx, const float *depth_dev, const float *q
     return MVS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// batched sweep over the frame store (recon.cpp:65-117: every main frame of a sequence against its neighbours)
+// ------------------------------------------------------------------------------------------------------
+int sweep_batch_impl(mvs_ctx *ctx, int nmain, const int *main_slots, const float *main_cams, int nside, const int *side_slots, const float *side_cams,
+                     int nplanes, float z_lo, float z_hi, float *depth_out, float *cost_out)
+{
+    if (!ctx) return MVS_EINVAL;
+    if (nmain < 1 || nside < 1 || nside > 255 || !main_slots || !main_cams || !side_slots || !side_cams || !depth_out)
+        return fail(ctx, MVS_EINVAL, "mvs_sweep_batch: bad arguments (nmain=%d, nside=%d: 1..255 side views per main frame)", nmain, nside);
+    if (nplanes < 1 || nplanes > 4096) return fail(ctx, MVS_EINVAL, "mvs_sweep_batch: nplanes=%d out of range 1..4096", nplanes);
+    if (ctx->sampler != MVS_SAMPLER_FIXED) return fail(ctx, MVS_EINVAL, "mvs_sweep_batch: implemented for MVS_SAMPLER_FIXED (the library default)");
+    if (ctx->W > 16383 || ctx->H > 16383) return fail(ctx, MVS_EINVAL, "mvs_sweep_batch: images of up to 16383 x 16383");
+    for (int m = 0; m < nmain; m++) {
+        if (main_slots[m] < 0 || main_slots[m] >= ctx->store_cap || !ctx->store_have[main_slots[m]])
+            return fail(ctx, MVS_EINVAL, "mvs_sweep_batch: main frame %d: slot %d holds no frame", m, main_slots[m]);
+        for (int v = 0; v < nside; v++) {
+            const int sl = side_slots[(size_t)m * nside + v];
+            if (sl < 0 || sl >= ctx->store_cap || !ctx->store_have[sl]) return fail(ctx, MVS_EINVAL, "mvs_sweep_batch: main frame %d, side view %d: slot %d holds no frame", m, v, sl);
+        }
+    }
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->W, H = ctx->H;
+    const size_t P = (size_t)W * H;
+    const int pitch = ((W + 2 + 63) / 64) * 64;
+    const size_t slab = (size_t)pitch * (H + 2);
+    int rc = ensure_fx_lut(ctx);
+    if (rc) return rc;
+
+    // one device block: [parameter blocks][view matrices][plane table][view slots][region plans][depth, cost, index per frame]
+    const int tiles_x = div_up(W, TILE_W), tiles_y = div_up(H, FX_TILE_H), nchunks = div_up(nplanes, FX_PC);
+    const size_t plan_entries = (size_t)tiles_x * tiles_y * nchunks * nside;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_params = 0, o_q = up(o_params + sizeof(SweepParams) * nmain), o_z = up(o_q + sizeof(float) * 12 * nside * nmain),
+                 o_slots = up(o_z + sizeof(float) * nplanes), o_stats = up(o_slots + sizeof(int) * nside * nmain), o_plan = up(o_stats + 64),
+                 o_out = up(o_plan + sizeof(uint2) * plan_entries * nmain), total = up(o_out + 3 * P * sizeof(float) * nmain);
+    if ((rc = ensure(ctx, ctx->batch_buf, total))) return rc;
+    char *base = (char *)ctx->batch_buf.ptr;
+    // host staging (kept alive until the copies below have run: the call ends with a synchronisation)
+    std::vector<char> host(o_plan);
+    float *zt = (float *)(host.data() + o_z);
+    plane_table(nplanes, z_lo, z_hi, zt);
+    memcpy(host.data() + o_slots, side_slots, sizeof(int) * nside * nmain);
+    for (int m = 0; m < nmain; m++) {
+        float *qm = (float *)(host.data() + o_q) + (size_t)12 * nside * m;
+        for (int v = 0; v < nside; v++) view_matrix(main_cams + 16 * m, side_cams + 16 * ((size_t)m * nside + v), W, H, qm + 12 * v);
+        SweepParams &p = ((SweepParams *)(host.data() + o_params))[m];
+        memset(&p, 0, sizeof(p));
+        p.main_img = (const uint8_t *)ctx->store_raw.ptr + P * main_slots[m];
+        p.pads = (const uint8_t *)ctx->store_pads.ptr;
+        p.pad_slab = slab;
+        p.quads = (const uint32_t *)ctx->store_quads.ptr;
+        p.quads16 = nullptr;
+        p.pitch = pitch;
+        p.W = W;
+        p.H = H;
+        p.D = nplanes;
+        p.V = nside;
+        p.v0 = 0;
+        p.vcount = nside;
+        p.Q = (const float *)(base + o_q) + (size_t)12 * nside * m;
+        p.z = (const float *)(base + o_z);
+        p.volume = nullptr;
+        p.depth = (float *)(base + o_out) + (size_t)m * P;                   // [depth of every frame][cost of every frame][index of every frame]
+        p.cost = (float *)(base + o_out) + (size_t)(nmain + m) * P;
+        p.index = (int *)(base + o_out) + (size_t)(2 * nmain + m) * P;
+        p.invW = 1.0f / (float)W;
+        p.invH = 1.0f / (float)H;
+        p.Wp = (float)W + 0.5f;
+        p.Hp = (float)H + 0.5f;
+        p.plan = (const uint2 *)(base + o_plan) + plan_entries * m;
+        p.tiles_x = tiles_x;
+        p.tiles_y = tiles_y;
+        p.nchunks = nchunks;
+        p.chunk0 = 0;
+        p.chunk1 = nchunks;
+        p.ty0 = 0;
+        p.tyn = tiles_y;
+        p.tile_h = FX_TILE_H;
+        p.pc = FX_PC;
+        p.row_begin = 0;
+        p.row_end = H;
+        p.plane_begin = 0;
+        p.plane_end = nplanes;
+        p.plan_stats = nullptr;  // (planner counters: not needed here)
+        p.cps = nchunks;  // several frames fill the chip: no plane split, no partial bests
+        p.part = nullptr;
+        p.view_slot = (const int *)(base + o_slots) + (size_t)nside * m;
+        p.debug = 0;
+    }
+    MVS_HIP(ctx, hipMemcpyAsync(base, host.data(), o_plan, hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(ctx, hipMemsetAsync(base + o_stats, 0, 64, ctx->stream));
+    {
+        ProfileScope ps(ctx, MVS_K_PLAN);
+        plan_regions_fx_batch<<<dim3((unsigned)((plan_entries + 255) / 256), (unsigned)nmain), 256, 0, ctx->stream>>>((const SweepParams *)(base + o_params));
+        MVS_HIP(ctx, hipGetLastError());
+    }
+    {
+        ProfileScope ps(ctx, MVS_K_SWEEP);
+        const int groups = div_up(tiles_x, 2) * div_up(tiles_y, 4);
+        sweep_fx_tiled_batch<<<dim3((unsigned)(div_up(groups, 8) * 64), 1, (unsigned)nmain), 256, 0, ctx->stream>>>((const SweepParams *)(base + o_params),
+                                                                                                             (const uint32_t *)ctx->fx_lut.ptr);
+        MVS_HIP(ctx, hipGetLastError());
+    }
+    MVS_HIP(ctx, hipMemcpyAsync(depth_out, base + o_out, P * sizeof(float) * nmain, hipMemcpyDeviceToHost, ctx->stream));
+    if (cost_out) MVS_HIP(ctx, hipMemcpyAsync(cost_out, base + o_out + P * sizeof(float) * nmain, P * sizeof(float) * nmain, hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
 }  // namespace mvs
+
+extern "C" int mvs_sweep_batch(mvs_ctx *ctx, int nmain, const int *main_slots, const float *main_cams, int nside, const int *side_slots, const float *side_cams, int nplanes,
+                               float z_lo, float z_hi, float *depth_out, float *cost_out)
+{
+    return mvs::sweep_batch_impl(ctx, nmain, main_slots, main_cams, nside, side_slots, side_cams, nplanes, z_lo, z_hi, depth_out, cost_out);
+}

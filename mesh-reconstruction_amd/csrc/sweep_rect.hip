@@ -469,12 +469,15 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
             // wait, so their consumers cannot be scheduled above it.  A plane that is not FULL is read as well (somewhere in or past
             // the LDS: harmless) and skipped at the compute stage: no second shape of the pipeline.
             auto issue = [&](int k, int buf) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // m0 on the clobber list: the compiler re-materialises it before its own LDS copies
                 asm volatile("s_add_u32 m0, %8, %9\n\ts_nop 0\n\t"
                              "ds_read_addtid_b32 %0 offset:%10\n\tds_read_addtid_b32 %1 offset:%11\n\tds_read_addtid_b32 %2 offset:%12\n\tds_read_addtid_b32 %3 offset:%13\n\t"
                              "ds_read_addtid_b32 %4 offset:%14\n\tds_read_addtid_b32 %5 offset:%15\n\tds_read_addtid_b32 %6 offset:%16\n\tds_read_addtid_b32 %7 offset:%17"
                              : "=v"(qd[buf][0]), "=v"(qd[buf][1]), "=v"(qd[buf][2]), "=v"(qd[buf][3]), "=v"(qd[buf][4]), "=v"(qd[buf][5]), "=v"(qd[buf][6]), "=v"(qd[buf][7])
                              : "s"(slot_byte), "s"(fld[k]), "n"(0), "n"(RS * 4), "n"(RS * 8), "n"(RS * 12), "n"(RS * 16), "n"(RS * 20), "n"(RS * 24), "n"(RS * 28)
                              : "m0", "scc");
+#pragma clang diagnostic pop
             };
             auto consume = [&](int k, int buf, bool more_in_flight) {
                 if (more_in_flight)

@@ -51,6 +51,7 @@ struct SweepParams {
     int *__restrict__ plan_stats;  // [0] regions too large for LDS, [1] regions not skipped (planner output)
     int cps;             // plane chunks per workgroup: blockIdx.y selects chunks [chunk0 + y*cps, +cps) of a tile
     uint2 *__restrict__ part;  // plane-split launches with fused depth selection: [gridDim.y][P] partial bests
+    const int *__restrict__ view_slot;  // nullable: slab of view v's padded / quad image (frame store slots, mvs_sweep_batch); null = slab v
     int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: linear tile order; bit 2: never use the plane-independent-w path; bit 3: exact sampler: force the 4 x 16 shape, fixed sampler: no region look-ahead; fixed sampler only: bit 4: BORDER regions as FAST, bit 5: skip the sample loop)
 };
 
@@ -187,6 +188,7 @@ inline int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount, int til
     p.cps = p.nchunks;
     p.part = nullptr;
     p.plan_stats = nullptr;
+    p.view_slot = nullptr;
     p.debug = 0;
     return MVS_OK;
 }

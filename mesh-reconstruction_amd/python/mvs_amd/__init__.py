@@ -61,6 +61,9 @@ ABI = [
     ("mvs_sweep_row_granularity", _i, []),
     ("mvs_sweep_row_granularity_of", _i, [_vp]),
     ("mvs_sweep_plan_shape", _i, [_vp]),
+    ("mvs_frame_store", _i, [_vp, _i]),
+    ("mvs_frame_upload", _i, [_vp, _i, _vp]),
+    ("mvs_sweep_batch", _i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, C.c_float, C.c_float, _vp, _vp]),
     ("mvs_sweep_argmin", _i, [_vp]),
     ("mvs_sweep_argmin_partial", _i, [_vp, _vp, _i, _i, _vp]),
     ("mvs_sweep_combine_partials", _i, [_vp, _vp, _i]),
@@ -337,6 +340,31 @@ class Context:
 
     def plan_shape(self):
         return self.lib.mvs_sweep_plan_shape(self.h)
+
+    # ---- frame store + batched sweep (a sequence on one GPU) ------------------------------------
+    def frame_store(self, capacity):
+        self._check(self.lib.mvs_frame_store(self.h, int(capacity)))
+        self._store_keep = {}
+
+    def frame_upload(self, slot, frame):
+        f = _u8(frame, (self.H, self.W))
+        self._store_keep[int(slot)] = f   # the copy is asynchronous: keep the array alive until the next synchronising call
+        self._check(self.lib.mvs_frame_upload(self.h, int(slot), f.ctypes.data_as(C.c_void_p)))
+
+    def sweep_batch(self, main_slots, main_cams, side_slots, side_cams, nplanes, z_lo=-1.0, z_hi=1.0, want_cost=False, out=None):
+        """mvs_sweep_batch: main_slots [M], main_cams [M,4,4], side_slots [M,S], side_cams [M,S,4,4] -> depth [M,H,W] (, cost [M,H,W])"""
+        ms = np.ascontiguousarray(main_slots, dtype=np.int32)
+        ss = np.ascontiguousarray(side_slots, dtype=np.int32)
+        M, S = ss.shape
+        mc = _f32(np.asarray(main_cams, dtype=np.float32).reshape(M, 4, 4))
+        sc = _f32(np.asarray(side_cams, dtype=np.float32).reshape(M, S, 4, 4))
+        depth = out if out is not None else np.empty((M, self.H, self.W), np.float32)
+        cost = np.empty((M, self.H, self.W), np.float32) if want_cost else None
+        self._check(self.lib.mvs_sweep_batch(self.h, M, ms.ctypes.data_as(C.c_void_p), mc.ctypes.data_as(C.c_void_p), S, ss.ctypes.data_as(C.c_void_p),
+                                             sc.ctypes.data_as(C.c_void_p), int(nplanes), float(z_lo), float(z_hi), depth.ctypes.data_as(C.c_void_p),
+                                             cost.ctypes.data_as(C.c_void_p) if want_cost else None))
+        self._store_keep = {}
+        return (depth, cost) if want_cost else depth
 
     def depth_device_array(self):
         """zero-copy [H, W] f32 view of the device depth map for torch.as_tensor(..., device='cuda') (valid until the

@@ -64,3 +64,38 @@ def test_c5_sequence_frame_by_frame_and_two_rank_gather(oracle):
     two = json.loads(lines[0])
     assert two["frames"] == single, "frame-sharded run differs from the single-process run"
     assert two["cloud_points"] == sum(s["points"] for s in single)
+
+
+def test_c5_batched_resident_entry_equals_one_call_path_on_all_120_frames():
+    """the frame store + mvs_sweep_batch (frames uploaded once, several main frames per launch) against the one-call mvs_sweep, every
+    one of the 120 zatisi main frames, depth and best cost bit for bit; batches of 1, 7 and 16 main frames"""
+    seq = c5_common.Sequence()
+    W, H, n = seq.W, seq.H, seq.n
+    frames = [seq.frame(f) for f in range(n)]
+    with mvs_amd.Context(W, H) as ctx:
+        ref = {}
+        for f in range(n):
+            ids = seq.sides(f)
+            d, c = ctx.sweep(seq.cams[f], frames[f], np.stack([seq.cams[j] for j in ids]), [frames[j] for j in ids], c5_common.PLANES, want_cost=True)
+            ref[f] = (c5_common.crc(d), c5_common.crc(c))
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.frame_store(n)
+        for f in range(n):
+            ctx.frame_upload(f, frames[f])
+        done = 0
+        for batch in (1, 7, 16):
+            while done < n and (batch == 16 or done < {1: 3, 7: 3 + 28}[batch]):
+                mains = list(range(done, min(n, done + batch)))
+                side_slots = np.array([seq.sides(f) for f in mains], np.int32)
+                depth, cost = ctx.sweep_batch(mains, np.stack([seq.cams[f] for f in mains]), side_slots,
+                                              np.stack([np.stack([seq.cams[j] for j in seq.sides(f)]) for f in mains]), c5_common.PLANES, want_cost=True)
+                for k, f in enumerate(mains):
+                    assert (c5_common.crc(depth[k]), c5_common.crc(cost[k])) == ref[f], "main frame %d (batch of %d)" % (f, len(mains))
+                done += len(mains)
+        assert done == n
+        # argument checks: an empty slot, a slot outside the store
+        with pytest.raises(mvs_amd.MvsError):
+            ctx.sweep_batch([n + 5], seq.cams[:1], np.array([[0, 1, 2, 3]], np.int32), np.stack([seq.cams[:4]]), c5_common.PLANES)
+        ctx.frame_store(4)   # re-sizing empties the store
+        with pytest.raises(mvs_amd.MvsError):
+            ctx.sweep_batch([0], seq.cams[:1], np.array([[0, 1, 2, 3]], np.int32), np.stack([seq.cams[:4]]), c5_common.PLANES)
