@@ -213,19 +213,36 @@ int mvs_frame_upload(mvs_ctx *ctx, int slot, const uint8_t *frame_hw);
 int mvs_sweep_batch(mvs_ctx *ctx, int nmain, const int *main_slots, const float *main_cams, int nside, const int *side_slots,
                     const float *side_cams, int nplanes, float z_lo, float z_hi, float *depth_out, float *cost_out);
 
-/* ---- one main view on several GPUs of one node (SURVEY.md section 8b "multi-GPU", north_star) ----------------------------------
+/* ---- one main view on several GPUs of one node (SURVEY.md section 8b "multi-GPU", 8e, north_star) -----------------------------
  * A communicator owns one context per listed device and one RCCL communicator across them (librccl is loaded when the first
- * communicator is created; the library has no link dependency on it).  mvs_sweep_sharded deals the side views to the GPUs, every
- * GPU builds the packed volume of its views (one host thread per GPU), the volumes are summed over xGMI -- reduce-scatter by plane
- * slices + partial selection + all-gather of the 8-byte partials when nplanes is a multiple of the GPU count, an in-place all-reduce
- * + mvs_sweep_argmin otherwise -- and rank 0's result is returned.  Cells are integers, so depth_hw / cost_hw are bit-identical to
- * mvs_sweep on one GPU.  The sampler of a communicator's contexts is set through mvs_comm_context(). */
+ * communicator is created; the library has no link dependency on it).  mvs_sweep_sharded runs ONE main view on all of them, one host
+ * thread per GPU, and returns the depth map (and best cost) of the whole view -- bit-identical to mvs_sweep on one GPU in every mode
+ * (cells are integers, sums are exact):
+ *   MVS_SHARD_ROWS (default)  every GPU holds all side views and sweeps a band of the main view's pixel rows, depth selected inside
+ *                             the kernel; each band is copied from its GPU into depth_hw / cost_hw.  4 bytes per pixel and map, no
+ *                             collective: the split that scales.
+ *   MVS_SHARD_VIEWS           the north_star's split: the side views are dealt to the GPUs, every GPU builds the packed volume of its
+ *                             views, the volumes are all-reduced over xGMI per plane group (mvs_comm_set_plane_groups, default 4) on
+ *                             a second stream while the next group is swept, depth is selected from the sum.  2 (n-1)/n x 4 P D
+ *                             bytes per GPU on the links: cannot scale at the BASELINE sizes, built because
+ *                             the north_star names it.
+ *   MVS_SHARD_VIEWS_SCATTER   the same split, half the bytes, no overlap: reduce-scatter by plane slices + partial selection +
+ *                             all-gather of 8-byte partials (nplanes a multiple of the GPU count; otherwise as MVS_SHARD_VIEWS).
+ * A rank that fails before the exchange makes every rank skip it (host barrier + shared error flag); a failure inside the exchange
+ * aborts all communicators (ncclCommAbort) so that no rank is left waiting; mvs_sweep_sharded then returns MVS_ESTATE until a new
+ * communicator is created.  The sampler of a communicator's contexts is set through mvs_comm_context(). */
+#define MVS_SHARD_ROWS 0
+#define MVS_SHARD_VIEWS 1
+#define MVS_SHARD_VIEWS_SCATTER 2
 typedef struct mvs_comm mvs_comm;
 mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height); /* NULL on error: mvs_comm_last_error(NULL) */
 void mvs_comm_destroy(mvs_comm *comm);
 int mvs_comm_size(const mvs_comm *comm);
 mvs_ctx *mvs_comm_context(mvs_comm *comm, int rank); /* borrowed; NULL if rank is out of range */
 const char *mvs_comm_last_error(const mvs_comm *comm);
+int mvs_comm_set_mode(mvs_comm *comm, int mode);   /* MVS_SHARD_* */
+int mvs_comm_mode(const mvs_comm *comm);
+int mvs_comm_set_plane_groups(mvs_comm *comm, int groups); /* MVS_SHARD_VIEWS: plane groups of the all-reduce pipeline, 1..64 */
 int mvs_sweep_sharded(mvs_comm *comm, const float main_cam[16], const uint8_t *main_hw, int nviews, const float *side_cams /* nviews*16 */,
                       const uint8_t *const *side_frames, int nplanes, float z_lo, float z_hi, float *depth_hw, float *cost_hw /* nullable */);
 

@@ -1,20 +1,32 @@
 // comm.cpp -- the sweep of ONE main view on several GPUs of one node behind the C ABI (mvs_comm_*, mvs_sweep_sharded).
 //
-// SURVEY.md section 8(b), multi-GPU row / north_star: the V side views are dealt to the GPUs, every GPU builds the packed volume
-// of its views, and the volumes are summed over xGMI with RCCL.  Cells are integers (count << CS | sum), so the sum is exact and
-// the depth map is bit-identical to the single-GPU one.  The exchange is a reduce-scatter by plane slices (rank r receives the
-// summed cells of planes [r D/G, (r+1) D/G)), a partial depth selection per rank (mvs_sweep_argmin_partial), an all-gather of
-// the 8-byte partial records and the merge in plane order (mvs_sweep_combine_partials): half the bytes of an all-reduce on the
-// links.  When the plane count is not a multiple of the GPU count the volume is all-reduced in place instead.
-// One host thread per GPU drives its context, as the C ABI asks ("calls on a context are serialised by the caller").
+// SURVEY.md section 8(b), multi-GPU row / 8(e).  One host thread per GPU drives its context, as the C ABI asks ("calls on a context
+// are serialised by the caller").  Three ways to split the work (mvs_comm_set_mode):
+//   MVS_SHARD_ROWS (default)   every GPU holds all side views and sweeps a band of the main view's pixel rows with depth selection
+//                              inside the kernel (rows are independent); each band goes straight from its GPU into the
+//                              caller's depth map -- 4 bytes per pixel in total, NO data-path collective.  The split that scales.
+//   MVS_SHARD_VIEWS            the north_star's split: the V side views are dealt to the GPUs, every GPU builds the packed volume of
+//                              its views, the volumes are summed over xGMI with RCCL -- an all-reduce per plane group on a second
+//                              stream while the next group is being swept -- and depth is selected from the summed volume.
+//   MVS_SHARD_VIEWS_SCATTER    the same split with half the bytes on the links and no overlap: reduce-scatter by plane slices, a partial
+//                              selection per rank, all-gather of the 8-byte partials, merge in plane order (plane count a multiple
+//                              of the GPU count; otherwise it runs as MVS_SHARD_VIEWS).
+// Cells are integers (count << CS | sum): sums are exact, every mode returns the single-GPU depth map bit for bit.
+// Failure handling: every rank does its local work and its allocations first; the ranks then meet at a host-side barrier and look
+// at a shared error flag BEFORE anybody enters a collective -- a rank that failed early makes all of them skip the exchange instead
+// of leaving the others waiting in RCCL for ever.  A failure inside the exchange aborts every communicator (ncclCommAbort), which
+// unblocks the other ranks; the communicator is unusable afterwards (mvs_sweep_sharded then returns MVS_ESTATE).
 // RCCL is resolved with dlopen at mvs_comm_create: libmvs_hip.so itself has no link dependency on librccl, and a process that has
-// already loaded one (PyTorch) shares it.
+// already loaded one (PyTorch) shares it.  MVS_RCCL_LIBRARY names another library file (tests: a missing one).
 #include "mvs_internal.hpp"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,6 +37,7 @@ struct Rccl {
     void *handle = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -33,12 +46,17 @@ struct Rccl {
 
     bool load()
     {
-        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        const char *override_name = getenv("MVS_RCCL_LIBRARY");
+        std::string last;
+        for (const char *name : {override_name ? override_name : "librccl.so.1", override_name ? override_name : "librccl.so"}) {
+            (void)dlerror();
             handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (handle) break;
+            const char *e = dlerror();  // ONE call: dlerror() clears the message it returns
+            last = e ? e : "unknown error";
         }
         if (!handle) {
-            error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "unknown error");
+            error = std::string("cannot load librccl.so: ") + last;
             return false;
         }
         auto sym = [&](const char *n) {
@@ -48,11 +66,12 @@ struct Rccl {
         };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
         ReduceScatter = (decltype(ReduceScatter))sym("ncclReduceScatter");
         AllGather = (decltype(AllGather))sym("ncclAllGather");
         AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        return CommInitAll && CommDestroy && ReduceScatter && AllGather && AllReduce && GetErrorString;
+        return CommInitAll && CommDestroy && CommAbort && ReduceScatter && AllGather && AllReduce && GetErrorString;
     }
 };
 
@@ -64,9 +83,36 @@ struct mvs_comm {
     std::vector<mvs_ctx *> ctx;
     std::vector<ncclComm_t> comms;
     std::vector<mvs::DevBuf> slice, part, parts;  // per rank: the plane slice it owns, its partial bests, everybody's partial bests
+    std::vector<hipStream_t> comm_stream;         // per rank: the collectives of MVS_SHARD_VIEWS run beside the sweep of the next plane group
+    std::vector<std::vector<hipEvent_t>> events;  // per rank: plane group swept / plane group summed
+    int mode = MVS_SHARD_ROWS;
+    int plane_groups = 4;
+    bool broken = false;  // a collective failed and the communicators were aborted
     Rccl rccl;
     char err[512] = {0};
 };
+
+namespace {
+// all ranks meet here between their local work and the exchange (C++17: no std::barrier)
+struct HostBarrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int waiting = 0, generation = 0, n;
+    explicit HostBarrier(int n_) : n(n_) {}
+    void arrive_and_wait()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        const int gen = generation;
+        if (++waiting == n) {
+            waiting = 0;
+            generation++;
+            cv.notify_all();
+        } else {
+            cv.wait(lock, [&] { return gen != generation; });
+        }
+    }
+};
+}  // namespace
 
 using namespace mvs;
 
@@ -109,6 +155,13 @@ mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height)
     c->slice.resize(n);
     c->part.resize(n);
     c->parts.resize(n);
+    c->comm_stream.assign(n, nullptr);
+    c->events.resize(n);
+    if (!c->rccl.load()) {  // before anything touches a GPU: the error path of a missing library must not need one
+        comm_fail(nullptr, MVS_EHIP, "mvs_comm_create: %s", c->rccl.error.c_str());
+        mvs_comm_destroy(c);
+        return nullptr;
+    }
     for (int i = 0; i < n; i++) {
         mvs_ctx *x = mvs_create(devices[i], width, height);
         if (!x) {
@@ -117,11 +170,6 @@ mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height)
             return nullptr;
         }
         c->ctx.push_back(x);
-    }
-    if (!c->rccl.load()) {
-        comm_fail(nullptr, MVS_EHIP, "mvs_comm_create: %s", c->rccl.error.c_str());
-        mvs_comm_destroy(c);
-        return nullptr;
     }
     c->comms.assign(n, nullptr);
     const ncclResult_t r = c->rccl.CommInitAll(c->comms.data(), n, devices);
@@ -143,9 +191,14 @@ void mvs_comm_destroy(mvs_comm *c)
         (void)mvs_synchronize(c->ctx[i]);
         for (DevBuf *b : {&c->slice[i], &c->part[i], &c->parts[i]})
             if (b->ptr) (void)hipFree(b->ptr);
+        if (c->comm_stream[i]) {
+            (void)hipStreamSynchronize(c->comm_stream[i]);
+            (void)hipStreamDestroy(c->comm_stream[i]);
+        }
+        for (hipEvent_t e : c->events[i]) (void)hipEventDestroy(e);
     }
     for (ncclComm_t k : c->comms)
-        if (k && c->rccl.CommDestroy) (void)c->rccl.CommDestroy(k);
+        if (k && !c->broken && c->rccl.CommDestroy) (void)c->rccl.CommDestroy(k);  // (aborted communicators are already gone)
     for (mvs_ctx *x : c->ctx) mvs_destroy(x);
     delete c;
 }
@@ -154,15 +207,33 @@ int mvs_comm_size(const mvs_comm *c) { return c ? c->n : MVS_EINVAL; }
 mvs_ctx *mvs_comm_context(mvs_comm *c, int rank) { return (c && rank >= 0 && rank < c->n) ? c->ctx[rank] : nullptr; }
 const char *mvs_comm_last_error(const mvs_comm *c) { return c ? c->err : g_comm_err; }
 
+int mvs_comm_set_mode(mvs_comm *c, int mode)
+{
+    if (!c) return MVS_EINVAL;
+    if (mode != MVS_SHARD_ROWS && mode != MVS_SHARD_VIEWS && mode != MVS_SHARD_VIEWS_SCATTER) return comm_fail(c, MVS_EINVAL, "mvs_comm_set_mode: unknown mode %d", mode);
+    c->mode = mode;
+    return MVS_OK;
+}
+
+int mvs_comm_mode(const mvs_comm *c) { return c ? c->mode : MVS_EINVAL; }
+
+int mvs_comm_set_plane_groups(mvs_comm *c, int groups)
+{
+    if (!c) return MVS_EINVAL;
+    if (groups < 1 || groups > 64) return comm_fail(c, MVS_EINVAL, "mvs_comm_set_plane_groups: %d out of range 1..64", groups);
+    c->plane_groups = groups;
+    return MVS_OK;
+}
+
 int mvs_sweep_sharded(mvs_comm *c, const float main_cam[16], const uint8_t *main_hw, int nviews, const float *side_cams,
                       const uint8_t *const *side_frames, int nplanes, float z_lo, float z_hi, float *depth_hw, float *cost_hw)
 {
     if (!c) return MVS_EINVAL;
+    if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_sweep_sharded: the communicators were aborted after a failed collective; create a new mvs_comm");
     if (!main_cam || !main_hw || !depth_hw || nviews < 0 || (nviews > 0 && (!side_cams || !side_frames)))
         return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: null argument");
     if (nplanes < 1 || nplanes > 4096) return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: nplanes=%d out of range 1..4096", nplanes);
-    // Everything a rank could reject is checked HERE, before any rank enters a collective: a rank that returned early would leave the
-    // others waiting in RCCL for ever.  (A HIP or RCCL failure in the middle of the exchange is not recoverable either way.)
+    // everything a rank could reject for the arguments' sake is checked here, once
     for (int v = 0; v < nviews; v++)
         if (!side_frames[v]) return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: side_frames[%d] is null", v);
     const int view_limit = mvs_sweep_sampler(c->ctx[0]) == MVS_SAMPLER_FIXED ? 255 : 256;  // the SUMMED cells must hold every view's count
@@ -171,51 +242,143 @@ int mvs_sweep_sharded(mvs_comm *c, const float main_cam[16], const uint8_t *main
         if (mvs_sweep_sampler(c->ctx[r]) != mvs_sweep_sampler(c->ctx[0]))
             return comm_fail(c, MVS_ESTATE, "mvs_sweep_sharded: rank %d uses another sampler than rank 0 (cells of different formats cannot be summed)", r);
     const int n = c->n;
-    const size_t P = (size_t)c->W * c->H;
-    // plane slices of equal size: reduce-scatter; otherwise (or with the test hook MVS_COMM_ALLREDUCE set) all-reduce in place
-    const bool scatter = nplanes % n == 0 && getenv("MVS_COMM_ALLREDUCE") == nullptr;
+    const int W = c->W, H = c->H;
+    const size_t P = (size_t)W * H;
+    const bool rows = c->mode == MVS_SHARD_ROWS;
+    // plane slices of equal size: reduce-scatter; otherwise (or with the test hook MVS_COMM_ALLREDUCE set) the all-reduce pipeline
+    const bool scatter = c->mode == MVS_SHARD_VIEWS_SCATTER && nplanes % n == 0 && getenv("MVS_COMM_ALLREDUCE") == nullptr;
     const int slice_planes = nplanes / n;
+    // row bands on the sweep's tile-row granularity, equal but for the last
+    const int gran = mvs_sweep_row_granularity_of(c->ctx[0]);
+    const int band = ((H + gran - 1) / gran + n - 1) / n * gran;
+    // plane groups of the all-reduce pipeline, on the sweep's plane granularity
+    std::vector<std::pair<int, int>> groups;
+    {
+        const int pg = mvs_sweep_plane_granularity();
+        const int per = std::max(pg, ((nplanes + c->plane_groups - 1) / c->plane_groups + pg - 1) / pg * pg);
+        for (int first = 0; first < nplanes; first += per) groups.emplace_back(first, std::min(per, nplanes - first));
+    }
     std::vector<int> rc(n, MVS_OK);
     std::vector<std::string> msg(n);
+    std::atomic<int> failed{0};
+    HostBarrier meet(n);
+    auto abort_all = [&]() {  // a collective failed on this rank: unblock everybody else (idempotent enough: RCCL tolerates a second abort of a dead communicator poorly, so once)
+        static std::mutex once;
+        std::lock_guard<std::mutex> lock(once);
+        if (c->broken) return;
+        c->broken = true;
+        for (ncclComm_t k : c->comms)
+            if (k) (void)c->rccl.CommAbort(k);
+    };
     auto worker = [&](int r) {
         mvs_ctx *x = c->ctx[r];
         auto fail_here = [&](int code, const char *what, const char *detail) {
             rc[r] = code;
             msg[r] = std::string(what) + ": " + detail;
+            failed.store(1);
         };
-        if (hipSetDevice(c->devices[r]) != hipSuccess) return fail_here(MVS_EHIP, "hipSetDevice", "failed");
-        // view shard of this rank: a contiguous range, empty for ranks beyond the view count
-        const int per = (nviews + n - 1) / n;
-        const int v0 = std::min(r * per, nviews), vn = std::max(0, std::min(per, nviews - v0));
+        uint32_t *vol = nullptr;
+        hipStream_t st = nullptr;
+        const int per = (nviews + n - 1) / n;  // view shard of this rank: a contiguous range, empty for ranks beyond the view count
+        const int v0 = rows ? 0 : std::min(r * per, nviews), vn = rows ? nviews : std::max(0, std::min(per, nviews - v0));
+        const int r0 = std::min(r * band, H), rn = std::max(0, std::min(band, H - r0));
+        // ---- phase 1: everything local (inputs, allocations; in rows mode the whole job) ----
+        [&]() {
+            if (hipSetDevice(c->devices[r]) != hipSuccess) return fail_here(MVS_EHIP, "hipSetDevice", "failed");
+            int e;
+            st = x->stream;
+            if ((e = mvs_sweep_set_main(x, main_cam, main_hw))) return fail_here(e, "mvs_sweep_set_main", mvs_last_error(x));
+            if ((e = mvs_sweep_set_views(x, vn, side_cams + 16 * (size_t)v0, side_frames + v0))) return fail_here(e, "mvs_sweep_set_views", mvs_last_error(x));
+            if ((e = mvs_sweep_set_planes(x, nplanes, z_lo, z_hi))) return fail_here(e, "mvs_sweep_set_planes", mvs_last_error(x));
+            if (rows) {
+                if (rn > 0) {
+                    if ((e = mvs_sweep_run_rows(x, 0, nviews, r0, rn, MVS_SWEEP_FUSED_ARGMIN))) return fail_here(e, "mvs_sweep_run_rows", mvs_last_error(x));
+                    // the band goes straight into the caller's maps: 4 bytes per pixel and map, no collective
+                    if (hipMemcpyAsync(depth_hw + (size_t)r0 * W, (const float *)x->depth.ptr + (size_t)r0 * W, (size_t)rn * W * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+                        return fail_here(MVS_EHIP, "hipMemcpyAsync", "depth band");
+                    if (cost_hw && hipMemcpyAsync(cost_hw + (size_t)r0 * W, (const float *)x->cost.ptr + (size_t)r0 * W, (size_t)rn * W * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+                        return fail_here(MVS_EHIP, "hipMemcpyAsync", "cost band");
+                }
+                if ((e = mvs_synchronize(x))) return fail_here(e, "mvs_synchronize", mvs_last_error(x));
+                return;
+            }
+            // views: the first sweep launch allocates the volume and the outputs; the buffers of the exchange follow
+            if (scatter) {
+                if ((e = mvs_sweep_run(x, 0, vn, MVS_SWEEP_VOLUME))) return fail_here(e, "mvs_sweep_run", mvs_last_error(x));
+                if ((e = ensure(x, c->slice[r], (size_t)slice_planes * P * 4)) || (e = ensure(x, c->part[r], P * 8)) || (e = ensure(x, c->parts[r], (size_t)n * P * 8)))
+                    return fail_here(e, "device allocation", mvs_last_error(x));
+            } else {
+                if (!c->comm_stream[r] && hipStreamCreateWithFlags(&c->comm_stream[r], hipStreamNonBlocking) != hipSuccess) return fail_here(MVS_EHIP, "hipStreamCreate", "failed");
+                while (c->events[r].size() < 2 * groups.size()) {
+                    hipEvent_t ev;
+                    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail_here(MVS_EHIP, "hipEventCreate", "failed");
+                    c->events[r].push_back(ev);
+                }
+                if ((e = mvs_sweep_run_planes(x, 0, vn, groups[0].first, groups[0].second, MVS_SWEEP_VOLUME))) return fail_here(e, "mvs_sweep_run_planes", mvs_last_error(x));
+            }
+            size_t vol_bytes = 0;
+            vol = (uint32_t *)mvs_sweep_volume_device(x, &vol_bytes);
+            if (!vol) return fail_here(MVS_ESTATE, "mvs_sweep_volume_device", mvs_last_error(x));
+        }();
+        if (rows) return;
+        // ---- every rank is through its local work: does anybody have to give up? ----
+        meet.arrive_and_wait();
+        if (failed.load()) {
+            if (rc[r] == MVS_OK) (void)mvs_synchronize(x);
+            return;
+        }
+        // ---- phase 2: the exchange ----
+        auto collective_failed = [&](const char *what, ncclResult_t q) {
+            fail_here(MVS_EHIP, what, c->rccl.GetErrorString(q));
+            abort_all();
+        };
         int e;
-        if ((e = mvs_sweep_set_main(x, main_cam, main_hw))) return fail_here(e, "mvs_sweep_set_main", mvs_last_error(x));
-        if ((e = mvs_sweep_set_views(x, vn, side_cams + 16 * (size_t)v0, side_frames + v0))) return fail_here(e, "mvs_sweep_set_views", mvs_last_error(x));
-        if ((e = mvs_sweep_set_planes(x, nplanes, z_lo, z_hi))) return fail_here(e, "mvs_sweep_set_planes", mvs_last_error(x));
-        if ((e = mvs_sweep_run(x, 0, vn, MVS_SWEEP_VOLUME))) return fail_here(e, "mvs_sweep_run", mvs_last_error(x));
-        size_t vol_bytes = 0;
-        uint32_t *vol = (uint32_t *)mvs_sweep_volume_device(x, &vol_bytes);
-        if (!vol) return fail_here(MVS_ESTATE, "mvs_sweep_volume_device", mvs_last_error(x));
-        hipStream_t st = x->stream;
         ncclResult_t q;
         if (scatter) {
-            if ((e = ensure(x, c->slice[r], (size_t)slice_planes * P * 4)) || (e = ensure(x, c->part[r], P * 8)) || (e = ensure(x, c->parts[r], (size_t)n * P * 8)))
-                return fail_here(e, "device allocation", mvs_last_error(x));
-            if ((q = c->rccl.ReduceScatter(vol, c->slice[r].ptr, (size_t)slice_planes * P, ncclUint32, ncclSum, c->comms[r], st)) != ncclSuccess)
-                return fail_here(MVS_EHIP, "ncclReduceScatter", c->rccl.GetErrorString(q));
-            if ((e = mvs_sweep_argmin_partial(x, c->slice[r].ptr, r * slice_planes, slice_planes, c->part[r].ptr)))
-                return fail_here(e, "mvs_sweep_argmin_partial", mvs_last_error(x));
-            if ((q = c->rccl.AllGather(c->part[r].ptr, c->parts[r].ptr, P, ncclUint64, c->comms[r], st)) != ncclSuccess)
-                return fail_here(MVS_EHIP, "ncclAllGather", c->rccl.GetErrorString(q));
-            if ((e = mvs_sweep_combine_partials(x, c->parts[r].ptr, n))) return fail_here(e, "mvs_sweep_combine_partials", mvs_last_error(x));
+            if ((q = c->rccl.ReduceScatter(vol, c->slice[r].ptr, (size_t)slice_planes * P, ncclUint32, ncclSum, c->comms[r], st)) != ncclSuccess) return collective_failed("ncclReduceScatter", q);
+            if ((e = mvs_sweep_argmin_partial(x, c->slice[r].ptr, r * slice_planes, slice_planes, c->part[r].ptr))) {
+                fail_here(e, "mvs_sweep_argmin_partial", mvs_last_error(x));
+                return abort_all();
+            }
+            if ((q = c->rccl.AllGather(c->part[r].ptr, c->parts[r].ptr, P, ncclUint64, c->comms[r], st)) != ncclSuccess) return collective_failed("ncclAllGather", q);
+            if ((e = mvs_sweep_combine_partials(x, c->parts[r].ptr, n))) {
+                fail_here(e, "mvs_sweep_combine_partials", mvs_last_error(x));
+                return abort_all();
+            }
         } else {
-            if ((q = c->rccl.AllReduce(vol, vol, (size_t)nplanes * P, ncclUint32, ncclSum, c->comms[r], st)) != ncclSuccess)
-                return fail_here(MVS_EHIP, "ncclAllReduce", c->rccl.GetErrorString(q));
-            if ((e = mvs_sweep_argmin(x))) return fail_here(e, "mvs_sweep_argmin", mvs_last_error(x));
+            // plane group g is summed over xGMI on the communication stream while group g + 1 is being swept on the context's stream
+            hipStream_t cs = c->comm_stream[r];
+            for (size_t g = 0; g < groups.size(); g++) {
+                if (g > 0 && (e = mvs_sweep_run_planes(x, 0, vn, groups[g].first, groups[g].second, MVS_SWEEP_VOLUME))) {
+                    fail_here(e, "mvs_sweep_run_planes", mvs_last_error(x));
+                    return abort_all();
+                }
+                hipEvent_t swept = c->events[r][2 * g], summed = c->events[r][2 * g + 1];
+                if (hipEventRecord(swept, st) != hipSuccess || hipStreamWaitEvent(cs, swept, 0) != hipSuccess) {
+                    fail_here(MVS_EHIP, "hipEventRecord / hipStreamWaitEvent", "failed");
+                    return abort_all();
+                }
+                uint32_t *grp = vol + (size_t)groups[g].first * P;
+                if ((q = c->rccl.AllReduce(grp, grp, (size_t)groups[g].second * P, ncclUint32, ncclSum, c->comms[r], cs)) != ncclSuccess) return collective_failed("ncclAllReduce", q);
+                if (hipEventRecord(summed, cs) != hipSuccess) {
+                    fail_here(MVS_EHIP, "hipEventRecord", "failed");
+                    return abort_all();
+                }
+            }
+            for (size_t g = 0; g < groups.size(); g++)
+                if (hipStreamWaitEvent(st, c->events[r][2 * g + 1], 0) != hipSuccess) {
+                    fail_here(MVS_EHIP, "hipStreamWaitEvent", "failed");
+                    return abort_all();
+                }
+            if ((e = mvs_sweep_argmin(x))) {
+                fail_here(e, "mvs_sweep_argmin", mvs_last_error(x));
+                return abort_all();
+            }
         }
         if (r == 0) {
-            if ((e = mvs_sweep_fetch(x, depth_hw, cost_hw, nullptr, nullptr))) return fail_here(e, "mvs_sweep_fetch", mvs_last_error(x));
+            if ((e = mvs_sweep_fetch(x, depth_hw, cost_hw, nullptr, nullptr))) fail_here(e, "mvs_sweep_fetch", mvs_last_error(x));
         } else if ((e = mvs_synchronize(x))) {
-            return fail_here(e, "mvs_synchronize", mvs_last_error(x));
+            fail_here(e, "mvs_synchronize", mvs_last_error(x));
         }
     };
     if (n == 1) {

@@ -17,6 +17,8 @@ MVS_SWEEP_VOLUME = 1
 MVS_SWEEP_FUSED_ARGMIN = 2
 MVS_SWEEP_FORCE_GENERIC = 4
 MVS_SWEEP_NO_RECT = 8
+MVS_SHARD_ROWS, MVS_SHARD_VIEWS, MVS_SHARD_VIEWS_SCATTER = 0, 1, 2
+SHARD_MODES = {"rows": 0, "views": 1, "views_scatter": 2}
 MVS_SAMPLER_FIXED, MVS_SAMPLER_EXACT_F32 = 0, 1
 SAMPLERS = {"fixed": MVS_SAMPLER_FIXED, "exact": MVS_SAMPLER_EXACT_F32}
 MVS_K_SWEEP, MVS_K_ARGMIN, MVS_K_PLAN, MVS_K_RASTER, MVS_K_PROJECT, MVS_K_FLOW = 0, 1, 2, 3, 4, 5
@@ -79,6 +81,9 @@ ABI = [
     ("mvs_comm_size", _i, [_vp]),
     ("mvs_comm_context", _vp, [_vp, _i]),
     ("mvs_comm_last_error", C.c_char_p, [_vp]),
+    ("mvs_comm_set_mode", _i, [_vp, _i]),
+    ("mvs_comm_mode", _i, [_vp]),
+    ("mvs_comm_set_plane_groups", _i, [_vp, _i]),
     ("mvs_sweep_sharded", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _f, _f, _fp, _fp]),
     ("mvs_profile_enable", _i, [_vp, _i]),
     ("mvs_profile_read", _i, [_vp, _fp, C.POINTER(_i), _i]),
@@ -157,7 +162,7 @@ def pinned_array(shape, dtype):
 
 
 class Comm:
-    """mvs_comm: one main view swept on several GPUs of one node (views dealt to the GPUs, volumes summed with RCCL)."""
+    """mvs_comm: one main view swept on several GPUs of one node (row bands by default; the views split with RCCL on request)."""
 
     def __init__(self, devices, width, height, sampler=None):
         self.lib = load_library()
@@ -174,6 +179,17 @@ class Comm:
 
     def size(self):
         return self.lib.mvs_comm_size(self.h)
+
+    def set_mode(self, mode, plane_groups=None):
+        """"rows" (default: row bands, no collective), "views" (plane-group all-reduce pipeline) or "views_scatter" (reduce-scatter)"""
+        rc = self.lib.mvs_comm_set_mode(self.h, SHARD_MODES[mode] if isinstance(mode, str) else int(mode))
+        if rc == 0 and plane_groups is not None:
+            rc = self.lib.mvs_comm_set_plane_groups(self.h, int(plane_groups))
+        if rc:
+            raise MvsError("libmvs_hip error %d: %s" % (rc, self.lib.mvs_comm_last_error(self.h).decode()))
+
+    def mode(self):
+        return self.lib.mvs_comm_mode(self.h)
 
     def close(self):
         if getattr(self, "h", None):

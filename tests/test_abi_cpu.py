@@ -55,6 +55,15 @@ def test_comm_argument_errors():
         assert "HIP" in str(e.value) or "no CPU fallback" in str(e.value)
 
 
+def test_comm_create_reports_a_missing_rccl_instead_of_crashing(monkeypatch):
+    """librccl is loaded before any GPU is touched; when it cannot be loaded mvs_comm_create returns NULL with the loader's message
+    (round 2 called dlerror() twice -- the second call returns NULL -- and built a std::string from it: a crash on exactly this path)"""
+    monkeypatch.setenv("MVS_RCCL_LIBRARY", "/nonexistent/librccl_missing.so")
+    with pytest.raises(mvs_amd.MvsError) as e:
+        mvs_amd.Comm([0], 64, 48)
+    assert "cannot load librccl" in str(e.value) and "librccl_missing" in str(e.value), str(e.value)
+
+
 def test_library_has_no_link_dependency_on_rccl():
     """RCCL is resolved with dlopen when a communicator is created (a process that already loaded one -- PyTorch -- shares it)"""
     import subprocess

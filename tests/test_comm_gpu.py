@@ -25,10 +25,17 @@ def test_single_device_comm_equals_one_call_sweep(oracle, sampler, monkeypatch):
     d_ref, c_ref, _, _ = oracle.sweep(main_cam, main_img, side_cams, sides, D, nthreads=8, sampler=sampler)
     np.testing.assert_array_equal(d1, d_ref)
     with mvs_amd.Comm([0], W, H, sampler=sampler) as comm:
-        assert comm.size() == 1
-        d, c = comm.sweep(main_cam, main_img, side_cams, sides, D)          # reduce-scatter / partial selection / all-gather / merge
-        np.testing.assert_array_equal(d, d1)
-        np.testing.assert_array_equal(c, c1)
+        assert comm.size() == 1 and comm.mode() == mvs_amd.MVS_SHARD_ROWS
+        for mode, groups in (("rows", None), ("views", 1), ("views", 2), ("views", 64), ("views_scatter", None)):
+            comm.set_mode(mode, groups)   # row bands / all-reduce pipeline by plane groups / reduce-scatter + partial selection + all-gather + merge
+            d, c = comm.sweep(main_cam, main_img, side_cams, sides, D)
+            np.testing.assert_array_equal(d, d1)
+            np.testing.assert_array_equal(c, c1)
+        with pytest.raises(mvs_amd.MvsError):
+            comm.set_mode(7)
+        with pytest.raises(mvs_amd.MvsError):
+            comm.set_mode("views", 0)
+        comm.set_mode("views_scatter")
         d, c = comm.sweep(main_cam, main_img, side_cams[:2], sides[:2], 7)   # other sizes on the same communicator
         with mvs_amd.Context(W, H, sampler=sampler) as ctx:
             d7, c7 = ctx.sweep(main_cam, main_img, side_cams[:2], sides[:2], 7, want_cost=True)
@@ -69,10 +76,12 @@ def test_multi_device_comm_equals_single_gpu(ndev):
     with mvs_amd.Context(W, H) as ctx:
         d1, c1 = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_cost=True)
     with mvs_amd.Comm(list(range(ndev)), W, H) as comm:
-        d, c = comm.sweep(main_cam, main_img, side_cams, sides, D)
-        np.testing.assert_array_equal(d, d1)
-        np.testing.assert_array_equal(c, c1)
-        d, c = comm.sweep(main_cam, main_img, side_cams, sides, D - 1)        # all-reduce fallback
+        for mode, groups in (("rows", None), ("views", 4), ("views", 1), ("views_scatter", None)):
+            comm.set_mode(mode, groups)
+            d, c = comm.sweep(main_cam, main_img, side_cams, sides, D)
+            np.testing.assert_array_equal(d, d1)
+            np.testing.assert_array_equal(c, c1)
+        d, c = comm.sweep(main_cam, main_img, side_cams, sides, D - 1)        # (scatter mode) all-reduce fallback
     with mvs_amd.Context(W, H) as ctx:
         d2, c2 = ctx.sweep(main_cam, main_img, side_cams, sides, D - 1, want_cost=True)
     np.testing.assert_array_equal(d, d2)
