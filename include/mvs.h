@@ -98,6 +98,16 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
                       const float *side_cams /* nside*16 */, const uint8_t *const *side_frames_hw, int use_farneback,
                       float *out_points7, int *out_count, float *depth_after_hw);
 
+/* Texture filter of Render::projected's frame texture.  The reference uploads the side frame with glGenerateMipmap and samples it
+ * with GL_LINEAR_MIPMAP_LINEAR (render_glx.cpp:83-85): MVS_FILTER_MIPMAP (default) builds the mip chain (2 x 2 box, u8 levels) per
+ * frame and blends the two levels the pixel's footprint calls for (fine derivatives on the 2 x 2 pixel quad, isotropic; DESIGN.md
+ * section 5 states the arithmetic, the oracle restates it); under magnification and at 1 : 1 it IS level-0 bilinear.
+ * MVS_FILTER_LEVEL0 samples level 0 only (rounds 1-2 of this library; the sweep's samplers always do). */
+#define MVS_FILTER_MIPMAP 0
+#define MVS_FILTER_LEVEL0 1
+int mvs_set_texture_filter(mvs_ctx *ctx, int filter);
+int mvs_texture_filter(const mvs_ctx *ctx);
+
 /* ---- point-cloud filter: replaces Heuristic::filterPoints (heuristic.cpp:55-176, recon.cpp:125) ------------------- */
 /* points4: npoints homogeneous rows; alpha = the reference's alphaVals.back() (radius = alpha/4, compared with squared
  * distances as the reference does).  keep_out receives the ascending indices of the retained points, *out_count how

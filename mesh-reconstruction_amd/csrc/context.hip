@@ -221,7 +221,7 @@ void mvs_destroy(mvs_ctx *ctx)
                       &ctx->volume_own, &ctx->depth, &ctx->cost, &ctx->index, &ctx->soup, &ctx->r_zbuf,
                       &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2,
                       &ctx->cubic_tab, &ctx->flow_arena, &ctx->frame_buf, &ctx->best_parts, &ctx->plan_stats, &ctx->probe_buf, &ctx->filter_sort, &ctx->raster_bins, &ctx->fx_lut, &ctx->side_quads, &ctx->side_quads16,
-                      &ctx->rect_tab, &ctx->store_raw, &ctx->store_pads, &ctx->store_quads, &ctx->batch_buf};
+                      &ctx->r_mips, &ctx->rect_tab, &ctx->store_raw, &ctx->store_pads, &ctx->store_quads, &ctx->batch_buf};
     for (int i = 0; i < 2; i++)
         if (ctx->flow_graph[i]) (void)hipGraphExecDestroy(ctx->flow_graph[i]);
     for (DevBuf *b : bufs)
@@ -399,27 +399,34 @@ int sweep_set_views_impl(mvs_ctx *ctx, int nviews, const float *side_cams, const
     if (!ctx || nviews < 0 || nviews > 256 || (nviews > 0 && (!side_cams || !side_frames)))
         return fail(ctx, MVS_EINVAL, "mvs_sweep_set_views: bad arguments (nviews=%d, must be 0..256)", nviews);
     if (!ctx->have_main) return fail(ctx, MVS_ESTATE, "mvs_sweep_set_views: call mvs_sweep_set_main first");
+    for (int v = 0; v < nviews; v++)
+        if (!side_frames[v]) return fail(ctx, MVS_EINVAL, "mvs_sweep_set_views: side_frames[%d] is null", v);
     MVS_HIP(ctx, hipSetDevice(ctx->device));
     const int W = ctx->W, H = ctx->H;
     const size_t P = (size_t)W * H;
+    // from here on the context's views are in flux: whatever fails below leaves it WITHOUT views (not with the previous call's
+    // flags over this call's sizes); V, the tables and the flags are committed together at the end
+    ctx->have_views = false;
+    ctx->plan_valid = false;
+    ctx->quads16_valid = false;
     ctx->pad_pitch = ((W + 2 + 63) / 64) * 64;
     ctx->pad_slab = (size_t)ctx->pad_pitch * (H + 2);
-    ctx->V = nviews;
+    ctx->V = 0;
     ctx->q_host.assign((size_t)nviews * 12, 0.f);
     if (nviews > 0) {
-        for (int v = 0; v < nviews; v++)
-            if (!side_frames[v]) return fail(ctx, MVS_EINVAL, "mvs_sweep_set_views: side_frames[%d] is null", v);
         // + 64: the staging loads of the exact sampler read whole dwords up to 7 bytes past a row's last used texel
         int rc = ensure(ctx, ctx->side_pads, ctx->pad_slab * nviews + 64);
         if (rc) return rc;
         if ((rc = ensure(ctx, ctx->upload, P * nviews))) return rc;  // one slot per view: no upload waits for the previous view's kernels
         if ((rc = ensure(ctx, ctx->qmats, sizeof(float) * 12 * nviews))) return rc;
-        if ((rc = ensure(ctx, ctx->side_quads, ctx->pad_slab * nviews * sizeof(uint32_t) + 256))) return rc;
+        if ((rc = ensure(ctx, ctx->side_quads, ctx->pad_slab * nviews * sizeof(uint32_t) + 4096))) return rc;
+        ctx->V = nviews;  // every allocation has succeeded: the buffers match this view count from here on
         for (int v = 0; v < nviews; v++) view_matrix(ctx->main_cam, side_cams + 16 * v, W, H, ctx->q_host.data() + 12 * v);
         MVS_HIP(ctx, hipMemcpyAsync(ctx->qmats.ptr, ctx->q_host.data(), sizeof(float) * 12 * nviews, hipMemcpyHostToDevice, ctx->stream));
         if (!defer_frames && (rc = sweep_upload_frames_impl(ctx, side_frames))) return rc;
         if (sync) MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    ctx->V = nviews;
     ctx->have_views = true;
     ctx->plan_valid = false;
     return MVS_OK;
@@ -452,6 +459,18 @@ int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const 
     return sweep_set_views_impl(ctx, nviews, side_cams, side_frames, true, false);
 }
 int mvs_sweep_set_planes(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi) { return sweep_set_planes_impl(ctx, nplanes, z_lo, z_hi, true); }
+
+int mvs_set_texture_filter(mvs_ctx *ctx, int filter)
+{
+    if (!ctx || (filter != MVS_FILTER_MIPMAP && filter != MVS_FILTER_LEVEL0)) return fail(ctx, MVS_EINVAL, "mvs_set_texture_filter: unknown filter %d", filter);
+    if (filter != ctx->texture_filter) {
+        // the cached flow graphs of mvs_process_frame were captured with the old kernel arguments
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->texture_filter = filter;
+    }
+    return MVS_OK;
+}
+int mvs_texture_filter(const mvs_ctx *ctx) { return ctx ? ctx->texture_filter : MVS_EINVAL; }
 
 int mvs_frame_store(mvs_ctx *ctx, int capacity) { return frame_store_impl(ctx, capacity); }
 int mvs_frame_upload(mvs_ctx *ctx, int slot, const uint8_t *frame_hw) { return frame_upload_impl(ctx, slot, frame_hw); }

@@ -414,11 +414,86 @@ __global__ __launch_bounds__(256) void shadow_dilate(const float *__restrict__ a
     out[p] = m;
 }
 
+// ---- mip chain of the frame texture (render_glx.cpp:83-85: GL_LINEAR_MIPMAP_LINEAR + glGenerateMipmap) ---------------------------
+// The contract is stated in oracle/raster_oracle.c (mip_build / mip_bilinear / orc_projected_filter) and DESIGN.md section 5: u8 levels
+// by 2 x 2 box with (sum + 2) >> 2, fine derivatives on the pixel's 2 x 2 quad with its own face, rho from the larger of the two
+// footprint axes, level = exponent of rho, blend fraction = rho 2^-level - 1, GL_REPEAT per level.
+constexpr int MAX_MIPS = 14;
+struct MipArgs {
+    int levels;                                       // levels above 0 (0: level 0 only)
+    int w[MAX_MIPS + 1], h[MAX_MIPS + 1], pitch[MAX_MIPS + 1];
+    unsigned off[MAX_MIPS + 1];                       // byte offset of the wrap-padded level image in `mips` (level 0: the padded frame itself)
+};
+
+// wrap-padded level l from wrap-padded level l - 1 (one thread per padded texel)
+__global__ __launch_bounds__(256) void mip_reduce(const uint8_t *__restrict__ src, int pw, int ph, int sp, uint8_t *__restrict__ dst, int w, int h, int dp)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= w + 2 || r >= h + 2) return;
+    int j = r - 1, i = c - 1;
+    j = j < 0 ? h - 1 : (j >= h ? 0 : j);
+    i = i < 0 ? w - 1 : (i >= w ? 0 : i);
+    const int x0 = min(2 * i, pw - 1), x1 = min(2 * i + 1, pw - 1), y0 = min(2 * j, ph - 1), y1 = min(2 * j + 1, ph - 1);
+    const int sum = src[(size_t)(y0 + 1) * sp + x0 + 1] + src[(size_t)(y0 + 1) * sp + x1 + 1] + src[(size_t)(y1 + 1) * sp + x0 + 1] + src[(size_t)(y1 + 1) * sp + x1 + 1];
+    dst[(size_t)r * dp + c] = (uint8_t)((sum + 2) >> 2);
+}
+
+// the small levels (<= 64 x 64 texels and everything above them) in one workgroup: one launch instead of one per level
+__global__ __launch_bounds__(256) void mip_tail(uint8_t *__restrict__ mips, const uint8_t *__restrict__ level0, MipArgs m, int first)
+{
+    for (int l = first; l <= m.levels; l++) {
+        const uint8_t *src = l - 1 == 0 ? level0 : mips + m.off[l - 1];
+        uint8_t *dst = mips + m.off[l];
+        const int pw = m.w[l - 1], ph = m.h[l - 1], sp = m.pitch[l - 1], w = m.w[l], h = m.h[l], dp = m.pitch[l];
+        for (int t = threadIdx.x; t < (w + 2) * (h + 2); t += blockDim.x) {
+            const int r = t / (w + 2), c = t % (w + 2);
+            int j = r - 1, i = c - 1;
+            j = j < 0 ? h - 1 : (j >= h ? 0 : j);
+            i = i < 0 ? w - 1 : (i >= w ? 0 : i);
+            const int x0 = min(2 * i, pw - 1), x1 = min(2 * i + 1, pw - 1), y0 = min(2 * j, ph - 1), y1 = min(2 * j + 1, ph - 1);
+            const int sum = src[(size_t)(y0 + 1) * sp + x0 + 1] + src[(size_t)(y0 + 1) * sp + x1 + 1] + src[(size_t)(y1 + 1) * sp + x0 + 1] + src[(size_t)(y1 + 1) * sp + x1 + 1];
+            dst[(size_t)r * dp + c] = (uint8_t)((sum + 2) >> 2);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ float mip_bilinear(const uint8_t *__restrict__ img, int w, int h, int pitch, float u, float vv)
+{
+    const float cx = __builtin_fmaf(u, (float)w, 0.5f);
+    const float cy = __builtin_fmaf(1.0f - vv, (float)h, 0.5f);
+    const int ix = (int)cx, iy = (int)cy;
+    const float ax = cx - (float)ix, ay = cy - (float)iy;
+    const uint8_t *q = img + (size_t)iy * pitch + ix;
+    const float t00 = (float)q[0], t01 = (float)q[1], t10 = (float)q[pitch], t11 = (float)q[pitch + 1];
+    const float dxt = t01 - t00, dy = t10 - t00, dxy = (t11 - t10) - dxt;
+    return __builtin_fmaf(ay, __builtin_fmaf(ax, dxy, dy), __builtin_fmaf(ax, dxt, t00));
+}
+
+// texture coordinates of a face at an NDC pixel centre, the face extrapolated past its edges (a GPU's helper invocations)
+__device__ __forceinline__ void face_uv(const TriRec &t, const float *__restrict__ v, const CamArg &prj, float xn, float yn, float &u, float &vv)
+{
+    float e[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) e[i] = __builtin_fmaf(t.a[i], xn, __builtin_fmaf(t.b[i], yn, t.c[i]));
+    const float esum = (e[0] + e[1]) + e[2];
+    float pos[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) pos[k] = __builtin_fmaf(e[0], v[k], __builtin_fmaf(e[1], v[3 + k], e[2] * v[6 + k])) / esum;
+    const float sx = xform(prj.m + 0, pos[0], pos[1], pos[2]);
+    const float sy = xform(prj.m + 4, pos[0], pos[1], pos[2]);
+    const float sw = xform(prj.m + 12, pos[0], pos[1], pos[2]);
+    u = __builtin_fmaf(0.5f, sx / sw, 0.5f);
+    vv = __builtin_fmaf(0.5f, sy / sw, 0.5f);
+}
+
 // shader.vert:9-13 + shader.frag:11-25 for the visible face of every main-view pixel
 __global__ __launch_bounds__(256) void project_texture(const float *__restrict__ soup, const TriRec *__restrict__ tris,
                                                        const int *__restrict__ ids, const float *__restrict__ shadow_gl,
                                                        const uint8_t *__restrict__ pad, int pitch, CamArg prj, int W,
-                                                       int H, float invW, float invH, uint8_t *__restrict__ out3)
+                                                       int H, float invW, float invH, uint8_t *__restrict__ out3,
+                                                       const uint8_t *__restrict__ mips, MipArgs mip)
 {
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -452,14 +527,28 @@ __global__ __launch_bounds__(256) void project_texture(const float *__restrict__
                 sj = ((sj % H) + H) % H;
                 const float shadowDepth = __builtin_fmaf(2.0f, shadow_gl[(size_t)sj * W + si], -1.0f);
                 if (shadowDepth + 0.01f > nz) {
-                    const float cx = __builtin_fmaf(u, fW, 0.5f);
-                    const float cy = __builtin_fmaf(1.0f - vv, fH, 0.5f);
-                    const int ix = (int)cx, iy = (int)cy;
-                    const float ax = cx - (float)ix, ay = cy - (float)iy;
-                    const uint8_t *q = pad + (size_t)iy * pitch + ix;
-                    const float t00 = (float)q[0], t01 = (float)q[1], t10 = (float)q[pitch], t11 = (float)q[pitch + 1];
-                    const float dxt = t01 - t00, dy = t10 - t00, dxy = (t11 - t10) - dxt;
-                    const float res = __builtin_fmaf(ay, __builtin_fmaf(ax, dxy, dy), __builtin_fmaf(ax, dxt, t00));
+                    float res = mip_bilinear(pad, W, H, pitch, u, vv);
+                    if (mip.levels > 0) {
+                        // the pixel's footprint in level-0 texels: finite differences on its 2 x 2 quad, same face
+                        float ux, vx, uy, vy;
+                        face_uv(t, v, prj, __builtin_fmaf((float)(2 * (col ^ 1) + 1), invW, -1.0f), yn, ux, vx);
+                        face_uv(t, v, prj, xn, __builtin_fmaf(-(float)(2 * (row ^ 1) + 1), invH, 1.0f), uy, vy);
+                        const float dudx = (ux - u) * fW, dvdx = (vx - vv) * fH, dudy = (uy - u) * fW, dvdy = (vy - vv) * fH;
+                        const float rx = dudx * dudx + dvdx * dvdx, ry = dudy * dudy + dvdy * dvdy;
+                        const float rho = sqrtf(rx > ry ? rx : ry);
+                        if (rho > 1.0f && rho < 3.0e38f) {
+                            const uint32_t bits = __builtin_bit_cast(uint32_t, rho);
+                            const int l0 = (int)((bits >> 23) & 0xffu) - 127;
+                            const float f = __builtin_bit_cast(float, (bits & 0x007fffffu) | 0x3f800000u) - 1.0f;  // rho 2^-l0 - 1, exact
+                            if (l0 >= mip.levels) {
+                                res = mip_bilinear(mips + mip.off[mip.levels], mip.w[mip.levels], mip.h[mip.levels], mip.pitch[mip.levels], u, vv);
+                            } else {
+                                const float s0 = l0 == 0 ? res : mip_bilinear(mips + mip.off[l0], mip.w[l0], mip.h[l0], mip.pitch[l0], u, vv);
+                                const float s1 = mip_bilinear(mips + mip.off[l0 + 1], mip.w[l0 + 1], mip.h[l0 + 1], mip.pitch[l0 + 1], u, vv);
+                                res = __builtin_fmaf(f, s1 - s0, s0);
+                            }
+                        }
+                    }
                     r = (uint8_t)(int)(res + 0.5f);
                     g = 255;
                 }
@@ -561,6 +650,39 @@ int projected_device(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_dev
     float *sh_raw = (float *)ctx->r_shadow.ptr, *sh_dil = sh_raw + P, *hf0 = sh_dil + P;
     pad_wrap_kernel<<<dim3(div_up(pitch, 256), H + 2), 256, 0, ctx->stream>>>(frame_dev, (uint8_t *)ctx->r_frame.ptr, W, H, pitch);
     MVS_HIP(ctx, hipGetLastError());
+    // the frame texture's mip chain (what the reference asks GL for; mvs_set_texture_filter(MVS_FILTER_LEVEL0) switches it off)
+    MipArgs mip;
+    memset(&mip, 0, sizeof(mip));
+    mip.w[0] = W;
+    mip.h[0] = H;
+    mip.pitch[0] = pitch;
+    if (ctx->texture_filter == MVS_FILTER_MIPMAP) {
+        size_t off = 0;
+        int l = 0;
+        while ((mip.w[l] > 1 || mip.h[l] > 1) && l < MAX_MIPS) {
+            l++;
+            mip.w[l] = mip.w[l - 1] > 1 ? mip.w[l - 1] >> 1 : 1;
+            mip.h[l] = mip.h[l - 1] > 1 ? mip.h[l - 1] >> 1 : 1;
+            mip.pitch[l] = mip.w[l] + 2;
+            mip.off[l] = (unsigned)off;
+            off += ((size_t)mip.pitch[l] * (mip.h[l] + 2) + 63) & ~(size_t)63;
+        }
+        mip.levels = l;
+        if ((rc = ensure(ctx, ctx->r_mips, off + 64))) return rc;
+        uint8_t *mips = (uint8_t *)ctx->r_mips.ptr;
+        int first_tail = mip.levels + 1;
+        for (int k = 1; k <= mip.levels; k++) {
+            if (mip.w[k] <= 64 && mip.h[k] <= 64) {
+                first_tail = k;
+                break;
+            }
+            const uint8_t *src = k == 1 ? (const uint8_t *)ctx->r_frame.ptr : mips + mip.off[k - 1];
+            mip_reduce<<<dim3(div_up(mip.w[k] + 2, 256), mip.h[k] + 2), 256, 0, ctx->stream>>>(src, mip.w[k - 1], mip.h[k - 1], mip.pitch[k - 1], mips + mip.off[k], mip.w[k],
+                                                                                          mip.h[k], mip.pitch[k]);
+        }
+        if (first_tail <= mip.levels) mip_tail<<<1, 256, 0, ctx->stream>>>(mips, (const uint8_t *)ctx->r_frame.ptr, mip, first_tail);
+        MVS_HIP(ctx, hipGetLastError());
+    }
     // pass 1: shadow map from the projector, GL orientation, then the dilation quirk
     if ((rc = run_raster(ctx, projector, 1, sh_raw, nullptr))) return rc;
     row0_prefix_min<<<1, 256, 0, ctx->stream>>>(sh_raw, W, hf0);
@@ -574,7 +696,7 @@ int projected_device(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_dev
     ProfileScope ps(ctx, MVS_K_PROJECT);
     project_texture<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, ctx->stream>>>(
         (const float *)ctx->soup.ptr, (const TriRec *)ctx->r_tmp2.ptr, (const int *)ctx->r_tmp0.ptr, sh_dil,
-        (const uint8_t *)ctx->r_frame.ptr, pitch, prj, W, H, 1.0f / (float)W, 1.0f / (float)H, out3_dev);
+        (const uint8_t *)ctx->r_frame.ptr, pitch, prj, W, H, 1.0f / (float)W, 1.0f / (float)H, out3_dev, (const uint8_t *)ctx->r_mips.ptr, mip);
     MVS_HIP(ctx, hipGetLastError());
     return MVS_OK;
 }

@@ -1044,9 +1044,29 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
 {
     if (!ctx) return MVS_EINVAL;
     if (!depth_hw) return fail(ctx, MVS_EINVAL, "mvs_sweep: depth_hw is null");
+    // whatever a later step would reject is rejected here, before the first copy of a caller buffer is queued
+    if (nviews < 0 || nviews > 256 || (nviews > 0 && (!side_cams || !side_frames))) return fail(ctx, MVS_EINVAL, "mvs_sweep: bad arguments (nviews=%d, must be 0..256)", nviews);
+    if (ctx->sampler == MVS_SAMPLER_FIXED && nviews > 255) return fail(ctx, MVS_EINVAL, "mvs_sweep: the fixed sampler's cells hold at most 255 views (have %d)", nviews);
+    if (nplanes < 1 || nplanes > 4096) return fail(ctx, MVS_EINVAL, "mvs_sweep: nplanes=%d out of range 1..4096", nplanes);
+    for (int v = 0; v < nviews; v++)
+        if (!side_frames[v]) return fail(ctx, MVS_EINVAL, "mvs_sweep: side_frames[%d] is null", v);
     int rc;
-    // everything below is queued on the stream without intermediate waits (the q / z host tables live in the context; pageable
-    // uploads return once staged); mvs_sweep_fetch at the end is the one synchronisation of the call
+    // Everything below is queued on the stream without intermediate waits (the q / z host tables live in the context; pageable
+    // uploads return once staged); mvs_sweep_fetch at the end is the one synchronisation of the call.  An early return must not
+    // leave copies of the caller's frames in flight (with mvs_host_alloc buffers they are truly asynchronous) nor the context
+    // claiming views whose frames never arrived: the guard joins the stream and drops the half-set inputs.
+    struct JoinOnError {
+        mvs_ctx *c;
+        bool armed = true;
+        ~JoinOnError()
+        {
+            if (!armed) return;
+            (void)hipStreamSynchronize(c->stream);
+            c->have_views = false;
+            c->plan_valid = false;
+            c->quads16_valid = false;
+        }
+    } join{ctx};
     if ((rc = sweep_set_main_impl(ctx, main_cam, main_hw, false))) return rc;
     if ((rc = sweep_set_views_impl(ctx, nviews, side_cams, side_frames, false, true))) return rc;  // tables only: the frames follow below
     if ((rc = sweep_set_planes_impl(ctx, nplanes, z_lo, z_hi, false))) return rc;
@@ -1072,6 +1092,7 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
         MVS_HIP(ctx, hipMemcpyAsync(volume_dhw, ctx->r_tmp0.ptr, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    join.armed = false;
     return MVS_OK;
 }
 

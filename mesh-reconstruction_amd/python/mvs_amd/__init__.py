@@ -63,6 +63,8 @@ ABI = [
     ("mvs_sweep_row_granularity", _i, []),
     ("mvs_sweep_row_granularity_of", _i, [_vp]),
     ("mvs_sweep_plan_shape", _i, [_vp]),
+    ("mvs_set_texture_filter", _i, [_vp, _i]),
+    ("mvs_texture_filter", _i, [_vp]),
     ("mvs_frame_store", _i, [_vp, _i]),
     ("mvs_frame_upload", _i, [_vp, _i, _vp]),
     ("mvs_sweep_batch", _i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, C.c_float, C.c_float, _vp, _vp]),
@@ -461,6 +463,10 @@ class Context:
         out = np.empty(rows.shape[0], np.float32)
         self._check(self.lib.mvs_depth_probe(self.h, _ptr(cam, _fp), rows.shape[0], _ptr(rows, _i32p), _ptr(cols, _i32p), _ptr(out, _fp)))
         return out
+
+    def set_texture_filter(self, name):
+        """"mipmap" (default: the reference's GL_LINEAR_MIPMAP_LINEAR request) or "level0" for Render::projected's frame texture"""
+        self._check(self.lib.mvs_set_texture_filter(self.h, {"mipmap": 0, "level0": 1}[name]))
 
     def projected(self, cam, frame, projector):
         cam = _f32(cam, (4, 4))

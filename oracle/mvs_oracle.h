@@ -96,6 +96,8 @@ void orc_shadow_dilate(float *zwin_gl, int W, int H);
 
 /* Render::projected: shadow pass, dilation, projective texture pass; out is H*W*3 u8 top-down.
  * render_glx.cpp:261-367 + shader.frag:11-25 */
+void orc_projected_filter(const float *soup, int nfaces, const float cam[16], const uint8_t *frame,
+                          const float projector[16], int W, int H, int mipmap, uint8_t *out_hw3);
 void orc_projected(const float *soup, int nfaces, const float cam[16], const uint8_t *frame,
                    const float projector[16], int W, int H, uint8_t *out_hw3);
 

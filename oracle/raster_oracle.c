@@ -214,8 +214,100 @@ void orc_shadow_dilate(float *shadow, int W, int H)
     free(prevRowHF);
 }
 
+/* ---- mip chain of the frame texture (render_glx.cpp:83-85: GL_LINEAR_MIPMAP_LINEAR + glGenerateMipmap) ----------------------
+ * The contract this project states for what the reference leaves to the OpenGL driver:
+ *   levels    level l has max(1, w >> 1) x max(1, h >> 1) texels of level l - 1's w x h; texel (i, j) = (a + b + c + d + 2) >> 2 over the
+ *             2 x 2 block at (2 i, 2 j) of level l - 1 (indices clamped to its last row / column), kept as u8 like a GL_R8 level
+ *   footprint fine derivatives on the pixel's 2 x 2 quad with the pixel's OWN face: partner pixels col ^ 1 and row ^ 1,
+ *             rho = sqrt(max(dudx^2 + dvdx^2, dudy^2 + dvdy^2)) in level-0 texels (GL 3.0 eq. 3.21, isotropic: the reference's
+ *             request for maximal anisotropy, render_glx.cpp:79-80, is implementation-defined and not modelled)
+ *   lod       rho <= 1: magnification, level 0 GL_LINEAR (the level-0 path unchanged).  Otherwise l0 = floor(log2 rho) from the
+ *             exponent and the fraction f = rho 2^-l0 - 1 (the piecewise-linear log2 of texture hardware; exact in f32), both levels
+ *             sampled bilinearly with GL_REPEAT, result fma(f, s1 - s0, s0); past the last level: that level alone
+ * Every operation is spelled out so that the HIP kernel (raster.hip: project_texture) reproduces it bit for bit. */
+#define ORC_MAX_MIPS 16
+typedef struct {
+    int levels;                      /* levels above 0 */
+    int w[ORC_MAX_MIPS], h[ORC_MAX_MIPS], pitch[ORC_MAX_MIPS];
+    uint8_t *pad[ORC_MAX_MIPS];      /* wrap-padded level images, [0] = the caller's level-0 padded frame */
+} MipChain;
+
+static void mip_build(const uint8_t *pad0, int W, int H, int pitch0, MipChain *mc)
+{
+    mc->levels = 0;
+    mc->w[0] = W;
+    mc->h[0] = H;
+    mc->pitch[0] = pitch0;
+    mc->pad[0] = (uint8_t *)pad0;
+    int l = 0;
+    while ((mc->w[l] > 1 || mc->h[l] > 1) && l + 1 < ORC_MAX_MIPS) {
+        const int pw = mc->w[l], ph = mc->h[l], w = pw > 1 ? pw >> 1 : 1, h = ph > 1 ? ph >> 1 : 1;
+        uint8_t *tight = (uint8_t *)malloc((size_t)w * h);
+        const uint8_t *src = mc->pad[l];
+        const int sp = mc->pitch[l];
+        for (int j = 0; j < h; j++)
+            for (int i = 0; i < w; i++) {
+                const int x0 = 2 * i < pw ? 2 * i : pw - 1, x1 = 2 * i + 1 < pw ? 2 * i + 1 : pw - 1;
+                const int y0 = 2 * j < ph ? 2 * j : ph - 1, y1 = 2 * j + 1 < ph ? 2 * j + 1 : ph - 1;
+                const int sum = src[(size_t)(y0 + 1) * sp + x0 + 1] + src[(size_t)(y0 + 1) * sp + x1 + 1] + src[(size_t)(y1 + 1) * sp + x0 + 1] +
+                                src[(size_t)(y1 + 1) * sp + x1 + 1];
+                tight[(size_t)j * w + i] = (uint8_t)((sum + 2) >> 2);
+            }
+        l++;
+        mc->w[l] = w;
+        mc->h[l] = h;
+        mc->pitch[l] = w + 2;
+        mc->pad[l] = (uint8_t *)malloc((size_t)(w + 2) * (h + 2));
+        orc_pad_image(tight, w, h, mc->pad[l], w + 2);
+        free(tight);
+    }
+    mc->levels = l;
+}
+
+static void mip_free(MipChain *mc)
+{
+    for (int l = 1; l <= mc->levels; l++) free(mc->pad[l]);
+}
+
+/* GL_LINEAR with GL_REPEAT at level l, texture coordinates (u, 1 - v) in [0, 1): the level-0 arithmetic of SURVEY A-7 */
+static float mip_bilinear(const MipChain *mc, int l, float u, float vv)
+{
+    const float cx = fmaf(u, (float)mc->w[l], 0.5f);
+    const float cy = fmaf(1.0f - vv, (float)mc->h[l], 0.5f);
+    const int ix = (int)cx, iy = (int)cy;
+    const float ax = cx - (float)ix, ay = cy - (float)iy;
+    const uint8_t *q = mc->pad[l] + (size_t)iy * mc->pitch[l] + ix;
+    const int pitch = mc->pitch[l];
+    const float t00 = (float)q[0], t01 = (float)q[1], t10 = (float)q[pitch], t11 = (float)q[pitch + 1];
+    const float dxt = t01 - t00, dy = t10 - t00, dxy = (t11 - t10) - dxt;
+    return fmaf(ay, fmaf(ax, dxy, dy), fmaf(ax, dxt, t00));
+}
+
+/* texture coordinates of face (t, v) at NDC pixel centre (xn, yn), the face extrapolated past its edges (what a GPU's helper
+ * invocations do for the finite differences) */
+static void face_uv(const TriSetup *t, const float *v, const float *projector, float xn, float yn, float *u, float *vv)
+{
+    float e[3];
+    for (int i = 0; i < 3; i++) e[i] = fmaf(t->a[i], xn, fmaf(t->b[i], yn, t->c[i]));
+    const float esum = (e[0] + e[1]) + e[2];
+    float pos[3];
+    for (int k = 0; k < 3; k++) pos[k] = fmaf(e[0], v[k], fmaf(e[1], v[3 + k], e[2] * v[6 + k])) / esum;
+    const float sx = xform(projector + 0, pos[0], pos[1], pos[2]);
+    const float sy = xform(projector + 4, pos[0], pos[1], pos[2]);
+    const float sw = xform(projector + 12, pos[0], pos[1], pos[2]);
+    *u = fmaf(0.5f, sx / sw, 0.5f);
+    *vv = fmaf(0.5f, sy / sw, 0.5f);
+}
+
 void orc_projected(const float *soup, int nfaces, const float cam[16], const uint8_t *frame,
                    const float projector[16], int W, int H, uint8_t *out_hw3)
+{
+    orc_projected_filter(soup, nfaces, cam, frame, projector, W, H, 1, out_hw3);
+}
+
+/* mipmap != 0: the frame texture is sampled with the mip chain above (the reference's request); 0: level 0 only */
+void orc_projected_filter(const float *soup, int nfaces, const float cam[16], const uint8_t *frame,
+                          const float projector[16], int W, int H, int mipmap, uint8_t *out_hw3)
 {
     const size_t P = (size_t)W * H;
     float *shadow = (float *)malloc(sizeof(float) * P);
@@ -230,6 +322,8 @@ void orc_projected(const float *soup, int nfaces, const float cam[16], const uin
     orc_shadow_dilate(shadow, W, H);
     /* frame texture: GL_RED u8, REPEAT, bilinear at level 0 (65-88) */
     orc_pad_image(frame, W, H, pad, pitch);
+    MipChain mc;
+    mip_build(pad, W, H, pitch, &mc);
     /* pass 2: main camera, colour + depth cleared (336) */
     raster_td(soup, nfaces, cam, W, H, zmain, id);
 
@@ -277,11 +371,37 @@ void orc_projected(const float *soup, int nfaces, const float cam[16], const uin
             const uint8_t *q = pad + (size_t)iy * pitch + ix;
             const float t00 = (float)q[0], t01 = (float)q[1], t10 = (float)q[pitch], t11 = (float)q[pitch + 1];
             const float dxt = t01 - t00, dy = t10 - t00, dxy = (t11 - t10) - dxt;
-            const float res = fmaf(ay, fmaf(ax, dxy, dy), fmaf(ax, dxt, t00));
+            float res = fmaf(ay, fmaf(ax, dxy, dy), fmaf(ax, dxt, t00));
+            if (mipmap && mc.levels > 0) {
+                /* footprint of the pixel in level-0 texels: finite differences on its 2 x 2 quad, same face */
+                float ux, vx, uy, vy;
+                face_uv(&t, v, projector, orc_pixel_xn(col ^ 1, W), yn, &ux, &vx);
+                face_uv(&t, v, projector, xn, orc_pixel_yn(row ^ 1, H), &uy, &vy);
+                const float dudx = (ux - u) * fW, dvdx = (vx - vv) * fH, dudy = (uy - u) * fW, dvdy = (vy - vv) * fH;
+                const float rx = dudx * dudx + dvdx * dvdx, ry = dudy * dudy + dvdy * dvdy;
+                const float rho = sqrtf(rx > ry ? rx : ry);
+                if (rho > 1.0f && rho < 3.0e38f) {
+                    uint32_t bits;
+                    memcpy(&bits, &rho, 4);
+                    int l0 = (int)((bits >> 23) & 0xffu) - 127;
+                    /* rho 2^-l0 - 1: the significand's fraction, exact */
+                    uint32_t mb = (bits & 0x007fffffu) | 0x3f800000u;
+                    float f;
+                    memcpy(&f, &mb, 4);
+                    f = f - 1.0f;
+                    if (l0 >= mc.levels) {
+                        res = mip_bilinear(&mc, mc.levels, u, vv);
+                    } else {
+                        const float s0 = l0 == 0 ? res : mip_bilinear(&mc, l0, u, vv), s1 = mip_bilinear(&mc, l0 + 1, u, vv);
+                        res = fmaf(f, s1 - s0, s0);
+                    }
+                }
+            }
             o[0] = (uint8_t)(int)(res + 0.5f); /* RGB8 framebuffer write */
             o[1] = o[2] = 255;                 /* shader.frag:24 */
         }
     }
+    mip_free(&mc);
     free(pad);
     free(id);
     free(zmain);

@@ -43,6 +43,7 @@ class Oracle:
             ("orc_depth", [_fp, C.c_int, _fp, C.c_int, C.c_int, _fp]),
             ("orc_shadow_dilate", [_fp, C.c_int, C.c_int]),
             ("orc_projected", [_fp, C.c_int, _fp, _u8p, _fp, C.c_int, C.c_int, _u8p]),
+            ("orc_projected_filter", [_fp, C.c_int, _fp, _u8p, _fp, C.c_int, C.c_int, C.c_int, _u8p]),
             ("orc_compare_u8", [_u8p, _u8p, C.c_int, C.c_int, _fp]),
             ("orc_compare_f32", [_fp, _fp, C.c_int, C.c_int, _fp]),
             ("orc_flow_remap", [_fp, C.c_int, _u8p, C.c_int, C.c_int, _u8p]),
@@ -170,14 +171,15 @@ class Oracle:
         self.lib.orc_shadow_dilate(self._p(a, _fp), W, H)
         return a
 
-    def projected(self, soup, cam, frame, projector):
+    def projected(self, soup, cam, frame, projector, mipmap=True):
+        """Render::projected; mipmap: the frame texture with its mip chain (what the reference asks GL for) or level 0 only"""
         H, W = frame.shape
         cam = np.ascontiguousarray(cam, np.float32)
         prj = np.ascontiguousarray(projector, np.float32)
         frame = np.ascontiguousarray(frame, np.uint8)
         out = np.empty((H, W, 3), np.uint8)
-        self.lib.orc_projected(self._p(soup, _fp), soup.shape[0], self._p(cam, _fp), self._p(frame, _u8p),
-                               self._p(prj, _fp), W, H, self._p(out, _u8p))
+        self.lib.orc_projected_filter(self._p(soup, _fp), soup.shape[0], self._p(cam, _fp), self._p(frame, _u8p),
+                                      self._p(prj, _fp), W, H, 1 if mipmap else 0, self._p(out, _u8p))
         return out
 
 

@@ -1,5 +1,7 @@
-"""How far is level-0 bilinear (what Render::projected and the sweep implement) from the reference's actual texture filter
-when a side view is MINIFIED?  createTexture asks for GL_LINEAR_MIPMAP_LINEAR + glGenerateMipmap + maximal anisotropy
+"""How far is level-0 bilinear (what the sweep's samplers implement, and Render::projected with MVS_FILTER_LEVEL0) from the
+reference's actual texture filter when a side view is MINIFIED?  (Since round 3 Render::projected builds the mip chain and blends
+two levels by default -- oracle/raster_oracle.c states that contract, tests/test_raster_gpu.py checks the HIP kernel against it;
+this test is the independent numpy statement of the same GL rule and keeps the numbers of DESIGN.md section 5.)  createTexture asks for GL_LINEAR_MIPMAP_LINEAR + glGenerateMipmap + maximal anisotropy
 (render_glx.cpp:79-85); SURVEY.md A-7 treats everything beyond level-0 bilinear as tolerance.  This test puts a number on it:
 a trilinear restatement (2x2 box mip chain, LOD = log2 of the isotropic footprint, linear blend of the two nearest levels --
 the GL 3.0 rules without the driver-specific anisotropic refinement) against level-0 bilinear, for a side view whose texels are

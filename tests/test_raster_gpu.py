@@ -192,9 +192,43 @@ def test_parity_hook_warp_by_depth(oracle, sampler):
         ctx.set_sampler(sampler)
         depth = ctx.depth(cam)
         warp = ctx.warp_by_depth(cam, depth, prj, side_img)
-        proj = ctx.projected(cam, side_img, prj)
+        ctx.set_texture_filter("level0")   # the sweep's samplers fetch level 0: the hook compares like with like (the mip-mapped
+        proj = ctx.projected(cam, side_img, prj)  # projected() departs from it wherever the footprint exceeds one texel)
     np.testing.assert_array_equal(warp, oracle.warp_by_depth(cam, depth, prj, side_img, sampler=sampler))
     both = (proj[..., 1] == 255) & (warp[..., 1] == 255)
     diff = np.abs(proj[..., 0].astype(int) - warp[..., 0].astype(int))[both]
     print("sampler %s: |warp - projected| <= %d grey levels, equal in %.4f of the pixels" % (sampler, diff.max(), np.mean(diff == 0)))
     assert both.mean() > 0.8 and diff.max() <= (1 if sampler == "exact" else 2) and np.mean(diff == 0) > (0.97 if sampler == "exact" else 0.80)
+
+
+@pytest.mark.parametrize("zoom", [1.0, 1.5, 2.0, 3.3])
+def test_projected_with_mipmaps_under_minification(oracle, zoom):
+    """the frame texture's mip chain (render_glx.cpp:83-85): a projector whose field of view is `zoom` times narrower than the main
+    camera's sees the surface `zoom` times denser, so a main-view pixel covers ~zoom texels of the side frame -- the footprint picks
+    levels 0 / 0-1 / 1 / 1-2 of the chain.  HIP == oracle byte for byte with the mip chain and with level 0 only; the two filters agree
+    at 1 : 1 and part ways under minification (on noise: the worst case)"""
+    W, H = 320, 208
+    verts, faces = scenes.heightfield_mesh(48)
+    soup, ctx = _both(oracle, W, H, verts, faces)
+    rng = np.random.default_rng(3)
+    frame = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    cam = synth.camera_at([0.02, -0.01, 0.0], W, H)
+    prj = synth.camera_at([0.05, 0.02, 0.0], W, H, fovx=synth.FOVX / zoom)
+    with ctx:
+        got = ctx.projected(cam, frame, prj)
+        ref = oracle.projected(soup, cam, frame, prj, mipmap=True)
+        np.testing.assert_array_equal(got, ref)
+        ctx.set_texture_filter("level0")
+        got0 = ctx.projected(cam, frame, prj)
+        ref0 = oracle.projected(soup, cam, frame, prj, mipmap=False)
+        np.testing.assert_array_equal(got0, ref0)
+        ctx.set_texture_filter("mipmap")
+        np.testing.assert_array_equal(ctx.projected(cam, frame, prj), ref)
+    valid = (ref[..., 1] == 255) & (ref0[..., 1] == 255)
+    assert valid.sum() > 2000 and np.array_equal(ref[..., 1], ref0[..., 1])
+    diff = np.abs(ref[..., 0].astype(int) - ref0[..., 0].astype(int))[valid]
+    print("zoom %.1f: mean |mipmap - level0| = %.2f grey levels on noise, %.1f %% of the pixels differ" % (zoom, diff.mean(), 100.0 * (diff > 0).mean()))
+    if zoom == 1.0:
+        assert diff.mean() < 2.0          # footprints within a few per cent of one texel: level 0 almost everywhere
+    if zoom >= 2.0:
+        assert diff.mean() > 10.0         # this is where the reference's mip-mapping matters
