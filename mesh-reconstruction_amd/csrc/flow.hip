@@ -224,11 +224,15 @@ __device__ __forceinline__ void update_matrix_at(const float *__restrict__ R0, c
     m[4] = r6 * r2 + r5 * r3;
 }
 
+// (blockIdx.z = flow of a batch: R1, flow and M advance by their strides, R0 -- the common first frame -- does not)
 __global__ __launch_bounds__(256) void update_matrices_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                               const float *__restrict__ flow, int w, int h,
-                                                              float *__restrict__ M)
+                                                              float *__restrict__ M, ptrdiff_t r1_z = 0, ptrdiff_t flow_z = 0, ptrdiff_t m_z = 0)
 {
     PIX2D
+    R1 += r1_z * blockIdx.z;
+    flow += flow_z * blockIdx.z;
+    M += m_z * blockIdx.z;
     update_matrix_at(R0, R1, flow[((size_t)y * w + x) * 2], flow[((size_t)y * w + x) * 2 + 1], x, y, w, h,
                      M + ((size_t)y * w + x) * 5);
 }
@@ -274,9 +278,14 @@ constexpr int FB_MAXM = 40;  // window radius the LDS buffer is sized for (winsi
 
 __global__ __launch_bounds__(256) void farneback_iteration_fused(const float *__restrict__ M_in, const float *__restrict__ R0,
                                                                  const float *__restrict__ R1, int w, int h, int m, double scale,
-                                                                 float *__restrict__ flow, float *__restrict__ M_out)
+                                                                 float *__restrict__ flow, float *__restrict__ M_out, ptrdiff_t m_z = 0, ptrdiff_t r1_z = 0,
+                                                                 ptrdiff_t flow_z = 0)
 {
     __shared__ double vsum[4 * (64 + 2 * FB_MAXM) * 5];
+    M_in += m_z * blockIdx.z;   // blockIdx.z = flow of a batch (mvs_process_frame: every side view of a main frame in one launch)
+    R1 += r1_z * blockIdx.z;
+    flow += flow_z * blockIdx.z;
+    if (M_out) M_out += m_z * blockIdx.z;
     const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * 4, cols = 64 + 2 * m;
     for (int i = threadIdx.x; i < 4 * cols; i += 256) {
         const int r = i / cols, cx = i - r * cols, gy = Y0 + r;
@@ -989,6 +998,174 @@ static int flow_run(mvs_ctx *ctx, const FlowBufs &b, int use_farneback)
         return MVS_OK;
     }
     return enqueue();
+}
+
+// ---- calculateFlow (Farneback) of SEVERAL next-frames against one previous frame in one pass --------------------------------
+// recon.cpp:76-112 computes calculateFlow(main frame, mixed_i) for every side view i of a main frame: same sizes, same parameters,
+// the same first frame.  As separate chains (one per side view, even on concurrent streams) a flow is ~150 launches of a few
+// microseconds each (11 pyramid levels x 7 iterations: 47 % of the time in 9 us launches, profiles/r02); here every launch covers
+// all B flows (blockIdx.z), so the launch count per main frame falls B-fold and the small pyramid levels fill more of the chip,
+// and everything that depends on the first frame alone (its blur, its polynomial expansion R0) is computed once, not B times.
+// Per-pixel arithmetic and summation orders are those of farneback_device: results are bit-identical.
+struct FlowBatchBufs {
+    float *F, *tmp, *blur, *I, *row3, *R, *M, *M2, *flowA, *flowB, *flow2, *var;
+    uint8_t *r8;
+    size_t floats;
+};
+
+static FlowBatchBufs flow_batch_layout(float *arena, size_t P, int B)
+{
+    FlowBatchBufs b;
+    const size_t n = (size_t)B + 1;  // image 0 = the common previous frame, 1 + i = next frame i
+    float *p = arena;
+    auto take = [&](size_t count) {
+        float *r = p;
+        p += count;
+        return r;
+    };
+    b.F = take(n * P);
+    b.tmp = take(n * P);
+    b.blur = take(n * P);
+    b.I = take(n * P);
+    b.row3 = take(n * 3 * P);
+    b.R = take(n * 5 * P);
+    b.M = take((size_t)B * 5 * P);
+    b.M2 = take((size_t)B * 5 * P);
+    b.flowA = take((size_t)B * 2 * P);
+    b.flowB = take((size_t)B * 2 * P);
+    b.flow2 = take((size_t)B * 2 * P);
+    b.var = take((size_t)B * P);
+    b.r8 = (uint8_t *)take(((size_t)B * P + 3) / 4);
+    b.floats = (size_t)(p - arena);
+    return b;
+}
+
+static int farneback_batch_enqueue(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8 /* B frames, P apart */, int B, float *out4 /* B x 4P */, const FlowBatchBufs &b)
+{
+    const int W = ctx->W, H = ctx->H;
+    const size_t P = (size_t)W * H;
+    const ptrdiff_t sP = (ptrdiff_t)P;
+    hipStream_t st = ctx->stream;
+    const double poly_sigma = (H + W) / 1000.0, pyr_scale = 0.8;  // flow.cpp:24-25
+    const int winsize = (H + W) / 100, poly_n = poly_sigma < 1.5 ? 5 : 7, iterations = 7;
+    int levels = 10;
+    if (poly_n > 15) return fail(ctx, MVS_EINVAL, "farneback: poly_n %d too large", poly_n);
+    const int m = winsize / 2;
+    if (m > FB_MAXM) return fail(ctx, MVS_EINVAL, "farneback (batched): window %d beyond the fused iteration's buffer", winsize);
+    int lw[64], lh[64];
+    double ls[64];
+    {
+        int k;
+        double scale = 1;
+        for (k = 0; k < levels; k++) {
+            scale *= pyr_scale;
+            if (W * scale < 32 || H * scale < 32) break;
+        }
+        levels = k;
+        for (k = 0; k <= levels; k++) {
+            scale = 1;
+            for (int i = 0; i < k; i++) scale *= pyr_scale;
+            ls[k] = scale;
+            lw[k] = (int)std::lrint(W * scale);
+            lh[k] = (int)std::lrint(H * scale);
+        }
+    }
+    u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(prev8, b.F, P);
+    u8_to_f32_kernel<<<g1(P * B), 256, 0, st>>>(next8, b.F + P, P * B);
+    PolyTaps pt;
+    farneback_taps(poly_n, poly_sigma, pt);
+    float *flow = nullptr, *prevflow = nullptr;
+    int pw = 0, ph = 0;
+    for (int k = levels; k >= 0; k--) {
+        const double sigma = (1. / ls[k] - 1) * 0.5;
+        int smooth_sz = (int)std::lrint(sigma * 5) | 1;
+        if (smooth_sz < 3) smooth_sz = 3;
+        if (smooth_sz > 63) return fail(ctx, MVS_EINVAL, "farneback: smoothing kernel %d too large", smooth_sz);
+        const int w = lw[k], h = lh[k];
+        flow = k == 0 ? b.flow2 : (prevflow == b.flowA ? b.flowB : b.flowA);
+        dim3 gF = g2(W, H), gL = g2(w, h), gB = g2(w, h);
+        gF.z = gL.z = (unsigned)(B + 1);
+        gB.z = (unsigned)B;
+        if (!prevflow) {
+            MVS_HIP(ctx, hipMemsetAsync(flow, 0, sizeof(float) * 2 * P * B, st));
+        } else {
+            resize_linear_kernel<2><<<gB, 256, 0, st>>>(prevflow, pw, ph, flow, w, h, (float)(1. / pyr_scale), 1, 2 * sP, 2 * sP);
+        }
+        Taps taps;
+        gaussian_taps(smooth_sz, sigma, taps.k);
+        gauss_kernel<false><<<gF, 256, 0, st>>>(b.F, W, H, taps, smooth_sz, b.tmp, sP, sP);
+        gauss_kernel<true><<<gF, 256, 0, st>>>(b.tmp, W, H, taps, smooth_sz, b.blur, sP, sP);
+        resize_linear_kernel<1><<<gL, 256, 0, st>>>(b.blur, W, H, b.I, w, h, 1.f, 0, sP, sP);
+        polyexp_vert<<<gL, 256, 0, st>>>(b.I, w, h, pt, b.row3, sP, 3 * sP);
+        polyexp_horiz<<<gL, 256, 0, st>>>(b.row3, w, h, pt, b.R, 3 * sP, 5 * sP);
+        const float *R0 = b.R, *R1 = b.R + 5 * P;
+        update_matrices_kernel<<<gB, 256, 0, st>>>(R0, R1, flow, w, h, b.M, 5 * sP, 2 * sP, 5 * sP);
+        const double bscale = 1. / ((double)winsize * winsize);
+        float *M_cur = b.M, *M_nxt = b.M2;
+        for (int it = 0; it < iterations; it++) {
+            farneback_iteration_fused<<<gB, 256, 0, st>>>(M_cur, R0, R1, w, h, m, bscale, flow, it < iterations - 1 ? M_nxt : nullptr, 5 * sP, 5 * sP, 2 * sP);
+            std::swap(M_cur, M_nxt);
+        }
+        MVS_HIP(ctx, hipGetLastError());
+        prevflow = flow;
+        pw = w;
+        ph = h;
+    }
+    // variance channel per flow: compare(prev, flowRemap(flow, next)) (flow.cpp:34), then the packing (37-41)
+    for (int i = 0; i < B; i++) {
+        int r;
+        if ((r = remap_device(ctx, b.flow2 + (size_t)i * 2 * P, 2, next8 + (size_t)i * P, b.r8 + (size_t)i * P))) return r;
+        if ((r = compare_device(ctx, prev8, b.r8 + (size_t)i * P, b.var + (size_t)i * P))) return r;
+        pack_flow4<<<g1(P), 256, 0, st>>>(b.flow2 + (size_t)i * 2 * P, b.var + (size_t)i * P, out4 + (size_t)i * 4 * P, P);
+    }
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+// calculateFlow(prev, next_i, useFarneback = true) for i < B on device buffers (next8: B frames P bytes apart, out4: B x H*W*4 f32);
+// in-stream, recorded once per (buffers, B) as a hipGraph and replayed
+int flow_farneback_batch_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int B, float *out4_dev)
+{
+    const size_t P = (size_t)ctx->W * ctx->H;
+    if (B < 1 || B > 64) return fail(ctx, MVS_EINVAL, "flow batch of %d", B);
+    int rc;
+    const FlowBatchBufs probe = flow_batch_layout(nullptr, P, B);
+    if ((rc = ensure(ctx, ctx->flow_batch_arena, sizeof(float) * probe.floats + 256))) return rc;
+    if ((rc = ensure_cubic_table(ctx))) return rc;
+    if ((rc = compare_prepare(ctx))) return rc;
+    const FlowBatchBufs b = flow_batch_layout((float *)ctx->flow_batch_arena.ptr, P, B);
+    static const bool no_graph = getenv("MVS_NO_GRAPH") != nullptr;
+    auto &g = ctx->flow_batch_graph;
+    const bool same = g.exec && g.arena == ctx->flow_batch_arena.ptr && g.tmp == ctx->r_tmp1.ptr && g.prev == prev_dev && g.next == next_dev && g.out == out4_dev && g.B == B;
+    if (g.exec && !same) {
+        (void)hipGraphExecDestroy(g.exec);
+        g.exec = nullptr;
+    }
+    if (!g.exec && !no_graph) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int r = farneback_batch_enqueue(ctx, prev_dev, next_dev, B, out4_dev, b);
+            const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+            if (r == MVS_OK && e == hipSuccess && graph && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                g.arena = ctx->flow_batch_arena.ptr;
+                g.tmp = ctx->r_tmp1.ptr;
+                g.prev = prev_dev;
+                g.next = next_dev;
+                g.out = out4_dev;
+                g.B = B;
+            } else {
+                g.exec = nullptr;
+                (void)hipGetLastError();
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+    }
+    ProfileScope ps(ctx, MVS_K_FLOW);
+    if (g.exec) {
+        MVS_HIP(ctx, hipGraphLaunch(g.exec, ctx->stream));
+        return MVS_OK;
+    }
+    return farneback_batch_enqueue(ctx, prev_dev, next_dev, B, out4_dev, b);
 }
 
 // calculateFlow on device buffers (prev/next: H*W u8, out4: H*W*4 f32), all in-stream

@@ -80,6 +80,12 @@ struct mvs_ctx {
     int texture_filter = MVS_FILTER_MIPMAP;  // Render::projected's frame texture: mip chain + trilinear (the reference's request) or level 0 only
     mvs::DevBuf cubic_tab;           // Q15 bicubic weights for remap (32*32*16 shorts)
     mvs::DevBuf flow_arena;          // optical-flow pyramids and work buffers
+    mvs::DevBuf flow_batch_arena;    // the same for the batched Farneback of mvs_process_frame (all side views of a main frame per launch)
+    struct FlowBatchGraph {
+        hipGraphExec_t exec = nullptr;
+        const void *arena = nullptr, *tmp = nullptr, *prev = nullptr, *next = nullptr, *out = nullptr;
+        int B = 0;
+    } flow_batch_graph;
     mvs::DevBuf frame_buf;           // mvs_process_frame: frames, depth, warped image, flows of one main frame
     mvs::DevBuf best_parts;          // plane-split sweeps: partial (best cell, best index) per split and pixel
     // frame store (mvs_frame_store / mvs_frame_upload / mvs_sweep_batch): the frames of a sequence, uploaded once, each as raw frame,
@@ -160,6 +166,7 @@ int depth_device(mvs_ctx *ctx, const float cam[16], float *out_dev);
 int projected_device(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev);
 int mix_background_device(mvs_ctx *ctx, const uint8_t *img3_dev, const uint8_t *bg_dev, float *depth_dev, uint8_t *out_dev);
 int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int use_farneback, float *out4_dev);
+int flow_farneback_batch_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int B, float *out4_dev);  // next: B frames, W*H bytes apart
 int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows, bool on_device, const float main_cam[16],
                      const float *side_cams, const float *depth, float *out_points7, int *out_count);
 int compare_prepare(mvs_ctx *ctx);  // allocates compare_device's arena (must not happen during graph capture)

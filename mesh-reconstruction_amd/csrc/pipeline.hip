@@ -42,7 +42,12 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     // cached graph) while the main stream goes on rasterising the next view; a flow is a chain of small kernels that fills
     // 150 of 256 CUs at best, so up to four of them overlap.  Everything joins before triangulatePixels.
     static const bool serial = getenv("MVS_SERIAL_FLOWS") != nullptr;  // A/B: all flows in the main stream, as before
-    const int nlanes = serial ? 0 : std::min(nside, (int)mvs_ctx::kFlowLanes);
+    // Farneback (-f): the flows of all side views in ONE pass after the last mixed image (every launch covers all of them; what
+    // depends on the main frame alone is computed once) -- a Farneback flow is ~150 launches of a few microseconds, and concurrency
+    // between lanes does not buy what sharing the launches does.  MVS_FB_LANES=1 keeps the per-view chains on the lanes (A/B).
+    static const bool fb_lanes = getenv("MVS_FB_LANES") != nullptr;
+    const bool fb_batch = use_farneback && nside > 0 && !serial && !fb_lanes;
+    const int nlanes = (serial || fb_batch) ? 0 : std::min(nside, (int)mvs_ctx::kFlowLanes);
     for (int l = 0; l < nlanes; l++)
         if (!ctx->lanes[l].stream) MVS_HIP(ctx, hipStreamCreateWithFlags(&ctx->lanes[l].stream, hipStreamNonBlocking));
     while ((int)ctx->lane_events.size() < 2 * nside) {
@@ -95,7 +100,9 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
         if ((rc = projected_device(ctx, main_cam, d_side, side_cams + 16 * i, d_out3))) return rc;   // :85
         if ((rc = mix_background_device(ctx, d_out3, d_main, d_depth, d_mixed))) return rc;           // :86
         float *fl = d_flows + (size_t)i * 4 * P;
-        if (nlanes == 0) {
+        if (fb_batch) {
+            // (after the loop)
+        } else if (nlanes == 0) {
             if ((rc = flow_device(ctx, d_main, d_mixed, use_farneback, fl))) return rc;               // :89
         } else {
             mvs_ctx::FlowLane &lane = ctx->lanes[i % nlanes];
@@ -111,6 +118,7 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
         }
         flow_ptrs[i] = fl;
     }
+    if (fb_batch && (rc = flow_farneback_batch_device(ctx, d_main, d_mixed0, nside, d_flows))) return rc;                                            // :89, all side views
     for (int i = 0; i < nside && nlanes > 0; i++) MVS_HIP(ctx, hipStreamWaitEvent(st, ctx->lane_events[2 * i + 1], 0));
     if (depth_after_hw) MVS_HIP(ctx, hipMemcpyAsync(depth_after_hw, d_depth, sizeof(float) * P, hipMemcpyDeviceToHost, st));
     rc = triangulate_impl(ctx, nside, flow_ptrs.data(), true, main_cam, side_cams, d_depth, out_points7, out_count);  // :114
