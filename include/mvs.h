@@ -98,6 +98,11 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
                       const float *side_cams /* nside*16 */, const uint8_t *const *side_frames_hw, int use_farneback,
                       float *out_points7, int *out_count, float *depth_after_hw);
 
+/* cv::resize(frame, Size(dw, dh)) as Configuration applies it to every decoded frame when -s / the clip size asks for it
+ * (configuration.cpp:233: INTER_LINEAR -- the CV_INTER_AREA in that call lands in the ignored fx argument): OpenCV's fixed-point
+ * bilinear resize on u8, 1 or 3 interleaved channels, host buffers in and out. */
+int mvs_resize_u8(mvs_ctx *ctx, const uint8_t *src, int src_w, int src_h, int channels, uint8_t *dst, int dst_w, int dst_h);
+
 /* Texture filter of Render::projected's frame texture.  The reference uploads the side frame with glGenerateMipmap and samples it
  * with GL_LINEAR_MIPMAP_LINEAR (render_glx.cpp:83-85): MVS_FILTER_MIPMAP (default) builds the mip chain (2 x 2 box, u8 levels) per
  * frame and blends the two levels the pixel's footprint calls for (fine derivatives on the 2 x 2 pixel quad, isotropic; DESIGN.md

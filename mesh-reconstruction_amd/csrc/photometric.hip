@@ -341,7 +341,58 @@ int remap_device(mvs_ctx *ctx, const float *flow, int stride, const uint8_t *img
 
 using namespace mvs;
 
+// cv::resize(..., Size(dw, dh)) INTER_LINEAR on u8 (configuration.cpp:233; the fixed-point arithmetic is stated in
+// oracle/photometric_oracle.c: orc_resize_linear_u8): one thread per destination pixel, all channels
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t *__restrict__ src, int sw, int sh, int channels, uint8_t *__restrict__ dst, int dw, int dh,
+                                                               double sx, double sy)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    auto axis = [](int d, double scale, int ssize, int &s, int &w0, int &w1) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) {
+            s = 0;
+            f = 0.f;
+        }
+        if (s >= ssize - 1) {
+            s = ssize - 1;
+            f = 0.f;
+        }
+        w0 = (short)__float2int_rn((1.f - f) * 2048.f);
+        w1 = (short)__float2int_rn(f * 2048.f);
+    };
+    int x0, a0, a1, y0, b0, b1;
+    axis(x, sx, sw, x0, a0, a1);
+    axis(y, sy, sh, y0, b0, b1);
+    const int x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
+    for (int c = 0; c < channels; c++) {
+        const int S0 = src[((size_t)y0 * sw + x0) * channels + c] * a0 + src[((size_t)y0 * sw + x1) * channels + c] * a1;
+        const int S1 = src[((size_t)y1 * sw + x0) * channels + c] * a0 + src[((size_t)y1 * sw + x1) * channels + c] * a1;
+        dst[((size_t)y * dw + x) * channels + c] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
 extern "C" {
+
+int mvs_resize_u8(mvs_ctx *ctx, const uint8_t *src, int sw, int sh, int channels, uint8_t *dst, int dw, int dh)
+{
+    if (!ctx || !src || !dst) return fail(ctx, MVS_EINVAL, "mvs_resize_u8: null argument");
+    if (sw < 1 || sh < 1 || dw < 1 || dh < 1 || (channels != 1 && channels != 3) || (size_t)sw * sh > ((size_t)1 << 30) || (size_t)dw * dh > ((size_t)1 << 30))
+        return fail(ctx, MVS_EINVAL, "mvs_resize_u8: bad sizes (%d x %d x %d -> %d x %d)", sw, sh, channels, dw, dh);
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ns = (size_t)sw * sh * channels, nd = (size_t)dw * dh * channels;
+    int rc;
+    if ((rc = ensure(ctx, ctx->upload, ns + nd + 256))) return rc;
+    uint8_t *s = (uint8_t *)ctx->upload.ptr, *d = s + ((ns + 255) & ~(size_t)255);
+    MVS_HIP(ctx, hipMemcpyAsync(s, src, ns, hipMemcpyHostToDevice, ctx->stream));
+    resize_linear_u8_kernel<<<dim3(div_up(dw, 64), div_up(dh, 4)), 256, 0, ctx->stream>>>(s, sw, sh, channels, d, dw, dh, (double)sw / dw, (double)sh / dh);
+    MVS_HIP(ctx, hipGetLastError());
+    MVS_HIP(ctx, hipMemcpyAsync(dst, d, nd, hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
 
 int mvs_compare(mvs_ctx *ctx, const uint8_t *prev_hw, const uint8_t *next_hw, float *out_hw)
 {

@@ -19,6 +19,7 @@
 #include <fstream>
 #include <sstream>
 
+#include "../../include/mvs.h"
 #include "recon.hpp"
 
 namespace {
@@ -169,9 +170,11 @@ bool readPgm(const std::string &path, int w, int h, Mat &out)
     int pw = 0, ph = 0, maxv = 0;
     f >> magic >> pw >> ph >> maxv;
     f.get();
-    if (magic != "P5" || pw != w || ph != h || maxv != 255) throw std::runtime_error("frame " + path + ": expected binary PGM of the clip size");
-    out.create(h, w, mvs::U8C1);
-    f.read(reinterpret_cast<char *>(out.data), (std::streamsize)w * h);
+    if (magic != "P5" || pw < 1 || ph < 1 || maxv != 255) throw std::runtime_error("frame " + path + ": expected a binary 8-bit PGM");
+    (void)w;  // a frame of another size than the (scaled) clip is resized by the caller, as configuration.cpp:232-233 does
+    (void)h;
+    out.create(ph, pw, mvs::U8C1);
+    f.read(reinterpret_cast<char *>(out.data), (std::streamsize)pw * ph);
     return (bool)f;
 }
 
@@ -184,11 +187,13 @@ bool readPpm(const std::string &path, int w, int h, Mat &out)
     int pw = 0, ph = 0, maxv = 0;
     f >> magic >> pw >> ph >> maxv;
     f.get();
-    if (magic != "P6" || pw != w || ph != h || maxv != 255) throw std::runtime_error("frame " + path + ": expected binary PPM of the clip size");
-    out.create(h, w, mvs::U8C3);
-    f.read(reinterpret_cast<char *>(out.data), (std::streamsize)w * h * 3);
+    if (magic != "P6" || pw < 1 || ph < 1 || maxv != 255) throw std::runtime_error("frame " + path + ": expected a binary 8-bit PPM");
+    (void)w;
+    (void)h;
+    out.create(ph, pw, mvs::U8C3);
+    f.read(reinterpret_cast<char *>(out.data), (std::streamsize)pw * ph * 3);
     uint8_t *p = out.ptr<uint8_t>();
-    for (size_t i = 0; i < (size_t)w * h; i++) std::swap(p[3 * i], p[3 * i + 2]);
+    for (size_t i = 0; i < (size_t)pw * ph; i++) std::swap(p[3 * i], p[3 * i + 2]);
     return (bool)f;
 }
 
@@ -356,11 +361,14 @@ void Configuration::parseYaml(const std::string &path)
         snprintf(name, sizeof(name), "/%06d.pgm", fi * (int)skipFrames + 1);
         Mat g;
         if (readPgm(clipPath + ".frames" + name, width, height, g)) {
-            frames[fi] = g;
+            setFrame(fi, g);  // (resized when its size is not the clip's, configuration.cpp:232-233)
             continue;
         }
         snprintf(name, sizeof(name), "/%06d.ppm", fi * (int)skipFrames + 1);
-        if (readPpm(clipPath + ".frames" + name, width, height, g)) colorFrames[fi] = g;
+        if (readPpm(clipPath + ".frames" + name, width, height, g)) {
+            if (g.cols != width || g.rows != height) g = resizedToClipSize(g);
+            colorFrames[fi] = g;
+        }
     }
     colorFramesReady();
 }
@@ -575,15 +583,36 @@ const Mat Configuration::frame(int frameNo) const
 const Mat Configuration::camera(int frameNo) const { return cameras.at(frameNo); }
 const std::vector<Mat> Configuration::allCameras() const { return cameras; }
 
-void Configuration::setFrameColor(int frameNo, const Mat bgr)
+static Mat resizedToClip(const Mat &frame, int width, int height);
+
+// configuration.cpp:232-235: a decoded frame whose size is not (width, height) -- the -s option divides those -- goes through
+// cv::resize(frame, frames[fi], cv::Size(width, height), CV_INTER_AREA), i.e. INTER_LINEAR (the constant lands in the ignored fx
+// argument): mvs_resize_u8, on a context of its own (created on first use)
+Mat Configuration::resizedToClipSize(const Mat &frame) const { return resizedToClip(frame, width, height); }
+
+static Mat resizedToClip(const Mat &frame, int width, int height)
 {
-    if (bgr.type() != mvs::U8C3 || bgr.cols != width || bgr.rows != height) throw std::runtime_error("setFrameColor: frame must be H x W x 3 u8 of the clip size");
+    static mvs_ctx *ctx = nullptr;
+    if (!ctx) ctx = mvs_create(0, width, height);
+    if (!ctx) throw std::runtime_error(std::string("resize: ") + mvs_last_error(nullptr));
+    Mat out(height, width, frame.type());
+    if (mvs_resize_u8(ctx, frame.ptr<uchar>(0), frame.cols, frame.rows, frame.channels(), out.ptr<uchar>(0), width, height))
+        throw std::runtime_error(std::string("resize: ") + mvs_last_error(ctx));
+    return out;
+}
+
+void Configuration::setFrameColor(int frameNo, const Mat bgr_in)
+{
+    if (bgr_in.type() != mvs::U8C3) throw std::runtime_error("setFrameColor: frame must be H x W x 3 u8");
+    const Mat bgr = (bgr_in.cols != width || bgr_in.rows != height) ? resizedToClip(bgr_in, width, height) : bgr_in;
     colorFrames.at(frameNo) = bgr;
     colorFramesReady();
 }
 
-void Configuration::setFrame(int frameNo, const Mat gray)
+void Configuration::setFrame(int frameNo, const Mat gray_in)
 {
-    if (gray.type() != mvs::U8C1 || gray.cols != width || gray.rows != height) throw std::runtime_error("setFrame: frame must be H x W u8 of the clip size");
+    if (gray_in.type() != mvs::U8C1) throw std::runtime_error("setFrame: frame must be H x W u8");
+    // (the reference resizes the decoded BGR frame and converts to grey afterwards; a grey frame of another size is resized as is)
+    const Mat gray = (gray_in.cols != width || gray_in.rows != height) ? resizedToClip(gray_in, width, height) : gray_in;
     frames.at(frameNo) = gray;
 }

@@ -91,6 +91,7 @@ protected:
     std::vector<Mat> frames;
     std::vector<Mat> colorFrames;  // kept until the exposure estimate has turned them into `frames`
     void colorFramesReady();
+    Mat resizedToClipSize(const Mat &frame) const;  // configuration.cpp:232-233 (cv::resize, bilinear) through mvs_resize_u8
     std::vector<Mat> cameras;
     std::vector<float> nearVals, farVals;
     Mat bundles;

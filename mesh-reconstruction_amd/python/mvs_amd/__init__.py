@@ -63,6 +63,7 @@ ABI = [
     ("mvs_sweep_row_granularity", _i, []),
     ("mvs_sweep_row_granularity_of", _i, [_vp]),
     ("mvs_sweep_plan_shape", _i, [_vp]),
+    ("mvs_resize_u8", _i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
     ("mvs_set_texture_filter", _i, [_vp, _i]),
     ("mvs_texture_filter", _i, [_vp]),
     ("mvs_frame_store", _i, [_vp, _i]),
@@ -462,6 +463,15 @@ class Context:
             raise ValueError("rows and cols differ in length")
         out = np.empty(rows.shape[0], np.float32)
         self._check(self.lib.mvs_depth_probe(self.h, _ptr(cam, _fp), rows.shape[0], _ptr(rows, _i32p), _ptr(cols, _i32p), _ptr(out, _fp)))
+        return out
+
+    def resize(self, img, dw, dh):
+        """cv::resize(img, Size(dw, dh)) INTER_LINEAR on u8 (configuration.cpp:233)"""
+        img = np.ascontiguousarray(img, np.uint8)
+        sh, sw = img.shape[:2]
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, ch), np.uint8)
+        self._check(self.lib.mvs_resize_u8(self.h, img.ctypes.data_as(C.c_void_p), sw, sh, ch, out.ctypes.data_as(C.c_void_p), int(dw), int(dh)))
         return out
 
     def set_texture_filter(self, name):

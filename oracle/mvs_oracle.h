@@ -113,6 +113,7 @@ void orc_compare_f32(const float *prev, const float *next, int W, int H, float *
 
 /* util.cpp:390-403: bicubic remap of a u8 image by a dense flow (stride = floats per pixel: 2 or 4) */
 void orc_flow_remap(const float *flow, int stride, const uint8_t *image, int W, int H, uint8_t *out);
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int channels, uint8_t *dst, int dw, int dh); /* configuration.cpp:233 */
 /* the Q15 4x4 bicubic weight table (32*32 sub-pixel positions x 16 taps) remap uses; out nullable */
 void orc_remap_cubic_table(short *out);
 

@@ -258,3 +258,59 @@ void orc_flow_remap(const float *flow, int stride, const uint8_t *image, int W, 
             out[(size_t)y * W + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
         }
 }
+
+
+/* ---- cv::resize(src, dst, Size(w, h)) with INTER_LINEAR on 8-bit images (configuration.cpp:233) ------------------------------------
+ * The reference calls cv::resize(frame, frames[fi], cv::Size(width, height), CV_INTER_AREA): the fourth POSITIONAL argument of
+ * cv::resize is fx, not the interpolation, so CV_INTER_AREA (= 3) lands in a scale factor that is ignored because dsize is given,
+ * and the interpolation stays at its default, INTER_LINEAR.  OpenCV's 8-bit path is fixed point (imgproc/resize.cpp, the classic
+ * HResizeLinear + VResizeLinear<uchar, int, short, FixedPtCast<int, uchar, 22>> pair): source coordinate (d + 0.5) scale - 0.5,
+ * clamped at both ends; weights cvRound((1 - f) 2048), cvRound(f 2048) as shorts; horizontal pass in int; vertical pass
+ * (((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4)) >> 16) + 2) >> 2.  OpenCV is not in the tree (version unpinned): restated from the
+ * published source; tests/test_pinning_cpu.py checks it against the plain float formula. */
+static void resize_axis(int dsize, int ssize, int *idx, short *w0, short *w1)
+{
+    const double scale = (double)ssize / dsize;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) {
+            s = 0;
+            f = 0.f;
+        }
+        if (s >= ssize - 1) {
+            s = ssize - 1;
+            f = 0.f;
+        }
+        idx[d] = s;
+        /* saturate_cast<short>(x) = cvRound: round half to even, like lrintf in the default rounding mode */
+        w0[d] = (short)lrintf((1.f - f) * 2048.f);
+        w1[d] = (short)lrintf(f * 2048.f);
+    }
+}
+
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int channels, uint8_t *dst, int dw, int dh)
+{
+    int *xi = (int *)malloc(sizeof(int) * dw), *yi = (int *)malloc(sizeof(int) * dh);
+    short *xa = (short *)malloc(sizeof(short) * 2 * dw), *ya = (short *)malloc(sizeof(short) * 2 * dh);
+    resize_axis(dw, sw, xi, xa, xa + dw);
+    resize_axis(dh, sh, yi, ya, ya + dh);
+    for (int y = 0; y < dh; y++) {
+        const int y0 = yi[y], y1 = y0 + 1 < sh ? y0 + 1 : sh - 1;
+        const int b0 = ya[y], b1 = ya[dh + y];
+        for (int x = 0; x < dw; x++) {
+            const int x0 = xi[x], x1 = x0 + 1 < sw ? x0 + 1 : sw - 1;
+            const int a0 = xa[x], a1 = xa[dw + x];
+            for (int c = 0; c < channels; c++) {
+                const int S0 = src[((size_t)y0 * sw + x0) * channels + c] * a0 + src[((size_t)y0 * sw + x1) * channels + c] * a1;
+                const int S1 = src[((size_t)y1 * sw + x0) * channels + c] * a0 + src[((size_t)y1 * sw + x1) * channels + c] * a1;
+                dst[((size_t)y * dw + x) * channels + c] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
+    }
+    free(xi);
+    free(yi);
+    free(xa);
+    free(ya);
+}

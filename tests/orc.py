@@ -47,6 +47,7 @@ class Oracle:
             ("orc_compare_u8", [_u8p, _u8p, C.c_int, C.c_int, _fp]),
             ("orc_compare_f32", [_fp, _fp, C.c_int, C.c_int, _fp]),
             ("orc_flow_remap", [_fp, C.c_int, _u8p, C.c_int, C.c_int, _u8p]),
+            ("orc_resize_linear_u8", [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]),
         ]:
             if hasattr(L, name):
                 getattr(L, name).argtypes = args
@@ -201,6 +202,15 @@ class Oracle:
         image = np.ascontiguousarray(image, np.uint8)
         out = np.empty((H, W), np.uint8)
         self.lib.orc_flow_remap(self._p(flow, _fp), flow.shape[2], self._p(image, _u8p), W, H, self._p(out, _u8p))
+        return out
+
+    def resize_linear(self, img, dw, dh):
+        """cv::resize(img, Size(dw, dh)) INTER_LINEAR on u8, 1 or 3 channels (configuration.cpp:233)"""
+        img = np.ascontiguousarray(img, np.uint8)
+        sh, sw = img.shape[:2]
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, ch), np.uint8)
+        self.lib.orc_resize_linear_u8(self._p(img, _u8p), sw, sh, ch, self._p(out, _u8p), dw, dh)
         return out
 
     def cubic_table(self):

@@ -33,3 +33,14 @@ def test_flow_remap_matches_oracle(oracle, W, H, stride):
     with mvs_amd.Context(W, H) as ctx:
         got = ctx.flow_remap(flow, img)
     np.testing.assert_array_equal(got, oracle.flow_remap(flow, img))
+
+
+def test_resize_u8_equals_oracle(oracle):
+    """mvs_resize_u8 (Configuration's -s / clip-size resize, configuration.cpp:233) == the oracle's restatement of cv::resize, byte for byte"""
+    rng = np.random.default_rng(4)
+    with mvs_amd.Context(64, 48) as ctx:
+        for shape in ((480, 640), (211, 333, 3), (1080, 1920, 3)):
+            img = rng.integers(0, 256, shape, dtype=np.uint8)
+            sh, sw = shape[:2]
+            for dw, dh in ((sw // 2, sh // 2), (int(sw / 1.5), int(sh / 1.5)), (sw, sh), (sw + 37, sh + 11)):
+                np.testing.assert_array_equal(ctx.resize(img, dw, dh), oracle.resize_linear(img, dw, dh))

@@ -99,3 +99,28 @@ def test_farneback_polynomial_expansion_is_weighted_least_squares(oracle):
             r = np.linalg.solve(G, B.T @ (Wt * patch))      # r1, r2(x), r3(y), r4(x^2), r5(y^2), r6(xy)
             got = dst[y, x]                                  # OpenCV channel order: r3(y), r2(x), r5(y^2), r4(x^2), r6(xy)
             np.testing.assert_allclose([got[1], got[0], got[3], got[2], got[4]], r[1:], rtol=2e-4, atol=2e-4)
+
+
+def test_resize_linear_restatement_against_the_float_formula(oracle):
+    """cv::resize(..., INTER_LINEAR) on u8 (configuration.cpp:233; oracle: orc_resize_linear_u8, OpenCV's 11-bit fixed-point weights)
+    against the plain float bilinear formula with the same coordinate convention ((d + 0.5) scale - 0.5, clamped): within one grey
+    level everywhere, identical at 1 : 1, for grey and 3-channel images, down- and up-scaling"""
+    rng = np.random.default_rng(0)
+    for shape in ((97, 131), (60, 80, 3)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        sh, sw = shape[:2]
+        for dw, dh in ((65, 48), (sw, sh), (40, 90), (2 * sw, 2 * sh), (sw // 2, sh // 2)):
+            got = oracle.resize_linear(img, dw, dh).astype(np.float64)
+            xs, ys = (np.arange(dw) + 0.5) * sw / dw - 0.5, (np.arange(dh) + 0.5) * sh / dh - 0.5
+            x0, y0 = np.floor(xs).astype(int), np.floor(ys).astype(int)
+            fx, fy = xs - x0, ys - y0
+            fx = np.where((x0 < 0) | (x0 >= sw - 1), 0.0, fx)
+            fy = np.where((y0 < 0) | (y0 >= sh - 1), 0.0, fy)
+            x0, y0 = np.clip(x0, 0, sw - 1), np.clip(y0, 0, sh - 1)
+            x1, y1 = np.minimum(x0 + 1, sw - 1), np.minimum(y0 + 1, sh - 1)
+            f = img.astype(np.float64).reshape(sh, sw, -1)
+            wx, wy = fx[None, :, None], fy[:, None, None]
+            ref = (1 - wy) * ((1 - wx) * f[y0][:, x0] + wx * f[y0][:, x1]) + wy * ((1 - wx) * f[y1][:, x0] + wx * f[y1][:, x1])
+            assert np.abs(got.reshape(dh, dw, -1) - ref).max() <= 1.0
+            if (dw, dh) == (sw, sh):
+                np.testing.assert_array_equal(got.astype(np.uint8), img)
