@@ -833,7 +833,8 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
         p.plane_begin = plane_first;
         p.plane_end = min(ctx->D, plane_first + plane_count);
         ProfileScope ps(ctx, MVS_K_SWEEP);
-        const bool rect = ctx->rect_ok && !generic && ctx->V > 0 && !(flags & MVS_SWEEP_NO_RECT);
+        // (a run over zero views writes empty cells: the general kernel's job -- the rectified one iterates over regions)
+        const bool rect = ctx->rect_ok && !generic && ctx->V > 0 && view_count > 0 && !(flags & MVS_SWEEP_NO_RECT);
         const int nsplit = rect ? sweep_rect_launch(ctx, p, vol, fused, flags) : sweep_fx_launch(ctx, p, vol, fused, generic, flags);
         if (nsplit < 0) return nsplit;
         if (p.part) {

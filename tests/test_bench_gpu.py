@@ -40,7 +40,9 @@ def test_bench_line_contract_and_two_rank_shardings():
     assert single["n_gpus"] == 1 and single["vs_baseline"] is None and single["depth_check"] is True
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in single["roofline"], key
-    assert single["config"]["sampler"] == "fixed" and single["roofline"]["kernel"] == "sweep_fx_tiled"
+    # the SURVEY 8d ring is rectified: the fixed sampler's plan is served by sweep_fx_rect; N = 1 lines carry no scaling / shard
+    assert single["config"]["sampler"] == "fixed" and single["roofline"]["kernel"] == "sweep_fx_rect"
+    assert single["scaling"] is None and single["config"]["shard"] is None
     assert "one_call_mvs_sweep" not in single   # --no-extras
     # the default N > 1 line: strong scaling of one main view by row bands, the north_star's view shardings timed beside it
     dflt = _bench([], 2)
@@ -61,3 +63,11 @@ def test_bench_line_contract_and_two_rank_shardings():
     for s in ("exact",):
         ex = _bench(["--sampler", s], 1)
         assert ex["roofline"]["kernel"] == "sweep_tiled" and ex["depth_check"] is True
+    # the N = 1 line with its extras: the exact sampler, what the two samplers disagree on, general cameras, a >= 2 s sustained run
+    ext = _bench(["--with-extras"], 1)
+    assert ext["exact_sampler"]["sampler"] == "exact" and ext["exact_sampler"]["ms_per_step"] > 0
+    dis = ext["sampler_disagreement"]
+    # (c1: 32 planes, 4 views -- coarser than the c2 / c3 cases tests/test_sampler_tolerance_gpu.py holds to the stated tolerance)
+    assert dis["plane_flip_rate"] <= 0.06 and dis["plane_flip_rate_more_than_one_plane"] <= 0.003 and dis["mean_abs_best_cost_difference_grey_levels"] <= 0.2
+    assert ext["general_camera_path"]["kernel"] == "sweep_fx_tiled" and ext["general_camera_path"]["ms_per_step"] > 0
+    assert ext["sustained"]["seconds"] >= 1.9 and ext["sustained"]["steps"] >= 300
