@@ -188,6 +188,13 @@ int mvs_sweep_plan_shape(const mvs_ctx *ctx);
 /* per-pixel depth selection over the packed volume (async); valid after MVS_SWEEP_VOLUME runs or
  * after the caller has reduced the volume across ranks in place */
 int mvs_sweep_argmin(mvs_ctx *ctx);
+/* Sub-plane refinement (optional): replaces the selected plane's depth in the depth map by the vertex of
+ * the parabola through the mean costs of that plane and its two neighbours (clamped to half a plane step; planes at either end, or
+ * with a neighbour that no view sees, keep their depth).  Needs the packed volume and a depth selection of the same run
+ * (MVS_SWEEP_VOLUME | MVS_SWEEP_FUSED_ARGMIN, or MVS_SWEEP_VOLUME + mvs_sweep_argmin); best cost and index are unchanged.
+ * The plane step is what makes two samplers that pick neighbouring planes of equal cost differ by 1/D in depth; refined depths of the
+ * two samplers agree to a small fraction of it. */
+int mvs_sweep_refine_depth(mvs_ctx *ctx);
 /* The same selection in two steps, for a view-sharded job that REDUCE-SCATTERS the packed volume instead of all-reducing it
  * (half the bytes over xGMI): rank r owns the summed cells of planes [plane_first, plane_first + plane_count) in
  * `volume_slice_dev` ([plane_count][H][W] u32) and selects a partial best per pixel over them -- `partial_out_dev` receives

@@ -552,6 +552,36 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled(SweepParams p)
     }
 }
 
+// Sub-plane refinement of the selected depth: parabola through the mean costs of the selected plane and its
+// two neighbours, f32 with one rounding per operation -- oracle/sweep_oracle.c: orc_refine_depth states the arithmetic.
+template <int CS>
+__global__ __launch_bounds__(256) void refine_depth(const uint32_t *__restrict__ vol, size_t P, int D, const float *__restrict__ z, const int *__restrict__ index,
+                                                    float *__restrict__ depth)
+{
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int i = index[p];
+    if (i < 0) {
+        depth[p] = MVS_BACKGROUND_DEPTH;
+        return;
+    }
+    constexpr uint32_t M = (1u << CS) - 1u;
+    float zr = z[i];
+    if (i > 0 && i < D - 1) {
+        const uint32_t a = vol[(size_t)(i - 1) * P + p], b = vol[(size_t)i * P + p], c = vol[(size_t)(i + 1) * P + p];
+        if ((a >> CS) != 0u && (c >> CS) != 0u && (b >> CS) != 0u) {
+            const float ca = (float)(a & M) / (float)(a >> CS), cb = (float)(b & M) / (float)(b >> CS), cc = (float)(c & M) / (float)(c >> CS);
+            const float den = (ca - 2.0f * cb) + cc;
+            if (den > 0.0f) {
+                float t = (0.5f * (ca - cc)) / den;
+                t = t < -0.5f ? -0.5f : (t > 0.5f ? 0.5f : t);
+                zr = t >= 0.0f ? __builtin_fmaf(t, z[i + 1] - z[i], z[i]) : __builtin_fmaf(-t, z[i - 1] - z[i], z[i]);
+            }
+        }
+    }
+    depth[p] = zr;
+}
+
 // merge of the partial bests of a plane-split launch: splits are in ascending plane order and a later split wins only
 // if strictly better, so ties still go to the lowest plane
 template <int CS>
@@ -971,6 +1001,21 @@ int mvs_sweep_argmin(mvs_ctx *ctx)
     ProfileScope ps(ctx, MVS_K_ARGMIN);
     launch_argmin(ctx, ctx->volume, P, ctx->D, (const float *)ctx->ztab.ptr, (float *)ctx->depth.ptr, (float *)ctx->cost.ptr, (int *)ctx->index.ptr,
                   nullptr, 0);
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
+}
+
+int mvs_sweep_refine_depth(mvs_ctx *ctx)
+{
+    if (!ctx) return MVS_EINVAL;
+    if (!ctx->have_planes || !ctx->volume || !ctx->index.ptr)
+        return fail(ctx, MVS_ESTATE, "mvs_sweep_refine_depth: needs the packed volume and a depth selection (MVS_SWEEP_VOLUME | MVS_SWEEP_FUSED_ARGMIN, or mvs_sweep_argmin)");
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->W * ctx->H;
+    if (ctx->sampler == MVS_SAMPLER_FIXED)
+        refine_depth<CS_FIXED><<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(ctx->volume, P, ctx->D, (const float *)ctx->ztab.ptr, (const int *)ctx->index.ptr, (float *)ctx->depth.ptr);
+    else
+        refine_depth<CS_EXACT><<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(ctx->volume, P, ctx->D, (const float *)ctx->ztab.ptr, (const int *)ctx->index.ptr, (float *)ctx->depth.ptr);
     MVS_HIP(ctx, hipGetLastError());
     return MVS_OK;
 }

@@ -70,6 +70,7 @@ ABI = [
     ("mvs_frame_upload", _i, [_vp, _i, _vp]),
     ("mvs_sweep_batch", _i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, C.c_float, C.c_float, _vp, _vp]),
     ("mvs_sweep_argmin", _i, [_vp]),
+    ("mvs_sweep_refine_depth", _i, [_vp]),
     ("mvs_sweep_argmin_partial", _i, [_vp, _vp, _i, _i, _vp]),
     ("mvs_sweep_combine_partials", _i, [_vp, _vp, _i]),
     ("mvs_sweep_volume_device", _vp, [_vp, C.POINTER(_sz)]),
@@ -359,6 +360,10 @@ class Context:
 
     def plan_shape(self):
         return self.lib.mvs_sweep_plan_shape(self.h)
+
+    def sweep_refine_depth(self):
+        """sub-plane parabola refinement of the depth map (needs the volume and a depth selection of the same run)"""
+        self._check(self.lib.mvs_sweep_refine_depth(self.h))
 
     # ---- frame store + batched sweep (a sequence on one GPU) ------------------------------------
     def frame_store(self, capacity):

@@ -75,6 +75,8 @@ void orc_sweep_fx(const float main_cam[16], const uint8_t *main_img, int W, int 
                   const uint8_t *const *side_imgs, int D, float z_lo, float z_hi, uint32_t *volume, float *depth, float *best_cost,
                   int32_t *best_idx, int nthreads);
 void orc_argmin_fx(const uint32_t *volume, int W, int H, int D, const float *z, float *depth, float *best_cost, int32_t *best_idx);
+/* sub-plane parabola refinement of the selected plane; cs = 16 / 24: cell format of the exact / fixed sampler */
+void orc_refine_depth(const uint32_t *volume, int W, int H, int D, const float *z, const int32_t *idx, int cs, float *depth);
 void orc_warp_by_depth_fx(const float main_cam[16], const float *depth, const float side_cam[16], const uint8_t *frame, int W, int H,
                           uint8_t *out_hw2);
 

@@ -449,3 +449,41 @@ void orc_mix_background(const uint8_t *img_hw3, const uint8_t *bg_hw, float *dep
         }
     }
 }
+
+
+/* ---- sub-plane refinement of the selected depth (SURVEY.md section 7.2 K6 "optional sub-plane parabola refinement") --------------
+ * The plane sweep quantises depth to the plane step; two samplers (or two runs with slightly different costs) that pick neighbouring
+ * planes of nearly equal cost then differ by a whole step.  The usual remedy: fit a parabola through the mean costs of the selected
+ * plane and its two neighbours and move to its vertex.  Defined here in f32, one rounding per operation (the HIP kernel
+ * refine_depth mirrors it bit for bit):
+ *   c_k = (float)sum_k / (float)count_k          (fixed sampler: / (255 count_k): the same scale for all three, it cancels)
+ *   den = (c_- - 2 c_0) + c_+ ;  refined only if 0 < i < D - 1, both neighbours have a view in frame, and den > 0
+ *   t   = 0.5 (c_- - c_+) / den, clamped to [-0.5, 0.5]
+ *   z   = t >= 0 ? fma(t, z_{i+1} - z_i, z_i) : fma(-t, z_{i-1} - z_i, z_i)      (planes need not be equidistant)
+ * cs = 16 (exact sampler's cells) or 24 (fixed sampler's). */
+void orc_refine_depth(const uint32_t *volume, int W, int H, int D, const float *z, const int32_t *idx, int cs, float *depth)
+{
+    const size_t P = (size_t)W * H;
+    const uint32_t M = (1u << cs) - 1u;
+    for (size_t p = 0; p < P; p++) {
+        const int i = idx[p];
+        if (i < 0) {
+            depth[p] = 1.0f; /* backgroundDepth */
+            continue;
+        }
+        float zr = z[i];
+        if (i > 0 && i < D - 1) {
+            const uint32_t a = volume[(size_t)(i - 1) * P + p], b = volume[(size_t)i * P + p], c = volume[(size_t)(i + 1) * P + p];
+            if ((a >> cs) != 0u && (c >> cs) != 0u && (b >> cs) != 0u) {
+                const float ca = (float)(a & M) / (float)(a >> cs), cb = (float)(b & M) / (float)(b >> cs), cc = (float)(c & M) / (float)(c >> cs);
+                const float den = (ca - 2.0f * cb) + cc;
+                if (den > 0.0f) {
+                    float t = (0.5f * (ca - cc)) / den;
+                    t = t < -0.5f ? -0.5f : (t > 0.5f ? 0.5f : t);
+                    zr = t >= 0.0f ? fmaf(t, z[i + 1] - z[i], z[i]) : fmaf(-t, z[i - 1] - z[i], z[i]);
+                }
+            }
+        }
+        depth[p] = zr;
+    }
+}

@@ -136,6 +136,17 @@ class Oracle:
         fn(self._p(vol, _u32p), W, H, D, self._p(z, _fp), self._p(depth, _fp), self._p(cost, _fp), self._p(idx, _i32p))
         return depth, cost, idx
 
+    def refine_depth(self, vol, z, idx, sampler="exact"):
+        """sub-plane parabola refinement of the selected planes `idx` over the packed volume"""
+        D, H, W = vol.shape
+        vol = np.ascontiguousarray(vol, np.uint32)
+        z = np.ascontiguousarray(z, np.float32)
+        idx = np.ascontiguousarray(idx, np.int32)
+        depth = np.empty((H, W), np.float32)
+        self.lib.orc_refine_depth.argtypes = [_u32p, C.c_int, C.c_int, C.c_int, _fp, _i32p, C.c_int, _fp]
+        self.lib.orc_refine_depth(self._p(vol, _u32p), W, H, D, self._p(z, _fp), self._p(idx, _i32p), 16 if sampler == "exact" else 24, self._p(depth, _fp))
+        return depth
+
     def mix_background(self, img3, bg, depth):
         H, W = bg.shape
         img3 = np.ascontiguousarray(img3, np.uint8)
