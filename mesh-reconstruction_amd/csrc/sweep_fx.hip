@@ -242,11 +242,14 @@ __device__ __forceinline__ void stage_region_fx(const uint32_t *__restrict__ qua
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int units = rw >> 2;
-    const uint32_t *src = quads + (uint32_t)(y0 * pitch + x0) + 4 * lane;  // a slab has fewer than 2^32 quads
+    // buffer form of the LDS copy: the view's quad image as a resource (SGPRs), the row's byte offset wave-uniform, 16 bytes per lane --
+    // through a plain pointer the compiler forms a 64-bit per-lane address for every row (2 VGPRs + 2 VALU instructions per copy)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)quads, 0, (int)0xffffffffu, 0x00020000);  // a slab is below 2^32 bytes (images up to 16383^2)
+    const uint32_t row0 = 4u * (uint32_t)(y0 * pitch + x0), rstep = 4u * (uint32_t)pitch;
+    const uint32_t lane16 = 16u * (uint32_t)lane;
     if (lane < units) {  // one exec-mask change around the whole loop, not one per row
         for (int ry = wave; ry < rh; ry += 4)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)ry * pitch),
-                                             (__attribute__((address_space(3))) void *)(lds + ry * FX_ROW_DW + FX_LUT_DW + col), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)(lds + ry * FX_ROW_DW + FX_LUT_DW + col), 16, lane16, row0 + rstep * (uint32_t)ry, 0, 0);
     }
 }
 
@@ -621,6 +624,11 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
 #endif
         uint32_t *const vol_chunk = WRITE_VOLUME ? p.volume + (size_t)d0 * P : nullptr;
         const bool whole = d0 + PC <= p.D;  // uniform: every plane of the chunk exists
+        // the chunk's 16 planes as one buffer resource (plane k at byte offset 4 P k: below 2^32 for frames up to 8192^2; larger frames
+        // take the pointer form): a store is resource + 32-bit lane offset + wave-uniform plane offset, no 64-bit per-lane pointer
+        const bool vol_rsrc = WRITE_VOLUME && (unsigned long long)P * 4ull * (unsigned long long)PC < (1ull << 32);
+        const __amdgpu_buffer_rsrc_t rvol = __builtin_amdgcn_make_buffer_rsrc((void *)vol_chunk, 0, (int)0xffffffffu, 0x00020000);
+        const uint32_t plane_bytes = (uint32_t)(4u * (uint32_t)P);
 #pragma unroll
         for (int j = 0; j < NPX; j++) {
             if (ok[j]) {
@@ -637,7 +645,12 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
 #pragma unroll
                     for (int k = 0; k < PC; k++) {
                         const uint32_t cell = acc[j][k] + views;
-                        if (WRITE_VOLUME) __builtin_nontemporal_store(cell, vol_chunk + (size_t)k * P + pix);  // written once, read by a later kernel: keep it out of the L2 the quad images live in
+                        if (WRITE_VOLUME) {  // non-temporal: written once, read by a later kernel: keep it out of the L2 the quad images live in
+                            if (vol_rsrc)
+                                __builtin_amdgcn_raw_buffer_store_b32(cell, rvol, 4u * pix, plane_bytes * (uint32_t)k, 2);
+                            else
+                                __builtin_nontemporal_store(cell, vol_chunk + (size_t)k * P + pix);
+                        }
                         if (FUSED) {
                             const bool better = umul24u(cell & 0xffffffu, best >> 24) < umul24u(best & 0xffffffu, cell >> 24);
                             best = better ? cell : best;

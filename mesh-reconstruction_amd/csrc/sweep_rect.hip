@@ -314,6 +314,7 @@ struct RectArgs {
     size_t pad_slab;
     int pitch, W, H, D, V, v0, vcount, nchunks, chunk0, chunk1, cps, ty0, tyn, tiles_x;
     int slot_dw;   // dwords per LDS slot = 256 x copy instructions per region (one instruction fills 256 dwords); two slots
+    int debug;     // timing experiments, honoured by builds with -DMVS_RX_EXPERIMENTS only: 1 no copies, 2 no sampling, 4 no barrier, 16 no epilogue (wrong results)
 };
 
 template <typename T>
@@ -321,6 +322,11 @@ __device__ __forceinline__ T cold_get(uintptr_t c, size_t off)
 {
     return *(const __attribute__((address_space(4))) T *)(c + off);
 }
+#ifdef MVS_RX_EXPERIMENTS
+#define RX_DBG(a, bit) (((a).debug & (bit)) != 0)
+#else
+#define RX_DBG(a, bit) false
+#endif
 #define RX_COLD(c, T, field) cold_get<T>((uintptr_t)(c), offsetof(RectCold, field))
 
 // raw buffer resource over `bytes` bytes at p (gfx950: dword 3 = 0x00020000, 32-bit data format): buffer instructions take a
@@ -380,6 +386,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     // empty), ysrc / yn = Y record dwords 2 / 3 (byte offset of the box's first row in the quad images; rows | y0 << 8).  Rows of RS
     // quads, 64 16-byte units per instruction; only the last instruction of a region runs under a lane mask.
     auto issue_copy = [&](uint32_t xsx, uint32_t ysrc, uint32_t yn, uint32_t slot_dw0) {
+        if (RX_DBG(a, 1)) return;
         const int n = (int)((yn & 0xffu) * (xsx >> 16));
         const uint32_t src = (xsx & 0xffffu) + ysrc;
         uint32_t *dst = smem + slot_dw0 + wave * 256;
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
         // every copy and every record this wavefront asked for has landed ...
         wait_vm<0>();
         // ... and so have every other wavefront's; nobody reads region r - 1 any more
-        __builtin_amdgcn_s_barrier();
+        if (!RX_DBG(a, 4)) __builtin_amdgcn_s_barrier();
         // request region r + 1 into the other slot and the records of region r + 2: in flight during this region's sampling
         if (r + 1 < nreg) issue_copy(rdl(x1r, 6), rdl(y1r, 2), rdl(y1r, 3), slot_nxt);
         const uint32_t x2r = load_x(c2.xo), y2r = load_y(c2.yo);
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
 
         // ---- sample region r ----
         const uint32_t special = (sum01 | sum23) & 0xc000c000u;
-        {
+        if (!RX_DBG(a, 2)) {
             const uint32_t slot_byte = lds_base + slot_cur * 4u;
             uint32_t qd[RX_DOUBLE_BUFFER ? 2 : 1][8];
             // FULL planes (certificates hold, nothing out of frame): LDS base in M0 (ds_read_addtid_b32: M0 + offset + 4 lane, no
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
         }
 
         // ---- chunk epilogue ----
-        if (v + 1 == vend) {
+        if (v + 1 == vend && !RX_DBG(a, 16)) {
             const int d0 = chunk * RX_PC + wave * RX_KW;
             const size_t P = (size_t)a.W * a.H;
             const uint32_t pix0 = 4u * (uint32_t)(row0 * a.W + col);  // byte offset of this lane's first pixel inside a plane
@@ -747,6 +754,8 @@ int sweep_rect_plan(mvs_ctx *ctx)
     if (ctx->V == 0) return MVS_OK;
     for (int v = 0; v < ctx->V; v++)
         if (!rect_view_host(ctx->q_host.data() + 12 * v)) return MVS_OK;  // a view that is not rectified: the general kernel
+    // the kernel addresses the quad images through one buffer resource with 32-bit byte offsets
+    if ((unsigned long long)ctx->pad_slab * (unsigned long long)ctx->V * 4ull >= (1ull << 32)) return MVS_OK;
     SweepParams q;
     fill_params(ctx, q, 0, ctx->V, RX_TILE_H, RX_PC);
     int rc;
@@ -765,7 +774,8 @@ int sweep_rect_plan(mvs_ctx *ctx)
     MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int max_rw = stats[0], max_rh = stats[1];
     int rs = 0;
-    for (int cand : {96, 128})
+    if (getenv("MVS_RECT_VERBOSE")) fprintf(stderr, "sweep_rect_plan: widest box %d quads, tallest %d rows\n", max_rw, max_rh);
+    for (int cand : {64, 84, 96, 128})  // row strides the kernel is compiled for
         if (max_rw <= cand) {
             rs = cand;
             break;
@@ -854,6 +864,7 @@ int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsign
     a.tyn = p.tyn;
     a.tiles_x = p.tiles_x;
     a.slot_dw = ctx->rect_slot_dw;
+    a.debug = p.debug;
     size_t lds = (size_t)2 * a.slot_dw * 4;
     if (fused) lds = lds < 16384 ? 16384 : lds;  // the cross-wavefront depth selection borrows 16 KiB
     if (lds > 160 * 1024) return fail(ctx, MVS_EINVAL, "sweep_rect_launch: %zu bytes of LDS", lds);
@@ -872,7 +883,8 @@ int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsign
         a.part = p.part;
     }
     const dim3 grid((unsigned)(div_up(groups, 8) * 64), (unsigned)nsplit);
-    rc = ctx->rect_rs == 96 ? launch_rect<96>(ctx, a, grid, lds, vol, fused) : launch_rect<128>(ctx, a, grid, lds, vol, fused);
+    rc = ctx->rect_rs == 64 ? launch_rect<64>(ctx, a, grid, lds, vol, fused) : ctx->rect_rs == 84 ? launch_rect<84>(ctx, a, grid, lds, vol, fused)
+       : ctx->rect_rs == 96 ? launch_rect<96>(ctx, a, grid, lds, vol, fused) : launch_rect<128>(ctx, a, grid, lds, vol, fused);
     if (rc) return rc;
     return nsplit;
 }

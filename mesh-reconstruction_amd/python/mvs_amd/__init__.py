@@ -106,7 +106,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("MVS_HIP_LIBRARY") or LIB_PATH   # MVS_HIP_LIBRARY: A/B timing of two builds in one GPU session (tools/)
     if not os.path.exists(path):
         raise MvsError(
             "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
