@@ -23,12 +23,15 @@
 // but a wavefront owns ALL 8 rows of the tile and 4 of the 16 planes (lane = column): 32 accumulators per thread, and a plane's
 // uniform work (decode, weight word, LDS base) is shared by 8 rows.
 //
-// Region pipeline.  Per (chunk, view) the planner's box of the view's quad image is copied into one of S LDS slots by
-// global_load_lds_dwordx4 (dense rows of RS quads, 1 KiB = 64 lanes x 16 B per instruction, per-lane source offsets fixed for the
-// launch).  Copies run L = S - 1 regions ahead; a wavefront waits for ITS OWN copies of the region at hand with a counted
-// s_waitcnt vmcnt(n) -- the younger regions' copies stay in flight -- and one s_barrier per region makes every wavefront's part
-// visible and frees the slot the next copy goes to.  Descriptors and the X / Y / W table entries come in by scalar loads, one
-// region ahead.  LDS reads in the sample loop are inline asm (the compiler would order every ds_read behind ALL pending LDS-DMA).
+// Region pipeline.  Per (chunk, view) the planner's box of the view's quad image is copied into one of two LDS slots by
+// buffer_load_dwordx4 ... lds (dense rows of RS quads, 1 KiB = 64 lanes x 16 B per instruction, per-lane source offsets fixed for the
+// launch), one region ahead of the one being sampled; s_waitcnt vmcnt(0) + one s_barrier per region make every wavefront's part
+// visible and free the slot the next copy goes to.  The X / Y records of the coming regions travel through vector registers (lane l =
+// dword l, v_readlane when the region's turn comes).  The sample loop is one inline-asm statement per plane (M0-based
+// ds_read_addtid_b32, v_dot4_u32_u8, v_sad_u16; planes that are not FULL run it with EXEC = 0): the compiler would order every ds_read
+// behind ALL pending LDS copies, and a per-plane branch costs more scalar instructions than the plane's arithmetic.
+// What bounds it (profiles/r03): vector-instruction issue.  Measured and rejected: a second region of look-ahead
+// with counted waits (three slots, records through an LDS ring; +10 %), row-wise copies (+8 %), copies that all hit in L2 (no change).
 #include "sweep_shared.hpp"
 
 #include <cstddef>
@@ -314,7 +317,7 @@ struct RectArgs {
     size_t pad_slab;
     int pitch, W, H, D, V, v0, vcount, nchunks, chunk0, chunk1, cps, ty0, tyn, tiles_x;
     int slot_dw;   // dwords per LDS slot = 256 x copy instructions per region (one instruction fills 256 dwords); two slots
-    int debug;     // timing experiments, honoured by builds with -DMVS_RX_EXPERIMENTS only: 1 no copies, 2 no sampling, 4 no barrier, 16 no epilogue (wrong results)
+    int debug;     // timing experiments, honoured by builds with -DMVS_RX_EXPERIMENTS only: 1 no copies, 2 no sampling, 4 no barrier, 8 every copy from one box, 16 no epilogue (wrong results)
 };
 
 template <typename T>
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
 {
     constexpr int UNITS = RS / 4;  // 16-byte units per region row
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)smem;  // (through a generic pointer: a null check per use)
 
     const int band_tile = grouped_tile(blockIdx.x, a.tiles_x, a.tyn);
     if (band_tile < 0) return;
@@ -388,16 +391,30 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     auto issue_copy = [&](uint32_t xsx, uint32_t ysrc, uint32_t yn, uint32_t slot_dw0) {
         if (RX_DBG(a, 1)) return;
         const int n = (int)((yn & 0xffu) * (xsx >> 16));
-        const uint32_t src = (xsx & 0xffffu) + ysrc;
+        const uint32_t src = RX_DBG(a, 8) ? 0u : (xsx & 0xffffu) + ysrc;  // (experiment 8: every region copies the same box: the copies hit in L2)
         uint32_t *dst = smem + slot_dw0 + wave * 256;
-#pragma unroll
-        for (int t = 0; t < RX_MAX_NI; t++) {
-            const int left = n - (wave + 4 * t) * 64;  // units of the region this instruction still has to copy (wave-uniform)
-            if (left >= 64) {
+        const int left = n - wave * 64;  // units of the region this wavefront still has to copy (wave-uniform)
+        auto copy = [&](int t, bool whole) {
+            int lim = left - 256 * t;
+            asm volatile("" : "+s"(lim));  // (or the compiler folds the uniform test that led here into this per-lane one: an EXEC mask and its branch per instruction)
+            if (whole || lane < lim)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rquads, (__attribute__((address_space(3))) void *)(dst + t * 1024), 16, srcoff[t], src, 0, 0);
-            } else if (left > 0) {
-                if (lane < left) __builtin_amdgcn_raw_ptr_buffer_load_lds(rquads, (__attribute__((address_space(3))) void *)(dst + t * 1024), 16, srcoff[t], src, 0, 0);
+        };
+        // whole instructions, then the region's last one under a lane mask; nothing left: no later instruction of this wavefront either
+        static_assert(RX_MAX_NI == 3, "the nest below");
+        if (left >= 64) {
+            copy(0, true);
+            if (left >= 320) {
+                copy(1, true);
+                if (left >= 576)
+                    copy(2, true);
+                else if (left > 512)
+                    copy(2, false);
+            } else if (left > 256) {
+                copy(1, false);
             }
+        } else if (left > 0) {
+            copy(0, false);
         }
     };
 
@@ -412,18 +429,20 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     // X and Y records); past the workgroup's last region it stays there (prefetches re-read the last records).
     struct Cursor {
         int vleft, left;  // views left in this chunk after this one; regions left after this one
-        uint32_t xo, yo;
+        uint32_t xo;      // byte offset of the region's X record; the Y records are half as long and walked in step: Y record at ybase + xo / 2
     };
-    const uint32_t xstep = 128u * (uint32_t)NC, ystep = 64u * (uint32_t)NC;          // next view, same chunk
-    const uint32_t xwrap = 128u - xstep * (uint32_t)(a.vcount - 1), ywrap = 64u - ystep * (uint32_t)(a.vcount - 1);  // first view of the next chunk
+    const uint32_t xstep = 128u * (uint32_t)NC;  // next view, same chunk
+    const int vlast = a.vcount - 1;
+    const uint32_t xwrap = 128u - xstep * (uint32_t)vlast;  // first view of the next chunk
     auto advance = [&](Cursor &c) {
         if (c.left <= 0) return;
         c.left--;
         const bool wrap = c.vleft == 0;
         c.xo += wrap ? xwrap : xstep;
-        c.yo += wrap ? ywrap : ystep;
-        c.vleft = wrap ? a.vcount - 1 : c.vleft - 1;
+        c.vleft = wrap ? vlast : c.vleft - 1;
     };
+    const uint32_t x_first = xw_wg + 128u * (uint32_t)(a.v0 * NC + chunk_first);
+    const uint32_t ybase = yr_wg + 64u * (uint32_t)(a.v0 * NC + chunk_first) - (x_first >> 1);
 
     uint32_t acc[8][RX_KW];
     uint32_t best[8];
@@ -439,14 +458,13 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     uint32_t spacc = 0u;  // per plane of this wavefront (one byte each): views of the current chunk whose plane was NOT counted as a whole
 
     Cursor c2;  // region r + 2: the one whose records are fetched next
-    c2.vleft = a.vcount - 1;
+    c2.vleft = vlast;
     c2.left = nreg - 1;
-    c2.xo = xw_wg + 128u * (uint32_t)(a.v0 * NC + chunk_first);
-    c2.yo = yr_wg + 64u * (uint32_t)(a.v0 * NC + chunk_first);
+    c2.xo = x_first;
     // prologue: the records of regions 0 and 1, the copy of region 0
-    uint32_t x0r = load_x(c2.xo), y0r = load_y(c2.yo);  // region r
+    uint32_t x0r = load_x(c2.xo), y0r = load_y(ybase + (c2.xo >> 1));  // region r
     advance(c2);
-    uint32_t x1r = load_x(c2.xo), y1r = load_y(c2.yo);  // region r + 1
+    uint32_t x1r = load_x(c2.xo), y1r = load_y(ybase + (c2.xo >> 1));  // region r + 1
     advance(c2);
     uint32_t slot_cur = 0u, slot_nxt = (uint32_t)a.slot_dw;  // LDS dword offsets of the two slots
     if (nreg > 0) issue_copy(rdl(x0r, 6), rdl(y0r, 2), rdl(y0r, 3), slot_cur);
@@ -459,9 +477,10 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
         if (!RX_DBG(a, 4)) __builtin_amdgcn_s_barrier();
         // request region r + 1 into the other slot and the records of region r + 2: in flight during this region's sampling
         if (r + 1 < nreg) issue_copy(rdl(x1r, 6), rdl(y1r, 2), rdl(y1r, 3), slot_nxt);
-        const uint32_t x2r = load_x(c2.xo), y2r = load_y(c2.yo);
+        const uint32_t x2r = load_x(c2.xo), y2r = load_y(ybase + (c2.xo >> 1));
         advance(c2);
-        const uint32_t sum01 = rdl(x0r, 0) + rdl(y0r, 0), sum23 = rdl(x0r, 1) + rdl(y0r, 1);  // per plane: LDS byte offset, or a flag bit
+        const uint32_t rsum = x0r + y0r;                            // (one vector add, two v_readlane: not four and two scalar adds)
+        const uint32_t sum01 = rdl(rsum, 0), sum23 = rdl(rsum, 1);  // per plane: LDS byte offset, or a flag bit
         const uint32_t we[RX_KW] = {rdl(x0r, 2), rdl(x0r, 3), rdl(x0r, 4), rdl(x0r, 5)};
         const uint32_t fld[RX_KW] = {sum01 & 0xffffu, sum01 >> 16, sum23 & 0xffffu, sum23 >> 16};
 
@@ -469,53 +488,34 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
         const uint32_t special = (sum01 | sum23) & 0xc000c000u;
         if (!RX_DBG(a, 2)) {
             const uint32_t slot_byte = lds_base + slot_cur * 4u;
-            uint32_t qd[RX_DOUBLE_BUFFER ? 2 : 1][8];
-            // FULL planes (certificates hold, nothing out of frame): LDS base in M0 (ds_read_addtid_b32: M0 + offset + 4 lane, no
-            // address register) and weight word in an SGPR; the reads of plane k + 1 are in flight while plane k is consumed.  LDS reads
-            // return in order, so "at most 8 outstanding" means the older plane has landed; the loaded registers are operands of the
-            // wait, so their consumers cannot be scheduled above it.  A plane that is not FULL is read as well (somewhere in or past
-            // the LDS: harmless) and skipped at the compute stage: no second shape of the pipeline.
-            auto issue = [&](int k, int buf) {
+            uint32_t qd[1][8];
+            // One asm statement per plane, branch-free: LDS base in M0 (ds_read_addtid_b32: M0 + offset + 4 lane, no address register),
+            // weight word in an SGPR, 8 reads, 8 v_dot4, 8 v_sad_u16 (all dot products before all differences: a v_sad right behind the
+            // v_dot4 it consumes costs wait states).  A plane that is not FULL reads as well (somewhere in or past the LDS: harmless) and
+            // runs its 16 vector instructions with EXEC = 0; the `special` block below does those planes.  The s_and between the write
+            // of M0 and the first read is the wait state that pair needs.
+#pragma unroll
+            for (int k = 0; k < RX_KW; k++) {
 #pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"  // m0 on the clobber list: the compiler re-materialises it before its own LDS copies
-                asm volatile("s_add_u32 m0, %8, %9\n\ts_nop 0\n\t"
-                             "ds_read_addtid_b32 %0 offset:%10\n\tds_read_addtid_b32 %1 offset:%11\n\tds_read_addtid_b32 %2 offset:%12\n\tds_read_addtid_b32 %3 offset:%13\n\t"
-                             "ds_read_addtid_b32 %4 offset:%14\n\tds_read_addtid_b32 %5 offset:%15\n\tds_read_addtid_b32 %6 offset:%16\n\tds_read_addtid_b32 %7 offset:%17"
-                             : "=v"(qd[buf][0]), "=v"(qd[buf][1]), "=v"(qd[buf][2]), "=v"(qd[buf][3]), "=v"(qd[buf][4]), "=v"(qd[buf][5]), "=v"(qd[buf][6]), "=v"(qd[buf][7])
-                             : "s"(slot_byte), "s"(fld[k]), "n"(0), "n"(RS * 4), "n"(RS * 8), "n"(RS * 12), "n"(RS * 16), "n"(RS * 20), "n"(RS * 24), "n"(RS * 28)
-                             : "m0", "scc");
+#pragma clang diagnostic ignored "-Winline-asm"
+                asm volatile("s_add_u32 m0, %[slot], %[fld]\n\t"
+                             "s_and_b32 vcc_lo, %[fld], 0xc000\n\t"
+                             "ds_read_addtid_b32 %[q0] offset:%[o0]\n\tds_read_addtid_b32 %[q1] offset:%[o1]\n\tds_read_addtid_b32 %[q2] offset:%[o2]\n\tds_read_addtid_b32 %[q3] offset:%[o3]\n\t"
+                             "ds_read_addtid_b32 %[q4] offset:%[o4]\n\tds_read_addtid_b32 %[q5] offset:%[o5]\n\tds_read_addtid_b32 %[q6] offset:%[o6]\n\tds_read_addtid_b32 %[q7] offset:%[o7]\n\t"
+                             "s_cselect_b64 exec, 0, -1\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "v_dot4_u32_u8 %[q0], %[q0], %[w], 0\n\tv_dot4_u32_u8 %[q1], %[q1], %[w], 0\n\tv_dot4_u32_u8 %[q2], %[q2], %[w], 0\n\tv_dot4_u32_u8 %[q3], %[q3], %[w], 0\n\t"
+                             "v_dot4_u32_u8 %[q4], %[q4], %[w], 0\n\tv_dot4_u32_u8 %[q5], %[q5], %[w], 0\n\tv_dot4_u32_u8 %[q6], %[q6], %[w], 0\n\tv_dot4_u32_u8 %[q7], %[q7], %[w], 0\n\t"
+                             "v_sad_u16 %[a0], %[q0], %[i0], %[a0]\n\tv_sad_u16 %[a1], %[q1], %[i1], %[a1]\n\tv_sad_u16 %[a2], %[q2], %[i2], %[a2]\n\tv_sad_u16 %[a3], %[q3], %[i3], %[a3]\n\t"
+                             "v_sad_u16 %[a4], %[q4], %[i4], %[a4]\n\tv_sad_u16 %[a5], %[q5], %[i5], %[a5]\n\tv_sad_u16 %[a6], %[q6], %[i6], %[a6]\n\tv_sad_u16 %[a7], %[q7], %[i7], %[a7]\n\t"
+                             "s_mov_b64 exec, -1"
+                             : [q0] "=&v"(qd[0][0]), [q1] "=&v"(qd[0][1]), [q2] "=&v"(qd[0][2]), [q3] "=&v"(qd[0][3]), [q4] "=&v"(qd[0][4]), [q5] "=&v"(qd[0][5]), [q6] "=&v"(qd[0][6]), [q7] "=&v"(qd[0][7]),
+                               [a0] "+v"(acc[0][k]), [a1] "+v"(acc[1][k]), [a2] "+v"(acc[2][k]), [a3] "+v"(acc[3][k]), [a4] "+v"(acc[4][k]), [a5] "+v"(acc[5][k]), [a6] "+v"(acc[6][k]), [a7] "+v"(acc[7][k])
+                             : [slot] "s"(slot_byte), [fld] "s"(fld[k]), [w] "s"(we[k]),
+                               [i0] "v"(Im255[0]), [i1] "v"(Im255[1]), [i2] "v"(Im255[2]), [i3] "v"(Im255[3]), [i4] "v"(Im255[4]), [i5] "v"(Im255[5]), [i6] "v"(Im255[6]), [i7] "v"(Im255[7]),
+                               [o0] "n"(0), [o1] "n"(RS * 4), [o2] "n"(RS * 8), [o3] "n"(RS * 12), [o4] "n"(RS * 16), [o5] "n"(RS * 20), [o6] "n"(RS * 24), [o7] "n"(RS * 28)
+                             : "m0", "scc", "vcc");
 #pragma clang diagnostic pop
-            };
-            auto consume = [&](int k, int buf, bool more_in_flight) {
-                if (more_in_flight)
-                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(qd[buf][0]), "+v"(qd[buf][1]), "+v"(qd[buf][2]), "+v"(qd[buf][3]), "+v"(qd[buf][4]), "+v"(qd[buf][5]), "+v"(qd[buf][6]), "+v"(qd[buf][7]));
-                else
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qd[buf][0]), "+v"(qd[buf][1]), "+v"(qd[buf][2]), "+v"(qd[buf][3]), "+v"(qd[buf][4]), "+v"(qd[buf][5]), "+v"(qd[buf][6]), "+v"(qd[buf][7]));
-                if (__builtin_expect((fld[k] & 0xc000u) != 0u, 0)) {
-                    spacc += 1u << (8 * k);  // not FULL: this view's count does not go to every cell of the plane
-                } else {
-                    // all dot products, then all differences: a v_sad right behind the v_dot4 it consumes costs three wait states
-#pragma unroll
-                    for (int j = 0; j < 8; j++) qd[buf][j] = __builtin_amdgcn_udot4(qd[buf][j], we[k], 0u, false);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) acc[j][k] = sad_u16(qd[buf][j], Im255[j], acc[j][k]);
-                }
-            };
-            if (RX_DOUBLE_BUFFER) {
-                issue(0, 0);
-                issue(1, 1);
-                consume(0, 0, true);
-                issue(2, 0);
-                consume(1, 1, true);
-                issue(3, 1);
-                consume(2, 0, true);
-                consume(3, 1, false);
-            } else {  // 8 registers less; the other wavefronts of the SIMD cover the LDS latency
-#pragma unroll
-                for (int k = 0; k < RX_KW; k++) {
-                    issue(k, 0);
-                    consume(k, 0, false);
-                }
             }
             // the other planes: part of the tile out of frame (MASKED), nothing in frame, or a certificate failed (SEMI)
             if (special) {
@@ -529,7 +529,9 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                 const bool staged = (xsx >> 16) != 0u && (yn & 0xffu) != 0u;
 #pragma unroll
                 for (int k = 0; k < RX_KW; k++) {
-                    if (!(fld[k] & 0xc000u) || !staged) continue;
+                    if (!(fld[k] & 0xc000u)) continue;
+                    spacc += 1u << (8 * k);  // not FULL: this view's count does not go to every cell of the plane
+                    if (!staged) continue;
                     const uint32_t xe = xt[k], ye = yt[k];
                     const int nx = (int)((xe >> 20) & 127u), ny = (int)((ye >> 20) & 127u);
                     if ((xe & ye) & RX_UNIFORM) {
