@@ -280,6 +280,24 @@ int mvs_profile_enable(mvs_ctx *ctx, int on);
 /* synchronises, then returns summed elapsed ms and launch count per kernel class since the last reset */
 int mvs_profile_read(mvs_ctx *ctx, float ms_sum[MVS_K_COUNT], int launches[MVS_K_COUNT], int reset);
 
+/* ---- surface meshing: replaces poissonSurface (recon.hpp:37, cgal_poisson.cpp:47-136, pcl.cpp:193-228) ----
+ * Poisson reconstruction of oriented samples on a regular grid (csrc/poisson.hip): normals splatted with fixed-point atomics,
+ * laplace(chi) = div V solved with hipFFT, level set through the samples meshed by surface nets.  Context-free (device 0 of the
+ * calling thread's HIP runtime state); no CPU path.
+ *   points     n rows x, y, z, w (homogeneous, as recon.cpp:121 hands them over);  normals  n rows nx, ny, nz (pointing out of the solid)
+ *   grid_log2  log2 of the nodes per axis, 4..9; 0 = chosen from n (32..256)
+ *   smooth_cells  standard deviation (grid cells) of the Gaussian low-pass applied to chi; 1.0 is a good default
+ *   keep_fields  non-zero: keep chi and the splatted integer fields for mvs_surface_grid (tests)
+ * The alpha shape of the first iteration (alphaShapeFaces, recon.hpp:33-34) is host-only code: libmvs_host.so, host/alpha_shapes.cpp. */
+typedef struct mvs_surface mvs_surface;
+int mvs_poisson_surface(const float *points, const float *normals, int n, int grid_log2, float smooth_cells, int keep_fields, mvs_surface **out);
+int mvs_surface_counts(const mvs_surface *s, int *vertices, int *faces);
+int mvs_surface_fetch(const mvs_surface *s, float *vertices /* V x 4, w = 1 */, int32_t *faces /* F x 3, normals along the samples' */);
+int mvs_surface_grid(const mvs_surface *s, int *nodes_per_axis, float origin3[3], float *spacing, float *level, float *chi /* G^3, nullable */,
+                     int32_t *splat /* 4 G^3: vx, vy, vz, weight in units of 2^-16; nullable */);
+void mvs_surface_free(mvs_surface *s);
+const char *mvs_surface_last_error(void); /* of the calling thread */
+
 /* library / device info string, e.g. "libmvs_hip gfx950 AMD Instinct MI355X" */
 const char *mvs_device_info(mvs_ctx *ctx);
 

@@ -1,0 +1,433 @@
+// poisson.hip -- poissonSurface (recon.hpp:37, cgal_poisson.cpp:47-136 / pcl.cpp:193-228 of the reference) on gfx950.
+//
+// The reference hands oriented points to CGAL's Poisson_reconstruction_function + make_surface_mesh (or, in pcl.cpp, to PCL's
+// Poisson): third-party host code that is neither in this image nor vendored by the reference.  Both solve the same problem
+// (Kazhdan, Bolitho, Hoppe: "Poisson surface reconstruction", SGP 2006): find the scalar field chi whose gradient best matches the
+// field V of the samples' normals, laplace(chi) = div V, and extract the level set through the samples.  This is that method on a
+// REGULAR grid sized for one MI355X (G^3 nodes, G <= 512: 0.5 GB per field at G = 512 out of 288 GB), which is the form the paper
+// itself starts from (its section 3) before it introduces the octree to save memory:
+//   1. the samples' normals are splatted onto the grid nodes with trilinear weights -- 32-bit fixed-point atomics, so the field does
+//      not depend on the order the atomics land in (bit-reproducible, and the CPU oracle gets the same integers);
+//   2. laplace(chi) = div V is solved in the Fourier domain (hipFFT: three real-to-complex transforms, chi^ = -i k.V^ / |k|^2 with a
+//      Gaussian low-pass of `smooth` cells, one complex-to-real transform); periodic boundaries, kept away by padding the box;
+//   3. the level: the mean of chi (trilinear) over the samples, summed on the host in sample order (deterministic);
+//   4. the level set is meshed by surface nets (one vertex per grid cell the surface passes through, at the mean of its edge
+//      crossings; one quad = two triangles per grid edge that changes sign), vertices and faces numbered in grid order by
+//      exclusive scans (rocPRIM), faces oriented along +grad chi = the samples' normals (outward, like cgal_poisson.cpp:128-132).
+// Output: vertices N x 4 homogeneous (w = 1), faces F x 3 int32, as Mesh (recon.hpp:19-24).  Not CGAL's triangulation: a different
+// mesh of the same level set family (no Delaunay refinement, no angle / radius / distance criteria); DESIGN.md section 9 says so.
+// Checked against oracle/poisson_oracle.py (numpy, float64) on the same inputs: identical splat integers, chi within 1e-4 of its
+// range, surfaces within a fraction of a cell (tests/test_meshing_gpu.py).
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/mvs.h"
+
+namespace {
+
+constexpr float SPLAT_SCALE = 65536.0f;  // fixed point of the splatted fields: 2^-16 per unit weight
+
+struct Grid {
+    int G;            // nodes per axis
+    float ox, oy, oz; // position of node (0, 0, 0)
+    float h;          // node spacing
+};
+
+__device__ __forceinline__ size_t node(const Grid &g, int i, int j, int k) { return ((size_t)k * g.G + j) * g.G + i; }
+
+// samples: xyzw rows (w divides) + normal rows
+__global__ void splat_kernel(Grid g, const float *__restrict__ pts, const float *__restrict__ nrm, int n, int *__restrict__ vx, int *__restrict__ vy,
+                             int *__restrict__ vz, int *__restrict__ wt)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float w = pts[4 * s + 3];
+    const float gx = (pts[4 * s] / w - g.ox) / g.h, gy = (pts[4 * s + 1] / w - g.oy) / g.h, gz = (pts[4 * s + 2] / w - g.oz) / g.h;
+    const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    if (i < 0 || j < 0 || k < 0 || i + 1 >= g.G || j + 1 >= g.G || k + 1 >= g.G) return;  // (the box is padded: cannot happen for the box's own samples)
+    const float tx = gx - fx, ty = gy - fy, tz = gz - fz;
+    const float nx = nrm[3 * s], ny = nrm[3 * s + 1], nz = nrm[3 * s + 2];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int di = c & 1, dj = (c >> 1) & 1, dk = c >> 2;
+        const float wgt = (di ? tx : 1.0f - tx) * (dj ? ty : 1.0f - ty) * (dk ? tz : 1.0f - tz);
+        const size_t q = node(g, i + di, j + dj, k + dk);
+        atomicAdd(&vx[q], (int)rintf(nx * wgt * SPLAT_SCALE));
+        atomicAdd(&vy[q], (int)rintf(ny * wgt * SPLAT_SCALE));
+        atomicAdd(&vz[q], (int)rintf(nz * wgt * SPLAT_SCALE));
+        atomicAdd(&wt[q], (int)rintf(wgt * SPLAT_SCALE));
+    }
+}
+
+__global__ void fixed_to_float_kernel(const int *__restrict__ a, float *__restrict__ out, size_t n)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) out[q] = (float)a[q] * (1.0f / SPLAT_SCALE);
+}
+
+// chi^ = -i (k . V^) / |k|^2 * exp(-sigma^2 |k|^2 / 2) / G^3, k = 2 pi f / G per axis (f the signed frequency, 0 at the Nyquist
+// frequency: the derivative of that mode is not defined on the grid); in place in sx
+__global__ void spectral_solve_kernel(int G, float sigma, hipfftComplex *__restrict__ sx, const hipfftComplex *__restrict__ sy,
+                                      const hipfftComplex *__restrict__ sz)
+{
+    const int H = G / 2 + 1;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (size_t)G * G * H) return;
+    const int a = (int)(q % H), b = (int)((q / H) % G), c = (int)(q / ((size_t)H * G));  // hipFFT's R2C layout: [z][y][x / 2 + 1]
+    auto freq = [&](int f) { return f * 2 == G ? 0 : (f * 2 > G ? f - G : f); };
+    const float two_pi_over_G = 6.28318530717958647692f / (float)G;
+    const float kx = two_pi_over_G * (float)freq(a), ky = two_pi_over_G * (float)freq(b), kz = two_pi_over_G * (float)freq(c);
+    const float k2 = kx * kx + ky * ky + kz * kz;
+    hipfftComplex out = {0.0f, 0.0f};
+    if (k2 > 0.0f) {
+        const float re = kx * sx[q].x + ky * sy[q].x + kz * sz[q].x, im = kx * sx[q].y + ky * sy[q].y + kz * sz[q].y;
+        const float s = expf(-0.5f * sigma * sigma * k2) / (k2 * (float)G * (float)G * (float)G);
+        out.x = im * s;   // -i (re + i im) = im - i re
+        out.y = -re * s;
+    }
+    sx[q] = out;
+}
+
+__device__ __forceinline__ float trilinear(const Grid &g, const float *__restrict__ f, float x, float y, float z)
+{
+    const float gx = (x - g.ox) / g.h, gy = (y - g.oy) / g.h, gz = (z - g.oz) / g.h;
+    const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    i = min(max(i, 0), g.G - 2), j = min(max(j, 0), g.G - 2), k = min(max(k, 0), g.G - 2);
+    const float tx = gx - (float)i, ty = gy - (float)j, tz = gz - (float)k;
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int di = c & 1, dj = (c >> 1) & 1, dk = c >> 2;
+        acc += (di ? tx : 1.0f - tx) * (dj ? ty : 1.0f - ty) * (dk ? tz : 1.0f - tz) * f[node(g, i + di, j + dj, k + dk)];
+    }
+    return acc;
+}
+
+__global__ void sample_kernel(Grid g, const float *__restrict__ chi, const float *__restrict__ pts, int n, float *__restrict__ out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float w = pts[4 * s + 3];
+    out[s] = trilinear(g, chi, pts[4 * s] / w, pts[4 * s + 1] / w, pts[4 * s + 2] / w);
+}
+
+// cells: (G - 1)^3, cell (i, j, k) spans nodes i .. i + 1; "inside" = chi < iso (chi grows along the normals, which point out)
+__device__ __forceinline__ size_t cell_id(int C, int i, int j, int k) { return ((size_t)k * C + j) * C + i; }
+
+__global__ void cell_flags_kernel(Grid g, const float *__restrict__ chi, float iso, int *__restrict__ flag)
+{
+    const int C = g.G - 1;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (size_t)C * C * C) return;
+    const int i = (int)(q % C), j = (int)((q / C) % C), k = (int)(q / ((size_t)C * C));
+    int inside = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) inside += chi[node(g, i + (c & 1), j + ((c >> 1) & 1), k + (c >> 2))] < iso ? 1 : 0;
+    flag[q] = (inside != 0 && inside != 8) ? 1 : 0;
+}
+
+__global__ void cell_vertices_kernel(Grid g, const float *__restrict__ chi, float iso, const int *__restrict__ flag, const int *__restrict__ index,
+                                     float *__restrict__ vertices)
+{
+    const int C = g.G - 1;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (size_t)C * C * C || !flag[q]) return;
+    const int i = (int)(q % C), j = (int)((q / C) % C), k = (int)(q / ((size_t)C * C));
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) v[c] = chi[node(g, i + (c & 1), j + ((c >> 1) & 1), k + (c >> 2))] - iso;
+    // the 12 edges of the cell as pairs of corner numbers (bit 0: x, bit 1: y, bit 2: z), in a fixed order
+    const int ea[12] = {0, 2, 4, 6, 0, 1, 4, 5, 0, 1, 2, 3}, eb[12] = {1, 3, 5, 7, 2, 3, 6, 7, 4, 5, 6, 7};
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    int m = 0;
+#pragma unroll
+    for (int e = 0; e < 12; e++) {
+        const float a = v[ea[e]], b = v[eb[e]];
+        if ((a < 0.0f) != (b < 0.0f)) {
+            const float t = a / (a - b);
+            const int ca = ea[e], cb = eb[e];
+            sx += (float)(ca & 1) + t * (float)((cb & 1) - (ca & 1));
+            sy += (float)((ca >> 1) & 1) + t * (float)(((cb >> 1) & 1) - ((ca >> 1) & 1));
+            sz += (float)(ca >> 2) + t * (float)((cb >> 2) - (ca >> 2));
+            m++;
+        }
+    }
+    const float inv = 1.0f / (float)m;
+    float *out = vertices + 4 * (size_t)index[q];
+    out[0] = g.ox + g.h * ((float)i + sx * inv);
+    out[1] = g.oy + g.h * ((float)j + sy * inv);
+    out[2] = g.oz + g.h * ((float)k + sz * inv);
+    out[3] = 1.0f;
+}
+
+// grid edges: 3 per node (towards +x, +y, +z); an edge makes a quad when its ends lie on different sides and all four cells around
+// it exist.  flag: 1 = inside -> outside along the axis, 2 = outside -> inside.
+__device__ __forceinline__ int edge_state(const Grid &g, const float *__restrict__ chi, float iso, int i, int j, int k, int axis)
+{
+    const int C = g.G - 1;
+    const int i2 = i + (axis == 0), j2 = j + (axis == 1), k2 = k + (axis == 2);
+    if (i2 > C || j2 > C || k2 > C) return 0;
+    // the two axes across: cells at offsets -1 and 0 must exist
+    const int u = axis == 0 ? j : (axis == 1 ? k : i), w = axis == 0 ? k : (axis == 1 ? i : j);
+    if (u < 1 || u > C - 1 || w < 1 || w > C - 1) return 0;
+    const bool a = chi[node(g, i, j, k)] < iso, b = chi[node(g, i2, j2, k2)] < iso;
+    return a == b ? 0 : (a ? 1 : 2);
+}
+
+__global__ void edge_flags_kernel(Grid g, const float *__restrict__ chi, float iso, int *__restrict__ flag)
+{
+    const size_t n = (size_t)g.G * g.G * g.G;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= 3 * n) return;
+    const int axis = (int)(q / n);
+    const size_t r = q % n;
+    const int i = (int)(r % g.G), j = (int)((r / g.G) % g.G), k = (int)(r / ((size_t)g.G * g.G));
+    flag[q] = edge_state(g, chi, iso, i, j, k, axis) ? 1 : 0;
+}
+
+__global__ void edge_faces_kernel(Grid g, const float *__restrict__ chi, float iso, const int *__restrict__ flag, const int *__restrict__ index,
+                                  const int *__restrict__ cell_index, int *__restrict__ faces)
+{
+    const size_t n = (size_t)g.G * g.G * g.G;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= 3 * n || !flag[q]) return;
+    const int axis = (int)(q / n);
+    const size_t r = q % n;
+    const int i = (int)(r % g.G), j = (int)((r / g.G) % g.G), k = (int)(r / ((size_t)g.G * g.G));
+    const int st = edge_state(g, chi, iso, i, j, k, axis);
+    const int C = g.G - 1;
+    // the four cells around the edge, counter-clockwise seen from the positive end of the axis: offsets (-1,-1), (0,-1), (0,0), (-1,0)
+    // in the two axes (u, w) with axis = u x w: x: (y, z), y: (z, x), z: (x, y)
+    const int du[4] = {-1, 0, 0, -1}, dw[4] = {-1, -1, 0, 0};
+    int v[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int ci = i, cj = j, ck = k;
+        if (axis == 0) cj += du[c], ck += dw[c];
+        else if (axis == 1) ck += du[c], ci += dw[c];
+        else ci += du[c], cj += dw[c];
+        v[c] = cell_index[cell_id(C, ci, cj, ck)];
+    }
+    if (st == 2) {  // outside -> inside along the axis: the normal points down the axis
+        const int t = v[1];
+        v[1] = v[3];
+        v[3] = t;
+    }
+    int *out = faces + 6 * (size_t)index[q];
+    out[0] = v[0], out[1] = v[1], out[2] = v[2];
+    out[3] = v[0], out[4] = v[2], out[5] = v[3];
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess; }
+    template <class T> T *as() { return (T *)p; }
+};
+
+thread_local std::string g_poisson_error;
+int fail(int code, const char *what)
+{
+    g_poisson_error = what;
+    return code;
+}
+
+bool scan(int *flags, int *offsets, size_t n, hipStream_t st, DevBuf &tmp, size_t &tmp_bytes)
+{
+    size_t need = 0;
+    if (rocprim::exclusive_scan(nullptr, need, flags, offsets, 0, n, rocprim::plus<int>(), st) != hipSuccess) return false;
+    if (need > tmp_bytes) {
+        if (tmp.p) (void)hipFree(tmp.p);
+        tmp.p = nullptr;
+        if (!tmp.alloc(need)) return false;
+        tmp_bytes = need;
+    }
+    return rocprim::exclusive_scan(tmp.p, need, flags, offsets, 0, n, rocprim::plus<int>(), st) == hipSuccess;
+}
+
+}  // namespace
+
+struct mvs_surface {
+    Grid grid{};
+    float iso = 0.0f;
+    std::vector<float> vertices;   // 4 per vertex
+    std::vector<int32_t> faces;    // 3 per face
+    std::vector<float> chi;        // G^3, kept when asked for (tests)
+    std::vector<int32_t> splat;    // 4 G^3 (vx, vy, vz, weight), kept when asked for (tests)
+};
+
+extern "C" const char *mvs_surface_last_error(void) { return g_poisson_error.c_str(); }
+
+extern "C" int mvs_poisson_surface(const float *points, const float *normals, int n, int grid_log2, float smooth_cells, int keep_fields, mvs_surface **out)
+{
+    if (!points || !normals || n < 1 || !out || grid_log2 < 0 || grid_log2 > 9 || !(smooth_cells >= 0.0f)) return fail(MVS_EINVAL, "mvs_poisson_surface: bad argument");
+    *out = nullptr;
+    int devices = 0;
+    if (hipGetDeviceCount(&devices) != hipSuccess || devices < 1) return fail(MVS_EHIP, "mvs_poisson_surface: no HIP device (this library has no CPU path)");
+    // the box: the samples' bounding cube, padded by a quarter of its side on every face (periodic solve: keep the wrap-around away)
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int s = 0; s < n; s++) {
+        const float w = points[4 * s + 3];
+        for (int c = 0; c < 3; c++) {
+            const double v = (double)(points[4 * s + c] / w);
+            if (!(v == v) || std::fabs(v) > 1e30) return fail(MVS_EINVAL, "mvs_poisson_surface: a point is not finite");
+            lo[c] = std::min(lo[c], v), hi[c] = std::max(hi[c], v);
+        }
+    }
+    double side = 0.0;
+    for (int c = 0; c < 3; c++) side = std::max(side, hi[c] - lo[c]);
+    if (!(side > 0.0)) return fail(MVS_EINVAL, "mvs_poisson_surface: the points have no extent");
+    int lg = grid_log2;
+    if (lg == 0) {  // a cell about as wide as the samples are apart: a closed surface sampled by n points has ~0.56 sqrt(n) of them across, the box is 1.5 x
+        const double want = std::sqrt((double)n);
+        lg = 5;
+        while (lg < 8 && (double)(1 << lg) < want) lg++;
+    }
+    if (lg < 4) return fail(MVS_EINVAL, "mvs_poisson_surface: the grid needs at least 16 nodes per axis");
+    Grid g;
+    g.G = 1 << lg;
+    const double box = 1.5 * side;
+    g.h = (float)(box / (double)(g.G - 1));
+    g.ox = (float)(0.5 * (lo[0] + hi[0]) - 0.5 * box);
+    g.oy = (float)(0.5 * (lo[1] + hi[1]) - 0.5 * box);
+    g.oz = (float)(0.5 * (lo[2] + hi[2]) - 0.5 * box);
+    const size_t N3 = (size_t)g.G * g.G * g.G, S3 = (size_t)g.G * g.G * (g.G / 2 + 1);
+    const int C = g.G - 1;
+    const size_t C3 = (size_t)C * C * C;
+
+    mvs_surface *res = new (std::nothrow) mvs_surface;
+    if (!res) return fail(MVS_ENOMEM, "mvs_poisson_surface: host allocation failed");
+    res->grid = g;
+    hipStream_t st = nullptr;
+    DevBuf d_pts, d_nrm, d_fix, d_real, d_spec, d_flag, d_index, d_cell_index, d_tmp, d_samples, d_vertices, d_faces;
+    size_t tmp_bytes = 0;
+    hipfftHandle fwd = 0, inv = 0;
+    bool have_fwd = false, have_inv = false;
+    int rc = MVS_OK;
+    const char *msg = "";
+#define PS_TRY(cond, code, text) do { if (!(cond)) { rc = (code); msg = (text); goto done; } } while (0)
+    {
+        PS_TRY(d_pts.alloc((size_t)n * 16) && d_nrm.alloc((size_t)n * 12) && d_fix.alloc(4 * N3 * 4) && d_real.alloc(3 * N3 * 4) && d_spec.alloc(3 * S3 * 8) &&
+                   d_flag.alloc(3 * N3 * 4) && d_index.alloc((3 * N3 + 1) * 4) && d_cell_index.alloc((C3 + 1) * 4) && d_samples.alloc((size_t)n * 4),
+               MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
+        PS_TRY(hipMemcpy(d_pts.p, points, (size_t)n * 16, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_nrm.p, normals, (size_t)n * 12, hipMemcpyHostToDevice) == hipSuccess &&
+                   hipMemsetAsync(d_fix.p, 0, 4 * N3 * 4, st) == hipSuccess,
+               MVS_EHIP, "mvs_poisson_surface: upload failed");
+        int *vx = d_fix.as<int>(), *vy = vx + N3, *vz = vy + N3, *wt = vz + N3;
+        splat_kernel<<<(n + 255) / 256, 256, 0, st>>>(g, d_pts.as<float>(), d_nrm.as<float>(), n, vx, vy, vz, wt);
+        fixed_to_float_kernel<<<(unsigned)((3 * N3 + 255) / 256), 256, 0, st>>>(vx, d_real.as<float>(), 3 * N3);
+        PS_TRY(hipGetLastError() == hipSuccess, MVS_EHIP, "mvs_poisson_surface: splat launch failed");
+        PS_TRY(hipfftPlan3d(&fwd, g.G, g.G, g.G, HIPFFT_R2C) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: hipfftPlan3d (R2C) failed");
+        have_fwd = true;
+        PS_TRY(hipfftPlan3d(&inv, g.G, g.G, g.G, HIPFFT_C2R) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: hipfftPlan3d (C2R) failed");
+        have_inv = true;
+        PS_TRY(hipfftSetStream(fwd, st) == HIPFFT_SUCCESS && hipfftSetStream(inv, st) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: hipfftSetStream failed");
+        hipfftComplex *spec = d_spec.as<hipfftComplex>();
+        for (int c = 0; c < 3; c++)
+            PS_TRY(hipfftExecR2C(fwd, d_real.as<float>() + c * N3, spec + c * S3) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: forward FFT failed");
+        spectral_solve_kernel<<<(unsigned)((S3 + 255) / 256), 256, 0, st>>>(g.G, smooth_cells, spec, spec + S3, spec + 2 * S3);
+        float *chi = d_real.as<float>();  // (the transform may overwrite its input: spec[0] is not used again)
+        PS_TRY(hipfftExecC2R(inv, spec, chi) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: inverse FFT failed");
+        sample_kernel<<<(n + 255) / 256, 256, 0, st>>>(g, chi, d_pts.as<float>(), n, d_samples.as<float>());
+        std::vector<float> samples((size_t)n);
+        PS_TRY(hipMemcpyAsync(samples.data(), d_samples.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess, MVS_EHIP,
+               "mvs_poisson_surface: sampling failed");
+        double sum = 0.0;
+        for (int s = 0; s < n; s++) sum += (double)samples[s];
+        const float iso = (float)(sum / (double)n);
+        res->iso = iso;
+        // vertices
+        int *flag = d_flag.as<int>(), *cell_index = d_cell_index.as<int>();
+        cell_flags_kernel<<<(unsigned)((C3 + 255) / 256), 256, 0, st>>>(g, chi, iso, flag);
+        PS_TRY(hipMemsetAsync(flag + C3, 0, 4, st) == hipSuccess && scan(flag, cell_index, C3 + 1, st, d_tmp, tmp_bytes), MVS_EHIP, "mvs_poisson_surface: scan failed");
+        int nv = 0;
+        PS_TRY(hipMemcpyAsync(&nv, cell_index + C3, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: count failed");
+        PS_TRY(d_vertices.alloc((size_t)nv * 16), MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
+        if (nv > 0) cell_vertices_kernel<<<(unsigned)((C3 + 255) / 256), 256, 0, st>>>(g, chi, iso, flag, cell_index, d_vertices.as<float>());
+        res->vertices.resize((size_t)nv * 4);
+        if (nv > 0) PS_TRY(hipMemcpyAsync(res->vertices.data(), d_vertices.p, (size_t)nv * 16, hipMemcpyDeviceToHost, st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: download failed");
+        // faces (the cell flags are overwritten by the edge flags: the vertex kernel above is ordered before on the stream)
+        int *index = d_index.as<int>();
+        edge_flags_kernel<<<(unsigned)((3 * N3 + 255) / 256), 256, 0, st>>>(g, chi, iso, flag);
+        {
+            // flag has 3 N3 entries; the scan needs one more (the total): d_flag was sized 3 N3, so scan into index[0 .. 3 N3] with the
+            // total computed from the last offset + last flag
+            PS_TRY(scan(flag, index, 3 * N3, st, d_tmp, tmp_bytes), MVS_EHIP, "mvs_poisson_surface: scan failed");
+        }
+        int last_off = 0, last_flag = 0;
+        PS_TRY(hipMemcpyAsync(&last_off, index + 3 * N3 - 1, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                   hipMemcpyAsync(&last_flag, flag + 3 * N3 - 1, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess,
+               MVS_EHIP, "mvs_poisson_surface: count failed");
+        const int nq = last_off + last_flag;
+        PS_TRY(d_faces.alloc((size_t)nq * 24), MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
+        if (nq > 0) edge_faces_kernel<<<(unsigned)((3 * N3 + 255) / 256), 256, 0, st>>>(g, chi, iso, flag, index, cell_index, d_faces.as<int>());
+        res->faces.resize((size_t)nq * 6);
+        if (nq > 0) PS_TRY(hipMemcpyAsync(res->faces.data(), d_faces.p, (size_t)nq * 24, hipMemcpyDeviceToHost, st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: download failed");
+        if (keep_fields) {
+            res->chi.resize(N3);
+            res->splat.resize(4 * N3);
+            PS_TRY(hipMemcpyAsync(res->chi.data(), chi, N3 * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                       hipMemcpyAsync(res->splat.data(), d_fix.p, 4 * N3 * 4, hipMemcpyDeviceToHost, st) == hipSuccess,
+                   MVS_EHIP, "mvs_poisson_surface: download failed");
+        }
+        PS_TRY(hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess, MVS_EHIP, "mvs_poisson_surface: a kernel failed");
+    }
+done:
+#undef PS_TRY
+    if (have_fwd) (void)hipfftDestroy(fwd);
+    if (have_inv) (void)hipfftDestroy(inv);
+    if (rc != MVS_OK) {
+        delete res;
+        return fail(rc, msg);
+    }
+    *out = res;
+    return MVS_OK;
+}
+
+extern "C" int mvs_surface_counts(const mvs_surface *s, int *vertices, int *faces)
+{
+    if (!s) return MVS_EINVAL;
+    if (vertices) *vertices = (int)(s->vertices.size() / 4);
+    if (faces) *faces = (int)(s->faces.size() / 3);
+    return MVS_OK;
+}
+
+extern "C" int mvs_surface_fetch(const mvs_surface *s, float *vertices, int32_t *faces)
+{
+    if (!s) return MVS_EINVAL;
+    if (vertices && !s->vertices.empty()) std::memcpy(vertices, s->vertices.data(), s->vertices.size() * 4);
+    if (faces && !s->faces.empty()) std::memcpy(faces, s->faces.data(), s->faces.size() * 4);
+    return MVS_OK;
+}
+
+extern "C" int mvs_surface_grid(const mvs_surface *s, int *nodes_per_axis, float *origin3, float *spacing, float *level, float *chi, int32_t *splat)
+{
+    if (!s) return MVS_EINVAL;
+    if (nodes_per_axis) *nodes_per_axis = s->grid.G;
+    if (origin3) origin3[0] = s->grid.ox, origin3[1] = s->grid.oy, origin3[2] = s->grid.oz;
+    if (spacing) *spacing = s->grid.h;
+    if (level) *level = s->iso;
+    if (chi) {
+        if (s->chi.empty()) return MVS_ESTATE;
+        std::memcpy(chi, s->chi.data(), s->chi.size() * 4);
+    }
+    if (splat) {
+        if (s->splat.empty()) return MVS_ESTATE;
+        std::memcpy(splat, s->splat.data(), s->splat.size() * 4);
+    }
+    return MVS_OK;
+}
+
+extern "C" void mvs_surface_free(mvs_surface *s) { delete s; }

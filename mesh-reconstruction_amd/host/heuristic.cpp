@@ -317,15 +317,13 @@ Mesh Heuristic::tessellate(const Mat points, const Mat normals)
             alphaVals.push_back(1);  // "TODO: estimate some alpha value from the geometry", heuristic.cpp:530
             return result;
         }
-        if (!meshers.alphaShapeFaces) throw std::runtime_error("tessellate: no alphaShapeFaces callback installed");
         float alpha = 0;
-        Mat faces = meshers.alphaShapeFaces(points, &alpha);
+        Mat faces = meshers.alphaShapeFaces ? meshers.alphaShapeFaces(points, &alpha) : alphaShapeFaces(points, &alpha);
         alphaVals.push_back(alpha);
         return Mesh(points, faces);
     }
-    if (!meshers.poissonSurface) throw std::runtime_error("tessellate: no poissonSurface callback installed");
     if (alphaVals.empty()) throw std::runtime_error("tessellate: Poisson iteration before any alpha value was recorded");
-    Mesh result = meshers.poissonSurface(points, normals);
+    Mesh result = meshers.poissonSurface ? meshers.poissonSurface(points, normals) : poissonSurface(points, normals);
     alphaVals.push_back(alphaVals.back() / 2);
     return result;
 }

@@ -1,0 +1,24 @@
+// poisson.cpp -- poissonSurface (recon.hpp:37; cgal_poisson.cpp:47-136, pcl.cpp:225-228 of the reference) above the C ABI
+// (include/mvs.h: mvs_poisson_surface, csrc/poisson.hip).  Same call, same Mesh layout (vertices N x 4 homogeneous f32, faces F x 3
+// i32, normals out of the solid); what is inside is this library's grid Poisson solver, not CGAL's (see csrc/poisson.hip).
+#include <stdexcept>
+#include <string>
+
+#include "../../include/mvs.h"
+#include "recon.hpp"
+
+Mesh poissonSurface(const Mat points, const Mat normals)
+{
+    if (points.rows == 0) return Mesh(Mat(0, 4, mvs::F32C1), Mat(0, 3, mvs::S32C1));
+    if (points.cols != 4 || normals.cols != 3 || normals.rows != points.rows)
+        throw std::runtime_error("poissonSurface: points must be N x 4 (homogeneous) and normals N x 3");  // cgal_poisson.cpp:58-59 reads p[0..3], n[0..2]
+    mvs_surface *s = nullptr;
+    const int rc = mvs_poisson_surface(points.ptr<float>(), normals.ptr<float>(), points.rows, 0, 1.0f, 0, &s);
+    if (rc != MVS_OK) throw std::runtime_error(std::string("poissonSurface: ") + mvs_surface_last_error());  // cgal_poisson.cpp:73: assert(success)
+    int nv = 0, nf = 0;
+    mvs_surface_counts(s, &nv, &nf);
+    Mesh result(Mat(nv, 4, mvs::F32C1), Mat(nf, 3, mvs::S32C1));
+    mvs_surface_fetch(s, nv ? result.vertices.ptr<float>() : nullptr, nf ? result.faces.ptr<int32_t>() : nullptr);
+    mvs_surface_free(s);
+    return result;
+}

@@ -53,6 +53,11 @@ Mat mixBackground(const Mat image, const Mat background, Mat &depth);  // util.c
 Mat flowRemap(const Mat flow, const Mat image);            // util.cpp:390-403
 float sampleImage(const Mat image, float radiusSquared, const float x, const float y, char c);  // util.cpp:408-433 (recon.hpp:47)
 
+// == surface meshing (alpha_shapes.cpp:36-104, cgal_poisson.cpp:47-136): host/alpha_shapes.cpp, host/poisson.cpp ==
+Mat alphaShapeFaces(const Mat points);                // recon.hpp:33
+Mat alphaShapeFaces(const Mat points, float *alpha);  // recon.hpp:34: faces F x 3 i32 of the alpha shape that is one solid component; *alpha = the value chosen
+Mesh poissonSurface(const Mat points, const Mat normals);  // recon.hpp:37: points N x 4 homogeneous, normals N x 3
+
 // == configuration (configuration.cpp) ==
 class Configuration {
 public:
@@ -144,8 +149,8 @@ public:
     int nextSide(int mainNumber);
     void filterPoints(Mat &points, Mat &normals);
     // heuristic.cpp:525-545: first iteration -> the mesh file given with -m (alpha 1) or alpha shapes of the points (alpha from the
-    // mesher); later iterations -> Poisson surface (alpha halved).  The meshers themselves are CGAL / PCL host code outside the hot
-    // path: they are injected, the dispatch and the alphaVals bookkeeping filterPoints depends on are here.
+    // mesher); later iterations -> Poisson surface (alpha halved).  The meshers default to this library's own (alphaShapeFaces,
+    // poissonSurface above: SURVEY.md section 8f-4 without CGAL); a caller that links CGAL / PCL installs its own here.
     struct Meshers {
         std::function<Mat(const Mat points, float *alpha)> alphaShapeFaces;       // alpha_shapes.cpp:36-99
         std::function<Mesh(const Mat points, const Mat normals)> poissonSurface;  // cgal_poisson.cpp:47-136 or pcl.cpp

@@ -156,11 +156,15 @@ static int run_cpu(const std::string &tracks)
         (void)h2.notHappy(pts);
         (void)h2.tessellate(pts, nrm);
         CHECK(readCalls == 1 && h2.alphaVals.size() == 1 && h2.alphaVals.back() == 1.f, "tessellate: initial mesh file gives alpha 1");
+        // no meshers installed: the library's own alpha shapes (host/alpha_shapes.cpp) of the bundle's points, as recon.cpp:36 does
         Heuristic h3(&c);
         (void)h3.notHappy(pts);
-        threw = false;
-        try { (void)h3.tessellate(pts, nrm); } catch (const std::exception &) { threw = true; }
-        CHECK(threw, "tessellate without an installed mesher must fail loudly");
+        Mesh m3 = h3.tessellate(pts, nrm);
+        bool ok = m3.faces.rows > 0 && m3.vertices.rows == pts.rows && h3.alphaVals.size() == 1 && h3.alphaVals.back() > 0.f;
+        for (int i = 0; ok && i < m3.faces.rows; i++)
+            for (int k = 0; k < 3; k++) ok = ok && m3.faces.at<int32_t>(i, k) >= 0 && m3.faces.at<int32_t>(i, k) < pts.rows;
+        CHECK(ok, "tessellate with the built-in alpha shapes: %d faces over %d points, alpha %g", m3.faces.rows, pts.rows, h3.alphaVals.empty() ? -1.0 : (double)h3.alphaVals.back());
+        printf("alpha shape of the zatisi bundle: %d points, %d faces, alpha %g\n", pts.rows, m3.faces.rows, (double)h3.alphaVals.back());
     }
     printf("cpu selftest: %d failures\n", fails);
     return fails ? 1 : 0;
@@ -201,6 +205,36 @@ static int run_gpu(const std::string &tracks, const std::string &out)
         const double ms_plain = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         CHECK(count2 == cameraCount && hint2.chosen() == hint.chosen(), "chooseCameras differs between probed and whole-map depth");
         printf("chooseCameras (200 shots): %.1f ms with depth probes, %.1f ms with whole depth maps\n", ms_probe, ms_plain);
+    }
+    {
+        // recon.cpp:136 on a later iteration: Heuristic::tessellate -> the library's Poisson surface (csrc/poisson.hip) of oriented samples
+        Heuristic hp(&config);
+        const int n = 20000;
+        Mat pts(n, 4, mvs::F32C1), nrm(n, 3, mvs::F32C1);
+        for (int i = 0; i < n; i++) {  // a Fibonacci sphere of radius 0.7 around (0.1, -0.2, 3)
+            const double z = 1.0 - 2.0 * (i + 0.5) / n, r = std::sqrt(1.0 - z * z), phi = i * 2.399963229728653;
+            const double d[3] = {r * std::cos(phi), r * std::sin(phi), z};
+            const double c[3] = {0.1, -0.2, 3.0};
+            for (int k = 0; k < 3; k++) pts.at<float>(i, k) = (float)(2.0 * (c[k] + 0.7 * d[k])), nrm.at<float>(i, k) = (float)d[k];
+            pts.at<float>(i, 3) = 2.0f;  // homogeneous rows, w != 1
+        }
+        (void)hp.notHappy(pts);
+        (void)hp.notHappy(pts);
+        hp.alphaVals.push_back(0.5f);
+        const Mesh m = hp.tessellate(pts, nrm);
+        double worst = 0.0, vol = 0.0;
+        for (int i = 0; i < m.vertices.rows; i++) {
+            const float *v = m.vertices.ptr<float>(i);
+            const double dx = v[0] / v[3] - 0.1, dy = v[1] / v[3] + 0.2, dz = v[2] / v[3] - 3.0;
+            worst = std::max(worst, std::fabs(std::sqrt(dx * dx + dy * dy + dz * dz) - 0.7));
+        }
+        for (int i = 0; i < m.faces.rows; i++) {
+            const float *a = m.vertices.ptr<float>(m.faces.at<int32_t>(i, 0)), *b = m.vertices.ptr<float>(m.faces.at<int32_t>(i, 1)), *c = m.vertices.ptr<float>(m.faces.at<int32_t>(i, 2));
+            vol += (a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0])) / 6.0;
+        }
+        const double sphere = 4.0 / 3.0 * 3.14159265358979 * 0.7 * 0.7 * 0.7;
+        printf("poissonSurface: %d vertices, %d faces, worst radial error %.4f, volume %.4f (sphere %.4f)\n", m.vertices.rows, m.faces.rows, worst, vol, sphere);
+        CHECK(m.faces.rows > 1000 && worst < 0.02 && std::fabs(vol - sphere) < 0.02 * sphere && hp.alphaVals.back() == 0.25f, "tessellate with the built-in Poisson surface");
     }
     std::ofstream sel(out + "/chosen.txt");
     int mains = 0, pairs = 0;

@@ -92,6 +92,12 @@ ABI = [
     ("mvs_profile_enable", _i, [_vp, _i]),
     ("mvs_profile_read", _i, [_vp, _fp, C.POINTER(_i), _i]),
     ("mvs_device_info", C.c_char_p, [_vp]),
+    ("mvs_poisson_surface", _i, [_vp, _vp, _i, _i, _f, _i, _vp]),
+    ("mvs_surface_counts", _i, [_vp, _vp, _vp]),
+    ("mvs_surface_fetch", _i, [_vp, _vp, _vp]),
+    ("mvs_surface_grid", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mvs_surface_free", None, [_vp]),
+    ("mvs_surface_last_error", C.c_char_p, []),
 ]
 
 _lib = None
@@ -122,6 +128,28 @@ def load_library(path=None):
         lib.mvs_test_rcp.argtypes = [_vp, C.c_uint, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     _lib = lib
     return lib
+
+
+def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0):
+    """poissonSurface (recon.hpp:37) through mvs_poisson_surface: points N x 4 homogeneous, normals N x 3 (out of the solid)
+    -> (vertices V x 4 float32 with w = 1, faces F x 3 int32)"""
+    lib = load_library()
+    pts = np.ascontiguousarray(points, np.float32)
+    nrm = np.ascontiguousarray(normals, np.float32)
+    if pts.ndim != 2 or pts.shape[1] != 4 or nrm.shape != (len(pts), 3):
+        raise ValueError("points must be N x 4 and normals N x 3")
+    s = C.c_void_p()
+    if lib.mvs_poisson_surface(pts.ctypes.data_as(_vp), nrm.ctypes.data_as(_vp), len(pts), int(grid_log2), float(smooth_cells), 0, C.byref(s)) != 0:
+        raise MvsError(lib.mvs_surface_last_error().decode())
+    try:
+        nv, nf = C.c_int(), C.c_int()
+        lib.mvs_surface_counts(s, C.byref(nv), C.byref(nf))
+        v = np.zeros((nv.value, 4), np.float32)
+        f = np.zeros((nf.value, 3), np.int32)
+        lib.mvs_surface_fetch(s, v.ctypes.data_as(_vp), f.ctypes.data_as(_vp))
+    finally:
+        lib.mvs_surface_free(s)
+    return v, f
 
 
 def _f32(a, shape=None):

@@ -1,0 +1,244 @@
+"""CPU restatements for the surface-meshing row.  TEST INFRASTRUCTURE ONLY: imported by tests/ alone.
+
+alpha_shape(points): alphaShapeFaces (alpha_shapes.cpp:36-99 of the reference) from CGAL's published definitions, with the Delaunay
+triangulation taken from scipy (Qhull) -- an implementation independent of host/alpha_shapes.cpp's own triangulator:
+    REGULARIZED alpha complex: a finite cell is interior iff squared circumradius <= alpha; a facet is REGULAR iff exactly one of its
+    cells is interior; find_optimal_alpha(1) as CGAL's Alpha_shape_3.h states it (see host/alpha_shapes.cpp's header).
+poisson(points, normals, G, smooth): csrc/poisson.hip's grid Poisson reconstruction in float64 numpy (same box, same fixed-point
+splat, numpy FFT, same surface-nets rules).
+PARITY UNPINNED against the reference: CGAL / PCL are third-party packages that are neither in this image nor vendored by the
+reference, and the reference holds no golden output for either function (its TEST_BUILD mains read test/bunny_5000, not shipped)."""
+import numpy as np
+
+
+def squared_circumradius(p, q, r, s):
+    """CGAL's squared_radiusC3, float64, vectorised over rows."""
+    qp, rp, sp = q - p, r - p, s - p
+    qp2, rp2, sp2 = (qp * qp).sum(1), (rp * rp).sum(1), (sp * sp).sum(1)
+
+    def det3(a, b, c):
+        return (a[:, 0] * (b[:, 1] * c[:, 2] - b[:, 2] * c[:, 1]) - a[:, 1] * (b[:, 0] * c[:, 2] - b[:, 2] * c[:, 0]) + a[:, 2] * (b[:, 0] * c[:, 1] - b[:, 1] * c[:, 0]))
+
+    def rows(c0, c1):
+        return [np.stack([m[:, c0], m[:, c1], m2], 1) for m, m2 in ((qp, qp2), (rp, rp2), (sp, sp2))]
+
+    num_x = det3(*rows(1, 2))
+    num_y = det3(*rows(0, 2))
+    num_z = det3(*rows(0, 1))
+    den = det3(qp, rp, sp)
+    return (num_x ** 2 + num_y ** 2 + num_z ** 2) / (4.0 * den * den)
+
+
+def alpha_shape(points, forced_alpha=0.0):
+    """-> (faces F x 3 of input row indices, normals out of the solid; alpha; solid components; cells)"""
+    from scipy.spatial import Delaunay
+    pts = np.asarray(points, np.float32)
+    if pts.shape[1] == 4:
+        pts = (pts[:, :3] / pts[:, 3:4]).astype(np.float32)
+    xyz = pts.astype(np.float64)
+    uniq, inverse = np.unique(xyz, axis=0, return_inverse=True)
+    row_of = np.zeros(len(uniq), np.int64)
+    row_of[inverse.ravel()] = np.arange(len(xyz))        # the last row with those coordinates wins (alpha_shapes.cpp:49)
+    tri = Delaunay(uniq, qhull_options="Qt Qbb Qc")
+    cells = tri.simplices
+    nb = tri.neighbors                                     # -1: beyond the hull
+    a = squared_circumradius(*(uniq[cells[:, k]] for k in range(4)))
+    vmin = np.full(len(uniq), np.inf)
+    for k in range(4):
+        np.minimum.at(vmin, cells[:, k], a)
+    alpha_solid = vmin.max()
+    spectrum = np.unique(a[a > 0])
+
+    def components(alpha):
+        inside = a <= alpha
+        seen = np.zeros(len(cells), bool)
+        count = 0
+        for c in np.flatnonzero(inside):
+            if seen[c]:
+                continue
+            count += 1
+            stack = [c]
+            seen[c] = True
+            while stack:
+                x = stack.pop()
+                for y in nb[x]:
+                    if y >= 0 and inside[y] and not seen[y]:
+                        seen[y] = True
+                        stack.append(y)
+        return count
+
+    first = int(np.searchsorted(spectrum, alpha_solid, side="left"))
+    first = min(first, len(spectrum) - 1)
+    if components(alpha_solid) != 1:
+        length = len(spectrum) - first - 1
+        while length > 0:
+            half = length // 2
+            middle = first + half
+            if components(spectrum[middle]) > 1:
+                first = middle + 1
+                length = length - half - 1
+            else:
+                length = half
+    opt = first + 1 if first + 1 < len(spectrum) else first
+    alpha_opt = spectrum[opt]
+    alpha = forced_alpha if forced_alpha > 0 else alpha_opt
+    inside = a <= alpha
+    faces = []
+    for c in np.flatnonzero(inside):
+        for i in range(4):
+            y = nb[c, i]
+            if y >= 0 and inside[y]:
+                continue
+            f = [cells[c, k] for k in range(4) if k != i]
+            p0, p1, p2, pv = uniq[f[0]], uniq[f[1]], uniq[f[2]], uniq[cells[c, i]]
+            if np.dot(np.cross(p1 - p0, p2 - p0), pv - p0) > 0:
+                f[1], f[2] = f[2], f[1]
+            faces.append([row_of[f[0]], row_of[f[1]], row_of[f[2]]])
+    return np.array(faces, np.int32).reshape(-1, 3), float(np.float32(alpha_opt)), components(alpha), row_of[cells]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# grid Poisson reconstruction (csrc/poisson.hip)
+SPLAT_SCALE = np.float32(65536.0)
+
+
+def poisson_grid(points, grid_log2):
+    """the box and grid csrc/poisson.hip chooses: (G, origin float32[3], h float32)"""
+    p = np.asarray(points, np.float32)
+    xyz = (p[:, :3] / p[:, 3:4]).astype(np.float64)
+    lo, hi = xyz.min(0), xyz.max(0)
+    side = float((hi - lo).max())
+    n = len(p)
+    lg = grid_log2
+    if lg == 0:
+        want = np.sqrt(float(n))
+        lg = 5
+        while lg < 8 and float(1 << lg) < want:
+            lg += 1
+    G = 1 << lg
+    box = 1.5 * side
+    h = np.float32(box / float(G - 1))
+    origin = (0.5 * (lo + hi) - 0.5 * box).astype(np.float32)
+    return G, origin, h
+
+
+def poisson_splat(points, normals, G, origin, h):
+    """the four fixed-point fields [vx, vy, vz, weight][z][y][x], int32: the same integers as splat_kernel (float32 arithmetic in its order)"""
+    p = np.asarray(points, np.float32)
+    nrm = np.asarray(normals, np.float32)
+    g = ((p[:, :3] / p[:, 3:4]) - origin[None, :]) / h                     # float32 throughout
+    f = np.floor(g)
+    ijk = f.astype(np.int64)
+    ok = np.all((ijk >= 0) & (ijk + 1 < G), axis=1)
+    t = (g - f).astype(np.float32)
+    out = np.zeros((4, G, G, G), np.int64)
+    one = np.float32(1.0)
+    for c in range(8):
+        d = np.array([c & 1, (c >> 1) & 1, c >> 2])
+        w = np.ones(len(p), np.float32)
+        for a in range(3):
+            w = (w * (t[:, a] if d[a] else (one - t[:, a]))).astype(np.float32) if a else (t[:, a] if d[a] else (one - t[:, a])).astype(np.float32)
+        q = ijk + d[None, :]
+        for ch in range(3):
+            val = np.rint((nrm[:, ch] * w).astype(np.float32) * SPLAT_SCALE).astype(np.int64)
+            np.add.at(out[ch], (q[ok, 2], q[ok, 1], q[ok, 0]), val[ok])
+        np.add.at(out[3], (q[ok, 2], q[ok, 1], q[ok, 0]), np.rint(w * SPLAT_SCALE).astype(np.int64)[ok])
+    return out.astype(np.int32)
+
+
+def poisson_chi(splat, smooth):
+    """laplace(chi) = div V in the Fourier domain, float64: chi^ = -i k.V^ / |k|^2 exp(-sigma^2 |k|^2 / 2)"""
+    G = splat.shape[1]
+    V = splat[:3].astype(np.float64) / 65536.0
+    f = np.fft.fftfreq(G, 1.0 / G)
+    f[np.abs(f) * 2 == G] = 0.0
+    k = 2.0 * np.pi * f / G
+    fr = np.arange(G // 2 + 1, dtype=np.float64)
+    fr[fr * 2 == G] = 0.0
+    kx = (2.0 * np.pi * fr / G)[None, None, :]
+    ky = k[None, :, None]
+    kz = k[:, None, None]
+    k2 = kx * kx + ky * ky + kz * kz
+    S = [np.fft.rfftn(V[c]) for c in range(3)]
+    dot = kx * S[0] + ky * S[1] + kz * S[2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        chi_hat = np.where(k2 > 0, -1j * dot * np.exp(-0.5 * smooth * smooth * k2) / k2, 0.0)
+    return np.fft.irfftn(chi_hat, s=(G, G, G), axes=(0, 1, 2))
+
+
+def trilinear(field, G, origin, h, xyz):
+    g = (np.asarray(xyz, np.float64) - origin[None, :].astype(np.float64)) / float(h)
+    ijk = np.clip(np.floor(g).astype(np.int64), 0, G - 2)
+    t = g - ijk
+    acc = np.zeros(len(g))
+    for c in range(8):
+        d = np.array([c & 1, (c >> 1) & 1, c >> 2])
+        w = np.prod(np.where(d[None, :] == 1, t, 1.0 - t), axis=1)
+        q = ijk + d[None, :]
+        acc += w * field[q[:, 2], q[:, 1], q[:, 0]]
+    return acc
+
+
+def surface_nets(chi, iso, origin, h):
+    """csrc/poisson.hip's meshing rules on a given field: (vertices V x 4 float32, faces F x 3 int32), numbered in its order"""
+    chi = np.asarray(chi, np.float32)
+    iso = np.float32(iso)
+    G = chi.shape[0]
+    C = G - 1
+    inside = chi < iso                                              # [z][y][x]
+    corners = [(c & 1, (c >> 1) & 1, c >> 2) for c in range(8)]
+    cnt = np.zeros((C, C, C), np.int32)
+    for (dx, dy, dz) in corners:
+        cnt += inside[dz:dz + C, dy:dy + C, dx:dx + C]
+    mixed = (cnt != 0) & (cnt != 8)
+    index = np.full((C, C, C), -1, np.int64)
+    index[mixed] = np.arange(int(mixed.sum()))                       # C order = k, j, i with i fastest: the kernel's cell order
+    kk, jj, ii = np.nonzero(mixed)
+    v = [chi[kk + dz, jj + dy, ii + dx] - iso for (dx, dy, dz) in corners]
+    ea = [0, 2, 4, 6, 0, 1, 4, 5, 0, 1, 2, 3]
+    eb = [1, 3, 5, 7, 2, 3, 6, 7, 4, 5, 6, 7]
+    s = np.zeros((3, len(kk)), np.float32)
+    m = np.zeros(len(kk), np.int32)
+    for a, b in zip(ea, eb):
+        va, vb = v[a], v[b]
+        cross = (va < 0) != (vb < 0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (va / (va - vb)).astype(np.float32)
+        for axis in range(3):
+            ca, cb = np.float32(corners[a][axis]), np.float32(corners[b][axis])
+            s[axis] = np.where(cross, (s[axis] + (ca + t * (cb - ca)).astype(np.float32)).astype(np.float32), s[axis])
+        m += cross
+    inv = (np.float32(1.0) / m.astype(np.float32)).astype(np.float32)
+    verts = np.ones((len(kk), 4), np.float32)
+    for axis, base in enumerate((ii, jj, kk)):
+        verts[:, axis] = origin[axis] + np.float32(h) * (base.astype(np.float32) + (s[axis] * inv).astype(np.float32)).astype(np.float32)
+    faces = []
+    du, dw = [-1, 0, 0, -1], [-1, -1, 0, 0]
+    for axis in range(3):
+        # node (i, j, k) -> its +axis neighbour; the kernel numbers edges axis-major, then k, j, i
+        a = inside
+        b = np.roll(inside, -1, axis=2 - axis)
+        state = np.where(a == b, 0, np.where(a, 1, 2))
+        k, j, i = np.meshgrid(np.arange(G), np.arange(G), np.arange(G), indexing="ij")
+        along = (i, j, k)[axis]
+        u = (j, k, i)[axis]
+        w = (k, i, j)[axis]
+        valid = (along + 1 <= C) & (u >= 1) & (u <= C - 1) & (w >= 1) & (w <= C - 1) & (state != 0)
+        ek, ej, ei = np.nonzero(valid)
+        st = state[ek, ej, ei]
+        quad = np.zeros((len(ek), 4), np.int64)
+        for c in range(4):
+            ci, cj, ck = ei.copy(), ej.copy(), ek.copy()
+            if axis == 0:
+                cj += du[c]; ck += dw[c]
+            elif axis == 1:
+                ck += du[c]; ci += dw[c]
+            else:
+                ci += du[c]; cj += dw[c]
+            quad[:, c] = index[ck, cj, ci]
+        flip = st == 2
+        q1 = np.where(flip, quad[:, 3], quad[:, 1])
+        q3 = np.where(flip, quad[:, 1], quad[:, 3])
+        tri = np.stack([quad[:, 0], q1, quad[:, 2], quad[:, 0], quad[:, 2], q3], 1).reshape(-1, 3)
+        faces.append(tri)
+    return verts, np.concatenate(faces).astype(np.int32)
