@@ -106,3 +106,28 @@ def test_tessellate_of_the_cpp_mirror_reaches_it(tmp_path):
     exe = os.path.join(ROOT, "mesh-reconstruction_amd", "bin", "host_selftest")
     r = subprocess.run([exe, "gpu", os.path.join(ROOT, "tests", "data", "tracks"), str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert "gpu selftest: 0 failures" in r.stdout and "poissonSurface:" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_config5_outer_iteration_closes_points_filter_poisson_mesh_render():
+    """recon.cpp:114-136 + 42: the point blocks of a few zatisi main frames -> filterPoints -> poissonSurface -> the mesh the next
+    iteration renders.  (Synthetic frames: the cloud is whatever the flows give; what is checked is that the stages connect --
+    finite vertices, valid indices, a mesh the rasteriser accepts and sees.)"""
+    import c5_common
+    import mvs_amd
+    seq = c5_common.Sequence()
+    with mvs_amd.Context(seq.W, seq.H) as ctx:
+        ctx.load_mesh(seq.verts, seq.faces)
+        blocks = [c5_common.process_main_frame(ctx, seq, f)[2] for f in seq.mains[10:14]]
+        cloud = np.concatenate(blocks)
+        assert len(cloud) > 2000
+        cloud = cloud[::max(1, len(cloud) // 50000)]
+        xyz = cloud[:, :3] / cloud[:, 3:4]
+        extent = float(np.percentile(xyz, 95, axis=0).max() - np.percentile(xyz, 5, axis=0).min())
+        keep = ctx.filter_points(cloud[:, :4], 0.01 * extent)
+        pts, nrm = cloud[keep, :4], cloud[keep, 4:7]
+        assert 0 < len(pts) <= len(cloud)
+        v, f = mvs_amd.poisson_surface(pts, nrm)
+        assert len(v) > 100 and len(f) > 100 and np.isfinite(v).all() and f.min() >= 0 and f.max() < len(v)
+        ctx.load_mesh(v, f)
+        d = ctx.depth(seq.cams[seq.mains[12]])
+        assert (d != mvs_amd.BACKGROUND_DEPTH).any()
