@@ -6,7 +6,7 @@
 // `bundle` + `frames-enabled`), 1-based frame numbers, `skipFrames` re-indexing and `-s` down-scaling of
 // width/height/centre (configuration.cpp:160-165, 186-187, 207-212), and the accessors of recon.hpp:62-69.
 // What is replaced: cv::FileStorage by a reader for exactly that YAML subset (block maps / block sequences /
-// single-line flow sequences / `!!opencv-matrix` with rows, cols, dt, data); cv::VideoCapture by setFrame() or a
+// single-line flow sequences / `!!opencv-matrix` with rows, cols, dt, data); cv::VideoCapture by an uncompressed YUV4MPEG2 stream (readY4m), setFrame() or a
 // directory of binary PGM files `<clip path>.frames/%06d.pgm` (the clips are absent from the reference checkout:
 // .MISSING_LARGE_BLOBS) or binary PPM files `%06d.ppm` for colour; exit(1) by exceptions.  estimateExposure
 // (configuration.cpp:270-426, option -e) is a one-time host stage over the sparse bundle points and runs here on the host
@@ -197,6 +197,67 @@ bool readPpm(const std::string &path, int w, int h, Mat &out)
     return (bool)f;
 }
 
+// Uncompressed video: a YUV4MPEG2 stream (`ffmpeg -i clip.mkv clip.mkv.y4m`; 8-bit C420* / C422 / C444 / Cmono) read frame by frame the
+// way configuration.cpp:228-238 reads the clip: frame fi * skipFrames of the stream becomes tracked frame fi, the ones between are
+// skipped.  A decoder hands cv::VideoCapture B G R pixels: Y'CbCr -> R'G'B' here is ITU-R BT.601 limited range in 16.16 fixed point
+// with the chroma sample that covers the pixel (no chroma interpolation) -- FFmpeg's swscale output differs by its chroma filter; the
+// reference does not pin a decoder either.  Returns false when `path` is not such a stream.
+bool readY4m(const std::string &path, int skipFrames, int count, std::vector<Mat> &bgr)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::string header;
+    std::getline(f, header);
+    if (header.compare(0, 10, "YUV4MPEG2 ") != 0) return false;
+    int w = 0, h = 0, cw = 2, ch = 2;  // chroma subsampling factors; 0 = no chroma planes
+    std::istringstream tags(header.substr(10));
+    std::string tag;
+    while (tags >> tag) {
+        if (tag[0] == 'W') w = atoi(tag.c_str() + 1);
+        else if (tag[0] == 'H') h = atoi(tag.c_str() + 1);
+        else if (tag[0] == 'C') {
+            const std::string c = tag.substr(1);
+            if (c.compare(0, 3, "420") == 0) cw = 2, ch = 2;
+            else if (c == "422") cw = 2, ch = 1;
+            else if (c == "444") cw = 1, ch = 1;
+            else if (c == "mono") cw = 0, ch = 0;
+            else throw std::runtime_error("clip " + path + ": unsupported YUV4MPEG2 colour space " + c + " (8-bit 420 / 422 / 444 / mono only)");
+        }
+    }
+    if (w < 1 || h < 1) throw std::runtime_error("clip " + path + ": YUV4MPEG2 header without a size");
+    const size_t cpw = cw ? (size_t)(w + cw - 1) / cw : 0, cph = ch ? (size_t)(h + ch - 1) / ch : 0;
+    std::vector<uint8_t> Y((size_t)w * h), U(cpw * cph), V(cpw * cph);
+    bgr.assign(count, Mat());
+    int next = 0;  // tracked frame waiting for stream frame next * skipFrames
+    for (int si = 0; next < count; si++) {
+        std::string fh;
+        if (!std::getline(f, fh)) break;  // a clip shorter than the tracks: the remaining frames stay empty (frame() says so when asked)
+        if (fh.compare(0, 5, "FRAME") != 0) throw std::runtime_error("clip " + path + ": expected a FRAME marker");
+        f.read((char *)Y.data(), (std::streamsize)Y.size());
+        if (cw) {
+            f.read((char *)U.data(), (std::streamsize)U.size());
+            f.read((char *)V.data(), (std::streamsize)V.size());
+        }
+        if (!f) throw std::runtime_error("clip " + path + ": truncated frame");
+        if (si != next * skipFrames) continue;
+        Mat m(h, w, mvs::U8C3);
+        for (int y = 0; y < h; y++) {
+            uint8_t *row = m.ptr<uint8_t>(y);
+            for (int x = 0; x < w; x++) {
+                const int c = 298 * ((int)Y[(size_t)y * w + x] - 16);
+                int d = 0, e = 0;
+                if (cw) d = (int)U[(size_t)(y / ch) * cpw + x / cw] - 128, e = (int)V[(size_t)(y / ch) * cpw + x / cw] - 128;
+                auto clip8 = [](int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+                row[3 * x + 2] = clip8((c + 409 * e + 128) >> 8);            // R
+                row[3 * x + 1] = clip8((c - 100 * d - 208 * e + 128) >> 8);  // G
+                row[3 * x + 0] = clip8((c + 516 * d + 128) >> 8);            // B
+            }
+        }
+        bgr[next++] = m;
+    }
+    return true;
+}
+
 // cv::cvtColor(BGR2GRAY) for 8-bit images: fixed point, 14 fractional bits (OpenCV 3.x color.cpp: R 4899, G 9617, B 1868)
 Mat bgrToGray(const Mat &bgr)
 {
@@ -356,7 +417,15 @@ void Configuration::parseYaml(const std::string &path)
     colorFrames.assign(trackedFrameCount, Mat());
     // frames: optional directory of PGMs (grey) or PPMs (colour) next to the clip (stands in for cv::VideoCapture,
     // configuration.cpp:169-238)
+    {
+        // the clip itself if it is an uncompressed YUV4MPEG2 stream, or one next to it (`<clip>.y4m`)
+        std::vector<Mat> decoded;
+        if (readY4m(clipPath, (int)skipFrames, trackedFrameCount, decoded) || readY4m(clipPath + ".y4m", (int)skipFrames, trackedFrameCount, decoded))
+            for (int fi = 0; fi < trackedFrameCount; fi++)
+                if (!decoded[fi].empty()) colorFrames[fi] = (decoded[fi].cols != width || decoded[fi].rows != height) ? resizedToClipSize(decoded[fi]) : decoded[fi];
+    }
     for (int fi = 0; fi < trackedFrameCount; fi++) {
+        if (!colorFrames[fi].empty()) continue;
         char name[64];
         snprintf(name, sizeof(name), "/%06d.pgm", fi * (int)skipFrames + 1);
         Mat g;

@@ -354,6 +354,23 @@ static int run_exposure(const std::string &yaml, const std::string &out)
     return 0;
 }
 
+// host_selftest frames <tracks yaml> <out dir> [skip]: the grey frames Configuration ends up with (clip decoding -> resize -> BGR2GRAY)
+static int run_frames(const std::string &yaml, const std::string &out, int skip)
+{
+    Configuration config(yaml, skip);
+    int have = 0;
+    for (int i = 0; i < config.frameCount(); i++) {
+        Mat g;
+        try { g = config.frame(i); } catch (const std::exception &) { continue; }
+        char name[64];
+        snprintf(name, sizeof(name), "/gray_%03d.u8", i);
+        writeRaw(out + name, g);
+        have++;
+    }
+    printf("frames selftest: %d of %d frames, %d x %d\n", have, config.frameCount(), config.width, config.height);
+    return 0;
+}
+
 // host_selftest choose <tracks yaml> <verts.f32> <faces.i32> <camera threshold> <out.txt> [nodepth]
 // Heuristic::chooseCameras on a mesh from raw files, chosen schedule written as "main: side side ..." lines preceded by the pair
 // count and followed by the generator's state -- compared pair for pair with tests/policy_mirror.py.  With `nodepth` the renderer is
@@ -402,6 +419,7 @@ int main(int argc, char **argv)
 {
     try {
         if (argc >= 4 && !strcmp(argv[1], "exposure")) return run_exposure(argv[2], argv[3]);
+        if (argc >= 4 && !strcmp(argv[1], "frames")) return run_frames(argv[2], argv[3], argc > 4 ? atoi(argv[4]) : 1);
         if (argc >= 7 && !strcmp(argv[1], "choose")) return run_choose(argc, argv);
         if (argc >= 3 && !strcmp(argv[1], "cpu")) return run_cpu(argv[2]);
         if (argc >= 4 && !strcmp(argv[1], "gpu")) return run_gpu(argv[2], argv[3]);

@@ -154,3 +154,10 @@ def test_camera_selection_policy_matches_the_numpy_restatement(tmp_path, name, t
     assert state == rng.state, "the two implementations drew a different number of random values"
     assert (count, chosen) == (m_count, m_chosen)
     assert count >= 1 and all(m not in s for m, s in chosen)
+
+
+def test_uncompressed_clip_is_decoded_and_skipped_like_the_reference(tmp_path, oracle):
+    """Configuration's clip input (configuration.cpp:169-245) from a YUV4MPEG2 stream of the clip's own size (a smaller one is resized
+    on the GPU: tests/test_host_gpu.py)"""
+    import y4m_common
+    y4m_common.run(tmp_path, oracle, scale=1)

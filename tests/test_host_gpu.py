@@ -91,3 +91,9 @@ def test_camera_selection_with_occlusion_matches_the_numpy_restatement(oracle, t
         assert blocked[0] > 0, "this scene is meant to produce look-ups that hit geometry"
     assert state == rng.state
     assert (count, chosen) == (m_count, m_chosen)
+
+
+def test_a_clip_of_another_size_is_resized_on_the_way_in(oracle, tmp_path):
+    """configuration.cpp:232-233 (cv::resize of every decoded frame that is not the clip's size) behind the YUV4MPEG2 reader"""
+    import y4m_common
+    y4m_common.run(tmp_path, oracle, scale=2)
