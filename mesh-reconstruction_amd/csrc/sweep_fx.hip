@@ -381,6 +381,9 @@ __device__ __forceinline__ void sample_range_fx_checked(const Affine &A, float b
 // (19.0 vs 14.6 ns per wave-sample, tools/sweep_v2_probe.hip).
 // Timing experiments (tools/exp_fx.py, tools/fx_sections.py) are compiled in with -DMVS_FX_EXPERIMENTS only: even never-taken
 // branches on p.debug change register allocation enough to cost the production kernel a few per cent.
+#ifndef MVS_FX_CUT
+#define MVS_FX_CUT 0  // timing experiments WITHOUT instrumentation (tools/build_variant.sh cutNN "-DMVS_FX_CUT=NN" csrc/sweep_fx.hip): 1 no copies, 32 no sample loop, 64 no per-view barrier, 128 no chunk epilogue -- wrong results
+#endif
 #ifdef MVS_FX_EXPERIMENTS
 #define FX_PROF_DECL unsigned long long pt_prev = 0, pt_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_iter = 0, pt_chunks = 0; const bool pt_on = p.plan_stats != nullptr && threadIdx.x < 64
 #define FX_PROF_START() do { if (pt_on) pt_prev = __builtin_amdgcn_s_memtime(); } while (0)
@@ -463,6 +466,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
         for (int j = 0; j < NPX; j++)
 #pragma unroll
             for (int k = 0; k < PC; k++) acc[j][k] = 0u;
+        uint32_t row_checked = 0u;      // bit j: some view of this chunk took the per-sample in-frame test for row j of this wavefront (wave-uniform)
         uint32_t fast_views = 0u;       // views whose whole (tile, chunk) region is in frame: one count for every cell
         uint32_t lane_views[NPX];       // views of a BORDER region in which this pixel's whole plane range is in frame
 #pragma unroll
@@ -507,6 +511,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
             FX_PROF_MARK(0);
 #endif
             if (__builtin_expect(mode == FX_GENERIC, 0)) {
+                row_checked = ~0u;  // (its samples carry their own counts)
                 const uint32_t *qv = p.quads + p.pad_slab * (size_t)__builtin_amdgcn_readfirstlane((int)(desc.y >> 19));
 #pragma unroll
                 for (int j = 0; j < NPX; j++) {
@@ -528,6 +533,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
 #ifdef MVS_FX_EXPERIMENTS
                 if (!(p.debug & 1))  // timing experiment only: no copies
 #endif
+                if (!(MVS_FX_CUT & 1))
                 stage_region_fx(p.quads + p.pad_slab * (size_t)__builtin_amdgcn_readfirstlane((int)(desc.y >> 19)), p.pitch, x0, y0, rw, rh, qcol, lds);
             }
 #ifdef MVS_FX_EXPERIMENTS
@@ -535,6 +541,9 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // timing experiment only (racy): what the per-view barrier costs
             else
 #endif
+            if (MVS_FX_CUT & 64)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else
             __syncthreads();  // this view's region has landed (the barrier drains vmcnt) and the previous one is no longer read
             // Request the next staged view's region into the other half of the rows, if both regions are at most FX_HALF_COL quads
             // wide: its copy (L2 / Infinity Cache latency, 1-2 us) then overlaps this view's sampling (0.5 us of work for the
@@ -550,6 +559,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
 #ifdef MVS_FX_EXPERIMENTS
                     if (!(p.debug & 1))
 #endif
+                    if (!(MVS_FX_CUT & 1))
                         stage_region_fx(p.quads + p.pad_slab * (size_t)__builtin_amdgcn_readfirstlane((int)(dnext.y >> 19)), p.pitch, __builtin_amdgcn_readfirstlane((int)(dnext.x & 0xffffu)),
                                         __builtin_amdgcn_readfirstlane((int)(dnext.x >> 16)), rwn, __builtin_amdgcn_readfirstlane((int)((dnext.y >> 8) & 0xffu)), nqcol, lds);
                     ahead = true;
@@ -586,6 +596,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
                     checked = __builtin_amdgcn_ballot_w64(!inside && ok[j]) != 0ull;
                 }
                 if (checked) {
+                    row_checked |= 1u << j;
                     if (ok[j]) sample_range_fx_checked<0, PC>(A, bx, by, bw, zc, rg, lds, Im255[j], acc[j]);
                     continue;
                 }
@@ -598,6 +609,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
 #ifdef MVS_FX_EXPERIMENTS
                 if (p.debug & 32) continue;  // timing experiment only: everything but the sample loop
 #endif
+                if (MVS_FX_CUT & 32) continue;
                 __builtin_amdgcn_s_setprio(0);
                 if (j == 0) FX_PROF_MARK(3);
                 if (wconst) {
@@ -622,6 +634,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
         if (p.debug & 128) continue;  // timing experiment only: no chunk epilogue
         FX_PROF_START();
 #endif
+        if (MVS_FX_CUT & 128) continue;
         uint32_t *const vol_chunk = WRITE_VOLUME ? p.volume + (size_t)d0 * P : nullptr;
         const bool whole = d0 + PC <= p.D;  // uniform: every plane of the chunk exists
         // the chunk's 16 planes as one buffer resource (plane k at byte offset 4 P k: below 2^32 for frames up to 8192^2; larger frames
@@ -642,19 +655,42 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
                 }
                 const uint32_t views = fast_views + lane_views[j];
                 if (whole) {
+                    // (the store form is decided ONCE per row: inside the plane loop the compiler kept both forms and a branch per store)
+                    if (WRITE_VOLUME) {  // non-temporal: written once, read by a later kernel: keep it out of the L2 the quad images live in
+                        if (vol_rsrc) {
 #pragma unroll
-                    for (int k = 0; k < PC; k++) {
-                        const uint32_t cell = acc[j][k] + views;
-                        if (WRITE_VOLUME) {  // non-temporal: written once, read by a later kernel: keep it out of the L2 the quad images live in
-                            if (vol_rsrc)
-                                __builtin_amdgcn_raw_buffer_store_b32(cell, rvol, 4u * pix, plane_bytes * (uint32_t)k, 2);
-                            else
-                                __builtin_nontemporal_store(cell, vol_chunk + (size_t)k * P + pix);
+                            for (int k = 0; k < PC; k++) __builtin_amdgcn_raw_buffer_store_b32(acc[j][k] + views, rvol, 4u * pix, plane_bytes * (uint32_t)k, 2);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < PC; k++) __builtin_nontemporal_store(acc[j][k] + views, vol_chunk + (size_t)k * P + pix);
                         }
-                        if (FUSED) {
+                    }
+                    if (FUSED) {
+                        if (!((row_checked >> j) & 1u)) {
+                            // No view of this chunk tested this row's samples one by one: every accumulator is a bare sum (count field 0) and
+                            // all 16 cells of a pixel get the same count `views`, so inside the chunk they compare like their sums.  With the
+                            // plane in the low byte one v_min per cell keeps the lowest sum and, among equal sums, the lowest plane -- what
+                            // the cross-multiplied comparison, strict and in plane order, decides; it is then needed once per chunk, not
+                            // once per cell (2 instructions per cell instead of 6, and no 16-deep dependent chain).
+                            uint32_t key[PC];
+#pragma unroll
+                            for (int k = 0; k < PC; k++) key[k] = (acc[j][k] << 8) | (uint32_t)k;
+#pragma unroll
+                            for (int w = PC / 2; w >= 1; w >>= 1)
+#pragma unroll
+                                for (int k = 0; k < w; k++) key[k] = min(key[k], key[k + w]);
+                            const uint32_t cell = (key[0] >> 8) + views;
                             const bool better = umul24u(cell & 0xffffffu, best >> 24) < umul24u(best & 0xffffffu, cell >> 24);
                             best = better ? cell : best;
-                            bi = better ? d0 + k : bi;
+                            bi = better ? d0 + (int)(key[0] & 0xffu) : bi;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < PC; k++) {
+                                const uint32_t cell = acc[j][k] + views;
+                                const bool better = umul24u(cell & 0xffffffu, best >> 24) < umul24u(best & 0xffffffu, cell >> 24);
+                                best = better ? cell : best;
+                                bi = better ? d0 + k : bi;
+                            }
                         }
                     }
                 } else {

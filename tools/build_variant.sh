@@ -20,6 +20,6 @@ for o in build/*.o; do
     fi
 done
 mkdir -p lib/variants
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "lib/variants/libmvs_hip_$tag.so" $objs -ldl -lpthread
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "lib/variants/libmvs_hip_$tag.so" $objs -L/opt/rocm/lib -lhipfft -Wl,-rpath,/opt/rocm/lib -ldl -lpthread
 rm -rf "$tmp"
 echo "lib/variants/libmvs_hip_$tag.so"
