@@ -62,6 +62,7 @@ struct mvs_ctx {
     // rectified fast path of the fixed sampler (sweep_rect.hip): per (tile column | tile row, view, plane) texel + phase + certificates
     mvs::DevBuf rect_tab;
     bool rect_ok = false;            // the current plan can be served by sweep_fx_rect
+    bool fx_general_planned = false; // the general tiled kernel's plan exists for the current (views, planes) (made on demand when rect_ok)
     int rect_rs = 0, rect_slot_dw = 0, rect_dpad = 0;
     std::vector<unsigned char> rect_cold_host;  // host copy of the kernel's cold block (sweep_rect.hip: RectCold)
     bool rect_cold_sent = false;

@@ -104,9 +104,9 @@ __global__ __launch_bounds__(256) void sweep_generic(SweepParams p)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void plan_regions(SweepParams p, uint2 *__restrict__ plan)
 {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = p.tiles_x * p.tiles_y * p.nchunks * p.V;
-    if (tid >= total) return;
+    const bool live = (int)(blockIdx.x * blockDim.x + threadIdx.x) < total;  // (no early return: the counters are reduced per wavefront)
+    const int tid = min((int)(blockIdx.x * blockDim.x + threadIdx.x), total - 1);
     const int v = tid % p.V;
     const int rest = tid / p.V;
     const int chunk = rest % p.nchunks;
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void plan_regions(SweepParams p, uint2 *__rest
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int c0 = tx * TILE_W, c1 = min(c0 + TILE_W, p.W) - 1;
     const int r0 = ty * p.tile_h, r1 = min(r0 + p.tile_h, p.H) - 1;
+    int too_large = 0;
     const int d0 = chunk * p.pc, d1 = min(d0 + p.pc, p.D) - 1;
     const float *q = p.Q + 12 * v;
     const float bx = q[2], by = q[6], bw = q[10];
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void plan_regions(SweepParams p, uint2 *__rest
         pitch = (rw + 31) & ~31;
         if (rw > MAX_RW || rw <= 0 || rh <= 0 || pitch * rh > LDS_QUADS) {
             mode = R_GENERIC;
-            atomicAdd(p.plan_stats, 1);
+            too_large = 1;
         } else if (xmin > 0.5f + m && xmax < p.Wp - m && ymin > 0.5f + m && ymax < p.Hp - m)
             mode = R_FAST;
         else
@@ -165,8 +166,12 @@ __global__ __launch_bounds__(256) void plan_regions(SweepParams p, uint2 *__rest
     uint2 d;
     d.x = (unsigned)x0 | ((unsigned)y0 << 16);
     d.y = (unsigned)rw | ((unsigned)rh << 8) | (mode << 16) | ((unsigned)(pitch >> 5) << 24);
-    plan[tid] = d;
-    if (mode != R_SKIP) atomicAdd(p.plan_stats + 1, 1);
+    if (live) plan[tid] = d;
+    const int n_large = wave_sum_i32(live ? too_large : 0), n_regions = wave_sum_i32(live && mode != R_SKIP ? 1 : 0);  // one atomic per wavefront, not per thread
+    if ((threadIdx.x & 63) == 0) {
+        if (n_large) atomicAdd(p.plan_stats, n_large);
+        if (n_regions) atomicAdd(p.plan_stats + 1, n_regions);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -709,6 +714,7 @@ __global__ void rcp_check_kernel(uint32_t exp_bits, unsigned long long *out)
 
 // sweep_fx.hip: the fixed-point sampler (contract v2)
 int sweep_fx_plan(mvs_ctx *ctx);
+int sweep_fx_plan_general(mvs_ctx *ctx);
 int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool generic, unsigned flags);
 int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsigned flags);
 int warp_by_depth_fx_launch(mvs_ctx *ctx, const float *depth_dev, const float *q_dev, const uint8_t *pad_dev, int pitch, uint8_t *out2_dev);
@@ -851,6 +857,12 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
             ctx->plan_shape = 3;
             ctx->plan_valid = true;
         }
+        // (a run over zero views writes empty cells: the general kernel's job -- the rectified one iterates over regions)
+        const bool rect = ctx->rect_ok && !generic && ctx->V > 0 && view_count > 0 && !(flags & MVS_SWEEP_NO_RECT);
+        if (!rect && !generic && ctx->V > 0 && !ctx->fx_general_planned) {  // left out while the rectified kernel served the plan; before
+            ProfileScope pp(ctx, MVS_K_PLAN);                               // fill_params: it may (re)allocate the plan
+            if ((rc = sweep_fx_plan_general(ctx))) return rc;
+        }
         SweepParams p;
         fill_params(ctx, p, view_first, view_count, 8, 16);
         p.debug = debug;
@@ -863,8 +875,6 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
         p.plane_begin = plane_first;
         p.plane_end = min(ctx->D, plane_first + plane_count);
         ProfileScope ps(ctx, MVS_K_SWEEP);
-        // (a run over zero views writes empty cells: the general kernel's job -- the rectified one iterates over regions)
-        const bool rect = ctx->rect_ok && !generic && ctx->V > 0 && view_count > 0 && !(flags & MVS_SWEEP_NO_RECT);
         const int nsplit = rect ? sweep_rect_launch(ctx, p, vol, fused, flags) : sweep_fx_launch(ctx, p, vol, fused, generic, flags);
         if (nsplit < 0) return nsplit;
         if (p.part) {

@@ -150,9 +150,9 @@ __device__ __forceinline__ SweepParams load_params(const SweepParams *src)
 // store when the views are given by slots, mvs_sweep_batch)
 __device__ __forceinline__ void plan_regions_fx_body(const SweepParams &p, uint2 *__restrict__ plan)
 {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = p.tiles_x * p.tiles_y * p.nchunks * p.V;
-    if (tid >= total) return;
+    const bool live = (int)(blockIdx.x * blockDim.x + threadIdx.x) < total;  // (no early return: the counters below are reduced per wavefront)
+    const int tid = min((int)(blockIdx.x * blockDim.x + threadIdx.x), total - 1);
     const int v = tid % p.V;
     const int rest = tid / p.V;
     const int chunk = rest % p.nchunks;
@@ -186,6 +186,7 @@ __device__ __forceinline__ void plan_regions_fx_body(const SweepParams &p, uint2
     }
     unsigned mode;
     int x0 = 0, y0 = 0, rw = 0, rh = 0;
+    int too_large = 0, staged_w = 0, staged_h = 0;
     // the sampled position is (256 c + 4 +- 1/2) / 256 <= c + 0.018: covered by the margin like the f32 rounding of c itself
     const float m = PLAN_MARGIN;
     if (behind || !(xmin == xmin) || !(ymin == ymin) || !(xmax < 1.0e9f) || !(ymax < 1.0e9f) || !(xmin > -1.0e9f) || !(ymin > -1.0e9f)) {
@@ -201,20 +202,27 @@ __device__ __forceinline__ void plan_regions_fx_body(const SweepParams &p, uint2
         rh = y1 - y0 + 1;
         if (rw > FX_MAX_RW || rw <= 0 || rh <= 0 || rh > FX_ROWS) {
             mode = FX_GENERIC;
-            if (p.plan_stats) atomicAdd(p.plan_stats, 1);
+            too_large = 1;
         } else {
             mode = (xmin > 0.5f + m && xmax < p.Wp - m && ymin > 0.5f + m && ymax < p.Hp - m) ? FX_FAST : FX_BORDER;
-            if (p.plan_stats) {
-                atomicMax(p.plan_stats + 2, rw);  // largest staged region (diagnostic)
-                atomicMax(p.plan_stats + 3, rh);
-            }
+            staged_w = rw;  // largest staged region (diagnostic)
+            staged_h = rh;
         }
     }
     uint2 d;
     d.x = (unsigned)x0 | ((unsigned)y0 << 16);
     d.y = (unsigned)rw | ((unsigned)rh << 8) | (mode << 16) | ((unsigned)(p.view_slot ? p.view_slot[v] : v) << 19);
-    plan[tid] = d;
-    if (mode != FX_SKIP && p.plan_stats) atomicAdd(p.plan_stats + 1, 1);
+    if (live) plan[tid] = d;
+    if (p.plan_stats) {  // one atomic per wavefront and counter, not one per thread: they all hit the same four addresses
+        const int n_large = wave_sum_i32(live ? too_large : 0), n_regions = wave_sum_i32(live && mode != FX_SKIP ? 1 : 0);
+        const int w_max = wave_max_i32(live ? staged_w : 0), h_max = wave_max_i32(live ? staged_h : 0);
+        if ((threadIdx.x & 63) == 0) {
+            if (n_large) atomicAdd(p.plan_stats, n_large);
+            if (n_regions) atomicAdd(p.plan_stats + 1, n_regions);
+            if (w_max) atomicMax(p.plan_stats + 2, w_max);
+            if (h_max) atomicMax(p.plan_stats + 3, h_max);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void plan_regions_fx(SweepParams p, uint2 *__restrict__ plan) { plan_regions_fx_body(p, plan); }
@@ -860,7 +868,10 @@ int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool gen
     return nsplit;  // > 0: the caller merges the partial bests when p.part is set
 }
 
-int sweep_fx_plan(mvs_ctx *ctx)
+// The plan of the general tiled kernel (one descriptor per (tile, chunk, view)).  When every view is rectified the sweep runs on
+// sweep_fx_rect's own tables and this plan is made only if a launch asks for the general kernel (MVS_SWEEP_NO_RECT, a run over zero
+// views): a third of a millisecond at c3 that the one-call path does not have to wait for.
+int sweep_fx_plan_general(mvs_ctx *ctx)
 {
     int rc;
     if ((rc = ensure(ctx, ctx->plan_stats, 64))) return rc;
@@ -884,7 +895,17 @@ int sweep_fx_plan(mvs_ctx *ctx)
             fclose(f);
         }
     }
-    return sweep_rect_plan(ctx);  // rectified views: tables for sweep_fx_rect (sweep_rect.hip)
+    ctx->fx_general_planned = true;
+    return MVS_OK;
+}
+
+int sweep_fx_plan(mvs_ctx *ctx)
+{
+    ctx->fx_general_planned = false;
+    const int rc = sweep_rect_plan(ctx);  // rectified views: tables for sweep_fx_rect (sweep_rect.hip); sets ctx->rect_ok
+    if (rc) return rc;
+    if (ctx->rect_ok && !getenv("MVS_PLAN_DUMP")) return MVS_OK;
+    return sweep_fx_plan_general(ctx);
 }
 
 int warp_by_depth_fx_launch(mvs_ctx *ctx, const float *depth_dev, const float *q_dev, const uint8_t *pad_dev, int pitch, uint8_t *out2_dev)

@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void plan_rect_box(SweepParams p, RectTables r
 {
     const int NC = p.nchunks, dpad = rt.dpad;
     const int nx = p.tiles_x * p.V * NC, ny = p.tiles_y * p.V * NC;
-    int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= nx + ny) return;
+    const bool live = (int)(blockIdx.x * blockDim.x + threadIdx.x) < nx + ny;  // (no early return: the counters are reduced per wavefront)
+    int tid = min((int)(blockIdx.x * blockDim.x + threadIdx.x), nx + ny - 1);
     const int which = tid < nx ? 0 : 1;
     if (which == 1) tid -= nx;
     const int chunk = tid % NC, v = (tid / NC) % p.V, t = tid / (NC * p.V);
@@ -239,8 +239,13 @@ __global__ __launch_bounds__(256) void plan_rect_box(SweepParams p, RectTables r
     }
     const uint32_t org = any ? (which == 0 ? (lo & ~3u) : lo) : 0u;
     const uint32_t ext = any ? hi + 1u - org : 0u;
-    if (any) atomicMax(rt.stats + which, (int)ext);
-    (which == 0 ? rt.xbox : rt.ybox)[tid] = org | (min(ext, 0x7fffu) << 16) | (any ? 1u << 31 : 0u);
+    // widest / tallest box: one atomic per wavefront (21 000 threads on two addresses took 0.23 ms)
+    const int wx = wave_max_i32(live && any && which == 0 ? (int)ext : 0), wy = wave_max_i32(live && any && which == 1 ? (int)ext : 0);
+    if ((threadIdx.x & 63) == 0) {
+        if (wx) atomicMax(rt.stats + 0, wx);
+        if (wy) atomicMax(rt.stats + 1, wy);
+    }
+    if (live) (which == 0 ? rt.xbox : rt.ybox)[tid] = org | (min(ext, 0x7fffu) << 16) | (any ? 1u << 31 : 0u);
 }
 
 // Pass C (after the host has chosen the row stride RS of the LDS slots from pass B's counters).  One thread per (tile column or
@@ -254,8 +259,8 @@ __global__ __launch_bounds__(256) void plan_rect_pack(SweepParams p, RectTables 
 {
     const int NC = p.nchunks, dpad = rt.dpad;
     const int nx = p.tiles_x * p.V * NC * 4, ny = p.tiles_y * p.V * NC * 4;
-    int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= nx + ny) return;
+    const bool live = (int)(blockIdx.x * blockDim.x + threadIdx.x) < nx + ny;
+    int tid = min((int)(blockIdx.x * blockDim.x + threadIdx.x), nx + ny - 1);
     const int which = tid < nx ? 0 : 1;
     if (which == 1) tid -= nx;
     const int w = tid & 3, chunk = (tid >> 2) % NC, v = ((tid >> 2) / NC) % p.V, t = (tid >> 2) / (NC * p.V);
@@ -264,13 +269,19 @@ __global__ __launch_bounds__(256) void plan_rect_pack(SweepParams p, RectTables 
     const int org = (int)(box & 0xffffu), ext = (int)((box >> 16) & 0x7fffu);
     const bool any = (box >> 31) != 0u;
     uint32_t f[RX_KW];
+    int not_full = 0;
     for (int k = 0; k < RX_KW; k++) {
         const uint32_t e = ent[k];
         const int tex = ((int)(e & 0xfffffu) - RX_BIAS) >> 5;
         const bool full = (e & RX_UNIFORM) && ((e >> 20) & 127u) == 0u && any && tex >= org && tex - org < ext;
         f[k] = full ? (uint32_t)(tex - org) * (which == 0 ? 4u : 4u * (uint32_t)RS) : (which == 0 ? 0x4000u : 0x8000u);
-        if (!full) atomicAdd(rt.stats + 2, 1);
+        not_full += full ? 0 : 1;
     }
+    {
+        const int n = wave_sum_i32(live ? not_full : 0);
+        if ((threadIdx.x & 63) == 0 && n) atomicAdd(rt.stats + 2, n);
+    }
+    if (!live) return;
     if (which == 0) {
         uint32_t *rec = rt.xw + (size_t)tid * 8;
         const uint32_t *wv = rt.wt + (size_t)v * dpad + chunk * RX_PC + w * RX_KW;
