@@ -58,6 +58,7 @@ __global__ void splat_kernel(Grid g, const float *__restrict__ pts, const float 
     if (i < 0 || j < 0 || k < 0 || i + 1 >= g.G || j + 1 >= g.G || k + 1 >= g.G) return;  // (the box is padded: cannot happen for the box's own samples)
     const float tx = gx - fx, ty = gy - fy, tz = gz - fz;
     const float nx = nrm[3 * s], ny = nrm[3 * s + 1], nz = nrm[3 * s + 2];
+    if (!(fabsf(nx) <= 1e6f && fabsf(ny) <= 1e6f && fabsf(nz) <= 1e6f)) return;  // a sample without a usable normal (NaN: util.cpp:299's PCA can fail) votes for nothing
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const int di = c & 1, dj = (c >> 1) & 1, dk = c >> 2;

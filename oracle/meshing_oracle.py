@@ -129,7 +129,7 @@ def poisson_splat(points, normals, G, origin, h):
     g = ((p[:, :3] / p[:, 3:4]) - origin[None, :]) / h                     # float32 throughout
     f = np.floor(g)
     ijk = f.astype(np.int64)
-    ok = np.all((ijk >= 0) & (ijk + 1 < G), axis=1)
+    ok = np.all((ijk >= 0) & (ijk + 1 < G), axis=1) & np.all(np.abs(nrm) <= np.float32(1e6), axis=1)   # (NaN normals fail the comparison too)
     t = (g - f).astype(np.float32)
     out = np.zeros((4, G, G, G), np.int64)
     one = np.float32(1.0)
