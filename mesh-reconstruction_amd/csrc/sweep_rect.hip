@@ -249,12 +249,17 @@ __global__ __launch_bounds__(256) void plan_rect_box(SweepParams p, RectTables r
 }
 
 // Pass C (after the host has chosen the row stride RS of the LDS slots from pass B's counters).  One thread per (tile column or
-// tile row, view, chunk, wavefront): that wavefront's record of the region -- per plane a 16-bit field with the plane's share of
-// the LDS byte offset of its first texel quad (x: 4 (ix - x0); y: 4 RS (iy - y0); their sum stays below 2^14), or a flag (x: bit
-// 14, y: bit 15) = not a FULL plane, look at the full entry.  The sum of an x and a y field is the plane's whole offset, or has a
-// flag bit set; fields do not carry into each other.
-//   X record (8 dwords): x01, x23, W0, W1, W2, W3, 4 x0 | (any ? RS / 4 : 0) << 16, 0
-//   Y record (4 dwords): y01, y23, 4 (pad_slab v + y0 pitch), (any ? rows : 0) | y0 << 8
+// tile row, view, chunk, wavefront): that wavefront's record of the region.  Per plane a 16-bit field with the plane's share of the
+// LDS byte offset of the texel quad of the tile's pixel 0 -- x: 4 (ix - x0 + RX_BIAS_X); y: 4 RS (iy - y0 + RX_BIAS_Y); the biases
+// because pixel 0 of a tile that is partly out of frame lies left of / above the box (the kernel's copies land RX_BIAS bytes into
+// the slot, so base + x share + y share is the quad's address; the sum stays below 2^14) -- or a flag (x: bit 14, y: bit 15) = the
+// certificate failed, look at the full entry.  A plane whose certificate holds but whose tile is partly (MASKED) or wholly (NONE) out
+// of frame has no flag: its out-of-frame pixels come as a mask byte per plane (x: n | side << 7 as in the full entry, n = 64: nothing
+// in frame; y: the bit mask of the rows that are OUT of frame), zero for FULL planes.
+//   X record (8 dwords): x01, x23, W0, W1, W2, W3, 4 x0 | (any ? RS / 4 : 0) << 16, x masks of the four planes
+//   Y record (8 dwords): y01, y23, 4 (pad_slab v + y0 pitch), (any ? rows : 0) | y0 << 8, y masks of the four planes, 0, 0, 0
+constexpr int RX_BIAS_X = 64, RX_BIAS_Y = 8;  // quads / rows
+
 __global__ __launch_bounds__(256) void plan_rect_pack(SweepParams p, RectTables rt, int RS)
 {
     const int NC = p.nchunks, dpad = rt.dpad;
@@ -268,14 +273,30 @@ __global__ __launch_bounds__(256) void plan_rect_pack(SweepParams p, RectTables 
     const uint32_t box = (which == 0 ? rt.xbox : rt.ybox)[tid >> 2];
     const int org = (int)(box & 0xffffu), ext = (int)((box >> 16) & 0x7fffu);
     const bool any = (box >> 31) != 0u;
-    uint32_t f[RX_KW];
+    const int size = which == 0 ? TILE_W : RX_TILE_H;
+    uint32_t f[RX_KW], masks = 0u;
     int not_full = 0;
     for (int k = 0; k < RX_KW; k++) {
         const uint32_t e = ent[k];
         const int tex = ((int)(e & 0xfffffu) - RX_BIAS) >> 5;
-        const bool full = (e & RX_UNIFORM) && ((e >> 20) & 127u) == 0u && any && tex >= org && tex - org < ext;
-        f[k] = full ? (uint32_t)(tex - org) * (which == 0 ? 4u : 4u * (uint32_t)RS) : (which == 0 ? 0x4000u : 0x8000u);
-        not_full += full ? 0 : 1;
+        const int nout = (int)((e >> 20) & 127u), side = (int)((e >> 27) & 1u);
+        const bool nothing = nout >= size || !any;
+        // the in-frame pixels' texels lie inside the box (it is their bounding box); pixel 0's may lie up to `nout` texels before it
+        const int bias = which == 0 ? RX_BIAS_X : RX_BIAS_Y;
+        const int rel = tex - org + bias;
+        const bool certified = (e & RX_UNIFORM) != 0u && (nothing || (rel >= 0 && rel < ext + 2 * bias));
+        if (!certified) {
+            f[k] = which == 0 ? 0x4000u : 0x8000u;
+        } else {
+            f[k] = nothing ? 0u : (uint32_t)rel * (which == 0 ? 4u : 4u * (uint32_t)RS);
+            uint32_t m;
+            if (which == 0)
+                m = nothing ? 64u : (nout == 0 ? 0u : (uint32_t)nout | ((uint32_t)side << 7));
+            else  // rows out of frame: the first `nout` (side 0) or the last `nout` (side 1)
+                m = nothing ? 0xffu : (nout == 0 ? 0u : (side ? (0xffu << (RX_TILE_H - nout)) & 0xffu : (1u << nout) - 1u));
+            masks |= m << (8 * k);
+        }
+        not_full += (!certified || ((masks >> (8 * k)) & 0xffu)) ? 1 : 0;
     }
     {
         const int n = wave_sum_i32(live ? not_full : 0);
@@ -292,13 +313,15 @@ __global__ __launch_bounds__(256) void plan_rect_pack(SweepParams p, RectTables 
         rec[4] = wv[2];
         rec[5] = wv[3];
         rec[6] = 4u * (uint32_t)org | ((any ? (uint32_t)RS / 4u : 0u) << 16);
-        rec[7] = 0u;
+        rec[7] = masks;
     } else {
-        uint32_t *rec = rt.yr + (size_t)tid * 4;
+        uint32_t *rec = rt.yr + (size_t)tid * 8;
         rec[0] = f[0] | (f[1] << 16);
         rec[1] = f[2] | (f[3] << 16);
         rec[2] = 4u * ((uint32_t)p.pad_slab * (uint32_t)v + (uint32_t)(org * p.pitch));
         rec[3] = (any ? (uint32_t)ext : 0u) | ((uint32_t)org << 8);
+        rec[4] = masks;
+        rec[5] = rec[6] = rec[7] = 0u;
     }
 }
 
@@ -328,7 +351,7 @@ struct RectArgs {
     size_t pad_slab;
     int pitch, W, H, D, V, v0, vcount, nchunks, chunk0, chunk1, cps, ty0, tyn, tiles_x;
     int slot_dw;   // dwords per LDS slot = 256 x copy instructions per region (one instruction fills 256 dwords); two slots
-    int debug;     // timing experiments, honoured by builds with -DMVS_RX_EXPERIMENTS only: 1 no copies, 2 no sampling, 4 no barrier, 8 every copy from one box, 16 no epilogue (wrong results)
+    int debug;     // timing experiments, honoured by builds with -DMVS_RX_EXPERIMENTS only: 1 no copies, 2 no sampling, 4 no barrier, 8 every copy from one box, 16 no epilogue, 32 every plane taken for FULL, 64 no masks, 128 no failed-certificate block, 256 the plain comparison throughout (wrong results)
 };
 
 template <typename T>
@@ -338,6 +361,8 @@ __device__ __forceinline__ T cold_get(uintptr_t c, size_t off)
 }
 #ifdef MVS_RX_EXPERIMENTS
 #define RX_DBG(a, bit) (((a).debug & (bit)) != 0)
+#elif defined(MVS_RX_CUT)  // the same experiments decided at compile time (no run-time flag in the code: the production kernel minus the cut)
+#define RX_DBG(a, bit) (((MVS_RX_CUT) & (bit)) != 0)
 #else
 #define RX_DBG(a, bit) false
 #endif
@@ -355,6 +380,7 @@ template <int RS, bool WRITE_VOLUME, bool FUSED>
 __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs a)
 {
     constexpr int UNITS = RS / 4;  // 16-byte units per region row
+    constexpr int SLOT_BIAS_DW = RX_BIAS_X + RX_BIAS_Y * RS;  // dwords
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)smem;  // (through a generic pointer: a null check per use)
 
@@ -389,11 +415,11 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     const int vend = a.v0 + a.vcount;
     const int nreg = (chunk_last - chunk_first) * a.vcount;
 
-    // this wavefront's records of region (chunk, v), e = v NC + chunk: 8 dwords at xw_wg + 128 e bytes, 4 dwords at yr_wg + 64 e bytes;
+    // this wavefront's records of region (chunk, v), e = v NC + chunk: 8 dwords at xw_wg + 128 e bytes, 8 dwords at yr_wg + 128 e bytes;
     // both tables live in one allocation (a.xw < a.yr): one resource, two wave-uniform offsets
     const __amdgpu_buffer_rsrc_t rtab = make_rsrc(a.xw, 0xffffffffu);
     const uint32_t xw_wg = (uint32_t)(((size_t)tx * a.V * NC * 4 + wave) * 32);
-    const uint32_t yr_wg = (uint32_t)((size_t)((const char *)a.yr - (const char *)a.xw) + ((size_t)ty * a.V * NC * 4 + wave) * 16);
+    const uint32_t yr_wg = (uint32_t)((size_t)((const char *)a.yr - (const char *)a.xw) + ((size_t)ty * a.V * NC * 4 + wave) * 32);
     const __amdgpu_buffer_rsrc_t rquads = make_rsrc(a.quads, 0xffffffffu);
 
     // request a region into the slot at LDS dword `slot_dw0`: xsx = X record dword 6 (4 x0 | units per row << 16, 0 units if the box is
@@ -403,7 +429,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
         if (RX_DBG(a, 1)) return;
         const int n = (int)((yn & 0xffu) * (xsx >> 16));
         const uint32_t src = RX_DBG(a, 8) ? 0u : (xsx & 0xffffu) + ysrc;  // (experiment 8: every region copies the same box: the copies hit in L2)
-        uint32_t *dst = smem + slot_dw0 + wave * 256;
+        uint32_t *dst = smem + slot_dw0 + SLOT_BIAS_DW + wave * 256;  // (the records' offsets are biased: pixel 0 of a partly visible tile lies before the box)
         const int left = n - wave * 64;  // units of the region this wavefront still has to copy (wave-uniform)
         auto copy = [&](int t, bool whole) {
             int lim = left - 256 * t;
@@ -440,7 +466,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     // X and Y records); past the workgroup's last region it stays there (prefetches re-read the last records).
     struct Cursor {
         int vleft, left;  // views left in this chunk after this one; regions left after this one
-        uint32_t xo;      // byte offset of the region's X record; the Y records are half as long and walked in step: Y record at ybase + xo / 2
+        uint32_t xo;      // byte offset of the region's X record; the Y records are walked in step: Y record at xo + ydelta
     };
     const uint32_t xstep = 128u * (uint32_t)NC;  // next view, same chunk
     const int vlast = a.vcount - 1;
@@ -453,7 +479,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
         c.vleft = wrap ? vlast : c.vleft - 1;
     };
     const uint32_t x_first = xw_wg + 128u * (uint32_t)(a.v0 * NC + chunk_first);
-    const uint32_t ybase = yr_wg + 64u * (uint32_t)(a.v0 * NC + chunk_first) - (x_first >> 1);
+    const uint32_t ydelta = yr_wg - xw_wg;
 
     uint32_t acc[8][RX_KW];
     uint32_t best[8];
@@ -473,9 +499,9 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     c2.left = nreg - 1;
     c2.xo = x_first;
     // prologue: the records of regions 0 and 1, the copy of region 0
-    uint32_t x0r = load_x(c2.xo), y0r = load_y(ybase + (c2.xo >> 1));  // region r
+    uint32_t x0r = load_x(c2.xo), y0r = load_y(c2.xo + ydelta);  // region r
     advance(c2);
-    uint32_t x1r = load_x(c2.xo), y1r = load_y(ybase + (c2.xo >> 1));  // region r + 1
+    uint32_t x1r = load_x(c2.xo), y1r = load_y(c2.xo + ydelta);  // region r + 1
     advance(c2);
     uint32_t slot_cur = 0u, slot_nxt = (uint32_t)a.slot_dw;  // LDS dword offsets of the two slots
     if (nreg > 0) issue_copy(rdl(x0r, 6), rdl(y0r, 2), rdl(y0r, 3), slot_cur);
@@ -488,23 +514,39 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
         if (!RX_DBG(a, 4)) __builtin_amdgcn_s_barrier();
         // request region r + 1 into the other slot and the records of region r + 2: in flight during this region's sampling
         if (r + 1 < nreg) issue_copy(rdl(x1r, 6), rdl(y1r, 2), rdl(y1r, 3), slot_nxt);
-        const uint32_t x2r = load_x(c2.xo), y2r = load_y(ybase + (c2.xo >> 1));
+        const uint32_t x2r = load_x(c2.xo), y2r = load_y(c2.xo + ydelta);
         advance(c2);
         const uint32_t rsum = x0r + y0r;                            // (one vector add, two v_readlane: not four and two scalar adds)
         const uint32_t sum01 = rdl(rsum, 0), sum23 = rdl(rsum, 1);  // per plane: LDS byte offset, or a flag bit
         const uint32_t we[RX_KW] = {rdl(x0r, 2), rdl(x0r, 3), rdl(x0r, 4), rdl(x0r, 5)};
-        const uint32_t fld[RX_KW] = {sum01 & 0xffffu, sum01 >> 16, sum23 & 0xffffu, sum23 >> 16};
+        const uint32_t fmask = (RX_DBG(a, 32) || RX_DBG(a, 128)) ? 0x3fffu : 0xffffu;
+        const uint32_t fld[RX_KW] = {sum01 & fmask, (sum01 >> 16) & fmask, sum23 & fmask, (sum23 >> 16) & fmask};
 
         // ---- sample region r ----
-        const uint32_t special = (sum01 | sum23) & 0xc000c000u;
+        const uint32_t special = (RX_DBG(a, 32) || RX_DBG(a, 128)) ? 0u : (sum01 | sum23) & 0xc000c000u;
         if (!RX_DBG(a, 2)) {
             const uint32_t slot_byte = lds_base + slot_cur * 4u;
             uint32_t qd[1][8];
-            // One asm statement per plane, branch-free: LDS base in M0 (ds_read_addtid_b32: M0 + offset + 4 lane, no address register),
-            // weight word in an SGPR, 8 reads, 8 v_dot4, 8 v_sad_u16 (all dot products before all differences: a v_sad right behind the
-            // v_dot4 it consumes costs wait states).  A plane that is not FULL reads as well (somewhere in or past the LDS: harmless) and
-            // runs its 16 vector instructions with EXEC = 0; the `special` block below does those planes.  The s_and between the write
-            // of M0 and the first read is the wait state that pair needs.
+            // per plane: what is out of frame although the certificates hold (0: nothing -- with no flag in the field that is a FULL plane)
+            const uint32_t xmasks = (RX_DBG(a, 32) || RX_DBG(a, 64)) ? 0u : rdl(x0r, 7), ymasks = (RX_DBG(a, 32) || RX_DBG(a, 64)) ? 0u : rdl(y0r, 4);
+            const uint32_t anymask = xmasks | ymasks;
+            if (__builtin_expect(anymask != 0u, 0)) {
+#pragma unroll
+                for (int k = 0; k < RX_KW; k++)
+                    if (((anymask >> (8 * k)) & 0xffu) && !(fld[k] & 0xc000u)) spacc += 1u << (8 * k);  // this view's count does not go to every cell of the plane
+            }
+            // One asm statement per plane: LDS base in M0 (ds_read_addtid_b32: M0 + offset + 4 lane, no address register), weight word in
+            // an SGPR, 8 reads, 8 v_dot4, 8 v_sad_u16 (all dot products before all differences: a v_sad right behind the v_dot4 it
+            // consumes costs wait states).  A plane whose certificate failed (flag bits in the field) reads as well (somewhere in or past
+            // the LDS: harmless) and runs its vector instructions with EXEC = 0; the block below does those planes.  The s_and between
+            // the write of M0 and the first read is the wait state that pair needs.
+            // A plane of a tile at the border of the side view (its byte of `am` is not 0) branches to the tail INSIDE the statement --
+            // same registers, no second shape for the register allocator: EXEC = the lanes in frame (x byte: n | side << 7, n = 64:
+            // none), then row by row EXEC = that or nothing (y byte: the rows that are out), each cell that gets the sample counting it
+            // itself (+ 1 << 24).  The tail costs the planes that are FULL one taken s_branch.
+#define RX_ROW_TAIL(j)                                                                                                   \
+    "s_bitcmp0_b32 %[ym], %[yb" #j "]\n\ts_cselect_b64 exec, vcc, 0\n\tv_add_u32 %[a" #j "], 0x1000000, %[a" #j "]\n\t" \
+    "v_sad_u16 %[a" #j "], %[q" #j "], %[i" #j "], %[a" #j "]\n\t"
 #pragma unroll
             for (int k = 0; k < RX_KW; k++) {
 #pragma clang diagnostic push
@@ -514,21 +556,47 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                              "ds_read_addtid_b32 %[q0] offset:%[o0]\n\tds_read_addtid_b32 %[q1] offset:%[o1]\n\tds_read_addtid_b32 %[q2] offset:%[o2]\n\tds_read_addtid_b32 %[q3] offset:%[o3]\n\t"
                              "ds_read_addtid_b32 %[q4] offset:%[o4]\n\tds_read_addtid_b32 %[q5] offset:%[o5]\n\tds_read_addtid_b32 %[q6] offset:%[o6]\n\tds_read_addtid_b32 %[q7] offset:%[o7]\n\t"
                              "s_cselect_b64 exec, 0, -1\n\t"
+                             "s_bfe_u32 vcc_lo, %[am], %[kb]\n\t"  // this plane's byte of the masks: SCC = not 0
+                             "s_cbranch_scc1 1f\n\t"
                              "s_waitcnt lgkmcnt(0)\n\t"
                              "v_dot4_u32_u8 %[q0], %[q0], %[w], 0\n\tv_dot4_u32_u8 %[q1], %[q1], %[w], 0\n\tv_dot4_u32_u8 %[q2], %[q2], %[w], 0\n\tv_dot4_u32_u8 %[q3], %[q3], %[w], 0\n\t"
                              "v_dot4_u32_u8 %[q4], %[q4], %[w], 0\n\tv_dot4_u32_u8 %[q5], %[q5], %[w], 0\n\tv_dot4_u32_u8 %[q6], %[q6], %[w], 0\n\tv_dot4_u32_u8 %[q7], %[q7], %[w], 0\n\t"
                              "v_sad_u16 %[a0], %[q0], %[i0], %[a0]\n\tv_sad_u16 %[a1], %[q1], %[i1], %[a1]\n\tv_sad_u16 %[a2], %[q2], %[i2], %[a2]\n\tv_sad_u16 %[a3], %[q3], %[i3], %[a3]\n\t"
                              "v_sad_u16 %[a4], %[q4], %[i4], %[a4]\n\tv_sad_u16 %[a5], %[q5], %[i5], %[a5]\n\tv_sad_u16 %[a6], %[q6], %[i6], %[a6]\n\tv_sad_u16 %[a7], %[q7], %[i7], %[a7]\n\t"
-                             "s_mov_b64 exec, -1"
+                             "2:\n\t"
+                             "s_mov_b64 exec, -1\n\t"
+                             "s_branch 9f\n\t"
+                             // ---- the tail: lanes in frame from the x byte
+                             "1:\n\t"
+                             "s_bfe_u32 vcc_lo, %[xm], %[nb]\n\t"        // n (6 bits)
+                             "s_bitcmp1_b32 %[xm], %[sb]\n\t"            // side
+                             "s_cbranch_scc1 3f\n\t"
+                             "s_lshl_b64 exec, exec, vcc_lo\n\t"         // the first n lanes are out
+                             "s_branch 4f\n\t"
+                             "3:\n\t"
+                             "s_lshr_b64 exec, exec, vcc_lo\n\t"         // the last n lanes are out
+                             "4:\n\t"
+                             "s_bitcmp1_b32 %[xm], %[eb]\n\t"            // n = 64: nothing in frame
+                             "s_cselect_b64 exec, 0, exec\n\t"
+                             "s_mov_b64 vcc, exec\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "v_dot4_u32_u8 %[q0], %[q0], %[w], 0\n\tv_dot4_u32_u8 %[q1], %[q1], %[w], 0\n\tv_dot4_u32_u8 %[q2], %[q2], %[w], 0\n\tv_dot4_u32_u8 %[q3], %[q3], %[w], 0\n\t"
+                             "v_dot4_u32_u8 %[q4], %[q4], %[w], 0\n\tv_dot4_u32_u8 %[q5], %[q5], %[w], 0\n\tv_dot4_u32_u8 %[q6], %[q6], %[w], 0\n\tv_dot4_u32_u8 %[q7], %[q7], %[w], 0\n\t"
+                             RX_ROW_TAIL(0) RX_ROW_TAIL(1) RX_ROW_TAIL(2) RX_ROW_TAIL(3) RX_ROW_TAIL(4) RX_ROW_TAIL(5) RX_ROW_TAIL(6) RX_ROW_TAIL(7)
+                             "s_branch 2b\n\t"
+                             "9:"
                              : [q0] "=&v"(qd[0][0]), [q1] "=&v"(qd[0][1]), [q2] "=&v"(qd[0][2]), [q3] "=&v"(qd[0][3]), [q4] "=&v"(qd[0][4]), [q5] "=&v"(qd[0][5]), [q6] "=&v"(qd[0][6]), [q7] "=&v"(qd[0][7]),
                                [a0] "+v"(acc[0][k]), [a1] "+v"(acc[1][k]), [a2] "+v"(acc[2][k]), [a3] "+v"(acc[3][k]), [a4] "+v"(acc[4][k]), [a5] "+v"(acc[5][k]), [a6] "+v"(acc[6][k]), [a7] "+v"(acc[7][k])
-                             : [slot] "s"(slot_byte), [fld] "s"(fld[k]), [w] "s"(we[k]),
+                             : [slot] "s"(slot_byte), [fld] "s"(fld[k]), [w] "s"(we[k]), [am] "s"(anymask), [xm] "s"(xmasks), [ym] "s"(ymasks),
                                [i0] "v"(Im255[0]), [i1] "v"(Im255[1]), [i2] "v"(Im255[2]), [i3] "v"(Im255[3]), [i4] "v"(Im255[4]), [i5] "v"(Im255[5]), [i6] "v"(Im255[6]), [i7] "v"(Im255[7]),
-                               [o0] "n"(0), [o1] "n"(RS * 4), [o2] "n"(RS * 8), [o3] "n"(RS * 12), [o4] "n"(RS * 16), [o5] "n"(RS * 20), [o6] "n"(RS * 24), [o7] "n"(RS * 28)
+                               [o0] "n"(0), [o1] "n"(RS * 4), [o2] "n"(RS * 8), [o3] "n"(RS * 12), [o4] "n"(RS * 16), [o5] "n"(RS * 20), [o6] "n"(RS * 24), [o7] "n"(RS * 28),
+                               [kb] "n"(8 * k | (8 << 16)), [nb] "n"(8 * k | (6 << 16)), [sb] "n"(8 * k + 7), [eb] "n"(8 * k + 6),
+                               [yb0] "n"(8 * k + 0), [yb1] "n"(8 * k + 1), [yb2] "n"(8 * k + 2), [yb3] "n"(8 * k + 3), [yb4] "n"(8 * k + 4), [yb5] "n"(8 * k + 5), [yb6] "n"(8 * k + 6), [yb7] "n"(8 * k + 7)
                              : "m0", "scc", "vcc");
 #pragma clang diagnostic pop
             }
-            // the other planes: part of the tile out of frame (MASKED), nothing in frame, or a certificate failed (SEMI)
+#undef RX_ROW_TAIL
+            // the planes whose certificate failed (a rounding boundary inside the tile), or whose offsets did not fit the record
             if (special) {
                 uintptr_t coldp = (uintptr_t)a.cold;
                 asm volatile("" : "+s"(coldp));  // not loop-invariant for the optimiser: fetched here, not held in SGPRs over the loop
@@ -550,7 +618,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                         // a lane range (from the X entry) and a row range (from the Y entry) are in frame: the fast path under a mask,
                         // the in-frame count per cell
                         const int tx0 = (int)(xe & 0xfffffu) - RX_BIAS, ty0 = (int)(ye & 0xfffffu) - RX_BIAS;
-                        const uint32_t addr = 4u * (uint32_t)lane + slot_byte + 4u * (uint32_t)(((ty0 >> 5) - y0) * RS + ((tx0 >> 5) - x0));
+                        const uint32_t addr = 4u * (uint32_t)lane + slot_byte + 4u * (uint32_t)(SLOT_BIAS_DW + ((ty0 >> 5) - y0) * RS + ((tx0 >> 5) - x0));
                         const bool lane_in = ((xe >> 27) & 1u) ? lane < TILE_W - nx : lane >= nx;
                         const int jlo = ((ye >> 27) & 1u) ? 0 : ny, jhi = ((ye >> 27) & 1u) ? RX_TILE_H - ny : RX_TILE_H;
                         if (lane_in) {
@@ -590,7 +658,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                             if (tyb > lo_bits && tyb < hiy_bits && row0 + j < a.H) {
                                 const uint32_t uy = tyb & 0x3fffffu;
                                 const uint32_t w = lut[((uy >> 3) & 31u) * 32u + kx];
-                                const uint32_t addr = 4u * (uint32_t)lane + slot_byte + 4u * (uint32_t)(((int)(uy >> 8) - y0) * RS + ixrel);
+                                const uint32_t addr = 4u * (uint32_t)lane + slot_byte + 4u * (uint32_t)(SLOT_BIAS_DW + ((int)(uy >> 8) - y0) * RS + ixrel);
                                 if (mine) {
                                     uint32_t quad;
                                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(quad) : "v"(addr));
@@ -612,7 +680,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
             // While every plane of every chunk so far was FULL for every view, every cell carries the same count and the packed cells
             // compare like their sums: "cell < best" (best starts at 0xffffffff) instead of the cross-multiplied comparison.  The
             // first chunk with a plane that is not FULL ends that for the rest of the workgroup (same packed cells, start value 1).
-            if (FUSED && plain && spacc != 0u) {
+            if (FUSED && plain && spacc != 0u && !RX_DBG(a, 256)) {
                 plain = false;
 #pragma unroll
                 for (int j = 0; j < 8; j++) best[j] = bi[j] < 0 ? 1u : best[j];
@@ -732,7 +800,7 @@ static RectSizes rect_sizes(const SweepParams &q)
     z.nxb = (size_t)q.tiles_x * q.V * q.nchunks;
     z.nyb = (size_t)q.tiles_y * q.V * q.nchunks;
     z.nxw = z.nxb * 32;
-    z.nyr = z.nyb * 16;
+    z.nyr = z.nyb * 32;
     z.total = 16 + z.nxw + z.nyr + 2 * z.nx + 2 * z.ny + z.nw + z.nxb + z.nyb + 64;  // + slack: prefetches read whole 8-dword lanes past a Y record
     return z;
 }
@@ -796,7 +864,8 @@ int sweep_rect_plan(mvs_ctx *ctx)
     if (!rs || max_rw <= 0 || max_rh <= 0 || max_rh > 32) return MVS_OK;  // wide baselines / few planes: boxes too large for the slots
     const int units = rs / 4;
     const int instrs = div_up(max_rh * units, 64);  // 1 KiB copy instructions per region
-    if (instrs > 4 * RX_MAX_NI || instrs * 1024 >= 16384) return MVS_OK;  // (the records hold 14-bit LDS offsets)
+    if (instrs > 4 * RX_MAX_NI || instrs * 1024 >= 16384) return MVS_OK;
+    if (4 * (rs + RX_BIAS_X) + 4 * rs * (max_rh + RX_BIAS_Y) >= 16384) return MVS_OK;  // the records hold 14-bit (biased) LDS offsets
     ctx->rect_rs = rs;
     ctx->rect_slot_dw = instrs * 256;
     ctx->rect_dpad = rt.dpad;
@@ -878,7 +947,7 @@ int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsign
     a.tiles_x = p.tiles_x;
     a.slot_dw = ctx->rect_slot_dw;
     a.debug = p.debug;
-    size_t lds = (size_t)2 * a.slot_dw * 4;
+    size_t lds = ((size_t)2 * a.slot_dw + RX_BIAS_X + (size_t)RX_BIAS_Y * ctx->rect_rs) * 4;  // two slots, the second one's data ends a bias further on
     if (fused) lds = lds < 16384 ? 16384 : lds;  // the cross-wavefront depth selection borrows 16 KiB
     if (lds > 160 * 1024) return fail(ctx, MVS_EINVAL, "sweep_rect_launch: %zu bytes of LDS", lds);
 

@@ -44,6 +44,6 @@ with mvs_amd.Context(W, H, sampler="fixed") as ctx:
         b = ctx.sweep_fetch(want_volume=False)
         print("depth equal", np.array_equal(a[0], b[0]), "index differs at", int(np.count_nonzero(a[2] != b[2])), "cost differs at", int(np.count_nonzero(a[1] != b[1])))
     if "--exp" in sys.argv:   # needs a build with -DMVS_RX_EXPERIMENTS (make -B CXXFLAGS="... -DMVS_RX_EXPERIMENTS")
-        for name_, bits in (("full", 0), ("no copies", 1), ("every copy from one box (L2 hits)", 8), ("one box, no sampling", 10), ("no sampling", 2), ("no barrier", 4), ("no epilogue", 16), ("no copies, no sampling", 3), ("no sampling, no epilogue", 18),
+        for name_, bits in (("full", 0), ("every plane taken for FULL", 32), ("no copies", 1), ("every copy from one box (L2 hits)", 8), ("one box, no sampling", 10), ("no sampling", 2), ("no barrier", 4), ("no epilogue", 16), ("no copies, no sampling", 3), ("no sampling, no epilogue", 18),
                             ("no copies, no barrier", 5), ("skeleton: none of the four", 23)):
             print("   %-36s %.3f ms  (fused only %.3f, volume only %.3f)" % (name_, timeit(ctx, both | (bits << 8)), timeit(ctx, mvs_amd.MVS_SWEEP_FUSED_ARGMIN | (bits << 8)), timeit(ctx, mvs_amd.MVS_SWEEP_VOLUME | (bits << 8))))
