@@ -606,22 +606,15 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                 const uint32_t xsx = rdl(x0r, 6), yn = rdl(y0r, 3);
                 const int x0 = (int)((xsx & 0xffffu) >> 2), y0 = (int)((yn >> 8) & 0x3fffu);
                 const bool staged = (xsx >> 16) != 0u && (yn & 0xffu) != 0u;
-                // ONE copy of this block's code for the four planes (a run-time loop; the plane's accumulators go through `row`): unrolled
-                // it was 40 % of the kernel's instructions for 0.3 % of its planes, and the region loop jumped across all of it
-#pragma unroll 1
+#pragma unroll
                 for (int k = 0; k < RX_KW; k++) {
-                    const uint32_t fk = k == 0 ? fld[0] : (k == 1 ? fld[1] : (k == 2 ? fld[2] : fld[3]));
-                    if (!(fk & 0xc000u)) continue;
+                    if (!(fld[k] & 0xc000u)) continue;
                     spacc += 1u << (8 * k);  // not FULL: this view's count does not go to every cell of the plane
                     if (!staged) continue;
-                    const uint32_t wk = k == 0 ? we[0] : (k == 1 ? we[1] : (k == 2 ? we[2] : we[3]));
-                    uint32_t row[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) row[j] = k == 0 ? acc[j][0] : (k == 1 ? acc[j][1] : (k == 2 ? acc[j][2] : acc[j][3]));
                     const uint32_t xe = xt[k], ye = yt[k];
                     const int nx = (int)((xe >> 20) & 127u), ny = (int)((ye >> 20) & 127u);
                     if ((xe & ye) & RX_UNIFORM) {
-                        if (nx >= TILE_W || ny >= RX_TILE_H) continue;  // nothing in frame (nothing to write back)
+                        if (nx >= TILE_W || ny >= RX_TILE_H) continue;  // nothing in frame
                         // a lane range (from the X entry) and a row range (from the Y entry) are in frame: the fast path under a mask,
                         // the in-frame count per cell
                         const int tx0 = (int)(xe & 0xfffffu) - RX_BIAS, ty0 = (int)(ye & 0xfffffu) - RX_BIAS;
@@ -634,9 +627,10 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qd[0][0]), "+v"(qd[0][1]), "+v"(qd[0][2]), "+v"(qd[0][3]), "+v"(qd[0][4]), "+v"(qd[0][5]), "+v"(qd[0][6]), "+v"(qd[0][7]));
 #pragma unroll
                             for (int j = 0; j < 8; j++)
-                                if (j >= jlo && j < jhi) row[j] = sad_u16(__builtin_amdgcn_udot4(qd[0][j], wk, 0u, false), Im255[j], row[j] + (1u << 24));
+                                if (j >= jlo && j < jhi) acc[j][k] = sad_u16(__builtin_amdgcn_udot4(qd[0][j], we[k], 0u, false), Im255[j], acc[j][k] + (1u << 24));
                         }
-                    } else {
+                        continue;
+                    }
                     // A certificate failed (a rounding boundary inside the tile: ~0.3 % of the planes on the SURVEY 8d ring): the contract's
                     // expression per lane (columns) and per row, then one pass per group of lanes that share a phase and a texel offset
                     // (usually two groups), each with wave-uniform weights and LDS bases like the fast path.
@@ -668,18 +662,10 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                                 if (mine) {
                                     uint32_t quad;
                                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(quad) : "v"(addr));
-                                    row[j] = sad_u16(__builtin_amdgcn_udot4(quad, w, 0u, false), Im255[j], row[j] + (1u << 24));
+                                    acc[j][k] = sad_u16(__builtin_amdgcn_udot4(quad, w, 0u, false), Im255[j], acc[j][k] + (1u << 24));
                                 }
                             }
                         }
-                    }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        acc[j][0] = k == 0 ? row[j] : acc[j][0];
-                        acc[j][1] = k == 1 ? row[j] : acc[j][1];
-                        acc[j][2] = k == 2 ? row[j] : acc[j][2];
-                        acc[j][3] = k == 3 ? row[j] : acc[j][3];
                     }
                 }
             }
