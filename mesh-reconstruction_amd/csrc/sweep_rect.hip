@@ -482,13 +482,12 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     const uint32_t ydelta = yr_wg - xw_wg;
 
     uint32_t acc[8][RX_KW];
-    // The running best of this wavefront's planes (packed cell, plane) per pixel lives in LDS, not in 16 registers: it is touched once
-    // per chunk, and the final selection across the four wavefronts reads it from there anyway.  [wave][row][lane], own entries only.
-    uint2 *const best_state = (uint2 *)smem + (wave * 8) * 64 + lane;  // + 64 j
-    constexpr uint32_t BEST_DW = FUSED ? 2u * 4u * 8u * 64u : 0u;     // the slots come after it
+    uint32_t best[8];
+    int bi[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        if (FUSED) best_state[64 * j] = make_uint2(0xffffffffu, 0xffffffffu);  // plain comparison (chunk epilogue); the cross-multiplied one starts from (sum 1, count 0)
+        best[j] = 0xffffffffu;  // plain comparison (chunk epilogue); the cross-multiplied one starts from (sum 1, count 0)
+        bi[j] = -1;
 #pragma unroll
         for (int k = 0; k < RX_KW; k++) acc[j][k] = 0u;
     }
@@ -504,7 +503,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     advance(c2);
     uint32_t x1r = load_x(c2.xo), y1r = load_y(c2.xo + ydelta);  // region r + 1
     advance(c2);
-    uint32_t slot_cur = BEST_DW, slot_nxt = BEST_DW + (uint32_t)a.slot_dw;  // LDS dword offsets of the two slots
+    uint32_t slot_cur = 0u, slot_nxt = (uint32_t)a.slot_dw;  // LDS dword offsets of the two slots
     if (nreg > 0) issue_copy(rdl(x0r, 6), rdl(y0r, 2), rdl(y0r, 3), slot_cur);
     int chunk = chunk_first, v = a.v0;
 
@@ -684,42 +683,26 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
             if (FUSED && plain && spacc != 0u && !RX_DBG(a, 256)) {
                 plain = false;
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint2 st = best_state[64 * j];
-                    if ((int)st.y < 0) best_state[64 * j] = make_uint2(1u, st.y);
-                }
+                for (int j = 0; j < 8; j++) best[j] = bi[j] < 0 ? 1u : best[j];
             }
             auto finish = [&](auto checked_rows, auto plain_compare) {
-                uint32_t cnt[RX_KW];  // FULL planes: every cell gets the views' count
 #pragma unroll
-                for (int k = 0; k < RX_KW; k++) cnt[k] = ((uint32_t)a.vcount - ((spacc >> (8 * k)) & 0xffu)) << 24;
-                if (WRITE_VOLUME) {
+                for (int k = 0; k < RX_KW; k++) {
+                    const uint32_t cntk = ((uint32_t)a.vcount - ((spacc >> (8 * k)) & 0xffu)) << 24;  // FULL planes: every cell gets the view's count
+                    if (d0 + k < a.D) {
+                        // one resource per plane (a volume can exceed the 4 GiB a resource spans), rows by the wave-uniform offset
+                        const __amdgpu_buffer_rsrc_t rvol = make_rsrc(WRITE_VOLUME ? a.volume + (size_t)(d0 + k) * P : nullptr, 0xffffffffu);
 #pragma unroll
-                    for (int k = 0; k < RX_KW; k++) {
-                        if (d0 + k < a.D) {
-                            // one resource per plane (a volume can exceed the 4 GiB a resource spans), rows by the wave-uniform offset
-                            const __amdgpu_buffer_rsrc_t rvol = make_rsrc(a.volume + (size_t)(d0 + k) * P, 0xffffffffu);
-#pragma unroll
-                            for (int j = 0; j < 8; j++)
-                                if (!checked_rows.value || j < nrows) __builtin_amdgcn_raw_buffer_store_b32(acc[j][k] + cnt[k], rvol, pix0, 4u * (uint32_t)(j * a.W), 2);  // nt: written once, read by a later kernel
-                        }
-                    }
-                }
-                if (FUSED) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        if (!checked_rows.value || j < nrows) {
-                            uint2 st = best_state[64 * j];
-#pragma unroll
-                            for (int k = 0; k < RX_KW; k++) {
-                                if (d0 + k < a.D) {
-                                    const uint32_t cell = acc[j][k] + cnt[k];
-                                    const bool better = plain_compare.value ? cell < st.x : umul24u(cell & 0xffffffu, st.x >> 24) < umul24u(st.x & 0xffffffu, cell >> 24);
-                                    st.x = better ? cell : st.x;
-                                    st.y = better ? (uint32_t)(d0 + k) : st.y;
+                        for (int j = 0; j < 8; j++) {
+                            if (!checked_rows.value || j < nrows) {
+                                const uint32_t cell = acc[j][k] + cntk;
+                                if (WRITE_VOLUME) __builtin_amdgcn_raw_buffer_store_b32(cell, rvol, pix0, 4u * (uint32_t)(j * a.W), 2);  // nt: written once, read by a later kernel
+                                if (FUSED) {
+                                    const bool better = plain_compare.value ? cell < best[j] : umul24u(cell & 0xffffffu, best[j] >> 24) < umul24u(best[j] & 0xffffffu, cell >> 24);
+                                    best[j] = better ? cell : best[j];
+                                    bi[j] = better ? d0 + k : bi[j];
                                 }
                             }
-                            best_state[64 * j] = st;
                         }
                     }
                 }
@@ -756,8 +739,11 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
 
     // ---- depth selection across the four wavefronts (each holds the best of its own planes): lowest cost, ties -> lowest plane ----
     if (FUSED) {
-        __syncthreads();  // every wavefront's running best is final
-        const uint2 *ex = (const uint2 *)smem;  // [wave][row][lane]
+        __syncthreads();  // every copy has landed and every sample loop is done: the slots are free
+        uint2 *ex = (uint2 *)smem;  // [wave][row][lane]
+#pragma unroll
+        for (int j = 0; j < 8; j++) ex[(wave * 8 + j) * 64 + lane] = make_uint2(best[j], (uint32_t)bi[j]);
+        __syncthreads();
         const size_t P = (size_t)a.W * a.H;
         float *depth = RX_COLD(a.cold, float *, depth), *cost = RX_COLD(a.cold, float *, cost);
         int *index = RX_COLD(a.cold, int *, index);
@@ -962,7 +948,7 @@ int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsign
     a.slot_dw = ctx->rect_slot_dw;
     a.debug = p.debug;
     size_t lds = ((size_t)2 * a.slot_dw + RX_BIAS_X + (size_t)RX_BIAS_Y * ctx->rect_rs) * 4;  // two slots, the second one's data ends a bias further on
-    if (fused) lds += 16384;  // the running best per (wavefront, row, lane), in front of the slots
+    if (fused) lds = lds < 16384 ? 16384 : lds;  // the cross-wavefront depth selection borrows 16 KiB
     if (lds > 160 * 1024) return fail(ctx, MVS_EINVAL, "sweep_rect_launch: %zu bytes of LDS", lds);
 
     const int groups = div_up(p.tiles_x, 2) * div_up(p.tyn, 4);
