@@ -226,6 +226,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="--config c5: main frames per mvs_sweep_batch launch")
     ap.add_argument("--onecall", action="store_true", help="--config c5: mvs_sweep per main frame instead of the frame store + mvs_sweep_batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--general-cameras", action="store_true",
+                    help="time the general-camera geometry (side cameras turned by 12 mrad: sweep_fx_tiled) instead of the SURVEY 8d ring; for profiles, not the headline")
     ap.add_argument("--fused", action="store_true", help="also time the no-volume variant (depth only)")
     ap.add_argument("--separate-argmin", action="store_true",
                     help="single GPU: run argmin_volume as its own pass over the volume (the multi-GPU views pipeline)")
@@ -283,6 +285,23 @@ def main():
         main_cam, main_img, side_cams, sides, gt = synth.make_views(W, H, V, radius=radius, seed=synth.SEED_SCENE + seed_off)
     else:
         main_cam, main_img, side_cams, sides = synth.noise_views(W, H, V, seed=synth.SEED_NOISE + seed_off)
+        gt = None
+
+    def general_cameras():
+        """the ring's cameras, each turned by a few milliradians about two axes (yaw = 0.012 cos a, pitch = 0.012 sin a): no view is
+        rectified against the main view any more, so the sweep takes the general tiled kernel with its per-sample reciprocal -- the
+        rate for rotated / forward-moving cameras such as the bundled tracks.  Timing only: the frames stay those of the ring."""
+        cams = []
+        for vi in range(V):
+            ang = 2.0 * np.pi * vi / max(V, 1)
+            yaw, pitch = 0.012 * np.cos(ang), 0.012 * np.sin(ang)
+            cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+            rot = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+            cams.append(synth.camera_at([radius * np.cos(ang), radius * np.sin(ang), 0.0], W, H, rot=rot))
+        return np.stack(cams)
+
+    if args.general_cameras:  # profiling aid (tools/prof_sweep.sh <tag> --general-cameras): the general tiled kernel as the timed workload
+        side_cams = general_cameras()
         gt = None
 
     # one explicit (non-default) stream for kernels AND collectives: torch's default stream has handle 0, which the ABI
@@ -448,19 +467,6 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t1) / n * 1e3
 
-    def general_cameras():
-        """the ring's cameras, each turned by a few milliradians about two axes (yaw = 0.012 cos a, pitch = 0.012 sin a): no view is
-        rectified against the main view any more, so the sweep takes the general tiled kernel with its per-sample reciprocal -- the
-        rate for rotated / forward-moving cameras such as the bundled tracks.  Timing only: the frames stay those of the ring."""
-        cams = []
-        for vi in range(V):
-            ang = 2.0 * np.pi * vi / max(V, 1)
-            yaw, pitch = 0.012 * np.cos(ang), 0.012 * np.sin(ang)
-            cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
-            rot = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
-            cams.append(synth.camera_at([radius * np.cos(ang), radius * np.sin(ang), 0.0], W, H, rot=rot))
-        return np.stack(cams)
-
     # co-headline: the same frames under general (rotated) cameras; and the exact-f32 sampler on both geometries
     general_ms = exact = disagreement = sustained = None
     if world == 1 and not args.no_extras:
@@ -562,7 +568,7 @@ def main():
             "vs_baseline": None,
             "dtype": DTYPE[args.sampler],
             "data": "synthetic (%s)" % args.data + (" [TEST HOOK: ranks share one GPU over gloo -- not a measurement]" if same_device else ""),
-            "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V),
+            "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V) + (" (GENERAL CAMERAS: side views turned by 12 mrad, not the SURVEY 8d ring)" if args.general_cameras else ""),
                        "sampler": args.sampler, "shard": None if world == 1 else shard, "collective": args.collective if shard == "views" else ("all_gather of depth rows" if shard == "rows" and world > 1 else None),
                        "views_per_rank": primary["views"], "rows_per_rank": [n for _, n in bands] if shard == "rows" else None,
                        "collective_bytes_per_rank_per_step": primary["collective_bytes_per_rank"], "alternatives": alternatives, "device": ctx.info()},
