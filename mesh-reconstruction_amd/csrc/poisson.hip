@@ -319,7 +319,7 @@ extern "C" int mvs_poisson_surface(const float *points, const float *normals, in
     int rc = MVS_OK;
     const char *msg = "";
 #define PS_TRY(cond, code, text) do { if (!(cond)) { rc = (code); msg = (text); goto done; } } while (0)
-    {
+    try {
         PS_TRY(d_pts.alloc((size_t)n * 16) && d_nrm.alloc((size_t)n * 12) && d_fix.alloc(4 * N3 * 4) && d_real.alloc(3 * N3 * 4) && d_spec.alloc(3 * S3 * 8) &&
                    d_flag.alloc(3 * N3 * 4) && d_index.alloc((3 * N3 + 1) * 4) && d_cell_index.alloc((C3 + 1) * 4) && d_samples.alloc((size_t)n * 4),
                MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
@@ -384,6 +384,9 @@ extern "C" int mvs_poisson_surface(const float *points, const float *normals, in
                    MVS_EHIP, "mvs_poisson_surface: download failed");
         }
         PS_TRY(hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess, MVS_EHIP, "mvs_poisson_surface: a kernel failed");
+    } catch (...) {  // a host vector could not grow: no exception crosses the C boundary
+        rc = MVS_ENOMEM;
+        msg = "mvs_poisson_surface: host allocation failed";
     }
 done:
 #undef PS_TRY

@@ -599,12 +599,18 @@ AlphaResult alpha_shape(const float *rows, int nrows, int cols, double forced_al
 }  // namespace
 
 // C entry points (ctypes in tests/test_meshing_cpu.py; a C caller): points = rows x cols floats (cols 3: Cartesian, 4: homogeneous).
-// faces / cells may be null (count only).  Returns 0, or 1 when a buffer is too small (the counts say what is needed).
+// faces / cells may be null (count only).  Returns 0, 1 when a buffer is too small (the counts say what is needed), 2 for a bad argument,
+// 3 when memory ran out.
 extern "C" int mvs_alpha_shape_faces(const float *points, int rows, int cols, float forced_alpha, int32_t *faces, int face_capacity, int *face_count,
                                      float *alpha, int *solid_components)
 {
     if (!points || rows < 0 || (cols != 3 && cols != 4) || !face_count) return 2;
-    const AlphaResult r = alpha_shape(points, rows, cols, forced_alpha);
+    AlphaResult r;
+    try {
+        r = alpha_shape(points, rows, cols, forced_alpha);
+    } catch (...) {  // (allocation failure: no exception may cross the C boundary)
+        return 3;
+    }
     *face_count = (int)(r.faces.size() / 3);
     if (alpha) *alpha = (float)r.alpha;
     if (solid_components) *solid_components = r.components;
@@ -618,7 +624,12 @@ extern "C" int mvs_alpha_shape_faces(const float *points, int rows, int cols, fl
 extern "C" int mvs_delaunay3_cells(const float *points, int rows, int cols, int32_t *cells, int cell_capacity, int *cell_count)
 {
     if (!points || rows < 0 || (cols != 3 && cols != 4) || !cell_count) return 2;
-    const AlphaResult r = alpha_shape(points, rows, cols, 0.0);
+    AlphaResult r;
+    try {
+        r = alpha_shape(points, rows, cols, 0.0);
+    } catch (...) {
+        return 3;
+    }
     *cell_count = (int)(r.cells.size() / 4);
     if (cells) {
         if (cell_capacity < *cell_count) return 1;
