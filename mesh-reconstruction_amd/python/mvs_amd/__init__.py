@@ -130,6 +130,36 @@ def load_library(path=None):
     return lib
 
 
+_host_lib = None
+
+
+def alpha_shape_faces(points, forced_alpha=0.0):
+    """alphaShapeFaces (recon.hpp:33-34) through libmvs_host.so (host code, no GPU): points N x 3 or N x 4 (homogeneous)
+    -> (faces F x 3 int32 of row indices, normals out of the solid; the alpha chosen; solid components at that alpha)"""
+    global _host_lib
+    if _host_lib is None:
+        load_library()  # libmvs_host.so links libmvs_hip.so
+        path = os.path.join(os.path.dirname(LIB_PATH), "libmvs_host.so")
+        if not os.path.exists(path):
+            raise MvsError("host library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        _host_lib = C.CDLL(path)
+        _host_lib.mvs_alpha_shape_faces.restype = _i
+        _host_lib.mvs_alpha_shape_faces.argtypes = [_vp, _i, _i, _f, _vp, _i, _vp, _vp, _vp]
+    pts = np.ascontiguousarray(points, np.float32)
+    if pts.ndim != 2 or pts.shape[1] not in (3, 4):
+        raise ValueError("points must be N x 3 or N x 4")
+    count, alpha, comps = C.c_int(), C.c_float(), C.c_int()
+    rc = _host_lib.mvs_alpha_shape_faces(pts.ctypes.data_as(_vp), pts.shape[0], pts.shape[1], float(forced_alpha), None, 0, C.byref(count), C.byref(alpha), C.byref(comps))
+    if rc != 0:
+        raise MvsError("mvs_alpha_shape_faces failed (%d)" % rc)
+    faces = np.zeros((count.value, 3), np.int32)
+    rc = _host_lib.mvs_alpha_shape_faces(pts.ctypes.data_as(_vp), pts.shape[0], pts.shape[1], float(forced_alpha), faces.ctypes.data_as(_vp), count.value, C.byref(count),
+                                         C.byref(alpha), C.byref(comps))
+    if rc != 0:
+        raise MvsError("mvs_alpha_shape_faces failed (%d)" % rc)
+    return faces, alpha.value, comps.value
+
+
 def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0):
     """poissonSurface (recon.hpp:37) through mvs_poisson_surface: points N x 4 homogeneous, normals N x 3 (out of the solid)
     -> (vertices V x 4 float32 with w = 1, faces F x 3 int32)"""

@@ -145,3 +145,11 @@ def test_the_cpp_mirror_uses_it_for_the_first_iteration():
     exe = os.path.join(ROOT, "mesh-reconstruction_amd", "bin", "host_selftest")
     r = subprocess.run([exe, "cpu", os.path.join(ROOT, "tests", "data", "tracks")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "cpu selftest: 0 failures" in r.stdout and "alpha shape of the zatisi bundle" in r.stdout
+
+
+def test_python_binding():
+    sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
+    import mvs_amd
+    cube = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], np.float32)
+    f, a, c = mvs_amd.alpha_shape_faces(cube)
+    assert f.shape == (12, 3) and a == 0.75 and c == 1
