@@ -153,3 +153,23 @@ def test_python_binding():
     cube = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], np.float32)
     f, a, c = mvs_amd.alpha_shape_faces(cube)
     assert f.shape == (12, 3) and a == 0.75 and c == 1
+
+
+def test_golden_vectors_alpha_and_poisson_oracle(lib):
+    """tests/golden/meshing_small.npz (tests/golden/make_meshing_golden.py): the C++ alpha shapes and the oracle both reproduce the stored
+    faces / alpha / cells; the Poisson oracle reproduces its stored fields (drift guard; the HIP side: tests/test_meshing_gpu.py)"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "meshing_small.npz"))
+    want = set(map(tuple, g["alpha_faces"].tolist()))
+    faces, alpha, comps = mc.alpha_shape(lib, g["alpha_points"])
+    assert mc.canonical_faces(faces) == want and np.float32(alpha) == g["alpha"] and comps == int(g["alpha_components"])
+    assert _cells(mc.delaunay_cells(lib, g["alpha_points"])) == _cells(g["alpha_cells"])
+    of, oa, oc, _ = mo.alpha_shape(g["alpha_points"])
+    assert mc.canonical_faces(of) == want and np.float32(oa) == g["alpha"]
+    G, origin, h = mo.poisson_grid(g["poisson_points"], 5)
+    assert G == int(g["poisson_G"]) and np.array_equal(origin, g["poisson_origin"]) and np.float32(h) == g["poisson_h"]
+    splat = mo.poisson_splat(g["poisson_points"], g["poisson_normals"], G, origin, h)
+    assert np.array_equal(splat, g["poisson_splat"])
+    chi = mo.poisson_chi(splat, 1.0)
+    np.testing.assert_allclose(chi, g["poisson_chi"], rtol=0, atol=2e-6 * float(np.ptp(g["poisson_chi"])))
+    v, f = mo.surface_nets(g["poisson_chi"], g["poisson_level"], origin, h)
+    assert np.array_equal(f, g["poisson_faces"]) and np.array_equal(v, g["poisson_vertices"])

@@ -132,3 +132,16 @@ def test_config5_outer_iteration_closes_points_filter_poisson_mesh_render():
         ctx.load_mesh(v, f)
         d = ctx.depth(seq.cams[seq.mains[12]])
         assert (d != mvs_amd.BACKGROUND_DEPTH).any()
+
+
+def test_golden_vectors(hip):
+    """the HIP Poisson surface against tests/golden/meshing_small.npz directly (so that kernel and oracle cannot drift together unnoticed)"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "meshing_small.npz"))
+    r = mc.poisson(hip, g["poisson_points"], g["poisson_normals"], 5, 1.0)
+    assert r["G"] == int(g["poisson_G"]) and np.array_equal(r["origin"], g["poisson_origin"]) and np.float32(r["h"]) == g["poisson_h"]
+    assert np.array_equal(r["splat"], g["poisson_splat"])
+    rng_ = float(np.ptp(g["poisson_chi"]))
+    assert np.abs(r["chi"] - g["poisson_chi"]).max() <= 1e-5 * rng_ and abs(r["iso"] - float(g["poisson_level"])) <= 1e-5 * rng_
+    # the level set of a field that differs in its last bits: the same surface up to the cells those bits decide
+    assert abs(len(r["vertices"]) - len(g["poisson_vertices"])) <= 0.01 * len(g["poisson_vertices"]) + 2
+    assert abs(mc.signed_volume(r["vertices"], r["faces"]) - mc.signed_volume(g["poisson_vertices"], g["poisson_faces"])) <= 1e-3 * abs(mc.signed_volume(g["poisson_vertices"], g["poisson_faces"]))
