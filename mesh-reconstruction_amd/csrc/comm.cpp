@@ -16,8 +16,18 @@
 // at a shared error flag BEFORE anybody enters a collective -- a rank that failed early makes all of them skip the exchange instead
 // of leaving the others waiting in RCCL for ever.  A failure inside the exchange aborts every communicator (ncclCommAbort), which
 // unblocks the other ranks; the communicator is unusable afterwards (mvs_sweep_sharded then returns MVS_ESTATE).
-// RCCL is resolved with dlopen at mvs_comm_create: libmvs_hip.so itself has no link dependency on librccl, and a process that has
-// already loaded one (PyTorch) shares it.  MVS_RCCL_LIBRARY names another library file (tests: a missing one).
+// Abort is best effort: ncclCommAbort is called on every rank's communicator from the failing rank's thread while the other ranks'
+// threads may be inside a collective on theirs -- that is what unblocks them; RCCL documents the call as safe from another thread, and the
+// communicator is never used again.
+// RCCL is resolved with dlopen at mvs_comm_create (libmvs_hip.so itself has no link dependency on librccl, and a process that has
+// already loaded one -- PyTorch -- shares it), but only the two view-sharded modes need it: a default librccl that cannot be loaded leaves
+// a communicator that serves MVS_SHARD_ROWS (no collective) and reports the loader's message when a views mode is selected; the RCCL
+// communicators themselves (ncclCommInitAll) are created by the first sweep that exchanges anything.  MVS_RCCL_LIBRARY names another
+// library file -- an explicit request, so a file that cannot be loaded fails mvs_comm_create (tests: a missing one, and the loopback
+// stand-in of tests/loopback_rccl/ that lets n ranks share the one GPU of a test box).
+// Test hooks (never set in production): MVS_COMM_ALLOW_SAME_DEVICE=1 accepts a device listed more than once (RCCL itself refuses that;
+// the loopback library does not); MVS_COMM_TEST_FAIL_RANK=r makes rank r fail in its local phase, as a device allocation would;
+// MVS_COMM_ALLREDUCE=1 runs the scatter mode as the all-reduce pipeline.
 #include "mvs_internal.hpp"
 
 #include <dlfcn.h>
@@ -71,8 +81,9 @@ struct Rccl {
         AllGather = (decltype(AllGather))sym("ncclAllGather");
         AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        return CommInitAll && CommDestroy && CommAbort && ReduceScatter && AllGather && AllReduce && GetErrorString;
+        return usable();
     }
+    bool usable() const { return CommInitAll && CommDestroy && CommAbort && ReduceScatter && AllGather && AllReduce && GetErrorString; }
 };
 
 }  // namespace
@@ -137,7 +148,8 @@ mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height)
         comm_fail(nullptr, MVS_EINVAL, "mvs_comm_create: need 1..64 devices (n = %d)", n);
         return nullptr;
     }
-    for (int i = 0; i < n; i++)
+    const char *same = getenv("MVS_COMM_ALLOW_SAME_DEVICE");  // test hook: n ranks on one GPU (with the loopback collective library)
+    for (int i = 0; i < n && !(same && atoi(same) != 0); i++)
         for (int j = 0; j < i; j++)
             if (devices[i] == devices[j]) {
                 comm_fail(nullptr, MVS_EINVAL, "mvs_comm_create: device %d listed twice (one rank per GPU)", devices[i]);
@@ -157,7 +169,9 @@ mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height)
     c->parts.resize(n);
     c->comm_stream.assign(n, nullptr);
     c->events.resize(n);
-    if (!c->rccl.load()) {  // before anything touches a GPU: the error path of a missing library must not need one
+    // before anything touches a GPU (the error path of a missing library must not need one).  Only the view-sharded modes need RCCL:
+    // a library named explicitly must load; the default one may be absent -- rows mode works without, a views mode then says why not
+    if (!c->rccl.load() && getenv("MVS_RCCL_LIBRARY")) {
         comm_fail(nullptr, MVS_EHIP, "mvs_comm_create: %s", c->rccl.error.c_str());
         mvs_comm_destroy(c);
         return nullptr;
@@ -171,16 +185,22 @@ mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height)
         }
         c->ctx.push_back(x);
     }
-    c->comms.assign(n, nullptr);
-    const ncclResult_t r = c->rccl.CommInitAll(c->comms.data(), n, devices);
-    if (r != ncclSuccess) {
-        comm_fail(nullptr, MVS_EHIP, "mvs_comm_create: ncclCommInitAll failed: %s", c->rccl.GetErrorString(r));
-        c->comms.clear();
-        mvs_comm_destroy(c);
-        return nullptr;
-    }
     snprintf(c->err, sizeof(c->err), "no error");
     return c;
+}
+
+// the RCCL communicators, created by the first sweep that exchanges anything (rows mode never does)
+static int comm_init_rccl(mvs_comm *c)
+{
+    if (!c->comms.empty()) return MVS_OK;
+    if (!c->rccl.usable()) return comm_fail(c, MVS_EHIP, "mvs_sweep_sharded: the view-sharded modes need RCCL: %s", c->rccl.error.c_str());
+    c->comms.assign(c->n, nullptr);
+    const ncclResult_t r = c->rccl.CommInitAll(c->comms.data(), c->n, c->devices.data());
+    if (r != ncclSuccess) {
+        c->comms.clear();
+        return comm_fail(c, MVS_EHIP, "mvs_sweep_sharded: ncclCommInitAll failed: %s", c->rccl.GetErrorString(r));
+    }
+    return MVS_OK;
 }
 
 void mvs_comm_destroy(mvs_comm *c)
@@ -211,6 +231,7 @@ int mvs_comm_set_mode(mvs_comm *c, int mode)
 {
     if (!c) return MVS_EINVAL;
     if (mode != MVS_SHARD_ROWS && mode != MVS_SHARD_VIEWS && mode != MVS_SHARD_VIEWS_SCATTER) return comm_fail(c, MVS_EINVAL, "mvs_comm_set_mode: unknown mode %d", mode);
+    if (mode != MVS_SHARD_ROWS && !c->rccl.usable()) return comm_fail(c, MVS_EHIP, "mvs_comm_set_mode: the view-sharded modes need RCCL: %s", c->rccl.error.c_str());
     c->mode = mode;
     return MVS_OK;
 }
@@ -245,6 +266,12 @@ int mvs_sweep_sharded(mvs_comm *c, const float main_cam[16], const uint8_t *main
     const int W = c->W, H = c->H;
     const size_t P = (size_t)W * H;
     const bool rows = c->mode == MVS_SHARD_ROWS;
+    if (!rows) {
+        const int e = comm_init_rccl(c);
+        if (e) return e;
+    }
+    const char *fail_rank_env = getenv("MVS_COMM_TEST_FAIL_RANK");  // test hook: this rank gives up in its local phase
+    const int test_fail_rank = fail_rank_env ? atoi(fail_rank_env) : -1;
     // plane slices of equal size: reduce-scatter; otherwise (or with the test hook MVS_COMM_ALLREDUCE set) the all-reduce pipeline
     const bool scatter = c->mode == MVS_SHARD_VIEWS_SCATTER && nplanes % n == 0 && getenv("MVS_COMM_ALLREDUCE") == nullptr;
     const int slice_planes = nplanes / n;
@@ -285,6 +312,7 @@ int mvs_sweep_sharded(mvs_comm *c, const float main_cam[16], const uint8_t *main
         // ---- phase 1: everything local (inputs, allocations; in rows mode the whole job) ----
         [&]() {
             if (hipSetDevice(c->devices[r]) != hipSuccess) return fail_here(MVS_EHIP, "hipSetDevice", "failed");
+            if (r == test_fail_rank) return fail_here(MVS_ENOMEM, "test hook", "MVS_COMM_TEST_FAIL_RANK names this rank");
             int e;
             st = x->stream;
             if ((e = mvs_sweep_set_main(x, main_cam, main_hw))) return fail_here(e, "mvs_sweep_set_main", mvs_last_error(x));

@@ -1,0 +1,127 @@
+"""mvs_sweep_sharded with n = 2, 4, 8 ranks on the ONE GPU of a test box.  RCCL refuses two ranks per device, so
+the seven collective entry points mvs_comm resolves with dlopen come from tests/loopback_rccl (a thread barrier + kernels between
+same-device buffers, selected through the MVS_RCCL_LIBRARY hook) and MVS_COMM_ALLOW_SAME_DEVICE=1 lifts the one-rank-per-GPU check.
+What this executes for the first time with more than one rank: the host barrier and the shared error flag, the plane-group all-reduce
+pipeline on the second stream, reduce-scatter slicing + partial selection + all-gather + merge, row bands, view shards that are empty
+(more ranks than views), and the abort path.  It measures nothing: no scaling curve exists until a multi-GPU node runs the real library
+(tests/test_comm_gpu.py keeps those cases, skipping here)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mvs_amd
+from mvs_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOOPBACK = os.path.join(ROOT, "tests", "loopback_rccl", "_build", "libloopback_rccl.so")
+
+
+@pytest.fixture
+def loopback(monkeypatch):
+    assert os.path.exists(LOOPBACK), "build it: make -C tests/loopback_rccl (or __graft_entry__.build())"
+    monkeypatch.setenv("MVS_RCCL_LIBRARY", LOOPBACK)
+    monkeypatch.setenv("MVS_COMM_ALLOW_SAME_DEVICE", "1")
+
+
+_SCENES = {}
+
+
+def _scene(W, H, D, V):
+    key = (W, H, D, V)
+    if key not in _SCENES:
+        main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.2)
+        with mvs_amd.Context(W, H) as ctx:
+            d1, c1 = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_cost=True)
+        _SCENES[key] = (main_cam, main_img, side_cams, sides, d1, c1)
+    return _SCENES[key]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_every_mode_with_n_ranks_equals_the_single_gpu_sweep_at_c2_size(loopback, n):
+    """c2's size (1280 x 720, 64 planes, 8 views): depth and best cost bit-identical to mvs_sweep in rows / views x plane groups {1, 4} /
+    views_scatter"""
+    W, H, D, V = 1280, 720, 64, 8
+    main_cam, main_img, side_cams, sides, d1, c1 = _scene(W, H, D, V)
+    with mvs_amd.Comm([0] * n, W, H) as comm:
+        assert comm.size() == n
+        for mode, groups in (("rows", None), ("views", 1), ("views", 4), ("views_scatter", None)):
+            comm.set_mode(mode, groups)
+            d, c = comm.sweep(main_cam, main_img, side_cams, sides, D)
+            np.testing.assert_array_equal(d, d1, err_msg="%s n=%d" % (mode, n))
+            np.testing.assert_array_equal(c, c1, err_msg="%s n=%d" % (mode, n))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("sampler", ["fixed", "exact"])
+def test_ragged_shards(loopback, sampler):
+    """more ranks than views (empty view shards), a plane count that is no multiple of the ranks (scatter falls back to the all-reduce
+    pipeline), a height that leaves the last row band short and some ranks without rows, both samplers"""
+    W, H, D, V = 320, 72, 40, 3
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
+    with mvs_amd.Context(W, H, sampler=sampler) as ctx:
+        d1, c1 = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_cost=True)
+        d0, c0 = ctx.sweep(main_cam, main_img, side_cams[:0], [], D, want_cost=True)
+    for n in (2, 4, 8):
+        with mvs_amd.Comm([0] * n, W, H, sampler=sampler) as comm:
+            for mode, groups in (("rows", None), ("views", 2), ("views", 64), ("views_scatter", None)):
+                comm.set_mode(mode, groups)
+                d, c = comm.sweep(main_cam, main_img, side_cams, sides, D)
+                np.testing.assert_array_equal(d, d1, err_msg="%s n=%d" % (mode, n))
+                np.testing.assert_array_equal(c, c1, err_msg="%s n=%d" % (mode, n))
+                d, c = comm.sweep(main_cam, main_img, side_cams[:0], [], D)   # no views at all
+                np.testing.assert_array_equal(d, d0)
+
+
+def _worker(n, mode, groups, env_extra, timeout=300):
+    env = dict(os.environ, MVS_RCCL_LIBRARY=LOOPBACK, MVS_COMM_ALLOW_SAME_DEVICE="1", **env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "comm_loopback_worker.py"), str(n), mode, str(groups)], env=env, capture_output=True, text=True,
+                         timeout=timeout)   # a hang is a TimeoutExpired here: the failure this test exists to catch
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode,groups", [("rows", 1), ("views", 4), ("views_scatter", 1)])
+def test_a_rank_that_fails_locally_makes_every_rank_return(mode, groups):
+    """one rank gives up in its local phase (as a failed device allocation would): nobody enters a collective, the call returns that rank's
+    error within the timeout, and the communicator is still usable afterwards"""
+    assert os.path.exists(LOOPBACK)
+    r = _worker(4, mode, groups, {"MVS_COMM_TEST_FAIL_RANK": "2"})
+    assert "rank 2" in r["first"] and "MVS_COMM_TEST_FAIL_RANK" in r["first"], r
+    assert r["first_s"] < 60.0, r
+    assert "rank 2" in r["second"], r   # the hook is still set: the same error again, not a hang and not MVS_ESTATE
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode,groups,fail", [("views", 4, "allreduce:1:2"), ("views", 1, "allreduce:0:1"), ("views_scatter", 1, "reducescatter:3:1"),
+                                              ("views_scatter", 1, "allgather:2:1")])
+def test_a_failing_collective_aborts_every_rank(mode, groups, fail):
+    """a collective returns an error on one rank while the others are waiting inside theirs: the abort path unblocks them, the call
+    returns an error within the timeout, and the communicator refuses further work (MVS_ESTATE: create a new one)"""
+    assert os.path.exists(LOOPBACK)
+    r = _worker(4, mode, groups, {"LOOPBACK_RCCL_FAIL": fail})
+    assert r["first"] != "ok" and "nccl" in r["first"], r
+    assert r["first_s"] < 60.0, r
+    assert "aborted" in r["second"], r
+
+
+def test_rows_mode_needs_no_collective_library(monkeypatch):
+    """the default mode exchanges nothing, so a communicator comes up and sweeps without any RCCL communicator being created
+    (ncclCommInitAll is deferred to the first sweep that exchanges something): two ranks on one device -- which RCCL itself would refuse at
+    init -- are fine in rows mode"""
+    W, H, D, V = 320, 200, 32, 4
+    main_cam, main_img, side_cams, sides, d1, c1 = _scene(W, H, D, V)
+    monkeypatch.setenv("MVS_COMM_ALLOW_SAME_DEVICE", "1")
+    monkeypatch.delenv("MVS_RCCL_LIBRARY", raising=False)
+    with mvs_amd.Comm([0, 0], W, H) as comm:   # real RCCL loaded (torch has it), never initialised: two ranks on one device are fine in rows mode
+        d, c = comm.sweep(main_cam, main_img, side_cams, sides, D)
+        np.testing.assert_array_equal(d, d1)
+        np.testing.assert_array_equal(c, c1)
