@@ -79,7 +79,7 @@ def cpu_baseline(cfg, main_cam, main_img, side_cams, sides, sampler="fixed"):
     }
 
 
-def pmc_traffic(kernel_prefix, config):
+def pmc_traffic(kernel_prefix, config, tag=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*/pmc_*.json, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs;
     FETCH_SIZE doubled for 16-byte-per-lane streams as MI355X_MICROARCH.md prescribes).  None if absent."""
@@ -91,6 +91,8 @@ def pmc_traffic(kernel_prefix, config):
         m = re.search(r"profiles[/\\]r(\d+)[/\\]pmc_[^_]+_v(\d+)", path)
         return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_%s_*.json" % config)), key=version_key):
+        if tag is not None and tag not in os.path.basename(path):   # e.g. "general": the summaries taken with --general-cameras
+            continue
         try:
             rec = json.load(open(path))
             for name, c in rec.get("kernels", {}).items():
@@ -524,6 +526,43 @@ def main():
         sustained = {"steps": 100 * len(blocks), "seconds": total, "ms_per_step": total / (100 * len(blocks)) * 1e3,
                      "first_100_steps_ms": blocks[0] / 100 * 1e3, "last_100_steps_ms": blocks[-1] / 100 * 1e3}
 
+    # what a NEW (main, views) set costs when its raw u8 frames are already in HBM: view matrices, quad images
+    # straight from the raw frames, region plan and the sweep, timed together per step -- no PCIe, nothing prepared outside the timed loop
+    cold = None
+    if world == 1 and not args.no_extras:
+        raw_main = torch.as_tensor(np.ascontiguousarray(main_img), device="cuda")
+        raw_sides = [torch.as_tensor(np.ascontiguousarray(s_), device="cuda") for s_ in sides]
+        side_ptrs = [t_.data_ptr() for t_ in raw_sides]
+        with mvs_amd.Context(W, H, local_rank, sampler=args.sampler) as cctx:
+            cctx.set_stream(stream.cuda_stream)
+            cctx.sweep_use_volume(vol_t.data_ptr(), vol_t.numel() * 4)   # (the primary context is idle meanwhile)
+            cctx.sweep_set_planes(D)
+
+            def cold_once():
+                cctx.sweep_set_main_device(main_cam, raw_main.data_ptr())
+                cctx.sweep_set_views_device(side_cams, side_ptrs)
+                cctx.sweep_run(0, V, both)
+            for _ in range(5):
+                cold_once()
+            torch.cuda.synchronize()
+            n_cold = max(10, args.steps)
+            t1 = time.perf_counter()
+            for _ in range(n_cold):
+                cold_once()
+            torch.cuda.synchronize()
+            cold_ms = (time.perf_counter() - t1) / n_cold * 1e3
+            cold_crc = zlib.crc32(np.ascontiguousarray(cctx.sweep_fetch()[0]).tobytes())
+            cold_shape = cctx.plan_shape()
+        if cold_crc != crc1:
+            raise SystemExit("cold step: depth crc %08x differs from the resident sweep's %08x" % (cold_crc, crc1))
+        cold_bytes = float(P) * (V + 8.0 * D + 9.0)
+        cold = {"ms": cold_ms, "samples_per_s": float(P) * D * V / (cold_ms * 1e-3), "frac": cold_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "kernel": {1: "sweep_tiled", 2: "sweep_tiled", 3: "sweep_fx_tiled", 4: "sweep_fx_rect"}.get(cold_shape),
+                "includes": "mvs_sweep_set_main_device + mvs_sweep_set_views_device (view matrices, quad images of all views from the raw u8 frames in one "
+                            "pass) + region plan (with its one host read-back) + sweep with depth selection + combine_best; raw frames resident in HBM, no PCIe",
+                "depth_crc32": cold_crc}
+        del raw_main, raw_sides
+
     # the one-call entry (host frames in, host depth out: PCIe, padding and planning inside the call) -- reported beside, never as `value`
     onecall_ms = None
     if world == 1 and not args.no_extras:
@@ -578,7 +617,8 @@ def main():
                          "bound_note": "the rectified-view kernel issues ~3.4 vector and ~3.3 scalar instructions per wave-sample; what bounds it is in DESIGN.md section 4 and profiles/",
                          "valu_utilisation": traffic["valu_utilisation"] if traffic else None,   # from the same PMC summary as `traffic`
                          "valu_utilisation_note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel cycles) from the PMC summary named in traffic_source",
-                         "bytes_per_launch": sweep_bytes, "bytes_formula": "P (V_loc + 8 D + 9), SURVEY.md 8(d)", "ms_per_launch": sweep_ms},
+                         "bytes_per_launch": sweep_bytes, "bytes_formula": "P (V_loc + 8 D + 9), SURVEY.md 8(d)", "ms_per_launch": sweep_ms,
+                         "ms_per_launch_covers": sweep_kernel + " + combine_best (one HIP-event pair around both launches, averaged over the timed steps)"},
             "kernels": {"sweep_ms": sweep_ms, "argmin_ms": argmin_ms if separate else None,
                         "argmin_GBps": argmin_bytes / (argmin_ms * 1e-3) / 1e9 if argmin_ms > 0 else None,
                         "depth_selection": "argmin_volume pass" if separate else "fused into " + sweep_kernel,
@@ -588,10 +628,15 @@ def main():
             "depth_crc32": primary["crc"],   # equal across N for the strong-scaling shardings (asserted against the in-process single-GPU run)
             "depth_crc32_single_gpu": crc1,
         }
+        if cold is not None:
+            out["cold_step"] = cold
         if general_ms is not None:
+            gtraffic = pmc_traffic(general_kernel, args.config, tag="general") if general_kernel else None
             out["general_camera_path"] = {
                 "ms_per_step": general_ms, "samples_per_s": float(P) * D * V / (general_ms * 1e-3), "kernel": general_kernel,
                 "roofline_frac": sweep_bytes / (general_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "roofline_traffic": gtraffic["bytes"] if gtraffic else None, "roofline_traffic_source": gtraffic["source"] if gtraffic else None,
+                "valu_utilisation": gtraffic["valu_utilisation"] if gtraffic else None,
                 "note": "same frames, side cameras turned by 12 mrad about two axes: no view is rectified any more, the general tiled kernel "
                         "with its per-sample reciprocal runs -- the rate for rotated / forward-moving cameras such as the bundled tracks "
                         "(timing only; DESIGN.md section 4)"}

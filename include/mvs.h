@@ -159,6 +159,12 @@ int mvs_sweep_sampler(const mvs_ctx *ctx);
 int mvs_sweep_set_main(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw);
 int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames);
 int mvs_sweep_set_planes(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi);
+/* The same with frames that already live in the memory of the context's GPU (a decoder's output, a previous stage's result): H*W u8,
+ * tightly packed.  Stream-ordered like a kernel launch: nothing crosses PCIe, nothing synchronises, and the frames are read by work
+ * queued on the context's stream -- they must stay unchanged until that work has run (mvs_synchronize, or the caller's own stream
+ * order when mvs_set_stream shares a stream).  The side views' quad images are written straight from the raw frames in one pass. */
+int mvs_sweep_set_main_device(mvs_ctx *ctx, const float main_cam[16], const void *main_dev);
+int mvs_sweep_set_views_device(mvs_ctx *ctx, int nviews, const float *side_cams, const void *const *side_frames_dev);
 
 #define MVS_SWEEP_VOLUME 1u       /* materialise the packed cost volume in HBM */
 #define MVS_SWEEP_FUSED_ARGMIN 2u /* select depth inside the sweep kernel (no volume read-back pass) */
@@ -221,7 +227,7 @@ int mvs_sweep_view_matrices(mvs_ctx *ctx, float *q_out);
 /* ---- a sequence on one GPU: frames uploaded once, several main frames per launch (recon.cpp:65-117) -------------------------
  * The reference sweeps every chosen main frame against a handful of neighbouring frames; through mvs_sweep each frame of the
  * sequence crosses PCIe once per main frame that uses it, and a 640 x 480 frame leaves most of the chip idle.  The frame store keeps
- * every frame of the sequence resident (raw, wrap-padded and as quad image: 9 bytes per pixel); mvs_sweep_batch then sweeps nmain
+ * every frame of the sequence resident (raw and as quad image: 5 bytes per pixel); mvs_sweep_batch then sweeps nmain
  * main frames, each against its own nside side views -- all of them slots of the store -- in ONE launch of the general tiled kernel
  * (fixed sampler) and returns the nmain depth maps (and best costs) tightly packed.  Results are bit-identical to mvs_sweep on the
  * same frames and cameras.
@@ -232,6 +238,15 @@ int mvs_sweep_view_matrices(mvs_ctx *ctx, float *q_out);
  *                                    depth_out[nmain*H*W], cost_out nullable; synchronises */
 int mvs_frame_store(mvs_ctx *ctx, int capacity);
 int mvs_frame_upload(mvs_ctx *ctx, int slot, const uint8_t *frame_hw);
+int mvs_frame_upload_device(mvs_ctx *ctx, int slot, const void *frame_dev); /* the frame is already on the context's GPU (stream-ordered) */
+/* ONE main view over the frame store -- the resident-handle form of mvs_sweep for a caller that keeps its sequence on the device
+ * (the loop of recon.cpp:65-117 through RenderHIP): main and side views are slots, nothing is uploaded, copied or
+ * re-prepared (the quad images were built by mvs_frame_upload); the call pays the view matrices, the region plan, the sweep with depth
+ * selection and the download of depth_hw (and cost_hw, nullable).  Bit-identical to mvs_sweep on the same frames and cameras; fixed
+ * sampler; synchronises.  Afterwards the context's staged state (mvs_sweep_run, mvs_sweep_depth_device ...) refers to these views
+ * until the next setter; re-uploading one of the slots in between changes the frame under it. */
+int mvs_sweep_handles(mvs_ctx *ctx, int main_slot, const float main_cam[16], int nside, const int *side_slots, const float *side_cams /* nside*16 */,
+                      int nplanes, float z_lo, float z_hi, float *depth_hw, float *cost_hw);
 int mvs_sweep_batch(mvs_ctx *ctx, int nmain, const int *main_slots, const float *main_cams, int nside, const int *side_slots,
                     const float *side_cams, int nplanes, float z_lo, float z_hi, float *depth_out, float *cost_out);
 

@@ -55,6 +55,14 @@ struct mvs_ctx {
     mvs::DevBuf side_quads;          // fixed sampler: quad image of every padded side view (4 bytes per texel), built by mvs_sweep_set_views
     mvs::DevBuf side_quads16;        // exact sampler: f16 quad image (8 bytes per texel), built on demand by ensure_quads16
     bool quads16_valid = false;
+    bool pads_valid = false;         // side_pads (wrap-padded u8 frames) matches the current quad images: rebuilt on demand by ensure_pads
+    mvs::DevBuf frame_ptrs;          // mvs_sweep_set_views_device: device table of the caller's frame pointers
+    std::vector<const uint8_t *> frame_ptrs_host;
+    // mvs_sweep_handles: the current main / side views are slots of the frame store (no copies: the kernels read the store)
+    bool views_in_store = false;
+    int main_store_slot = -1;
+    mvs::DevBuf view_slots;          // device: slot of view v
+    std::vector<int> view_slots_host;
     mvs::DevBuf fx_lut;              // fixed sampler: 32 x 32 table of packed 8-bit bilinear weights
     int plan_shape = 2;              // what the plan was made for: 1 = exact sampler, 2 px x 32 planes; 2 = exact, 4 px x 16 planes; 3 = fixed sampler
     bool plan_forced = false;        // plan made with the 4 x 16 shape forced (timing experiments)
@@ -90,8 +98,8 @@ struct mvs_ctx {
     mvs::DevBuf frame_buf;           // mvs_process_frame: frames, depth, warped image, flows of one main frame
     mvs::DevBuf best_parts;          // plane-split sweeps: partial (best cell, best index) per split and pixel
     // frame store (mvs_frame_store / mvs_frame_upload / mvs_sweep_batch): the frames of a sequence, uploaded once, each as raw frame,
-    // wrap-padded frame and quad image; main and side views of the batched sweep are slots of it
-    mvs::DevBuf store_raw, store_pads, store_quads, batch_buf;
+    // quad image (5 bytes per pixel); main and side views of the batched sweep are slots of it
+    mvs::DevBuf store_raw, store_quads, batch_buf;
     int store_cap = 0;
     std::vector<unsigned char> store_have;
     // the launch-bound flow pipelines (~350 small kernels for Farneback) are captured once into a hipGraph per
@@ -150,9 +158,10 @@ void plane_table(int D, float z_lo, float z_hi, float *z);
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
 // the sweep's input setters with the final synchronisation optional (context.hip; mvs_sweep queues all of them and waits once)
-int sweep_set_main_impl(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, bool sync);
-int sweep_set_views_impl(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames, bool sync, bool defer_frames = false);
-int sweep_upload_frames_impl(mvs_ctx *ctx, const uint8_t *const *side_frames);
+int sweep_set_main_impl(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, bool sync, bool device = false);
+int sweep_set_views_impl(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames, bool sync, bool defer_frames = false, bool device = false);
+int sweep_upload_frames_impl(mvs_ctx *ctx, const uint8_t *const *side_frames, bool device = false);
+int ensure_pads(mvs_ctx *ctx);     // wrap-padded u8 frames of the current side views, rebuilt from the quad images when a path needs them
 int sweep_rect_plan(mvs_ctx *ctx);   // sweep_rect.hip: tables + eligibility of the rectified kernel for the current fixed-sampler plan
 struct SweepParams;
 int ensure_quads16(mvs_ctx *ctx);  // exact sampler's f16 quad image of the current side views  // the deferred half of sweep_set_views_impl

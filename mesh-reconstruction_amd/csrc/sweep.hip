@@ -857,6 +857,7 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
             ctx->plan_shape = 3;
             ctx->plan_valid = true;
         }
+        if (generic && (rc = ensure_pads(ctx))) return rc;  // the un-tiled kernel gathers single texels of the padded frames
         // (a run over zero views writes empty cells: the general kernel's job -- the rectified one iterates over regions)
         const bool rect = ctx->rect_ok && !generic && ctx->V > 0 && view_count > 0 && !(flags & MVS_SWEEP_NO_RECT);
         if (!rect && !generic && ctx->V > 0 && !ctx->fx_general_planned) {  // left out while the rectified kernel served the plan; before
@@ -886,6 +887,7 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
         return MVS_OK;
     }
     if (ctx->plan_valid && ctx->plan_shape == 3) ctx->plan_valid = false;  // the plan in memory belongs to the fixed sampler
+    if ((rc = ensure_pads(ctx))) return rc;  // the exact sampler's generic regions and its un-tiled kernel gather from the padded frames
     if (!generic && (rc = ensure_quads16(ctx))) return rc;
 
     // thread shape of the tiled kernel (see the constants at the top): 2 pixels x 32 planes unless the planner finds
@@ -1149,6 +1151,67 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
         MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     join.armed = false;
+    return MVS_OK;
+}
+
+// One main view whose frames are already slots of the frame store (mvs_frame_store / mvs_frame_upload): the loop of recon.cpp:65-117
+// with the sequence's frames cached on the device.  No frame crosses PCIe and none is copied or re-prepared -- the quad images were
+// built at upload; the call pays the view matrices, the region plan, the sweep with depth selection and the depth download.
+int mvs_sweep_handles(mvs_ctx *ctx, int main_slot, const float main_cam[16], int nside, const int *side_slots, const float *side_cams, int nplanes, float z_lo,
+                      float z_hi, float *depth_hw, float *cost_hw)
+{
+    if (!ctx) return MVS_EINVAL;
+    if (!main_cam || !depth_hw || nside < 0 || nside > 255 || (nside > 0 && (!side_slots || !side_cams)))
+        return fail(ctx, MVS_EINVAL, "mvs_sweep_handles: bad arguments (nside=%d: 0..255 side views)", nside);
+    if (nplanes < 1 || nplanes > 4096) return fail(ctx, MVS_EINVAL, "mvs_sweep_handles: nplanes=%d out of range 1..4096", nplanes);
+    if (ctx->sampler != MVS_SAMPLER_FIXED) return fail(ctx, MVS_EINVAL, "mvs_sweep_handles: implemented for MVS_SAMPLER_FIXED (the library default)");
+    if (ctx->W > 16383 || ctx->H > 16383) return fail(ctx, MVS_EINVAL, "mvs_sweep_handles: images of up to 16383 x 16383");
+    if (main_slot < 0 || main_slot >= ctx->store_cap || !ctx->store_have[main_slot]) return fail(ctx, MVS_EINVAL, "mvs_sweep_handles: main slot %d holds no frame", main_slot);
+    for (int v = 0; v < nside; v++)
+        if (side_slots[v] < 0 || side_slots[v] >= ctx->store_cap || !ctx->store_have[side_slots[v]])
+            return fail(ctx, MVS_EINVAL, "mvs_sweep_handles: side view %d: slot %d holds no frame", v, side_slots[v]);
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->W, H = ctx->H;
+    int rc;
+    // the context's sweep inputs become references into the store (whatever fails below leaves it without views)
+    ctx->have_views = false;
+    ctx->plan_valid = false;
+    ctx->quads16_valid = false;
+    ctx->pads_valid = false;
+    struct DropOnError {
+        mvs_ctx *c;
+        bool armed = true;
+        ~DropOnError()
+        {
+            if (!armed) return;
+            (void)hipStreamSynchronize(c->stream);
+            c->have_views = false;
+            c->views_in_store = false;
+            c->plan_valid = false;
+        }
+    } drop{ctx};
+    memcpy(ctx->main_cam, main_cam, sizeof(float) * 16);
+    ctx->main_store_slot = main_slot;
+    ctx->have_main = true;
+    ctx->pad_pitch = ((W + 2 + 63) / 64) * 64;
+    ctx->pad_slab = (size_t)ctx->pad_pitch * (H + 2);
+    ctx->V = 0;
+    ctx->q_host.assign((size_t)nside * 12, 0.f);
+    ctx->view_slots_host.assign(side_slots, side_slots + nside);
+    if (nside > 0) {
+        if ((rc = ensure(ctx, ctx->qmats, sizeof(float) * 12 * nside))) return rc;
+        if ((rc = ensure(ctx, ctx->view_slots, sizeof(int) * 256))) return rc;
+        for (int v = 0; v < nside; v++) view_matrix(ctx->main_cam, side_cams + 16 * v, W, H, ctx->q_host.data() + 12 * v);
+        MVS_HIP(ctx, hipMemcpyAsync(ctx->qmats.ptr, ctx->q_host.data(), sizeof(float) * 12 * nside, hipMemcpyHostToDevice, ctx->stream));
+        MVS_HIP(ctx, hipMemcpyAsync(ctx->view_slots.ptr, ctx->view_slots_host.data(), sizeof(int) * nside, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->V = nside;
+    ctx->views_in_store = nside > 0;
+    ctx->have_views = true;
+    if ((rc = sweep_set_planes_impl(ctx, nplanes, z_lo, z_hi, false))) return rc;
+    if ((rc = mvs_sweep_run(ctx, 0, nside, MVS_SWEEP_FUSED_ARGMIN))) return rc;  // plans on demand (rectified or general kernel)
+    if ((rc = mvs_sweep_fetch(ctx, depth_hw, cost_hw, nullptr, nullptr))) return rc;
+    drop.armed = false;
     return MVS_OK;
 }
 

@@ -967,7 +967,7 @@ int sweep_batch_impl(mvs_ctx *ctx, int nmain, const int *main_slots, const float
         SweepParams &p = ((SweepParams *)(host.data() + o_params))[m];
         memset(&p, 0, sizeof(p));
         p.main_img = (const uint8_t *)ctx->store_raw.ptr + P * main_slots[m];
-        p.pads = (const uint8_t *)ctx->store_pads.ptr;
+        p.pads = nullptr;  // (the tiled kernel reads quad images only)
         p.pad_slab = slab;
         p.quads = (const uint32_t *)ctx->store_quads.ptr;
         p.quads16 = nullptr;

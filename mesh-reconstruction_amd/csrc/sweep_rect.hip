@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void plan_rect_pack(SweepParams p, RectTables 
         uint32_t *rec = rt.yr + (size_t)tid * 8;
         rec[0] = f[0] | (f[1] << 16);
         rec[1] = f[2] | (f[3] << 16);
-        rec[2] = 4u * ((uint32_t)p.pad_slab * (uint32_t)v + (uint32_t)(org * p.pitch));
+        rec[2] = 4u * ((uint32_t)p.pad_slab * (uint32_t)(p.view_slot ? p.view_slot[v] : v) + (uint32_t)(org * p.pitch));  // (frame-store slot: mvs_sweep_handles)
         rec[3] = (any ? (uint32_t)ext : 0u) | ((uint32_t)org << 8);
         rec[4] = masks;
         rec[5] = rec[6] = rec[7] = 0u;
@@ -836,7 +836,7 @@ int sweep_rect_plan(mvs_ctx *ctx)
     for (int v = 0; v < ctx->V; v++)
         if (!rect_view_host(ctx->q_host.data() + 12 * v)) return MVS_OK;  // a view that is not rectified: the general kernel
     // the kernel addresses the quad images through one buffer resource with 32-bit byte offsets
-    if ((unsigned long long)ctx->pad_slab * (unsigned long long)ctx->V * 4ull >= (1ull << 32)) return MVS_OK;
+    if ((unsigned long long)ctx->pad_slab * (unsigned long long)(ctx->views_in_store ? ctx->store_cap : ctx->V) * 4ull >= (1ull << 32)) return MVS_OK;
     SweepParams q;
     fill_params(ctx, q, 0, ctx->V, RX_TILE_H, RX_PC);
     int rc;
@@ -873,7 +873,7 @@ int sweep_rect_plan(mvs_ctx *ctx)
     MVS_HIP(ctx, hipGetLastError());
     // the cold block (device memory, after the tables)
     RectCold cold;
-    cold.main_img = (const uint8_t *)ctx->main_img.ptr;
+    cold.main_img = main_image_ptr(ctx);
     cold.xt = rt.xt;
     cold.yt = rt.yt;
     cold.lut = (const uint32_t *)ctx->fx_lut.ptr;
@@ -915,7 +915,7 @@ int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsign
     RectCold *cold_dev = (RectCold *)((uint32_t *)ctx->rect_tab.ptr + rect_table_dwords(p));
     RectCold cold;
     memcpy(&cold, ctx->rect_cold_host.data(), sizeof(RectCold));
-    cold.main_img = (const uint8_t *)ctx->main_img.ptr;
+    cold.main_img = main_image_ptr(ctx);
     cold.depth = (float *)ctx->depth.ptr;
     cold.cost = (float *)ctx->cost.ptr;
     cold.index = (int *)ctx->index.ptr;

@@ -146,13 +146,19 @@ __device__ __forceinline__ int grouped_tile(int bid, int tiles_x, int tiles_y)
     return (tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : -1;
 }
 
+// the main view: the context's own copy, or a slot of the frame store (mvs_sweep_handles)
+inline const uint8_t *main_image_ptr(const mvs_ctx *ctx)
+{
+    return ctx->main_store_slot >= 0 ? (const uint8_t *)ctx->store_raw.ptr + (size_t)ctx->W * ctx->H * (size_t)ctx->main_store_slot : (const uint8_t *)ctx->main_img.ptr;
+}
+
 // host: launch parameters of the whole image / all planes; callers narrow the ranges
 inline int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount, int tile_h, int pc)
 {
-    p.main_img = (const uint8_t *)ctx->main_img.ptr;
-    p.pads = (const uint8_t *)ctx->side_pads.ptr;
+    p.main_img = main_image_ptr(ctx);
+    p.pads = ctx->pads_valid ? (const uint8_t *)ctx->side_pads.ptr : nullptr;  // rebuilt on demand (ensure_pads) by the paths that gather single texels
     p.pad_slab = ctx->pad_slab;
-    p.quads = (const uint32_t *)ctx->side_quads.ptr;
+    p.quads = ctx->views_in_store ? (const uint32_t *)ctx->store_quads.ptr : (const uint32_t *)ctx->side_quads.ptr;
     p.quads16 = (const uint2 *)ctx->side_quads16.ptr;
     p.pitch = ctx->pad_pitch;
     p.W = ctx->W;
@@ -188,7 +194,7 @@ inline int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount, int til
     p.cps = p.nchunks;
     p.part = nullptr;
     p.plan_stats = nullptr;
-    p.view_slot = nullptr;
+    p.view_slot = ctx->views_in_store ? (const int *)ctx->view_slots.ptr : nullptr;  // mvs_sweep_handles: view v is slot view_slot[v] of the frame store
     p.debug = 0;
     return MVS_OK;
 }

@@ -56,6 +56,8 @@ ABI = [
     ("mvs_sweep_set_main", _i, [_vp, _fp, _u8p]),
     ("mvs_sweep_set_views", _i, [_vp, _i, _fp, C.POINTER(_u8p)]),
     ("mvs_sweep_set_planes", _i, [_vp, _i, _f, _f]),
+    ("mvs_sweep_set_main_device", _i, [_vp, _fp, _vp]),
+    ("mvs_sweep_set_views_device", _i, [_vp, _i, _fp, C.POINTER(_vp)]),
     ("mvs_sweep_run", _i, [_vp, _i, _i, C.c_uint]),
     ("mvs_sweep_run_planes", _i, [_vp, _i, _i, _i, _i, C.c_uint]),
     ("mvs_sweep_plane_granularity", _i, []),
@@ -68,6 +70,8 @@ ABI = [
     ("mvs_texture_filter", _i, [_vp]),
     ("mvs_frame_store", _i, [_vp, _i]),
     ("mvs_frame_upload", _i, [_vp, _i, _vp]),
+    ("mvs_frame_upload_device", _i, [_vp, _i, _vp]),
+    ("mvs_sweep_handles", _i, [_vp, _i, _fp, _i, _vp, _vp, _i, _f, _f, _vp, _vp]),
     ("mvs_sweep_batch", _i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, C.c_float, C.c_float, _vp, _vp]),
     ("mvs_sweep_argmin", _i, [_vp]),
     ("mvs_sweep_refine_depth", _i, [_vp]),
@@ -395,6 +399,19 @@ class Context:
         self._check(self.lib.mvs_sweep_set_planes(self.h, int(nplanes), float(z_lo), float(z_hi)))
         self.D = int(nplanes)
 
+    def sweep_set_main_device(self, main_cam, main_ptr):
+        """mvs_sweep_set_main_device: main_ptr = address of H*W u8 in the memory of the context's GPU (e.g. tensor.data_ptr()); stream-ordered"""
+        cam = _f32(main_cam, (4, 4))
+        self._check(self.lib.mvs_sweep_set_main_device(self.h, _ptr(cam, _fp), C.c_void_p(int(main_ptr))))
+
+    def sweep_set_views_device(self, side_cams, side_ptrs):
+        """mvs_sweep_set_views_device: side_ptrs = device addresses of the side frames (H*W u8 each); stream-ordered, no synchronisation"""
+        V = len(side_ptrs)
+        cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((0, 4, 4), np.float32)
+        arr = (_vp * max(V, 1))(*[C.c_void_p(int(q)) for q in side_ptrs])
+        self._check(self.lib.mvs_sweep_set_views_device(self.h, V, _ptr(cams, _fp), arr))
+        self.V = V
+
     def sweep_run(self, view_first=0, view_count=None, flags=MVS_SWEEP_VOLUME):
         if view_count is None:
             view_count = self.V - view_first
@@ -432,6 +449,24 @@ class Context:
         f = _u8(frame, (self.H, self.W))
         self._store_keep[int(slot)] = f   # the copy is asynchronous: keep the array alive until the next synchronising call
         self._check(self.lib.mvs_frame_upload(self.h, int(slot), f.ctypes.data_as(C.c_void_p)))
+
+    def frame_upload_device(self, slot, frame_ptr):
+        """mvs_frame_upload_device: frame_ptr = device address of H*W u8 (stream-ordered)"""
+        self._check(self.lib.mvs_frame_upload_device(self.h, int(slot), C.c_void_p(int(frame_ptr))))
+
+    def sweep_handles(self, main_slot, main_cam, side_slots, side_cams, nplanes, z_lo=-1.0, z_hi=1.0, want_cost=False, out=None):
+        """mvs_sweep_handles: one main view whose frames are slots of the frame store -> depth [H,W] (, cost)"""
+        ss = np.ascontiguousarray(side_slots, dtype=np.int32).reshape(-1)
+        S = len(ss)
+        mc = _f32(main_cam, (4, 4))
+        sc = _f32(np.asarray(side_cams, dtype=np.float32).reshape(S, 4, 4)) if S else np.zeros((1, 4, 4), np.float32)
+        depth = out if out is not None else np.empty((self.H, self.W), np.float32)
+        cost = np.empty((self.H, self.W), np.float32) if want_cost else None
+        self._check(self.lib.mvs_sweep_handles(self.h, int(main_slot), _ptr(mc, _fp), S, ss.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p), int(nplanes),
+                                               float(z_lo), float(z_hi), depth.ctypes.data_as(C.c_void_p), cost.ctypes.data_as(C.c_void_p) if want_cost else None))
+        self._store_keep = {}
+        self.V, self.D = S, int(nplanes)
+        return (depth, cost) if want_cost else depth
 
     def sweep_batch(self, main_slots, main_cams, side_slots, side_cams, nplanes, z_lo=-1.0, z_hi=1.0, want_cost=False, out=None):
         """mvs_sweep_batch: main_slots [M], main_cams [M,4,4], side_slots [M,S], side_cams [M,S,4,4] -> depth [M,H,W] (, cost [M,H,W])"""

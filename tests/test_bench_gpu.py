@@ -71,3 +71,8 @@ def test_bench_line_contract_and_two_rank_shardings():
     assert dis["plane_flip_rate"] <= 0.06 and dis["plane_flip_rate_more_than_one_plane"] <= 0.003 and dis["mean_abs_best_cost_difference_grey_levels"] <= 0.2
     assert ext["general_camera_path"]["kernel"] == "sweep_fx_tiled" and ext["general_camera_path"]["ms_per_step"] > 0
     assert ext["sustained"]["seconds"] >= 1.9 and ext["sustained"]["steps"] >= 300
+    # a new (main, views) set from raw frames resident in HBM: prepared, planned and swept inside the timed step, same depth map
+    cold = ext["cold_step"]
+    assert cold["ms"] >= ext["ms_per_step"] * 0.9 and cold["depth_crc32"] == ext["depth_crc32_single_gpu"] and 0.0 < cold["frac"] < 1.0
+    assert "combine_best" in ext["roofline"]["ms_per_launch_covers"]
+    assert "roofline_traffic" in ext["general_camera_path"]
