@@ -281,6 +281,7 @@ void mvs_destroy(mvs_ctx *ctx)
         if (lane.stream) (void)hipStreamDestroy(lane.stream);
     }
     for (hipEvent_t e : ctx->lane_events) (void)hipEventDestroy(e);
+    if (ctx->plan_event) (void)hipEventDestroy(ctx->plan_event);
     if (ctx->filter_pinned) (void)hipHostFree(ctx->filter_pinned);
     for (int e = 0; e < 2; e++)
         if (ctx->filter_ev[e]) (void)hipEventDestroy(ctx->filter_ev[e]);
@@ -482,6 +483,7 @@ int sweep_set_views_impl(mvs_ctx *ctx, int nviews, const float *side_cams, const
     ctx->pad_slab = (size_t)ctx->pad_pitch * (H + 2);
     ctx->V = 0;
     ctx->q_host.assign((size_t)nviews * 12, 0.f);
+    bool planned = false;
     if (nviews > 0) {
         int rc;
         if (!device && (rc = ensure(ctx, ctx->upload, P * nviews))) return rc;  // one slot per view: no upload waits for the previous view's kernels
@@ -490,12 +492,33 @@ int sweep_set_views_impl(mvs_ctx *ctx, int nviews, const float *side_cams, const
         ctx->V = nviews;  // every allocation has succeeded: the buffers match this view count from here on
         for (int v = 0; v < nviews; v++) view_matrix(ctx->main_cam, side_cams + 16 * v, W, H, ctx->q_host.data() + 12 * v);
         MVS_HIP(ctx, hipMemcpyAsync(ctx->qmats.ptr, ctx->q_host.data(), sizeof(float) * 12 * nviews, hipMemcpyHostToDevice, ctx->stream));
-        if (!defer_frames && (rc = sweep_upload_frames_impl(ctx, side_frames, device))) return rc;
+        // With the planes already set, the fixed sampler's region plan -- cameras and planes, no frames -- is made HERE, ahead of the
+        // frames: the quad-image pass is queued between the planner's launches and its one host read-back and runs during that round trip
+        struct Upload : PlanHook {
+            mvs_ctx *c;
+            const uint8_t *const *frames;
+            bool device;
+            int run() override { return sweep_upload_frames_impl(c, frames, device); }
+        } upload;
+        upload.c = ctx;
+        upload.frames = side_frames;
+        upload.device = device;
+        if (!defer_frames && ctx->have_planes && ctx->sampler == MVS_SAMPLER_FIXED && nviews <= 255 && W <= 16383 && H <= 16383) {
+            ctx->have_views = true;   // (the planner reads the context's views)
+            ProfileScope ps(ctx, MVS_K_PLAN);
+            rc = sweep_fx_plan(ctx, &upload);
+            ctx->have_views = false;
+            if (rc) return rc;
+            planned = true;
+        } else if (!defer_frames && (rc = upload.run())) {
+            return rc;
+        }
         if (sync) MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     ctx->V = nviews;
     ctx->have_views = true;
-    ctx->plan_valid = false;
+    ctx->plan_valid = planned;
+    if (planned) ctx->plan_shape = 3;
     return MVS_OK;
 }
 

@@ -74,6 +74,7 @@ struct mvs_ctx {
     int rect_rs = 0, rect_slot_dw = 0, rect_dpad = 0;
     std::vector<unsigned char> rect_cold_host;  // host copy of the kernel's cold block (sweep_rect.hip: RectCold)
     bool rect_cold_sent = false;
+    hipEvent_t plan_event = nullptr;  // the rectified planner's read-back has landed (the host waits for this, not for the whole stream)
     mvs::DevBuf probe_buf;           // mvs_depth_probe: pixel coordinates in, depths out
     mvs::DevBuf raster_bins;         // face binning of large meshes: per-bin counts / offsets / lists, shared list of large faces
     mvs::DevBuf filter_sort;         // mvs_filter_points, dense clouds: keys and a second copy of the upper lists for the global sorts
@@ -161,8 +162,13 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 int sweep_set_main_impl(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, bool sync, bool device = false);
 int sweep_set_views_impl(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames, bool sync, bool defer_frames = false, bool device = false);
 int sweep_upload_frames_impl(mvs_ctx *ctx, const uint8_t *const *side_frames, bool device = false);
+struct PlanHook {  // work a caller wants queued between the planner's launches and the planner's one host read-back (it then runs while the host waits)
+    virtual int run() = 0;
+    virtual ~PlanHook() = default;
+};
+int sweep_fx_plan(mvs_ctx *ctx, PlanHook *between = nullptr);  // sweep_fx.hip: the fixed sampler's region plan (rectified tables or the general plan)
 int ensure_pads(mvs_ctx *ctx);     // wrap-padded u8 frames of the current side views, rebuilt from the quad images when a path needs them
-int sweep_rect_plan(mvs_ctx *ctx);   // sweep_rect.hip: tables + eligibility of the rectified kernel for the current fixed-sampler plan
+int sweep_rect_plan(mvs_ctx *ctx, PlanHook *between = nullptr);   // sweep_rect.hip: tables + eligibility of the rectified kernel for the current fixed-sampler plan
 struct SweepParams;
 int ensure_quads16(mvs_ctx *ctx);  // exact sampler's f16 quad image of the current side views  // the deferred half of sweep_set_views_impl
 int sweep_set_planes_impl(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi, bool sync);

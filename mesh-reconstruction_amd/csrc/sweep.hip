@@ -713,7 +713,6 @@ __global__ void rcp_check_kernel(uint32_t exp_bits, unsigned long long *out)
 }
 
 // sweep_fx.hip: the fixed-point sampler (contract v2)
-int sweep_fx_plan(mvs_ctx *ctx);
 int sweep_fx_plan_general(mvs_ctx *ctx);
 int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool generic, unsigned flags);
 int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsigned flags);
@@ -1129,13 +1128,22 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
     if ((rc = sweep_set_views_impl(ctx, nviews, side_cams, side_frames, false, true))) return rc;  // tables only: the frames follow below
     if ((rc = sweep_set_planes_impl(ctx, nplanes, z_lo, z_hi, false))) return rc;
     // the region plan needs the cameras and the planes, not the frames: queued first, it runs while the host stages the uploads
-    if (ctx->sampler == MVS_SAMPLER_FIXED && nviews > 0 && nviews <= 255) {
+    // (and the uploads are queued BEFORE the host waits for the rectified planner's counters: they run during that round trip)
+    struct Upload : PlanHook {
+        mvs_ctx *c;
+        const uint8_t *const *frames;
+        int run() override { return sweep_upload_frames_impl(c, frames); }
+    } upload;
+    upload.c = ctx;
+    upload.frames = side_frames;
+    if (ctx->sampler == MVS_SAMPLER_FIXED && nviews > 0 && nviews <= 255 && ctx->W <= 16383 && ctx->H <= 16383) {
         ProfileScope ps(ctx, MVS_K_PLAN);
-        if ((rc = sweep_fx_plan(ctx))) return rc;
+        if ((rc = sweep_fx_plan(ctx, &upload))) return rc;
         ctx->plan_shape = 3;
         ctx->plan_valid = true;
+    } else if ((rc = upload.run())) {
+        return rc;
     }
-    if ((rc = sweep_upload_frames_impl(ctx, side_frames))) return rc;
     const unsigned flags = MVS_SWEEP_FUSED_ARGMIN | (volume_dhw ? MVS_SWEEP_VOLUME : 0u);
     if ((rc = mvs_sweep_run(ctx, 0, nviews, flags))) return rc;
     if ((rc = mvs_sweep_fetch(ctx, depth_hw, cost_hw, nullptr, nullptr))) return rc;

@@ -899,10 +899,10 @@ int sweep_fx_plan_general(mvs_ctx *ctx)
     return MVS_OK;
 }
 
-int sweep_fx_plan(mvs_ctx *ctx)
+int sweep_fx_plan(mvs_ctx *ctx, PlanHook *between)
 {
     ctx->fx_general_planned = false;
-    const int rc = sweep_rect_plan(ctx);  // rectified views: tables for sweep_fx_rect (sweep_rect.hip); sets ctx->rect_ok
+    const int rc = sweep_rect_plan(ctx, between);  // (runs `between` exactly once, whatever it decides)  // rectified views: tables for sweep_fx_rect (sweep_rect.hip); sets ctx->rect_ok
     if (rc) return rc;
     if (ctx->rect_ok && !getenv("MVS_PLAN_DUMP")) return MVS_OK;
     return sweep_fx_plan_general(ctx);

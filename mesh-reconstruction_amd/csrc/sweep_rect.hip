@@ -827,21 +827,35 @@ static size_t rect_table_dwords(const SweepParams &q) { return rect_sizes(q).tot
 // Builds the tables for the current (views, planes) and decides whether the rectified kernel serves this plan: every view
 // eligible (host check on the f32 view matrices) and every region box within a slot shape the kernel is compiled for (counters of
 // pass B: one stream synchronisation per plan).  Called from sweep_fx_plan.
-int sweep_rect_plan(mvs_ctx *ctx)
+int sweep_rect_plan(mvs_ctx *ctx, PlanHook *between)
 {
+    struct RunHookOnce {  // whichever way this function leaves, the caller's work has been queued exactly once
+        PlanHook *h;
+        int rc = MVS_OK;
+        bool done = false;
+        int go()
+        {
+            if (!done && h) rc = h->run();
+            done = true;
+            return rc;
+        }
+    } hook{between};
     ctx->rect_ok = false;
     ctx->rect_cold_sent = false;  // the tables (and the cold block behind them) may move
-    if (getenv("MVS_NO_RECT")) return MVS_OK;
-    if (ctx->V == 0) return MVS_OK;
+    if (getenv("MVS_NO_RECT")) return hook.go();
+    if (ctx->V == 0) return hook.go();
     for (int v = 0; v < ctx->V; v++)
-        if (!rect_view_host(ctx->q_host.data() + 12 * v)) return MVS_OK;  // a view that is not rectified: the general kernel
+        if (!rect_view_host(ctx->q_host.data() + 12 * v)) return hook.go();  // a view that is not rectified: the general kernel
     // the kernel addresses the quad images through one buffer resource with 32-bit byte offsets
-    if ((unsigned long long)ctx->pad_slab * (unsigned long long)(ctx->views_in_store ? ctx->store_cap : ctx->V) * 4ull >= (1ull << 32)) return MVS_OK;
+    if ((unsigned long long)ctx->pad_slab * (unsigned long long)(ctx->views_in_store ? ctx->store_cap : ctx->V) * 4ull >= (1ull << 32)) return hook.go();
     SweepParams q;
     fill_params(ctx, q, 0, ctx->V, RX_TILE_H, RX_PC);
     int rc;
-    if ((rc = ensure(ctx, ctx->rect_tab, rect_table_dwords(q) * sizeof(uint32_t) + sizeof(RectCold) + 256))) return rc;
-    if ((rc = ensure_fx_lut(ctx))) return rc;
+    if ((rc = ensure(ctx, ctx->rect_tab, rect_table_dwords(q) * sizeof(uint32_t) + sizeof(RectCold) + 256)) || (rc = ensure_fx_lut(ctx))) {
+        (void)hook.go();
+        return rc;
+    }
+    if (!ctx->plan_event) MVS_HIP(ctx, hipEventCreateWithFlags(&ctx->plan_event, hipEventDisableTiming));
     RectTables rt;
     rect_tables(ctx, q, rt);
     MVS_HIP(ctx, hipMemsetAsync(rt.stats, 0, 64, ctx->stream));
@@ -852,7 +866,10 @@ int sweep_rect_plan(mvs_ctx *ctx)
     MVS_HIP(ctx, hipGetLastError());
     int stats[4] = {0, 0, 0, 0};
     MVS_HIP(ctx, hipMemcpyAsync(stats, rt.stats, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream));
-    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MVS_HIP(ctx, hipEventRecord(ctx->plan_event, ctx->stream));
+    // the caller's work (quad images of the new views) goes into the queue NOW: it runs while the host waits for the counters
+    if ((rc = hook.go())) return rc;
+    MVS_HIP(ctx, hipEventSynchronize(ctx->plan_event));
     const int max_rw = stats[0], max_rh = stats[1];
     int rs = 0;
     if (getenv("MVS_RECT_VERBOSE")) fprintf(stderr, "sweep_rect_plan: widest box %d quads, tallest %d rows\n", max_rw, max_rh);

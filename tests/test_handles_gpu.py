@@ -65,8 +65,7 @@ def _handles_case(W, H, D, V, main_cam, main_img, side_cams, sides, expect_shape
     with mvs_amd.Context(W, H) as ctx:
         d1, c1 = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_cost=True)
     cap = V + 5
-    order = [(3 * k + 2) % cap for k in range(V + 1)]     # slots in no particular order; slot != view index
-    assert len(set(order)) == V + 1
+    order = [int(k) for k in np.random.default_rng(V).permutation(cap)[:V + 1]]     # slots in no particular order; slot != view index
     with mvs_amd.Context(W, H) as ctx:
         ctx.frame_store(cap)
         ctx.frame_upload(order[0], main_img)
