@@ -144,10 +144,14 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
             need = sorted(set(mains) | set(j for f in mains for j in sides_of(f)))
             for j in need:
                 ctx.frame_upload(j, frame(j))
-            for i in range(0, len(mains), batch):
+            # two batches in flight (mvs_sweep_batch_async): batch i's depth maps cross PCIe on the copy stream while batch i + 1 is
+            # planned and swept, and the host prepares batch i + 1 meanwhile; the results alternate between two page-locked buffers
+            for k, i in enumerate(range(0, len(mains), batch)):
                 mb = mains[i:i + batch]
-                depth = ctx.sweep_batch(mb, np.stack([cams[f] for f in mb]), np.array([sides_of(f) for f in mb], np.int32),
-                                        np.stack([side_cams[f] for f in mb]), D, out=out_pinned[:len(mb)])[len(mb) - 1]
+                ctx.sweep_batch_async(mb, np.stack([cams[f] for f in mb]), np.array([sides_of(f) for f in mb], np.int32),
+                                      np.stack([side_cams[f] for f in mb]), D, out=out_pinned[k & 1][:len(mb)])
+                depth = out_pinned[k & 1][len(mb) - 1]
+            ctx.sweep_batch_wait()
         else:
             for f in mains:
                 depth = ctx.sweep(cams[f], frame(f), side_cams[f], [frame(j) for j in sides_of(f)], D)
@@ -161,7 +165,7 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
     out_pinned = None
     if batched:
         ctx.frame_store(nframes)
-        out_pinned = mvs_amd.pinned_array((batch, H, W), np.float32)   # page-locked result buffer (mvs_host_alloc), reused by every batch
+        out_pinned = [mvs_amd.pinned_array((batch, H, W), np.float32) for _ in range(2)]   # page-locked result buffers (mvs_host_alloc), alternating
     seq = [mine[i % len(mine)] for i in range(CLOCK_RAMP_STEPS + args.warmup + args.steps)]
     run_frames(seq[:CLOCK_RAMP_STEPS + args.warmup])   # untimed: clock ramp, then the warm-up steps asked for
     barrier()
@@ -198,9 +202,9 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
             "dtype": DTYPE[args.sampler],
             "data": "synthetic frames on the cameras of tracks/zatisi.yaml" + (" [TEST HOOK: ranks share one GPU over gloo]" if same_device else ""),
             "config": {"workload": "c5: zatisi.yaml %d frames, 640x480, %d planes, %d side views per main frame, one main frame per step; " % (nframes, D, V) +
-                                   ("frame store + mvs_sweep_batch, %d main frames per launch (host frames in once, host depth out: PCIe and per-frame planning included)" % batch
+                                   ("frame store + mvs_sweep_batch_async, %d main frames per launch, two launches in flight (host frames in once, host depth out: PCIe and per-frame planning included)" % batch
                                     if batched else "mvs_sweep per main frame (host frames in, host depth out: PCIe and per-frame planning included)"),
-                       "entry": "mvs_sweep_batch" if batched else "mvs_sweep", "main_frames_per_launch": batch if batched else 1,
+                       "entry": "mvs_sweep_batch_async" if batched else "mvs_sweep", "main_frames_per_launch": batch if batched else 1,
                        "one_call_mvs_sweep_ms_per_main_frame": onecall_ms,
                        "sampler": args.sampler, "shard": None if world == 1 else "frames", "frames_per_rank": len(mine), "plan_shape": shape, "device": ctx.info()},
             "roofline": {"bound": "hbm", "kernel": "sweep_fx_tiled_batch" if batched else {1: "sweep_tiled", 2: "sweep_tiled", 3: "sweep_fx_tiled", 4: "sweep_fx_rect"}.get(shape), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

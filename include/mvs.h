@@ -249,6 +249,13 @@ int mvs_sweep_handles(mvs_ctx *ctx, int main_slot, const float main_cam[16], int
                       int nplanes, float z_lo, float z_hi, float *depth_hw, float *cost_hw);
 int mvs_sweep_batch(mvs_ctx *ctx, int nmain, const int *main_slots, const float *main_cams, int nside, const int *side_slots,
                     const float *side_cams, int nplanes, float z_lo, float z_hi, float *depth_out, float *cost_out);
+/* The same without waiting: the batch is queued and the call returns; depth_out / cost_out (which must stay valid, and should be
+ * page-locked: mvs_host_alloc) are complete when mvs_sweep_batch_wait returns.  Two batches can be in flight -- the results of one
+ * cross PCIe on a second stream while the next is planned and swept, and the host prepares that next one meanwhile; a third call waits
+ * for the oldest.  Frames a queued batch uses must not be re-uploaded before it has been waited for.  (mvs_sweep_batch = this + wait.) */
+int mvs_sweep_batch_async(mvs_ctx *ctx, int nmain, const int *main_slots, const float *main_cams, int nside, const int *side_slots,
+                          const float *side_cams, int nplanes, float z_lo, float z_hi, float *depth_out, float *cost_out);
+int mvs_sweep_batch_wait(mvs_ctx *ctx);
 
 /* ---- one main view on several GPUs of one node (SURVEY.md section 8b "multi-GPU", 8e, north_star) -----------------------------
  * A communicator owns one context per listed device and one RCCL communicator across them (librccl is loaded when the first

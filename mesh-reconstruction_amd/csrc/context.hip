@@ -259,6 +259,7 @@ void mvs_destroy(mvs_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->own_stream && ctx->own_stream != ctx->stream) (void)hipStreamSynchronize(ctx->own_stream);
     for (auto &lane : ctx->lanes)  // before any buffer is freed: a lane may still read frame_buf or its arena
         if (lane.stream) (void)hipStreamSynchronize(lane.stream);
@@ -266,7 +267,7 @@ void mvs_destroy(mvs_ctx *ctx)
                       &ctx->volume_own, &ctx->depth, &ctx->cost, &ctx->index, &ctx->soup, &ctx->r_zbuf,
                       &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2,
                       &ctx->cubic_tab, &ctx->flow_arena, &ctx->frame_buf, &ctx->best_parts, &ctx->plan_stats, &ctx->probe_buf, &ctx->filter_sort, &ctx->raster_bins, &ctx->fx_lut, &ctx->side_quads, &ctx->side_quads16,
-                      &ctx->r_mips, &ctx->flow_batch_arena, &ctx->rect_tab, &ctx->store_raw, &ctx->store_quads, &ctx->batch_buf, &ctx->frame_ptrs, &ctx->view_slots};
+                      &ctx->r_mips, &ctx->flow_batch_arena, &ctx->rect_tab, &ctx->store_raw, &ctx->store_quads, &ctx->batch_slot[0].buf, &ctx->batch_slot[1].buf, &ctx->frame_ptrs, &ctx->view_slots};
     for (int i = 0; i < 2; i++)
         if (ctx->flow_graph[i]) (void)hipGraphExecDestroy(ctx->flow_graph[i]);
     if (ctx->flow_batch_graph.exec) (void)hipGraphExecDestroy(ctx->flow_batch_graph.exec);
@@ -282,6 +283,11 @@ void mvs_destroy(mvs_ctx *ctx)
     }
     for (hipEvent_t e : ctx->lane_events) (void)hipEventDestroy(e);
     if (ctx->plan_event) (void)hipEventDestroy(ctx->plan_event);
+    for (auto &b : ctx->batch_slot) {
+        if (b.swept) (void)hipEventDestroy(b.swept);
+        if (b.landed) (void)hipEventDestroy(b.landed);
+    }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->filter_pinned) (void)hipHostFree(ctx->filter_pinned);
     for (int e = 0; e < 2; e++)
         if (ctx->filter_ev[e]) (void)hipEventDestroy(ctx->filter_ev[e]);

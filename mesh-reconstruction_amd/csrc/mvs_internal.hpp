@@ -100,7 +100,17 @@ struct mvs_ctx {
     mvs::DevBuf best_parts;          // plane-split sweeps: partial (best cell, best index) per split and pixel
     // frame store (mvs_frame_store / mvs_frame_upload / mvs_sweep_batch): the frames of a sequence, uploaded once, each as raw frame,
     // quad image (5 bytes per pixel); main and side views of the batched sweep are slots of it
-    mvs::DevBuf store_raw, store_quads, batch_buf;
+    mvs::DevBuf store_raw, store_quads;
+    // mvs_sweep_batch_async: two batches in flight, each with its own device block and host staging; the results of a batch travel on
+    // the copy stream while the next batch is planned and swept on the context's stream
+    struct BatchSlot {
+        mvs::DevBuf buf;
+        std::vector<char> host;
+        hipEvent_t swept = nullptr, landed = nullptr;  // kernel done (copy stream waits for it) / results in the caller's memory
+        bool busy = false;
+    } batch_slot[2];
+    int batch_next = 0;
+    hipStream_t copy_stream = nullptr;
     int store_cap = 0;
     std::vector<unsigned char> store_have;
     // the launch-bound flow pipelines (~350 small kernels for Farneback) are captured once into a hipGraph per

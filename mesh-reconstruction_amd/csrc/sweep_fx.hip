@@ -29,7 +29,13 @@
 
 namespace mvs {
 
-constexpr int FX_ROWS = 32;       // region rows (and weight-table rows) per LDS image
+#ifndef MVS_FX_ROWS
+#define MVS_FX_ROWS 32
+#endif
+#ifndef MVS_FX_OCC
+#define MVS_FX_OCC 4
+#endif
+constexpr int FX_ROWS = MVS_FX_ROWS;       // region rows (and weight-table rows) per LDS image (timing experiments: -DMVS_FX_ROWS=24 -DMVS_FX_OCC=5, wrong weights for ky >= 24)
 constexpr int FX_ROW_DW = 256;    // dwords per LDS row
 constexpr int FX_LUT_DW = 32;     // of which the first 32 hold the weight-table row
 constexpr int FX_MAX_RW = FX_ROW_DW - FX_LUT_DW;  // 224 quads
@@ -38,7 +44,7 @@ constexpr float FX_MAGIC = 12582912.0f;            // 1.5 * 2^23: floats in [2^2
 constexpr int FX_TILE_H = 8, FX_PC = 16, FX_NPX = 2;  // 64x8-pixel tiles, 16 planes per chunk: 32 accumulators per thread
 constexpr int FX_GS = 2;          // samples per software-pipeline group (4: 12 more VGPRs, spills, 1.505 vs 1.479 ms at c3)
 constexpr int FX_VB = 64;         // views per batch of LDS-resident per-view constants
-constexpr int FX_WG_PER_CU = 4;   // launch bound (waves per SIMD): 128 VGPRs, 39.5 KiB of LDS (5 would need <= 96 VGPRs: the kernel needs ~125)
+constexpr int FX_WG_PER_CU = MVS_FX_OCC;   // launch bound (waves per SIMD): 128 VGPRs, 39.5 KiB of LDS (5 would need <= 96 VGPRs: the kernel needs ~125)
 
 enum FxMode : unsigned { FX_SKIP = 0, FX_FAST = 1, FX_BORDER = 2, FX_GENERIC = 3 };
 
@@ -922,6 +928,22 @@ int warp_by_depth_fx_launch(mvs_ctx *ctx, const float *depth_dev, const float *q
 // ------------------------------------------------------------------------------------------------------
 // batched sweep over the frame store (recon.cpp:65-117: every main frame of a sequence against its neighbours)
 // ------------------------------------------------------------------------------------------------------
+// all queued batches have delivered their results (and their slots are free again)
+int sweep_batch_wait_impl(mvs_ctx *ctx)
+{
+    if (!ctx) return MVS_EINVAL;
+    int rc = MVS_OK;
+    for (auto &b : ctx->batch_slot)
+        if (b.busy) {
+            if (hipEventSynchronize(b.landed) != hipSuccess) rc = fail(ctx, MVS_EHIP, "mvs_sweep_batch_wait: hipEventSynchronize failed");
+            b.busy = false;
+        }
+    return rc;
+}
+
+// Queues one batch and returns: parameter blocks and plan on the context's stream, the sweep behind them, the results' way home on the
+// copy stream (ordered behind the sweep by an event) -- so the NEXT batch's planner and sweep start while this batch's depth maps are
+// still crossing PCIe, and the host prepares that next batch meanwhile.  Two batches in flight; a third call waits for the oldest.
 int sweep_batch_impl(mvs_ctx *ctx, int nmain, const int *main_slots, const float *main_cams, int nside, const int *side_slots, const float *side_cams,
                      int nplanes, float z_lo, float z_hi, float *depth_out, float *cost_out)
 {
@@ -954,10 +976,25 @@ int sweep_batch_impl(mvs_ctx *ctx, int nmain, const int *main_slots, const float
     const size_t o_params = 0, o_q = up(o_params + sizeof(SweepParams) * nmain), o_z = up(o_q + sizeof(float) * 12 * nside * nmain),
                  o_slots = up(o_z + sizeof(float) * nplanes), o_stats = up(o_slots + sizeof(int) * nside * nmain), o_plan = up(o_stats + 64),
                  o_out = up(o_plan + sizeof(uint2) * plan_entries * nmain), total = up(o_out + 3 * P * sizeof(float) * nmain);
-    if ((rc = ensure(ctx, ctx->batch_buf, total))) return rc;
-    char *base = (char *)ctx->batch_buf.ptr;
-    // host staging (kept alive until the copies below have run: the call ends with a synchronisation)
-    std::vector<char> host(o_plan);
+    if (!ctx->copy_stream) MVS_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    mvs_ctx::BatchSlot &slot = ctx->batch_slot[ctx->batch_next];
+    ctx->batch_next ^= 1;
+    if (slot.busy) {  // the batch before the previous one used this slot: its results must have landed before its buffers are reused
+        MVS_HIP(ctx, hipEventSynchronize(slot.landed));
+        slot.busy = false;
+    }
+    if (!slot.swept) {
+        MVS_HIP(ctx, hipEventCreateWithFlags(&slot.swept, hipEventDisableTiming));
+        MVS_HIP(ctx, hipEventCreateWithFlags(&slot.landed, hipEventDisableTiming));
+    }
+    if (total > slot.buf.bytes && slot.buf.ptr) {  // (ensure() below frees the old block after joining the context's stream only)
+        MVS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    }
+    if ((rc = ensure(ctx, slot.buf, total))) return rc;
+    char *base = (char *)slot.buf.ptr;
+    // host staging: lives in the slot until the slot is reused (the copy below is asynchronous)
+    std::vector<char> &host = slot.host;
+    host.assign(o_plan, 0);
     float *zt = (float *)(host.data() + o_z);
     plane_table(nplanes, z_lo, z_hi, zt);
     memcpy(host.data() + o_slots, side_slots, sizeof(int) * nside * nmain);
@@ -1022,9 +1059,12 @@ int sweep_batch_impl(mvs_ctx *ctx, int nmain, const int *main_slots, const float
                                                                                                              (const uint32_t *)ctx->fx_lut.ptr);
         MVS_HIP(ctx, hipGetLastError());
     }
-    MVS_HIP(ctx, hipMemcpyAsync(depth_out, base + o_out, P * sizeof(float) * nmain, hipMemcpyDeviceToHost, ctx->stream));
-    if (cost_out) MVS_HIP(ctx, hipMemcpyAsync(cost_out, base + o_out + P * sizeof(float) * nmain, P * sizeof(float) * nmain, hipMemcpyDeviceToHost, ctx->stream));
-    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MVS_HIP(ctx, hipEventRecord(slot.swept, ctx->stream));
+    MVS_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, slot.swept, 0));
+    MVS_HIP(ctx, hipMemcpyAsync(depth_out, base + o_out, P * sizeof(float) * nmain, hipMemcpyDeviceToHost, ctx->copy_stream));
+    if (cost_out) MVS_HIP(ctx, hipMemcpyAsync(cost_out, base + o_out + P * sizeof(float) * nmain, P * sizeof(float) * nmain, hipMemcpyDeviceToHost, ctx->copy_stream));
+    MVS_HIP(ctx, hipEventRecord(slot.landed, ctx->copy_stream));
+    slot.busy = true;
     return MVS_OK;
 }
 
@@ -1033,5 +1073,18 @@ int sweep_batch_impl(mvs_ctx *ctx, int nmain, const int *main_slots, const float
 extern "C" int mvs_sweep_batch(mvs_ctx *ctx, int nmain, const int *main_slots, const float *main_cams, int nside, const int *side_slots, const float *side_cams, int nplanes,
                                float z_lo, float z_hi, float *depth_out, float *cost_out)
 {
+    const int rc = mvs::sweep_batch_impl(ctx, nmain, main_slots, main_cams, nside, side_slots, side_cams, nplanes, z_lo, z_hi, depth_out, cost_out);
+    const int rw = mvs::sweep_batch_wait_impl(ctx);  // (also after an error: nothing of an earlier asynchronous batch stays in flight)
+    if (rc) return rc;
+    if (rw) return rw;
+    if (ctx && hipStreamSynchronize(ctx->stream) != hipSuccess) return mvs::fail(ctx, MVS_EHIP, "mvs_sweep_batch: hipStreamSynchronize failed");  // "synchronises": queued uploads included
+    return MVS_OK;
+}
+
+extern "C" int mvs_sweep_batch_async(mvs_ctx *ctx, int nmain, const int *main_slots, const float *main_cams, int nside, const int *side_slots, const float *side_cams,
+                                     int nplanes, float z_lo, float z_hi, float *depth_out, float *cost_out)
+{
     return mvs::sweep_batch_impl(ctx, nmain, main_slots, main_cams, nside, side_slots, side_cams, nplanes, z_lo, z_hi, depth_out, cost_out);
 }
+
+extern "C" int mvs_sweep_batch_wait(mvs_ctx *ctx) { return mvs::sweep_batch_wait_impl(ctx); }

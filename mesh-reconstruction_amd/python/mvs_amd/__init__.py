@@ -73,6 +73,8 @@ ABI = [
     ("mvs_frame_upload_device", _i, [_vp, _i, _vp]),
     ("mvs_sweep_handles", _i, [_vp, _i, _fp, _i, _vp, _vp, _i, _f, _f, _vp, _vp]),
     ("mvs_sweep_batch", _i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, C.c_float, C.c_float, _vp, _vp]),
+    ("mvs_sweep_batch_async", _i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, C.c_float, C.c_float, _vp, _vp]),
+    ("mvs_sweep_batch_wait", _i, [_vp]),
     ("mvs_sweep_argmin", _i, [_vp]),
     ("mvs_sweep_refine_depth", _i, [_vp]),
     ("mvs_sweep_argmin_partial", _i, [_vp, _vp, _i, _i, _vp]),
@@ -467,6 +469,21 @@ class Context:
         self._store_keep = {}
         self.V, self.D = S, int(nplanes)
         return (depth, cost) if want_cost else depth
+
+    def sweep_batch_async(self, main_slots, main_cams, side_slots, side_cams, nplanes, out, z_lo=-1.0, z_hi=1.0, cost_out=None):
+        """mvs_sweep_batch_async: queues the batch; `out` [M,H,W] f32 (page-locked: pinned_array) is complete after sweep_batch_wait()"""
+        ms = np.ascontiguousarray(main_slots, dtype=np.int32)
+        ss = np.ascontiguousarray(side_slots, dtype=np.int32)
+        M, S = ss.shape
+        mc = _f32(np.asarray(main_cams, dtype=np.float32).reshape(M, 4, 4))
+        sc = _f32(np.asarray(side_cams, dtype=np.float32).reshape(M, S, 4, 4))
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size >= M * self.H * self.W
+        self._check(self.lib.mvs_sweep_batch_async(self.h, M, ms.ctypes.data_as(C.c_void_p), mc.ctypes.data_as(C.c_void_p), S, ss.ctypes.data_as(C.c_void_p),
+                                                   sc.ctypes.data_as(C.c_void_p), int(nplanes), float(z_lo), float(z_hi), out.ctypes.data_as(C.c_void_p),
+                                                   cost_out.ctypes.data_as(C.c_void_p) if cost_out is not None else None))
+
+    def sweep_batch_wait(self):
+        self._check(self.lib.mvs_sweep_batch_wait(self.h))
 
     def sweep_batch(self, main_slots, main_cams, side_slots, side_cams, nplanes, z_lo=-1.0, z_hi=1.0, want_cost=False, out=None):
         """mvs_sweep_batch: main_slots [M], main_cams [M,4,4], side_slots [M,S], side_cams [M,S,4,4] -> depth [M,H,W] (, cost [M,H,W])"""

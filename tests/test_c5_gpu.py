@@ -93,6 +93,21 @@ def test_c5_batched_resident_entry_equals_one_call_path_on_all_120_frames():
                     assert (c5_common.crc(depth[k]), c5_common.crc(cost[k])) == ref[f], "main frame %d (batch of %d)" % (f, len(mains))
                 done += len(mains)
         assert done == n
+        # the asynchronous form: three batches queued back to back (two in flight, the third call waits for the oldest), each into
+        # its own page-locked buffer, complete after mvs_sweep_batch_wait; then a synchronous call on the same context
+        bufs = [(mvs_amd.pinned_array((8, H, W), np.float32), mvs_amd.pinned_array((8, H, W), np.float32)) for _ in range(3)]
+        for rnd in range(2):
+            groups = [list(range(rnd * 24 + 8 * k, rnd * 24 + 8 * k + 8)) for k in range(3)]
+            for (dbuf, cbuf), mains in zip(bufs, groups):
+                ctx.sweep_batch_async(mains, np.stack([seq.cams[f] for f in mains]), np.array([seq.sides(f) for f in mains], np.int32),
+                                      np.stack([np.stack([seq.cams[j] for j in seq.sides(f)]) for f in mains]), c5_common.PLANES, out=dbuf, cost_out=cbuf)
+            ctx.sweep_batch_wait()
+            for (dbuf, cbuf), mains in zip(bufs, groups):
+                for k, f in enumerate(mains):
+                    assert (c5_common.crc(dbuf[k]), c5_common.crc(cbuf[k])) == ref[f], "main frame %d (asynchronous batch)" % f
+        ctx.sweep_batch_wait()   # nothing in flight: returns at once
+        d = ctx.sweep_batch([5], seq.cams[5:6], np.array([seq.sides(5)], np.int32), np.stack([np.stack([seq.cams[j] for j in seq.sides(5)])]), c5_common.PLANES)
+        assert c5_common.crc(d[0]) == ref[5][0]
         # argument checks: an empty slot, a slot outside the store
         with pytest.raises(mvs_amd.MvsError):
             ctx.sweep_batch([n + 5], seq.cams[:1], np.array([[0, 1, 2, 3]], np.int32), np.stack([seq.cams[:4]]), c5_common.PLANES)
