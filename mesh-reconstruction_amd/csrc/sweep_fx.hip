@@ -471,9 +471,15 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
     }
     for (int chunk = chunk_first; chunk < chunk_last; chunk++) {
         const int d0 = chunk * PC;
-        float zc[PC];  // SGPRs; planes past D are evaluated on a clamped z and never stored
+        // SGPRs, by scalar loads through the constant address space (as per-lane global loads + v_readfirstlane each chunk began with 16
+        // vector-memory round trips on its critical path: a tenth of a 4-view chunk's time at 640 x 480); planes past D are evaluated on
+        // a clamped z and never stored
+        float zc[PC];
+        {
+            const __attribute__((address_space(4))) float *zs = (const __attribute__((address_space(4))) float *)(uintptr_t)p.z;
 #pragma unroll
-        for (int k = 0; k < PC; k++) zc[k] = uniform_f(p.z[min(d0 + k, p.D - 1)]);
+            for (int k = 0; k < PC; k++) zc[k] = zs[min(d0 + k, p.D - 1)];
+        }
 
         uint32_t acc[NPX][PC];
 #pragma unroll

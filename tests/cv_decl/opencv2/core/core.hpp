@@ -2,6 +2,7 @@
 // mesh-reconstruction_amd/host/render_hip_cv.cpp use, so that the seam file can be COMPILED (never linked or run) in an image
 // without OpenCV: a boundary check that the file matches the reference interface, not parity evidence (tests/test_host_cpu.py).
 #pragma once
+#include <cassert>  // (OpenCV's own core.hpp brings it in: render_glx.cpp relies on that)
 #include <cstddef>
 
 #define CV_8U 0
@@ -24,6 +25,7 @@ class Mat {
 public:
     Mat();
     Mat(int rows, int cols, int type);
+    Mat(int rows, int cols, int type, void *data);
     Mat(const Mat &);
     ~Mat();
     Mat &operator=(const Mat &);
@@ -33,6 +35,8 @@ public:
     bool isContinuous() const;
     bool empty() const;
     int type() const;
+    int depth() const;
+    size_t elemSize() const;
     int channels() const;
     size_t total() const;
     template <class T> T *ptr(int row = 0);
@@ -42,4 +46,8 @@ public:
     int rows, cols;
     unsigned char *data;
 };
+void flip(const Mat &src, Mat &dst, int flipCode);
+// (cv::MatExpr in OpenCV; declarations enough for `2 * m - 1`, render_glx.cpp:395)
+Mat operator*(double a, const Mat &m);
+Mat operator-(const Mat &m, double b);
 }  // namespace cv
