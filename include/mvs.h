@@ -303,11 +303,16 @@ int mvs_profile_enable(mvs_ctx *ctx, int on);
 int mvs_profile_read(mvs_ctx *ctx, float ms_sum[MVS_K_COUNT], int launches[MVS_K_COUNT], int reset);
 
 /* ---- surface meshing: replaces poissonSurface (recon.hpp:37, cgal_poisson.cpp:47-136, pcl.cpp:193-228) ----
- * Poisson reconstruction of oriented samples on a regular grid (csrc/poisson.hip): normals splatted with fixed-point atomics,
+ * Poisson reconstruction of oriented samples on a regular grid (csrc/poisson.hip): normals splatted with 64-bit fixed-point atomics,
  * laplace(chi) = div V solved with hipFFT, level set through the samples meshed by surface nets.  Context-free (device 0 of the
  * calling thread's HIP runtime state); no CPU path.
- *   points     n rows x, y, z, w (homogeneous, as recon.cpp:121 hands them over);  normals  n rows nx, ny, nz (pointing out of the solid)
- *   grid_log2  log2 of the nodes per axis, 4..9; 0 = chosen from n (32..256)
+ *   points     n rows x, y, z, w (homogeneous, as recon.cpp:121 hands them over);  normals  n rows nx, ny, nz (pointing out of the solid;
+ *              a component that is NaN or beyond 1e4 in magnitude makes the sample vote for nothing)
+ *   grid_log2  log2 of the nodes per axis, 4..9; 0 = from the samples' average 6-nearest-neighbour spacing, the reference's own
+ *              yardstick (CGAL::compute_average_spacing(points, 6), cgal_poisson.cpp:77): the coarsest of 32..512 nodes per axis whose
+ *              node spacing is at most 0.75 x that spacing, which keeps the surface within the reference's approximation bound of
+ *              0.375 x average spacing (cgal_poisson.cpp:52) on the analytic test surfaces; mvs_surface_spacing reports the average
+ *              spacing, the node spacing and whether the ratio could be kept (512 nodes per axis may still be too coarse)
  *   smooth_cells  standard deviation (grid cells) of the Gaussian low-pass applied to chi; 1.0 is a good default
  *   keep_fields  non-zero: keep chi and the splatted integer fields for mvs_surface_grid (tests)
  * The alpha shape of the first iteration (alphaShapeFaces, recon.hpp:33-34) is host-only code: libmvs_host.so, host/alpha_shapes.cpp. */
@@ -316,7 +321,8 @@ int mvs_poisson_surface(const float *points, const float *normals, int n, int gr
 int mvs_surface_counts(const mvs_surface *s, int *vertices, int *faces);
 int mvs_surface_fetch(const mvs_surface *s, float *vertices /* V x 4, w = 1 */, int32_t *faces /* F x 3, normals along the samples' */);
 int mvs_surface_grid(const mvs_surface *s, int *nodes_per_axis, float origin3[3], float *spacing, float *level, float *chi /* G^3, nullable */,
-                     int32_t *splat /* 4 G^3: vx, vy, vz, weight in units of 2^-16; nullable */);
+                     int64_t *splat /* 4 G^3: vx, vy, vz, weight in units of 2^-16; nullable */);
+int mvs_surface_spacing(const mvs_surface *s, float *average_spacing /* of the samples, 6 nearest neighbours */, float *node_spacing, int *ratio_kept);
 void mvs_surface_free(mvs_surface *s);
 const char *mvs_surface_last_error(void); /* of the calling thread */
 

@@ -6,8 +6,15 @@
 // field V of the samples' normals, laplace(chi) = div V, and extract the level set through the samples.  This is that method on a
 // REGULAR grid sized for one MI355X (G^3 nodes, G <= 512: 0.5 GB per field at G = 512 out of 288 GB), which is the form the paper
 // itself starts from (its section 3) before it introduces the octree to save memory:
-//   1. the samples' normals are splatted onto the grid nodes with trilinear weights -- 32-bit fixed-point atomics, so the field does
-//      not depend on the order the atomics land in (bit-reproducible, and the CPU oracle gets the same integers);
+//   0. the grid follows the reference's own yardstick: CGAL::compute_average_spacing(points, 6) (cgal_poisson.cpp:77 -- per sample the
+//      mean distance to its 6 nearest neighbours, averaged over the samples), computed here on the device with a sorted cell grid and
+//      an exact ring search, and the node spacing h is the largest 1.5 side / (2^k - 1), k = 5..9, with h <= 0.75 x that spacing:
+//      measured on analytic surfaces the surface-nets vertices then stay within the reference's approximation bound of 0.375 x average
+//      spacing (cgal_poisson.cpp:52, 99; tests/test_meshing_gpu.py); mvs_surface_spacing reports both numbers, and whether k = 9 was
+//      too coarse to keep the ratio;
+//   1. the samples' normals are splatted onto the grid nodes with trilinear weights -- 64-bit fixed-point atomics, so the field does
+//      not depend on the order the atomics land in (bit-reproducible, and the CPU oracle gets the same integers) and a node cannot
+//      overflow however many samples an outlier-stretched box packs into one cell (2^47 unit weights);
 //   2. laplace(chi) = div V is solved in the Fourier domain (hipFFT: three real-to-complex transforms, chi^ = -i k.V^ / |k|^2 with a
 //      Gaussian low-pass of `smooth` cells, one complex-to-real transform); periodic boundaries, kept away by padding the box;
 //   3. the level: the mean of chi (trilinear) over the samples, summed on the host in sample order (deterministic);
@@ -18,11 +25,13 @@
 // mesh of the same level set family (no Delaunay refinement, no angle / radius / distance criteria); DESIGN.md section 9 says so.
 // Checked against oracle/poisson_oracle.py (numpy, float64) on the same inputs: identical splat integers, chi within 1e-4 of its
 // range, surfaces within a fraction of a cell (tests/test_meshing_gpu.py).
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -36,6 +45,9 @@
 namespace {
 
 constexpr float SPLAT_SCALE = 65536.0f;  // fixed point of the splatted fields: 2^-16 per unit weight
+constexpr float NORMAL_LIMIT = 1.0e4f;    // a normal component beyond this (or NaN) is no estimate: the sample votes for nothing (and n * w * 2^16 stays far inside int64 / exact in float)
+constexpr int KNN = 6;                    // cgal_poisson.cpp:77: compute_average_spacing(points, 6)
+typedef long long fix_t;
 
 struct Grid {
     int G;            // nodes per axis
@@ -46,8 +58,8 @@ struct Grid {
 __device__ __forceinline__ size_t node(const Grid &g, int i, int j, int k) { return ((size_t)k * g.G + j) * g.G + i; }
 
 // samples: xyzw rows (w divides) + normal rows
-__global__ void splat_kernel(Grid g, const float *__restrict__ pts, const float *__restrict__ nrm, int n, int *__restrict__ vx, int *__restrict__ vy,
-                             int *__restrict__ vz, int *__restrict__ wt)
+__global__ void splat_kernel(Grid g, const float *__restrict__ pts, const float *__restrict__ nrm, int n, fix_t *__restrict__ vx, fix_t *__restrict__ vy,
+                             fix_t *__restrict__ vz, fix_t *__restrict__ wt)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
@@ -58,20 +70,117 @@ __global__ void splat_kernel(Grid g, const float *__restrict__ pts, const float 
     if (i < 0 || j < 0 || k < 0 || i + 1 >= g.G || j + 1 >= g.G || k + 1 >= g.G) return;  // (the box is padded: cannot happen for the box's own samples)
     const float tx = gx - fx, ty = gy - fy, tz = gz - fz;
     const float nx = nrm[3 * s], ny = nrm[3 * s + 1], nz = nrm[3 * s + 2];
-    if (!(fabsf(nx) <= 1e6f && fabsf(ny) <= 1e6f && fabsf(nz) <= 1e6f)) return;  // a sample without a usable normal (NaN: util.cpp:299's PCA can fail) votes for nothing
+    if (!(fabsf(nx) <= NORMAL_LIMIT && fabsf(ny) <= NORMAL_LIMIT && fabsf(nz) <= NORMAL_LIMIT)) return;  // a sample without a usable normal (NaN: util.cpp:299's PCA can fail) votes for nothing
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const int di = c & 1, dj = (c >> 1) & 1, dk = c >> 2;
         const float wgt = (di ? tx : 1.0f - tx) * (dj ? ty : 1.0f - ty) * (dk ? tz : 1.0f - tz);
         const size_t q = node(g, i + di, j + dj, k + dk);
-        atomicAdd(&vx[q], (int)rintf(nx * wgt * SPLAT_SCALE));
-        atomicAdd(&vy[q], (int)rintf(ny * wgt * SPLAT_SCALE));
-        atomicAdd(&vz[q], (int)rintf(nz * wgt * SPLAT_SCALE));
-        atomicAdd(&wt[q], (int)rintf(wgt * SPLAT_SCALE));
+        // (two's complement: the unsigned 64-bit atomic adds signed values correctly)
+        atomicAdd((unsigned long long *)&vx[q], (unsigned long long)(fix_t)rintf(nx * wgt * SPLAT_SCALE));
+        atomicAdd((unsigned long long *)&vy[q], (unsigned long long)(fix_t)rintf(ny * wgt * SPLAT_SCALE));
+        atomicAdd((unsigned long long *)&vz[q], (unsigned long long)(fix_t)rintf(nz * wgt * SPLAT_SCALE));
+        atomicAdd((unsigned long long *)&wt[q], (unsigned long long)(fix_t)rintf(wgt * SPLAT_SCALE));
     }
 }
 
-__global__ void fixed_to_float_kernel(const int *__restrict__ a, float *__restrict__ out, size_t n)
+// ---- average spacing (step 0): CGAL::compute_average_spacing(points, 6), cgal_poisson.cpp:77 -----------------------------------
+// Per sample the mean distance to its KNN nearest OTHER samples (CGAL asks its k-d tree for k + 1 neighbours and skips the query point
+// itself; coincident samples count, at distance 0), averaged over the samples.  On the device: the samples are sorted by the cell of
+// a uniform grid (cell ~ two sample spacings of a surface sampling: a handful of samples per cell), a sample scans the block of
+// (2R + 1)^3 cells around its own -- one binary search per cell row, the cells of a row are consecutive keys -- and stops as soon as
+// its KNN-th distance is at most R cells: everything outside the block is farther than that.  R doubles otherwise (sparse corners,
+// volumetric clouds).  Exact, not approximate; the host sums the per-sample means in sample order (deterministic).
+struct CellGrid {
+    float ox, oy, oz, inv, cell;
+    int nx, ny, nz;
+};
+
+__device__ __forceinline__ void cell_of(const CellGrid &c, float x, float y, float z, int &i, int &j, int &k)
+{
+    i = min(max((int)floorf((x - c.ox) * c.inv), 0), c.nx - 1);
+    j = min(max((int)floorf((y - c.oy) * c.inv), 0), c.ny - 1);
+    k = min(max((int)floorf((z - c.oz) * c.inv), 0), c.nz - 1);
+}
+
+__global__ void cell_keys_kernel(CellGrid c, const float *__restrict__ pts, int n, unsigned *__restrict__ keys, int *__restrict__ ids)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float w = pts[4 * s + 3];
+    int i, j, k;
+    cell_of(c, pts[4 * s] / w, pts[4 * s + 1] / w, pts[4 * s + 2] / w, i, j, k);
+    keys[s] = (unsigned)((k * c.ny + j) * c.nx + i);
+    ids[s] = s;
+}
+
+__global__ void cell_points_kernel(const float *__restrict__ pts, const int *__restrict__ ids, int n, float4 *__restrict__ sorted)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int q = ids[s];
+    const float w = pts[4 * q + 3];
+    sorted[s] = make_float4(pts[4 * q] / w, pts[4 * q + 1] / w, pts[4 * q + 2] / w, 0.0f);
+}
+
+__device__ __forceinline__ int lower_bound_u32(const unsigned *__restrict__ a, int n, unsigned key)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void knn_spacing_kernel(CellGrid c, const unsigned *__restrict__ keys, const float4 *__restrict__ sorted, const int *__restrict__ ids, int n,
+                                   float *__restrict__ out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float4 p = sorted[s];
+    int ci, cj, ck;
+    cell_of(c, p.x, p.y, p.z, ci, cj, ck);
+    float best[KNN];
+    const int rmax = max(c.nx, max(c.ny, c.nz));
+    for (int R = 1;; R *= 2) {
+#pragma unroll
+        for (int t = 0; t < KNN; t++) best[t] = 3.0e38f;
+        const int i0 = max(ci - R, 0), i1 = min(ci + R, c.nx - 1);
+        for (int k = max(ck - R, 0); k <= min(ck + R, c.nz - 1); k++)
+            for (int j = max(cj - R, 0); j <= min(cj + R, c.ny - 1); j++) {
+                const unsigned row = (unsigned)((k * c.ny + j) * c.nx);
+                const int a = lower_bound_u32(keys, n, row + (unsigned)i0), b = lower_bound_u32(keys, n, row + (unsigned)i1 + 1u);
+                for (int t = a; t < b; t++) {
+                    if (t == s) continue;
+                    const float4 q = sorted[t];
+                    const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+                    float d = dx * dx + dy * dy + dz * dz;
+                    if (d < best[KNN - 1]) {  // insertion into the ascending list
+#pragma unroll
+                        for (int u = 0; u < KNN; u++) {
+                            const float lo = fminf(best[u], d);
+                            d = fmaxf(best[u], d);
+                            best[u] = lo;
+                        }
+                    }
+                }
+            }
+        const float reach = (float)R * c.cell;
+        if (best[KNN - 1] <= reach * reach || R >= rmax) break;
+    }
+    float sum = 0.0f;
+    int m = 0;
+#pragma unroll
+    for (int t = 0; t < KNN; t++)
+        if (best[t] < 3.0e38f) {
+            sum += sqrtf(best[t]);
+            m++;
+        }
+    out[ids[s]] = m ? sum / (float)m : 0.0f;
+}
+
+__global__ void fixed_to_float_kernel(const fix_t *__restrict__ a, float *__restrict__ out, size_t n)
 {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n) out[q] = (float)a[q] * (1.0f / SPLAT_SCALE);
@@ -245,6 +354,20 @@ int fail(int code, const char *what)
     return code;
 }
 
+template <class K, class V>
+bool sort_pairs(K *keys_in, K *keys_out, V *vals_in, V *vals_out, size_t n, hipStream_t st, void **tmp, size_t &tmp_bytes)
+{
+    size_t need = 0;
+    if (rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, n, 0, sizeof(K) * 8, st) != hipSuccess) return false;
+    if (need > tmp_bytes) {
+        if (*tmp) (void)hipFree(*tmp);
+        *tmp = nullptr;
+        if (hipMalloc(tmp, need) != hipSuccess) return false;
+        tmp_bytes = need;
+    }
+    return rocprim::radix_sort_pairs(*tmp, need, keys_in, keys_out, vals_in, vals_out, n, 0, sizeof(K) * 8, st) == hipSuccess;
+}
+
 bool scan(int *flags, int *offsets, size_t n, hipStream_t st, DevBuf &tmp, size_t &tmp_bytes)
 {
     size_t need = 0;
@@ -258,15 +381,28 @@ bool scan(int *flags, int *offsets, size_t n, hipStream_t st, DevBuf &tmp, size_
     return rocprim::exclusive_scan(tmp.p, need, flags, offsets, 0, n, rocprim::plus<int>(), st) == hipSuccess;
 }
 
+// hipFFT plans of the last grid size, kept for the process (rocFFT compiles its kernels for a size at the first
+// plan of that size in a process -- about 2 s at 256^3 -- and building the two plans costs tens of milliseconds every time after that;
+// Heuristic::tessellate calls this once per outer iteration with clouds of similar size, i.e. the same grid).  One size is kept (a plan
+// holds work buffers); the mutex also serialises the transforms of concurrent callers on the shared plans.
+struct PlanCache {
+    std::mutex m;
+    int G = 0;
+    hipfftHandle fwd = 0, inv = 0;
+};
+PlanCache g_plans;
+
 }  // namespace
 
 struct mvs_surface {
     Grid grid{};
     float iso = 0.0f;
+    float spacing = 0.0f;     // CGAL::compute_average_spacing(points, 6) of the samples
+    int ratio_kept = 1;       // node spacing <= 0.75 x average spacing (0: the finest grid, 512^3, is coarser than that)
     std::vector<float> vertices;   // 4 per vertex
     std::vector<int32_t> faces;    // 3 per face
     std::vector<float> chi;        // G^3, kept when asked for (tests)
-    std::vector<int32_t> splat;    // 4 G^3 (vx, vy, vz, weight), kept when asked for (tests)
+    std::vector<int64_t> splat;    // 4 G^3 (vx, vy, vz, weight), kept when asked for (tests)
 };
 
 extern "C" const char *mvs_surface_last_error(void) { return g_poisson_error.c_str(); }
@@ -290,16 +426,80 @@ extern "C" int mvs_poisson_surface(const float *points, const float *normals, in
     double side = 0.0;
     for (int c = 0; c < 3; c++) side = std::max(side, hi[c] - lo[c]);
     if (!(side > 0.0)) return fail(MVS_EINVAL, "mvs_poisson_surface: the points have no extent");
-    int lg = grid_log2;
-    if (lg == 0) {  // a cell about as wide as the samples are apart: a closed surface sampled by n points has ~0.56 sqrt(n) of them across, the box is 1.5 x
-        const double want = std::sqrt((double)n);
+    const double box = 1.5 * side;
+    // ---- step 0: the samples' average spacing (device), then the grid ----
+    hipStream_t st = nullptr;
+    DevBuf d_pts, d_nrm;
+    if (!d_pts.alloc((size_t)n * 16) || !d_nrm.alloc((size_t)n * 12)) return fail(MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
+    if (hipMemcpy(d_pts.p, points, (size_t)n * 16, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_nrm.p, normals, (size_t)n * 12, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(MVS_EHIP, "mvs_poisson_surface: upload failed");
+    double spacing = 0.0;
+    {
+        // The cell grid spans a ROBUST extent of the samples (2nd .. 98th percentile per axis, plus a margin): a few outliers must not
+        // blow the cells up until the real samples share one of them (the search stays exact either way: samples outside the grid are
+        // binned into its border cells, and a border cell is only skipped when it is farther away than the search radius).
+        CellGrid cg;
+        double rlo[3], rhi[3], rside = 0.0;
+        try {
+            std::vector<float> axis((size_t)n);
+            for (int c = 0; c < 3; c++) {
+                for (int s = 0; s < n; s++) axis[(size_t)s] = points[4 * s + c] / points[4 * s + 3];
+                const size_t a = (size_t)(0.02 * (double)(n - 1)), b = (size_t)(0.98 * (double)(n - 1));
+                std::nth_element(axis.begin(), axis.begin() + (std::ptrdiff_t)a, axis.end());
+                rlo[c] = (double)axis[a];
+                std::nth_element(axis.begin(), axis.begin() + (std::ptrdiff_t)b, axis.end());
+                rhi[c] = (double)axis[b];
+                rside = std::max(rside, rhi[c] - rlo[c]);
+            }
+        } catch (...) {
+            return fail(MVS_ENOMEM, "mvs_poisson_surface: host allocation failed");
+        }
+        if (!(rside > 0.0)) {  // degenerate percentiles (most samples coincide): the full box
+            rside = side;
+            for (int c = 0; c < 3; c++) rlo[c] = lo[c], rhi[c] = hi[c];
+        }
+        const double cell = std::max(2.0 * rside / std::sqrt((double)n), rside / 1000.0);  // ~ two spacings of a surface sampling; at most ~1000 cells per axis
+        cg.cell = (float)cell;
+        cg.inv = (float)(1.0 / cell);
+        cg.ox = (float)(rlo[0] - 2.0 * cell), cg.oy = (float)(rlo[1] - 2.0 * cell), cg.oz = (float)(rlo[2] - 2.0 * cell);
+        cg.nx = std::max(1, std::min(1024, (int)std::floor((rhi[0] - rlo[0]) / cell) + 5));
+        cg.ny = std::max(1, std::min(1024, (int)std::floor((rhi[1] - rlo[1]) / cell) + 5));
+        cg.nz = std::max(1, std::min(1024, (int)std::floor((rhi[2] - rlo[2]) / cell) + 5));
+        DevBuf k0, k1, i0, i1, sorted, per;
+        void *tmp = nullptr;
+        size_t tmp_bytes = 0;
+        bool ok = k0.alloc((size_t)n * 4) && k1.alloc((size_t)n * 4) && i0.alloc((size_t)n * 4) && i1.alloc((size_t)n * 4) && sorted.alloc((size_t)n * 16) && per.alloc((size_t)n * 4);
+        std::vector<float> host;
+        try {
+            host.resize((size_t)n);
+        } catch (...) {
+            ok = false;
+        }
+        if (ok) {
+            cell_keys_kernel<<<(n + 255) / 256, 256, 0, st>>>(cg, d_pts.as<float>(), n, k0.as<unsigned>(), i0.as<int>());
+            ok = sort_pairs(k0.as<unsigned>(), k1.as<unsigned>(), i0.as<int>(), i1.as<int>(), (size_t)n, st, &tmp, tmp_bytes);
+        }
+        if (ok) {
+            cell_points_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_pts.as<float>(), i1.as<int>(), n, sorted.as<float4>());
+            knn_spacing_kernel<<<(n + 127) / 128, 128, 0, st>>>(cg, k1.as<unsigned>(), sorted.as<float4>(), i1.as<int>(), n, per.as<float>());
+            ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(host.data(), per.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+        }
+        if (tmp) (void)hipFree(tmp);
+        if (!ok) return fail(MVS_EHIP, "mvs_poisson_surface: average spacing failed");
+        for (int s = 0; s < n; s++) spacing += (double)host[s];
+        spacing /= (double)n;
+    }
+    int lg = grid_log2, ratio_kept = 1;
+    if (lg == 0) {  // the coarsest grid whose nodes are at most 0.75 average spacings apart (header: step 0); 512^3 at the most
         lg = 5;
-        while (lg < 8 && (double)(1 << lg) < want) lg++;
+        while (lg < 9 && box / (double)((1 << lg) - 1) > 0.75 * spacing) lg++;
+        ratio_kept = box / (double)((1 << lg) - 1) <= 0.75 * spacing ? 1 : 0;
+    } else {
+        ratio_kept = box / (double)((1 << lg) - 1) <= 0.75 * spacing ? 1 : 0;
     }
     if (lg < 4) return fail(MVS_EINVAL, "mvs_poisson_surface: the grid needs at least 16 nodes per axis");
     Grid g;
     g.G = 1 << lg;
-    const double box = 1.5 * side;
     g.h = (float)(box / (double)(g.G - 1));
     g.ox = (float)(0.5 * (lo[0] + hi[0]) - 0.5 * box);
     g.oy = (float)(0.5 * (lo[1] + hi[1]) - 0.5 * box);
@@ -311,36 +511,47 @@ extern "C" int mvs_poisson_surface(const float *points, const float *normals, in
     mvs_surface *res = new (std::nothrow) mvs_surface;
     if (!res) return fail(MVS_ENOMEM, "mvs_poisson_surface: host allocation failed");
     res->grid = g;
-    hipStream_t st = nullptr;
-    DevBuf d_pts, d_nrm, d_fix, d_real, d_spec, d_flag, d_index, d_cell_index, d_tmp, d_samples, d_vertices, d_faces;
+    res->spacing = (float)spacing;
+    res->ratio_kept = ratio_kept;
+    DevBuf d_fix, d_real, d_spec, d_flag, d_index, d_cell_index, d_tmp, d_samples, d_vertices, d_faces;
     size_t tmp_bytes = 0;
-    hipfftHandle fwd = 0, inv = 0;
-    bool have_fwd = false, have_inv = false;
     int rc = MVS_OK;
     const char *msg = "";
 #define PS_TRY(cond, code, text) do { if (!(cond)) { rc = (code); msg = (text); goto done; } } while (0)
     try {
-        PS_TRY(d_pts.alloc((size_t)n * 16) && d_nrm.alloc((size_t)n * 12) && d_fix.alloc(4 * N3 * 4) && d_real.alloc(3 * N3 * 4) && d_spec.alloc(3 * S3 * 8) &&
+        PS_TRY(d_fix.alloc(4 * N3 * sizeof(fix_t)) && d_real.alloc(3 * N3 * 4) && d_spec.alloc(3 * S3 * 8) &&
                    d_flag.alloc(3 * N3 * 4) && d_index.alloc((3 * N3 + 1) * 4) && d_cell_index.alloc((C3 + 1) * 4) && d_samples.alloc((size_t)n * 4),
                MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
-        PS_TRY(hipMemcpy(d_pts.p, points, (size_t)n * 16, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_nrm.p, normals, (size_t)n * 12, hipMemcpyHostToDevice) == hipSuccess &&
-                   hipMemsetAsync(d_fix.p, 0, 4 * N3 * 4, st) == hipSuccess,
-               MVS_EHIP, "mvs_poisson_surface: upload failed");
-        int *vx = d_fix.as<int>(), *vy = vx + N3, *vz = vy + N3, *wt = vz + N3;
+        PS_TRY(hipMemsetAsync(d_fix.p, 0, 4 * N3 * sizeof(fix_t), st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: clearing the grid failed");
+        fix_t *vx = d_fix.as<fix_t>(), *vy = vx + N3, *vz = vy + N3, *wt = vz + N3;
         splat_kernel<<<(n + 255) / 256, 256, 0, st>>>(g, d_pts.as<float>(), d_nrm.as<float>(), n, vx, vy, vz, wt);
         fixed_to_float_kernel<<<(unsigned)((3 * N3 + 255) / 256), 256, 0, st>>>(vx, d_real.as<float>(), 3 * N3);
         PS_TRY(hipGetLastError() == hipSuccess, MVS_EHIP, "mvs_poisson_surface: splat launch failed");
-        PS_TRY(hipfftPlan3d(&fwd, g.G, g.G, g.G, HIPFFT_R2C) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: hipfftPlan3d (R2C) failed");
-        have_fwd = true;
-        PS_TRY(hipfftPlan3d(&inv, g.G, g.G, g.G, HIPFFT_C2R) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: hipfftPlan3d (C2R) failed");
-        have_inv = true;
-        PS_TRY(hipfftSetStream(fwd, st) == HIPFFT_SUCCESS && hipfftSetStream(inv, st) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: hipfftSetStream failed");
         hipfftComplex *spec = d_spec.as<hipfftComplex>();
-        for (int c = 0; c < 3; c++)
-            PS_TRY(hipfftExecR2C(fwd, d_real.as<float>() + c * N3, spec + c * S3) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: forward FFT failed");
-        spectral_solve_kernel<<<(unsigned)((S3 + 255) / 256), 256, 0, st>>>(g.G, smooth_cells, spec, spec + S3, spec + 2 * S3);
         float *chi = d_real.as<float>();  // (the transform may overwrite its input: spec[0] is not used again)
-        PS_TRY(hipfftExecC2R(inv, spec, chi) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: inverse FFT failed");
+        {
+            std::lock_guard<std::mutex> lock(g_plans.m);  // the plans of the last grid size are kept for the process (see PlanCache)
+            if (g_plans.G != g.G) {
+                if (g_plans.G) {
+                    (void)hipfftDestroy(g_plans.fwd);
+                    (void)hipfftDestroy(g_plans.inv);
+                    g_plans.G = 0;
+                }
+                hipfftHandle fwd = 0, inv = 0;
+                PS_TRY(hipfftPlan3d(&fwd, g.G, g.G, g.G, HIPFFT_R2C) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: hipfftPlan3d (R2C) failed");
+                if (hipfftPlan3d(&inv, g.G, g.G, g.G, HIPFFT_C2R) != HIPFFT_SUCCESS) {
+                    (void)hipfftDestroy(fwd);
+                    PS_TRY(false, MVS_EHIP, "mvs_poisson_surface: hipfftPlan3d (C2R) failed");
+                }
+                g_plans.fwd = fwd, g_plans.inv = inv, g_plans.G = g.G;
+            }
+            PS_TRY(hipfftSetStream(g_plans.fwd, st) == HIPFFT_SUCCESS && hipfftSetStream(g_plans.inv, st) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: hipfftSetStream failed");
+            for (int c = 0; c < 3; c++)
+                PS_TRY(hipfftExecR2C(g_plans.fwd, d_real.as<float>() + c * N3, spec + c * S3) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: forward FFT failed");
+            spectral_solve_kernel<<<(unsigned)((S3 + 255) / 256), 256, 0, st>>>(g.G, smooth_cells, spec, spec + S3, spec + 2 * S3);
+            PS_TRY(hipfftExecC2R(g_plans.inv, spec, chi) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: inverse FFT failed");
+            PS_TRY(hipStreamSynchronize(st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: the transforms failed");  // before another caller may use the plans
+        }
         sample_kernel<<<(n + 255) / 256, 256, 0, st>>>(g, chi, d_pts.as<float>(), n, d_samples.as<float>());
         std::vector<float> samples((size_t)n);
         PS_TRY(hipMemcpyAsync(samples.data(), d_samples.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess, MVS_EHIP,
@@ -380,7 +591,7 @@ extern "C" int mvs_poisson_surface(const float *points, const float *normals, in
             res->chi.resize(N3);
             res->splat.resize(4 * N3);
             PS_TRY(hipMemcpyAsync(res->chi.data(), chi, N3 * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                       hipMemcpyAsync(res->splat.data(), d_fix.p, 4 * N3 * 4, hipMemcpyDeviceToHost, st) == hipSuccess,
+                       hipMemcpyAsync(res->splat.data(), d_fix.p, 4 * N3 * sizeof(fix_t), hipMemcpyDeviceToHost, st) == hipSuccess,
                    MVS_EHIP, "mvs_poisson_surface: download failed");
         }
         PS_TRY(hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess, MVS_EHIP, "mvs_poisson_surface: a kernel failed");
@@ -390,8 +601,6 @@ extern "C" int mvs_poisson_surface(const float *points, const float *normals, in
     }
 done:
 #undef PS_TRY
-    if (have_fwd) (void)hipfftDestroy(fwd);
-    if (have_inv) (void)hipfftDestroy(inv);
     if (rc != MVS_OK) {
         delete res;
         return fail(rc, msg);
@@ -416,7 +625,16 @@ extern "C" int mvs_surface_fetch(const mvs_surface *s, float *vertices, int32_t 
     return MVS_OK;
 }
 
-extern "C" int mvs_surface_grid(const mvs_surface *s, int *nodes_per_axis, float *origin3, float *spacing, float *level, float *chi, int32_t *splat)
+extern "C" int mvs_surface_spacing(const mvs_surface *s, float *average_spacing, float *node_spacing, int *ratio_kept)
+{
+    if (!s) return MVS_EINVAL;
+    if (average_spacing) *average_spacing = s->spacing;
+    if (node_spacing) *node_spacing = s->grid.h;
+    if (ratio_kept) *ratio_kept = s->ratio_kept;
+    return MVS_OK;
+}
+
+extern "C" int mvs_surface_grid(const mvs_surface *s, int *nodes_per_axis, float *origin3, float *spacing, float *level, float *chi, int64_t *splat)
 {
     if (!s) return MVS_EINVAL;
     if (nodes_per_axis) *nodes_per_axis = s->grid.G;
@@ -429,7 +647,7 @@ extern "C" int mvs_surface_grid(const mvs_surface *s, int *nodes_per_axis, float
     }
     if (splat) {
         if (s->splat.empty()) return MVS_ESTATE;
-        std::memcpy(splat, s->splat.data(), s->splat.size() * 4);
+        std::memcpy(splat, s->splat.data(), s->splat.size() * sizeof(int64_t));
     }
     return MVS_OK;
 }

@@ -102,6 +102,7 @@ ABI = [
     ("mvs_surface_counts", _i, [_vp, _vp, _vp]),
     ("mvs_surface_fetch", _i, [_vp, _vp, _vp]),
     ("mvs_surface_grid", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mvs_surface_spacing", _i, [_vp, _vp, _vp, _vp]),
     ("mvs_surface_free", None, [_vp]),
     ("mvs_surface_last_error", C.c_char_p, []),
 ]

@@ -102,18 +102,29 @@ def alpha_shape(points, forced_alpha=0.0):
 SPLAT_SCALE = np.float32(65536.0)
 
 
+def average_spacing(points, k=6):
+    """CGAL::compute_average_spacing(points, k) (cgal_poisson.cpp:77): per sample the mean distance to its k nearest OTHER samples
+    (CGAL queries k + 1 neighbours and skips the query point), averaged over the samples; scipy's k-d tree, float64"""
+    from scipy.spatial import cKDTree
+    p = np.asarray(points, np.float32)
+    xyz = (p[:, :3] / p[:, 3:4]).astype(np.float64)
+    kk = min(k, len(xyz) - 1)
+    d, _ = cKDTree(xyz).query(xyz, k=kk + 1)
+    return float(d[:, 1:].mean())
+
+
 def poisson_grid(points, grid_log2):
-    """the box and grid csrc/poisson.hip chooses: (G, origin float32[3], h float32)"""
+    """the box and grid csrc/poisson.hip chooses: (G, origin float32[3], h float32); grid_log2 = 0: the coarsest of 32..512 nodes per
+    axis with node spacing <= 0.75 x the samples' average 6-nearest-neighbour spacing"""
     p = np.asarray(points, np.float32)
     xyz = (p[:, :3] / p[:, 3:4]).astype(np.float64)
     lo, hi = xyz.min(0), xyz.max(0)
     side = float((hi - lo).max())
-    n = len(p)
     lg = grid_log2
     if lg == 0:
-        want = np.sqrt(float(n))
+        sp = average_spacing(p)
         lg = 5
-        while lg < 8 and float(1 << lg) < want:
+        while lg < 9 and 1.5 * side / float((1 << lg) - 1) > 0.75 * sp:
             lg += 1
     G = 1 << lg
     box = 1.5 * side
@@ -123,13 +134,14 @@ def poisson_grid(points, grid_log2):
 
 
 def poisson_splat(points, normals, G, origin, h):
-    """the four fixed-point fields [vx, vy, vz, weight][z][y][x], int32: the same integers as splat_kernel (float32 arithmetic in its order)"""
+    """the four fixed-point fields [vx, vy, vz, weight][z][y][x], int64: the same integers as splat_kernel (float32 arithmetic in its order)"""
     p = np.asarray(points, np.float32)
     nrm = np.asarray(normals, np.float32)
     g = ((p[:, :3] / p[:, 3:4]) - origin[None, :]) / h                     # float32 throughout
     f = np.floor(g)
     ijk = f.astype(np.int64)
-    ok = np.all((ijk >= 0) & (ijk + 1 < G), axis=1) & np.all(np.abs(nrm) <= np.float32(1e6), axis=1)   # (NaN normals fail the comparison too)
+    ok = np.all((ijk >= 0) & (ijk + 1 < G), axis=1) & np.all(np.abs(nrm) <= np.float32(1e4), axis=1)   # (NaN normals fail the comparison too)
+    nrm = np.where(ok[:, None], nrm, np.float32(0.0))        # masked BEFORE the integer cast: NaN -> int64 is undefined (and warns)
     t = (g - f).astype(np.float32)
     out = np.zeros((4, G, G, G), np.int64)
     one = np.float32(1.0)
@@ -143,7 +155,7 @@ def poisson_splat(points, normals, G, origin, h):
             val = np.rint((nrm[:, ch] * w).astype(np.float32) * SPLAT_SCALE).astype(np.int64)
             np.add.at(out[ch], (q[ok, 2], q[ok, 1], q[ok, 0]), val[ok])
         np.add.at(out[3], (q[ok, 2], q[ok, 1], q[ok, 0]), np.rint(w * SPLAT_SCALE).astype(np.int64)[ok])
-    return out.astype(np.int32)
+    return out
 
 
 def poisson_chi(splat, smooth):

@@ -80,10 +80,12 @@ def poisson(hip, pts, nrm, grid_log2=0, smooth=1.0, keep=True):
     origin = np.zeros(3, np.float32)
     h, iso = ctypes.c_float(), ctypes.c_float()
     hip.mvs_surface_grid(s, ctypes.byref(G), origin.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h), ctypes.byref(iso), None, None)
-    out = {"vertices": v, "faces": f, "G": G.value, "origin": origin, "h": h.value, "iso": iso.value}
+    avg, node, kept = ctypes.c_float(), ctypes.c_float(), ctypes.c_int()
+    assert hip.mvs_surface_spacing(s, ctypes.byref(avg), ctypes.byref(node), ctypes.byref(kept)) == 0 and node.value == h.value
+    out = {"vertices": v, "faces": f, "G": G.value, "origin": origin, "h": h.value, "iso": iso.value, "spacing": avg.value, "ratio_kept": kept.value}
     if keep:
         chi = np.zeros((G.value,) * 3, np.float32)
-        splat = np.zeros((4,) + (G.value,) * 3, np.int32)
+        splat = np.zeros((4,) + (G.value,) * 3, np.int64)
         assert hip.mvs_surface_grid(s, None, None, None, None, chi.ctypes.data_as(ctypes.c_void_p), splat.ctypes.data_as(ctypes.c_void_p)) == 0
         out["chi"], out["splat"] = chi, splat
     hip.mvs_surface_free(s)

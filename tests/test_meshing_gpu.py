@@ -86,6 +86,45 @@ def test_sphere_and_torus_are_closed_outward_and_within_a_cell(hip):
     assert d.max() <= 1.5 * r["h"]
 
 
+def test_grid_from_the_average_spacing_keeps_the_references_approximation_bound(hip):
+    """cgal_poisson.cpp:77 measures the samples' average 6-nearest-neighbour spacing and :52 / :99 asks the mesher for an approximation
+    error of at most 0.375 x that spacing.  The grid is chosen from the same yardstick (device k-NN == scipy's k-d tree), and on analytic
+    surfaces every vertex of the output lies within that bound of the true surface."""
+    rng = np.random.default_rng(4)
+    for name, (pts, nrm), dist in (
+            ("sphere", _sphere(rng, 30000, (1.0, 2.0, -3.0), 1.5), lambda v: np.abs(np.linalg.norm(v[:, :3] - np.array([1.0, 2.0, -3.0]), axis=1) - 1.5)),
+            ("torus", _torus(rng, 60000, 1.0, 0.35), lambda v: np.abs(np.hypot(np.hypot(v[:, 0], v[:, 1]) - 1.0, v[:, 2]) - 0.35)),
+            ("small sphere", _sphere(rng, 4000, (0.0, 0.0, 0.0), 0.5), lambda v: np.abs(np.linalg.norm(v[:, :3], axis=1) - 0.5))):
+        r = mc.poisson(hip, pts, nrm, 0, 1.0, keep=False)
+        sp = mo.average_spacing(pts)
+        assert abs(r["spacing"] - sp) <= 1e-5 * sp, name
+        G, origin, h = mo.poisson_grid(pts, 0)
+        assert r["G"] == G and np.float32(r["h"]) == h and r["ratio_kept"] == 1 and r["h"] <= 0.75 * sp, name
+        assert G == 32 or 1.5 * float(np.ptp(pts[:, :3] / pts[:, 3:4], axis=0).max()) / (G // 2 - 1) > 0.75 * sp, name   # the coarsest grid that keeps the ratio
+        err = dist(r["vertices"])
+        assert err.max() <= 0.375 * sp, (name, float(err.max()), 0.375 * sp, r["h"])
+    # a forced coarse grid reports that the ratio is not kept (and the default caps at 512 nodes per axis)
+    pts, nrm = _sphere(rng, 30000, (0, 0, 0), 1.0)
+    assert mc.poisson(hip, pts, nrm, 5, 1.0, keep=False)["ratio_kept"] == 0
+
+
+def test_a_cell_that_collects_more_than_2_pow_31_does_not_wrap(hip):
+    """two outliers stretch the box until the real samples share a few cells; with 32-bit accumulators the weight and normal
+    fields wrapped silently.  The fields are 64-bit now: the integers equal the oracle's (numpy int64)"""
+    rng = np.random.default_rng(11)
+    pts, nrm = _sphere(rng, 400000, (0.0, 0.0, 0.0), 0.01)
+    pts[0, :3] = (-40.0, -40.0, -40.0)
+    pts[1, :3] = (40.0, 40.0, 40.0)
+    pts[:, 3] = 1.0
+    nrm[5] = (3.0e4, 0.0, 0.0)            # beyond the guard: votes for nothing
+    r = mc.poisson(hip, pts, nrm, 5, 1.0)
+    G, origin, h = mo.poisson_grid(pts, 5)
+    splat = mo.poisson_splat(pts, nrm, G, origin, h)
+    assert splat[3].max() > 2 ** 31 and np.array_equal(splat, r["splat"])
+    sp = mo.average_spacing(pts)          # the two outliers must neither slow the neighbour search to a crawl nor change its result
+    assert abs(r["spacing"] - sp) <= 1e-4 * sp
+
+
 def test_a_rerun_gives_the_same_bytes_and_bad_arguments_fail(hip):
     rng = np.random.default_rng(9)
     pts, nrm = _sphere(rng, 5000, (0, 0, 0), 1.0)
