@@ -170,7 +170,7 @@ bool readPgm(const std::string &path, int w, int h, Mat &out)
     int pw = 0, ph = 0, maxv = 0;
     f >> magic >> pw >> ph >> maxv;
     f.get();
-    if (magic != "P5" || pw < 1 || ph < 1 || maxv != 255) throw std::runtime_error("frame " + path + ": expected a binary 8-bit PGM");
+    if (magic != "P5" || pw < 1 || ph < 1 || pw > 16384 || ph > 16384 || maxv != 255) throw std::runtime_error("frame " + path + ": expected a binary 8-bit PGM of at most 16384 x 16384");
     (void)w;  // a frame of another size than the (scaled) clip is resized by the caller, as configuration.cpp:232-233 does
     (void)h;
     out.create(ph, pw, mvs::U8C1);
@@ -187,7 +187,7 @@ bool readPpm(const std::string &path, int w, int h, Mat &out)
     int pw = 0, ph = 0, maxv = 0;
     f >> magic >> pw >> ph >> maxv;
     f.get();
-    if (magic != "P6" || pw < 1 || ph < 1 || maxv != 255) throw std::runtime_error("frame " + path + ": expected a binary 8-bit PPM");
+    if (magic != "P6" || pw < 1 || ph < 1 || pw > 16384 || ph > 16384 || maxv != 255) throw std::runtime_error("frame " + path + ": expected a binary 8-bit PPM of at most 16384 x 16384");
     (void)w;
     (void)h;
     out.create(ph, pw, mvs::U8C3);
@@ -217,14 +217,15 @@ bool readY4m(const std::string &path, int skipFrames, int count, std::vector<Mat
         else if (tag[0] == 'H') h = atoi(tag.c_str() + 1);
         else if (tag[0] == 'C') {
             const std::string c = tag.substr(1);
-            if (c.compare(0, 3, "420") == 0) cw = 2, ch = 2;
+            // exact tags only: C420p10 / C420p12 / C420p16 carry two bytes per sample and would decode as garbage
+            if (c == "420" || c == "420jpeg" || c == "420mpeg2" || c == "420paldv") cw = 2, ch = 2;
             else if (c == "422") cw = 2, ch = 1;
             else if (c == "444") cw = 1, ch = 1;
             else if (c == "mono") cw = 0, ch = 0;
             else throw std::runtime_error("clip " + path + ": unsupported YUV4MPEG2 colour space " + c + " (8-bit 420 / 422 / 444 / mono only)");
         }
     }
-    if (w < 1 || h < 1) throw std::runtime_error("clip " + path + ": YUV4MPEG2 header without a size");
+    if (w < 1 || h < 1 || w > 16384 || h > 16384) throw std::runtime_error("clip " + path + ": YUV4MPEG2 header without a size (or beyond 16384 x 16384)");
     const size_t cpw = cw ? (size_t)(w + cw - 1) / cw : 0, cph = ch ? (size_t)(h + ch - 1) / ch : 0;
     std::vector<uint8_t> Y((size_t)w * h), U(cpw * cph), V(cpw * cph);
     bgr.assign(count, Mat());
@@ -656,17 +657,20 @@ static Mat resizedToClip(const Mat &frame, int width, int height);
 
 // configuration.cpp:232-235: a decoded frame whose size is not (width, height) -- the -s option divides those -- goes through
 // cv::resize(frame, frames[fi], cv::Size(width, height), CV_INTER_AREA), i.e. INTER_LINEAR (the constant lands in the ignored fx
-// argument): mvs_resize_u8, on a context of its own (created on first use)
+// argument): mvs_resize_u8, on a context of its own per call
 Mat Configuration::resizedToClipSize(const Mat &frame) const { return resizedToClip(frame, width, height); }
 
 static Mat resizedToClip(const Mat &frame, int width, int height)
 {
-    static mvs_ctx *ctx = nullptr;
-    if (!ctx) ctx = mvs_create(0, width, height);
+    // a context per call, destroyed before returning: no process-wide handle that is never released or shared between threads
+    // (a frame is resized once, when it is loaded; creating a context is a stream creation)
+    mvs_ctx *ctx = mvs_create(0, width, height);
     if (!ctx) throw std::runtime_error(std::string("resize: ") + mvs_last_error(nullptr));
     Mat out(height, width, frame.type());
-    if (mvs_resize_u8(ctx, frame.ptr<uchar>(0), frame.cols, frame.rows, frame.channels(), out.ptr<uchar>(0), width, height))
-        throw std::runtime_error(std::string("resize: ") + mvs_last_error(ctx));
+    const int rc = mvs_resize_u8(ctx, frame.ptr<uchar>(0), frame.cols, frame.rows, frame.channels(), out.ptr<uchar>(0), width, height);
+    const std::string msg = rc ? mvs_last_error(ctx) : "";
+    mvs_destroy(ctx);
+    if (rc) throw std::runtime_error("resize: " + msg);
     return out;
 }
 

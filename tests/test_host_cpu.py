@@ -161,3 +161,19 @@ def test_uncompressed_clip_is_decoded_and_skipped_like_the_reference(tmp_path, o
     on the GPU: tests/test_host_gpu.py)"""
     import y4m_common
     y4m_common.run(tmp_path, oracle, scale=1)
+
+
+def test_high_bit_depth_y4m_streams_are_refused(tmp_path):
+    """C420p10 & co. carry two bytes per sample: read as 8-bit they would decode as garbage and fail late with a misleading message
+     -- the colour tag is matched exactly and the rest is refused by name"""
+    import re
+    import y4m_common
+    text = open(os.path.join(TRACKS, "zatisi.yaml")).read()
+    yaml_path = tmp_path / "zatisi.yaml"
+    yaml_path.write_text(text)
+    clip = re.search(r"path:\s*\"?([^\s\"]+)", text).group(1)
+    with open(tmp_path / (clip + ".y4m"), "wb") as f:
+        f.write(b"YUV4MPEG2 W640 H480 F25:1 Ip A1:1 C420p10\n")
+        f.write(b"FRAME\n" + bytes(640 * 480 * 3))
+    r = subprocess.run([y4m_common.SELFTEST, "frames", str(yaml_path), str(tmp_path), "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "unsupported YUV4MPEG2 colour space 420p10" in (r.stdout + r.stderr), r.stdout + r.stderr
