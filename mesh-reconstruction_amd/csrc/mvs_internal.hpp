@@ -70,6 +70,12 @@ struct mvs_ctx {
     // rectified fast path of the fixed sampler (sweep_rect.hip): per (tile column | tile row, view, plane) texel + phase + certificates
     mvs::DevBuf rect_tab;
     bool rect_ok = false;            // the current plan can be served by sweep_fx_rect
+    // rectified path of the exact sampler (sweep_xrect.hip): box tables, LDS row stride and slot size of the current plan
+    mvs::DevBuf xrect_tab;
+    bool xrect_ok = false;
+    int xrect_rs = 0, xrect_slot_bytes = 0;
+    bool exact_tiled_planned = false;  // sweep_tiled's region plan exists for the current (views, planes) (made on demand when xrect_ok)
+    int exact_last_shape = 0;          // what served the exact sampler's last run: 1 / 2 (sweep_tiled's thread shapes) or 5 (sweep_exact_rect)
     bool fx_general_planned = false; // the general tiled kernel's plan exists for the current (views, planes) (made on demand when rect_ok)
     int rect_rs = 0, rect_slot_dw = 0, rect_dpad = 0;
     std::vector<unsigned char> rect_cold_host;  // host copy of the kernel's cold block (sweep_rect.hip: RectCold)

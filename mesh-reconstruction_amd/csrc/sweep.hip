@@ -716,6 +716,8 @@ __global__ void rcp_check_kernel(uint32_t exp_bits, unsigned long long *out)
 int sweep_fx_plan_general(mvs_ctx *ctx);
 int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool generic, unsigned flags);
 int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsigned flags);
+int sweep_xrect_plan(mvs_ctx *ctx);  // sweep_xrect.hip: the exact sampler on rectified views
+int sweep_xrect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsigned flags);
 int warp_by_depth_fx_launch(mvs_ctx *ctx, const float *depth_dev, const float *q_dev, const uint8_t *pad_dev, int pitch, uint8_t *out2_dev);
 
 // defined in context.hip
@@ -803,7 +805,12 @@ int mvs_sweep_set_sampler(mvs_ctx *ctx, int sampler)
 
 int mvs_sweep_sampler(const mvs_ctx *ctx) { return ctx ? ctx->sampler : MVS_EINVAL; }
 
-int mvs_sweep_plan_shape(const mvs_ctx *ctx) { return (ctx && ctx->plan_valid) ? ((ctx->plan_shape == 3 && ctx->rect_ok) ? 4 : ctx->plan_shape) : 0; }
+int mvs_sweep_plan_shape(const mvs_ctx *ctx)
+{
+    if (!ctx || !ctx->plan_valid) return 0;
+    if (ctx->plan_shape == 3) return ctx->rect_ok ? 4 : 3;
+    return ctx->exact_last_shape;  // exact sampler: what served the last run (1 / 2: sweep_tiled's thread shapes, 5: sweep_exact_rect)
+}
 
 int mvs_sweep_run_planes(mvs_ctx *ctx, int view_first, int view_count, int plane_first, int plane_count, unsigned flags)
 {
@@ -889,11 +896,43 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
     if ((rc = ensure_pads(ctx))) return rc;  // the exact sampler's generic regions and its un-tiled kernel gather from the padded frames
     if (!generic && (rc = ensure_quads16(ctx))) return rc;
 
-    // thread shape of the tiled kernel (see the constants at the top): 2 pixels x 32 planes unless the planner finds
+    // Rectified views (the ring of SURVEY 8d) are served by sweep_exact_rect (sweep_xrect.hip); anything else, MVS_SWEEP_NO_RECT and the
+    // forced 4 x 16 shape by sweep_tiled, whose region plan is made when it is first needed.
+    // Thread shape of the tiled kernel (see the constants at the top): 2 pixels x 32 planes unless the planner finds
     // that more than 2 % of the regions a 32-plane chunk touches do not fit the LDS staging buffer
     const bool force_tall = (debug & 8) != 0;
-    if (ctx->plan_valid && ctx->plan_forced != force_tall) ctx->plan_valid = false;
     if (!generic && !ctx->plan_valid && ctx->V > 0) {
+        ProfileScope ps(ctx, MVS_K_PLAN);
+        if ((rc = sweep_xrect_plan(ctx))) return rc;
+        ctx->exact_tiled_planned = false;
+        ctx->plan_shape = 1;
+        ctx->plan_valid = true;
+    }
+    const bool xrect = ctx->xrect_ok && ctx->plan_valid && !generic && ctx->V > 0 && view_count > 0 && !force_tall && !(flags & MVS_SWEEP_NO_RECT);
+    if (xrect) {
+        SweepParams p;
+        fill_params(ctx, p, view_first, view_count, 8, 16);
+        p.debug = debug;
+        p.chunk0 = plane_first / 16;
+        p.chunk1 = div_up(plane_first + plane_count, 16);
+        p.ty0 = row_first / 8;
+        p.tyn = div_up(row_first + row_count, 8) - p.ty0;
+        p.row_begin = row_first;
+        p.row_end = min(ctx->H, row_first + row_count);
+        ProfileScope ps(ctx, MVS_K_SWEEP);
+        const int nsplit = sweep_xrect_launch(ctx, p, vol, fused, flags);
+        if (nsplit < 0) return nsplit;
+        if (p.part) {
+            const size_t first = (size_t)p.row_begin * ctx->W;
+            const size_t count = (size_t)(p.row_end - p.row_begin) * ctx->W;
+            combine_best<CS_EXACT><<<(unsigned)((count + 255) / 256), 256, 0, ctx->stream>>>(p, nsplit, first, count);
+            MVS_HIP(ctx, hipGetLastError());
+        }
+        ctx->exact_last_shape = 5;
+        return MVS_OK;
+    }
+    if (ctx->exact_tiled_planned && ctx->plan_forced != force_tall) ctx->exact_tiled_planned = false;
+    if (!generic && !ctx->exact_tiled_planned && ctx->V > 0) {
         if ((rc = ensure(ctx, ctx->plan_stats, 64))) return rc;
         int *stats = (int *)ctx->plan_stats.ptr;
         ProfileScope ps(ctx, MVS_K_PLAN);
@@ -914,9 +953,10 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
             MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if ((long long)h[0] * 50 <= (long long)h[1]) break;  // at most 2 % oversize: keep 2 x 32
         }
-        ctx->plan_valid = true;
+        ctx->exact_tiled_planned = true;
         ctx->plan_forced = force_tall;
     }
+    ctx->exact_last_shape = ctx->plan_shape;
     const int shape = (generic || ctx->V == 0) ? 2 : ctx->plan_shape;
     const int tile_h = shape == 1 ? 8 : 16, pc = shape == 1 ? 32 : 16;
 

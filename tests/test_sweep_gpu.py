@@ -217,8 +217,8 @@ def test_c3_full_size_properties(sampler):
         #     fixed sampler: the general-camera code path (per-sample reciprocal) on this plane-independent-w geometry
         #     (the ring is rectified: the fixed sampler's runs above took sweep_fx_rect, plan shape 4; here the general tiled kernel,
         #     with and without its plane-independent-w shortcut)
-        assert ctx.plan_shape() == (1 if sampler == "exact" else 4)
-        for extra in ((8 << 8,) if sampler == "exact" else (mvs_amd.MVS_SWEEP_NO_RECT, mvs_amd.MVS_SWEEP_NO_RECT | (4 << 8))):
+        assert ctx.plan_shape() == (5 if sampler == "exact" else 4)   # the ring is rectified: sweep_exact_rect / sweep_fx_rect served the runs above
+        for extra in ((8 << 8, mvs_amd.MVS_SWEEP_NO_RECT) if sampler == "exact" else (mvs_amd.MVS_SWEEP_NO_RECT, mvs_amd.MVS_SWEEP_NO_RECT | (4 << 8))):
             ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN | extra)
             d_s, c_s, i_s, _ = ctx.sweep_fetch()
             np.testing.assert_array_equal(i_t, i_s)
