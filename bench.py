@@ -30,6 +30,7 @@ import zlib
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))
 
+KERNEL_OF_SHAPE = {1: "sweep_tiled", 2: "sweep_tiled", 3: "sweep_fx_tiled", 4: "sweep_fx_rect", 5: "sweep_exact_rect"}   # mvs_sweep_plan_shape
 CONFIGS = {
     # name: (W, H, D, V)   -- BASELINE.json configs[]
     "c1": (640, 480, 32, 4),
@@ -207,7 +208,7 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
                        "entry": "mvs_sweep_batch_async" if batched else "mvs_sweep", "main_frames_per_launch": batch if batched else 1,
                        "one_call_mvs_sweep_ms_per_main_frame": onecall_ms,
                        "sampler": args.sampler, "shard": None if world == 1 else "frames", "frames_per_rank": len(mine), "plan_shape": shape, "device": ctx.info()},
-            "roofline": {"bound": "hbm", "kernel": "sweep_fx_tiled_batch" if batched else {1: "sweep_tiled", 2: "sweep_tiled", 3: "sweep_fx_tiled", 4: "sweep_fx_rect"}.get(shape), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "sweep_fx_tiled_batch" if batched else KERNEL_OF_SHAPE.get(shape), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": sweep_bytes, "ms_per_launch": sweep_ms,
                          "bytes_formula": "P (V + 1) + 8 P: no volume is materialised on this path (SURVEY.md 8d, fused lower bound)"},
             "depth_in_frame_fraction": float((depth != 1.0).mean())}), flush=True)
@@ -330,7 +331,7 @@ def main():
     ctx.sweep_run(0, V, both)
     depth1 = ctx.sweep_fetch()[0]
     # the kernel that serves this plan: the SURVEY 8d ring is rectified (plan shape 4: sweep_fx_rect), anything else the general tiled kernel
-    sweep_kernel = {1: "sweep_tiled", 2: "sweep_tiled", 3: "sweep_fx_tiled", 4: "sweep_fx_rect"}.get(ctx.plan_shape(), "sweep_fx_tiled")
+    sweep_kernel = KERNEL_OF_SHAPE.get(ctx.plan_shape(), "sweep_fx_tiled")
     crc1 = zlib.crc32(np.ascontiguousarray(depth1).tobytes())
     depth_t = torch.as_tensor(ctx.depth_device_array(), device="cuda")
 
@@ -483,7 +484,7 @@ def main():
             gctx.sweep_set(main_cam, main_img, gcams, sides, D)
             time_resident(gctx, both, 20)
             general_ms = time_resident(gctx, both, args.steps)
-            general_kernel = {1: "sweep_tiled", 2: "sweep_tiled", 3: "sweep_fx_tiled", 4: "sweep_fx_rect"}.get(gctx.plan_shape())
+            general_kernel = KERNEL_OF_SHAPE.get(gctx.plan_shape())
             gctx.set_sampler(other)
             other_general_ms = time_resident(gctx, both, args.steps)
         with mvs_amd.Context(W, H, local_rank, sampler=other) as octx2:
@@ -492,9 +493,10 @@ def main():
             time_resident(octx2, both, 20)
             other_ms = time_resident(octx2, both, args.steps)
             octx2.sweep_run(0, V, both)
+            other_kernel = KERNEL_OF_SHAPE.get(octx2.plan_shape())
             d_o, c_o, i_o, _ = octx2.sweep_fetch()
         d_p, c_p, i_p, _ = ctx.sweep_fetch()
-        other_block = {"sampler": other, "ms_per_step": other_ms, "samples_per_s": float(P) * D * V / (other_ms * 1e-3),
+        other_block = {"sampler": other, "kernel": other_kernel, "ms_per_step": other_ms, "samples_per_s": float(P) * D * V / (other_ms * 1e-3),
                        "roofline_frac": float(P) * (V + 8.0 * D + 9.0) / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "general_cameras_ms_per_step": other_general_ms}
         exact = other_block if other == "exact" else {"sampler": "exact", "ms_per_step": primary["ms_per_step"], "note": "this run's primary sampler"}
@@ -561,7 +563,7 @@ def main():
             raise SystemExit("cold step: depth crc %08x differs from the resident sweep's %08x" % (cold_crc, crc1))
         cold_bytes = float(P) * (V + 8.0 * D + 9.0)
         cold = {"ms": cold_ms, "samples_per_s": float(P) * D * V / (cold_ms * 1e-3), "frac": cold_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "kernel": {1: "sweep_tiled", 2: "sweep_tiled", 3: "sweep_fx_tiled", 4: "sweep_fx_rect"}.get(cold_shape),
+                "kernel": KERNEL_OF_SHAPE.get(cold_shape),
                 "includes": "mvs_sweep_set_main_device + mvs_sweep_set_views_device (view matrices, quad images of all views from the raw u8 frames in one "
                             "pass) + region plan (with its one host read-back) + sweep with depth selection + combine_best; raw frames resident in HBM, no PCIe",
                 "depth_crc32": cold_crc}

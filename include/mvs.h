@@ -169,7 +169,7 @@ int mvs_sweep_set_views_device(mvs_ctx *ctx, int nviews, const float *side_cams,
 #define MVS_SWEEP_VOLUME 1u       /* materialise the packed cost volume in HBM */
 #define MVS_SWEEP_FUSED_ARGMIN 2u /* select depth inside the sweep kernel (no volume read-back pass) */
 #define MVS_SWEEP_FORCE_GENERIC 4u /* use the un-tiled global-gather kernel (test / fallback path) */
-#define MVS_SWEEP_NO_RECT 8u       /* fixed sampler: never take the rectified-view kernel (sweep_fx_rect); results are bit-identical either way */
+#define MVS_SWEEP_NO_RECT 8u       /* never take the rectified-view kernels (sweep_fx_rect / sweep_exact_rect); results are bit-identical either way */
 /* accumulate views [view_first, view_first + view_count) into the packed volume / fused outputs (async) */
 int mvs_sweep_run(mvs_ctx *ctx, int view_first, int view_count, unsigned flags);
 /* the same for planes [plane_first, plane_first + plane_count) only (MVS_SWEEP_VOLUME; boundaries on multiples of
@@ -189,7 +189,9 @@ int mvs_sweep_row_granularity_of(const mvs_ctx *ctx);   /* what the context's cu
  * bit-identical to 1; the choice follows how many warped 32-plane footprints fit the LDS staging buffer), 3 = fixed sampler
  * (2 pixels x 16 planes, 64x8-pixel tiles), 4 = fixed sampler, every side view rectified against the main view (pure translation
  * in its focal plane, equal intrinsics): the kernel sweep_fx_rect (8 pixels x 4 planes per thread, wave-uniform sampling
- * positions; bit-identical to 3, which MVS_SWEEP_NO_RECT selects). */
+ * positions; bit-identical to 3, which MVS_SWEEP_NO_RECT selects), 5 = exact sampler on rectified views: the kernel sweep_exact_rect
+ * (same thread shape; projection, reciprocal, trunc / fract and frame tests once per (column, plane, view) and per (row, plane, view);
+ * bit-identical to 1 / 2).  For the exact sampler the value names what served the LAST run. */
 int mvs_sweep_plan_shape(const mvs_ctx *ctx);
 /* per-pixel depth selection over the packed volume (async); valid after MVS_SWEEP_VOLUME runs or
  * after the caller has reduced the volume across ranks in place */

@@ -34,6 +34,7 @@ namespace {
 
 constexpr int XR_TILE_H = 8, XR_PC = 16, XR_KW = 4;  // tile rows, planes per chunk, planes per wavefront
 constexpr int XR_MAX_NI = 6;                          // 1 KiB copy instructions per wavefront and region, at most (24 KiB per slot: c3's boxes are ~84 quads x 24 rows of 8 bytes)
+constexpr int XR_MAX_REGIONS = 256;                    // (chunks x views) of one workgroup: 16 KiB of records at the most
 constexpr int XR_WAVES = 4;                           // launch bound: <= 128 VGPRs (two 18 KiB slots at c3 leave room for four workgroups per CU anyway)
 
 typedef const __attribute__((address_space(4))) uint32_t *cu32;
@@ -43,8 +44,8 @@ __device__ __forceinline__ T as_const(const U *p) { return (T)(uintptr_t)p; }
 
 struct XrArgs {
     const uint2 *__restrict__ quads16;   // f16 quad images of the side views, pad_slab quads each
-    const uint32_t *__restrict__ xbox;   // [tiles_x][V][NC]  x0 | quads << 16 (0 quads: nothing of the tile column in frame)
-    const uint32_t *__restrict__ ybox;   // [tiles_y][V][NC]  y0 | rows << 16
+    const uint32_t *__restrict__ xrec;   // [tiles_x][V][NC][8]  X records (plan_xrect)
+    const uint32_t *__restrict__ yrec;   // [tiles_y][V][NC][8]  Y records
     const float *__restrict__ Q;         // V x 12
     const float *__restrict__ z;         // D
     const uint8_t *__restrict__ main_img;
@@ -79,12 +80,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint3
 }
 
 // ------------------------------------------------------------------------------------------------------
-// planner: the box of a view's quad image a (tile column | tile row, 16-plane chunk) touches
+// planner: one 8-dword record per (tile column, view, chunk) and per (tile row, view, chunk)
 // ------------------------------------------------------------------------------------------------------
-// One thread per (axis tile, view, chunk).  cx over the tile's columns and the chunk's planes is monotone in both, so its extremes are
-// at the four corners; samples out of frame (cx <= 0.5 or >= W + 0.5) are masked in the kernel and need no texel, hence the clamp.
-// stats: [0] widest box (quads), [1] tallest box (rows).
-__global__ __launch_bounds__(256) void plan_xrect(XrArgs a, int tiles_y, uint32_t *__restrict__ xbox, uint32_t *__restrict__ ybox, int *__restrict__ stats)
+// X record: q0, q2, q3, r = RN(1 / q11) | box (x0 | quads << 16; 0 quads: nothing of the tile column in frame) | flags | 8 x0 | 0
+// Y record: q5, q6, q7, 8 (pad_slab v + y0 pitch) | box (y0 | rows << 16) | flags | 0 | 0
+// flags: bit d = every valid pixel of the tile column (row) is in frame at plane d of the chunk; bit 16 + d = some pixel is.
+// cx over the tile's columns and the chunk's planes is monotone in both (compositions of roundings of monotone functions): the box is
+// bounded by the four corner evaluations, and a plane is in frame for every column iff it is for the two end columns.  Samples out of
+// frame (cx <= 0.5 or >= W + 0.5) are masked in the kernel and need no texel, hence the clamp.  stats: [0] widest box, [1] tallest.
+__global__ __launch_bounds__(256) void plan_xrect(XrArgs a, int tiles_y, uint32_t *__restrict__ xrec, uint32_t *__restrict__ yrec, int *__restrict__ stats)
 {
     const int NC = a.nchunks;
     const int nx = a.tiles_x * a.V * NC, ny = tiles_y * a.V * NC;
@@ -95,39 +99,67 @@ __global__ __launch_bounds__(256) void plan_xrect(XrArgs a, int tiles_y, uint32_
     const int chunk = e % NC, v = (e / NC) % a.V, t = e / (NC * a.V);
     const float *q = a.Q + 12 * v;
     const float r = rcp_rn(q[11]);
-    const int d0 = chunk * XR_PC, d1 = min(d0 + XR_PC, a.D) - 1;
+    const int d0 = chunk * XR_PC;
     const int size = is_y ? a.H : a.W;
     const int p0 = t * (is_y ? XR_TILE_H : TILE_W), p1 = min(p0 + (is_y ? XR_TILE_H : TILE_W), size) - 1;
-    float lo = 3.0e38f, hi = -3.0e38f;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int pix = (k & 1) ? p1 : p0;
-        const float z = a.z[(k & 2) ? d1 : d0];
-        float c;
-        if (is_y) {
-            const float yn = __builtin_fmaf(-(float)(2 * pix + 1), a.invH, 1.0f);
-            c = __builtin_fmaf(z, q[6], __builtin_fmaf(q[5], yn, q[7])) * r;
-        } else {
-            const float xn = __builtin_fmaf((float)(2 * pix + 1), a.invW, -1.0f);
-            c = __builtin_fmaf(z, q[2], __builtin_fmaf(q[0], xn, q[3])) * r;
-        }
-        lo = fminf(lo, c);
-        hi = fmaxf(hi, c);
-    }
     const float lim = (float)size + 0.5f;
+    float lo = 3.0e38f, hi = -3.0e38f;
+    uint32_t flags = 0u;
+    for (int k = 0; k < XR_PC; k++) {
+        const float z = a.z[min(d0 + k, a.D - 1)];
+        float c[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int pix = s ? p1 : p0;
+            if (is_y) {
+                const float yn = __builtin_fmaf(-(float)(2 * pix + 1), a.invH, 1.0f);
+                c[s] = __builtin_fmaf(z, q[6], __builtin_fmaf(q[5], yn, q[7])) * r;
+            } else {
+                const float xn = __builtin_fmaf((float)(2 * pix + 1), a.invW, -1.0f);
+                c[s] = __builtin_fmaf(z, q[2], __builtin_fmaf(q[0], xn, q[3])) * r;
+            }
+        }
+        const float cl = fminf(c[0], c[1]), ch = fmaxf(c[0], c[1]);
+        if (cl > 0.5f && ch < lim) flags |= 1u << k;
+        if (ch > 0.5f && cl < lim) flags |= 1u << (16 + k);
+        if (d0 + k < a.D) {
+            lo = fminf(lo, cl);
+            hi = fmaxf(hi, ch);
+        }
+    }
     uint32_t box = 0u;
-    int extent = 0;
+    int extent = 0, i0 = 0;
     if (hi > 0.5f && lo < lim && lo == lo && hi == hi) {  // something can be in frame: the texels of the in-frame samples, i = trunc(c) in [0, size]
-        int i0 = (int)fmaxf(lo, 0.0f), i1 = (int)fminf(hi, lim);
+        i0 = (int)fmaxf(lo, 0.0f);
+        int i1 = (int)fminf(hi, lim);
         i0 = max(0, min(i0, size));
         i1 = max(i0, min(i1, size));
         if (!is_y) i0 &= ~1;  // 16-byte copy units = two quads
         extent = i1 - i0 + 1;
         if (!is_y) extent = (extent + 1) & ~1;
         box = (uint32_t)i0 | ((uint32_t)extent << 16);
+    } else {
+        flags = 0u;
     }
-    if (live) (is_y ? ybox : xbox)[e] = box;
-    // one atomic per wavefront and counter (the kernel that reads them back is waited for by the host)
+    if (live) {
+        uint32_t *rec = (is_y ? yrec : xrec) + (size_t)e * 8;
+        if (is_y) {
+            rec[0] = __builtin_bit_cast(uint32_t, q[5]);
+            rec[1] = __builtin_bit_cast(uint32_t, q[6]);
+            rec[2] = __builtin_bit_cast(uint32_t, q[7]);
+            rec[3] = 8u * ((uint32_t)a.pad_slab * (uint32_t)v + (uint32_t)i0 * (uint32_t)a.pitch);
+        } else {
+            rec[0] = __builtin_bit_cast(uint32_t, q[0]);
+            rec[1] = __builtin_bit_cast(uint32_t, q[2]);
+            rec[2] = __builtin_bit_cast(uint32_t, q[3]);
+            rec[3] = __builtin_bit_cast(uint32_t, r);
+        }
+        rec[4] = box;
+        rec[5] = flags;
+        rec[6] = is_y ? 0u : 8u * (uint32_t)i0;
+        rec[7] = 0u;
+    }
+    // one atomic per wavefront and counter (the host waits for the kernel before it reads them)
     int wx = (live && !is_y) ? extent : 0, wy = (live && is_y) ? extent : 0;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -143,6 +175,17 @@ __global__ __launch_bounds__(256) void plan_xrect(XrArgs a, int tiles_y, uint32_
 // ------------------------------------------------------------------------------------------------------
 // sweep kernel
 // ------------------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// The 64-byte record of a region out of LDS.  Inline asm: the compiler orders a ds_read it can see behind ALL pending LDS copies; issue
+// and wait sit in ONE statement -- between two statements the compiler is free to move a loaded register before its data has arrived.
+__device__ __forceinline__ void lds_read_record(uint32_t addr, u32x4 &x0, u32x4 &x1, u32x4 &y0, u32x4 &y1)
+{
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x0), "=&v"(x1), "=&v"(y0), "=&v"(y1)
+                 : "v"(addr));
+}
+
 template <bool WRITE_VOLUME, bool FUSED>
 __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
 {
@@ -162,12 +205,30 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
     const float xn = __builtin_fmaf((float)(2 * col + 1), a.invW, -1.0f);
     const int rowl = row0 + (lane & 7);  // lane l also works for row l & 7 of the tile (per-row values are computed once, on 8 lanes' worth of work)
     const float ynl = __builtin_fmaf(-(float)(2 * rowl + 1), a.invH, 1.0f);
-    const unsigned long long cols_mask = __builtin_amdgcn_ballot_w64(col_ok);
-    const uint32_t rows_mask = (1u << nrows) - 1u;
 
     uint32_t Im[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) Im[j] = (col_ok && row0 + j < a.H) ? (uint32_t)a.main_img[(size_t)(row0 + j) * a.W + col] : 0u;
+
+    const int chunk_first = a.chunk0 + (int)blockIdx.y * a.cps;
+    const int chunk_last = min(a.chunk1, chunk_first + a.cps);
+    const int vend = a.v0 + a.vcount;
+    const int nreg = (chunk_last - chunk_first) * a.vcount;
+
+    // The records of ALL this workgroup's regions go into LDS once (16 dwords per region: X record, Y record): read from there a
+    // region's constants cost an LDS round trip instead of dependent scalar loads from memory on the critical path of every region
+    // (the first form of this kernel spent 0.74 of its 1.66 ms at c3 on that skeleton).
+    const uint32_t ctab_byte = 2u * (uint32_t)a.slot_bytes;
+    {
+        uint32_t *ctab = smem + (ctab_byte >> 2);
+        const uint32_t *xrec = a.xrec + (size_t)tx * a.V * NC * 8, *yrec = a.yrec + (size_t)ty * a.V * NC * 8;
+        for (int i = threadIdx.x; i < nreg * 16; i += 256) {
+            const int e = i >> 4, w = i & 15;
+            const int chunk = chunk_first + e / a.vcount, v = a.v0 + e % a.vcount;
+            ctab[i] = w < 8 ? xrec[(size_t)(v * NC + chunk) * 8 + w] : yrec[(size_t)(v * NC + chunk) * 8 + (w - 8)];
+        }
+    }
+    __syncthreads();
 
     // per-lane source offsets (bytes) of this wavefront's copy instructions: instruction i = wave + 4 t fills LDS bytes [1024 i, 1024 i + 1024)
     // of the slot = 16-byte units g = 64 i + lane of the dense [row][rs] region image
@@ -179,13 +240,14 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
         srcoff[t] = 8u * (uint32_t)((g / units) * a.pitch + (g % units) * 2);
     }
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(a.quads16, 0xffffffffu);
-    const cu32 xbox = as_const<cu32>(a.xbox + (size_t)tx * a.V * NC), ybox = as_const<cu32>(a.ybox + (size_t)ty * a.V * NC);
+    const uint32_t rs8 = 8u * (uint32_t)a.rs;
 
-    auto issue_copy = [&](int v, int chunk, uint32_t slot_byte) {
-        const uint32_t xb = xbox[v * NC + chunk], yb = ybox[v * NC + chunk];
+    // copy of the region whose X / Y records are (xr, yr) into the slot at `slot_byte`
+    auto issue_copy = [&](const u32x4 &xr1, const u32x4 &yr0, const u32x4 &yr1, uint32_t slot_byte) {
+        const uint32_t xb = (uint32_t)__builtin_amdgcn_readfirstlane((int)xr1.x), yb = (uint32_t)__builtin_amdgcn_readfirstlane((int)yr1.x);
         if ((xb >> 16) == 0u || (yb >> 16) == 0u || XR_DBG(a, 1)) return;
         const int n = (int)(yb >> 16) * units;  // whole rows of rs quads (what lies right of the box is copied along and never read)
-        const uint32_t src = XR_DBG(a, 8) ? 0u : 8u * ((uint32_t)a.pad_slab * (uint32_t)v + (yb & 0xffffu) * (uint32_t)a.pitch + (xb & 0xffffu));
+        const uint32_t src = XR_DBG(a, 8) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)xr1.z) + (uint32_t)__builtin_amdgcn_readfirstlane((int)yr0.w);
         char *dst = (char *)smem + slot_byte + wave * 1024;
 #pragma unroll
         for (int t = 0; t < XR_MAX_NI; t++) {
@@ -198,14 +260,6 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
         }
     };
 
-    const int chunk_first = a.chunk0 + (int)blockIdx.y * a.cps;
-    const int chunk_last = min(a.chunk1, chunk_first + a.cps);
-    const int vend = a.v0 + a.vcount;
-    const int nreg = (chunk_last - chunk_first) * a.vcount;
-    const cf32 zs = as_const<cf32>(a.z);
-    const cf32 Qs = as_const<cf32>(a.Q);
-    const uint32_t rs8 = 8u * (uint32_t)a.rs;
-
     uint32_t acc[8][XR_KW];
     uint32_t best[8];
     int bi[8];
@@ -217,75 +271,106 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
         for (int k = 0; k < XR_KW; k++) acc[j][k] = 0u;
     }
     int notfull[XR_KW] = {0, 0, 0, 0};  // per plane of this wavefront: views of the current chunk whose count did NOT go to every cell of the plane (wave-uniform)
+    float zc[XR_KW] = {0.0f, 0.0f, 0.0f, 0.0f};
 
     uint32_t slot_cur = 0u, slot_nxt = (uint32_t)a.slot_bytes;
     int chunk = chunk_first, v = a.v0;
-    if (nreg > 0) issue_copy(v, chunk, slot_cur);
+    const uint32_t ctab_addr = lds_base + ctab_byte;
+    // records of region 0 (its copy goes out before the loop) -- 64 bytes per region
+    u32x4 x0r, x1r, y0r, y1r;
+    lds_read_record(ctab_addr, x0r, x1r, y0r, y1r);
+    if (nreg > 0) issue_copy(x1r, y0r, y1r, slot_cur);
 
     for (int r = 0; r < nreg; r++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's copies of region r have landed ...
         __builtin_amdgcn_s_barrier();                      // ... and everybody else's; nobody reads region r - 1 any more
-        int vn = v + 1, cn = chunk;
-        if (vn == vend) {
-            vn = a.v0;
-            cn++;
+        // the records of region r + 1 (past the last region: of the last one again), its copy into the other slot: in flight during this region's sampling
+        const uint32_t nxt = ctab_addr + 64u * (uint32_t)min(r + 1, nreg - 1);
+        u32x4 nx0, nx1, ny0, ny1;
+        lds_read_record(nxt, nx0, nx1, ny0, ny1);
+        if (r + 1 < nreg) issue_copy(nx1, ny0, ny1, slot_nxt);
+
+        if (v == a.v0) {  // first view of a chunk: this wavefront's four planes
+            const cf32 zs = as_const<cf32>(a.z);
+#pragma unroll
+            for (int k = 0; k < XR_KW; k++) zc[k] = zs[min(chunk * XR_PC + wave * XR_KW + k, a.D - 1)];
         }
-        if (r + 1 < nreg) issue_copy(vn, cn, slot_nxt);  // in flight during this region's sampling
 
         // ---- sample region r ----
-        const uint32_t xb = xbox[v * NC + chunk], yb = ybox[v * NC + chunk];
-        const cf32 q = Qs + 12 * v;
-        const float q0 = q[0], q2 = q[2], q3 = q[3], q5 = q[5], q6 = q[6], q7 = q[7];
-        const float rr = rcp_rn(q[11]);
+        // (through integer temporaries: __builtin_bit_cast applied directly to an ext-vector element reads element 0 with this hipcc)
+        const uint32_t u0 = x0r.x, u1 = x0r.y, u2 = x0r.z, u3 = x0r.w, u5 = y0r.x, u6 = y0r.y, u7 = y0r.z;
+        const float q0 = __builtin_bit_cast(float, u0), q2 = __builtin_bit_cast(float, u1), q3 = __builtin_bit_cast(float, u2), rr = __builtin_bit_cast(float, u3);
+        const float q5 = __builtin_bit_cast(float, u5), q6 = __builtin_bit_cast(float, u6), q7 = __builtin_bit_cast(float, u7);
+        const uint32_t xb = (uint32_t)__builtin_amdgcn_readfirstlane((int)x1r.x), yb = (uint32_t)__builtin_amdgcn_readfirstlane((int)y1r.x);
+        const uint32_t xfl = (uint32_t)__builtin_amdgcn_readfirstlane((int)x1r.y), yfl = (uint32_t)__builtin_amdgcn_readfirstlane((int)y1r.y);
         const float Ax = __builtin_fmaf(q0, xn, q3), Ayl = __builtin_fmaf(q5, ynl, q7);
-        const bool staged = (xb >> 16) != 0u && (yb >> 16) != 0u;
         const int x0 = (int)(xb & 0xffffu), y0 = (int)(yb & 0xffffu);
         const uint32_t slot_addr = lds_base + slot_cur;
+        const uint32_t both_fl = (xfl & yfl) >> (4 * wave);  // bit k: plane k of this wavefront is in frame for every pixel of the tile; bit 16 + k: for some pixel
 #pragma unroll
         for (int k = 0; k < XR_KW; k++) {
-            const float z = zs[min(chunk * XR_PC + wave * XR_KW + k, a.D - 1)];
-            const float cx = __builtin_fmaf(z, q2, Ax) * rr;
-            const float cyl = __builtin_fmaf(z, q6, Ayl) * rr;
-            const bool inx = col_ok && cx > 0.5f && cx < a.Wp;
-            const bool inyl = rowl < a.H && cyl > 0.5f && cyl < a.Hp;
-            const unsigned long long xm = __builtin_amdgcn_ballot_w64(inx);
-            const uint32_t ym = (uint32_t)__builtin_amdgcn_ballot_w64(inyl) & 0xffu;
-            const bool full = xm == cols_mask && ym == rows_mask;
-            if (!full) notfull[k]++;
-            if (!staged || xm == 0ull || ym == 0u || XR_DBG(a, 2)) continue;
+            if (!((both_fl >> (16 + k)) & 1u) || XR_DBG(a, 2)) {  // nothing of the tile in frame at this plane
+                notfull[k]++;
+                continue;
+            }
+            const float cx = __builtin_fmaf(zc[k], q2, Ax) * rr;
+            const float cyl = __builtin_fmaf(zc[k], q6, Ayl) * rr;
             const float fx = __builtin_amdgcn_fractf(cx);
             const uint32_t addrx = slot_addr + (uint32_t)(((int)cx - x0) << 3);
             const float fyl = __builtin_amdgcn_fractf(cyl);
-            const uint32_t rowoffl = (uint32_t)((int)cyl - y0) * rs8;
-            auto rows = [&](auto counted) {
-                // the 8 reads first, one wait, then the arithmetic (inline asm: the compiler would order a ds_read behind ALL pending LDS copies)
+            const int iyl = (int)cyl;
+            const int iy0 = __builtin_amdgcn_readlane(iyl, 0);
+            // rows of the tile usually sample consecutive texel rows (cy advances by one per row up to its rounding): then a row's address is the previous one + a stride
+            const bool consecutive = ((uint32_t)__builtin_amdgcn_ballot_w64(iyl - (lane & 7) == iy0) & 0xffu) == 0xffu;
+            if (((both_fl >> k) & 1u) && consecutive) {
+                // the 8 reads first, one wait, then the arithmetic
                 unsigned long long h[8];
-                float fy[8];
+                uint32_t ad = addrx + (uint32_t)(iy0 - y0) * rs8;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    fy[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyl), j));
-                    const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)rowoffl, j);
-                    const uint32_t ad = ((ym >> j) & 1u) ? addrx + ro : addrx;  // (a row out of frame reads its lane's own column of the box's first row: harmless, dropped below)
                     asm volatile("ds_read_b64 %0, %1" : "=v"(h[j]) : "v"(ad));
+                    ad += rs8;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]));
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const half4_t q4 = __builtin_bit_cast(half4_t, h[j]);
+                    const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyl), j));
                     const float ta = __builtin_fmaf(fx, (float)q4[1], (float)q4[0]);
                     const float tb = __builtin_fmaf(fx, (float)q4[3], (float)q4[2]);
-                    const int Iq = (int)__builtin_fmaf(fy[j], tb, ta);
-                    if (counted.value) {
-                        if ((ym >> j) & 1u) acc[j][k] = sad_u32((uint32_t)Iq, Im[j], acc[j][k] + 65536u);  // wave-uniform test; the lanes out of frame are masked by the caller
-                    } else {
-                        acc[j][k] = sad_u32((uint32_t)Iq, Im[j], acc[j][k]);
+                    acc[j][k] = sad_u32((uint32_t)(int)__builtin_fmaf(fy, tb, ta), Im[j], acc[j][k]);
+                }
+            } else {
+                // a tile at the border of the side view, or rows that do not advance in step: the frame tests per lane and per row, each
+                // sampled cell counting its sample itself
+                notfull[k]++;
+                const bool inx = col_ok && cx > 0.5f && cx < a.Wp;
+                const uint32_t ym = (uint32_t)__builtin_amdgcn_ballot_w64(rowl < a.H && cyl > 0.5f && cyl < a.Hp) & 0xffu;
+                // the rows' values out of lanes 0..7 BEFORE the lanes out of frame are masked off (a v_readlane inside the divergent
+                // region would read what the compiler computed there -- for the active lanes only)
+                const uint32_t rowoffl = (uint32_t)(iyl - y0) * rs8;
+                uint32_t ro[8];
+                float fyr[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    ro[j] = (uint32_t)__builtin_amdgcn_readlane((int)rowoffl, j);
+                    fyr[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyl), j));
+                }
+                if (inx) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        if ((ym >> j) & 1u) {  // wave-uniform
+                            const uint32_t ad = addrx + ro[j];
+                            unsigned long long hq;
+                            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(hq) : "v"(ad));
+                            const half4_t q4 = __builtin_bit_cast(half4_t, hq);
+                            const float fy = fyr[j];
+                            const float ta = __builtin_fmaf(fx, (float)q4[1], (float)q4[0]);
+                            const float tb = __builtin_fmaf(fx, (float)q4[3], (float)q4[2]);
+                            acc[j][k] = sad_u32((uint32_t)(int)__builtin_fmaf(fy, tb, ta), Im[j], acc[j][k] + 65536u);
+                        }
                     }
                 }
-            };
-            if (full) {
-                rows(std::false_type{});
-            } else if (inx) {
-                rows(std::true_type{});
             }
         }
 
@@ -324,8 +409,14 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
             for (int k = 0; k < XR_KW; k++) notfull[k] = 0;
         }
 
-        v = vn;
-        chunk = cn;
+        if (++v == vend) {
+            v = a.v0;
+            chunk++;
+        }
+        x0r = nx0;
+        x1r = nx1;
+        y0r = ny0;
+        y1r = ny1;
         const uint32_t sw = slot_cur;
         slot_cur = slot_nxt;
         slot_nxt = sw;
@@ -404,8 +495,8 @@ void fill_args(mvs_ctx *ctx, const SweepParams &p, XrArgs &a)
     a.rs = ctx->xrect_rs;
     a.slot_bytes = ctx->xrect_slot_bytes;
     const size_t nxb = (size_t)a.tiles_x * a.V * a.nchunks;
-    a.xbox = (const uint32_t *)ctx->xrect_tab.ptr + 16;
-    a.ybox = a.xbox + nxb;
+    a.xrec = (const uint32_t *)ctx->xrect_tab.ptr + 16;
+    a.yrec = a.xrec + 8 * nxb;
 }
 
 }  // namespace
@@ -417,7 +508,7 @@ bool rect_view_host(const float *q);  // sweep_rect.hip
 int sweep_xrect_plan(mvs_ctx *ctx)
 {
     ctx->xrect_ok = false;
-    if (getenv("MVS_NO_RECT") || ctx->V == 0) return MVS_OK;
+    if (getenv("MVS_NO_RECT") || ctx->V == 0 || ctx->V > XR_MAX_REGIONS) return MVS_OK;
     for (int v = 0; v < ctx->V; v++)
         if (!rect_view_host(ctx->q_host.data() + 12 * v)) return MVS_OK;
     if ((unsigned long long)ctx->pad_slab * (unsigned long long)ctx->V * 8ull >= (1ull << 32)) return MVS_OK;  // one buffer resource, 32-bit byte offsets
@@ -430,17 +521,26 @@ int sweep_xrect_plan(mvs_ctx *ctx)
     const int tiles_y = div_up(ctx->H, XR_TILE_H);
     const size_t nxb = (size_t)a.tiles_x * a.V * a.nchunks, nyb = (size_t)tiles_y * a.V * a.nchunks;
     int rc;
-    if ((rc = ensure(ctx, ctx->xrect_tab, (16 + nxb + nyb) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->xrect_tab, (16 + 8 * (nxb + nyb)) * sizeof(uint32_t)))) return rc;
     fill_args(ctx, p, a);  // (the table may have moved)
     int *stats = (int *)ctx->xrect_tab.ptr;
     MVS_HIP(ctx, hipMemsetAsync(stats, 0, 64, ctx->stream));
-    plan_xrect<<<(unsigned)((nxb + nyb + 255) / 256), 256, 0, ctx->stream>>>(a, tiles_y, (uint32_t *)a.xbox, (uint32_t *)a.ybox, stats);
+    plan_xrect<<<(unsigned)((nxb + nyb + 255) / 256), 256, 0, ctx->stream>>>(a, tiles_y, (uint32_t *)a.xrec, (uint32_t *)a.yrec, stats);
     MVS_HIP(ctx, hipGetLastError());
     int h[2] = {0, 0};
     MVS_HIP(ctx, hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int max_rw = h[0], max_rh = h[1];
-    if (getenv("MVS_RECT_VERBOSE")) fprintf(stderr, "sweep_xrect_plan: widest box %d quads, tallest %d rows\n", max_rw, max_rh);
+    if (getenv("MVS_RECT_VERBOSE")) {
+        fprintf(stderr, "sweep_xrect_plan: widest box %d quads, tallest %d rows\n", max_rw, max_rh);
+        uint32_t rec[32];
+        for (int which = 0; which < 2; which++) {
+            if (hipMemcpy(rec, which ? a.yrec : a.xrec, sizeof(rec), hipMemcpyDeviceToHost) != hipSuccess) break;
+            for (int e = 0; e < 4; e++)
+                fprintf(stderr, "  %c record %d: %g %g %g %08x | box %08x flags %08x src %u\n", which ? 'Y' : 'X', e, __builtin_bit_cast(float, rec[8 * e]), __builtin_bit_cast(float, rec[8 * e + 1]),
+                        __builtin_bit_cast(float, rec[8 * e + 2]), rec[8 * e + 3], rec[8 * e + 4], rec[8 * e + 5], rec[8 * e + 6]);
+        }
+    }
     if (max_rw <= 0 || max_rh <= 0) return MVS_OK;  // nothing in frame anywhere: the general kernel writes the empty cells
     const int rs = (max_rw + 1) & ~1;
     const int units = rs / 2;
@@ -457,13 +557,14 @@ int sweep_xrect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsig
 {
     XrArgs a;
     fill_args(ctx, p, a);
-    size_t lds = 2 * (size_t)a.slot_bytes;
-    if (fused) lds = lds < 16384 ? 16384 : lds;  // the cross-wavefront depth selection borrows 16 KiB
     const int groups = div_up(a.tiles_x, 2) * div_up(p.tyn, 4);
     const int nch = p.chunk1 - p.chunk0, tiles = a.tiles_x * p.tyn;
     int want = (int)((flags >> 16) & 0xffu);
     if (!want) want = div_up(16 * ctx->num_cus, tiles);
     p.cps = div_up(nch, max(1, min(want, nch)));
+    p.cps = max(1, min(p.cps, XR_MAX_REGIONS / max(1, p.vcount)));  // the records of a workgroup's regions live in LDS (64 bytes each)
+    size_t lds = 2 * (size_t)a.slot_bytes + 64 * (size_t)p.cps * (size_t)max(1, p.vcount);
+    if (fused) lds = lds < 16384 ? 16384 : lds;  // the cross-wavefront depth selection borrows 16 KiB
     a.cps = p.cps;
     const int nsplit = div_up(nch, p.cps);
     int rc;

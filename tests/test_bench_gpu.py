@@ -62,7 +62,7 @@ def test_bench_line_contract_and_two_rank_shardings():
         assert a["depth_crc32"] == single["depth_crc32"] and a["collective_bytes_per_rank_per_step"] > 0 and a["views_per_rank"] == 2
     for s in ("exact",):
         ex = _bench(["--sampler", s], 1)
-        assert ex["roofline"]["kernel"] == "sweep_tiled" and ex["depth_check"] is True
+        assert ex["roofline"]["kernel"] in ("sweep_tiled", "sweep_exact_rect") and ex["depth_check"] is True   # (the ring is rectified: sweep_exact_rect where its boxes fit the LDS slots)
     # the N = 1 line with its extras: the exact sampler, what the two samplers disagree on, general cameras, a >= 2 s sustained run
     ext = _bench(["--with-extras"], 1)
     assert ext["exact_sampler"]["sampler"] == "exact" and ext["exact_sampler"]["ms_per_step"] > 0
