@@ -14,7 +14,7 @@ import json
 import sys
 
 # kernels whose reads are 16 bytes per lane: argmin_volume streams uint4; sweep_fx_tiled fills LDS with global_load_lds_dwordx4
-WIDE_READERS = ("void mvs::argmin_volume<4", "void mvs::sweep_fx_tiled", "void mvs::sweep_tiled", "void mvs::sweep_fx_rect")
+WIDE_READERS = ("void mvs::argmin_volume<4", "void mvs::sweep_fx_tiled", "void mvs::sweep_tiled", "void mvs::sweep_fx_rect", "void mvs::sweep_exact_rect")
 
 
 def main():
@@ -23,7 +23,7 @@ def main():
     for d in sys.argv[4:]:
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                agg[r["Kernel_Name"].replace("(anonymous namespace)::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     kernels = {}
     for k, v in agg.items():
         short = k.replace("void mvs::", "").split("(")[0]
