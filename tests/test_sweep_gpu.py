@@ -208,6 +208,7 @@ def test_c3_full_size_properties(sampler):
         d_f, c_f, i_f, _ = ctx.sweep_fetch()
         np.testing.assert_array_equal(i_t, i_f)
         np.testing.assert_array_equal(d_t, d_f)
+        assert ctx.plan_shape() == (5 if sampler == "exact" else 4)   # the ring is rectified: sweep_exact_rect / sweep_fx_rect served the runs above
         # (2) tiled == generic kernel, index for index
         ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN | mvs_amd.MVS_SWEEP_FORCE_GENERIC)
         d_g, c_g, i_g, _ = ctx.sweep_fetch()
@@ -217,7 +218,6 @@ def test_c3_full_size_properties(sampler):
         #     fixed sampler: the general-camera code path (per-sample reciprocal) on this plane-independent-w geometry
         #     (the ring is rectified: the fixed sampler's runs above took sweep_fx_rect, plan shape 4; here the general tiled kernel,
         #     with and without its plane-independent-w shortcut)
-        assert ctx.plan_shape() == (5 if sampler == "exact" else 4)   # the ring is rectified: sweep_exact_rect / sweep_fx_rect served the runs above
         for extra in ((8 << 8, mvs_amd.MVS_SWEEP_NO_RECT) if sampler == "exact" else (mvs_amd.MVS_SWEEP_NO_RECT, mvs_amd.MVS_SWEEP_NO_RECT | (4 << 8))):
             ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN | extra)
             d_s, c_s, i_s, _ = ctx.sweep_fetch()
