@@ -59,7 +59,7 @@ struct XrArgs {
     int rs;          // quads per LDS row (even)
     int slot_bytes;  // bytes per LDS slot (a multiple of 4096)
     float invW, invH, Wp, Hp;
-    int debug;  // timing experiments (MVS_XR_EXPERIMENTS builds only): 1 no copies, 2 no sampling, 8 every copy from one box -- wrong results
+    int debug;  // timing experiments (MVS_XR_EXPERIMENTS builds only): 1 no copies, 2 no sampling, 8 every copy from one box, 16 the per-row values (texel row, fraction) for free -- wrong results
 };
 #ifdef MVS_XR_EXPERIMENTS
 #define XR_DBG(a, bit) (((a).debug & (bit)) != 0)
@@ -319,9 +319,9 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
             const uint32_t addrx = slot_addr + (uint32_t)(((int)cx - x0) << 3);
             const float fyl = __builtin_amdgcn_fractf(cyl);
             const int iyl = (int)cyl;
-            const int iy0 = __builtin_amdgcn_readlane(iyl, 0);
+            const int iy0 = XR_DBG(a, 16) ? y0 : __builtin_amdgcn_readlane(iyl, 0);
             // rows of the tile usually sample consecutive texel rows (cy advances by one per row up to its rounding): then a row's address is the previous one + a stride
-            const bool consecutive = ((uint32_t)__builtin_amdgcn_ballot_w64(iyl - (lane & 7) == iy0) & 0xffu) == 0xffu;
+            const bool consecutive = XR_DBG(a, 16) || ((uint32_t)__builtin_amdgcn_ballot_w64(iyl - (lane & 7) == iy0) & 0xffu) == 0xffu;
             if (((both_fl >> k) & 1u) && consecutive) {
                 // the 8 reads first, one wait, then the arithmetic
                 unsigned long long h[8];
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const half4_t q4 = __builtin_bit_cast(half4_t, h[j]);
-                    const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyl), j));
+                    const float fy = XR_DBG(a, 16) ? zc[(j + k) & 3] : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyl), j));  // (experiment 16: what the per-row values cost -- an SGPR that is there anyway)
                     const float ta = __builtin_fmaf(fx, (float)q4[1], (float)q4[0]);
                     const float tb = __builtin_fmaf(fx, (float)q4[3], (float)q4[2]);
                     acc[j][k] = sad_u32((uint32_t)(int)__builtin_fmaf(fy, tb, ta), Im[j], acc[j][k]);

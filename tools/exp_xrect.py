@@ -30,5 +30,5 @@ with mvs_amd.Context(W, H, sampler="exact") as ctx:
           (t(both), ctx.plan_shape(), t(mvs_amd.MVS_SWEEP_FUSED_ARGMIN), t(mvs_amd.MVS_SWEEP_VOLUME), t(both | mvs_amd.MVS_SWEEP_NO_RECT)))
     print("   splits:", " ".join("%d: %.3f" % (s, t(both | (s << 16))) for s in (1, 2, 4, 8)))
     if "--exp" in sys.argv:
-        for label, bits in (("full", 0), ("no copies", 1), ("no sampling", 2), ("neither", 3), ("every copy from one box", 8)):
+        for label, bits in (("full", 0), ("no copies", 1), ("no sampling", 2), ("neither", 3), ("every copy from one box", 8), ("per-row values for free", 16)):
             print("   %-28s %.3f ms" % (label, t(both | (bits << 8))))
