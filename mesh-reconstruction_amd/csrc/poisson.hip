@@ -90,7 +90,11 @@ __global__ void splat_kernel(Grid g, const float *__restrict__ pts, const float 
 // a uniform grid (cell ~ two sample spacings of a surface sampling: a handful of samples per cell), a sample scans the block of
 // (2R + 1)^3 cells around its own -- one binary search per cell row, the cells of a row are consecutive keys -- and stops as soon as
 // its KNN-th distance is at most R cells: everything outside the block is farther than that.  R doubles otherwise (sparse corners,
-// volumetric clouds).  Exact, not approximate; the host sums the per-sample means in sample order (deterministic).
+// volumetric clouds).  Exact, not approximate -- up to a budget of KNN_BUDGET candidates per sample, which only a cloud with most of
+// its samples inside one cell (densities many orders of magnitude apart) can exhaust: the distances found until then are used (an upper
+// bound of the true ones), so that no input can turn the search into an n^2 scan that runs for minutes.  The host sums the per-sample
+// means in sample order (deterministic).
+constexpr int KNN_BUDGET = 1 << 17;
 struct CellGrid {
     float ox, oy, oz, inv, cell;
     int nx, ny, nz;
@@ -143,6 +147,7 @@ __global__ void knn_spacing_kernel(CellGrid c, const unsigned *__restrict__ keys
     cell_of(c, p.x, p.y, p.z, ci, cj, ck);
     float best[KNN];
     const int rmax = max(c.nx, max(c.ny, c.nz));
+    int budget = KNN_BUDGET;
     for (int R = 1;; R *= 2) {
 #pragma unroll
         for (int t = 0; t < KNN; t++) best[t] = 3.0e38f;
@@ -150,7 +155,10 @@ __global__ void knn_spacing_kernel(CellGrid c, const unsigned *__restrict__ keys
         for (int k = max(ck - R, 0); k <= min(ck + R, c.nz - 1); k++)
             for (int j = max(cj - R, 0); j <= min(cj + R, c.ny - 1); j++) {
                 const unsigned row = (unsigned)((k * c.ny + j) * c.nx);
-                const int a = lower_bound_u32(keys, n, row + (unsigned)i0), b = lower_bound_u32(keys, n, row + (unsigned)i1 + 1u);
+                const int a = lower_bound_u32(keys, n, row + (unsigned)i0);
+                int b = lower_bound_u32(keys, n, row + (unsigned)i1 + 1u);
+                if (best[KNN - 1] == 0.0f || budget <= 0) b = a;  // nothing can come closer than coincident samples; or the budget is spent
+                budget -= b - a;
                 for (int t = a; t < b; t++) {
                     if (t == s) continue;
                     const float4 q = sorted[t];
@@ -167,7 +175,7 @@ __global__ void knn_spacing_kernel(CellGrid c, const unsigned *__restrict__ keys
                 }
             }
         const float reach = (float)R * c.cell;
-        if (best[KNN - 1] <= reach * reach || R >= rmax) break;
+        if (best[KNN - 1] <= reach * reach || R >= rmax || budget <= 0) break;
     }
     float sum = 0.0f;
     int m = 0;
