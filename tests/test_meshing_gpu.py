@@ -125,6 +125,24 @@ def test_a_cell_that_collects_more_than_2_pow_31_does_not_wrap(hip):
     assert abs(r["spacing"] - sp) <= 1e-4 * sp
 
 
+def test_average_spacing_on_clouds_of_mixed_density_and_coincident_samples(hip):
+    """the neighbour search must neither crawl nor go wrong when densities differ by orders of magnitude (a tight cluster inside a sparse
+    shell: most samples share a few cells of any uniform grid) or when samples coincide (distance 0 counts, as in CGAL)"""
+    import time
+    rng = np.random.default_rng(21)
+    shell, n1 = _sphere(rng, 20000, (0.0, 0.0, 0.0), 1.0)
+    cluster, n2 = _sphere(rng, 60000, (0.3, 0.1, -0.2), 0.002)
+    pts, nrm = np.concatenate([shell, cluster]), np.concatenate([n1, n2])
+    t0 = time.perf_counter()
+    r = mc.poisson(hip, pts, nrm, 6, 1.0, keep=False)
+    assert time.perf_counter() - t0 < 30.0
+    sp = mo.average_spacing(pts)
+    assert sp * (1 - 1e-4) <= r["spacing"] <= sp * 1.05, (r["spacing"], sp)    # exact unless the candidate budget was spent (then an upper bound)
+    dup = np.concatenate([shell[:5000]] * 8)                                     # every sample 8 times: the 6 nearest neighbours are copies
+    r = mc.poisson(hip, dup, np.concatenate([n1[:5000]] * 8), 6, 1.0, keep=False)
+    assert r["spacing"] == 0.0 and mo.average_spacing(dup) == 0.0
+
+
 def test_a_rerun_gives_the_same_bytes_and_bad_arguments_fail(hip):
     rng = np.random.default_rng(9)
     pts, nrm = _sphere(rng, 5000, (0, 0, 0), 1.0)
