@@ -151,15 +151,16 @@ __global__ void pads_from_quads_kernel(const uint32_t *__restrict__ quads, uint8
 // The exact sampler's LDS quad {t00 + 0.5, t01 - t00, t10 - t00, (t11 - t10) - (t01 - t00)} as four f16 (all exactly representable),
 // precomputed per texel of a padded side view: the sweep then fills its LDS region with global->LDS copies instead of building the
 // quads from bytes on the VALU for every (tile, chunk, view).  8 bytes per texel; built on demand (mvs_sweep_run with that sampler).
-__global__ void quad16_image_views_kernel(const uint8_t *__restrict__ pads, uint2 *__restrict__ q16, int W, int H, int pitch, size_t pad_slab)
+// (from the u8 quad image, whose entry (r, c) holds exactly the four texels needed: one dword in, two out)
+__global__ void quad16_image_views_kernel(const uint32_t *__restrict__ quads, uint2 *__restrict__ q16, int W, int H, int pitch, size_t pad_slab)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     if (c >= pitch) return;
     uint2 q = make_uint2(0u, 0u);
     if (r <= H && c <= W) {
-        const uint8_t *p0 = pads + pad_slab * blockIdx.z + (size_t)r * pitch + c;
-        const float t00 = (float)p0[0], t01 = (float)p0[1], t10 = (float)p0[pitch], t11 = (float)p0[pitch + 1];
+        const uint32_t u = quads[pad_slab * blockIdx.z + (size_t)r * pitch + c];
+        const float t00 = (float)(u & 0xffu), t01 = (float)((u >> 8) & 0xffu), t10 = (float)((u >> 16) & 0xffu), t11 = (float)(u >> 24);
         const _Float16 h0 = (_Float16)(t00 + 0.5f), h1 = (_Float16)(t01 - t00), h2 = (_Float16)(t10 - t00), h3 = (_Float16)((t11 - t10) - (t01 - t00));
         q.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
         q.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
@@ -191,11 +192,11 @@ int ensure_pads(mvs_ctx *ctx)
 int ensure_quads16(mvs_ctx *ctx)
 {
     if (ctx->quads16_valid || ctx->V <= 0) return MVS_OK;
-    int rc = ensure_pads(ctx);
-    if (rc) return rc;
+    if (ctx->views_in_store) return fail(ctx, MVS_ESTATE, "the current side views are frame-store slots (mvs_sweep_handles): only the fixed sampler's tiled kernels run on them");
+    int rc;
     if ((rc = ensure(ctx, ctx->side_quads16, ctx->pad_slab * ctx->V * sizeof(uint2) + 256))) return rc;
     const dim3 grid(div_up(ctx->pad_pitch, 256), ctx->H + 2, ctx->V);
-    quad16_image_views_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)ctx->side_pads.ptr, (uint2 *)ctx->side_quads16.ptr, ctx->W, ctx->H, ctx->pad_pitch,
+    quad16_image_views_kernel<<<grid, 256, 0, ctx->stream>>>((const uint32_t *)ctx->side_quads.ptr, (uint2 *)ctx->side_quads16.ptr, ctx->W, ctx->H, ctx->pad_pitch,
                                                              ctx->pad_slab);
     MVS_HIP(ctx, hipGetLastError());
     ctx->quads16_valid = true;

@@ -893,7 +893,6 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
         return MVS_OK;
     }
     if (ctx->plan_valid && ctx->plan_shape == 3) ctx->plan_valid = false;  // the plan in memory belongs to the fixed sampler
-    if ((rc = ensure_pads(ctx))) return rc;  // the exact sampler's generic regions and its un-tiled kernel gather from the padded frames
     if (!generic && (rc = ensure_quads16(ctx))) return rc;
 
     // Rectified views (the ring of SURVEY 8d) are served by sweep_exact_rect (sweep_xrect.hip); anything else, MVS_SWEEP_NO_RECT and the
@@ -931,6 +930,7 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
         ctx->exact_last_shape = 5;
         return MVS_OK;
     }
+    if ((rc = ensure_pads(ctx))) return rc;  // sweep_tiled's generic regions and the un-tiled kernel gather single texels of the padded frames
     if (ctx->exact_tiled_planned && ctx->plan_forced != force_tall) ctx->exact_tiled_planned = false;
     if (!generic && !ctx->exact_tiled_planned && ctx->V > 0) {
         if ((rc = ensure(ctx, ctx->plan_stats, 64))) return rc;
