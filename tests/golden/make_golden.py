@@ -29,6 +29,21 @@ def main():
     np.savez_compressed(os.path.join(HERE, "sweep_small_fx.npz"), D=D, depth=depth, cost=cost, idx=idx, vol=vol, lut=o.fx_weight_table())
     print("wrote sweep_small_fx.npz", depth.shape, vol.shape)
     stage_small(o)
+    rect_small(o)
+
+
+def rect_small(o):
+    """a geometry the RECTIFIED-view kernels serve (sweep_fx_rect / sweep_exact_rect: the SURVEY 8d ring at a size whose boxes fit their LDS
+    slots), both samplers: inputs, depth / index / best cost in full, the packed volume as a checksum and a 1-in-4 probe"""
+    W, H, D, V = 192, 40, 32, 3
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.1, freq_scale=0.4)
+    out = {"main_cam": main_cam, "main_img": main_img, "side_cams": side_cams, "side_imgs": np.stack(sides), "D": D}
+    for sampler in ("exact", "fixed"):
+        depth, cost, idx, vol = o.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, sampler=sampler)
+        out.update({"depth_" + sampler: depth, "cost_" + sampler: cost, "idx_" + sampler: idx.astype(np.int16), "vol_crc_" + sampler: _crc(vol),
+                    "vol_probe_" + sampler: vol[::2, ::2, ::2].copy()})
+    np.savez_compressed(os.path.join(HERE, "sweep_rect_small.npz"), **out)
+    print("wrote sweep_rect_small.npz", depth.shape, vol.shape)
 
 
 def _crc(a):

@@ -256,3 +256,17 @@ def test_golden_sweep_fixture_fixed_sampler(oracle):
     np.testing.assert_array_equal(idx, f["idx"])
     np.testing.assert_array_equal(depth, f["depth"])
     np.testing.assert_array_equal(cost, f["cost"])
+
+
+def test_golden_rect_fixture(oracle):
+    """pins both samplers' oracles on the geometry the rectified-view kernels serve (tests/golden/sweep_rect_small.npz; the GPU suite holds
+    sweep_fx_rect / sweep_exact_rect against the same file without the oracle in the loop)"""
+    import zlib
+    g = np.load(os.path.join(GOLDEN, "sweep_rect_small.npz"))
+    for sampler in ("exact", "fixed"):
+        depth, cost, idx, vol = oracle.sweep(g["main_cam"], g["main_img"], g["side_cams"], list(g["side_imgs"]), int(g["D"]), want_volume=True, sampler=sampler)
+        np.testing.assert_array_equal(depth, g["depth_" + sampler])
+        np.testing.assert_array_equal(cost, g["cost_" + sampler])
+        np.testing.assert_array_equal(idx, g["idx_" + sampler])
+        np.testing.assert_array_equal(vol[::2, ::2, ::2], g["vol_probe_" + sampler])
+        assert np.uint32(zlib.crc32(np.ascontiguousarray(vol).tobytes())) == g["vol_crc_" + sampler]

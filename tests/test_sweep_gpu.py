@@ -628,3 +628,26 @@ def test_sweep_matches_the_committed_golden_vectors(sampler):
         np.testing.assert_array_equal(idx, f["idx"])
         np.testing.assert_array_equal(depth, f["depth"])
         np.testing.assert_array_equal(cost, f["cost"])
+
+
+def test_rectified_kernels_match_the_committed_golden_vectors(sampler):
+    """sweep_fx_rect / sweep_exact_rect through the C ABI against tests/golden/sweep_rect_small.npz (the oracle's output, committed): no
+    oracle runs here; the plan shape says the rectified kernel served the run, and the general kernels must give the same bytes"""
+    import os
+    import zlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sweep_rect_small.npz"))
+    H, W = g["main_img"].shape
+    V, D = len(g["side_imgs"]), int(g["D"])
+    both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    with mvs_amd.Context(W, H, sampler=sampler) as ctx:
+        ctx.sweep_set(g["main_cam"], g["main_img"], g["side_cams"], list(g["side_imgs"]), D)
+        for flags, shape in ((both, 4 if sampler == "fixed" else 5), (both | mvs_amd.MVS_SWEEP_NO_RECT, None)):
+            ctx.sweep_run(0, V, flags)
+            if shape is not None:
+                assert ctx.plan_shape() == shape
+            depth, cost, idx, vol = ctx.sweep_fetch(want_volume=True)
+            np.testing.assert_array_equal(depth, g["depth_" + sampler])
+            np.testing.assert_array_equal(cost, g["cost_" + sampler])
+            np.testing.assert_array_equal(idx, g["idx_" + sampler])
+            np.testing.assert_array_equal(vol[::2, ::2, ::2], g["vol_probe_" + sampler])
+            assert np.uint32(zlib.crc32(np.ascontiguousarray(vol).tobytes())) == g["vol_crc_" + sampler]
