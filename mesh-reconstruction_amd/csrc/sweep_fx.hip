@@ -396,7 +396,7 @@ __device__ __forceinline__ void sample_range_fx_checked(const Affine &A, float b
 // Timing experiments (tools/exp_fx.py, tools/fx_sections.py) are compiled in with -DMVS_FX_EXPERIMENTS only: even never-taken
 // branches on p.debug change register allocation enough to cost the production kernel a few per cent.
 #ifndef MVS_FX_CUT
-#define MVS_FX_CUT 0  // timing experiments WITHOUT instrumentation (tools/build_variant.sh cutNN "-DMVS_FX_CUT=NN" csrc/sweep_fx.hip): 1 no copies, 32 no sample loop, 64 no per-view barrier, 128 no chunk epilogue -- wrong results
+#define MVS_FX_CUT 0  // timing experiments WITHOUT instrumentation (tools/build_variant.sh cutNN "-DMVS_FX_CUT=NN" csrc/sweep_fx.hip): 1 no copies, 32 no sample loop, 64 no per-view barrier, 128 no chunk epilogue, 256 no cold paths (GENERIC regions, per-sample frame tests: what the hot path alone needs in registers) -- wrong results
 #endif
 #ifdef MVS_FX_EXPERIMENTS
 #define FX_PROF_DECL unsigned long long pt_prev = 0, pt_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_iter = 0, pt_chunks = 0; const bool pt_on = p.plan_stats != nullptr && threadIdx.x < 64
@@ -530,7 +530,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
             if (pt_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             FX_PROF_MARK(0);
 #endif
-            if (__builtin_expect(mode == FX_GENERIC, 0)) {
+            if (__builtin_expect(mode == FX_GENERIC, 0) && !(MVS_FX_CUT & 256)) {
                 row_checked = ~0u;  // (its samples carry their own counts)
                 const uint32_t *qv = p.quads + p.pad_slab * (size_t)__builtin_amdgcn_readfirstlane((int)(desc.y >> 19));
 #pragma unroll
@@ -615,7 +615,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
                     }
                     checked = __builtin_amdgcn_ballot_w64(!inside && ok[j]) != 0ull;
                 }
-                if (checked) {
+                if (checked && !(MVS_FX_CUT & 256)) {
                     row_checked |= 1u << j;
                     if (ok[j]) sample_range_fx_checked<0, PC>(A, bx, by, bw, zc, rg, lds, Im255[j], acc[j]);
                     continue;
