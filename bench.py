@@ -548,15 +548,22 @@ def main():
                 cctx.sweep_set_main_device(main_cam, raw_main.data_ptr())
                 cctx.sweep_set_views_device(side_cams, side_ptrs)
                 cctx.sweep_run(0, V, both)
-            for _ in range(5):
-                cold_once()
-            torch.cuda.synchronize()
+            def time_cold():
+                for _ in range(5):
+                    cold_once()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n_cold):
+                    cold_once()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / n_cold * 1e3
             n_cold = max(10, args.steps)
-            t1 = time.perf_counter()
-            for _ in range(n_cold):
-                cold_once()
-            torch.cuda.synchronize()
-            cold_ms = (time.perf_counter() - t1) / n_cold * 1e3
+            # the library reuses the region plan when a new view set has the view matrices, planes and slots of the last one (a fixed rig's
+            # next frames); the cold step proper is a set with NEW cameras, so the reuse is switched off for it and reported beside it
+            os.environ["MVS_NO_PLAN_CACHE"] = "1"
+            cold_ms = time_cold()
+            del os.environ["MVS_NO_PLAN_CACHE"]
+            same_rig_ms = time_cold()
             cold_crc = zlib.crc32(np.ascontiguousarray(cctx.sweep_fetch()[0]).tobytes())
             cold_shape = cctx.plan_shape()
         if cold_crc != crc1:
@@ -566,6 +573,9 @@ def main():
                 "kernel": KERNEL_OF_SHAPE.get(cold_shape),
                 "includes": "mvs_sweep_set_main_device + mvs_sweep_set_views_device (view matrices, quad images of all views from the raw u8 frames in one "
                             "pass) + region plan (with its one host read-back) + sweep with depth selection + combine_best; raw frames resident in HBM, no PCIe",
+                "same_cameras_ms": same_rig_ms,
+                "same_cameras_note": "the same step when the new views come from the cameras of the last set (a fixed rig's next frames): the region plan is reused, "
+                                     "what is left beside the sweep is the main frame's copy, the view matrices and the quad images",
                 "depth_crc32": cold_crc}
         del raw_main, raw_sides
 

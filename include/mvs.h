@@ -162,7 +162,9 @@ int mvs_sweep_set_planes(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi);
 /* The same with frames that already live in the memory of the context's GPU (a decoder's output, a previous stage's result): H*W u8,
  * tightly packed.  Stream-ordered like a kernel launch: nothing crosses PCIe, nothing synchronises, and the frames are read by work
  * queued on the context's stream -- they must stay unchanged until that work has run (mvs_synchronize, or the caller's own stream
- * order when mvs_set_stream shares a stream).  The side views' quad images are written straight from the raw frames in one pass. */
+ * order when mvs_set_stream shares a stream).  The side views' quad images are written straight from the raw frames in one pass.
+ * (Any of the view setters: when the new set has the view matrices and planes of the last planned one -- a fixed camera rig
+ * delivering its next frames -- the region plan in memory is reused; it depends on the cameras, not on the frames.) */
 int mvs_sweep_set_main_device(mvs_ctx *ctx, const float main_cam[16], const void *main_dev);
 int mvs_sweep_set_views_device(mvs_ctx *ctx, int nviews, const float *side_cams, const void *const *side_frames_dev);
 

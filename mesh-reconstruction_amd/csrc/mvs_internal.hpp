@@ -76,6 +76,11 @@ struct mvs_ctx {
     int xrect_rs = 0, xrect_slot_bytes = 0;
     bool exact_tiled_planned = false;  // sweep_tiled's region plan exists for the current (views, planes) (made on demand when xrect_ok)
     int exact_last_shape = 0;          // what served the exact sampler's last run: 1 / 2 (sweep_tiled's thread shapes) or 5 (sweep_exact_rect)
+    // what the fixed sampler's plan in memory (rectified tables, general plan) was made for: a new set of views with the SAME view matrices,
+    // planes and slots -- a fixed camera rig delivering its next frames -- reuses it instead of planning again
+    bool snap_valid = false, snap_in_store = false;
+    std::vector<float> snap_q, snap_z;
+    std::vector<int> snap_slots;
     bool fx_general_planned = false; // the general tiled kernel's plan exists for the current (views, planes) (made on demand when rect_ok)
     int rect_rs = 0, rect_slot_dw = 0, rect_dpad = 0;
     std::vector<unsigned char> rect_cold_host;  // host copy of the kernel's cold block (sweep_rect.hip: RectCold)

@@ -799,6 +799,7 @@ int mvs_sweep_set_sampler(mvs_ctx *ctx, int sampler)
         MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // queued kernels read the plan of the old sampler
         ctx->sampler = sampler;
         ctx->plan_valid = false;
+        ctx->snap_valid = false;  // (the exact sampler's planner reuses the plan buffer)
     }
     return MVS_OK;
 }
@@ -933,6 +934,7 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
     if ((rc = ensure_pads(ctx))) return rc;  // sweep_tiled's generic regions and the un-tiled kernel gather single texels of the padded frames
     if (ctx->exact_tiled_planned && ctx->plan_forced != force_tall) ctx->exact_tiled_planned = false;
     if (!generic && !ctx->exact_tiled_planned && ctx->V > 0) {
+        ctx->snap_valid = false;  // ctx->plan is about to hold the exact sampler's regions
         if ((rc = ensure(ctx, ctx->plan_stats, 64))) return rc;
         int *stats = (int *)ctx->plan_stats.ptr;
         ProfileScope ps(ctx, MVS_K_PLAN);

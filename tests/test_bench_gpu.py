@@ -74,5 +74,6 @@ def test_bench_line_contract_and_two_rank_shardings():
     # a new (main, views) set from raw frames resident in HBM: prepared, planned and swept inside the timed step, same depth map
     cold = ext["cold_step"]
     assert cold["ms"] >= ext["ms_per_step"] * 0.9 and cold["depth_crc32"] == ext["depth_crc32_single_gpu"] and 0.0 < cold["frac"] < 1.0
+    assert 0.0 < cold["same_cameras_ms"] <= cold["ms"] * 1.2   # (the plan reused: not slower than planning, up to noise)
     assert "combine_best" in ext["roofline"]["ms_per_launch_covers"]
     assert "roofline_traffic" in ext["general_camera_path"]

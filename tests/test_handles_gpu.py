@@ -149,3 +149,34 @@ def test_handles_errors_and_state():
             ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
         # and the host-pointer path works on the same context afterwards
         np.testing.assert_array_equal(ctx.sweep(main_cam, main_img, side_cams, sides, D), d)
+
+
+def test_a_fixed_rigs_next_frames_reuse_the_plan_and_new_cameras_do_not(oracle, monkeypatch):
+    """the plan depends on cameras and planes, not on frames: new frames under the cameras of the last set must give what a fresh context gives
+    (plan reused), and so must new cameras, new planes and a new main camera in between (plan remade) -- each against the oracle"""
+    W, H, D, V = 320, 200, 32, 4
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.2)
+    rng = np.random.default_rng(5)
+    frames2 = [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(V + 1)]
+    rot = _rotated(side_cams, W, H, V, 0.2)
+
+    def ref(mc, mi, sc, si, planes):
+        return oracle.sweep(mc, mi, sc, si, planes, nthreads=8, sampler="fixed")[0]
+    with mvs_amd.Context(W, H) as ctx:
+        np.testing.assert_array_equal(ctx.sweep(main_cam, main_img, side_cams, sides, D), ref(main_cam, main_img, side_cams, sides, D))
+        np.testing.assert_array_equal(ctx.sweep(main_cam, frames2[0], side_cams, frames2[1:], D), ref(main_cam, frames2[0], side_cams, frames2[1:], D))   # same rig, new frames
+        np.testing.assert_array_equal(ctx.sweep(main_cam, frames2[0], rot, frames2[1:], D), ref(main_cam, frames2[0], rot, frames2[1:], D))               # new cameras: general kernel
+        np.testing.assert_array_equal(ctx.sweep(main_cam, main_img, rot, sides, D), ref(main_cam, main_img, rot, sides, D))                                 # same (general) rig, new frames
+        np.testing.assert_array_equal(ctx.sweep(main_cam, main_img, side_cams, sides, D + 7), ref(main_cam, main_img, side_cams, sides, D + 7))           # new planes
+        np.testing.assert_array_equal(ctx.sweep(side_cams[0], sides[0], side_cams[1:], sides[1:], D + 7), ref(side_cams[0], sides[0], side_cams[1:], sides[1:], D + 7))   # new main camera
+        # staged form: views set twice with the same cameras (the second time the plan is reused), then with the reuse switched off
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        ctx.sweep_set_views(side_cams, frames2[1:])
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        a = ctx.sweep_fetch()[0]
+        monkeypatch.setenv("MVS_NO_PLAN_CACHE", "1")
+        ctx.sweep_set_views(side_cams, frames2[1:])
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        np.testing.assert_array_equal(ctx.sweep_fetch()[0], a)
+    np.testing.assert_array_equal(a, ref(main_cam, main_img, side_cams, frames2[1:], D))
