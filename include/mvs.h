@@ -159,7 +159,8 @@ int mvs_sweep_sampler(const mvs_ctx *ctx);
 int mvs_sweep_set_main(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw);
 int mvs_sweep_set_views(mvs_ctx *ctx, int nviews, const float *side_cams, const uint8_t *const *side_frames);
 int mvs_sweep_set_planes(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi);
-/* The same with frames that already live in the memory of the context's GPU (a decoder's output, a previous stage's result): H*W u8,
+/* The same with frames that already live in the memory of the context's GPU (a decoder's output, a previous stage's result; no counterpart
+ * in the reference, whose frames are host cv::Mat: Configuration::frame, configuration.cpp:437-440): H*W u8,
  * tightly packed.  Stream-ordered like a kernel launch: nothing crosses PCIe, nothing synchronises, and the frames are read by work
  * queued on the context's stream -- they must stay unchanged until that work has run (mvs_synchronize, or the caller's own stream
  * order when mvs_set_stream shares a stream).  The side views' quad images are written straight from the raw frames in one pass.
