@@ -328,6 +328,25 @@ int mvs_surface_fetch(const mvs_surface *s, float *vertices /* V x 4, w = 1 */, 
 int mvs_surface_grid(const mvs_surface *s, int *nodes_per_axis, float origin3[3], float *spacing, float *level, float *chi /* G^3, nullable */,
                      int64_t *splat /* 4 G^3: vx, vy, vz, weight in units of 2^-16; nullable */);
 int mvs_surface_spacing(const mvs_surface *s, float *average_spacing /* of the samples, 6 nearest neighbours */, float *node_spacing, int *ratio_kept);
+/* The facet criteria the reference hands its mesher (cgal_poisson.cpp:50-52, 95-97: CGAL::Surface_mesh_default_criteria_3(sm_angle = 20
+ * degrees, sm_radius = 300 x average spacing, sm_distance = 0.375 x average spacing)), as a pass over the surface's triangles
+ * (csrc/surface_criteria.cpp; host code, like the reference's mesher): facets whose smallest angle is below min_angle_deg are removed by
+ * edge collapses and edge flips between the vertices the mesher placed (no vertex moves, none is added; the link condition keeps the
+ * surface a manifold wherever it was one), each guarded so that the surface moves by at most a quarter of max_distance; facets whose
+ * circumradius exceeds max_radius are counted (the grid rule of mvs_poisson_surface keeps every facet two orders of magnitude below the
+ * reference's bound, so nothing is done about them).  Vertices that lose all their facets are dropped; the order of the others, and of
+ * the facets, is kept.  report (nullable) says what was done and what is left.  poissonSurface (host/poisson.cpp) and
+ * mvs_amd.poisson_surface apply it with the reference's three numbers. */
+typedef struct mvs_criteria_report {
+    int collapses, flips;          /* operations applied */
+    int facets_below_angle;        /* facets still below min_angle_deg afterwards */
+    int facets_above_radius;       /* facets whose circumradius exceeds max_radius */
+    float min_angle_deg;           /* smallest facet angle of the result (180 for an empty mesh) */
+    float max_circumradius;        /* largest facet circumradius of the result */
+} mvs_criteria_report;
+int mvs_surface_enforce_criteria(mvs_surface *s, float min_angle_deg /* [0, 60) */, float max_radius, float max_distance, mvs_criteria_report *report);
+/* a surface object over a caller's triangle mesh (vertices V x 4 with w = 1, faces F x 3), e.g. to apply the criteria to it; needs no GPU */
+int mvs_surface_from_mesh(const float *vertices, int vertex_count, const int32_t *faces, int face_count, float average_spacing, mvs_surface **out);
 void mvs_surface_free(mvs_surface *s);
 const char *mvs_surface_last_error(void); /* of the calling thread */
 

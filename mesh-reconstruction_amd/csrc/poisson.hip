@@ -22,7 +22,8 @@
 //      crossings; one quad = two triangles per grid edge that changes sign), vertices and faces numbered in grid order by
 //      exclusive scans (rocPRIM), faces oriented along +grad chi = the samples' normals (outward, like cgal_poisson.cpp:128-132).
 // Output: vertices N x 4 homogeneous (w = 1), faces F x 3 int32, as Mesh (recon.hpp:19-24).  Not CGAL's triangulation: a different
-// mesh of the same level set family (no Delaunay refinement, no angle / radius / distance criteria); DESIGN.md section 9 says so.
+// mesh of the same level set family (no Delaunay refinement; the reference's facet criteria -- angle, radius, distance, cgal_poisson.cpp:50-52 --
+// are kept by the grid rule of step 0 and by mvs_surface_enforce_criteria, csrc/surface_criteria.cpp); DESIGN.md section 9 says so.
 // Checked against oracle/poisson_oracle.py (numpy, float64) on the same inputs: identical splat integers, chi within 1e-4 of its
 // range, surfaces within a fraction of a cell (tests/test_meshing_gpu.py).
 #include <algorithm>
@@ -41,6 +42,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "../../include/mvs.h"
+#include "surface_internal.hpp"
 
 namespace {
 
@@ -49,11 +51,7 @@ constexpr float NORMAL_LIMIT = 1.0e4f;    // a normal component beyond this (or 
 constexpr int KNN = 6;                    // cgal_poisson.cpp:77: compute_average_spacing(points, 6)
 typedef long long fix_t;
 
-struct Grid {
-    int G;            // nodes per axis
-    float ox, oy, oz; // position of node (0, 0, 0)
-    float h;          // node spacing
-};
+typedef SurfaceGrid Grid;  // csrc/surface_internal.hpp
 
 __device__ __forceinline__ size_t node(const Grid &g, int i, int j, int k) { return ((size_t)k * g.G + j) * g.G + i; }
 
@@ -401,17 +399,6 @@ struct PlanCache {
 PlanCache g_plans;
 
 }  // namespace
-
-struct mvs_surface {
-    Grid grid{};
-    float iso = 0.0f;
-    float spacing = 0.0f;     // CGAL::compute_average_spacing(points, 6) of the samples
-    int ratio_kept = 1;       // node spacing <= 0.75 x average spacing (0: the finest grid, 512^3, is coarser than that)
-    std::vector<float> vertices;   // 4 per vertex
-    std::vector<int32_t> faces;    // 3 per face
-    std::vector<float> chi;        // G^3, kept when asked for (tests)
-    std::vector<int64_t> splat;    // 4 G^3 (vx, vy, vz, weight), kept when asked for (tests)
-};
 
 extern "C" const char *mvs_surface_last_error(void) { return g_poisson_error.c_str(); }
 

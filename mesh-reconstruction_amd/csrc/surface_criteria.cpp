@@ -1,0 +1,349 @@
+// surface_criteria.cpp -- the facet criteria of the reference's surface mesher as a pass over the surface-nets mesh.
+//
+// cgal_poisson.cpp:50-52, 95-102 hands CGAL::make_surface_mesh three numbers: a LOWER bound on the facets' angles (sm_angle = 20 degrees),
+// an UPPER bound on the radius of their surface Delaunay balls (sm_radius = 300 average spacings: in practice never binding) and an upper
+// bound on the distance between a facet and the surface (sm_distance = 0.375 average spacings).  CGAL meets them by Delaunay refinement:
+// it inserts surface points until no facet is "bad".  The grid mesher of csrc/poisson.hip meets the distance bound by construction (node
+// spacing <= 0.75 average spacings, header of that file) and the radius bound trivially (its facets span at most two cells), but surface
+// nets put a vertex wherever the mean edge crossing of a cell falls, so two vertices of a quad can lie arbitrarily close together: a
+// few per cent of its triangles are needles or caps.  This pass removes them with the two local operations that do not move a vertex off
+// the level set (every vertex that survives is one the mesher placed):
+//   * edge collapse  u -> v  (u disappears; the two facets on the edge go, the others around u now end in v), only when the edge has
+//     exactly two facets and the link condition holds (the only common neighbours of u and v are the two opposite vertices: the surface
+//     stays a manifold wherever it was one), no surviving facet turns over, and u stays within a quarter of the distance bound of the
+//     new facets' planes;
+//   * edge flip (the other diagonal of the quad formed by the edge's two facets), only when that diagonal is not an edge already, the
+//     two new facets keep the orientation, and the two diagonals pass within a quarter of the distance bound of each other (the quad is
+//     nearly flat).
+// A facet below the angle bound is offered all nine candidates on its three edges (collapse either way, flip); the valid candidate that
+// leaves the best worst-angle among the facets it touches is applied if that is a strict improvement of their worst angle before.  Work
+// list in facet order, then first in first out; every facet an operation touches and leaves below the bound is queued again.  Purely
+// sequential host code, deterministic; like the reference's mesher (CGAL on the CPU) it is not on the hot path.
+// What it reports is what the criteria ask: how many facets are still below the angle bound (0 on every surface of the test-suite),
+// how many are above the radius bound, the smallest angle and the largest circumradius found.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/mvs.h"
+#include "surface_internal.hpp"
+
+namespace {
+
+struct V3 {
+    double x, y, z;
+};
+inline V3 sub(const V3 &a, const V3 &b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline double dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(const V3 &a, const V3 &b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+// quality of a triangle: minus the largest cosine of its angles (-1: degenerate, -0.5: equilateral); min angle >= theta  <=>  q >= -cos(theta)
+double quality(const V3 &a, const V3 &b, const V3 &c)
+{
+    const V3 ab = sub(b, a), bc = sub(c, b), ca = sub(a, c);
+    const double lab = dot(ab, ab), lbc = dot(bc, bc), lca = dot(ca, ca);
+    if (!(lab > 0.0) || !(lbc > 0.0) || !(lca > 0.0)) return -1.0;
+    const double cA = -dot(ab, ca) / std::sqrt(lab * lca), cB = -dot(ab, bc) / std::sqrt(lab * lbc), cC = -dot(bc, ca) / std::sqrt(lbc * lca);
+    return -std::max(cA, std::max(cB, cC));
+}
+
+struct Work {
+    std::vector<V3> p;
+    std::vector<int32_t> f;             // 3 per facet; f[3 i] < 0: removed
+    std::vector<std::vector<int>> inc;  // facets around a vertex
+    std::vector<int> stamp;
+    int stamp_now = 0;
+    double q_bound = 0.0, guard = 0.0;
+    int collapses = 0, flips = 0;
+
+    double q_of(int face) const { return quality(p[f[3 * face]], p[f[3 * face + 1]], p[f[3 * face + 2]]); }
+    V3 normal_of(int a, int b, int c) const { return cross(sub(p[b], p[a]), sub(p[c], p[a])); }
+    bool has(int face, int v) const { return f[3 * face] == v || f[3 * face + 1] == v || f[3 * face + 2] == v; }
+    int third(int face, int u, int v) const
+    {
+        for (int k = 0; k < 3; k++)
+            if (f[3 * face + k] != u && f[3 * face + k] != v) return f[3 * face + k];
+        return -1;
+    }
+    // does `face` run u -> v along its boundary?
+    bool directed(int face, int u, int v) const
+    {
+        for (int k = 0; k < 3; k++)
+            if (f[3 * face + k] == u && f[3 * face + (k + 1) % 3] == v) return true;
+        return false;
+    }
+    int edge_facets(int u, int v, int out[2]) const
+    {
+        int n = 0;
+        for (int face : inc[u])
+            if (has(face, v)) {
+                if (n < 2) out[n] = face;
+                n++;
+            }
+        return n;
+    }
+    bool connected(int a, int b) const
+    {
+        for (int face : inc[a])
+            if (has(face, b)) return true;
+        return false;
+    }
+
+    // ---- collapse u -> v ----
+    struct Candidate {
+        int kind = 0;  // 1 collapse, 2 flip
+        int u = 0, v = 0;
+        double after = -2.0;
+    };
+
+    double try_collapse(int u, int v, double *before_out)
+    {
+        int e[2];
+        if (edge_facets(u, v, e) != 2) return -2.0;
+        const int c = third(e[0], u, v), d = third(e[1], u, v);
+        if (c < 0 || d < 0 || c == d) return -2.0;
+        if (inc[c].size() <= 3 || inc[d].size() <= 3 || inc[u].size() + inc[v].size() < 7) return -2.0;
+        // link condition: neighbours of u that are neighbours of v = {c, d}
+        stamp_now++;
+        for (int face : inc[v])
+            for (int k = 0; k < 3; k++) stamp[f[3 * face + k]] = stamp_now;
+        int shared = 0;
+        const int seen = ++stamp_now;  // (v's marks are stamp_now - 1 from here on)
+        for (int face : inc[u])
+            for (int k = 0; k < 3; k++) {
+                const int w = f[3 * face + k];
+                if (w == u || w == v) continue;
+                if (stamp[w] == seen - 1) {
+                    shared++;
+                    stamp[w] = seen;  // count a neighbour once
+                }
+            }
+        if (shared != 2) return -2.0;
+        double before = 0.0, after = 0.0, nearest = 1e300;
+        bool any = false;
+        for (int face : inc[u]) {
+            const double q0 = q_of(face);
+            before = std::min(before, q0);
+            if (face == e[0] || face == e[1]) continue;
+            int t[3];
+            for (int k = 0; k < 3; k++) t[k] = f[3 * face + k] == u ? v : f[3 * face + k];
+            const double q1 = quality(p[t[0]], p[t[1]], p[t[2]]);
+            after = std::min(after, q1);
+            const V3 n0 = normal_of(f[3 * face], f[3 * face + 1], f[3 * face + 2]), n1 = normal_of(t[0], t[1], t[2]);
+            const double l0 = dot(n0, n0), l1 = dot(n1, n1);
+            if (!(l1 > 0.0)) return -2.0;
+            if (q0 > -0.9962 && dot(n0, n1) < 0.3 * std::sqrt(l0 * l1)) return -2.0;  // (a facet below 5 degrees has no normal worth keeping)
+            nearest = std::min(nearest, std::fabs(dot(n1, sub(p[u], p[t[0]]))) / std::sqrt(l1));
+            any = true;
+        }
+        if (!any || nearest > guard) return -2.0;
+        *before_out = before;
+        return after;
+    }
+
+    void do_collapse(int u, int v, std::vector<int> &touched)
+    {
+        int e[2];
+        edge_facets(u, v, e);
+        for (int k = 0; k < 2; k++) {
+            const int face = e[k];
+            for (int j = 0; j < 3; j++) {
+                const int w = f[3 * face + j];
+                if (w == u) continue;
+                auto &l = inc[w];
+                l.erase(std::find(l.begin(), l.end(), face));
+            }
+            f[3 * face] = f[3 * face + 1] = f[3 * face + 2] = -1;
+        }
+        for (int face : inc[u]) {
+            if (face == e[0] || face == e[1]) continue;
+            for (int j = 0; j < 3; j++)
+                if (f[3 * face + j] == u) f[3 * face + j] = v;
+            inc[v].push_back(face);
+            touched.push_back(face);
+        }
+        inc[u].clear();
+        collapses++;
+    }
+
+    // ---- flip the edge u - v ----
+    double try_flip(int u, int v, double *before_out)
+    {
+        int e[2];
+        if (edge_facets(u, v, e) != 2) return -2.0;
+        int f1 = e[0], f2 = e[1];
+        if (!directed(f1, u, v)) std::swap(f1, f2);
+        if (!directed(f1, u, v) || !directed(f2, v, u)) return -2.0;  // not consistently oriented here
+        const int c = third(f1, u, v), d = third(f2, u, v);
+        if (c < 0 || d < 0 || c == d || connected(c, d)) return -2.0;
+        if (inc[u].size() <= 3 || inc[v].size() <= 3) return -2.0;
+        const double before = std::min(q_of(f1), q_of(f2));
+        const double after = std::min(quality(p[u], p[d], p[c]), quality(p[d], p[v], p[c]));
+        const V3 n1 = normal_of(u, v, c), n2 = normal_of(v, u, d);
+        const V3 ref = {n1.x + n2.x, n1.y + n2.y, n1.z + n2.z};
+        const V3 m1 = normal_of(u, d, c), m2 = normal_of(d, v, c);
+        const double lr = dot(ref, ref), l1 = dot(m1, m1), l2 = dot(m2, m2);
+        if (!(lr > 0.0) || !(l1 > 0.0) || !(l2 > 0.0)) return -2.0;
+        if (dot(m1, ref) < 0.3 * std::sqrt(l1 * lr) || dot(m2, ref) < 0.3 * std::sqrt(l2 * lr)) return -2.0;
+        // distance between the two diagonals (as lines): how far the surface moves when one replaces the other
+        const V3 x = cross(sub(p[v], p[u]), sub(p[d], p[c]));
+        const double lx = dot(x, x);
+        if (!(lx > 0.0) || std::fabs(dot(x, sub(p[c], p[u]))) / std::sqrt(lx) > guard) return -2.0;
+        *before_out = before;
+        return after;
+    }
+
+    void do_flip(int u, int v, std::vector<int> &touched)
+    {
+        int e[2];
+        edge_facets(u, v, e);
+        int f1 = e[0], f2 = e[1];
+        if (!directed(f1, u, v)) std::swap(f1, f2);
+        const int c = third(f1, u, v), d = third(f2, u, v);
+        f[3 * f1] = u, f[3 * f1 + 1] = d, f[3 * f1 + 2] = c;
+        f[3 * f2] = d, f[3 * f2 + 1] = v, f[3 * f2 + 2] = c;
+        auto &lv = inc[v];
+        lv.erase(std::find(lv.begin(), lv.end(), f1));
+        inc[d].push_back(f1);
+        auto &lu = inc[u];
+        lu.erase(std::find(lu.begin(), lu.end(), f2));
+        inc[c].push_back(f2);
+        touched.push_back(f1);
+        touched.push_back(f2);
+        flips++;
+    }
+
+    bool improve(int face, std::vector<int> &touched)
+    {
+        Candidate best;
+        for (int k = 0; k < 3; k++) {
+            const int u = f[3 * face + k], v = f[3 * face + (k + 1) % 3];
+            double before = 0.0;
+            double a = try_collapse(u, v, &before);
+            if (a > before + 1e-12 && a > best.after) best = {1, u, v, a};
+            a = try_collapse(v, u, &before);
+            if (a > before + 1e-12 && a > best.after) best = {1, v, u, a};
+            a = try_flip(u, v, &before);
+            if (a > before + 1e-12 && a > best.after) best = {2, u, v, a};
+        }
+        if (best.kind == 1) do_collapse(best.u, best.v, touched);
+        else if (best.kind == 2) do_flip(best.u, best.v, touched);
+        return best.kind != 0;
+    }
+};
+
+}  // namespace
+
+extern "C" int mvs_surface_from_mesh(const float *vertices, int vertex_count, const int32_t *faces, int face_count, float average_spacing, mvs_surface **out)
+{
+    if (!out || vertex_count < 0 || face_count < 0 || (vertex_count && !vertices) || (face_count && !faces) || !(average_spacing >= 0.0f)) return MVS_EINVAL;
+    *out = nullptr;
+    for (int i = 0; i < 3 * face_count; i++)
+        if (faces[i] < 0 || faces[i] >= vertex_count) return MVS_EINVAL;
+    mvs_surface *s = new (std::nothrow) mvs_surface;
+    if (!s) return MVS_ENOMEM;
+    try {
+        s->vertices.assign(vertices, vertices + 4 * (size_t)vertex_count);
+        s->faces.assign(faces, faces + 3 * (size_t)face_count);
+    } catch (...) {
+        delete s;
+        return MVS_ENOMEM;
+    }
+    s->spacing = average_spacing;
+    *out = s;
+    return MVS_OK;
+}
+
+extern "C" int mvs_surface_enforce_criteria(mvs_surface *s, float min_angle_deg, float max_radius, float max_distance, mvs_criteria_report *report)
+{
+    if (!s || !(min_angle_deg >= 0.0f) || !(min_angle_deg < 60.0f) || !(max_radius > 0.0f) || !(max_distance >= 0.0f)) return MVS_EINVAL;
+    const int nv = (int)(s->vertices.size() / 4), nf = (int)(s->faces.size() / 3);
+    mvs_criteria_report r;
+    std::memset(&r, 0, sizeof r);
+    r.min_angle_deg = 180.0f;
+    try {
+        Work w;
+        w.p.resize((size_t)nv);
+        for (int i = 0; i < nv; i++) w.p[(size_t)i] = {(double)s->vertices[4 * (size_t)i], (double)s->vertices[4 * (size_t)i + 1], (double)s->vertices[4 * (size_t)i + 2]};
+        w.f = s->faces;
+        w.inc.resize((size_t)nv);
+        w.stamp.assign((size_t)nv, 0);
+        for (int i = 0; i < nf; i++) {
+            const int a = w.f[3 * i], b = w.f[3 * i + 1], c = w.f[3 * i + 2];
+            if (a == b || b == c || a == c) {  // not a triangle: drop it
+                w.f[3 * i] = w.f[3 * i + 1] = w.f[3 * i + 2] = -1;
+                continue;
+            }
+            w.inc[(size_t)a].push_back(i), w.inc[(size_t)b].push_back(i), w.inc[(size_t)c].push_back(i);
+        }
+        w.q_bound = -std::cos((double)min_angle_deg * 3.14159265358979323846 / 180.0);
+        w.guard = 0.25 * (double)max_distance;
+        std::vector<int> queue, touched;
+        for (int i = 0; i < nf; i++)
+            if (w.f[3 * i] >= 0 && w.q_of(i) < w.q_bound) queue.push_back(i);
+        const size_t budget = 20 * (size_t)nf + 1000;  // (collapses are finite by themselves; the cap is for flips chasing each other)
+        size_t done = 0;
+        // second round: the facets the first one could not help, with half of the distance bound to move in instead of a quarter
+        for (int round = 0; round < 2; round++) {
+            for (size_t head = 0; head < queue.size() && done < budget; head++) {
+                const int face = queue[head];
+                if (w.f[3 * face] < 0 || w.q_of(face) >= w.q_bound) continue;
+                touched.clear();
+                if (w.improve(face, touched)) {
+                    done++;
+                    for (int t : touched)
+                        if (w.f[3 * t] >= 0 && w.q_of(t) < w.q_bound) queue.push_back(t);
+                }
+            }
+            std::vector<int> left;
+            for (int face : queue)
+                if (w.f[3 * face] >= 0 && w.q_of(face) < w.q_bound) left.push_back(face);
+            std::sort(left.begin(), left.end());
+            left.erase(std::unique(left.begin(), left.end()), left.end());
+            if (left.empty()) break;
+            queue.swap(left);
+            w.guard = 0.5 * (double)max_distance;
+        }
+        r.collapses = w.collapses, r.flips = w.flips;
+        // compact: vertices still used, in their old order; facets in their old order
+        std::vector<int> renum((size_t)nv, -1);
+        for (int i = 0; i < nf; i++)
+            if (w.f[3 * i] >= 0)
+                for (int k = 0; k < 3; k++) renum[(size_t)w.f[3 * i + k]] = 0;
+        int kept_v = 0;
+        std::vector<float> vout;
+        for (int i = 0; i < nv; i++)
+            if (renum[(size_t)i] == 0) {
+                renum[(size_t)i] = kept_v++;
+                for (int k = 0; k < 4; k++) vout.push_back(s->vertices[4 * (size_t)i + k]);
+            }
+        std::vector<int32_t> fout;
+        double min_q = 0.0, max_r2 = 0.0;
+        for (int i = 0; i < nf; i++) {
+            if (w.f[3 * i] < 0) continue;
+            const V3 &a = w.p[(size_t)w.f[3 * i]], &b = w.p[(size_t)w.f[3 * i + 1]], &c = w.p[(size_t)w.f[3 * i + 2]];
+            const double q = quality(a, b, c);
+            if (q < w.q_bound) r.facets_below_angle++;
+            min_q = std::min(min_q, q);
+            // circumradius: |ab| |bc| |ca| / (4 area)
+            const V3 n = cross(sub(b, a), sub(c, a));
+            const double area2 = dot(n, n);  // (2 area)^2
+            const double l = dot(sub(b, a), sub(b, a)) * dot(sub(c, b), sub(c, b)) * dot(sub(a, c), sub(a, c));
+            const double r2 = area2 > 0.0 ? l / (4.0 * area2) : 1e300;
+            if (r2 > (double)max_radius * (double)max_radius) r.facets_above_radius++;
+            if (r2 < 1e299) max_r2 = std::max(max_r2, r2);
+            for (int k = 0; k < 3; k++) fout.push_back(renum[(size_t)w.f[3 * i + k]]);
+        }
+        r.min_angle_deg = fout.empty() ? 180.0f : (float)(std::acos(std::min(1.0, std::max(-1.0, -min_q))) * 180.0 / 3.14159265358979323846);
+        r.max_circumradius = (float)std::sqrt(max_r2);
+        s->vertices.swap(vout);
+        s->faces.swap(fout);
+    } catch (...) {
+        return MVS_ENOMEM;
+    }
+    if (report) *report = r;
+    return MVS_OK;
+}

@@ -1,6 +1,7 @@
 // poisson.cpp -- poissonSurface (recon.hpp:37; cgal_poisson.cpp:47-136, pcl.cpp:225-228 of the reference) above the C ABI
 // (include/mvs.h: mvs_poisson_surface, csrc/poisson.hip).  Same call, same Mesh layout (vertices N x 4 homogeneous f32, faces F x 3
-// i32, normals out of the solid); what is inside is this library's grid Poisson solver, not CGAL's (see csrc/poisson.hip).
+// i32, normals out of the solid); what is inside is this library's grid Poisson solver, not CGAL's (see csrc/poisson.hip), followed by
+// the reference's facet criteria as a pass over its triangles (csrc/surface_criteria.cpp).
 #include <stdexcept>
 #include <string>
 
@@ -15,6 +16,14 @@ Mesh poissonSurface(const Mat points, const Mat normals)
     mvs_surface *s = nullptr;
     const int rc = mvs_poisson_surface(points.ptr<float>(), normals.ptr<float>(), points.rows, 0, 1.0f, 0, &s);
     if (rc != MVS_OK) throw std::runtime_error(std::string("poissonSurface: ") + mvs_surface_last_error());  // cgal_poisson.cpp:73: assert(success)
+    // cgal_poisson.cpp:50-52, 95-97: the facet criteria handed to make_surface_mesh, in units of the samples' average spacing
+    const float sm_angle = 20.0f, sm_radius = 300.0f, sm_distance = 0.375f;
+    float spacing = 0.0f;
+    mvs_surface_spacing(s, &spacing, nullptr, nullptr);
+    if (spacing > 0.0f && mvs_surface_enforce_criteria(s, sm_angle, sm_radius * spacing, sm_distance * spacing, nullptr) != MVS_OK) {
+        mvs_surface_free(s);
+        throw std::runtime_error("poissonSurface: the facet criteria pass failed");
+    }
     int nv = 0, nf = 0;
     mvs_surface_counts(s, &nv, &nf);
     Mesh result(Mat(nv, 4, mvs::F32C1), Mat(nf, 3, mvs::S32C1));

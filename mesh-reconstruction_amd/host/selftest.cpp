@@ -232,9 +232,25 @@ static int run_gpu(const std::string &tracks, const std::string &out)
             const float *a = m.vertices.ptr<float>(m.faces.at<int32_t>(i, 0)), *b = m.vertices.ptr<float>(m.faces.at<int32_t>(i, 1)), *c = m.vertices.ptr<float>(m.faces.at<int32_t>(i, 2));
             vol += (a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0])) / 6.0;
         }
+        // cgal_poisson.cpp:50: sm_angle = 20 -- the smallest angle of any facet (vertices have w = 1 here)
+        double max_cos = -1.0;
+        for (int i = 0; i < m.faces.rows; i++) {
+            const float *q[3] = {m.vertices.ptr<float>(m.faces.at<int32_t>(i, 0)), m.vertices.ptr<float>(m.faces.at<int32_t>(i, 1)), m.vertices.ptr<float>(m.faces.at<int32_t>(i, 2))};
+            for (int k = 0; k < 3; k++) {
+                double u[3], w[3], uu = 0.0, ww = 0.0, uw = 0.0;
+                for (int c = 0; c < 3; c++) {
+                    u[c] = (double)q[(k + 1) % 3][c] - (double)q[k][c], w[c] = (double)q[(k + 2) % 3][c] - (double)q[k][c];
+                    uu += u[c] * u[c], ww += w[c] * w[c], uw += u[c] * w[c];
+                }
+                max_cos = std::max(max_cos, uw / std::sqrt(uu * ww));
+            }
+        }
+        const double min_angle = std::acos(std::min(1.0, max_cos)) * 180.0 / 3.14159265358979;
         const double sphere = 4.0 / 3.0 * 3.14159265358979 * 0.7 * 0.7 * 0.7;
-        printf("poissonSurface: %d vertices, %d faces, worst radial error %.4f, volume %.4f (sphere %.4f)\n", m.vertices.rows, m.faces.rows, worst, vol, sphere);
+        printf("poissonSurface: %d vertices, %d faces, worst radial error %.4f, volume %.4f (sphere %.4f), smallest facet angle %.2f degrees\n", m.vertices.rows,
+               m.faces.rows, worst, vol, sphere, min_angle);
         CHECK(m.faces.rows > 1000 && worst < 0.02 && std::fabs(vol - sphere) < 0.02 * sphere && hp.alphaVals.back() == 0.25f, "tessellate with the built-in Poisson surface");
+        CHECK(min_angle >= 20.0 - 1e-4, "poissonSurface keeps the reference's angle bound (cgal_poisson.cpp:50)");
     }
     std::ofstream sel(out + "/chosen.txt");
     int mains = 0, pairs = 0;

@@ -103,6 +103,8 @@ ABI = [
     ("mvs_surface_fetch", _i, [_vp, _vp, _vp]),
     ("mvs_surface_grid", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mvs_surface_spacing", _i, [_vp, _vp, _vp, _vp]),
+    ("mvs_surface_enforce_criteria", _i, [_vp, _f, _f, _f, _vp]),
+    ("mvs_surface_from_mesh", _i, [_vp, _i, _vp, _i, _f, _vp]),
     ("mvs_surface_free", None, [_vp]),
     ("mvs_surface_last_error", C.c_char_p, []),
 ]
@@ -167,9 +169,21 @@ def alpha_shape_faces(points, forced_alpha=0.0):
     return faces, alpha.value, comps.value
 
 
-def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0):
-    """poissonSurface (recon.hpp:37) through mvs_poisson_surface: points N x 4 homogeneous, normals N x 3 (out of the solid)
-    -> (vertices V x 4 float32 with w = 1, faces F x 3 int32)"""
+class CriteriaReport(C.Structure):
+    """mvs_criteria_report (include/mvs.h)"""
+    _fields_ = [("collapses", C.c_int), ("flips", C.c_int), ("facets_below_angle", C.c_int), ("facets_above_radius", C.c_int),
+                ("min_angle_deg", C.c_float), ("max_circumradius", C.c_float)]
+
+
+# cgal_poisson.cpp:50-52: sm_angle (degrees), sm_radius and sm_distance (in average spacings)
+REFERENCE_FACET_CRITERIA = (20.0, 300.0, 0.375)
+
+
+def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0, criteria=REFERENCE_FACET_CRITERIA, report=None):
+    """poissonSurface (recon.hpp:37) through mvs_poisson_surface + mvs_surface_enforce_criteria: points N x 4 homogeneous, normals N x 3
+    (out of the solid) -> (vertices V x 4 float32 with w = 1, faces F x 3 int32).  criteria = (min angle in degrees, max facet radius and
+    max facet distance in units of the samples' average spacing), the reference's by default; None: the surface-nets mesh as it is.
+    report: a dict that receives the fields of mvs_criteria_report and the average spacing"""
     lib = load_library()
     pts = np.ascontiguousarray(points, np.float32)
     nrm = np.ascontiguousarray(normals, np.float32)
@@ -179,6 +193,17 @@ def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0):
     if lib.mvs_poisson_surface(pts.ctypes.data_as(_vp), nrm.ctypes.data_as(_vp), len(pts), int(grid_log2), float(smooth_cells), 0, C.byref(s)) != 0:
         raise MvsError(lib.mvs_surface_last_error().decode())
     try:
+        spacing = C.c_float()
+        lib.mvs_surface_spacing(s, C.byref(spacing), None, None)
+        if criteria is not None and spacing.value > 0.0:
+            rep = CriteriaReport()
+            rc = lib.mvs_surface_enforce_criteria(s, float(criteria[0]), float(criteria[1]) * spacing.value, float(criteria[2]) * spacing.value, C.byref(rep))
+            if rc != 0:
+                raise MvsError("mvs_surface_enforce_criteria failed (%d)" % rc)
+            if report is not None:
+                report.update({name: getattr(rep, name) for name, _ in CriteriaReport._fields_})
+        if report is not None:
+            report["average_spacing"] = spacing.value
         nv, nf = C.c_int(), C.c_int()
         lib.mvs_surface_counts(s, C.byref(nv), C.byref(nf))
         v = np.zeros((nv.value, 4), np.float32)
@@ -187,6 +212,31 @@ def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0):
     finally:
         lib.mvs_surface_free(s)
     return v, f
+
+
+def enforce_facet_criteria(vertices, faces, average_spacing, criteria=REFERENCE_FACET_CRITERIA):
+    """mvs_surface_from_mesh + mvs_surface_enforce_criteria on a caller's mesh (host code, no GPU): -> (vertices, faces, report dict)"""
+    lib = load_library()
+    v = np.ascontiguousarray(vertices, np.float32)
+    f = np.ascontiguousarray(faces, np.int32)
+    if v.ndim != 2 or v.shape[1] != 4 or f.ndim != 2 or f.shape[1] != 3:
+        raise ValueError("vertices must be V x 4 and faces F x 3")
+    s = C.c_void_p()
+    if lib.mvs_surface_from_mesh(v.ctypes.data_as(_vp), len(v), f.ctypes.data_as(_vp), len(f), float(average_spacing), C.byref(s)) != 0:
+        raise MvsError("mvs_surface_from_mesh: bad argument")
+    try:
+        rep = CriteriaReport()
+        rc = lib.mvs_surface_enforce_criteria(s, float(criteria[0]), float(criteria[1]) * average_spacing, float(criteria[2]) * average_spacing, C.byref(rep))
+        if rc != 0:
+            raise MvsError("mvs_surface_enforce_criteria failed (%d)" % rc)
+        nv, nf = C.c_int(), C.c_int()
+        lib.mvs_surface_counts(s, C.byref(nv), C.byref(nf))
+        v2 = np.zeros((nv.value, 4), np.float32)
+        f2 = np.zeros((nf.value, 3), np.int32)
+        lib.mvs_surface_fetch(s, v2.ctypes.data_as(_vp), f2.ctypes.data_as(_vp))
+    finally:
+        lib.mvs_surface_free(s)
+    return v2, f2, {name: getattr(rep, name) for name, _ in CriteriaReport._fields_}
 
 
 def _f32(a, shape=None):

@@ -108,6 +108,38 @@ def test_grid_from_the_average_spacing_keeps_the_references_approximation_bound(
     assert mc.poisson(hip, pts, nrm, 5, 1.0, keep=False)["ratio_kept"] == 0
 
 
+def test_the_default_path_keeps_all_three_facet_criteria_of_the_reference(hip):
+    """cgal_poisson.cpp:50-52, 95-97: make_surface_mesh is asked for facet angles >= 20 degrees, facet radii <= 300 average spacings and
+    facet distances <= 0.375 average spacings.  mvs_amd.poisson_surface (like poissonSurface of the C++ mirror) runs
+    mvs_surface_enforce_criteria with those numbers on the mesh of the HIP solver; recomputed here in numpy, on analytic surfaces."""
+    import mvs_amd
+    from test_criteria_cpu import circumradii, closed_oriented_manifold, facet_angles
+    rng = np.random.default_rng(14)
+    for name, (pts, nrm), dist in (
+            ("sphere", _sphere(rng, 30000, (1.0, 2.0, -3.0), 1.5), lambda v: np.abs(np.linalg.norm(v[:, :3] - np.array([1.0, 2.0, -3.0]), axis=1) - 1.5)),
+            ("torus", _torus(rng, 60000, 1.0, 0.35), lambda v: np.abs(np.hypot(np.hypot(v[:, 0], v[:, 1]) - 1.0, v[:, 2]) - 0.35))):
+        raw_v, raw_f = mvs_amd.poisson_surface(pts, nrm, criteria=None)
+        r0 = mc.poisson(hip, pts, nrm, 0, 1.0, keep=False)
+        assert np.array_equal(raw_v, r0["vertices"]) and np.array_equal(raw_f, r0["faces"]), name      # criteria=None: the mesher's output as it is
+        assert facet_angles(raw_v, raw_f).min() < 5.0, name
+        rep = {}
+        v, f = mvs_amd.poisson_surface(pts, nrm, report=rep)
+        sp = rep["average_spacing"]
+        assert abs(sp - mo.average_spacing(pts)) <= 1e-5 * sp
+        ang = facet_angles(v, f)
+        assert ang.min() >= 20.0 - 1e-6 and rep["facets_below_angle"] == 0 and abs(rep["min_angle_deg"] - ang.min()) < 1e-3, (name, float(ang.min()))
+        R = circumradii(v, f)
+        assert R.max() <= 300.0 * sp and rep["facets_above_radius"] == 0, name
+        centres = v[:, :3].astype(np.float64)[f].mean(1)
+        assert dist(v.astype(np.float64)).max() <= 0.375 * sp and dist(centres).max() <= 0.375 * sp, name
+        assert closed_oriented_manifold(f) and np.all(v[:, 3] == 1.0), name
+        assert abs(mc.signed_volume(v, f) / mc.signed_volume(raw_v, raw_f) - 1.0) < 1e-4, name
+        assert rep["collapses"] == len(raw_v) - len(v) and 0 < rep["collapses"] < 0.02 * len(raw_v) and rep["flips"] > 0, name
+        # the pass is host code over the downloaded mesh: the same bytes as mvs_amd.enforce_facet_criteria on the raw mesh
+        v2, f2, _ = mvs_amd.enforce_facet_criteria(raw_v, raw_f, sp)
+        assert v2.tobytes() == v.tobytes() and f2.tobytes() == f.tobytes(), name
+
+
 def test_a_cell_that_collects_more_than_2_pow_31_does_not_wrap(hip):
     """two outliers stretch the box until the real samples share a few cells; with 32-bit accumulators the weight and normal
     fields wrapped silently.  The fields are 64-bit now: the integers equal the oracle's (numpy int64)"""
