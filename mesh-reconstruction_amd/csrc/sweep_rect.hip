@@ -351,7 +351,7 @@ struct RectArgs {
     size_t pad_slab;
     int pitch, W, H, D, V, v0, vcount, nchunks, chunk0, chunk1, cps, ty0, tyn, tiles_x;
     int slot_dw;   // dwords per LDS slot = 256 x copy instructions per region (one instruction fills 256 dwords); two slots
-    int debug;     // timing experiments, honoured by builds with -DMVS_RX_EXPERIMENTS only: 1 no copies, 2 no sampling, 4 no barrier, 8 every copy from one box, 16 no epilogue, 32 every plane taken for FULL, 64 no masks, 128 no failed-certificate block, 256 the plain comparison throughout (wrong results)
+    int debug;     // timing experiments, honoured by builds with -DMVS_RX_EXPERIMENTS only: 1 no copies, 2 no sampling, 4 no barrier, 8 every copy from one box, 16 no epilogue, 32 every plane taken for FULL, 64 no masks, 128 no failed-certificate block, 256 the plain comparison throughout, 512 half the regions with each sampled / copied / finished twice = the work of 8 planes per wavefront (wrong results)
 };
 
 template <typename T>
@@ -411,7 +411,9 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     }
 
     const int chunk_first = a.chunk0 + (int)blockIdx.y * a.cps;
-    const int chunk_last = min(a.chunk1, chunk_first + a.cps);
+    const int chunk_last_all = min(a.chunk1, chunk_first + a.cps);
+    // (timing experiment 512: half the regions, each sampled and finished twice -- the work of 8 planes per wavefront at today's registers and copies; wrong results)
+    const int chunk_last = RX_DBG(a, 512) ? chunk_first + max(1, (chunk_last_all - chunk_first) / 2) : chunk_last_all;
     const int vend = a.v0 + a.vcount;
     const int nreg = (chunk_last - chunk_first) * a.vcount;
 
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
         if (!RX_DBG(a, 4)) __builtin_amdgcn_s_barrier();
         // request region r + 1 into the other slot and the records of region r + 2: in flight during this region's sampling
         if (r + 1 < nreg) issue_copy(rdl(x1r, 6), rdl(y1r, 2), rdl(y1r, 3), slot_nxt);
+        if (RX_DBG(a, 512) && r + 1 < nreg) issue_copy(rdl(x1r, 6), rdl(y1r, 2), rdl(y1r, 3), slot_nxt);  // (twice the bytes per region, like a 32-plane box)
         const uint32_t x2r = load_x(c2.xo), y2r = load_y(c2.xo + ydelta);
         advance(c2);
         const uint32_t rsum = x0r + y0r;                            // (one vector add, two v_readlane: not four and two scalar adds)
@@ -548,7 +551,8 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     "s_bitcmp0_b32 %[ym], %[yb" #j "]\n\ts_cselect_b64 exec, vcc, 0\n\tv_add_u32 %[a" #j "], 0x1000000, %[a" #j "]\n\t" \
     "v_sad_u16 %[a" #j "], %[q" #j "], %[i" #j "], %[a" #j "]\n\t"
 #pragma unroll
-            for (int k = 0; k < RX_KW; k++) {
+            for (int kk = 0; kk < (RX_DBG(a, 512) ? 2 * RX_KW : RX_KW); kk++) {
+                const int k = kk % RX_KW;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
                 asm volatile("s_add_u32 m0, %[slot], %[fld]\n\t"
@@ -685,13 +689,14 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
 #pragma unroll
                 for (int j = 0; j < 8; j++) best[j] = bi[j] < 0 ? 1u : best[j];
             }
+            int d_extra = 0;  // (experiment 512 only)
             auto finish = [&](auto checked_rows, auto plain_compare) {
 #pragma unroll
                 for (int k = 0; k < RX_KW; k++) {
                     const uint32_t cntk = ((uint32_t)a.vcount - ((spacc >> (8 * k)) & 0xffu)) << 24;  // FULL planes: every cell gets the view's count
-                    if (d0 + k < a.D) {
+                    if (d0 + k + d_extra < a.D) {
                         // one resource per plane (a volume can exceed the 4 GiB a resource spans), rows by the wave-uniform offset
-                        const __amdgpu_buffer_rsrc_t rvol = make_rsrc(WRITE_VOLUME ? a.volume + (size_t)(d0 + k) * P : nullptr, 0xffffffffu);
+                        const __amdgpu_buffer_rsrc_t rvol = make_rsrc(WRITE_VOLUME ? a.volume + (size_t)(d0 + k + d_extra) * P : nullptr, 0xffffffffu);
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
                             if (!checked_rows.value || j < nrows) {
@@ -707,6 +712,11 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                     }
                 }
             };
+            if (RX_DBG(a, 512) && col_ok) {  // the other half of the workgroup's planes: the same store traffic
+                d_extra = (chunk_last - chunk_first) * RX_PC;
+                finish(std::false_type{}, std::true_type{});
+                d_extra = 0;
+            }
             if (col_ok) {
                 if (nrows == 8 && plain)
                     finish(std::false_type{}, std::true_type{});
@@ -966,6 +976,9 @@ int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsign
     a.debug = p.debug;
     size_t lds = ((size_t)2 * a.slot_dw + RX_BIAS_X + (size_t)RX_BIAS_Y * ctx->rect_rs) * 4;  // two slots, the second one's data ends a bias further on
     if (fused) lds = lds < 16384 ? 16384 : lds;  // the cross-wavefront depth selection borrows 16 KiB
+#ifdef MVS_RX_CUT
+    if (const char *e = getenv("MVS_RX_LDS")) lds = std::max(lds, (size_t)atoi(e));  // timing experiments: occupancy through the LDS request
+#endif
     if (lds > 160 * 1024) return fail(ctx, MVS_EINVAL, "sweep_rect_launch: %zu bytes of LDS", lds);
 
     const int groups = div_up(p.tiles_x, 2) * div_up(p.tyn, 4);
