@@ -6,6 +6,8 @@ triangulation taken from scipy (Qhull) -- an implementation independent of host/
     cells is interior; find_optimal_alpha(1) as CGAL's Alpha_shape_3.h states it (see host/alpha_shapes.cpp's header).
 poisson(points, normals, G, smooth): csrc/poisson.hip's grid Poisson reconstruction in float64 numpy (same box, same fixed-point
 splat, numpy FFT, same surface-nets rules).
+enforce_facet_criteria(vertices, faces, angle, radius, distance): csrc/surface_criteria.cpp's pass for the facet criteria the reference
+hands CGAL (cgal_poisson.cpp:50-52, 95-97), operation for operation.
 PARITY UNPINNED against the reference: CGAL / PCL are third-party packages that are neither in this image nor vendored by the
 reference, and the reference holds no golden output for either function (its TEST_BUILD mains read test/bunny_5000, not shipped)."""
 import numpy as np
@@ -254,3 +256,219 @@ def surface_nets(chi, iso, origin, h):
         tri = np.stack([quad[:, 0], q1, quad[:, 2], quad[:, 0], quad[:, 2], q3], 1).reshape(-1, 3)
         faces.append(tri)
     return verts, np.concatenate(faces).astype(np.int32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# facet criteria (csrc/surface_criteria.cpp): cgal_poisson.cpp:50-52, 95-97 hands make_surface_mesh a lower bound on the facets' angles
+# (sm_angle = 20 degrees), an upper bound on their circumradius (sm_radius x average spacing) and on their distance to the surface
+# (sm_distance x average spacing).  The restatement below follows the pass operation for operation in float64 Python scalars (the
+# C++ is compiled with -ffp-contract=off and uses double throughout: the same IEEE operations in the same order), including the order
+# of the incidence lists and of the work list, so that the result can be compared index for index on small meshes.
+def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_distance):
+    """-> (vertices V' x 4 float32, faces F' x 3 int32, report dict).  Pure-Python loops: use on meshes of a few ten thousand facets."""
+    import math
+    vin = np.asarray(vertices, np.float32)
+    p = [(float(r[0]), float(r[1]), float(r[2])) for r in vin]
+    f = [[int(x) for x in r] for r in np.asarray(faces)]
+    nv, nf = len(p), len(f)
+    inc = [[] for _ in range(nv)]
+
+    def sub(a, b):
+        return (a[0] - b[0], a[1] - b[1], a[2] - b[2])
+
+    def dot(a, b):
+        return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+
+    def cross(a, b):
+        return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+
+    def quality(a, b, c):
+        ab, bc, ca = sub(b, a), sub(c, b), sub(a, c)
+        lab, lbc, lca = dot(ab, ab), dot(bc, bc), dot(ca, ca)
+        if not lab > 0.0 or not lbc > 0.0 or not lca > 0.0:
+            return -1.0
+        cA, cB, cC = -dot(ab, ca) / math.sqrt(lab * lca), -dot(ab, bc) / math.sqrt(lab * lbc), -dot(bc, ca) / math.sqrt(lbc * lca)
+        return -max(cA, max(cB, cC))
+
+    def q_of(i):
+        return quality(p[f[i][0]], p[f[i][1]], p[f[i][2]])
+
+    def normal_of(a, b, c):
+        return cross(sub(p[b], p[a]), sub(p[c], p[a]))
+
+    def third(i, u, v):
+        for w in f[i]:
+            if w != u and w != v:
+                return w
+        return -1
+
+    def directed(i, u, v):
+        t = f[i]
+        return any(t[k] == u and t[(k + 1) % 3] == v for k in range(3))
+
+    def edge_facets(u, v):
+        return [i for i in inc[u] if v in f[i]]
+
+    for i in range(nf):
+        a, b, c = f[i]
+        if a == b or b == c or a == c:
+            f[i] = [-1, -1, -1]
+            continue
+        inc[a].append(i), inc[b].append(i), inc[c].append(i)
+    q_bound = -math.cos(float(np.float32(min_angle_deg)) * 3.14159265358979323846 / 180.0)
+    guard = [0.25 * float(np.float32(max_distance))]
+    count = {"collapses": 0, "flips": 0}
+
+    def try_collapse(u, v):
+        e = edge_facets(u, v)
+        if len(e) != 2:
+            return None
+        c, d = third(e[0], u, v), third(e[1], u, v)
+        if c < 0 or d < 0 or c == d:
+            return None
+        if len(inc[c]) <= 3 or len(inc[d]) <= 3 or len(inc[u]) + len(inc[v]) < 7:
+            return None
+        nbv = set(w for i in inc[v] for w in f[i])
+        shared = set(w for i in inc[u] for w in f[i] if w != u and w != v and w in nbv)
+        if len(shared) != 2:
+            return None
+        before, after, nearest, any_ = 0.0, 0.0, 1e300, False
+        for i in inc[u]:
+            q0 = q_of(i)
+            before = min(before, q0)
+            if i == e[0] or i == e[1]:
+                continue
+            t = [v if w == u else w for w in f[i]]
+            after = min(after, quality(p[t[0]], p[t[1]], p[t[2]]))
+            n0, n1 = normal_of(*f[i]), normal_of(*t)
+            l0, l1 = dot(n0, n0), dot(n1, n1)
+            if not l1 > 0.0:
+                return None
+            if q0 > -0.9962 and dot(n0, n1) < 0.3 * math.sqrt(l0 * l1):
+                return None
+            nearest = min(nearest, abs(dot(n1, sub(p[u], p[t[0]]))) / math.sqrt(l1))
+            any_ = True
+        if not any_ or nearest > guard[0]:
+            return None
+        return after, before
+
+    def do_collapse(u, v, touched):
+        e = edge_facets(u, v)[:2]
+        for i in e:
+            for w in f[i]:
+                if w != u:
+                    inc[w].remove(i)
+            f[i] = [-1, -1, -1]
+        for i in inc[u]:
+            if i == e[0] or i == e[1]:
+                continue
+            f[i] = [v if w == u else w for w in f[i]]
+            inc[v].append(i)
+            touched.append(i)
+        inc[u] = []
+        count["collapses"] += 1
+
+    def flip_pair(u, v):
+        e = edge_facets(u, v)
+        if len(e) != 2:
+            return None
+        f1, f2 = e
+        if not directed(f1, u, v):
+            f1, f2 = f2, f1
+        return f1, f2
+
+    def try_flip(u, v):
+        pair = flip_pair(u, v)
+        if pair is None:
+            return None
+        f1, f2 = pair
+        if not directed(f1, u, v) or not directed(f2, v, u):
+            return None
+        c, d = third(f1, u, v), third(f2, u, v)
+        if c < 0 or d < 0 or c == d or any(d in f[i] for i in inc[c]):
+            return None
+        if len(inc[u]) <= 3 or len(inc[v]) <= 3:
+            return None
+        before = min(q_of(f1), q_of(f2))
+        after = min(quality(p[u], p[d], p[c]), quality(p[d], p[v], p[c]))
+        n1, n2 = normal_of(u, v, c), normal_of(v, u, d)
+        ref = (n1[0] + n2[0], n1[1] + n2[1], n1[2] + n2[2])
+        m1, m2 = normal_of(u, d, c), normal_of(d, v, c)
+        lr, l1, l2 = dot(ref, ref), dot(m1, m1), dot(m2, m2)
+        if not lr > 0.0 or not l1 > 0.0 or not l2 > 0.0:
+            return None
+        if dot(m1, ref) < 0.3 * math.sqrt(l1 * lr) or dot(m2, ref) < 0.3 * math.sqrt(l2 * lr):
+            return None
+        x = cross(sub(p[v], p[u]), sub(p[d], p[c]))
+        lx = dot(x, x)
+        if not lx > 0.0 or abs(dot(x, sub(p[c], p[u]))) / math.sqrt(lx) > guard[0]:
+            return None
+        return after, before
+
+    def do_flip(u, v, touched):
+        f1, f2 = flip_pair(u, v)
+        c, d = third(f1, u, v), third(f2, u, v)
+        f[f1] = [u, d, c]
+        f[f2] = [d, v, c]
+        inc[v].remove(f1)
+        inc[d].append(f1)
+        inc[u].remove(f2)
+        inc[c].append(f2)
+        touched += [f1, f2]
+        count["flips"] += 1
+
+    def improve(i, touched):
+        best = (0, 0, 0, -2.0)
+        for k in range(3):
+            u, v = f[i][k], f[i][(k + 1) % 3]
+            for kind, a, b, fn in ((1, u, v, try_collapse), (1, v, u, try_collapse), (2, u, v, try_flip)):
+                r = fn(a, b)
+                if r is not None and r[0] > r[1] + 1e-12 and r[0] > best[3]:
+                    best = (kind, a, b, r[0])
+        if best[0] == 1:
+            do_collapse(best[1], best[2], touched)
+        elif best[0] == 2:
+            do_flip(best[1], best[2], touched)
+        return best[0] != 0
+
+    queue = [i for i in range(nf) if f[i][0] >= 0 and q_of(i) < q_bound]
+    budget, done = 20 * nf + 1000, 0
+    for _round in range(2):
+        head = 0
+        while head < len(queue) and done < budget:
+            i = queue[head]
+            head += 1
+            if f[i][0] < 0 or q_of(i) >= q_bound:
+                continue
+            touched = []
+            if improve(i, touched):
+                done += 1
+                queue += [t for t in touched if f[t][0] >= 0 and q_of(t) < q_bound]
+        left = sorted(set(i for i in queue if f[i][0] >= 0 and q_of(i) < q_bound))
+        if not left:
+            break
+        queue = left
+        guard[0] = 0.5 * float(np.float32(max_distance))
+    used = np.zeros(nv, bool)
+    alive = [t for t in f if t[0] >= 0]
+    for t in alive:
+        used[t] = True
+    renum = np.cumsum(used) - 1
+    fout = np.array([[renum[w] for w in t] for t in alive], np.int32).reshape(-1, 3)
+    report = dict(count)
+    min_q, max_r2, below, above = 0.0, 0.0, 0, 0
+    for t in alive:
+        a, b, c = p[t[0]], p[t[1]], p[t[2]]
+        q = quality(a, b, c)
+        below += q < q_bound
+        min_q = min(min_q, q)
+        n = cross(sub(b, a), sub(c, a))
+        area2 = dot(n, n)
+        l = dot(sub(b, a), sub(b, a)) * dot(sub(c, b), sub(c, b)) * dot(sub(a, c), sub(a, c))
+        r2 = l / (4.0 * area2) if area2 > 0.0 else 1e300
+        above += r2 > float(np.float32(max_radius)) * float(np.float32(max_radius))
+        if r2 < 1e299:
+            max_r2 = max(max_r2, r2)
+    report.update(facets_below_angle=int(below), facets_above_radius=int(above),
+                  min_angle_deg=180.0 if not alive else math.degrees(math.acos(min(1.0, max(-1.0, -min_q)))), max_circumradius=math.sqrt(max_r2))
+    return vin[used], fout, report

@@ -48,10 +48,14 @@ def main():
     chi = mo.poisson_chi(splat, 1.0)
     iso = mo.trilinear(chi, G, origin, h, ppts[:, :3] / ppts[:, 3:4]).mean()
     verts, pfaces = mo.surface_nets(chi.astype(np.float32), np.float32(iso), origin, h)
-    np.savez_compressed(os.path.join(HERE, "meshing_small.npz"), alpha_points=pts, alpha_faces=canonical(faces), alpha=np.float32(alpha), alpha_components=comps,
+    # the facet criteria of cgal_poisson.cpp:50-52 on that mesh (average spacing of the 1500 samples; 20 degrees, 300 and 0.375 spacings)
+    spacing = np.float32(mo.average_spacing(ppts))
+    cverts, cfaces, crep = mo.enforce_facet_criteria(verts, pfaces, 20.0, 300.0 * float(spacing), 0.375 * float(spacing))
+    np.savez_compressed(os.path.join(HERE, "meshing_small.npz"), criteria_spacing=spacing, criteria_vertices=cverts, criteria_faces=cfaces,
+                        criteria_ops=np.array([crep["collapses"], crep["flips"], crep["facets_below_angle"]], np.int32), alpha_points=pts, alpha_faces=canonical(faces), alpha=np.float32(alpha), alpha_components=comps,
                         alpha_cells=sorted_rows(cells), poisson_points=ppts, poisson_normals=pnrm, poisson_G=G, poisson_origin=origin,
                         poisson_h=np.float32(h), poisson_splat=splat, poisson_chi=chi.astype(np.float32), poisson_level=np.float32(iso), poisson_vertices=verts, poisson_faces=pfaces)
-    print("wrote meshing_small.npz: %d alpha faces (alpha %g), %d Poisson vertices, %d faces" % (len(faces), alpha, len(verts), len(pfaces)))
+    print("wrote meshing_small.npz: %d alpha faces (alpha %g), %d Poisson vertices, %d faces; criteria pass: %s" % (len(faces), alpha, len(verts), len(pfaces), crep))
 
 
 if __name__ == "__main__":
