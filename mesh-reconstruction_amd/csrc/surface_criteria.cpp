@@ -54,8 +54,8 @@ struct Work {
     std::vector<V3> p;
     std::vector<int32_t> f;             // 3 per facet; f[3 i] < 0: removed
     std::vector<std::vector<int>> inc;  // facets around a vertex
-    std::vector<int> stamp;
-    int stamp_now = 0;
+    std::vector<long long> stamp;  // (two stamps per collapse candidate: 64 bits, so that no mesh size can wrap them)
+    long long stamp_now = 0;
     double q_bound = 0.0, guard = 0.0;
     int collapses = 0, flips = 0;
 
@@ -111,7 +111,7 @@ struct Work {
         for (int face : inc[v])
             for (int k = 0; k < 3; k++) stamp[f[3 * face + k]] = stamp_now;
         int shared = 0;
-        const int seen = ++stamp_now;  // (v's marks are stamp_now - 1 from here on)
+        const long long seen = ++stamp_now;  // (v's marks are stamp_now - 1 from here on)
         for (int face : inc[u])
             for (int k = 0; k < 3; k++) {
                 const int w = f[3 * face + k];
