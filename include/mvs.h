@@ -320,9 +320,21 @@ int mvs_profile_read(mvs_ctx *ctx, float ms_sum[MVS_K_COUNT], int launches[MVS_K
  *              spacing, the node spacing and whether the ratio could be kept (512 nodes per axis may still be too coarse)
  *   smooth_cells  standard deviation (grid cells) of the Gaussian low-pass applied to chi; 1.0 is a good default
  *   keep_fields  non-zero: keep chi and the splatted integer fields for mvs_surface_grid (tests)
- * The alpha shape of the first iteration (alphaShapeFaces, recon.hpp:33-34) is host-only code: libmvs_host.so, host/alpha_shapes.cpp. */
+ * The alpha shape of the first iteration (alphaShapeFaces, recon.hpp:33-34) is host-only code: libmvs_host.so, host/alpha_shapes.cpp.
+ *   support_spacings (mvs_poisson_surface_ex)  the level set is meshed only in cells within this many average spacings (rounded up to whole
+ *              nodes, Chebyshev distance) of a grid node that collected sample weight; 0 = everywhere.  Away from the samples the solved
+ *              field is flat and hovers around the level: on open or noisy clouds (what recon.cpp:121 collects from the flows) the level
+ *              set there is a closing sheet no sample supports plus numerical fuzz -- 97 % of 16 M vertices on the config-5 cloud of
+ *              tests/test_meshing_gpu.py.  The reference's mesher returns such sheets too (coarse ones: its Delaunay refinement has no
+ *              resolution where there are no points); this grid would return them at full resolution, so it does not return them at
+ *              all.  Closed, evenly sampled surfaces are not affected (every cell of the surface is next to a sample).
+ *              mvs_poisson_surface uses MVS_POISSON_SUPPORT_DEFAULT. */
+#define MVS_POISSON_SUPPORT_DEFAULT 8.0f
 typedef struct mvs_surface mvs_surface;
 int mvs_poisson_surface(const float *points, const float *normals, int n, int grid_log2, float smooth_cells, int keep_fields, mvs_surface **out);
+int mvs_poisson_surface_ex(const float *points, const float *normals, int n, int grid_log2, float smooth_cells, float support_spacings, int keep_fields,
+                           mvs_surface **out);
+int mvs_surface_support(const mvs_surface *s, int *support_nodes /* the radius used, in nodes; 0: no trimming */);
 int mvs_surface_counts(const mvs_surface *s, int *vertices, int *faces);
 int mvs_surface_fetch(const mvs_surface *s, float *vertices /* V x 4, w = 1 */, int32_t *faces /* F x 3, normals along the samples' */);
 int mvs_surface_grid(const mvs_surface *s, int *nodes_per_axis, float origin3[3], float *spacing, float *level, float *chi /* G^3, nullable */,

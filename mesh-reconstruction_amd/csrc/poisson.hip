@@ -18,6 +18,11 @@
 //   2. laplace(chi) = div V is solved in the Fourier domain (hipFFT: three real-to-complex transforms, chi^ = -i k.V^ / |k|^2 with a
 //      Gaussian low-pass of `smooth` cells, one complex-to-real transform); periodic boundaries, kept away by padding the box;
 //   3. the level: the mean of chi (trilinear) over the samples, summed on the host in sample order (deterministic);
+//   4a. only where the samples say something: cells within MVS_POISSON_SUPPORT_DEFAULT (8) average spacings of a node that collected
+//      sample weight (a node mask, dilated by a max filter per axis).  Away from the samples chi is flat and hovers around the level;
+//      on an open or noisy cloud the level set there is a closing sheet no sample supports plus numerical fuzz at full grid
+//      resolution (measured on the config-5 cloud of the test-suite: 16 M vertices, 97 % of them tens of spacings from any sample).
+//      mvs_poisson_surface_ex(support 0) returns the closed surface;
 //   4. the level set is meshed by surface nets (one vertex per grid cell the surface passes through, at the mean of its edge
 //      crossings; one quad = two triangles per grid edge that changes sign), vertices and faces numbered in grid order by
 //      exclusive scans (rocPRIM), faces oriented along +grad chi = the samples' normals (outward, like cgal_poisson.cpp:128-132).
@@ -242,7 +247,30 @@ __global__ void sample_kernel(Grid g, const float *__restrict__ chi, const float
 // cells: (G - 1)^3, cell (i, j, k) spans nodes i .. i + 1; "inside" = chi < iso (chi grows along the normals, which point out)
 __device__ __forceinline__ size_t cell_id(int C, int i, int j, int k) { return ((size_t)k * C + j) * C + i; }
 
-__global__ void cell_flags_kernel(Grid g, const float *__restrict__ chi, float iso, int *__restrict__ flag)
+// ---- support of the samples (step 4a): a cell is meshed only where the samples say something about the surface ----
+// node mask: 1 where a node within `R` nodes (Chebyshev distance, no wrap) collected any sample weight.  Seed, then one max-filter pass
+// per axis (in -> out).  A cell belongs to the support when its low corner node does.
+__global__ void support_seed_kernel(const fix_t *__restrict__ wt, unsigned char *__restrict__ m, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) m[i] = wt[i] > 0 ? 1 : 0;
+}
+
+__global__ void support_dilate_kernel(Grid g, const unsigned char *__restrict__ in, unsigned char *__restrict__ out, int R, int axis)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)g.G * g.G * g.G;
+    if (q >= n) return;
+    const int c[3] = {(int)(q % g.G), (int)((q / g.G) % g.G), (int)(q / ((size_t)g.G * g.G))};
+    const size_t stride = axis == 0 ? 1 : (axis == 1 ? (size_t)g.G : (size_t)g.G * g.G);
+    const int lo = max(0, c[axis] - R), hi = min(g.G - 1, c[axis] + R);
+    const unsigned char *base = in + q - (size_t)c[axis] * stride;
+    unsigned char v = 0;
+    for (int t = lo; t <= hi && !v; t++) v = base[(size_t)t * stride];
+    out[q] = v;
+}
+
+__global__ void cell_flags_kernel(Grid g, const float *__restrict__ chi, float iso, const unsigned char *__restrict__ support, int *__restrict__ flag)
 {
     const int C = g.G - 1;
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,7 +279,7 @@ __global__ void cell_flags_kernel(Grid g, const float *__restrict__ chi, float i
     int inside = 0;
 #pragma unroll
     for (int c = 0; c < 8; c++) inside += chi[node(g, i + (c & 1), j + ((c >> 1) & 1), k + (c >> 2))] < iso ? 1 : 0;
-    flag[q] = (inside != 0 && inside != 8) ? 1 : 0;
+    flag[q] = (inside != 0 && inside != 8 && (!support || support[node(g, i, j, k)])) ? 1 : 0;
 }
 
 __global__ void cell_vertices_kernel(Grid g, const float *__restrict__ chi, float iso, const int *__restrict__ flag, const int *__restrict__ index,
@@ -290,7 +318,7 @@ __global__ void cell_vertices_kernel(Grid g, const float *__restrict__ chi, floa
 
 // grid edges: 3 per node (towards +x, +y, +z); an edge makes a quad when its ends lie on different sides and all four cells around
 // it exist.  flag: 1 = inside -> outside along the axis, 2 = outside -> inside.
-__device__ __forceinline__ int edge_state(const Grid &g, const float *__restrict__ chi, float iso, int i, int j, int k, int axis)
+__device__ __forceinline__ int edge_state(const Grid &g, const float *__restrict__ chi, float iso, const unsigned char *__restrict__ support, int i, int j, int k, int axis)
 {
     const int C = g.G - 1;
     const int i2 = i + (axis == 0), j2 = j + (axis == 1), k2 = k + (axis == 2);
@@ -299,10 +327,22 @@ __device__ __forceinline__ int edge_state(const Grid &g, const float *__restrict
     const int u = axis == 0 ? j : (axis == 1 ? k : i), w = axis == 0 ? k : (axis == 1 ? i : j);
     if (u < 1 || u > C - 1 || w < 1 || w > C - 1) return 0;
     const bool a = chi[node(g, i, j, k)] < iso, b = chi[node(g, i2, j2, k2)] < iso;
-    return a == b ? 0 : (a ? 1 : 2);
+    if (a == b) return 0;
+    if (support) {  // ... and have a vertex: all four inside the samples' support (they are mixed cells: they contain this edge)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int du = (c == 0 || c == 3) ? -1 : 0, dw = c < 2 ? -1 : 0;
+            int ci = i, cj = j, ck = k;
+            if (axis == 0) cj += du, ck += dw;
+            else if (axis == 1) ck += du, ci += dw;
+            else ci += du, cj += dw;
+            if (!support[node(g, ci, cj, ck)]) return 0;
+        }
+    }
+    return a ? 1 : 2;
 }
 
-__global__ void edge_flags_kernel(Grid g, const float *__restrict__ chi, float iso, int *__restrict__ flag)
+__global__ void edge_flags_kernel(Grid g, const float *__restrict__ chi, float iso, const unsigned char *__restrict__ support, int *__restrict__ flag)
 {
     const size_t n = (size_t)g.G * g.G * g.G;
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -310,10 +350,10 @@ __global__ void edge_flags_kernel(Grid g, const float *__restrict__ chi, float i
     const int axis = (int)(q / n);
     const size_t r = q % n;
     const int i = (int)(r % g.G), j = (int)((r / g.G) % g.G), k = (int)(r / ((size_t)g.G * g.G));
-    flag[q] = edge_state(g, chi, iso, i, j, k, axis) ? 1 : 0;
+    flag[q] = edge_state(g, chi, iso, support, i, j, k, axis) ? 1 : 0;
 }
 
-__global__ void edge_faces_kernel(Grid g, const float *__restrict__ chi, float iso, const int *__restrict__ flag, const int *__restrict__ index,
+__global__ void edge_faces_kernel(Grid g, const float *__restrict__ chi, float iso, const unsigned char *__restrict__ support, const int *__restrict__ flag, const int *__restrict__ index,
                                   const int *__restrict__ cell_index, int *__restrict__ faces)
 {
     const size_t n = (size_t)g.G * g.G * g.G;
@@ -322,7 +362,7 @@ __global__ void edge_faces_kernel(Grid g, const float *__restrict__ chi, float i
     const int axis = (int)(q / n);
     const size_t r = q % n;
     const int i = (int)(r % g.G), j = (int)((r / g.G) % g.G), k = (int)(r / ((size_t)g.G * g.G));
-    const int st = edge_state(g, chi, iso, i, j, k, axis);
+    const int st = edge_state(g, chi, iso, support, i, j, k, axis);
     const int C = g.G - 1;
     // the four cells around the edge, counter-clockwise seen from the positive end of the axis: offsets (-1,-1), (0,-1), (0,0), (-1,0)
     // in the two axes (u, w) with axis = u x w: x: (y, z), y: (z, x), z: (x, y)
@@ -404,7 +444,14 @@ extern "C" const char *mvs_surface_last_error(void) { return g_poisson_error.c_s
 
 extern "C" int mvs_poisson_surface(const float *points, const float *normals, int n, int grid_log2, float smooth_cells, int keep_fields, mvs_surface **out)
 {
-    if (!points || !normals || n < 1 || !out || grid_log2 < 0 || grid_log2 > 9 || !(smooth_cells >= 0.0f)) return fail(MVS_EINVAL, "mvs_poisson_surface: bad argument");
+    return mvs_poisson_surface_ex(points, normals, n, grid_log2, smooth_cells, MVS_POISSON_SUPPORT_DEFAULT, keep_fields, out);
+}
+
+extern "C" int mvs_poisson_surface_ex(const float *points, const float *normals, int n, int grid_log2, float smooth_cells, float support_spacings, int keep_fields,
+                                      mvs_surface **out)
+{
+    if (!points || !normals || n < 1 || !out || grid_log2 < 0 || grid_log2 > 9 || !(smooth_cells >= 0.0f) || !(support_spacings >= 0.0f) || support_spacings > 1.0e6f)
+        return fail(MVS_EINVAL, "mvs_poisson_surface: bad argument");
     *out = nullptr;
     int devices = 0;
     if (hipGetDeviceCount(&devices) != hipSuccess || devices < 1) return fail(MVS_EHIP, "mvs_poisson_surface: no HIP device (this library has no CPU path)");
@@ -508,7 +555,7 @@ extern "C" int mvs_poisson_surface(const float *points, const float *normals, in
     res->grid = g;
     res->spacing = (float)spacing;
     res->ratio_kept = ratio_kept;
-    DevBuf d_fix, d_real, d_spec, d_flag, d_index, d_cell_index, d_tmp, d_samples, d_vertices, d_faces;
+    DevBuf d_fix, d_real, d_spec, d_flag, d_index, d_cell_index, d_tmp, d_samples, d_vertices, d_faces, d_mask;
     size_t tmp_bytes = 0;
     int rc = MVS_OK;
     const char *msg = "";
@@ -555,9 +602,23 @@ extern "C" int mvs_poisson_surface(const float *points, const float *normals, in
         for (int s = 0; s < n; s++) sum += (double)samples[s];
         const float iso = (float)(sum / (double)n);
         res->iso = iso;
+        // the samples' support: nodes within support_spacings average spacings of a node that collected weight (0: everywhere)
+        const unsigned char *support = nullptr;
+        if (support_spacings > 0.0f && spacing > 0.0) {
+            const int R = (int)std::min((double)g.G, std::ceil((double)support_spacings * spacing / (double)g.h));
+            res->support_cells = R;
+            PS_TRY(d_mask.alloc(2 * N3), MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
+            unsigned char *m0 = d_mask.as<unsigned char>(), *m1 = m0 + N3;
+            support_seed_kernel<<<(unsigned)((N3 + 255) / 256), 256, 0, st>>>(wt, m0, N3);
+            support_dilate_kernel<<<(unsigned)((N3 + 255) / 256), 256, 0, st>>>(g, m0, m1, R, 0);
+            support_dilate_kernel<<<(unsigned)((N3 + 255) / 256), 256, 0, st>>>(g, m1, m0, R, 1);
+            support_dilate_kernel<<<(unsigned)((N3 + 255) / 256), 256, 0, st>>>(g, m0, m1, R, 2);
+            PS_TRY(hipGetLastError() == hipSuccess, MVS_EHIP, "mvs_poisson_surface: support mask launch failed");
+            support = m1;
+        }
         // vertices
         int *flag = d_flag.as<int>(), *cell_index = d_cell_index.as<int>();
-        cell_flags_kernel<<<(unsigned)((C3 + 255) / 256), 256, 0, st>>>(g, chi, iso, flag);
+        cell_flags_kernel<<<(unsigned)((C3 + 255) / 256), 256, 0, st>>>(g, chi, iso, support, flag);
         PS_TRY(hipMemsetAsync(flag + C3, 0, 4, st) == hipSuccess && scan(flag, cell_index, C3 + 1, st, d_tmp, tmp_bytes), MVS_EHIP, "mvs_poisson_surface: scan failed");
         int nv = 0;
         PS_TRY(hipMemcpyAsync(&nv, cell_index + C3, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: count failed");
@@ -567,7 +628,7 @@ extern "C" int mvs_poisson_surface(const float *points, const float *normals, in
         if (nv > 0) PS_TRY(hipMemcpyAsync(res->vertices.data(), d_vertices.p, (size_t)nv * 16, hipMemcpyDeviceToHost, st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: download failed");
         // faces (the cell flags are overwritten by the edge flags: the vertex kernel above is ordered before on the stream)
         int *index = d_index.as<int>();
-        edge_flags_kernel<<<(unsigned)((3 * N3 + 255) / 256), 256, 0, st>>>(g, chi, iso, flag);
+        edge_flags_kernel<<<(unsigned)((3 * N3 + 255) / 256), 256, 0, st>>>(g, chi, iso, support, flag);
         {
             // flag has 3 N3 entries; the scan needs one more (the total): d_flag was sized 3 N3, so scan into index[0 .. 3 N3] with the
             // total computed from the last offset + last flag
@@ -579,7 +640,7 @@ extern "C" int mvs_poisson_surface(const float *points, const float *normals, in
                MVS_EHIP, "mvs_poisson_surface: count failed");
         const int nq = last_off + last_flag;
         PS_TRY(d_faces.alloc((size_t)nq * 24), MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
-        if (nq > 0) edge_faces_kernel<<<(unsigned)((3 * N3 + 255) / 256), 256, 0, st>>>(g, chi, iso, flag, index, cell_index, d_faces.as<int>());
+        if (nq > 0) edge_faces_kernel<<<(unsigned)((3 * N3 + 255) / 256), 256, 0, st>>>(g, chi, iso, support, flag, index, cell_index, d_faces.as<int>());
         res->faces.resize((size_t)nq * 6);
         if (nq > 0) PS_TRY(hipMemcpyAsync(res->faces.data(), d_faces.p, (size_t)nq * 24, hipMemcpyDeviceToHost, st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: download failed");
         if (keep_fields) {
@@ -626,6 +687,13 @@ extern "C" int mvs_surface_spacing(const mvs_surface *s, float *average_spacing,
     if (average_spacing) *average_spacing = s->spacing;
     if (node_spacing) *node_spacing = s->grid.h;
     if (ratio_kept) *ratio_kept = s->ratio_kept;
+    return MVS_OK;
+}
+
+extern "C" int mvs_surface_support(const mvs_surface *s, int *support_nodes)
+{
+    if (!s) return MVS_EINVAL;
+    if (support_nodes) *support_nodes = s->support_cells;
     return MVS_OK;
 }
 

@@ -99,6 +99,8 @@ ABI = [
     ("mvs_profile_read", _i, [_vp, _fp, C.POINTER(_i), _i]),
     ("mvs_device_info", C.c_char_p, [_vp]),
     ("mvs_poisson_surface", _i, [_vp, _vp, _i, _i, _f, _i, _vp]),
+    ("mvs_poisson_surface_ex", _i, [_vp, _vp, _i, _i, _f, _f, _i, _vp]),
+    ("mvs_surface_support", _i, [_vp, _vp]),
     ("mvs_surface_counts", _i, [_vp, _vp, _vp]),
     ("mvs_surface_fetch", _i, [_vp, _vp, _vp]),
     ("mvs_surface_grid", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -179,18 +181,23 @@ class CriteriaReport(C.Structure):
 REFERENCE_FACET_CRITERIA = (20.0, 300.0, 0.375)
 
 
-def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0, criteria=REFERENCE_FACET_CRITERIA, report=None):
+POISSON_SUPPORT_DEFAULT = 8.0   # MVS_POISSON_SUPPORT_DEFAULT (include/mvs.h)
+
+
+def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0, criteria=REFERENCE_FACET_CRITERIA, report=None, support_spacings=POISSON_SUPPORT_DEFAULT):
     """poissonSurface (recon.hpp:37) through mvs_poisson_surface + mvs_surface_enforce_criteria: points N x 4 homogeneous, normals N x 3
     (out of the solid) -> (vertices V x 4 float32 with w = 1, faces F x 3 int32).  criteria = (min angle in degrees, max facet radius and
     max facet distance in units of the samples' average spacing), the reference's by default; None: the surface-nets mesh as it is.
-    report: a dict that receives the fields of mvs_criteria_report and the average spacing"""
+    support_spacings: the level set is meshed only within that many average spacings of the samples (0: everywhere; include/mvs.h).
+    report: a dict that receives the fields of mvs_criteria_report, the average spacing and the support radius in nodes"""
     lib = load_library()
     pts = np.ascontiguousarray(points, np.float32)
     nrm = np.ascontiguousarray(normals, np.float32)
     if pts.ndim != 2 or pts.shape[1] != 4 or nrm.shape != (len(pts), 3):
         raise ValueError("points must be N x 4 and normals N x 3")
     s = C.c_void_p()
-    if lib.mvs_poisson_surface(pts.ctypes.data_as(_vp), nrm.ctypes.data_as(_vp), len(pts), int(grid_log2), float(smooth_cells), 0, C.byref(s)) != 0:
+    if lib.mvs_poisson_surface_ex(pts.ctypes.data_as(_vp), nrm.ctypes.data_as(_vp), len(pts), int(grid_log2), float(smooth_cells), float(support_spacings), 0,
+                                  C.byref(s)) != 0:
         raise MvsError(lib.mvs_surface_last_error().decode())
     try:
         spacing = C.c_float()
@@ -203,7 +210,10 @@ def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0, criteria=REF
             if report is not None:
                 report.update({name: getattr(rep, name) for name, _ in CriteriaReport._fields_})
         if report is not None:
+            nodes = C.c_int()
+            lib.mvs_surface_support(s, C.byref(nodes))
             report["average_spacing"] = spacing.value
+            report["support_nodes"] = nodes.value
         nv, nf = C.c_int(), C.c_int()
         lib.mvs_surface_counts(s, C.byref(nv), C.byref(nf))
         v = np.zeros((nv.value, 4), np.float32)

@@ -193,8 +193,17 @@ def trilinear(field, G, origin, h, xyz):
     return acc
 
 
-def surface_nets(chi, iso, origin, h):
-    """csrc/poisson.hip's meshing rules on a given field: (vertices V x 4 float32, faces F x 3 int32), numbered in its order"""
+def poisson_support(splat, nodes):
+    """the samples' support (csrc/poisson.hip step 4a): [z][y][x] bool, nodes within `nodes` nodes (Chebyshev, no wrap) of a node that collected
+    sample weight; nodes = ceil(support_spacings x average spacing / h), at most G"""
+    import scipy.ndimage as ndi
+    seed = (np.asarray(splat[3]) > 0).astype(np.uint8)
+    return ndi.maximum_filter(seed, size=2 * int(nodes) + 1, mode="constant", cval=0).astype(bool)
+
+
+def surface_nets(chi, iso, origin, h, support=None):
+    """csrc/poisson.hip's meshing rules on a given field: (vertices V x 4 float32, faces F x 3 int32), numbered in its order.
+    support: poisson_support's node mask (a cell is meshed when its low corner node is inside), None: everywhere"""
     chi = np.asarray(chi, np.float32)
     iso = np.float32(iso)
     G = chi.shape[0]
@@ -205,6 +214,8 @@ def surface_nets(chi, iso, origin, h):
     for (dx, dy, dz) in corners:
         cnt += inside[dz:dz + C, dy:dy + C, dx:dx + C]
     mixed = (cnt != 0) & (cnt != 8)
+    if support is not None:
+        mixed &= np.asarray(support, bool)[:C, :C, :C]
     index = np.full((C, C, C), -1, np.int64)
     index[mixed] = np.arange(int(mixed.sum()))                       # C order = k, j, i with i fastest: the kernel's cell order
     kk, jj, ii = np.nonzero(mixed)
@@ -220,7 +231,8 @@ def surface_nets(chi, iso, origin, h):
             t = (va / (va - vb)).astype(np.float32)
         for axis in range(3):
             ca, cb = np.float32(corners[a][axis]), np.float32(corners[b][axis])
-            s[axis] = np.where(cross, (s[axis] + (ca + t * (cb - ca)).astype(np.float32)).astype(np.float32), s[axis])
+            with np.errstate(invalid="ignore"):                      # (t is inf or NaN on edges that do not cross: not selected)
+                s[axis] = np.where(cross, (s[axis] + (ca + t * (cb - ca)).astype(np.float32)).astype(np.float32), s[axis])
         m += cross
     inv = (np.float32(1.0) / m.astype(np.float32)).astype(np.float32)
     verts = np.ones((len(kk), 4), np.float32)
@@ -250,6 +262,9 @@ def surface_nets(chi, iso, origin, h):
             else:
                 ci += du[c]; cj += dw[c]
             quad[:, c] = index[ck, cj, ci]
+        if support is not None:                                      # all four cells around the edge have a vertex
+            have = (quad >= 0).all(1)
+            quad, st = quad[have], st[have]
         flip = st == 2
         q1 = np.where(flip, quad[:, 3], quad[:, 1])
         q3 = np.where(flip, quad[:, 1], quad[:, 3])

@@ -63,13 +63,18 @@ def edge_use(faces):
     return c
 
 
-def poisson(hip, pts, nrm, grid_log2=0, smooth=1.0, keep=True):
+def poisson(hip, pts, nrm, grid_log2=0, smooth=1.0, keep=True, support=None):
+    """support: None = mvs_poisson_surface (the default support radius), a number = mvs_poisson_surface_ex with that many spacings (0: no trimming)"""
     pts = np.ascontiguousarray(pts, np.float32)
     nrm = np.ascontiguousarray(nrm, np.float32)
     s = ctypes.c_void_p()
     hip.mvs_surface_last_error.restype = ctypes.c_char_p
-    rc = hip.mvs_poisson_surface(pts.ctypes.data_as(ctypes.c_void_p), nrm.ctypes.data_as(ctypes.c_void_p), len(pts), grid_log2, ctypes.c_float(smooth), int(keep),
-                                 ctypes.byref(s))
+    if support is None:
+        rc = hip.mvs_poisson_surface(pts.ctypes.data_as(ctypes.c_void_p), nrm.ctypes.data_as(ctypes.c_void_p), len(pts), grid_log2, ctypes.c_float(smooth), int(keep),
+                                     ctypes.byref(s))
+    else:
+        rc = hip.mvs_poisson_surface_ex(pts.ctypes.data_as(ctypes.c_void_p), nrm.ctypes.data_as(ctypes.c_void_p), len(pts), grid_log2, ctypes.c_float(smooth),
+                                        ctypes.c_float(support), int(keep), ctypes.byref(s))
     if rc != 0:
         raise RuntimeError(hip.mvs_surface_last_error().decode())
     nv, nf, G = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -82,7 +87,10 @@ def poisson(hip, pts, nrm, grid_log2=0, smooth=1.0, keep=True):
     hip.mvs_surface_grid(s, ctypes.byref(G), origin.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h), ctypes.byref(iso), None, None)
     avg, node, kept = ctypes.c_float(), ctypes.c_float(), ctypes.c_int()
     assert hip.mvs_surface_spacing(s, ctypes.byref(avg), ctypes.byref(node), ctypes.byref(kept)) == 0 and node.value == h.value
-    out = {"vertices": v, "faces": f, "G": G.value, "origin": origin, "h": h.value, "iso": iso.value, "spacing": avg.value, "ratio_kept": kept.value}
+    nodes = ctypes.c_int()
+    assert hip.mvs_surface_support(s, ctypes.byref(nodes)) == 0
+    out = {"vertices": v, "faces": f, "G": G.value, "origin": origin, "h": h.value, "iso": iso.value, "spacing": avg.value, "ratio_kept": kept.value,
+           "support_nodes": nodes.value}
     if keep:
         chi = np.zeros((G.value,) * 3, np.float32)
         splat = np.zeros((4,) + (G.value,) * 3, np.int64)

@@ -54,9 +54,12 @@ def test_every_stage_against_the_oracle(hip, lg, n):
     assert np.abs(chi - r["chi"]).max() <= 1e-5 * (chi.max() - chi.min())
     xyz = pts[:, :3] / pts[:, 3:4]
     assert abs(mo.trilinear(chi, G, origin, h, xyz).mean() - r["iso"]) <= 1e-5 * (chi.max() - chi.min())
-    v, f = mo.surface_nets(r["chi"], r["iso"], origin, h)
+    assert r["support_nodes"] == min(G, int(np.ceil(8.0 * r["spacing"] / r["h"])))          # MVS_POISSON_SUPPORT_DEFAULT spacings, in nodes
+    v, f = mo.surface_nets(r["chi"], r["iso"], origin, h, mo.poisson_support(splat, r["support_nodes"]))
     assert np.array_equal(f, r["faces"]) and len(v) == len(r["vertices"])
     assert np.abs(v - r["vertices"]).max() <= 2e-6 * float(np.abs(origin).max() + G * h)
+    v0, f0 = mo.surface_nets(r["chi"], r["iso"], origin, h)                                 # a closed, evenly sampled surface: nothing is trimmed
+    assert np.array_equal(f0, f) and np.array_equal(v0, v)
     # meshed from the oracle's own field the surface is the same up to the cells the float32 field decides differently
     v2, f2 = mo.surface_nets(chi.astype(np.float32), np.float32(mo.trilinear(chi, G, origin, h, xyz).mean()), origin, h)
     assert abs(len(v2) - len(v)) <= 0.002 * len(v) + 2
@@ -106,6 +109,45 @@ def test_grid_from_the_average_spacing_keeps_the_references_approximation_bound(
     # a forced coarse grid reports that the ratio is not kept (and the default caps at 512 nodes per axis)
     pts, nrm = _sphere(rng, 30000, (0, 0, 0), 1.0)
     assert mc.poisson(hip, pts, nrm, 5, 1.0, keep=False)["ratio_kept"] == 0
+
+
+def test_an_open_patch_is_meshed_where_the_samples_are_and_nowhere_else(hip):
+    """Samples of a spherical cap only (what one side of a scene looks like to recon.cpp:114-121): the solved field is flat away from the
+    samples and its level set there is a closing sheet plus fuzz.  mvs_poisson_surface meshes the cells within MVS_POISSON_SUPPORT_DEFAULT
+    average spacings of a node that collected sample weight -- equal, face for face, to the oracle's surface nets under the oracle's mask --
+    and mvs_poisson_surface_ex(support 0) still returns the closed surface."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(77)
+    pts, nrm = _sphere(rng, 30000, (0.0, 0.0, 0.0), 1.0)
+    keep = pts[:, 2] / pts[:, 3] > 0.2
+    pts, nrm = pts[keep], nrm[keep]
+    closed = mc.poisson(hip, pts, nrm, 7, 1.0, support=0.0)
+    r = mc.poisson(hip, pts, nrm, 7, 1.0)
+    assert closed["support_nodes"] == 0 and r["support_nodes"] == int(np.ceil(8.0 * r["spacing"] / r["h"])) > 0
+    assert np.array_equal(closed["chi"], r["chi"]) and closed["iso"] == r["iso"]                # the same field, the same level
+    G, origin, h = mo.poisson_grid(pts, 7)
+    mask = mo.poisson_support(r["splat"], r["support_nodes"])
+    v, f = mo.surface_nets(r["chi"], r["iso"], origin, h, mask)
+    assert np.array_equal(f, r["faces"]) and len(v) == len(r["vertices"]) and np.abs(v - r["vertices"]).max() <= 2e-6 * float(np.abs(origin).max() + G * h)
+    v0, f0 = mo.surface_nets(closed["chi"], closed["iso"], origin, h)
+    assert np.array_equal(f0, closed["faces"])
+    # the closed surface has a sheet far from every sample; the trimmed one does not, and it loses nothing near the samples
+    tree = cKDTree(pts[:, :3] / pts[:, 3:4])
+    reach = (r["support_nodes"] + 2) * np.sqrt(3.0) * r["h"]
+    d_closed = tree.query(closed["vertices"][:, :3])[0]
+    d_trim = tree.query(r["vertices"][:, :3])[0]
+    assert d_trim.max() <= reach < d_closed.max() and (d_closed > reach).sum() > 0.05 * len(d_closed)
+    near = set(map(bytes, closed["vertices"][d_closed <= 4.0 * r["spacing"]]))
+    assert near <= set(map(bytes, r["vertices"]))
+    use = mc.edge_use(closed["faces"])
+    assert all(use[(b, a)] == c for (a, b), c in use.items())
+    use = mc.edge_use(r["faces"])
+    assert any(use[(b, a)] != c for (a, b), c in use.items())                                # open: it has a border
+    # the facet criteria pass leaves border edges alone and still reaches the angle bound on what it may touch
+    import mvs_amd
+    from test_criteria_cpu import facet_angles
+    v2, f2, rep = mvs_amd.enforce_facet_criteria(r["vertices"], r["faces"], r["spacing"])
+    assert rep["facets_below_angle"] <= 0.002 * len(f2) and (facet_angles(v2, f2).min(1) < 20.0).sum() == rep["facets_below_angle"]
 
 
 def test_the_default_path_keeps_all_three_facet_criteria_of_the_reference(hip):
