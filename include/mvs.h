@@ -312,7 +312,10 @@ int mvs_profile_read(mvs_ctx *ctx, float ms_sum[MVS_K_COUNT], int launches[MVS_K
  * laplace(chi) = div V solved with hipFFT, level set through the samples meshed by surface nets.  Context-free (device 0 of the
  * calling thread's HIP runtime state); no CPU path.
  *   points     n rows x, y, z, w (homogeneous, as recon.cpp:121 hands them over);  normals  n rows nx, ny, nz (pointing out of the solid;
- *              a component that is NaN or beyond 1e4 in magnitude makes the sample vote for nothing)
+ *              a component that is NaN or beyond 1e4 in magnitude makes the sample vote for nothing).  Their lengths act as confidences,
+ *              as given; poissonSurface (host/poisson.cpp) and mvs_amd.poisson_surface normalise them first, like the reference's PCL
+ *              backend without USE_PRECISION (pcl.cpp:198-202) -- see there for what the pdf lengths of triangulatePixels do otherwise.
+ *              The level is the median of chi over the samples (CGAL's Poisson_reconstruction_function: median value at the input points)
  *   grid_log2  log2 of the nodes per axis, 4..9; 0 = from the samples' average 6-nearest-neighbour spacing, the reference's own
  *              yardstick (CGAL::compute_average_spacing(points, 6), cgal_poisson.cpp:77): the coarsest of 32..512 nodes per axis whose
  *              node spacing is at most 0.75 x that spacing, which keeps the surface within the reference's approximation bound of
@@ -335,6 +338,10 @@ int mvs_poisson_surface(const float *points, const float *normals, int n, int gr
 int mvs_poisson_surface_ex(const float *points, const float *normals, int n, int grid_log2, float smooth_cells, float support_spacings, int keep_fields,
                            mvs_surface **out);
 int mvs_surface_support(const mvs_surface *s, int *support_nodes /* the radius used, in nodes; 0: no trimming */);
+/* The normals' lengths are confidences (triangulatePixels scales them by a pdf, util.cpp:322-327: 1e-6 .. 1e-4 on real frames) and only
+ * their ratios matter; before the fixed-point splat they are multiplied by the power of two that brings their median size into [0.5, 1)
+ * (exact; 2^0 for unit normals).  chi and the level of mvs_surface_grid carry that factor. */
+int mvs_surface_normal_scale(const mvs_surface *s, int *scale_log2);
 int mvs_surface_counts(const mvs_surface *s, int *vertices, int *faces);
 int mvs_surface_fetch(const mvs_surface *s, float *vertices /* V x 4, w = 1 */, int32_t *faces /* F x 3, normals along the samples' */);
 int mvs_surface_grid(const mvs_surface *s, int *nodes_per_axis, float origin3[3], float *spacing, float *level, float *chi /* G^3, nullable */,

@@ -17,7 +17,8 @@
 //      overflow however many samples an outlier-stretched box packs into one cell (2^47 unit weights);
 //   2. laplace(chi) = div V is solved in the Fourier domain (hipFFT: three real-to-complex transforms, chi^ = -i k.V^ / |k|^2 with a
 //      Gaussian low-pass of `smooth` cells, one complex-to-real transform); periodic boundaries, kept away by padding the box;
-//   3. the level: the mean of chi (trilinear) over the samples, summed on the host in sample order (deterministic);
+//   3. the level: the (lower) median of chi (trilinear) over the samples, as CGAL shifts its implicit function to the median value at the input
+//      points (Poisson_reconstruction_function::compute_implicit_function, called at cgal_poisson.cpp:72);
 //   4a. only where the samples say something: cells within MVS_POISSON_SUPPORT_DEFAULT (8) average spacings of a node that collected
 //      sample weight (a node mask, dilated by a max filter per axis).  Away from the samples chi is flat and hovers around the level;
 //      on an open or noisy cloud the level set there is a closing sheet no sample supports plus numerical fuzz at full grid
@@ -60,9 +61,9 @@ typedef SurfaceGrid Grid;  // csrc/surface_internal.hpp
 
 __device__ __forceinline__ size_t node(const Grid &g, int i, int j, int k) { return ((size_t)k * g.G + j) * g.G + i; }
 
-// samples: xyzw rows (w divides) + normal rows
-__global__ void splat_kernel(Grid g, const float *__restrict__ pts, const float *__restrict__ nrm, int n, fix_t *__restrict__ vx, fix_t *__restrict__ vy,
-                             fix_t *__restrict__ vz, fix_t *__restrict__ wt)
+// samples: xyzw rows (w divides) + normal rows; nscale: the power of two that brings the normals' median length near 1 (exact)
+__global__ void splat_kernel(Grid g, const float *__restrict__ pts, const float *__restrict__ nrm, int n, float nscale, fix_t *__restrict__ vx,
+                             fix_t *__restrict__ vy, fix_t *__restrict__ vz, fix_t *__restrict__ wt)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
@@ -72,8 +73,9 @@ __global__ void splat_kernel(Grid g, const float *__restrict__ pts, const float 
     const int i = (int)fx, j = (int)fy, k = (int)fz;
     if (i < 0 || j < 0 || k < 0 || i + 1 >= g.G || j + 1 >= g.G || k + 1 >= g.G) return;  // (the box is padded: cannot happen for the box's own samples)
     const float tx = gx - fx, ty = gy - fy, tz = gz - fz;
-    const float nx = nrm[3 * s], ny = nrm[3 * s + 1], nz = nrm[3 * s + 2];
+    float nx = nrm[3 * s], ny = nrm[3 * s + 1], nz = nrm[3 * s + 2];
     if (!(fabsf(nx) <= NORMAL_LIMIT && fabsf(ny) <= NORMAL_LIMIT && fabsf(nz) <= NORMAL_LIMIT)) return;  // a sample without a usable normal (NaN: util.cpp:299's PCA can fail) votes for nothing
+    nx *= nscale, ny *= nscale, nz *= nscale;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const int di = c & 1, dj = (c >> 1) & 1, dk = c >> 2;
@@ -531,6 +533,32 @@ extern "C" int mvs_poisson_surface_ex(const float *points, const float *normals,
         for (int s = 0; s < n; s++) spacing += (double)host[s];
         spacing /= (double)n;
     }
+    // ---- the normals' scale.  Their LENGTHS are confidences (triangulatePixels multiplies by a pdf, util.cpp:322-327: lengths of 1e-6 .. 1e-4
+    // on real frames) and only their ratios matter to the level set; the splat is fixed point (2^-16), so the normals are first multiplied
+    // by the power of two that brings the median of max(|nx|, |ny|, |nz|) over the usable, non-zero normals into [0.5, 1) -- exact, and
+    // 1 for unit normals -- kept low enough that the largest usable component stays within NORMAL_LIMIT.
+    int nscale_log2 = 0;
+    try {
+        std::vector<float> big;
+        big.reserve((size_t)n);
+        float largest = 0.0f;
+        for (int s = 0; s < n; s++) {
+            const float a = std::fabs(normals[3 * s]), b = std::fabs(normals[3 * s + 1]), c = std::fabs(normals[3 * s + 2]);
+            if (!(a <= NORMAL_LIMIT && b <= NORMAL_LIMIT && c <= NORMAL_LIMIT)) continue;
+            const float m = std::max(a, std::max(b, c));
+            if (m > 0.0f) big.push_back(m), largest = std::max(largest, m);
+        }
+        if (!big.empty()) {
+            const size_t mid = (big.size() - 1) / 2;  // the lower median
+            std::nth_element(big.begin(), big.begin() + (std::ptrdiff_t)mid, big.end());
+            int e = 0;
+            (void)std::frexp(big[mid], &e);  // median = m 2^e, m in [0.5, 1)
+            nscale_log2 = std::max(-100, std::min(100, -e));
+            while (nscale_log2 > -100 && std::ldexp((double)largest, nscale_log2) > (double)NORMAL_LIMIT) nscale_log2--;
+        }
+    } catch (...) {
+        return fail(MVS_ENOMEM, "mvs_poisson_surface: host allocation failed");
+    }
     int lg = grid_log2, ratio_kept = 1;
     if (lg == 0) {  // the coarsest grid whose nodes are at most 0.75 average spacings apart (header: step 0); 512^3 at the most
         lg = 5;
@@ -553,6 +581,7 @@ extern "C" int mvs_poisson_surface_ex(const float *points, const float *normals,
     mvs_surface *res = new (std::nothrow) mvs_surface;
     if (!res) return fail(MVS_ENOMEM, "mvs_poisson_surface: host allocation failed");
     res->grid = g;
+    res->normal_scale_log2 = nscale_log2;
     res->spacing = (float)spacing;
     res->ratio_kept = ratio_kept;
     DevBuf d_fix, d_real, d_spec, d_flag, d_index, d_cell_index, d_tmp, d_samples, d_vertices, d_faces, d_mask;
@@ -566,7 +595,7 @@ extern "C" int mvs_poisson_surface_ex(const float *points, const float *normals,
                MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
         PS_TRY(hipMemsetAsync(d_fix.p, 0, 4 * N3 * sizeof(fix_t), st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: clearing the grid failed");
         fix_t *vx = d_fix.as<fix_t>(), *vy = vx + N3, *vz = vy + N3, *wt = vz + N3;
-        splat_kernel<<<(n + 255) / 256, 256, 0, st>>>(g, d_pts.as<float>(), d_nrm.as<float>(), n, vx, vy, vz, wt);
+        splat_kernel<<<(n + 255) / 256, 256, 0, st>>>(g, d_pts.as<float>(), d_nrm.as<float>(), n, std::ldexp(1.0f, nscale_log2), vx, vy, vz, wt);
         fixed_to_float_kernel<<<(unsigned)((3 * N3 + 255) / 256), 256, 0, st>>>(vx, d_real.as<float>(), 3 * N3);
         PS_TRY(hipGetLastError() == hipSuccess, MVS_EHIP, "mvs_poisson_surface: splat launch failed");
         hipfftComplex *spec = d_spec.as<hipfftComplex>();
@@ -598,9 +627,10 @@ extern "C" int mvs_poisson_surface_ex(const float *points, const float *normals,
         std::vector<float> samples((size_t)n);
         PS_TRY(hipMemcpyAsync(samples.data(), d_samples.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess, MVS_EHIP,
                "mvs_poisson_surface: sampling failed");
-        double sum = 0.0;
-        for (int s = 0; s < n; s++) sum += (double)samples[s];
-        const float iso = (float)(sum / (double)n);
+        // the level: the MEDIAN of chi over the samples, as CGAL's Poisson_reconstruction_function shifts its function ("f() = 0 on the input
+        // points": median_value_at_input_vertices) -- the lower median; with confidences that span two decades the mean follows the few strong samples
+        std::nth_element(samples.begin(), samples.begin() + (std::ptrdiff_t)((n - 1) / 2), samples.end());
+        const float iso = samples[(size_t)((n - 1) / 2)];
         res->iso = iso;
         // the samples' support: nodes within support_spacings average spacings of a node that collected weight (0: everywhere)
         const unsigned char *support = nullptr;
@@ -694,6 +724,13 @@ extern "C" int mvs_surface_support(const mvs_surface *s, int *support_nodes)
 {
     if (!s) return MVS_EINVAL;
     if (support_nodes) *support_nodes = s->support_cells;
+    return MVS_OK;
+}
+
+extern "C" int mvs_surface_normal_scale(const mvs_surface *s, int *scale_log2)
+{
+    if (!s) return MVS_EINVAL;
+    if (scale_log2) *scale_log2 = s->normal_scale_log2;
     return MVS_OK;
 }
 

@@ -15,6 +15,7 @@ struct mvs_surface {
     float iso = 0.0f;
     float spacing = 0.0f;     // CGAL::compute_average_spacing(points, 6) of the samples
     int ratio_kept = 1;       // node spacing <= 0.75 x average spacing (0: the finest grid, 512^3, is coarser than that)
+    int normal_scale_log2 = 0;  // the normals were multiplied by 2^this before the fixed-point splat (chi and the level scale with it)
     int support_cells = 0;    // cells are meshed within this many nodes of a node that collected sample weight (0: everywhere)
     std::vector<float> vertices;   // 4 per vertex
     std::vector<int32_t> faces;    // 3 per face

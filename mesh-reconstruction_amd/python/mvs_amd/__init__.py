@@ -101,6 +101,7 @@ ABI = [
     ("mvs_poisson_surface", _i, [_vp, _vp, _i, _i, _f, _i, _vp]),
     ("mvs_poisson_surface_ex", _i, [_vp, _vp, _i, _i, _f, _f, _i, _vp]),
     ("mvs_surface_support", _i, [_vp, _vp]),
+    ("mvs_surface_normal_scale", _i, [_vp, _vp]),
     ("mvs_surface_counts", _i, [_vp, _vp, _vp]),
     ("mvs_surface_fetch", _i, [_vp, _vp, _vp]),
     ("mvs_surface_grid", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -184,17 +185,25 @@ REFERENCE_FACET_CRITERIA = (20.0, 300.0, 0.375)
 POISSON_SUPPORT_DEFAULT = 8.0   # MVS_POISSON_SUPPORT_DEFAULT (include/mvs.h)
 
 
-def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0, criteria=REFERENCE_FACET_CRITERIA, report=None, support_spacings=POISSON_SUPPORT_DEFAULT):
+def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0, criteria=REFERENCE_FACET_CRITERIA, report=None, support_spacings=POISSON_SUPPORT_DEFAULT,
+                    use_precision=False):
     """poissonSurface (recon.hpp:37) through mvs_poisson_surface + mvs_surface_enforce_criteria: points N x 4 homogeneous, normals N x 3
     (out of the solid) -> (vertices V x 4 float32 with w = 1, faces F x 3 int32).  criteria = (min angle in degrees, max facet radius and
     max facet distance in units of the samples' average spacing), the reference's by default; None: the surface-nets mesh as it is.
     support_spacings: the level set is meshed only within that many average spacings of the samples (0: everywhere; include/mvs.h).
+    use_precision: keep the normals' lengths as confidences (pcl.cpp:198-202's USE_PRECISION); by default they are normalised to unit length
+    first, like the reference's PCL backend does (host/poisson.cpp says why).
     report: a dict that receives the fields of mvs_criteria_report, the average spacing and the support radius in nodes"""
     lib = load_library()
     pts = np.ascontiguousarray(points, np.float32)
     nrm = np.ascontiguousarray(normals, np.float32)
     if pts.ndim != 2 or pts.shape[1] != 4 or nrm.shape != (len(pts), 3):
         raise ValueError("points must be N x 4 and normals N x 3")
+    if not use_precision:
+        with np.errstate(invalid="ignore", over="ignore"):
+            length = np.sqrt((nrm.astype(np.float64) ** 2).sum(1))
+            ok = (length > 0.0) & (length < 1e30)
+        nrm = np.where(ok[:, None], nrm.astype(np.float64) / np.where(ok, length, 1.0)[:, None], nrm).astype(np.float32)
     s = C.c_void_p()
     if lib.mvs_poisson_surface_ex(pts.ctypes.data_as(_vp), nrm.ctypes.data_as(_vp), len(pts), int(grid_log2), float(smooth_cells), float(support_spacings), 0,
                                   C.byref(s)) != 0:

@@ -135,15 +135,34 @@ def poisson_grid(points, grid_log2):
     return G, origin, h
 
 
+def normal_scale_log2(normals):
+    """csrc/poisson.hip: the power of two the normals are multiplied by before the fixed-point splat -- the lower median of
+    max(|nx|, |ny|, |nz|) over the usable (finite, every component <= 1e4), non-zero normals lands in [0.5, 1); lowered until the largest
+    usable component times it stays within 1e4; 0 when there is no such normal"""
+    import math
+    a = np.abs(np.asarray(normals, np.float32))
+    with np.errstate(invalid="ignore"):
+        ok = np.all(a <= np.float32(1e4), axis=1)
+    m = a[ok].max(1) if ok.any() else np.zeros(0, np.float32)
+    m = np.sort(m[m > 0])
+    if len(m) == 0:
+        return 0
+    k = max(-100, min(100, -math.frexp(float(m[(len(m) - 1) // 2]))[1]))
+    while k > -100 and math.ldexp(float(m[-1]), k) > 1e4:
+        k -= 1
+    return k
+
+
 def poisson_splat(points, normals, G, origin, h):
     """the four fixed-point fields [vx, vy, vz, weight][z][y][x], int64: the same integers as splat_kernel (float32 arithmetic in its order)"""
     p = np.asarray(points, np.float32)
     nrm = np.asarray(normals, np.float32)
+    scale = np.float32(2.0) ** np.float32(normal_scale_log2(nrm))
     g = ((p[:, :3] / p[:, 3:4]) - origin[None, :]) / h                     # float32 throughout
     f = np.floor(g)
     ijk = f.astype(np.int64)
     ok = np.all((ijk >= 0) & (ijk + 1 < G), axis=1) & np.all(np.abs(nrm) <= np.float32(1e4), axis=1)   # (NaN normals fail the comparison too)
-    nrm = np.where(ok[:, None], nrm, np.float32(0.0))        # masked BEFORE the integer cast: NaN -> int64 is undefined (and warns)
+    nrm = (np.where(ok[:, None], nrm, np.float32(0.0)) * scale).astype(np.float32)   # masked BEFORE the integer cast: NaN -> int64 is undefined (and warns); the scale is exact
     t = (g - f).astype(np.float32)
     out = np.zeros((4, G, G, G), np.int64)
     one = np.float32(1.0)
@@ -191,6 +210,13 @@ def trilinear(field, G, origin, h, xyz):
         q = ijk + d[None, :]
         acc += w * field[q[:, 2], q[:, 1], q[:, 0]]
     return acc
+
+
+def poisson_level(chi, G, origin, h, xyz):
+    """the level the surface is extracted at: the lower median of chi (trilinear) over the samples -- CGAL's Poisson_reconstruction_function
+    shifts its function to the median value at the input points (compute_implicit_function, cgal_poisson.cpp:72)"""
+    vals = np.sort(trilinear(chi, G, origin, h, xyz))
+    return vals[(len(vals) - 1) // 2]
 
 
 def poisson_support(splat, nodes):

@@ -46,7 +46,7 @@ def main():
     G, origin, h = mo.poisson_grid(ppts, 5)
     splat = mo.poisson_splat(ppts, pnrm, G, origin, h)
     chi = mo.poisson_chi(splat, 1.0)
-    iso = mo.trilinear(chi, G, origin, h, ppts[:, :3] / ppts[:, 3:4]).mean()
+    iso = mo.poisson_level(chi, G, origin, h, ppts[:, :3] / ppts[:, 3:4])
     verts, pfaces = mo.surface_nets(chi.astype(np.float32), np.float32(iso), origin, h)
     # the facet criteria of cgal_poisson.cpp:50-52 on that mesh (average spacing of the 1500 samples; 20 degrees, 300 and 0.375 spacings)
     spacing = np.float32(mo.average_spacing(ppts))

@@ -89,8 +89,10 @@ def poisson(hip, pts, nrm, grid_log2=0, smooth=1.0, keep=True, support=None):
     assert hip.mvs_surface_spacing(s, ctypes.byref(avg), ctypes.byref(node), ctypes.byref(kept)) == 0 and node.value == h.value
     nodes = ctypes.c_int()
     assert hip.mvs_surface_support(s, ctypes.byref(nodes)) == 0
+    nscale = ctypes.c_int()
+    assert hip.mvs_surface_normal_scale(s, ctypes.byref(nscale)) == 0
     out = {"vertices": v, "faces": f, "G": G.value, "origin": origin, "h": h.value, "iso": iso.value, "spacing": avg.value, "ratio_kept": kept.value,
-           "support_nodes": nodes.value}
+           "support_nodes": nodes.value, "normal_scale_log2": nscale.value}
     if keep:
         chi = np.zeros((G.value,) * 3, np.float32)
         splat = np.zeros((4,) + (G.value,) * 3, np.int64)

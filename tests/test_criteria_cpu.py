@@ -46,7 +46,7 @@ def closed_oriented_manifold(f):
 def oracle_surface(pts, nrm):
     G, origin, h = mo.poisson_grid(pts, 0)
     chi = mo.poisson_chi(mo.poisson_splat(pts, nrm, G, origin, h), 1.0)
-    iso = mo.trilinear(chi, G, origin, h, pts[:, :3] / pts[:, 3:4]).mean()
+    iso = mo.poisson_level(chi, G, origin, h, pts[:, :3] / pts[:, 3:4])
     v, f = mo.surface_nets(chi, iso, origin, h)
     return v, f, mo.average_spacing(pts)
 
@@ -78,7 +78,7 @@ def test_the_three_criteria_hold_on_surface_nets_and_the_surface_stays_what_it_w
     pts, nrm = make(np.random.default_rng(11))
     v, f, sp = oracle_surface(pts, nrm)
     before = facet_angles(v, f).min(1)
-    assert (before < 20.0).mean() > 0.005 and before.min() < 5.0          # surface nets do make needles and caps: the pass has work to do
+    assert (before < 20.0).mean() > 0.005 and before.min() < 12.0         # surface nets do make needles and caps: the pass has work to do
     assert closed_oriented_manifold(f)
     v2, f2, rep = mvs_amd.enforce_facet_criteria(v, f, sp)
     # (1) the angle bound, recomputed here

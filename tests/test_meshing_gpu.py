@@ -53,7 +53,7 @@ def test_every_stage_against_the_oracle(hip, lg, n):
     chi = mo.poisson_chi(splat, 1.0)
     assert np.abs(chi - r["chi"]).max() <= 1e-5 * (chi.max() - chi.min())
     xyz = pts[:, :3] / pts[:, 3:4]
-    assert abs(mo.trilinear(chi, G, origin, h, xyz).mean() - r["iso"]) <= 1e-5 * (chi.max() - chi.min())
+    assert abs(mo.poisson_level(chi, G, origin, h, xyz) - r["iso"]) <= 1e-5 * (chi.max() - chi.min())
     assert r["support_nodes"] == min(G, int(np.ceil(8.0 * r["spacing"] / r["h"])))          # MVS_POISSON_SUPPORT_DEFAULT spacings, in nodes
     v, f = mo.surface_nets(r["chi"], r["iso"], origin, h, mo.poisson_support(splat, r["support_nodes"]))
     assert np.array_equal(f, r["faces"]) and len(v) == len(r["vertices"])
@@ -61,7 +61,7 @@ def test_every_stage_against_the_oracle(hip, lg, n):
     v0, f0 = mo.surface_nets(r["chi"], r["iso"], origin, h)                                 # a closed, evenly sampled surface: nothing is trimmed
     assert np.array_equal(f0, f) and np.array_equal(v0, v)
     # meshed from the oracle's own field the surface is the same up to the cells the float32 field decides differently
-    v2, f2 = mo.surface_nets(chi.astype(np.float32), np.float32(mo.trilinear(chi, G, origin, h, xyz).mean()), origin, h)
+    v2, f2 = mo.surface_nets(chi.astype(np.float32), np.float32(mo.poisson_level(chi, G, origin, h, xyz)), origin, h)
     assert abs(len(v2) - len(v)) <= 0.002 * len(v) + 2
 
 
@@ -109,6 +109,44 @@ def test_grid_from_the_average_spacing_keeps_the_references_approximation_bound(
     # a forced coarse grid reports that the ratio is not kept (and the default caps at 512 nodes per axis)
     pts, nrm = _sphere(rng, 30000, (0, 0, 0), 1.0)
     assert mc.poisson(hip, pts, nrm, 5, 1.0, keep=False)["ratio_kept"] == 0
+
+
+def test_the_normals_lengths_are_confidences_whatever_their_scale(hip):
+    """triangulatePixels hands over normals scaled by a pdf (util.cpp:322-327): lengths of 1e-6 .. 1e-4 on real frames, far below the 2^-16
+    quantum of the fixed-point splat.  Only their ratios matter to the level set: the library multiplies them by an exact power of two
+    first (median size into [0.5, 1)), so a cloud whose normals are all scaled by 2^-17 gives the SAME bytes as the unit-length one, a scale
+    that is not a power of two the same surface, and one wild normal does not push the others below the quantum."""
+    rng = np.random.default_rng(123)
+    pts, nrm = _sphere(rng, 12000, (0.1, 0.2, -0.3), 0.9)
+    conf = rng.uniform(0.3, 1.0, size=(len(nrm), 1)).astype(np.float32)
+    nrm = (nrm * conf).astype(np.float32)
+    ref = mc.poisson(hip, pts, nrm, 6, 1.0)
+    k0 = mo.normal_scale_log2(nrm)
+    assert ref["normal_scale_log2"] == k0 and k0 in (0, 1)                                   # the median of the largest components is about 0.5
+    small = (nrm * np.float32(2.0 ** -17)).astype(np.float32)
+    r = mc.poisson(hip, pts, small, 6, 1.0)
+    assert r["normal_scale_log2"] == mo.normal_scale_log2(small) == k0 + 17
+    assert np.array_equal(r["splat"], ref["splat"]) and np.array_equal(r["chi"], ref["chi"]) and r["iso"] == ref["iso"]
+    assert r["vertices"].tobytes() == ref["vertices"].tobytes() and r["faces"].tobytes() == ref["faces"].tobytes()
+    assert np.array_equal(mo.poisson_splat(pts, small, *mo.poisson_grid(pts, 6)), r["splat"])
+    # pdf-sized normals, not a power of two: the same surface to within the fixed point's rounding
+    tiny = (nrm * np.float32(3.7e-6)).astype(np.float32)
+    r2 = mc.poisson(hip, pts, tiny, 6, 1.0)
+    assert np.abs(r2["splat"][:3]).max() > 2 ** 12                                           # the field is not quantised away
+    assert abs(len(r2["vertices"]) - len(ref["vertices"])) <= 0.005 * len(ref["vertices"]) + 2
+    rad = np.linalg.norm(r2["vertices"][:, :3] - np.array([0.1, 0.2, -0.3]), axis=1)
+    assert np.abs(rad - 0.9).max() <= 1.5 * r2["h"]
+    use = mc.edge_use(r2["faces"])
+    assert all(use[(b, a)] == c for (a, b), c in use.items())
+    # the scale follows the median, not the maximum: a few samples a thousand times as confident as the rest, one unusable normal (beyond
+    # 1e4: it votes for nothing) -- the others are not pushed below the quantum, and the splat still equals the oracle's
+    wild = tiny.copy()
+    wild[5:25] *= np.float32(1000.0)
+    wild[30] = [2.0e4, 0.0, 0.0]
+    r3 = mc.poisson(hip, pts, wild, 6, 1.0)
+    assert r3["normal_scale_log2"] == mo.normal_scale_log2(wild) == r2["normal_scale_log2"]
+    assert np.array_equal(mo.poisson_splat(pts, wild, *mo.poisson_grid(pts, 6)), r3["splat"])
+    assert np.abs(r3["splat"][:3]).max() > 2 ** 20 and np.median(np.abs(r3["splat"][:3][r3["splat"][:3] != 0])) > 2 ** 6
 
 
 def test_an_open_patch_is_meshed_where_the_samples_are_and_nowhere_else(hip):
@@ -160,12 +198,12 @@ def test_the_default_path_keeps_all_three_facet_criteria_of_the_reference(hip):
     for name, (pts, nrm), dist in (
             ("sphere", _sphere(rng, 30000, (1.0, 2.0, -3.0), 1.5), lambda v: np.abs(np.linalg.norm(v[:, :3] - np.array([1.0, 2.0, -3.0]), axis=1) - 1.5)),
             ("torus", _torus(rng, 60000, 1.0, 0.35), lambda v: np.abs(np.hypot(np.hypot(v[:, 0], v[:, 1]) - 1.0, v[:, 2]) - 0.35))):
-        raw_v, raw_f = mvs_amd.poisson_surface(pts, nrm, criteria=None)
+        raw_v, raw_f = mvs_amd.poisson_surface(pts, nrm, criteria=None, use_precision=True)   # (normals as given: the bytes of mc.poisson)
         r0 = mc.poisson(hip, pts, nrm, 0, 1.0, keep=False)
         assert np.array_equal(raw_v, r0["vertices"]) and np.array_equal(raw_f, r0["faces"]), name      # criteria=None: the mesher's output as it is
         assert facet_angles(raw_v, raw_f).min() < 5.0, name
         rep = {}
-        v, f = mvs_amd.poisson_surface(pts, nrm, report=rep)
+        v, f = mvs_amd.poisson_surface(pts, nrm, report=rep, use_precision=True)
         sp = rep["average_spacing"]
         assert abs(sp - mo.average_spacing(pts)) <= 1e-5 * sp
         ang = facet_angles(v, f)
@@ -258,8 +296,18 @@ def test_config5_outer_iteration_closes_points_filter_poisson_mesh_render():
         keep = ctx.filter_points(cloud[:, :4], 0.01 * extent)
         pts, nrm = cloud[keep, :4], cloud[keep, 4:7]
         assert 0 < len(pts) <= len(cloud)
-        v, f = mvs_amd.poisson_surface(pts, nrm)
+        # triangulatePixels scales the normals by its pdf (util.cpp:322-327): lengths far below the splat's 2^-16 quantum and two decades apart
+        length = np.linalg.norm(nrm, axis=1)
+        assert 0.0 < np.median(length) < 1e-3 and np.percentile(length, 99) > 10.0 * np.percentile(length, 1)
+        rep = {}
+        v, f = mvs_amd.poisson_surface(pts, nrm, report=rep)
         assert len(v) > 100 and len(f) > 100 and np.isfinite(v).all() and f.min() >= 0 and f.max() < len(v)
+        # ... and the surface is the samples' sheet: not fuzz in empty space (round 4: 16 M vertices before the normals' scale, the support
+        # mask and unit normals), most of it within a few spacings of a sample, facets below the angle bound an exception
+        from scipy.spatial import cKDTree
+        dist = cKDTree(pts[:, :3] / pts[:, 3:4]).query(v[:, :3])[0] / rep["average_spacing"]
+        assert len(v) < 10 * len(pts) and np.median(dist) < 1.0 and (dist < 3.0).mean() > 0.8 and dist.max() < 2.0 * np.sqrt(3.0) * (rep["support_nodes"] + 2)
+        assert rep["facets_below_angle"] < 0.005 * len(f)
         ctx.load_mesh(v, f)
         d = ctx.depth(seq.cams[seq.mains[12]])
         assert (d != mvs_amd.BACKGROUND_DEPTH).any()

@@ -1,5 +1,5 @@
 """The facet-criteria report of poissonSurface on a cloud the pipeline itself produces (config-5 outer iteration: point blocks of a few zatisi
-main frames -> filterPoints -> Poisson).  python tools/criteria_on_c5.py"""
+main frames -> filterPoints -> Poisson).  python tools/criteria_on_c5.py [--where] [--use-precision]"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,9 +18,10 @@ with mvs_amd.Context(seq.W, seq.H) as ctx:
     extent = float(np.percentile(xyz, 95, axis=0).max() - np.percentile(xyz, 5, axis=0).min())
     keep = ctx.filter_points(cloud[:, :4], 0.01 * extent)
     pts, nrm = cloud[keep, :4], cloud[keep, 4:7]
-    raw_v, raw_f = mvs_amd.poisson_surface(pts, nrm, criteria=None)
+    precision = "--use-precision" in sys.argv   # keep the pdf's lengths as confidences (pcl.cpp:198-202's USE_PRECISION) instead of unit normals
+    raw_v, raw_f = mvs_amd.poisson_surface(pts, nrm, criteria=None, use_precision=precision)
     rep = {}
-    v, f = mvs_amd.poisson_surface(pts, nrm, report=rep)
+    v, f = mvs_amd.poisson_surface(pts, nrm, report=rep, use_precision=precision)
     print("samples", len(pts), "raw", len(raw_v), len(raw_f), "->", len(v), len(f), rep)
     if "--where" in sys.argv:
         from scipy.spatial import cKDTree
