@@ -269,15 +269,10 @@ void mvs_destroy(mvs_ctx *ctx)
                       &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2,
                       &ctx->cubic_tab, &ctx->flow_arena, &ctx->frame_buf, &ctx->best_parts, &ctx->plan_stats, &ctx->probe_buf, &ctx->filter_sort, &ctx->raster_bins, &ctx->fx_lut, &ctx->side_quads, &ctx->side_quads16,
                       &ctx->r_mips, &ctx->flow_batch_arena, &ctx->rect_tab, &ctx->store_raw, &ctx->store_quads, &ctx->batch_slot[0].buf, &ctx->batch_slot[1].buf, &ctx->frame_ptrs, &ctx->view_slots, &ctx->xrect_tab};
-    for (int i = 0; i < 2; i++)
-        if (ctx->flow_graph[i]) (void)hipGraphExecDestroy(ctx->flow_graph[i]);
-    if (ctx->flow_batch_graph.exec) (void)hipGraphExecDestroy(ctx->flow_batch_graph.exec);
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     for (auto &lane : ctx->lanes) {
         if (lane.stream) (void)hipStreamSynchronize(lane.stream);
-        for (int i = 0; i < 2; i++)
-            if (lane.graph[i]) (void)hipGraphExecDestroy(lane.graph[i]);
         if (lane.arena.ptr) (void)hipFree(lane.arena.ptr);
         if (lane.cmp.ptr) (void)hipFree(lane.cmp.ptr);
         if (lane.stream) (void)hipStreamDestroy(lane.stream);

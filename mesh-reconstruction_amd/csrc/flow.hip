@@ -946,8 +946,7 @@ static int flow_prepare(mvs_ctx *ctx, FlowBufs &b)
 }
 
 // flow.cpp:19-42 on the buffers of `b`: inputs b.p8 / b.n8 (u8), output b.out4.  Everything between is a fixed
-// sequence of kernels on fixed buffers: recorded once per algorithm as a hipGraph and replayed
-// (MVS_NO_GRAPH=1 forces eager launches).
+// sequence of kernels on fixed buffers.
 static int flow_run(mvs_ctx *ctx, const FlowBufs &b, int use_farneback)
 {
     const int W = ctx->W, H = ctx->H;
@@ -971,32 +970,11 @@ static int flow_run(mvs_ctx *ctx, const FlowBufs &b, int use_farneback)
         MVS_HIP(ctx, hipGetLastError());
         return MVS_OK;
     };
-    const int gi = use_farneback ? 1 : 0;
-    static const bool no_graph = getenv("MVS_NO_GRAPH") != nullptr;
-    if (ctx->flow_graph[gi] && (ctx->flow_graph_arena[gi] != ctx->flow_arena.ptr || ctx->flow_graph_tmp[gi] != ctx->r_tmp1.ptr)) {
-        (void)hipGraphExecDestroy(ctx->flow_graph[gi]);
-        ctx->flow_graph[gi] = nullptr;
-    }
-    if (!ctx->flow_graph[gi] && !no_graph) {
-        hipGraph_t graph = nullptr;
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            const int r = enqueue();
-            const hipError_t e = hipStreamEndCapture(st, &graph);
-            if (r == MVS_OK && e == hipSuccess && graph && hipGraphInstantiate(&ctx->flow_graph[gi], graph, nullptr, nullptr, 0) == hipSuccess) {
-                ctx->flow_graph_arena[gi] = ctx->flow_arena.ptr;
-                ctx->flow_graph_tmp[gi] = ctx->r_tmp1.ptr;
-            } else {
-                ctx->flow_graph[gi] = nullptr;
-                (void)hipGetLastError();
-            }
-            if (graph) (void)hipGraphDestroy(graph);
-        }
-    }
+    // Eager launches.  Rounds 2-3 replayed this sequence as a hipGraph; round 4 found that a graph instantiated before some first-time
+    // event elsewhere in the process (the first mvs_poisson_surface call: rocFFT's run-time kernels, new code objects) replays with WRONG
+    // results afterwards -- silently, deterministically within the process, differently from process to process --
+    // and that on this ROCm the eager launches are no slower (mvs_process_frame 1.69 ms against 1.95 with the graphs).
     ProfileScope ps(ctx, MVS_K_FLOW);
-    if (ctx->flow_graph[gi]) {
-        MVS_HIP(ctx, hipGraphLaunch(ctx->flow_graph[gi], st));
-        return MVS_OK;
-    }
     return enqueue();
 }
 
@@ -1123,7 +1101,7 @@ static int farneback_batch_enqueue(mvs_ctx *ctx, const uint8_t *prev8, const uin
 }
 
 // calculateFlow(prev, next_i, useFarneback = true) for i < B on device buffers (next8: B frames P bytes apart, out4: B x H*W*4 f32);
-// in-stream, recorded once per (buffers, B) as a hipGraph and replayed
+// in-stream
 int flow_farneback_batch_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int B, float *out4_dev)
 {
     const size_t P = (size_t)ctx->W * ctx->H;
@@ -1134,37 +1112,7 @@ int flow_farneback_batch_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uin
     if ((rc = ensure_cubic_table(ctx))) return rc;
     if ((rc = compare_prepare(ctx))) return rc;
     const FlowBatchBufs b = flow_batch_layout((float *)ctx->flow_batch_arena.ptr, P, B);
-    static const bool no_graph = getenv("MVS_NO_GRAPH") != nullptr;
-    auto &g = ctx->flow_batch_graph;
-    const bool same = g.exec && g.arena == ctx->flow_batch_arena.ptr && g.tmp == ctx->r_tmp1.ptr && g.prev == prev_dev && g.next == next_dev && g.out == out4_dev && g.B == B;
-    if (g.exec && !same) {
-        (void)hipGraphExecDestroy(g.exec);
-        g.exec = nullptr;
-    }
-    if (!g.exec && !no_graph) {
-        hipGraph_t graph = nullptr;
-        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            const int r = farneback_batch_enqueue(ctx, prev_dev, next_dev, B, out4_dev, b);
-            const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-            if (r == MVS_OK && e == hipSuccess && graph && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                g.arena = ctx->flow_batch_arena.ptr;
-                g.tmp = ctx->r_tmp1.ptr;
-                g.prev = prev_dev;
-                g.next = next_dev;
-                g.out = out4_dev;
-                g.B = B;
-            } else {
-                g.exec = nullptr;
-                (void)hipGetLastError();
-            }
-            if (graph) (void)hipGraphDestroy(graph);
-        }
-    }
-    ProfileScope ps(ctx, MVS_K_FLOW);
-    if (g.exec) {
-        MVS_HIP(ctx, hipGraphLaunch(g.exec, ctx->stream));
-        return MVS_OK;
-    }
+    ProfileScope ps(ctx, MVS_K_FLOW);  // (eager launches: see flow_run)
     return farneback_batch_enqueue(ctx, prev_dev, next_dev, B, out4_dev, b);
 }
 

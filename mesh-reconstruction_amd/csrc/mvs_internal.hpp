@@ -102,11 +102,6 @@ struct mvs_ctx {
     mvs::DevBuf cubic_tab;           // Q15 bicubic weights for remap (32*32*16 shorts)
     mvs::DevBuf flow_arena;          // optical-flow pyramids and work buffers
     mvs::DevBuf flow_batch_arena;    // the same for the batched Farneback of mvs_process_frame (all side views of a main frame per launch)
-    struct FlowBatchGraph {
-        hipGraphExec_t exec = nullptr;
-        const void *arena = nullptr, *tmp = nullptr, *prev = nullptr, *next = nullptr, *out = nullptr;
-        int B = 0;
-    } flow_batch_graph;
     mvs::DevBuf frame_buf;           // mvs_process_frame: frames, depth, warped image, flows of one main frame
     mvs::DevBuf best_parts;          // plane-split sweeps: partial (best cell, best index) per split and pixel
     // frame store (mvs_frame_store / mvs_frame_upload / mvs_sweep_batch): the frames of a sequence, uploaded once, each as raw frame,
@@ -124,23 +119,15 @@ struct mvs_ctx {
     hipStream_t copy_stream = nullptr;
     int store_cap = 0;
     std::vector<unsigned char> store_have;
-    // the launch-bound flow pipelines (~350 small kernels for Farneback) are captured once into a hipGraph per
-    // algorithm and replayed; invalidated when the arena moves
     // mvs_process_frame runs the flows of one main frame's side views concurrently: a lane is everything calculateFlow keeps
-    // per call (stream, arena, compare pyramid, cached graphs); pipeline.hip swaps a lane into the fields below for one call
+    // per call (stream, arena, compare pyramid); pipeline.hip swaps a lane into the fields below for one call
     struct FlowLane {
         hipStream_t stream = nullptr;
         mvs::DevBuf arena, cmp;
-        hipGraphExec_t graph[2] = {nullptr, nullptr};
-        void *graph_arena[2] = {nullptr, nullptr};
-        void *graph_tmp[2] = {nullptr, nullptr};
     };
     static constexpr int kFlowLanes = 4;
     FlowLane lanes[kFlowLanes];
     std::vector<hipEvent_t> lane_events;  // 2 per side view: inputs ready, flow done
-    hipGraphExec_t flow_graph[2] = {nullptr, nullptr};
-    void *flow_graph_arena[2] = {nullptr, nullptr};
-    void *flow_graph_tmp[2] = {nullptr, nullptr};
 
     // ---- profiling -----------------------------------------------------------------------------------
     bool profiling = false;
@@ -206,6 +193,6 @@ int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, 
 int flow_farneback_batch_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int B, float *out4_dev);  // next: B frames, W*H bytes apart
 int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows, bool on_device, const float main_cam[16],
                      const float *side_cams, const float *depth, float *out_points7, int *out_count);
-int compare_prepare(mvs_ctx *ctx);  // allocates compare_device's arena (must not happen during graph capture)
+int compare_prepare(mvs_ctx *ctx);  // allocates compare_device's arena
 
 }  // namespace mvs

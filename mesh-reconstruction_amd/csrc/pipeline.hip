@@ -9,7 +9,7 @@
 // reference's own GL path does (two glReadPixels + two uploads per pair, render_glx.cpp:286,325,359,75).  Here the
 // frames go up once, every intermediate (depth, warped image, mask, flows) stays in HBM, and only the points come
 // back.  The flows of the side views are independent of each other, so each runs in one of four lanes (stream + arena +
-// cached hipGraph) while the main stream rasterises the next view.  Same kernels, same arithmetic: the result equals the
+// compare pyramid) while the main stream rasterises the next view.  Same kernels, same arithmetic: the result equals the
 // stage-by-stage calls bit for bit (tests/test_pipeline_gpu.py).
 #include "mvs_internal.hpp"
 
@@ -39,7 +39,7 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     float *d_depth = (float *)((uint8_t *)ctx->frame_buf.ptr + bytes_u8), *d_flows = d_depth + P;
 
     // The flows of the side views depend only on (main frame, mixed_i): each runs in a lane of its own (stream + arena +
-    // cached graph) while the main stream goes on rasterising the next view; a flow is a chain of small kernels that fills
+    // pyramid) while the main stream goes on rasterising the next view; a flow is a chain of small kernels that fills
     // 150 of 256 CUs at best, so up to four of them overlap.  Everything joins before triangulatePixels.
     static const bool serial = getenv("MVS_SERIAL_FLOWS") != nullptr;  // A/B: all flows in the main stream, as before
     // Farneback (-f): the flows of all side views in ONE pass after the last mixed image (every launch covers all of them; what
@@ -63,11 +63,6 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
             std::swap(c->stream, l.stream);
             std::swap(c->flow_arena, l.arena);
             std::swap(c->r_tmp1, l.cmp);
-            for (int i = 0; i < 2; i++) {
-                std::swap(c->flow_graph[i], l.graph[i]);
-                std::swap(c->flow_graph_arena[i], l.graph_arena[i]);
-                std::swap(c->flow_graph_tmp[i], l.graph_tmp[i]);
-            }
         }
         LaneScope(mvs_ctx *ctx_, mvs_ctx::FlowLane &lane) : c(ctx_), l(lane) { swap(); }
         ~LaneScope() { swap(); }

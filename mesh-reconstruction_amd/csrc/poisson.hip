@@ -472,7 +472,13 @@ extern "C" int mvs_poisson_surface_ex(const float *points, const float *normals,
     if (!(side > 0.0)) return fail(MVS_EINVAL, "mvs_poisson_surface: the points have no extent");
     const double box = 1.5 * side;
     // ---- step 0: the samples' average spacing (device), then the grid ----
-    hipStream_t st = nullptr;
+    // a stream of its own (not the legacy default stream, which synchronises with every blocking stream of the process)
+    struct OwnStream {
+        hipStream_t s = nullptr;
+        ~OwnStream() { if (s) (void)hipStreamDestroy(s); }
+    } own;
+    if (hipStreamCreateWithFlags(&own.s, hipStreamNonBlocking) != hipSuccess) return fail(MVS_EHIP, "mvs_poisson_surface: hipStreamCreate failed");
+    hipStream_t st = own.s;
     DevBuf d_pts, d_nrm;
     if (!d_pts.alloc((size_t)n * 16) || !d_nrm.alloc((size_t)n * 12)) return fail(MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
     if (hipMemcpy(d_pts.p, points, (size_t)n * 16, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_nrm.p, normals, (size_t)n * 12, hipMemcpyHostToDevice) != hipSuccess)

@@ -284,7 +284,7 @@ extern "C" int mvs_surface_enforce_criteria(mvs_surface *s, float min_angle_deg,
         std::vector<int> queue, touched;
         for (int i = 0; i < nf; i++)
             if (w.f[3 * i] >= 0 && w.q_of(i) < w.q_bound) queue.push_back(i);
-        const size_t budget = 20 * (size_t)nf + 1000;  // (collapses are finite by themselves; the cap is for flips chasing each other)
+        const size_t budget = 2 * (size_t)nf + 1000;  // (collapses are finite by themselves; the cap is for flips chasing each other: a clean surface needs nf / 50 operations)
         size_t done = 0;
         // second round: the facets the first one could not help, with half of the distance bound to move in instead of a quarter
         for (int round = 0; round < 2; round++) {

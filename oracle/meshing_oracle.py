@@ -473,7 +473,7 @@ def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_dista
         return best[0] != 0
 
     queue = [i for i in range(nf) if f[i][0] >= 0 and q_of(i) < q_bound]
-    budget, done = 20 * nf + 1000, 0
+    budget, done = 2 * nf + 1000, 0
     for _round in range(2):
         head = 0
         while head < len(queue) and done < budget:

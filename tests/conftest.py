@@ -23,6 +23,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """no test may hang the box it runs on (a hung GPU box is lost to everybody): with pytest-timeout installed every test gets a
+    generous limit -- the slowest takes about a minute"""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900))
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import orc

@@ -133,3 +133,49 @@ def test_the_plane_sweep_finds_the_surface_the_frames_show_on_the_tracks_cameras
         step = (hi - lo + 2 * margin) / D
         err = np.abs(depth.astype(np.float64) - z_true)[seen] / step
         assert np.median(err) <= 1.0 and (err <= 2.0).mean() > 0.8, (sampler, float(np.median(err)), float((err <= 2.0).mean()))
+
+
+def test_the_outer_iteration_converges_on_the_surface_the_frames_show():
+    """recon.cpp:42-136 as a whole, twice round: proxy mesh -> per main frame (depth, projected, mixBackground, Farneback flow, triangulatePixels)
+    -> the point blocks concatenated -> filterPoints -> poissonSurface (with the reference's facet criteria) -> loadMesh -> again.  The frames
+    are rendered from the bumped surface T, the first proxy is the plane without the bump; after each round the mesh the NEXT round renders
+    must lie closer to T (median |z - z_true| in a main camera's NDC z), and still cover what that camera sees of T."""
+    import c5_common
+    import mvs_amd
+    import scipy.ndimage as ndi
+    seq = c5_common.Sequence()
+    W, H = seq.W, seq.H
+    (Tv, Tf), mesh = _sheets(seq, 0.03)
+    rng = np.random.default_rng(10)
+    tex = ndi.gaussian_filter(rng.normal(size=(H, W)), 2.5)
+    tex = (127.5 + 110.0 * tex / np.abs(tex).max()).clip(0, 255).astype(np.uint8)
+    with mvs_amd.Context(W, H) as ctx:
+        mains = seq.mains[8:16:2]
+        need = sorted(set(j for f in mains for j in [f] + seq.sides(f)))
+        ctx.load_mesh(Tv, Tf)
+        frames = {j: ctx.projected(seq.cams[j], tex, seq.cams[seq.n // 2])[:, :, 0].copy() for j in need}
+        check = seq.mains[11]
+        z_true = ctx.depth(seq.cams[check]).astype(np.float64)
+        errors, cover = [], []
+        for it in range(3):
+            ctx.load_mesh(*mesh)
+            z_mesh = ctx.depth(seq.cams[check]).astype(np.float64)
+            both = (z_true < 1.0) & (z_mesh < 1.0)
+            errors.append(float(np.median(np.abs(z_mesh - z_true)[both])))
+            cover.append(both.sum() / (z_true < 1.0).sum())
+            if it == 2:
+                break
+            blocks = [ctx.process_frame(seq.cams[f], frames[f], np.stack([seq.cams[j] for j in seq.sides(f)]), [frames[j] for j in seq.sides(f)], True) for f in mains]
+            cloud = np.concatenate(blocks)
+            cloud = cloud[np.isfinite(cloud).all(1)]
+            cloud = cloud[::max(1, len(cloud) // 60000)]
+            xyz = cloud[:, :3] / cloud[:, 3:4]
+            keep = ctx.filter_points(cloud[:, :4], 0.01 * float(np.ptp(xyz, axis=0).max()))
+            assert len(keep) > 0.5 * len(cloud)
+            rep = {}
+            v, f = mvs_amd.poisson_surface(cloud[keep, :4], cloud[keep, 4:7], report=rep)
+            assert 1000 < len(v) < 10 * len(keep) and rep["facets_below_angle"] < 0.005 * len(f)
+            mesh = (v, f)
+        # measured: 0.0224 -> 0.0027 -> 0.0008, coverage 99 % -> 98 % -> 92 %
+        assert errors[1] < 0.25 * errors[0] and errors[2] < 0.6 * errors[1], errors
+        assert min(cover) > 0.85, cover

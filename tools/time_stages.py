@@ -11,7 +11,7 @@ for (W, H) in [(640, 480), (1920, 1080)]:
     with mvs_amd.Context(W, H) as ctx:
         ctx.load_mesh(verts, faces)
         def t(f, n=5):
-            f(); f(); ctx.synchronize(); t0 = time.perf_counter()   # two warm-ups: the first call of a flow algorithm records its hipGraph
+            f(); f(); ctx.synchronize(); t0 = time.perf_counter()   # two warm-ups: allocations, first launches
             for _ in range(n): r = f()
             return (time.perf_counter() - t0) / n * 1e3, r
         td, depth = t(lambda: ctx.depth(main))
