@@ -82,7 +82,7 @@ def test_process_frame_is_faster_than_stagewise():
 
 @pytest.mark.parametrize("nside", [0, 1, 6, 9])
 def test_process_frame_side_view_counts(nside):
-    """the side views' flows run concurrently in up to four lanes (stream + arena + graph each): fewer views than lanes,
+    """the side views' flows run concurrently in up to four lanes (stream + arena + compare pyramid each): fewer views than lanes,
     more views than lanes (lanes are reused in order) and repeated calls must all equal the stage-by-stage result"""
     W, H = 256, 160
     verts, faces = scenes.heightfield_mesh(48, extent=1.4)
@@ -101,7 +101,7 @@ def test_process_frame_side_view_counts(nside):
             mixed, depth = ctx.mix_background(ctx.projected(main, img, cam), main_img, depth)
             flows.append(ctx.flow(main_img, mixed, False))
         ref = ctx.triangulate(flows, main, sides, depth)
-        for _ in range(3):      # lanes, their graphs and events are reused from the second call on
+        for _ in range(3):      # lanes and events are reused from the second call on
             pts, depth_after = ctx.process_frame(main, main_img, sides, side_imgs, False, want_depth=True)
             np.testing.assert_array_equal(depth_after, depth)
             np.testing.assert_array_equal(pts, ref)
