@@ -45,6 +45,10 @@ int ensure(mvs_ctx *ctx, DevBuf &b, size_t bytes)
     if (e != hipSuccess) return fail(ctx, MVS_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
     b.ptr = p;
     b.bytes = bytes;
+    // MVS_POISON_ALLOC=1 (test hook): a fresh allocation is filled with 0xFF bytes (NaN as float, -1 as int) instead of whatever the
+    // allocator hands out -- zeros in a young process, which hides reads of memory nobody wrote
+    static const bool poison = getenv("MVS_POISON_ALLOC") != nullptr;
+    if (poison) MVS_HIP(ctx, hipMemsetAsync(p, 0xff, bytes, ctx->stream));
     return MVS_OK;
 }
 

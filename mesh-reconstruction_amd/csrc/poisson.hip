@@ -391,7 +391,12 @@ __global__ void edge_faces_kernel(Grid g, const float *__restrict__ chi, float i
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess; }
+    bool alloc(size_t bytes)
+    {
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return false;
+        static const bool poison = getenv("MVS_POISON_ALLOC") != nullptr;  // (test hook, as in context.hip's ensure)
+        return !poison || (hipMemset(p, 0xff, bytes ? bytes : 1) == hipSuccess);
+    }
     template <class T> T *as() { return (T *)p; }
 };
 
