@@ -309,8 +309,8 @@ int mvs_profile_read(mvs_ctx *ctx, float ms_sum[MVS_K_COUNT], int launches[MVS_K
 
 /* ---- surface meshing: replaces poissonSurface (recon.hpp:37, cgal_poisson.cpp:47-136, pcl.cpp:193-228) ----
  * Poisson reconstruction of oriented samples on a regular grid (csrc/poisson.hip): normals splatted with 64-bit fixed-point atomics,
- * laplace(chi) = div V solved with hipFFT, level set through the samples meshed by surface nets.  Context-free (device 0 of the
- * calling thread's HIP runtime state); no CPU path.
+ * laplace(chi) = div V solved with hipFFT, level set through the samples meshed by surface nets.  Context-free: runs on the calling
+ * thread's current HIP device (device 0 unless the caller has set another), on a stream of its own; no CPU path.
  *   points     n rows x, y, z, w (homogeneous, as recon.cpp:121 hands them over);  normals  n rows nx, ny, nz (pointing out of the solid;
  *              a component that is NaN or beyond 1e4 in magnitude makes the sample vote for nothing).  Their lengths act as confidences,
  *              as given; poissonSurface (host/poisson.cpp) and mvs_amd.poisson_surface normalise them first, like the reference's PCL

@@ -440,7 +440,7 @@ bool scan(int *flags, int *offsets, size_t n, hipStream_t st, DevBuf &tmp, size_
 // holds work buffers); the mutex also serialises the transforms of concurrent callers on the shared plans.
 struct PlanCache {
     std::mutex m;
-    int G = 0;
+    int G = 0, device = -1;  // (a plan belongs to the device it was made on)
     hipfftHandle fwd = 0, inv = 0;
 };
 PlanCache g_plans;
@@ -613,7 +613,9 @@ extern "C" int mvs_poisson_surface_ex(const float *points, const float *normals,
         float *chi = d_real.as<float>();  // (the transform may overwrite its input: spec[0] is not used again)
         {
             std::lock_guard<std::mutex> lock(g_plans.m);  // the plans of the last grid size are kept for the process (see PlanCache)
-            if (g_plans.G != g.G) {
+            int device = 0;
+            PS_TRY(hipGetDevice(&device) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: hipGetDevice failed");
+            if (g_plans.G != g.G || g_plans.device != device) {
                 if (g_plans.G) {
                     (void)hipfftDestroy(g_plans.fwd);
                     (void)hipfftDestroy(g_plans.inv);
@@ -625,7 +627,7 @@ extern "C" int mvs_poisson_surface_ex(const float *points, const float *normals,
                     (void)hipfftDestroy(fwd);
                     PS_TRY(false, MVS_EHIP, "mvs_poisson_surface: hipfftPlan3d (C2R) failed");
                 }
-                g_plans.fwd = fwd, g_plans.inv = inv, g_plans.G = g.G;
+                g_plans.fwd = fwd, g_plans.inv = inv, g_plans.G = g.G, g_plans.device = device;
             }
             PS_TRY(hipfftSetStream(g_plans.fwd, st) == HIPFFT_SUCCESS && hipfftSetStream(g_plans.inv, st) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: hipfftSetStream failed");
             for (int c = 0; c < 3; c++)
