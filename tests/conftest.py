@@ -30,7 +30,8 @@ def pytest_collection_modifyitems(config, items):
         return
     for item in items:
         if item.get_closest_marker("timeout") is None:
-            item.add_marker(pytest.mark.timeout(900))
+            # GPU tests: the watchdog-thread method (it ends the process): a signal cannot interrupt a call stuck inside the HIP runtime
+            item.add_marker(pytest.mark.timeout(900, method="thread") if item.get_closest_marker("gpu") else pytest.mark.timeout(900))
 
 
 @pytest.fixture(scope="session")
