@@ -83,6 +83,13 @@ __device__ __forceinline__ void for_lower_neighbours(int i, const float *__restr
             }
 }
 
+// 1 into *flag when a prefix-sum array of N + 1 non-negative counts decreases somewhere (its 32-bit sum wrapped)
+__global__ void offsets_wrap_check(const int *__restrict__ off_lo, const int *__restrict__ off_up, int N, int *__restrict__ flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N && (off_lo[i + 1] < off_lo[i] || off_up[i + 1] < off_up[i] || off_lo[i] < 0 || off_up[i] < 0)) *flag = 1;
+}
+
 __global__ __launch_bounds__(256) void nb_count(const float *__restrict__ p3, const int *__restrict__ cell3,
                                                 const int *__restrict__ head, const int *__restrict__ next, unsigned mask, int N,
                                                 float radius, int *__restrict__ cnt_lo, int *__restrict__ cnt_up)
@@ -391,11 +398,15 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
             rocprim::exclusive_scan(ctx->r_tmp0.ptr, scan_bytes, d_cnt_up, d_off_up, 0, (size_t)N + 1, rocprim::plus<int>(), st) != hipSuccess)
             return fail(ctx, MVS_EHIP, "mvs_filter_points: scan failed");
     }
+    // a 32-bit prefix sum that wraps shows as an offset smaller than its predecessor (counts are >= 0): flag in the spare entry of d_fill
+    offsets_wrap_check<<<g, 256, 0, st>>>(d_off_lo, d_off_up, N, d_fill + N);
     MVS_HIP(ctx, hipGetLastError());
-    int total = 0;
+    int total = 0, wrapped = 0;
     MVS_HIP(ctx, hipMemcpyAsync(&total, d_off_lo + N, sizeof(int), hipMemcpyDeviceToHost, st));
+    MVS_HIP(ctx, hipMemcpyAsync(&wrapped, d_fill + N, sizeof(int), hipMemcpyDeviceToHost, st));
     MVS_HIP(ctx, hipStreamSynchronize(st));
-    if (total < 0) return fail(ctx, MVS_ENOMEM, "mvs_filter_points: neighbour table overflows 2^31 entries");
+    if (total < 0 || wrapped)
+        return fail(ctx, MVS_ENOMEM, "mvs_filter_points: neighbour table overflows 2^31 entries (radius %g is far beyond the spacing of %d points)", (double)radius, N);
     lap("upload, hash, count, scan");
 
     // neighbour lists live in their own buffer (size known only now)

@@ -68,3 +68,17 @@ def test_round_limit_fallback_gives_the_same_selection(oracle, tmp_path):
     ref = oracle.filter_points(pts, alpha)[0]
     np.testing.assert_array_equal(limited, full)
     np.testing.assert_array_equal(full, ref)
+
+
+def test_a_radius_far_beyond_the_spacing_is_refused_not_wrapped():
+    """heuristic.cpp:74-89 asks for every neighbour within the radius: a radius that spans the whole cloud makes N^2 / 2 of them per table.
+    At 70 000 points that is 2.45e9 entries -- more than the 32-bit offsets hold; the prefix sum wraps (to a POSITIVE total here, so the sign
+    alone does not show it).  The call must say so, not build a table from wrapped offsets; the context stays usable."""
+    rng = np.random.default_rng(3)
+    N = 70000
+    pts = np.concatenate([rng.uniform(0, 1e-3, (N, 3)), np.ones((N, 1))], 1).astype(np.float32)
+    with mvs_amd.Context(64, 48) as ctx:
+        with pytest.raises(mvs_amd.MvsError, match="2\\^31"):
+            ctx.filter_points(pts, 10.0)
+        small = _cloud(rng, 3000, 10)
+        assert len(ctx.filter_points(small, 0.01)) > 0
