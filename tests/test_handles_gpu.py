@@ -180,3 +180,13 @@ def test_a_fixed_rigs_next_frames_reuse_the_plan_and_new_cameras_do_not(oracle, 
         ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
         np.testing.assert_array_equal(ctx.sweep_fetch()[0], a)
     np.testing.assert_array_equal(a, ref(main_cam, main_img, side_cams, frames2[1:], D))
+
+
+def test_no_state_of_a_long_lived_context_leaks_into_a_result():
+    """tests/perf/fuzz_api.py in short: random sequences of view sets (rectified, rotated, mixed), planes, sampler switches, MVS_SWEEP_NO_RECT, the
+    one-call entry, frame-store handles and device-resident setters on ONE context -- every result equal to a fresh context's for the same inputs"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "perf"))
+    import fuzz_api
+    assert sum(fuzz_api.run(seed, 30) for seed in (11, 12, 13)) == 0
