@@ -149,3 +149,13 @@ def test_stage_matches_the_committed_golden_vectors():
         # and the one-call form of the same stage
         one = ctx.process_frame(main, main_img, sides, side_imgs, False)
         assert one.shape[0] == int(g["points_n"]) and crc(one[:, :4]) == g["points_xyzw_crc"]
+
+
+def test_no_scratch_of_one_stage_shows_in_another_stages_result():
+    """tests/perf/fuzz_pipeline.py in short: random sequences of loadMesh, depth, projected, calculateFlow, mvs_process_frame, filterPoints and a small
+    sweep on one context (the stages share arenas and lanes), every output equal to a fresh context's"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "perf"))
+    import fuzz_pipeline
+    assert sum(fuzz_pipeline.run(seed, 25) for seed in (21, 22)) == 0
