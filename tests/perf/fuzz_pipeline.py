@@ -50,7 +50,12 @@ def run(seed, steps, verbose=False):
         cur = 0
         ctx.load_mesh(*meshes[cur])
         for step in range(steps):
-            op = str(rng.choice(["mesh", "depth", "projected", "flow", "process", "process", "filter", "sweep"]))
+            op = str(rng.choice(["mesh", "depth", "projected", "flow", "process", "process", "filter", "sweep", "poisson"]))
+            if op == "poisson":   # context-free, but it is what made a previously captured hipGraph replay wrongly: keep it in the mix
+                d = np.random.default_rng(int(rng.integers(0, 1 << 30))).normal(size=(1500, 3))
+                d /= np.linalg.norm(d, axis=1, keepdims=True)
+                mvs_amd.poisson_surface(np.concatenate([d, np.ones((1500, 1))], 1).astype(np.float32), d.astype(np.float32), grid_log2=int(rng.choice([4, 5])), criteria=None)
+                continue
             if op == "mesh":
                 cur = int(rng.integers(0, 2))
                 ctx.load_mesh(*meshes[cur])
