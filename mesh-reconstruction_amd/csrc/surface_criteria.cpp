@@ -85,6 +85,11 @@ struct Work {
             }
         return n;
     }
+    static void forget(std::vector<int> &list, int face)
+    {
+        const auto it = std::find(list.begin(), list.end(), face);
+        if (it != list.end()) list.erase(it);
+    }
     bool connected(int a, int b) const
     {
         for (int face : inc[a])
@@ -153,8 +158,7 @@ struct Work {
             for (int j = 0; j < 3; j++) {
                 const int w = f[3 * face + j];
                 if (w == u) continue;
-                auto &l = inc[w];
-                l.erase(std::find(l.begin(), l.end(), face));
+                forget(inc[w], face);
             }
             f[3 * face] = f[3 * face + 1] = f[3 * face + 2] = -1;
         }
@@ -205,11 +209,9 @@ struct Work {
         const int c = third(f1, u, v), d = third(f2, u, v);
         f[3 * f1] = u, f[3 * f1 + 1] = d, f[3 * f1 + 2] = c;
         f[3 * f2] = d, f[3 * f2 + 1] = v, f[3 * f2 + 2] = c;
-        auto &lv = inc[v];
-        lv.erase(std::find(lv.begin(), lv.end(), f1));
+        forget(inc[v], f1);
         inc[d].push_back(f1);
-        auto &lu = inc[u];
-        lu.erase(std::find(lu.begin(), lu.end(), f2));
+        forget(inc[u], f2);
         inc[c].push_back(f2);
         touched.push_back(f1);
         touched.push_back(f2);
