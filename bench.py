@@ -8,7 +8,10 @@ the BASELINE config already resident in HBM when the time
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--shard frames|views|rows]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py ...`; without a launcher
-`--gpus N` is refused (one process drives one GPU).  The N > 1 line is STRONG scaling of ONE main view at the named config:
+`--gpus N` starts that launcher itself as a CHILD process (before torch is imported or a GPU touched) and relays its output and
+exit code.  `--via-comm` is the other host for the same device code: ONE process, N GPUs, through the product's own multi-GPU entry
+(mvs_comm_set_* / mvs_comm_run, include/mvs.h: persistent rank threads, inputs resident); under a launcher rank 0 also runs it as a
+child process after the timed region and reports it as `via_comm`.  The N > 1 line is STRONG scaling of ONE main view at the named config:
   rows (default):   the pixel rows of the main view are split into bands, one per rank (rows are independent,
                     SURVEY 8e-2); each rank sweeps its band over all views, the depth bands are all-gathered
                     (4 B per pixel in total).  `value`.
@@ -217,6 +220,133 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
         dist.destroy_process_group()
 
 
+def run_via_comm(args, same_device):
+    """ONE process, N GPUs, through the C ABI's communicator: planes, main view and all side views uploaded to every rank once
+    (mvs_comm_set_*), then K timed mvs_comm_run calls -- each returns when every rank thread has finished its share and, in rows mode,
+    the depth bands have landed on GPU 0 by peer copies.  Strong scaling of one main view, like the torch.distributed line; the depth
+    map is checked (CRC) against a single-GPU sweep of the same view on GPU 0 in this process."""
+    import numpy as np
+    import torch  # noqa: F401  (first: libmvs_hip.so must share torch's HIP runtime)
+    LOOPBACK = os.path.join(ROOT, "tests", "loopback_rccl", "_build", "libloopback_rccl.so")
+    if same_device:   # test hook: N ranks on GPU 0 (one-GPU boxes); the views modes then need the loopback collective library
+        os.environ["MVS_TEST_HOOKS"] = "1"
+        os.environ["MVS_COMM_ALLOW_SAME_DEVICE"] = "1"
+        if os.path.exists(LOOPBACK):
+            os.environ["MVS_RCCL_LIBRARY"] = LOOPBACK
+    import mvs_amd
+    from mvs_amd import synth
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    N = args.gpus
+    have = torch.cuda.device_count()
+    if not same_device and N > have:
+        raise SystemExit("bench.py --via-comm --gpus %d: this node has %d GPUs" % (N, have))
+    devices = [0] * N if same_device else list(range(N))
+    cfg = CONFIGS[args.config]
+    W, H, D, V = cfg
+    P = W * H
+    if args.data == "scene":
+        main_cam, main_img, side_cams, sides, gt = synth.make_views(W, H, V, radius=0.15, seed=synth.SEED_SCENE)
+    else:
+        main_cam, main_img, side_cams, sides = synth.noise_views(W, H, V, seed=synth.SEED_NOISE)
+        gt = None
+    both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    with mvs_amd.Context(W, H, devices[0], sampler=args.sampler) as ctx:   # the single-GPU result the sharded runs must reproduce
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+        ctx.sweep_run(0, V, both)
+        depth1 = ctx.sweep_fetch()[0]
+        kernel = KERNEL_OF_SHAPE.get(ctx.plan_shape(), "sweep_fx_tiled")
+        for _ in range(CLOCK_RAMP_STEPS):
+            ctx.sweep_run(0, V, both)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.sweep_run(0, V, both)
+        ctx.synchronize()
+        single_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        info = ctx.info()
+    crc1 = zlib.crc32(np.ascontiguousarray(depth1).tobytes())
+    modes = args.via_comm_modes.split(",") if args.via_comm_modes else (["rows"] if args.no_extras else ["rows", "views", "views_scatter"])
+    results = {}
+    with mvs_amd.Comm(devices, W, H, sampler=args.sampler) as comm:
+        t0 = time.perf_counter()
+        comm.set(main_cam, main_img, side_cams, sides, D)
+        upload_ms = (time.perf_counter() - t0) * 1e3
+        gran = mvs_amd.load_library().mvs_sweep_row_granularity_of(comm.context(0))
+        band = ((H + gran - 1) // gran + N - 1) // N * gran
+        for mode in modes:
+            try:
+                comm.set_mode(mode, args.plane_groups if mode == "views" else None)
+                for _ in range(CLOCK_RAMP_STEPS + args.warmup):
+                    comm.run(mvs_amd.MVS_SWEEP_VOLUME)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    comm.run(mvs_amd.MVS_SWEEP_VOLUME)   # synchronous: every rank done, rows mode's bands on GPU 0
+                dt = time.perf_counter() - t0
+                depth = comm.fetch(want_cost=False)
+                crc = zlib.crc32(np.ascontiguousarray(depth).tobytes())
+                if crc != crc1:
+                    raise SystemExit("via-comm %s: depth crc %08x, the single-GPU sweep of the same view %08x" % (mode, crc, crc1))
+                ring = (N - 1) / N
+                results[mode] = {"ms_per_step": dt / args.steps * 1e3, "samples_per_s": float(P) * D * V / (dt / args.steps), "depth_crc32": crc,
+                                 "bytes_between_gpus_per_step": (8.0 * P * ring if mode == "rows" else
+                                                                 4.0 * P * D * 2 * ring * N if mode == "views" else (4.0 * P * D * ring + 8.0 * P * N * ring) * N)}
+            except mvs_amd.MvsError as e:   # e.g. no RCCL for a views mode: the rows line must still come out
+                if mode == "rows":
+                    raise
+                results[mode] = {"error": str(e)}
+    rows = results["rows"]
+    rows_alg_bytes = float(min(band, H)) * W * (V + 8.0 * D + 9.0)   # rank 0's band, SURVEY 8(d)
+    achieved = rows_alg_bytes / (rows["ms_per_step"] * 1e-3) / 1e9
+    out = {
+        "metric": "cost-volume samples/sec (pixels x planes x views)", "value": rows["samples_per_s"], "unit": "samples/s",
+        "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "clock_ramp_steps": CLOCK_RAMP_STEPS, "ms_per_step": rows["ms_per_step"],
+        "higher_is_better": True, "scaling": None if N == 1 else "strong", "vs_baseline": None, "dtype": DTYPE[args.sampler],
+        "data": "synthetic (%s)" % args.data + (" [TEST HOOK: %d ranks share one GPU (loopback collectives) -- not a measurement]" % N if same_device else ""),
+        "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V), "sampler": args.sampler,
+                   "entry": "mvs_comm_set_* + mvs_comm_run (include/mvs.h): one process, %d rank threads, inputs resident; each timed call returns when every "
+                            "rank has finished and -- rows mode -- its band of the depth and cost maps is on GPU 0 (peer copies, no collective)" % N,
+                   "shard": "rows", "rows_per_rank": band, "modes": results, "upload_all_ranks_ms": upload_ms,
+                   "single_gpu_resident_ms_per_step": single_ms, "speedup_vs_single_gpu_in_process": single_ms / rows["ms_per_step"], "device": info},
+        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_launch": rows_alg_bytes, "bytes_formula": "P_band (V + 8 D + 9), SURVEY.md 8(d): rank 0's row band",
+                     "ms_per_launch": rows["ms_per_step"], "ms_per_launch_covers": "one whole mvs_comm_run call (host dispatch to the rank threads, the band's sweep, "
+                     "the peer copies, the stream synchronisation): a lower bound on the kernel's own rate"},
+        "depth_crc32": rows["depth_crc32"], "depth_crc32_single_gpu": crc1,
+    }
+    if gt is not None:
+        out["depth_check"] = bool(np.median(np.abs(depth1 - gt)[16:-16, 16:-16]) <= 2.0 / D)
+    print(json.dumps(out), flush=True)
+
+
+def via_comm_child(args, timeout_s):
+    """rank 0 under a launcher, after its own timed region: the same N GPUs once more through the product's own multi-GPU entry, in a
+    CHILD process (a fresh process: no torch.distributed, its own contexts) with a time limit, so that a failure there cannot cost the
+    line.  Returns the child's parsed line, or {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--via-comm", "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--config", args.config, "--sampler", args.sampler, "--data", args.data, "--plane-groups", str(args.plane_groups)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                              "TORCHELASTIC_RUN_ID", "OMP_NUM_THREADS")}
+    try:
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            so, se = child.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            child.kill()   # (this exact child, by its PID)
+            child.communicate()
+            return {"error": "no result within %.0f s" % timeout_s}
+        lines = [l for l in so.splitlines() if l.startswith("{")]
+        if child.returncode != 0 or len(lines) != 1:
+            return {"error": "exit code %d: %s" % (child.returncode, (se or so)[-600:])}
+        rec = json.loads(lines[0])
+        return {"ms_per_step": rec["ms_per_step"], "samples_per_s": rec["value"], "entry": rec["config"]["entry"], "modes": rec["config"]["modes"],
+                "single_gpu_resident_ms_per_step": rec["config"]["single_gpu_resident_ms_per_step"],
+                "speedup_vs_single_gpu_in_process": rec["config"]["speedup_vs_single_gpu_in_process"], "depth_crc32": rec["depth_crc32"], "data": rec["data"]}
+    except Exception as e:   # never let this block cost the line
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,6 +375,11 @@ def main():
                     help="views sharding: all-reduce the volume in this many plane groups, overlapped with the sweep")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (for rocprofv3 runs: keeps per-kernel averages to the timed variant)")
+    ap.add_argument("--via-comm", action="store_true",
+                    help="ONE process drives the N GPUs through the C ABI's communicator (mvs_comm_set_* + mvs_comm_run: rank threads, inputs "
+                         "resident, rows mode gathers the depth bands on GPU 0 by peer copies) instead of one process per GPU under torch.distributed")
+    ap.add_argument("--via-comm-modes", default=None, help="--via-comm: comma-separated modes to time (rows,views,views_scatter); default rows, plus the views modes unless --no-extras")
+    ap.add_argument("--via-comm-timeout", type=float, default=240.0, help="seconds the launcher's rank 0 waits for its --via-comm child before giving up on the via_comm block")
     ap.add_argument("--data", default="scene", choices=["scene", "noise"],
                     help="scene: analytic surface ray-cast per view (SURVEY 8d, seed 0x5EED0001); noise: i.i.d. u8 (seed 0x5EED0002)")
     args = ap.parse_args()
@@ -252,13 +387,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and args.gpus > 1:
-        # one process drives one GPU: without a launcher only GPU 0 would work and the line would claim N of them
-        raise SystemExit("bench.py --gpus %d needs one process per GPU: launch it as\n  python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d --steps %d --warmup %d"
-                         % (args.gpus, args.gpus, args.gpus, args.steps, args.warmup))
-    args.gpus = world   # always report the ranks that actually ran
     same_device = os.environ.get("MVS_BENCH_SAME_DEVICE") == "1"
+    if args.via_comm:
+        if world > 1:
+            raise SystemExit("bench.py --via-comm is ONE process driving N GPUs: do not start it under torch.distributed.run")
+        return run_via_comm(args, same_device)
+    if world == 1 and args.gpus > 1:
+        # One process drives one GPU: the launcher is started HERE, as a child process, before torch is imported or anything touches a
+        # GPU (never an exec: a process that has initialised the GPU must not be replaced), with this command line; its output is this
+        # process's output (inherited descriptors) and its exit code is returned.
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("bench.py: --gpus %d without a launcher: starting `%s`" % (args.gpus, " ".join(cmd[1:10]) + " bench.py ..."), file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.call(cmd))
+    args.gpus = world   # always report the ranks that actually ran
 
     import numpy as np
     import torch  # first: libmvs_hip.so must share torch's HIP runtime (same soname)
@@ -453,6 +601,17 @@ def main():
                                   "sweep_ms": r["sweep_ms"], "views_per_rank": r["views"], "collective_bytes_per_rank_per_step": r["collective_bytes_per_rank"],
                                   "depth_crc32": r["crc"]}
 
+    # the same N GPUs through the product's own multi-GPU entry (mvs_comm_*: one process, rank threads, resident inputs), run by rank 0
+    # as a child process while the other ranks idle on the host (a gloo barrier: no GPU work queued by anybody meanwhile)
+    via_comm = None
+    if world > 1 and not args.no_extras and shard != "frames":
+        import datetime
+        idle = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=args.via_comm_timeout + 600))
+        torch.cuda.synchronize()
+        if rank == 0:
+            via_comm = via_comm_child(args, args.via_comm_timeout)
+        dist.barrier(group=idle)
+
     fused_ms = None
     if args.fused and world == 1:
         for _ in range(2):
@@ -560,9 +719,9 @@ def main():
             n_cold = max(10, args.steps)
             # the library reuses the region plan when a new view set has the view matrices, planes and slots of the last one (a fixed rig's
             # next frames); the cold step proper is a set with NEW cameras, so the reuse is switched off for it and reported beside it
-            os.environ["MVS_NO_PLAN_CACHE"] = "1"
+            cctx.set_plan_cache(False)
             cold_ms = time_cold()
-            del os.environ["MVS_NO_PLAN_CACHE"]
+            cctx.set_plan_cache(True)
             same_rig_ms = time_cold()
             cold_crc = zlib.crc32(np.ascontiguousarray(cctx.sweep_fetch()[0]).tobytes())
             cold_shape = cctx.plan_shape()
@@ -644,6 +803,8 @@ def main():
             "depth_crc32": primary["crc"],   # equal across N for the strong-scaling shardings (asserted against the in-process single-GPU run)
             "depth_crc32_single_gpu": crc1,
         }
+        if via_comm is not None:
+            out["via_comm"] = via_comm
         if cold is not None:
             out["cold_step"] = cold
         if general_ms is not None:

@@ -196,6 +196,10 @@ int mvs_sweep_row_granularity_of(const mvs_ctx *ctx);   /* what the context's cu
  * (same thread shape; projection, reciprocal, trunc / fract and frame tests once per (column, plane, view) and per (row, plane, view);
  * bit-identical to 1 / 2).  For the exact sampler the value names what served the LAST run. */
 int mvs_sweep_plan_shape(const mvs_ctx *ctx);
+/* diagnostic: the fixed sampler reuses its region plan when a new view set has the view matrices, planes and slots of the last planned
+ * one (a fixed rig's next frames; the plan depends on the cameras, not on the frames).  enable = 0 makes every view set plan again
+ * (bench.py's cold step times the planner that way); results are identical either way.  Default: enabled. */
+int mvs_sweep_set_plan_cache(mvs_ctx *ctx, int enable);
 /* per-pixel depth selection over the packed volume (async); valid after MVS_SWEEP_VOLUME runs or
  * after the caller has reduced the volume across ranks in place */
 int mvs_sweep_argmin(mvs_ctx *ctx);
@@ -294,6 +298,26 @@ int mvs_comm_mode(const mvs_comm *comm);
 int mvs_comm_set_plane_groups(mvs_comm *comm, int groups); /* MVS_SHARD_VIEWS: plane groups of the all-reduce pipeline, 1..64 */
 int mvs_sweep_sharded(mvs_comm *comm, const float main_cam[16], const uint8_t *main_hw, int nviews, const float *side_cams /* nviews*16 */,
                       const uint8_t *const *side_frames, int nplanes, float z_lo, float z_hi, float *depth_hw, float *cost_hw /* nullable */);
+/* The RESIDENT form (the staged mvs_sweep_set_* / mvs_sweep_run of one context, for a communicator): a sequence's caller -- the loop of
+ * recon.cpp:65-117 over main frames -- uploads once and sweeps many times; nothing crosses PCIe, is re-planned or re-prepared between runs.
+ *   mvs_comm_set_planes / _set_main / _set_views   upload to EVERY rank (each keeps all side views and the plan, so any mode can run on them;
+ *                        host pointers are not retained: the calls return when the copies have landed).  Like a context, a new main view
+ *                        invalidates the side views (their matrices depend on the main camera): set planes, then main, then views.
+ *   mvs_comm_run(flags)  one sweep of what is resident, in the current mode; returns when every rank has finished.  The depth and best-cost
+ *                        maps of the WHOLE view are left on rank 0's GPU (mvs_sweep_depth_device / _cost_device of mvs_comm_context(comm, 0);
+ *                        not the index map): MVS_SHARD_ROWS copies each rank's band there by peer copies over xGMI behind the rank's sweep
+ *                        (4 bytes per pixel and map in total, no collective, no host memory); the views modes end with the selection on
+ *                        every rank.  flags: 0, or MVS_SWEEP_VOLUME to make MVS_SHARD_ROWS materialise each rank's band of the packed
+ *                        volume as well (the views modes always build it).  The persistent rank threads do the work: no thread is created,
+ *                        no frame uploaded and no plan made per call.
+ *   mvs_comm_fetch       download rank 0's maps (either pointer may be NULL).
+ * mvs_sweep_sharded = set_planes + set_main + set_views + run + fetch in one pass over the ranks (in a views mode each rank uploads only its
+ * own views, and in rows mode the bands go straight to the caller's host maps); what it uploaded stays resident for mvs_comm_run in the same mode. */
+int mvs_comm_set_planes(mvs_comm *comm, int nplanes, float z_lo, float z_hi);
+int mvs_comm_set_main(mvs_comm *comm, const float main_cam[16], const uint8_t *main_hw);
+int mvs_comm_set_views(mvs_comm *comm, int nviews, const float *side_cams /* nviews*16 */, const uint8_t *const *side_frames);
+int mvs_comm_run(mvs_comm *comm, unsigned flags);
+int mvs_comm_fetch(mvs_comm *comm, float *depth_hw /* nullable */, float *cost_hw /* nullable */);
 
 /* ---- kernel timing (HIP events on the context's stream) ---------------------------------------- */
 #define MVS_K_SWEEP 0

@@ -1,10 +1,13 @@
 // comm.cpp -- the sweep of ONE main view on several GPUs of one node behind the C ABI (mvs_comm_*, mvs_sweep_sharded).
 //
 // SURVEY.md section 8(b), multi-GPU row / 8(e).  One host thread per GPU drives its context, as the C ABI asks ("calls on a context
-// are serialised by the caller").  Three ways to split the work (mvs_comm_set_mode):
+// are serialised by the caller"); the threads are PERSISTENT (started by the first call that needs more than one rank, parked on a
+// condition variable between calls, joined by mvs_comm_destroy) and a call hands them one job.  Three ways to split the work
+// (mvs_comm_set_mode):
 //   MVS_SHARD_ROWS (default)   every GPU holds all side views and sweeps a band of the main view's pixel rows with depth selection
-//                              inside the kernel (rows are independent); each band goes straight from its GPU into the
-//                              caller's depth map -- 4 bytes per pixel in total, NO data-path collective.  The split that scales.
+//                              inside the kernel (rows are independent); NO data-path collective: the bands go straight
+//                              from their GPUs into the caller's host maps (mvs_sweep_sharded) or, in the resident form, into rank 0's
+//                              depth / cost maps by peer copies over xGMI (mvs_comm_run: 4 bytes per pixel and map).  The split that scales.
 //   MVS_SHARD_VIEWS            the north_star's split: the V side views are dealt to the GPUs, every GPU builds the packed volume of
 //                              its views, the volumes are summed over xGMI with RCCL -- an all-reduce per plane group on a second
 //                              stream while the next group is being swept -- and depth is selected from the summed volume.
@@ -12,30 +15,35 @@
 //                              selection per rank, all-gather of the 8-byte partials, merge in plane order (plane count a multiple
 //                              of the GPU count; otherwise it runs as MVS_SHARD_VIEWS).
 // Cells are integers (count << CS | sum): sums are exact, every mode returns the single-GPU depth map bit for bit.
+// Two forms: mvs_sweep_sharded (host frames in, host maps out, one call) and the RESIDENT form -- mvs_comm_set_planes / _set_main /
+// _set_views upload once (every rank keeps all views, so any mode can run on them), mvs_comm_run sweeps what is resident and leaves the
+// maps on rank 0's GPU, mvs_comm_fetch downloads them: what a caller with a sequence, and bench.py --via-comm, time.
 // Failure handling: every rank does its local work and its allocations first; the ranks then meet at a host-side barrier and look
 // at a shared error flag BEFORE anybody enters a collective -- a rank that failed early makes all of them skip the exchange instead
 // of leaving the others waiting in RCCL for ever.  A failure inside the exchange aborts every communicator (ncclCommAbort), which
-// unblocks the other ranks; the communicator is unusable afterwards (mvs_sweep_sharded then returns MVS_ESTATE).
+// unblocks the other ranks; the communicator is unusable afterwards (calls return MVS_ESTATE).
 // Abort is best effort: ncclCommAbort is called on every rank's communicator from the failing rank's thread while the other ranks'
 // threads may be inside a collective on theirs -- that is what unblocks them; RCCL documents the call as safe from another thread, and the
 // communicator is never used again.
 // RCCL is resolved with dlopen at mvs_comm_create (libmvs_hip.so itself has no link dependency on librccl, and a process that has
 // already loaded one -- PyTorch -- shares it), but only the two view-sharded modes need it: a default librccl that cannot be loaded leaves
 // a communicator that serves MVS_SHARD_ROWS (no collective) and reports the loader's message when a views mode is selected; the RCCL
-// communicators themselves (ncclCommInitAll) are created by the first sweep that exchanges anything.  MVS_RCCL_LIBRARY names another
-// library file -- an explicit request, so a file that cannot be loaded fails mvs_comm_create (tests: a missing one, and the loopback
-// stand-in of tests/loopback_rccl/ that lets n ranks share the one GPU of a test box).
-// Test hooks (never set in production): MVS_COMM_ALLOW_SAME_DEVICE=1 accepts a device listed more than once (RCCL itself refuses that;
-// the loopback library does not); MVS_COMM_TEST_FAIL_RANK=r makes rank r fail in its local phase, as a device allocation would;
-// MVS_COMM_ALLREDUCE=1 runs the scatter mode as the all-reduce pipeline.
+// communicators themselves (ncclCommInitAll) are created by the first sweep that exchanges anything.
+// Test hooks (hooks.hpp: honoured only under MVS_TEST_HOOKS=1, read once by mvs_comm_create): MVS_RCCL_LIBRARY names another library
+// file -- an explicit request, so a file that cannot be loaded fails mvs_comm_create (tests: a missing one, and the loopback stand-in of
+// tests/loopback_rccl/ that lets n ranks share the one GPU of a test box); MVS_COMM_ALLOW_SAME_DEVICE=1 accepts a device listed more than
+// once (RCCL itself refuses that; the loopback library does not); MVS_COMM_TEST_FAIL_RANK=r makes rank r fail in its local phase, as a
+// device allocation would; MVS_COMM_ALLREDUCE=1 runs the scatter mode as the all-reduce pipeline.
 #include "mvs_internal.hpp"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -54,11 +62,10 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 
-    bool load()
+    bool load(const std::string &override_name)
     {
-        const char *override_name = getenv("MVS_RCCL_LIBRARY");
         std::string last;
-        for (const char *name : {override_name ? override_name : "librccl.so.1", override_name ? override_name : "librccl.so"}) {
+        for (const char *name : {override_name.empty() ? "librccl.so.1" : override_name.c_str(), override_name.empty() ? "librccl.so" : override_name.c_str()}) {
             (void)dlerror();
             handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (handle) break;
@@ -86,30 +93,11 @@ struct Rccl {
     bool usable() const { return CommInitAll && CommDestroy && CommAbort && ReduceScatter && AllGather && AllReduce && GetErrorString; }
 };
 
-}  // namespace
-
-struct mvs_comm {
-    int n = 0, W = 0, H = 0;
-    std::vector<int> devices;
-    std::vector<mvs_ctx *> ctx;
-    std::vector<ncclComm_t> comms;
-    std::vector<mvs::DevBuf> slice, part, parts;  // per rank: the plane slice it owns, its partial bests, everybody's partial bests
-    std::vector<hipStream_t> comm_stream;         // per rank: the collectives of MVS_SHARD_VIEWS run beside the sweep of the next plane group
-    std::vector<std::vector<hipEvent_t>> events;  // per rank: plane group swept / plane group summed
-    int mode = MVS_SHARD_ROWS;
-    int plane_groups = 4;
-    bool broken = false;  // a collective failed and the communicators were aborted
-    Rccl rccl;
-    char err[512] = {0};
-};
-
-namespace {
-// all ranks meet here between their local work and the exchange (C++17: no std::barrier)
+// all ranks meet here between their local work and the exchange (C++17: no std::barrier); reusable, lives with the communicator
 struct HostBarrier {
     std::mutex m;
     std::condition_variable cv;
-    int waiting = 0, generation = 0, n;
-    explicit HostBarrier(int n_) : n(n_) {}
+    int waiting = 0, generation = 0, n = 1;
     void arrive_and_wait()
     {
         std::unique_lock<std::mutex> lock(m);
@@ -123,7 +111,112 @@ struct HostBarrier {
         }
     }
 };
+
+// The rank threads: started once, parked between calls.  dispatch() hands every rank the same job (called with the rank) and returns when
+// all of them are through it; rank 0's share runs on the CALLING thread (one wake-up less on the critical path, and n = 1 needs no thread).
+struct RankThreads {
+    std::vector<std::thread> threads;  // ranks 1 .. n-1
+    std::mutex m;
+    std::condition_variable start, done;
+    const std::function<void(int)> *job = nullptr;
+    long generation = 0;
+    int remaining = 0;
+    bool quit = false;
+
+    void loop(int rank)
+    {
+        long seen = 0;
+        for (;;) {
+            const std::function<void(int)> *j;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                start.wait(lock, [&] { return quit || generation != seen; });
+                if (quit) return;
+                seen = generation;
+                j = job;
+            }
+            (*j)(rank);
+            {
+                std::lock_guard<std::mutex> lock(m);
+                if (--remaining == 0) done.notify_one();
+            }
+        }
+    }
+    void dispatch(int n, const std::function<void(int)> &f)
+    {
+        if (n > 1) {
+            std::lock_guard<std::mutex> lock(m);
+            if (threads.empty())
+                for (int r = 1; r < n; r++) threads.emplace_back(&RankThreads::loop, this, r);
+            job = &f;
+            remaining = n - 1;
+            generation++;
+        }
+        if (n > 1) start.notify_all();
+        f(0);
+        if (n > 1) {
+            std::unique_lock<std::mutex> lock(m);
+            done.wait(lock, [&] { return remaining == 0; });
+            job = nullptr;
+        }
+    }
+    void stop()
+    {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            quit = true;
+        }
+        start.notify_all();
+        for (auto &t : threads) t.join();
+        threads.clear();
+    }
+};
+
+// what one call asks of every rank (null / false members: leave what is resident alone)
+struct Job {
+    const char *who = "mvs_comm";
+    bool set_planes = false;
+    int nplanes = 0;
+    float z_lo = 0.f, z_hi = 0.f;
+    const float *main_cam = nullptr;
+    const uint8_t *main_hw = nullptr;
+    bool set_views = false, shard_upload = false;  // shard_upload: a views mode uploads only the rank's own views (the one-call form)
+    int nviews = 0;
+    const float *side_cams = nullptr;
+    const uint8_t *const *side_frames = nullptr;
+    bool run = false;
+    unsigned run_flags = 0;                      // rows mode: MVS_SWEEP_VOLUME also materialises the band of the volume
+    float *depth_hw = nullptr, *cost_hw = nullptr;  // run: the maps go to the caller's host memory; both null: they stay on rank 0's GPU
+};
+
 }  // namespace
+
+struct mvs_comm {
+    int n = 0, W = 0, H = 0;
+    std::vector<int> devices;
+    std::vector<mvs_ctx *> ctx;
+    std::vector<ncclComm_t> comms;
+    std::vector<mvs::DevBuf> slice, part, parts;  // per rank: the plane slice it owns, its partial bests, everybody's partial bests
+    std::vector<hipStream_t> comm_stream;         // per rank: the collectives of MVS_SHARD_VIEWS run beside the sweep of the next plane group
+    std::vector<std::vector<hipEvent_t>> events;  // per rank: plane group swept / plane group summed
+    int mode = MVS_SHARD_ROWS;
+    int plane_groups = 4;
+    bool broken = false;  // a collective failed and the communicators were aborted
+    std::mutex abort_once;  // (a member: communicators of one process do not share it)
+    Rccl rccl;
+    mvs::Hooks hooks;     // environment switches as read by mvs_comm_create (hooks.hpp)
+    RankThreads ranks;
+    HostBarrier meet;
+    // what is resident on the ranks' GPUs (the resident form, and what mvs_sweep_sharded leaves behind)
+    bool have_main = false, have_views = false, have_planes = false, have_result = false;
+    int V = 0, D = 0;
+    std::vector<int> res_v0, res_vn;  // per rank: the global view range its context holds
+    // per call
+    std::vector<int> rc;
+    std::vector<std::string> msg;
+    std::atomic<int> failed{0};
+    char err[512] = {0};
+};
 
 using namespace mvs;
 
@@ -148,8 +241,8 @@ mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height)
         comm_fail(nullptr, MVS_EINVAL, "mvs_comm_create: need 1..64 devices (n = %d)", n);
         return nullptr;
     }
-    const char *same = getenv("MVS_COMM_ALLOW_SAME_DEVICE");  // test hook: n ranks on one GPU (with the loopback collective library)
-    for (int i = 0; i < n && !(same && atoi(same) != 0); i++)
+    const Hooks hooks = read_hooks();
+    for (int i = 0; i < n && !hooks.comm_allow_same_device; i++)  // (test hook: n ranks on one GPU, with the loopback collective library)
         for (int j = 0; j < i; j++)
             if (devices[i] == devices[j]) {
                 comm_fail(nullptr, MVS_EINVAL, "mvs_comm_create: device %d listed twice (one rank per GPU)", devices[i]);
@@ -160,6 +253,7 @@ mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height)
         comm_fail(nullptr, MVS_ENOMEM, "mvs_comm_create: out of host memory");
         return nullptr;
     }
+    c->hooks = hooks;
     c->n = n;
     c->W = width;
     c->H = height;
@@ -169,9 +263,14 @@ mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height)
     c->parts.resize(n);
     c->comm_stream.assign(n, nullptr);
     c->events.resize(n);
+    c->res_v0.assign(n, 0);
+    c->res_vn.assign(n, 0);
+    c->rc.assign(n, MVS_OK);
+    c->msg.resize(n);
+    c->meet.n = n;
     // before anything touches a GPU (the error path of a missing library must not need one).  Only the view-sharded modes need RCCL:
     // a library named explicitly must load; the default one may be absent -- rows mode works without, a views mode then says why not
-    if (!c->rccl.load() && getenv("MVS_RCCL_LIBRARY")) {
+    if (!c->rccl.load(hooks.rccl_library) && !hooks.rccl_library.empty()) {
         comm_fail(nullptr, MVS_EHIP, "mvs_comm_create: %s", c->rccl.error.c_str());
         mvs_comm_destroy(c);
         return nullptr;
@@ -190,15 +289,15 @@ mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height)
 }
 
 // the RCCL communicators, created by the first sweep that exchanges anything (rows mode never does)
-static int comm_init_rccl(mvs_comm *c)
+static int comm_init_rccl(mvs_comm *c, const char *who)
 {
     if (!c->comms.empty()) return MVS_OK;
-    if (!c->rccl.usable()) return comm_fail(c, MVS_EHIP, "mvs_sweep_sharded: the view-sharded modes need RCCL: %s", c->rccl.error.c_str());
+    if (!c->rccl.usable()) return comm_fail(c, MVS_EHIP, "%s: the view-sharded modes need RCCL: %s", who, c->rccl.error.c_str());
     c->comms.assign(c->n, nullptr);
     const ncclResult_t r = c->rccl.CommInitAll(c->comms.data(), c->n, c->devices.data());
     if (r != ncclSuccess) {
         c->comms.clear();
-        return comm_fail(c, MVS_EHIP, "mvs_sweep_sharded: ncclCommInitAll failed: %s", c->rccl.GetErrorString(r));
+        return comm_fail(c, MVS_EHIP, "%s: ncclCommInitAll failed: %s", who, c->rccl.GetErrorString(r));
     }
     return MVS_OK;
 }
@@ -206,6 +305,7 @@ static int comm_init_rccl(mvs_comm *c)
 void mvs_comm_destroy(mvs_comm *c)
 {
     if (!c) return;
+    c->ranks.stop();
     for (size_t i = 0; i < c->ctx.size(); i++) {
         (void)hipSetDevice(c->devices[i]);
         (void)mvs_synchronize(c->ctx[i]);
@@ -246,93 +346,97 @@ int mvs_comm_set_plane_groups(mvs_comm *c, int groups)
     return MVS_OK;
 }
 
-int mvs_sweep_sharded(mvs_comm *c, const float main_cam[16], const uint8_t *main_hw, int nviews, const float *side_cams,
-                      const uint8_t *const *side_frames, int nplanes, float z_lo, float z_hi, float *depth_hw, float *cost_hw)
+}  // extern "C"
+
+// One job on every rank.  The caller has checked the arguments; this function owns the sharding arithmetic, the two phases and the
+// failure protocol described at the top of the file.
+static int comm_execute(mvs_comm *c, const Job &job)
 {
-    if (!c) return MVS_EINVAL;
-    if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_sweep_sharded: the communicators were aborted after a failed collective; create a new mvs_comm");
-    if (!main_cam || !main_hw || !depth_hw || nviews < 0 || (nviews > 0 && (!side_cams || !side_frames)))
-        return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: null argument");
-    if (nplanes < 1 || nplanes > 4096) return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: nplanes=%d out of range 1..4096", nplanes);
-    // everything a rank could reject for the arguments' sake is checked here, once
-    for (int v = 0; v < nviews; v++)
-        if (!side_frames[v]) return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: side_frames[%d] is null", v);
-    const int view_limit = mvs_sweep_sampler(c->ctx[0]) == MVS_SAMPLER_FIXED ? 255 : 256;  // the SUMMED cells must hold every view's count
-    if (nviews > view_limit) return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: %d views, the sampler's cells hold at most %d", nviews, view_limit);
-    for (int r = 1; r < c->n; r++)
-        if (mvs_sweep_sampler(c->ctx[r]) != mvs_sweep_sampler(c->ctx[0]))
-            return comm_fail(c, MVS_ESTATE, "mvs_sweep_sharded: rank %d uses another sampler than rank 0 (cells of different formats cannot be summed)", r);
     const int n = c->n;
     const int W = c->W, H = c->H;
     const size_t P = (size_t)W * H;
     const bool rows = c->mode == MVS_SHARD_ROWS;
-    if (!rows) {
-        const int e = comm_init_rccl(c);
+    const int nviews = job.set_views ? job.nviews : c->V;
+    const int nplanes = job.set_planes ? job.nplanes : c->D;
+    const bool exchange = job.run && !rows;                                       // RCCL collectives
+    const bool gather = job.run && rows && !job.depth_hw && !job.cost_hw && n > 1;  // rows, resident: the bands travel to rank 0 by peer copies
+    if (exchange) {
+        const int e = comm_init_rccl(c, job.who);
         if (e) return e;
     }
-    const char *fail_rank_env = getenv("MVS_COMM_TEST_FAIL_RANK");  // test hook: this rank gives up in its local phase
-    const int test_fail_rank = fail_rank_env ? atoi(fail_rank_env) : -1;
     // plane slices of equal size: reduce-scatter; otherwise (or with the test hook MVS_COMM_ALLREDUCE set) the all-reduce pipeline
-    const bool scatter = c->mode == MVS_SHARD_VIEWS_SCATTER && nplanes % n == 0 && getenv("MVS_COMM_ALLREDUCE") == nullptr;
+    const bool scatter = c->mode == MVS_SHARD_VIEWS_SCATTER && nplanes > 0 && nplanes % n == 0 && !c->hooks.comm_allreduce;
     const int slice_planes = nplanes / n;
     // row bands on the sweep's tile-row granularity, equal but for the last
     const int gran = mvs_sweep_row_granularity_of(c->ctx[0]);
     const int band = ((H + gran - 1) / gran + n - 1) / n * gran;
     // plane groups of the all-reduce pipeline, on the sweep's plane granularity
     std::vector<std::pair<int, int>> groups;
-    {
+    if (exchange && !scatter) {
         const int pg = mvs_sweep_plane_granularity();
         const int per = std::max(pg, ((nplanes + c->plane_groups - 1) / c->plane_groups + pg - 1) / pg * pg);
         for (int first = 0; first < nplanes; first += per) groups.emplace_back(first, std::min(per, nplanes - first));
     }
-    std::vector<int> rc(n, MVS_OK);
-    std::vector<std::string> msg(n);
-    std::atomic<int> failed{0};
-    HostBarrier meet(n);
-    auto abort_all = [&]() {  // a collective failed on this rank: unblock everybody else (idempotent enough: RCCL tolerates a second abort of a dead communicator poorly, so once)
-        static std::mutex once;
-        std::lock_guard<std::mutex> lock(once);
+    std::fill(c->rc.begin(), c->rc.end(), MVS_OK);
+    for (auto &m : c->msg) m.clear();
+    c->failed.store(0);
+    auto abort_all = [&]() {  // a collective failed on this rank: unblock everybody else (RCCL tolerates a second abort of a dead communicator poorly, so once)
+        std::lock_guard<std::mutex> lock(c->abort_once);
         if (c->broken) return;
         c->broken = true;
         for (ncclComm_t k : c->comms)
             if (k) (void)c->rccl.CommAbort(k);
     };
-    auto worker = [&](int r) {
+    const std::function<void(int)> worker = [&](int r) {
         mvs_ctx *x = c->ctx[r];
         auto fail_here = [&](int code, const char *what, const char *detail) {
-            rc[r] = code;
-            msg[r] = std::string(what) + ": " + detail;
-            failed.store(1);
+            c->rc[r] = code;
+            c->msg[r] = std::string(what) + ": " + detail;
+            c->failed.store(1);
         };
         uint32_t *vol = nullptr;
         hipStream_t st = nullptr;
         const int per = (nviews + n - 1) / n;  // view shard of this rank: a contiguous range, empty for ranks beyond the view count
         const int v0 = rows ? 0 : std::min(r * per, nviews), vn = rows ? nviews : std::max(0, std::min(per, nviews - v0));
         const int r0 = std::min(r * band, H), rn = std::max(0, std::min(band, H - r0));
-        // ---- phase 1: everything local (inputs, allocations; in rows mode the whole job) ----
+        int lv0 = v0;  // first view of the shard as the rank's context numbers its resident views
+        // ---- phase 1: everything local (inputs, allocations; in rows mode the whole sweep) ----
         [&]() {
             if (hipSetDevice(c->devices[r]) != hipSuccess) return fail_here(MVS_EHIP, "hipSetDevice", "failed");
-            if (r == test_fail_rank) return fail_here(MVS_ENOMEM, "test hook", "MVS_COMM_TEST_FAIL_RANK names this rank");
+            if (r == c->hooks.comm_fail_rank && (job.run || job.set_views)) return fail_here(MVS_ENOMEM, "test hook", "MVS_COMM_TEST_FAIL_RANK names this rank");
             int e;
             st = x->stream;
-            if ((e = mvs_sweep_set_main(x, main_cam, main_hw))) return fail_here(e, "mvs_sweep_set_main", mvs_last_error(x));
-            if ((e = mvs_sweep_set_views(x, vn, side_cams + 16 * (size_t)v0, side_frames + v0))) return fail_here(e, "mvs_sweep_set_views", mvs_last_error(x));
-            if ((e = mvs_sweep_set_planes(x, nplanes, z_lo, z_hi))) return fail_here(e, "mvs_sweep_set_planes", mvs_last_error(x));
+            // planes before views: mvs_sweep_set_views plans with the planes it finds (one planner pass per call, not two)
+            if (job.set_planes && (e = sweep_set_planes_impl(x, job.nplanes, job.z_lo, job.z_hi, false))) return fail_here(e, "mvs_sweep_set_planes", mvs_last_error(x));
+            if (job.main_hw && (e = sweep_set_main_impl(x, job.main_cam, job.main_hw, false))) return fail_here(e, "mvs_sweep_set_main", mvs_last_error(x));
+            if (job.set_views) {
+                const int u0 = job.shard_upload ? v0 : 0, un = job.shard_upload ? vn : nviews;
+                if ((e = sweep_set_views_impl(x, un, job.side_cams + 16 * (size_t)u0, job.side_frames + u0, false))) return fail_here(e, "mvs_sweep_set_views", mvs_last_error(x));
+                c->res_v0[r] = u0;
+                c->res_vn[r] = un;
+            }
+            if (!job.run) {
+                if ((e = mvs_synchronize(x))) return fail_here(e, "mvs_synchronize", mvs_last_error(x));  // the caller's buffers are not retained
+                return;
+            }
+            lv0 = v0 - c->res_v0[r];
+            if (lv0 < 0 || lv0 + vn > c->res_vn[r])
+                return fail_here(MVS_ESTATE, job.who, "this rank does not hold the views the mode needs (uploaded by mvs_sweep_sharded under another mode): call mvs_comm_set_views");
             if (rows) {
                 if (rn > 0) {
-                    if ((e = mvs_sweep_run_rows(x, 0, nviews, r0, rn, MVS_SWEEP_FUSED_ARGMIN))) return fail_here(e, "mvs_sweep_run_rows", mvs_last_error(x));
-                    // the band goes straight into the caller's maps: 4 bytes per pixel and map, no collective
-                    if (hipMemcpyAsync(depth_hw + (size_t)r0 * W, (const float *)x->depth.ptr + (size_t)r0 * W, (size_t)rn * W * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+                    if ((e = mvs_sweep_run_rows(x, 0, nviews, r0, rn, MVS_SWEEP_FUSED_ARGMIN | (job.run_flags & MVS_SWEEP_VOLUME)))) return fail_here(e, "mvs_sweep_run_rows", mvs_last_error(x));
+                    // the one-call form: the band goes straight into the caller's maps: 4 bytes per pixel and map, no collective
+                    if (job.depth_hw && hipMemcpyAsync(job.depth_hw + (size_t)r0 * W, (const float *)x->depth.ptr + (size_t)r0 * W, (size_t)rn * W * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
                         return fail_here(MVS_EHIP, "hipMemcpyAsync", "depth band");
-                    if (cost_hw && hipMemcpyAsync(cost_hw + (size_t)r0 * W, (const float *)x->cost.ptr + (size_t)r0 * W, (size_t)rn * W * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+                    if (job.cost_hw && hipMemcpyAsync(job.cost_hw + (size_t)r0 * W, (const float *)x->cost.ptr + (size_t)r0 * W, (size_t)rn * W * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
                         return fail_here(MVS_EHIP, "hipMemcpyAsync", "cost band");
-                }
-                if ((e = mvs_synchronize(x))) return fail_here(e, "mvs_synchronize", mvs_last_error(x));
+                }   // (rank 0 always has rows: its maps exist when the others copy their bands into them)
+                if (!gather && (e = mvs_synchronize(x))) return fail_here(e, "mvs_synchronize", mvs_last_error(x));
                 return;
             }
             // views: the first sweep launch allocates the volume and the outputs; the buffers of the exchange follow
             if (scatter) {
-                if ((e = mvs_sweep_run(x, 0, vn, MVS_SWEEP_VOLUME))) return fail_here(e, "mvs_sweep_run", mvs_last_error(x));
+                if ((e = mvs_sweep_run(x, lv0, vn, MVS_SWEEP_VOLUME))) return fail_here(e, "mvs_sweep_run", mvs_last_error(x));
                 if ((e = ensure(x, c->slice[r], (size_t)slice_planes * P * 4)) || (e = ensure(x, c->part[r], P * 8)) || (e = ensure(x, c->parts[r], (size_t)n * P * 8)))
                     return fail_here(e, "device allocation", mvs_last_error(x));
             } else {
@@ -342,17 +446,31 @@ int mvs_sweep_sharded(mvs_comm *c, const float main_cam[16], const uint8_t *main
                     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail_here(MVS_EHIP, "hipEventCreate", "failed");
                     c->events[r].push_back(ev);
                 }
-                if ((e = mvs_sweep_run_planes(x, 0, vn, groups[0].first, groups[0].second, MVS_SWEEP_VOLUME))) return fail_here(e, "mvs_sweep_run_planes", mvs_last_error(x));
+                if ((e = mvs_sweep_run_planes(x, lv0, vn, groups[0].first, groups[0].second, MVS_SWEEP_VOLUME))) return fail_here(e, "mvs_sweep_run_planes", mvs_last_error(x));
             }
             size_t vol_bytes = 0;
             vol = (uint32_t *)mvs_sweep_volume_device(x, &vol_bytes);
             if (!vol) return fail_here(MVS_ESTATE, "mvs_sweep_volume_device", mvs_last_error(x));
         }();
-        if (rows) return;
+        if (!exchange && !gather) return;
         // ---- every rank is through its local work: does anybody have to give up? ----
-        meet.arrive_and_wait();
-        if (failed.load()) {
-            if (rc[r] == MVS_OK) (void)mvs_synchronize(x);
+        c->meet.arrive_and_wait();
+        if (c->failed.load()) {
+            if (c->rc[r] == MVS_OK) (void)mvs_synchronize(x);
+            return;
+        }
+        int e;
+        if (gather) {
+            // rows, resident: rank 0's maps exist (its launch is queued) and every other rank copies its band into them over xGMI -- a peer
+            // copy on the rank's own stream behind its sweep; 4 bytes per pixel and map in total, no collective, no host memory
+            if (r > 0 && rn > 0) {
+                mvs_ctx *x0 = c->ctx[0];
+                const size_t off = (size_t)r0 * W, bytes = (size_t)rn * W * 4;
+                if (hipMemcpyPeerAsync((float *)x0->depth.ptr + off, c->devices[0], (const float *)x->depth.ptr + off, c->devices[r], bytes, st) != hipSuccess ||
+                    hipMemcpyPeerAsync((float *)x0->cost.ptr + off, c->devices[0], (const float *)x->cost.ptr + off, c->devices[r], bytes, st) != hipSuccess)
+                    fail_here(MVS_EHIP, "hipMemcpyPeerAsync", "band to rank 0");
+            }
+            if ((e = mvs_synchronize(x))) fail_here(e, "mvs_synchronize", mvs_last_error(x));
             return;
         }
         // ---- phase 2: the exchange ----
@@ -360,7 +478,6 @@ int mvs_sweep_sharded(mvs_comm *c, const float main_cam[16], const uint8_t *main
             fail_here(MVS_EHIP, what, c->rccl.GetErrorString(q));
             abort_all();
         };
-        int e;
         ncclResult_t q;
         if (scatter) {
             if ((q = c->rccl.ReduceScatter(vol, c->slice[r].ptr, (size_t)slice_planes * P, ncclUint32, ncclSum, c->comms[r], st)) != ncclSuccess) return collective_failed("ncclReduceScatter", q);
@@ -377,7 +494,7 @@ int mvs_sweep_sharded(mvs_comm *c, const float main_cam[16], const uint8_t *main
             // plane group g is summed over xGMI on the communication stream while group g + 1 is being swept on the context's stream
             hipStream_t cs = c->comm_stream[r];
             for (size_t g = 0; g < groups.size(); g++) {
-                if (g > 0 && (e = mvs_sweep_run_planes(x, 0, vn, groups[g].first, groups[g].second, MVS_SWEEP_VOLUME))) {
+                if (g > 0 && (e = mvs_sweep_run_planes(x, lv0, vn, groups[g].first, groups[g].second, MVS_SWEEP_VOLUME))) {
                     fail_here(e, "mvs_sweep_run_planes", mvs_last_error(x));
                     return abort_all();
                 }
@@ -403,21 +520,148 @@ int mvs_sweep_sharded(mvs_comm *c, const float main_cam[16], const uint8_t *main
                 return abort_all();
             }
         }
-        if (r == 0) {
-            if ((e = mvs_sweep_fetch(x, depth_hw, cost_hw, nullptr, nullptr))) fail_here(e, "mvs_sweep_fetch", mvs_last_error(x));
+        if (r == 0 && (job.depth_hw || job.cost_hw)) {
+            if ((e = mvs_sweep_fetch(x, job.depth_hw, job.cost_hw, nullptr, nullptr))) fail_here(e, "mvs_sweep_fetch", mvs_last_error(x));
         } else if ((e = mvs_synchronize(x))) {
             fail_here(e, "mvs_synchronize", mvs_last_error(x));
         }
     };
-    if (n == 1) {
-        worker(0);
-    } else {
-        std::vector<std::thread> threads;
-        for (int r = 0; r < n; r++) threads.emplace_back(worker, r);
-        for (auto &t : threads) t.join();
+    c->ranks.dispatch(n, worker);
+    // what the ranks hold now (a failed upload leaves the communicator without that input, like a context)
+    bool ok = true;
+    for (int r = 0; r < n; r++) ok = ok && c->rc[r] == MVS_OK;
+    if (job.set_planes) {
+        c->have_planes = ok;
+        c->D = job.nplanes;
     }
+    if (job.main_hw) {
+        c->have_main = ok;
+        c->have_views = false;  // the view matrices depend on the main camera (as mvs_sweep_set_main)
+    }
+    if (job.set_views) {
+        c->have_views = ok;
+        c->V = job.nviews;
+    }
+    if (job.run) c->have_result = ok;
     for (int r = 0; r < n; r++)
-        if (rc[r] != MVS_OK) return comm_fail(c, rc[r], "mvs_sweep_sharded: rank %d (device %d): %s", r, c->devices[r], msg[r].c_str());
+        if (c->rc[r] != MVS_OK) return comm_fail(c, c->rc[r], "%s: rank %d (device %d): %s", job.who, r, c->devices[r], c->msg[r].c_str());
+    return MVS_OK;
+}
+
+static int comm_check_views(mvs_comm *c, const char *who, int nviews)
+{
+    const int view_limit = mvs_sweep_sampler(c->ctx[0]) == MVS_SAMPLER_FIXED ? 255 : 256;  // the SUMMED cells must hold every view's count
+    if (nviews > view_limit) return comm_fail(c, MVS_EINVAL, "%s: %d views, the sampler's cells hold at most %d", who, nviews, view_limit);
+    for (int r = 1; r < c->n; r++)
+        if (mvs_sweep_sampler(c->ctx[r]) != mvs_sweep_sampler(c->ctx[0]))
+            return comm_fail(c, MVS_ESTATE, "%s: rank %d uses another sampler than rank 0 (cells of different formats cannot be summed)", who, r);
+    return MVS_OK;
+}
+
+extern "C" {
+
+int mvs_sweep_sharded(mvs_comm *c, const float main_cam[16], const uint8_t *main_hw, int nviews, const float *side_cams,
+                      const uint8_t *const *side_frames, int nplanes, float z_lo, float z_hi, float *depth_hw, float *cost_hw)
+{
+    if (!c) return MVS_EINVAL;
+    if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_sweep_sharded: the communicators were aborted after a failed collective; create a new mvs_comm");
+    if (!main_cam || !main_hw || !depth_hw || nviews < 0 || (nviews > 0 && (!side_cams || !side_frames)))
+        return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: null argument");
+    if (nplanes < 1 || nplanes > 4096) return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: nplanes=%d out of range 1..4096", nplanes);
+    // everything a rank could reject for the arguments' sake is checked here, once
+    for (int v = 0; v < nviews; v++)
+        if (!side_frames[v]) return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: side_frames[%d] is null", v);
+    int e = comm_check_views(c, "mvs_sweep_sharded", nviews);
+    if (e) return e;
+    Job job;
+    job.who = "mvs_sweep_sharded";
+    job.set_planes = true;
+    job.nplanes = nplanes;
+    job.z_lo = z_lo;
+    job.z_hi = z_hi;
+    job.main_cam = main_cam;
+    job.main_hw = main_hw;
+    job.set_views = true;
+    job.shard_upload = c->mode != MVS_SHARD_ROWS;  // a views mode: every rank uploads its own views only
+    job.nviews = nviews;
+    job.side_cams = side_cams;
+    job.side_frames = side_frames;
+    job.run = true;
+    job.depth_hw = depth_hw;
+    job.cost_hw = cost_hw;
+    return comm_execute(c, job);
+}
+
+int mvs_comm_set_planes(mvs_comm *c, int nplanes, float z_lo, float z_hi)
+{
+    if (!c) return MVS_EINVAL;
+    if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_comm_set_planes: the communicators were aborted after a failed collective; create a new mvs_comm");
+    if (nplanes < 1 || nplanes > 4096) return comm_fail(c, MVS_EINVAL, "mvs_comm_set_planes: nplanes=%d out of range 1..4096", nplanes);
+    Job job;
+    job.who = "mvs_comm_set_planes";
+    job.set_planes = true;
+    job.nplanes = nplanes;
+    job.z_lo = z_lo;
+    job.z_hi = z_hi;
+    return comm_execute(c, job);
+}
+
+int mvs_comm_set_main(mvs_comm *c, const float main_cam[16], const uint8_t *main_hw)
+{
+    if (!c) return MVS_EINVAL;
+    if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_comm_set_main: the communicators were aborted after a failed collective; create a new mvs_comm");
+    if (!main_cam || !main_hw) return comm_fail(c, MVS_EINVAL, "mvs_comm_set_main: null argument");
+    Job job;
+    job.who = "mvs_comm_set_main";
+    job.main_cam = main_cam;
+    job.main_hw = main_hw;
+    return comm_execute(c, job);
+}
+
+int mvs_comm_set_views(mvs_comm *c, int nviews, const float *side_cams, const uint8_t *const *side_frames)
+{
+    if (!c) return MVS_EINVAL;
+    if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_comm_set_views: the communicators were aborted after a failed collective; create a new mvs_comm");
+    if (nviews < 0 || (nviews > 0 && (!side_cams || !side_frames))) return comm_fail(c, MVS_EINVAL, "mvs_comm_set_views: null argument");
+    if (!c->have_main) return comm_fail(c, MVS_ESTATE, "mvs_comm_set_views: call mvs_comm_set_main first");
+    for (int v = 0; v < nviews; v++)
+        if (!side_frames[v]) return comm_fail(c, MVS_EINVAL, "mvs_comm_set_views: side_frames[%d] is null", v);
+    int e = comm_check_views(c, "mvs_comm_set_views", nviews);
+    if (e) return e;
+    Job job;
+    job.who = "mvs_comm_set_views";
+    job.set_views = true;
+    job.nviews = nviews;
+    job.side_cams = side_cams;
+    job.side_frames = side_frames;
+    return comm_execute(c, job);
+}
+
+int mvs_comm_run(mvs_comm *c, unsigned flags)
+{
+    if (!c) return MVS_EINVAL;
+    if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_comm_run: the communicators were aborted after a failed collective; create a new mvs_comm");
+    if (!c->have_main || !c->have_views || !c->have_planes)
+        return comm_fail(c, MVS_ESTATE, "mvs_comm_run: set planes, main view and side views first (mvs_comm_set_planes / _set_main / _set_views)");
+    if (flags & ~(unsigned)MVS_SWEEP_VOLUME) return comm_fail(c, MVS_EINVAL, "mvs_comm_run: flags may only carry MVS_SWEEP_VOLUME");
+    int e = comm_check_views(c, "mvs_comm_run", c->V);
+    if (e) return e;
+    Job job;
+    job.who = "mvs_comm_run";
+    job.run = true;
+    job.run_flags = flags;
+    return comm_execute(c, job);
+}
+
+int mvs_comm_fetch(mvs_comm *c, float *depth_hw, float *cost_hw)
+{
+    if (!c) return MVS_EINVAL;
+    if (!c->have_result) return comm_fail(c, MVS_ESTATE, "mvs_comm_fetch: no result yet (mvs_comm_run)");
+    // rank 0 alone: its context holds the maps of the whole view
+    mvs_ctx *x = c->ctx[0];
+    if (hipSetDevice(c->devices[0]) != hipSuccess) return comm_fail(c, MVS_EHIP, "mvs_comm_fetch: hipSetDevice failed");
+    const int e = mvs_sweep_fetch(x, depth_hw, cost_hw, nullptr, nullptr);
+    if (e) return comm_fail(c, e, "mvs_comm_fetch: %s", mvs_last_error(x));
     return MVS_OK;
 }
 

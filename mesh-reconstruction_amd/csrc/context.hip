@@ -47,8 +47,7 @@ int ensure(mvs_ctx *ctx, DevBuf &b, size_t bytes)
     b.bytes = bytes;
     // MVS_POISON_ALLOC=1 (test hook): a fresh allocation is filled with 0xFF bytes (NaN as float, -1 as int) instead of whatever the
     // allocator hands out -- zeros in a young process, which hides reads of memory nobody wrote
-    static const bool poison = getenv("MVS_POISON_ALLOC") != nullptr;
-    if (poison) MVS_HIP(ctx, hipMemsetAsync(p, 0xff, bytes, ctx->stream));
+    if (ctx->hooks.poison_alloc) MVS_HIP(ctx, hipMemsetAsync(p, 0xff, bytes, ctx->stream));
     return MVS_OK;
 }
 
@@ -246,6 +245,8 @@ mvs_ctx *mvs_create(int device, int width, int height)
         return nullptr;
     }
     ctx->stream = ctx->own_stream;
+    ctx->hooks = read_hooks();  // the only look at the environment this context ever takes (hooks.hpp)
+    ctx->plan_cache = !ctx->hooks.no_plan_cache;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         ctx->num_cus = prop.multiProcessorCount;

@@ -344,7 +344,7 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
     const int N = npoints;
     hipStream_t st = ctx->stream;
     // MVS_FILTER_TIMING=1: wall time of each stage on stderr (adds a stream synchronisation per stage)
-    static const bool timing = getenv("MVS_FILTER_TIMING") != nullptr;
+    const bool timing = ctx->hooks.filter_timing;
     auto clock_now = [] { return std::chrono::steady_clock::now(); };
     auto t_prev = clock_now();
     auto lap = [&](const char *what) {
@@ -413,8 +413,8 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
     if ((rc = ensure(ctx, ctx->r_tmp2, 2 * sizeof(Nb) * (size_t)(total > 0 ? total : 1)))) return rc;
     Nb *d_lo = (Nb *)ctx->r_tmp2.ptr, *d_up = d_lo + (total > 0 ? total : 1);
     // long lists (dense clouds): order them with global radix sorts instead of per-thread O(L^2) loops (see list_keys)
-    static const char *force_sorted = getenv("MVS_FILTER_SORTED_LISTS");  // test hook: "1" always, "0" never
-    const bool long_lists = (force_sorted ? force_sorted[0] == '1' : (long long)total > 24ll * N) && total > 0;
+    const int force_sorted = ctx->hooks.filter_sorted_lists;  // test hook: 1 always, 0 never
+    const bool long_lists = (force_sorted >= 0 ? force_sorted == 1 : (long long)total > 24ll * N) && total > 0;
     if (long_lists)
         nb_fill<false><<<g, 256, 0, st>>>(d_p3, d_c3, d_head, d_next, mask, N, radius, d_off_lo, d_off_up, d_fill, d_lo, d_up);
     else
@@ -516,7 +516,7 @@ int mvs_filter_points(mvs_ctx *ctx, const float *points4, int npoints, float alp
     MVS_HIP(ctx, hipGetLastError());
     lap("device sort by density");
     const float densityLimit = .7f;
-    static const int max_rounds = getenv("MVS_FILTER_MAX_ROUNDS") ? atoi(getenv("MVS_FILTER_MAX_ROUNDS")) : 2048;  // test hook
+    const int max_rounds = ctx->hooks.filter_max_rounds;  // 2048 unless the test hook says otherwise
     int rounds = 0;
     for (bool done = false; !done;) {
         int h_und[8];

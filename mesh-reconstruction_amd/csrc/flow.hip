@@ -849,7 +849,7 @@ static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, floa
         const int m = winsize / 2;
         const double bscale = 1. / ((double)winsize * winsize);
         // MVS_FB_UNFUSED=1 keeps the three-launch form of an iteration (A/B timing); windows beyond the LDS buffer use it too
-        static const bool unfused = getenv("MVS_FB_UNFUSED") != nullptr;
+        const bool unfused = ctx->hooks.fb_unfused;
         if (unfused || m > FB_MAXM) {
             for (int it = 0; it < iterations; it++) {
                 box_vert_kernel<<<g2(w, h), 256, 0, st>>>(M, w, h, m, vs);
@@ -894,7 +894,7 @@ static int variational_device(mvs_ctx *ctx, const float *I0, const float *I1, fl
     diff_kernel<true><<<g2(w, h), 256, 0, st>>>(B.Iy, w, h, B.Iyy);
     const dim3 half(div_up((w + 1) / 2, 64), div_up(h, 4));
     // MVS_VAR_UNFUSED=1 keeps the 13-launch form of a fixed-point iteration (A/B timing and the cross-check test)
-    static const bool unfused = getenv("MVS_VAR_UNFUSED") != nullptr;
+    const bool unfused = ctx->hooks.var_unfused;
     const int sor_iters = 5;
     if (2 * sor_iters > VT_HALO) return fail(ctx, MVS_EINVAL, "variational: %d SOR sweeps need a halo of %d", sor_iters, 2 * sor_iters);
     float *du_cur = B.du, *dv_cur = B.dv, *du_nxt = B.a11, *dv_nxt = B.a22;  // the fused form keeps coefficients on chip

@@ -1,0 +1,69 @@
+// hooks.cpp -- the one place where libmvs_hip.so reads the environment (hooks.hpp).
+#include "hooks.hpp"
+
+#include <cstdlib>
+#include <mutex>
+
+namespace mvs {
+
+namespace {
+bool flag(const char *name)
+{
+    const char *e = getenv(name);
+    return e && *e && atoi(e) != 0;
+}
+bool present(const char *name)  // switches that older tools set to any value
+{
+    const char *e = getenv(name);
+    return e && *e && !(e[0] == '0' && e[1] == 0);
+}
+int number(const char *name, int fallback)
+{
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : fallback;
+}
+std::string text(const char *name)
+{
+    const char *e = getenv(name);
+    return e ? std::string(e) : std::string();
+}
+}  // namespace
+
+Hooks read_hooks()
+{
+    Hooks h;
+    h.enabled = flag("MVS_TEST_HOOKS");
+    if (!h.enabled) return h;  // production: nothing else is looked at
+    h.rccl_library = text("MVS_RCCL_LIBRARY");
+    h.comm_allow_same_device = flag("MVS_COMM_ALLOW_SAME_DEVICE");
+    h.comm_fail_rank = number("MVS_COMM_TEST_FAIL_RANK", -1);
+    h.comm_allreduce = present("MVS_COMM_ALLREDUCE");
+    h.debug_flags = flag("MVS_DEBUG_FLAGS");
+    h.no_rect = present("MVS_NO_RECT");
+    h.no_plan_cache = present("MVS_NO_PLAN_CACHE");
+    h.plan_dump = text("MVS_PLAN_DUMP");
+    h.fx_prof = present("MVS_FX_PROF");
+    h.rect_verbose = present("MVS_RECT_VERBOSE");
+    h.rx_lds = number("MVS_RX_LDS", 0);
+    h.filter_timing = present("MVS_FILTER_TIMING");
+    h.filter_sorted_lists = number("MVS_FILTER_SORTED_LISTS", -1);
+    h.filter_max_rounds = number("MVS_FILTER_MAX_ROUNDS", 2048);
+    h.serial_flows = present("MVS_SERIAL_FLOWS");
+    h.fb_lanes = present("MVS_FB_LANES");
+    h.fb_unfused = present("MVS_FB_UNFUSED");
+    h.var_unfused = present("MVS_VAR_UNFUSED");
+    h.fb_direct_box = present("MVS_FB_DIRECT_BOX");
+    h.raster_bins = number("MVS_RASTER_BINS", -1);
+    h.poison_alloc = present("MVS_POISON_ALLOC");
+    return h;
+}
+
+const Hooks &process_hooks()
+{
+    static Hooks h;
+    static std::once_flag once;
+    std::call_once(once, [] { h = read_hooks(); });
+    return h;
+}
+
+}  // namespace mvs

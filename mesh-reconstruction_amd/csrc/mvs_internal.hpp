@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/mvs.h"
+#include "hooks.hpp"
 
 namespace mvs {
 
@@ -35,6 +36,8 @@ struct mvs_ctx {
     char err[512] = {0};
     char info[256] = {0};
     int num_cus = 0;
+    mvs::Hooks hooks;                // environment switches as read by mvs_create (all defaults unless MVS_TEST_HOOKS=1: hooks.hpp)
+    bool plan_cache = true;          // mvs_sweep_set_plan_cache
 
     // ---- sweep state (HBM resident) -------------------------------------------------------------
     // main image: H*W u8 tight.  side images: V slabs of (H+2) rows x pad_pitch bytes, 1-pixel

@@ -41,11 +41,11 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     // The flows of the side views depend only on (main frame, mixed_i): each runs in a lane of its own (stream + arena +
     // pyramid) while the main stream goes on rasterising the next view; a flow is a chain of small kernels that fills
     // 150 of 256 CUs at best, so up to four of them overlap.  Everything joins before triangulatePixels.
-    static const bool serial = getenv("MVS_SERIAL_FLOWS") != nullptr;  // A/B: all flows in the main stream, as before
+    const bool serial = ctx->hooks.serial_flows;  // A/B: all flows in the main stream, as before
     // Farneback (-f): the flows of all side views in ONE pass after the last mixed image (every launch covers all of them; what
     // depends on the main frame alone is computed once) -- a Farneback flow is ~150 launches of a few microseconds, and concurrency
     // between lanes does not buy what sharing the launches does.  MVS_FB_LANES=1 keeps the per-view chains on the lanes (A/B).
-    static const bool fb_lanes = getenv("MVS_FB_LANES") != nullptr;
+    const bool fb_lanes = ctx->hooks.fb_lanes;
     const bool fb_batch = use_farneback && nside > 0 && !serial && !fb_lanes;
     const int nlanes = (serial || fb_batch) ? 0 : std::min(nside, (int)mvs_ctx::kFlowLanes);
     for (int l = 0; l < nlanes; l++)

@@ -48,6 +48,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "../../include/mvs.h"
+#include "hooks.hpp"
 #include "surface_internal.hpp"
 
 namespace {
@@ -394,7 +395,7 @@ struct DevBuf {
     bool alloc(size_t bytes)
     {
         if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return false;
-        static const bool poison = getenv("MVS_POISON_ALLOC") != nullptr;  // (test hook, as in context.hip's ensure)
+        const bool poison = mvs::process_hooks().poison_alloc;  // (test hook, as in context.hip's ensure)
         return !poison || (hipMemset(p, 0xff, bytes ? bytes : 1) == hipSuccess);
     }
     template <class T> T *as() { return (T *)p; }

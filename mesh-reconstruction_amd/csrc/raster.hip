@@ -582,9 +582,9 @@ static int run_raster(mvs_ctx *ctx, const float cam[16], int mode, float *zout, 
     int rc = ensure(ctx, ctx->r_tmp2, sizeof(TriRec) * (size_t)(ctx->nfaces > 0 ? ctx->nfaces : 1));
     if (rc) return rc;
     BinState bins = {};
-    static const char *force_bins = getenv("MVS_RASTER_BINS");  // test hook: "1" always, "0" never
+    const int force_bins = ctx->hooks.raster_bins;  // test hook: 1 always, 0 never
     const int nbx = div_up(W, BIN), nby = div_up(H, BIN);
-    if (ctx->nfaces > 0 && nbx * nby <= 65536 && (force_bins ? force_bins[0] == '1' : ctx->nfaces >= BIN_MIN_FACES)) {
+    if (ctx->nfaces > 0 && nbx * nby <= 65536 && (force_bins >= 0 ? force_bins == 1 : ctx->nfaces >= BIN_MIN_FACES)) {
         const size_t nbins = (size_t)nbx * nby, F = (size_t)ctx->nfaces;
         if ((rc = ensure(ctx, ctx->raster_bins, sizeof(int) * (3 * nbins + 1 + BIN_MAXCOVER * F + F)))) return rc;
         bins.count = (int *)ctx->raster_bins.ptr;

@@ -788,6 +788,13 @@ int mvs_sweep_run_rows(mvs_ctx *ctx, int view_first, int view_count, int row_fir
 
 int mvs_sweep_row_granularity(void) { return ROW_GRAN; }
 
+int mvs_sweep_set_plan_cache(mvs_ctx *ctx, int enable)
+{
+    if (!ctx) return MVS_EINVAL;
+    ctx->plan_cache = enable != 0;
+    return MVS_OK;
+}
+
 // the fixed sampler's tiles are 8 rows tall whatever the plan; the exact sampler's 8 or 16 (hence 16)
 int mvs_sweep_row_granularity_of(const mvs_ctx *ctx) { return (ctx && ctx->sampler == MVS_SAMPLER_FIXED) ? 8 : ROW_GRAN; }
 
@@ -839,8 +846,7 @@ static int sweep_run_impl(mvs_ctx *ctx, int view_first, int view_count, int plan
     // Only the documented bits of `flags` reach the kernels.  Bits 8-23 carry timing-experiment switches (debug bits, forced plane-split
     // count: tools/exp_*.py, tests) and are honoured only when the process sets MVS_DEBUG_FLAGS=1: a caller's stray high bits must not
     // change tile order, look-ahead or split counts silently.
-    static const bool debug_flags = getenv("MVS_DEBUG_FLAGS") != nullptr && atoi(getenv("MVS_DEBUG_FLAGS")) != 0;
-    if (!debug_flags) flags &= (MVS_SWEEP_VOLUME | MVS_SWEEP_FUSED_ARGMIN | MVS_SWEEP_FORCE_GENERIC | MVS_SWEEP_NO_RECT);
+    if (!ctx->hooks.debug_flags) flags &= (MVS_SWEEP_VOLUME | MVS_SWEEP_FUSED_ARGMIN | MVS_SWEEP_FORCE_GENERIC | MVS_SWEEP_NO_RECT);
     const bool vol = flags & MVS_SWEEP_VOLUME, fused = flags & MVS_SWEEP_FUSED_ARGMIN;
     if (!vol && !fused) return fail(ctx, MVS_EINVAL, "mvs_sweep_run: flags select neither volume nor fused argmin");
     MVS_HIP(ctx, hipSetDevice(ctx->device));

@@ -851,7 +851,7 @@ int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool gen
     }
     const dim3 grid((unsigned)(div_up(groups, 8) * 64), (unsigned)nsplit);
 #ifdef MVS_FX_EXPERIMENTS
-    const bool prof = getenv("MVS_FX_PROF") != nullptr;
+    const bool prof = ctx->hooks.fx_prof;
     if (prof) {  // per-section cycle sums of wavefront 0 of every workgroup (s_memtime), printed after the launch
         if ((rc = ensure(ctx, ctx->plan_stats, 256))) return rc;
         p.plan_stats = (int *)ctx->plan_stats.ptr;
@@ -894,11 +894,11 @@ int sweep_fx_plan_general(mvs_ctx *ctx)
     q.plan = (const uint2 *)ctx->plan.ptr;
     // the planner's counters (oversize regions, regions not skipped, widest / tallest staged region) are a diagnostic nobody reads on
     // this path: 32 000 wavefronts' atomics on four addresses were most of the planner's 0.28 ms at c3.  MVS_PLAN_DUMP keeps them.
-    q.plan_stats = getenv("MVS_PLAN_DUMP") ? (int *)ctx->plan_stats.ptr : nullptr;
+    q.plan_stats = !ctx->hooks.plan_dump.empty() ? (int *)ctx->plan_stats.ptr : nullptr;
     if (q.plan_stats) MVS_HIP(ctx, hipMemsetAsync(q.plan_stats, 0, 4 * sizeof(int), ctx->stream));
     plan_regions_fx<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(q, (uint2 *)ctx->plan.ptr);
     MVS_HIP(ctx, hipGetLastError());
-    if (const char *path = getenv("MVS_PLAN_DUMP")) {  // diagnostic (tools/plan_hist.py): header {tiles_x, tiles_y, nchunks, V}, then the descriptors
+    if (const char *path = ctx->hooks.plan_dump.empty() ? nullptr : ctx->hooks.plan_dump.c_str()) {  // diagnostic (tools/plan_hist.py): header {tiles_x, tiles_y, nchunks, V}, then the descriptors
         std::vector<uint2> host(n);
         MVS_HIP(ctx, hipMemcpyAsync(host.data(), ctx->plan.ptr, n * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
         MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -917,15 +917,15 @@ int sweep_fx_plan(mvs_ctx *ctx, PlanHook *between)
 {
     // The plan depends on the view matrices (main and side cameras), the planes and, for store-resident views, the slots -- not on the
     // frames.  A fixed rig that delivers its next set of frames (the commonest "new view set" of all) therefore needs no planning: the
-    // tables in memory are the ones this call would compute.  (MVS_NO_PLAN_CACHE=1 plans regardless: bench.py's cold step times the plan.)
+    // tables in memory are the ones this call would compute.  (mvs_sweep_set_plan_cache(ctx, 0) plans regardless: bench.py's cold step times the plan.)
     const bool hit = ctx->snap_valid && ctx->snap_q == ctx->q_host && ctx->snap_z == ctx->z_host && ctx->snap_in_store == ctx->views_in_store &&
-                     (!ctx->views_in_store || ctx->snap_slots == ctx->view_slots_host) && !getenv("MVS_PLAN_DUMP") && !getenv("MVS_NO_PLAN_CACHE");
+                     (!ctx->views_in_store || ctx->snap_slots == ctx->view_slots_host) && ctx->hooks.plan_dump.empty() && ctx->plan_cache;
     if (hit) return between ? between->run() : MVS_OK;
     ctx->snap_valid = false;
     ctx->fx_general_planned = false;
     int rc = sweep_rect_plan(ctx, between);  // (runs `between` exactly once, whatever it decides)
     if (rc) return rc;
-    if (!ctx->rect_ok || getenv("MVS_PLAN_DUMP")) {
+    if (!ctx->rect_ok || !ctx->hooks.plan_dump.empty()) {
         if ((rc = sweep_fx_plan_general(ctx))) return rc;
     }
     ctx->snap_q = ctx->q_host;

@@ -852,7 +852,7 @@ int sweep_rect_plan(mvs_ctx *ctx, PlanHook *between)
     } hook{between};
     ctx->rect_ok = false;
     ctx->rect_cold_sent = false;  // the tables (and the cold block behind them) may move
-    if (getenv("MVS_NO_RECT")) return hook.go();
+    if (ctx->hooks.no_rect) return hook.go();
     if (ctx->V == 0) return hook.go();
     for (int v = 0; v < ctx->V; v++)
         if (!rect_view_host(ctx->q_host.data() + 12 * v)) return hook.go();  // a view that is not rectified: the general kernel
@@ -882,7 +882,7 @@ int sweep_rect_plan(mvs_ctx *ctx, PlanHook *between)
     MVS_HIP(ctx, hipEventSynchronize(ctx->plan_event));
     const int max_rw = stats[0], max_rh = stats[1];
     int rs = 0;
-    if (getenv("MVS_RECT_VERBOSE")) fprintf(stderr, "sweep_rect_plan: widest box %d quads, tallest %d rows\n", max_rw, max_rh);
+    if (ctx->hooks.rect_verbose) fprintf(stderr, "sweep_rect_plan: widest box %d quads, tallest %d rows\n", max_rw, max_rh);
     for (int cand : {64, 84, 96, 128})  // row strides the kernel is compiled for
         if (max_rw <= cand) {
             rs = cand;
@@ -977,7 +977,7 @@ int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsign
     size_t lds = ((size_t)2 * a.slot_dw + RX_BIAS_X + (size_t)RX_BIAS_Y * ctx->rect_rs) * 4;  // two slots, the second one's data ends a bias further on
     if (fused) lds = lds < 16384 ? 16384 : lds;  // the cross-wavefront depth selection borrows 16 KiB
 #ifdef MVS_RX_CUT
-    if (const char *e = getenv("MVS_RX_LDS")) lds = std::max(lds, (size_t)atoi(e));  // timing experiments: occupancy through the LDS request
+    if (ctx->hooks.rx_lds > 0) lds = std::max(lds, (size_t)ctx->hooks.rx_lds);  // timing experiments: occupancy through the LDS request
 #endif
     if (lds > 160 * 1024) return fail(ctx, MVS_EINVAL, "sweep_rect_launch: %zu bytes of LDS", lds);
 

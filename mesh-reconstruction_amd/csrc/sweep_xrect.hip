@@ -508,7 +508,7 @@ bool rect_view_host(const float *q);  // sweep_rect.hip
 int sweep_xrect_plan(mvs_ctx *ctx)
 {
     ctx->xrect_ok = false;
-    if (getenv("MVS_NO_RECT") || ctx->V == 0 || ctx->V > XR_MAX_REGIONS) return MVS_OK;
+    if (ctx->hooks.no_rect || ctx->V == 0 || ctx->V > XR_MAX_REGIONS) return MVS_OK;
     for (int v = 0; v < ctx->V; v++)
         if (!rect_view_host(ctx->q_host.data() + 12 * v)) return MVS_OK;
     if ((unsigned long long)ctx->pad_slab * (unsigned long long)ctx->V * 8ull >= (1ull << 32)) return MVS_OK;  // one buffer resource, 32-bit byte offsets
@@ -531,7 +531,7 @@ int sweep_xrect_plan(mvs_ctx *ctx)
     MVS_HIP(ctx, hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int max_rw = h[0], max_rh = h[1];
-    if (getenv("MVS_RECT_VERBOSE")) {
+    if (ctx->hooks.rect_verbose) {
         fprintf(stderr, "sweep_xrect_plan: widest box %d quads, tallest %d rows\n", max_rw, max_rh);
         uint32_t rec[32];
         for (int which = 0; which < 2; which++) {

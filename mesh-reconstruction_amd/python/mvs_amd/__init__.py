@@ -94,6 +94,12 @@ ABI = [
     ("mvs_comm_set_mode", _i, [_vp, _i]),
     ("mvs_comm_mode", _i, [_vp]),
     ("mvs_comm_set_plane_groups", _i, [_vp, _i]),
+    ("mvs_comm_set_planes", _i, [_vp, _i, _f, _f]),
+    ("mvs_comm_set_main", _i, [_vp, _fp, _u8p]),
+    ("mvs_comm_set_views", _i, [_vp, _i, _fp, C.POINTER(_u8p)]),
+    ("mvs_comm_run", _i, [_vp, C.c_uint]),
+    ("mvs_comm_fetch", _i, [_vp, _fp, _fp]),
+    ("mvs_sweep_set_plan_cache", _i, [_vp, _i]),
     ("mvs_sweep_sharded", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _f, _f, _fp, _fp]),
     ("mvs_profile_enable", _i, [_vp, _i]),
     ("mvs_profile_read", _i, [_vp, _fp, C.POINTER(_i), _i]),
@@ -362,6 +368,37 @@ class Comm:
             raise MvsError("libmvs_hip error %d: %s" % (rc, self.lib.mvs_comm_last_error(self.h).decode()))
         return depth, cost
 
+    def _check(self, rc):
+        if rc:
+            raise MvsError("libmvs_hip error %d: %s" % (rc, self.lib.mvs_comm_last_error(self.h).decode()))
+
+    def context(self, rank):
+        """the borrowed mvs_ctx handle of a rank (for the C entry points that take one)"""
+        return self.lib.mvs_comm_context(self.h, int(rank))
+
+    def set(self, main_cam, main_img, side_cams, side_imgs, nplanes, z_lo=-1.0, z_hi=1.0):
+        """the resident form: planes, main view and ALL side views uploaded to every rank once (mvs_comm_set_planes / _set_main / _set_views)"""
+        W, H = self.W, self.H
+        V = len(side_imgs)
+        cam = _f32(main_cam, (4, 4))
+        img = _u8(main_img, (H, W))
+        cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((1, 4, 4), np.float32)
+        frames = [_u8(s, (H, W)) for s in side_imgs]
+        arr = (_u8p * max(V, 1))(*[_ptr(f, _u8p) for f in frames])
+        self._check(self.lib.mvs_comm_set_planes(self.h, int(nplanes), float(z_lo), float(z_hi)))
+        self._check(self.lib.mvs_comm_set_main(self.h, _ptr(cam, _fp), _ptr(img, _u8p)))
+        self._check(self.lib.mvs_comm_set_views(self.h, V, _ptr(cams, _fp), arr))
+
+    def run(self, flags=0):
+        """one sweep of what is resident in the current mode; the maps stay on rank 0's GPU (mvs_comm_run)"""
+        self._check(self.lib.mvs_comm_run(self.h, int(flags)))
+
+    def fetch(self, want_cost=True):
+        depth = np.empty((self.H, self.W), np.float32)
+        cost = np.empty((self.H, self.W), np.float32) if want_cost else None
+        self._check(self.lib.mvs_comm_fetch(self.h, _ptr(depth, _fp), _ptr(cost, _fp) if want_cost else None))
+        return (depth, cost) if want_cost else depth
+
 
 class Context:
     """One GPU context (mvs_ctx).  Mirrors the life cycle of the reference's RenderGLX (render_glx.cpp:152-227)."""
@@ -504,6 +541,9 @@ class Context:
     def row_granularity(self):
         """row-band boundaries must be multiples of this (depends on the sampler set on the context)"""
         return self.lib.mvs_sweep_row_granularity_of(self.h)
+
+    def set_plan_cache(self, enable):
+        self._check(self.lib.mvs_sweep_set_plan_cache(self.h, 1 if enable else 0))
 
     def plan_shape(self):
         return self.lib.mvs_sweep_plan_shape(self.h)

@@ -12,6 +12,9 @@ except ImportError:
 # the sweep's timing-experiment flag bits (flags >> 8: debug switches, forced plane-split counts) are masked off by the library unless
 # this is set; several parity tests drive the kernels through them (bit-identical results are the point of those tests)
 os.environ.setdefault("MVS_DEBUG_FLAGS", "1")
+# the master switch of every environment hook of the library (csrc/hooks.hpp): without it the library reads no
+# other variable.  Contexts and communicators take their snapshot when they are created.
+os.environ.setdefault("MVS_TEST_HOOKS", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))

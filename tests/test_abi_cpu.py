@@ -117,3 +117,30 @@ int main(void)
     assert out.returncode == 0, out.stderr[-2000:]
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and ("refused:" in run.stdout or "created" in run.stdout), run.stdout + run.stderr
+
+
+def test_environment_hooks_are_dead_without_the_master_switch(monkeypatch):
+    """every environment switch of the library sits behind MVS_TEST_HOOKS=1 (csrc/hooks.hpp), read when a context or a
+    communicator is created.  Without it MVS_RCCL_LIBRARY -- which would dlopen an arbitrary file -- is not even looked at: naming a
+    missing library no longer fails mvs_comm_create for the library's sake (here, without a GPU, it fails later, for the device's)."""
+    monkeypatch.setenv("MVS_RCCL_LIBRARY", "/nonexistent/librccl_missing.so")
+    monkeypatch.setenv("MVS_TEST_HOOKS", "0")
+    try:
+        c = mvs_amd.Comm([0], 64, 48)
+        c.close()   # a GPU box: the communicator came up, the variable was ignored
+    except mvs_amd.MvsError as e:
+        assert "librccl_missing" not in str(e) and "no HIP device" in str(e), str(e)
+
+
+def test_no_getenv_outside_the_hooks_module():
+    """the one place the product library reads the environment is csrc/hooks.cpp"""
+    import glob
+    offenders = []
+    for path in glob.glob(os.path.join(ROOT, "mesh-reconstruction_amd", "csrc", "*")):
+        if os.path.basename(path) == "hooks.cpp":
+            continue
+        for i, line in enumerate(open(path, errors="replace"), 1):
+            code = line.split("//")[0]
+            if "getenv" in code:
+                offenders.append("%s:%d" % (os.path.basename(path), i))
+    assert not offenders, offenders

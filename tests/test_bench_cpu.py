@@ -53,12 +53,26 @@ def test_committed_profiles_resolve():
         assert 0.3 < got["valu_utilisation"] < 1.05
 
 
-def test_gpus_without_a_launcher_is_refused():
-    """`python bench.py --gpus 8` without torch.distributed.run would run on GPU 0 only and claim eight: it must refuse (and say how
-    to launch it) before touching any GPU"""
+def test_gpus_without_a_launcher_starts_the_launcher_as_a_child():
+    """`python bench.py --gpus 2` without torch.distributed.run: one process drives one GPU, so bench.py starts the launcher itself --
+    as a child process, before torch is imported or a GPU touched -- and relays its output and exit code (the first 8-GPU
+    node must yield a curve, not a usage error).  Here there is no GPU: both ranks come up under the launcher, say so, and the launcher's
+    non-zero exit code is what this process returns."""
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=120)
-    assert out.returncode != 0 and "torch.distributed.run" in out.stderr and "--nproc-per-node 8" in out.stderr
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c1", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert "--nproc-per-node 2" in out.stderr and "starting" in out.stderr            # the launcher was started by bench.py itself ...
+    assert out.stderr.count("bench.py needs a GPU") >= 1 or "ProcessGroupNCCL" in out.stderr or "NCCL" in out.stderr   # ... its ranks ran bench.py (and found no GPU)
+    assert out.returncode != 0                                                         # ... and its exit code came back
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_via_comm_refuses_a_launcher():
+    """--via-comm is ONE process driving N GPUs through mvs_comm_*: under torch.distributed.run it must refuse before touching anything"""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--via-comm"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "ONE process" in out.stderr

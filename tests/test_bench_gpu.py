@@ -60,6 +60,11 @@ def test_bench_line_contract_and_two_rank_shardings():
     assert set(alt) == {"views_allreduce", "views_reduce_scatter"}
     for a in alt.values():
         assert a["depth_crc32"] == single["depth_crc32"] and a["collective_bytes_per_rank_per_step"] > 0 and a["views_per_rank"] == 2
+    # ... and the same GPUs once more through the product's own multi-GPU entry (rank 0's child process: mvs_comm_set_* + mvs_comm_run)
+    vc = full["via_comm"]
+    assert "error" not in vc, vc
+    assert vc["depth_crc32"] == single["depth_crc32"] and vc["ms_per_step"] > 0 and "mvs_comm_run" in vc["entry"] and "TEST HOOK" in vc["data"]
+    assert set(vc["modes"]) == {"rows", "views", "views_scatter"} and all(m["depth_crc32"] == single["depth_crc32"] for m in vc["modes"].values())
     for s in ("exact",):
         ex = _bench(["--sampler", s], 1)
         assert ex["roofline"]["kernel"] in ("sweep_tiled", "sweep_exact_rect") and ex["depth_check"] is True   # (the ring is rectified: sweep_exact_rect where its boxes fit the LDS slots)
@@ -77,3 +82,20 @@ def test_bench_line_contract_and_two_rank_shardings():
     assert 0.0 < cold["same_cameras_ms"] <= cold["ms"] * 1.2   # (the plan reused: not slower than planning, up to noise)
     assert "combine_best" in ext["roofline"]["ms_per_launch_covers"]
     assert "roofline_traffic" in ext["general_camera_path"]
+
+
+def test_via_comm_line():
+    """bench.py --via-comm: ONE process drives N GPUs through mvs_comm_set_* / mvs_comm_run (here: 3 ranks on the one GPU, loopback
+    collectives, labelled as the test hook it is); the line keeps the contract and every mode reproduces the single-GPU depth map"""
+    env = dict(os.environ, MVS_BENCH_SAME_DEVICE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--via-comm", "--gpus", "3", "--config", "c1", "--steps", "3", "--warmup", "1"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 3 and rec["scaling"] == "strong" and "TEST HOOK" in rec["data"] and rec["depth_check"] is True
+    assert rec["depth_crc32"] == rec["depth_crc32_single_gpu"]
+    modes = rec["config"]["modes"]
+    assert set(modes) == {"rows", "views", "views_scatter"} and all(m["depth_crc32"] == rec["depth_crc32"] for m in modes.values())

@@ -125,3 +125,85 @@ def test_rows_mode_needs_no_collective_library(monkeypatch):
         d, c = comm.sweep(main_cam, main_img, side_cams, sides, D)
         np.testing.assert_array_equal(d, d1)
         np.testing.assert_array_equal(c, c1)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n", [2, 8])
+def test_the_resident_form_runs_every_mode_on_what_was_uploaded_once(loopback, n):
+    """mvs_comm_set_planes / _set_main / _set_views once, then mvs_comm_run in every mode (persistent rank threads, nothing uploaded or
+    planned per call) and mvs_comm_fetch: depth and best cost of the whole view, from rank 0's GPU, bit-identical to mvs_sweep -- rows mode's
+    bands arrive there by peer copies.  Repeated runs, mode switches without a new upload, a new main view, a new view set."""
+    W, H, D, V = 640, 360, 48, 6
+    main_cam, main_img, side_cams, sides, d1, c1 = _scene(W, H, D, V)
+    with mvs_amd.Comm([0] * n, W, H) as comm:
+        with pytest.raises(mvs_amd.MvsError, match="set planes, main view and side views first"):
+            comm.run()
+        comm.set(main_cam, main_img, side_cams, sides, D)
+        for mode, groups, flags in (("rows", None, 0), ("views", 3, 0), ("rows", None, mvs_amd.MVS_SWEEP_VOLUME), ("views_scatter", None, 0), ("views", 1, 0), ("rows", None, 0)):
+            comm.set_mode(mode, groups)
+            for _ in range(3):
+                comm.run(flags)
+            d, c = comm.fetch()
+            np.testing.assert_array_equal(d, d1, err_msg="%s n=%d" % (mode, n))
+            np.testing.assert_array_equal(c, c1, err_msg="%s n=%d" % (mode, n))
+        # a new main view invalidates the side views (their matrices depend on the main camera), like a context
+        lib = comm.lib
+        cam = np.ascontiguousarray(main_cam, np.float32)
+        img = np.ascontiguousarray(sides[0], np.uint8)
+        assert lib.mvs_comm_set_main(comm.h, cam.ctypes.data_as(mvs_amd._fp), img.ctypes.data_as(mvs_amd._u8p)) == 0
+        with pytest.raises(mvs_amd.MvsError, match="side views first"):
+            comm.run()
+        # another view set (the first side view as main frame, fewer views), swept resident, against a fresh single-GPU sweep
+        comm.set(side_cams[0], sides[0], side_cams[1:4], sides[1:4], 32)
+        with mvs_amd.Context(W, H) as ctx:
+            d2, c2 = ctx.sweep(side_cams[0], sides[0], side_cams[1:4], sides[1:4], 32, want_cost=True)
+        for mode in ("views_scatter", "rows"):
+            comm.set_mode(mode)
+            comm.run()
+            d, c = comm.fetch()
+            np.testing.assert_array_equal(d, d2)
+            np.testing.assert_array_equal(c, c2)
+
+
+def test_the_one_call_form_leaves_its_upload_resident_for_the_same_mode(loopback):
+    """mvs_sweep_sharded in a views mode uploads only each rank's own views: mvs_comm_run afterwards works in that split and says what is
+    missing in rows mode (which needs every view on every rank)"""
+    W, H, D, V = 320, 200, 32, 4
+    main_cam, main_img, side_cams, sides, d1, c1 = _scene(W, H, D, V)
+    with mvs_amd.Comm([0] * 4, W, H) as comm:
+        comm.set_mode("views", 2)
+        d, c = comm.sweep(main_cam, main_img, side_cams, sides, D)
+        np.testing.assert_array_equal(d, d1)
+        comm.run()
+        np.testing.assert_array_equal(comm.fetch()[0], d1)
+        comm.set_mode("rows")
+        with pytest.raises(mvs_amd.MvsError, match="mvs_comm_set_views"):
+            comm.run()
+        comm.sweep(main_cam, main_img, side_cams, sides, D)   # rows: all views everywhere
+        comm.set_mode("views_scatter")
+        comm.run()
+        np.testing.assert_array_equal(comm.fetch()[0], d1)
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("n", [2, 8])
+def test_every_mode_at_c4_size(loopback, n):
+    """BASELINE config 4's size -- 3840 x 2160, 256 planes, 32 views: an 8.49 GB packed volume per rank, 2.12 G cells, plane slices and
+    plane groups at offsets past 4 GiB -- through all three modes, resident and one-call, bit-identical to mvs_sweep (the
+    slice arithmetic of csrc/comm.cpp had only ever run at c2's size).  Noise frames: every cell matters, no depth meaning."""
+    W, H, D, V = 3840, 2160, 256, 32
+    main_cam, main_img, side_cams, sides = synth.noise_views(W, H, V)
+    with mvs_amd.Context(W, H) as ctx:
+        d1, c1 = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_cost=True)
+    with mvs_amd.Comm([0] * n, W, H) as comm:
+        comm.set(main_cam, main_img, side_cams, sides, D)
+        for mode, groups in (("rows", None), ("views", 4), ("views_scatter", None)):
+            comm.set_mode(mode, groups)
+            comm.run(mvs_amd.MVS_SWEEP_VOLUME)
+            d, c = comm.fetch()
+            np.testing.assert_array_equal(d, d1, err_msg="%s n=%d" % (mode, n))
+            np.testing.assert_array_equal(c, c1, err_msg="%s n=%d" % (mode, n))
+        comm.set_mode("views", 3)   # plane groups of 96, 96, 64 planes: the last group starts past 6 GiB
+        d, c = comm.sweep(main_cam, main_img, side_cams, sides, D)
+        np.testing.assert_array_equal(d, d1)
+        np.testing.assert_array_equal(c, c1)

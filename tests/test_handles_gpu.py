@@ -175,7 +175,7 @@ def test_a_fixed_rigs_next_frames_reuse_the_plan_and_new_cameras_do_not(oracle, 
         ctx.sweep_set_views(side_cams, frames2[1:])
         ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
         a = ctx.sweep_fetch()[0]
-        monkeypatch.setenv("MVS_NO_PLAN_CACHE", "1")
+        ctx.set_plan_cache(False)
         ctx.sweep_set_views(side_cams, frames2[1:])
         ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
         np.testing.assert_array_equal(ctx.sweep_fetch()[0], a)

@@ -1,4 +1,5 @@
 import json, os, sys, time
+os.environ.setdefault("MVS_TEST_HOOKS", "1")   # master switch of the library's environment hooks (csrc/hooks.hpp)
 os.environ.setdefault("MVS_DEBUG_FLAGS", "1")  # the library masks the experiment bits of `flags` otherwise
 sys.path.insert(0, os.path.join(os.getcwd(), "mesh-reconstruction_amd", "python"))
 import numpy as np, mvs_amd

@@ -3,6 +3,7 @@ sampler exist only in a library built with -DMVS_FX_EXPERIMENTS (make -B CXXFLAG
 slower than the production build; with the production build they time the unmodified kernel.
 debug bits (flags >> 8): 1 skip LDS staging*, 2 linear tile order, 4 never use the plane-independent-w path, 8 no region look-ahead, 16 treat BORDER regions as FAST*, 32 skip the sample loop*, 64 no per-view barrier*, 128 no chunk epilogue* (* = experiments build only for the fixed sampler); flags >> 16: forced plane splits"""
 import sys, os
+os.environ.setdefault("MVS_TEST_HOOKS", "1")   # master switch of the library's environment hooks (csrc/hooks.hpp)
 os.environ.setdefault("MVS_DEBUG_FLAGS", "1")  # the library masks the experiment bits of `flags` otherwise
 import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

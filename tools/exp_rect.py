@@ -2,6 +2,7 @@
     python tools/exp_rect.py [c1|c2|c3|c4|c5] [--check]
 Environment: MVS_RECT_SLOTS=S (LDS slots = look-ahead + 1)."""
 import sys, os
+os.environ.setdefault("MVS_TEST_HOOKS", "1")   # master switch of the library's environment hooks (csrc/hooks.hpp)
 os.environ.setdefault("MVS_DEBUG_FLAGS", "1")  # the library masks the experiment bits of `flags` otherwise
 import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of the plane-split count (flags >> 16) for full-frame sweeps: c1, c2, c3 (scene data)."""
 import json, os, sys, time
+os.environ.setdefault("MVS_TEST_HOOKS", "1")   # master switch of the library's environment hooks (csrc/hooks.hpp)
 os.environ.setdefault("MVS_DEBUG_FLAGS", "1")  # the library masks the experiment bits of `flags` otherwise
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))

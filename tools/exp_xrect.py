@@ -1,6 +1,7 @@
 """In-process timings of the exact sampler's rectified kernel (sweep_exact_rect) against sweep_tiled on the SURVEY 8d ring.
     python tools/exp_xrect.py [c2|c3|c5] [--exp]      (--exp: needs a -DMVS_XR_EXPERIMENTS build, tools/build_variant.sh xrexp -DMVS_XR_EXPERIMENTS csrc/sweep_xrect.hip)"""
 import os, sys, time
+os.environ.setdefault("MVS_TEST_HOOKS", "1")   # master switch of the library's environment hooks (csrc/hooks.hpp)
 os.environ.setdefault("MVS_DEBUG_FLAGS", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))

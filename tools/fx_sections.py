@@ -1,6 +1,7 @@
 """Per-section cycle counts of the fixed-sampler sweep's view loop (s_memtime, wavefront 0 of every workgroup).  Needs a library built
 with -DMVS_FX_EXPERIMENTS (make CXXFLAGS="... -DMVS_FX_EXPERIMENTS"); the production build ignores MVS_FX_PROF."""
 import sys, os
+os.environ.setdefault("MVS_TEST_HOOKS", "1")   # master switch of the library's environment hooks (csrc/hooks.hpp)
 os.environ.setdefault("MVS_DEBUG_FLAGS", "1")  # the library masks the experiment bits of `flags` otherwise
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))

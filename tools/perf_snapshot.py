@@ -1,6 +1,7 @@
 """One table of resident sweep times (volume + fused depth selection, frames in HBM) for the BASELINE shapes and both samplers, ring geometry
 (plane-independent w) and the same with that shortcut disabled (the path general cameras take): python tools/perf_snapshot.py > out.json"""
 import json, os, sys, time
+os.environ.setdefault("MVS_TEST_HOOKS", "1")   # master switch of the library's environment hooks (csrc/hooks.hpp)
 os.environ.setdefault("MVS_DEBUG_FLAGS", "1")  # the library masks the experiment bits of `flags` otherwise
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))

@@ -7,6 +7,7 @@ import numpy as np
 import torch  # noqa: F401 (HIP runtime first)
 
 path = os.path.join(tempfile.gettempdir(), "mvs_plan.bin")
+os.environ["MVS_TEST_HOOKS"] = "1"
 os.environ["MVS_PLAN_DUMP"] = path
 import mvs_amd
 from mvs_amd import synth

@@ -1,6 +1,7 @@
 """The general tiled kernel of the fixed sampler at c3 / c2 / c5-size: ring geometry with MVS_SWEEP_NO_RECT (hoisted reciprocal) and cameras
 turned by 12 mrad (the bench's general_camera_path), volume + fused / fused only, with a bit-identity check against the rectified kernel on the ring."""
 import os, sys, time
+os.environ.setdefault("MVS_TEST_HOOKS", "1")   # master switch of the library's environment hooks (csrc/hooks.hpp)
 os.environ.setdefault("MVS_DEBUG_FLAGS", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))

@@ -3,6 +3,7 @@
 8-way split of one main view, and check the zero-copy torch view of the depth map the all-gather uses.
 No collective is executed here (one GPU); the slowest band bounds the multi-GPU step from below."""
 import json, os, sys, time
+os.environ.setdefault("MVS_TEST_HOOKS", "1")   # master switch of the library's environment hooks (csrc/hooks.hpp)
 os.environ.setdefault("MVS_DEBUG_FLAGS", "1")  # the library masks the experiment bits of `flags` otherwise
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python"))

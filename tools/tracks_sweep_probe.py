@@ -8,6 +8,7 @@ import tempfile
 import numpy as np
 import torch  # noqa: F401 (HIP runtime first)
 PLAN = os.path.join(tempfile.gettempdir(), "mvs_plan_tracks.bin")
+os.environ["MVS_TEST_HOOKS"] = "1"
 os.environ["MVS_PLAN_DUMP"] = PLAN
 import mvs_amd
 from mvs_amd import tracks
