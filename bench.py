@@ -220,6 +220,79 @@ def run_sequence(args, rank, local_rank, world, dist, torch, np, mvs_amd, same_d
         dist.destroy_process_group()
 
 
+def farneback_levels(W, H, levels=10, pyr_scale=0.8):
+    """pyramid level sizes of cv::FarnebackOpticalFlow::calc with the reference's parameters (flow.cpp:24-26; SURVEY A-10): level k is
+    the frame scaled by 0.8^k, for as long as both sides stay >= 32 pixels"""
+    sizes, scale, k = [], 1.0, 0
+    for k in range(levels):
+        scale *= pyr_scale
+        if W * scale < 32 or H * scale < 32:
+            break
+    else:
+        k = levels
+    for i in range(k + 1):
+        s = pyr_scale ** i
+        sizes.append((int(round(W * s)), int(round(H * s))))
+    return sizes
+
+
+def flow_algorithmic_bytes(W, H, farneback):
+    """Compulsory HBM bytes of one calculateFlow call: every stage of the algorithm as published reads its
+    inputs once and writes its outputs once; intermediates a fused implementation can keep on chip are not counted."""
+    P = float(W) * H
+    variance = (8 + 1 + 1) * P + (2 + 2 * 4) * P * 4.0 / 3.0 * 2 + (8 + 4 + 16) * P   # flowRemap + compare's two pyramids (u8 in, f32 levels) + packing
+    if farneback:
+        total = 2 * (1 + 4) * P + variance          # u8 -> f32 of both frames
+        for (w, h) in farneback_levels(W, H):
+            Pk = float(w) * h
+            total += 16 * P + 8 * P + 8 * Pk        # GaussianBlur of both full-resolution frames (read + write), resize to the level (read, write)
+            total += 8 * Pk + 40 * Pk               # polynomial expansion: both level frames in, R0 and R1 (5 f32 per pixel each) out
+            total += 16 * Pk                        # the flow carried down from the coarser level (read at most 8 Pk, write 8 Pk)
+            total += (40 + 8 + 20) * Pk             # first M from R0, R1 and the flow
+            total += 7 * (20 + 8) * Pk + 6 * (40 + 20) * Pk   # 7 iterations: M in, flow out; all but the last also R0, R1 in, M out
+        return total
+    # variational refinement: warp + derivatives (I1, flow in; 8 derivative images out), then 5 fixed-point iterations that read the 8
+    # derivative images and u, v, du, dv and write du, dv (the 5 SOR sweeps of an iteration stay on chip), and the final sum
+    return (1 + 1) * P + 4 * P + 32 * P + 5 * (32 + 16 + 8) * P + 16 * P + variance
+
+
+def flow_block(mvs_amd, np, device):
+    """the flow stage north_star names beside the sweep (flow.cpp:19-42), on the record: device time of mvs_flow per algorithm and size
+    (HIP events around the whole call's device work: upload and download excluded), the algorithmic bytes above and the HBM fraction"""
+    out = {}
+    for (W, H) in ((640, 480), (1920, 1080)):
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+        s = W / 640.0
+
+        def tex(x, y):
+            return 127 + 50 * np.sin(x / (7.0 * s)) * np.cos(y / (9.0 * s)) + 40 * np.sin((x + y) / (13.0 * s)) + 30 * np.cos((x - 2 * y) / (17.0 * s))
+        a = tex(xx, yy).clip(0, 255).astype(np.uint8)
+        b = tex(xx - 2.5 * s, yy + 1.5 * s).clip(0, 255).astype(np.uint8)
+        with mvs_amd.Context(W, H, device) as ctx:
+            for name, fb in (("farneback", True), ("variational", False)):
+                for _ in range(3):
+                    flow = ctx.flow(a, b, fb)
+                ctx.profile_enable(True)
+                ctx.profile_read(reset=True)
+                n = 10
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    ctx.flow(a, b, fb)
+                wall = (time.perf_counter() - t0) / n * 1e3
+                ms, launches = ctx.profile_read(reset=True)
+                ctx.profile_enable(False)
+                dev = ms[mvs_amd.MVS_K_FLOW] / max(1, launches[mvs_amd.MVS_K_FLOW])
+                nbytes = flow_algorithmic_bytes(W, H, fb)
+                out["%s_%dx%d" % (name, W, H)] = {
+                    "device_ms": dev, "call_ms": wall, "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / (dev * 1e-3) / 1e9,
+                    "frac": nbytes / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS, "pixels_per_s": float(W) * H / (dev * 1e-3),
+                    "median_abs_flow_px": float(np.median(np.abs(flow[..., :2])))}
+    out["note"] = ("mvs_flow = calculateFlow (flow.cpp:19-42): dense flow + variance channel; device_ms from HIP events around the call's device work, call_ms "
+                   "with host frames in and the H x W x 4 f32 result out; bytes: flow_algorithmic_bytes in bench.py / DESIGN.md section 6; bound: launch "
+                   "latency at 640 x 480 (a Farneback call is ~150 launches), HBM / LDS at 1080p")
+    return out
+
+
 def run_via_comm(args, same_device):
     """ONE process, N GPUs, through the C ABI's communicator: planes, main view and all side views uploaded to every rank once
     (mvs_comm_set_*), then K timed mvs_comm_run calls -- each returns when every rank thread has finished its share and, in rows mode,
@@ -751,6 +824,10 @@ def main():
         onecall_ms = (time.perf_counter() - t1) / n1 * 1e3
         octx.close()
 
+    flow = None
+    if world == 1 and not args.no_extras:
+        flow = flow_block(mvs_amd, np, local_rank)
+
     # sanity: the timed path produced the surface it was rendered from
     depth = primary["depth"]
     if gt is not None:
@@ -817,6 +894,8 @@ def main():
                 "note": "same frames, side cameras turned by 12 mrad about two axes: no view is rectified any more, the general tiled kernel "
                         "with its per-sample reciprocal runs -- the rate for rotated / forward-moving cameras such as the bundled tracks "
                         "(timing only; DESIGN.md section 4)"}
+        if flow is not None:
+            out["flow"] = flow
         if exact is not None:
             out["exact_sampler"] = exact
         if disagreement is not None:

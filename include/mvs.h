@@ -337,8 +337,9 @@ int mvs_profile_read(mvs_ctx *ctx, float ms_sum[MVS_K_COUNT], int launches[MVS_K
  * thread's current HIP device (device 0 unless the caller has set another), on a stream of its own; no CPU path.
  *   points     n rows x, y, z, w (homogeneous, as recon.cpp:121 hands them over);  normals  n rows nx, ny, nz (pointing out of the solid;
  *              a component that is NaN or beyond 1e4 in magnitude makes the sample vote for nothing).  Their lengths act as confidences,
- *              as given; poissonSurface (host/poisson.cpp) and mvs_amd.poisson_surface normalise them first, like the reference's PCL
- *              backend without USE_PRECISION (pcl.cpp:198-202) -- see there for what the pdf lengths of triangulatePixels do otherwise.
+ *              as given -- the reference's semantics on both of its backends (cgal_poisson.cpp:58-69; pcl.cpp:23, 198-202).  The wrappers
+ *              with the reference's signature, poissonSurface (host/poisson.cpp) and mvs_amd.poisson_surface, normalise them first BY
+ *              DEFAULT: a deliberate divergence (see there for what the pdf lengths of triangulatePixels do to this solver), switchable.
  *              The level is the median of chi over the samples (CGAL's Poisson_reconstruction_function: median value at the input points)
  *   grid_log2  log2 of the nodes per axis, 4..9; 0 = from the samples' average 6-nearest-neighbour spacing, the reference's own
  *              yardstick (CGAL::compute_average_spacing(points, 6), cgal_poisson.cpp:77): the coarsest of 32..512 nodes per axis whose

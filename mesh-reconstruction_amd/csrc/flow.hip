@@ -224,6 +224,53 @@ __device__ __forceinline__ void update_matrix_at(const float *__restrict__ R0, c
     m[4] = r6 * r2 + r5 * r3;
 }
 
+// update_matrix_at without a branch, into registers: the 2 x 2 footprint of R1 is loaded whatever the flow says (from a clamped address
+// when it falls outside) and the two cases are selected afterwards -- the same operations on the same values, so the same bits; a thread
+// that owns several pixels can have all their gathers in flight at once.
+__device__ __forceinline__ void update_matrix_vals(const float *__restrict__ R0, const float *__restrict__ R1, float dx, float dy,
+                                                   int x, int y, int w, int h, float m[5])
+{
+    const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+    const size_t step1 = (size_t)w * 5;
+    const float *r0 = R0 + ((size_t)y * w + x) * 5;
+    const float r00 = r0[0], r01 = r0[1], r02 = r0[2], r03 = r0[3], r04 = r0[4];
+    float fx = x + dx, fy = y + dy;
+    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    fx -= x1;
+    fy -= y1;
+    const bool inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const float *p = R1 + (size_t)(inb ? y1 : 0) * step1 + (size_t)(inb ? x1 : 0) * 5;
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    float r2 = a00 * p[0] + a01 * p[5] + a10 * p[step1] + a11 * p[step1 + 5];
+    float r3 = a00 * p[1] + a01 * p[6] + a10 * p[step1 + 1] + a11 * p[step1 + 6];
+    float r4 = a00 * p[2] + a01 * p[7] + a10 * p[step1 + 2] + a11 * p[step1 + 7];
+    float r5 = a00 * p[3] + a01 * p[8] + a10 * p[step1 + 3] + a11 * p[step1 + 8];
+    float r6 = a00 * p[4] + a01 * p[9] + a10 * p[step1 + 4] + a11 * p[step1 + 9];
+    r4 = inb ? (r02 + r4) * 0.5f : r02;
+    r5 = inb ? (r03 + r5) * 0.5f : r03;
+    r6 = inb ? (r04 + r6) * 0.25f : r04 * 0.5f;
+    r2 = inb ? r2 : 0.f;
+    r3 = inb ? r3 : 0.f;
+    r2 = (r00 - r2) * 0.5f;
+    r3 = (r01 - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    if ((unsigned)(x - 5) >= (unsigned)(w - 10) || (unsigned)(y - 5) >= (unsigned)(h - 10)) {
+        const float scale = (x < 5 ? border[x] : 1.f) * (x >= w - 5 ? border[w - x - 1] : 1.f) *
+                            (y < 5 ? border[y] : 1.f) * (y >= h - 5 ? border[h - y - 1] : 1.f);
+        r2 *= scale;
+        r3 *= scale;
+        r4 *= scale;
+        r5 *= scale;
+        r6 *= scale;
+    }
+    m[0] = r4 * r4 + r6 * r6;
+    m[1] = (r4 + r5) * r6;
+    m[2] = r5 * r5 + r6 * r6;
+    m[3] = r4 * r2 + r6 * r3;
+    m[4] = r6 * r2 + r5 * r3;
+}
+
 // (blockIdx.z = flow of a batch: R1, flow and M advance by their strides, R0 -- the common first frame -- does not)
 __global__ __launch_bounds__(256) void update_matrices_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                               const float *__restrict__ flow, int w, int h,
@@ -317,6 +364,189 @@ __global__ __launch_bounds__(256) void farneback_iteration_fused(const float *__
     flow[((size_t)y * w + x) * 2] = dx;
     flow[((size_t)y * w + x) * 2 + 1] = dy;
     if (M_out) update_matrix_at(R0, R1, dx, dy, x, y, w, h, M_out + ((size_t)y * w + x) * 5);
+}
+
+// The same iteration with every value read ONCE per thread instead of once per sum (round 5).  The arithmetic is that of the kernels
+// above, operation for operation: a vertical sum is 0 + M[y-m] + ... + M[y+m] in f64 in that order, a horizontal sum 0 + vs[x-m] + ...
+// + vs[x+m] -- but a thread owns PY consecutive rows of one column (PX consecutive pixels of one row) and walks the 2m + PY (2m + PX)
+// values they need once, adding each value to every running sum whose window holds it: output p takes the values j = p .. p + 2m, in
+// ascending j, which IS its own fixed order.  What changes is the traffic: 2m + PY loads for PY vertical sums instead of PY (2m + 1), and
+// (2m + PX) / PX LDS reads per horizontal sum instead of 2m + 1 (the kernel above was bound by exactly those: 910 bytes of loads per
+// pixel and iteration at 1080p).  A workgroup owns 64 x TY pixels, TY = 2 PY = 4 PX; the vertical sums of its 64 + 2m columns live in LDS
+// as vs[row][channel][column], the column index padded by one slot every PX columns so that the lanes of a wavefront -- PX columns apart
+// -- hit different banks (stride PX + 1 doubles, odd).  Needs 2m >= PY - 1 (head and tail of the walk are unrolled); smaller windows,
+// and the test hook MVS_FB_DIRECT_BOX, take the kernel above.
+template <int N>
+struct FbAcc {
+    double s[N][5];
+};
+
+template <int PY>
+__global__ __launch_bounds__(256) void farneback_iteration_tiled(const float *__restrict__ M_in, const float *__restrict__ R0,
+                                                                 const float *__restrict__ R1, int w, int h, int m, double scale,
+                                                                 float *__restrict__ flow, float *__restrict__ M_out, ptrdiff_t m_z, ptrdiff_t r1_z,
+                                                                 ptrdiff_t flow_z)
+{
+    constexpr int TY = 2 * PY, PX = PY / 2;
+    extern __shared__ double fb_vs[];  // [TY][5][colsP]
+    M_in += m_z * blockIdx.z;
+    R1 += r1_z * blockIdx.z;
+    flow += flow_z * blockIdx.z;
+    if (M_out) M_out += m_z * blockIdx.z;
+    const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * TY, cols = 64 + 2 * m, colsP = cols + cols / PX + 1;
+    // ---- vertical sums: one (column, group of PY rows) per thread ----
+    for (int item = threadIdx.x; item < 2 * cols; item += 256) {
+        const int q = item >= cols ? 1 : 0, k = item - q * cols;
+        const int yb = Y0 + q * PY;
+        if (yb >= h) continue;
+        const int gx = clampi(X0 - m + k, 0, w - 1);
+        const float *col = M_in + (size_t)gx * 5;
+        FbAcc<PY> a;
+#pragma unroll
+        for (int p = 0; p < PY; p++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) a.s[p][c] = 0.;
+        auto row = [&](int j) { return col + (size_t)clampi(yb - m + j, 0, h - 1) * w * 5; };
+#pragma unroll
+        for (int j = 0; j < PY - 1; j++) {  // head: value j belongs to the windows of outputs 0 .. j
+            const float *v = row(j);
+            const float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3], v4 = v[4];
+#pragma unroll
+            for (int p = 0; p <= j; p++) {
+                a.s[p][0] += v0;
+                a.s[p][1] += v1;
+                a.s[p][2] += v2;
+                a.s[p][3] += v3;
+                a.s[p][4] += v4;
+            }
+        }
+        // every output's window holds the values j = PY - 1 .. 2m: walked in batches of FB_U rows, the loads of batch b + 1 issued before
+        // batch b is added (a workgroup's time is a chain of memory latencies, not arithmetic: the first form, one row per trip, ran
+        // no faster than the kernel it replaced)
+        {
+            constexpr int U = 8;
+            float cur[U][5], nxt[U][5];
+            int j = PY - 1;
+            const int end = 2 * m + 1;  // one past the last steady value
+            auto fetch = [&](float (&dst)[U][5], int j0) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const float *v = row(min(j0 + u, end - 1));  // (rows past the end are loaded again and not added)
+#pragma unroll
+                    for (int c = 0; c < 5; c++) dst[u][c] = v[c];
+                }
+            };
+            fetch(cur, j);
+            for (; j < end; j += U) {
+                if (j + U < end) fetch(nxt, j + U);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (j + u < end) {
+#pragma unroll
+                        for (int p = 0; p < PY; p++)
+#pragma unroll
+                            for (int c = 0; c < 5; c++) a.s[p][c] += cur[u][c];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int c = 0; c < 5; c++) cur[u][c] = nxt[u][c];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < PY - 1; t++) {  // tail: value 2m + 1 + t belongs to outputs t + 1 .. PY - 1
+            const float *v = row(2 * m + 1 + t);
+            const float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3], v4 = v[4];
+#pragma unroll
+            for (int p = t + 1; p < PY; p++) {
+                a.s[p][0] += v0;
+                a.s[p][1] += v1;
+                a.s[p][2] += v2;
+                a.s[p][3] += v3;
+                a.s[p][4] += v4;
+            }
+        }
+        const int kp = k + k / PX;
+#pragma unroll
+        for (int p = 0; p < PY; p++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) fb_vs[((size_t)(q * PY + p) * 5 + c) * colsP + kp] = a.s[p][c];
+    }
+    __syncthreads();
+    // ---- horizontal sums, solve, next M: PX consecutive pixels of one row per thread ----
+    constexpr int GPR = 64 / PX;  // threads per row
+    const int r = threadIdx.x / GPR, g = threadIdx.x - r * GPR, lx0 = g * PX, y = Y0 + r;
+    if (y >= h || X0 + lx0 >= w) return;
+    FbAcc<PX> t;
+#pragma unroll
+    for (int p = 0; p < PX; p++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) t.s[p][c] = 0.;
+    // box_horiz addresses column clampi(x + d, 0, w - 1); LDS column k holds clampi(X0 - m + k, 0, w - 1): value j of this thread's walk is
+    // column lx0 + j (padded index lx0 + j + g + j / PX)
+    const double *base = fb_vs + (size_t)r * 5 * colsP + lx0 + g;
+    auto val = [&](int j, int c) { return base[(size_t)c * colsP + j + j / PX]; };
+#pragma unroll
+    for (int j = 0; j < PX - 1; j++) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const double v = val(j, c);
+#pragma unroll
+            for (int p = 0; p <= j; p++) t.s[p][c] += v;
+        }
+    }
+#pragma unroll 4
+    for (int j = PX - 1; j <= 2 * m; j++) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const double v = val(j, c);
+#pragma unroll
+            for (int p = 0; p < PX; p++) t.s[p][c] += v;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PX - 1; u++) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const double v = val(2 * m + 1 + u, c);
+#pragma unroll
+            for (int p = u + 1; p < PX; p++) t.s[p][c] += v;
+        }
+    }
+    float dxs[PX], dys[PX];
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        double tt[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) tt[c] = t.s[p][c] * scale;
+        const double idet = 1. / (tt[0] * tt[2] - tt[1] * tt[1] + 1e-3);
+        dxs[p] = (float)((tt[0] * tt[4] - tt[1] * tt[3]) * idet);
+        dys[p] = (float)((tt[2] * tt[3] - tt[1] * tt[4]) * idet);
+    }
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        const int x = X0 + lx0 + p;
+        if (x < w) {
+            flow[((size_t)y * w + x) * 2] = dxs[p];
+            flow[((size_t)y * w + x) * 2 + 1] = dys[p];
+        }
+    }
+    if (!M_out) return;
+    // the next M of the thread's PX pixels: all gathers issued before any is used (pixels past the right edge compute on the last column
+    // and store nothing)
+    float mv[PX][5];
+#pragma unroll
+    for (int p = 0; p < PX; p++) update_matrix_vals(R0, R1, dxs[p], dys[p], min(X0 + lx0 + p, w - 1), y, w, h, mv[p]);
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        const int x = X0 + lx0 + p;
+        if (x < w) {
+            float *o = M_out + ((size_t)y * w + x) * 5;
+#pragma unroll
+            for (int c = 0; c < 5; c++) o[c] = mv[p][c];
+        }
+    }
 }
 
 // ---- variational refinement -------------------------------------------------------------------------------------
@@ -786,6 +1016,40 @@ static void farneback_taps(int n, double sigma, PolyTaps &t)  // FarnebackPrepar
 static dim3 g2(int w, int h) { return dim3(div_up(w, 64), div_up(h, 4)); }
 static unsigned g1(size_t n) { return (unsigned)((n + 255) / 256); }
 
+// one fused Farneback iteration over B flows (blockIdx.z): the tiled kernel where the window allows it, tall tiles where the image is large
+// enough to fill the chip with them
+static int launch_fb_iteration(mvs_ctx *ctx, const float *M_in, const float *R0, const float *R1, int w, int h, int m, double scale, float *flow, float *M_out, int B,
+                               ptrdiff_t m_z, ptrdiff_t r1_z, ptrdiff_t flow_z)
+{
+    hipStream_t st = ctx->stream;
+    if (m < 4 || ctx->hooks.fb_direct_box) {
+        dim3 g = g2(w, h);
+        g.z = (unsigned)B;
+        farneback_iteration_fused<<<g, 256, 0, st>>>(M_in, R0, R1, w, h, m, scale, flow, M_out, m_z, r1_z, flow_z);
+        return MVS_OK;
+    }
+    const int cols = 64 + 2 * m;
+    const bool tall = (size_t)div_up(w, 64) * div_up(h, 16) * B >= 2 * (size_t)ctx->num_cus;
+    if (tall) {
+        const size_t lds = (size_t)16 * 5 * (cols + cols / 4 + 1) * sizeof(double);
+        static bool attr_done = false;  // (per process; the attribute is a property of the kernel, not of a context)
+        if (!attr_done) {
+            MVS_HIP(ctx, hipFuncSetAttribute((const void *)farneback_iteration_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_done = true;
+        }
+        farneback_iteration_tiled<8><<<dim3(div_up(w, 64), div_up(h, 16), B), 256, lds, st>>>(M_in, R0, R1, w, h, m, scale, flow, M_out, m_z, r1_z, flow_z);
+    } else {
+        const size_t lds = (size_t)8 * 5 * (cols + cols / 2 + 1) * sizeof(double);
+        static bool attr_done = false;
+        if (!attr_done) {
+            MVS_HIP(ctx, hipFuncSetAttribute((const void *)farneback_iteration_tiled<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_done = true;
+        }
+        farneback_iteration_tiled<4><<<dim3(div_up(w, 64), div_up(h, 8), B), 256, lds, st>>>(M_in, R0, R1, w, h, m, scale, flow, M_out, m_z, r1_z, flow_z);
+    }
+    return MVS_OK;
+}
+
 // cv::FarnebackOpticalFlow::calc, flags 0.  f0/f1: f32 frames (W*H); flow_out: W*H*2.  arena: >= 30*P floats.
 static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, float *flow_out, float *arena, int levels,
                             double pyr_scale, int winsize, int iterations, int poly_n, double poly_sigma)
@@ -859,8 +1123,8 @@ static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, floa
         } else {
             float *M_cur = M, *M_nxt = (float *)vs;  // the fused form keeps the vertical sums on chip: vs is free
             for (int it = 0; it < iterations; it++) {
-                farneback_iteration_fused<<<g2(w, h), 256, 0, st>>>(M_cur, R0, R1, w, h, m, bscale, flow,
-                                                                    it < iterations - 1 ? M_nxt : nullptr);
+                int r = launch_fb_iteration(ctx, M_cur, R0, R1, w, h, m, bscale, flow, it < iterations - 1 ? M_nxt : nullptr, 1, 0, 0, 0);
+                if (r) return r;
                 std::swap(M_cur, M_nxt);
             }
         }
@@ -1081,7 +1345,8 @@ static int farneback_batch_enqueue(mvs_ctx *ctx, const uint8_t *prev8, const uin
         const double bscale = 1. / ((double)winsize * winsize);
         float *M_cur = b.M, *M_nxt = b.M2;
         for (int it = 0; it < iterations; it++) {
-            farneback_iteration_fused<<<gB, 256, 0, st>>>(M_cur, R0, R1, w, h, m, bscale, flow, it < iterations - 1 ? M_nxt : nullptr, 5 * sP, 5 * sP, 2 * sP);
+            int r = launch_fb_iteration(ctx, M_cur, R0, R1, w, h, m, bscale, flow, it < iterations - 1 ? M_nxt : nullptr, B, 5 * sP, 5 * sP, 2 * sP);
+            if (r) return r;
             std::swap(M_cur, M_nxt);
         }
         MVS_HIP(ctx, hipGetLastError());

@@ -11,21 +11,31 @@
 #include "../../include/mvs.h"
 #include "recon.hpp"
 
-Mesh poissonSurface(const Mat points, const Mat normals)
+static PoissonNormals g_poisson_normals = POISSON_UNIT_NORMALS;  // what the reference's two-argument call does here (see below)
+
+void setPoissonNormals(PoissonNormals mode) { g_poisson_normals = mode; }
+PoissonNormals poissonNormals() { return g_poisson_normals; }
+
+Mesh poissonSurface(const Mat points, const Mat normals) { return poissonSurface(points, normals, g_poisson_normals); }
+
+Mesh poissonSurface(const Mat points, const Mat normals, PoissonNormals mode)
 {
     if (points.rows == 0) return Mesh(Mat(0, 4, mvs::F32C1), Mat(0, 3, mvs::S32C1));
     if (points.cols != 4 || normals.cols != 3 || normals.rows != points.rows)
         throw std::runtime_error("poissonSurface: points must be N x 4 (homogeneous) and normals N x 3");  // cgal_poisson.cpp:58-59 reads p[0..3], n[0..2]
-    // The normals arrive scaled by triangulatePixels' pdf (util.cpp:322-327: lengths spanning two decades on real frames).  The reference's
-    // PCL backend normalises them unless it is built with USE_PRECISION ("may be better to disable, sometimes does more harm than use",
-    // pcl.cpp:198-202: pcl::Poisson's confidence flag off = unit normals); what CGAL does with the lengths cannot be looked up here.  Measured
-    // on a cloud this pipeline produces (tools/criteria_on_c5.py): with the pdf lengths as confidences the level set wanders off the
-    // weak samples (591 k vertices, half of them more than two spacings from any sample), with unit normals it is the sheet (171 k, median
-    // distance half a spacing).  So: unit normals, like pcl.cpp's default; MVS_POISSON_USE_PRECISION=1 keeps the lengths.
+    // A DELIBERATE DIVERGENCE from the reference.  The normals arrive scaled by triangulatePixels' pdf
+    // (util.cpp:322-327: lengths spanning two decades on real frames), and BOTH of the reference's backends use those lengths: the default
+    // one (Makefile:4, POISSON_LIBRARY = cgal) hands them to Poisson_reconstruction_function as they are (cgal_poisson.cpp:58-69), and
+    // pcl.cpp defines USE_PRECISION (pcl.cpp:23), so pcl::Poisson runs with setConfidence(true) (pcl.cpp:198-202) -- under a comment of the
+    // reference's author: "may be better to disable, sometimes does more harm than use".  On this library's grid solver it does more harm:
+    // on a cloud this pipeline produces (tools/criteria_on_c5.py) the level set under pdf-length confidences wanders off the weak samples
+    // (591 k vertices, half of them more than two spacings from any sample); with unit normals it is the sheet (171 k vertices, median
+    // distance half a spacing).  So the two-argument call of recon.hpp:37 normalises the normals first (POISSON_UNIT_NORMALS);
+    // setPoissonNormals(POISSON_CONFIDENCE_NORMALS), or the three-argument call, gives the reference's semantics.  No environment
+    // variable is read.
     std::vector<float> unit;
     const float *nrm = normals.ptr<float>();
-    const char *keep = std::getenv("MVS_POISSON_USE_PRECISION");
-    if (!(keep && keep[0] == '1')) {
+    if (mode == POISSON_UNIT_NORMALS) {
         unit.assign(nrm, nrm + 3 * (size_t)normals.rows);
         for (int i = 0; i < normals.rows; i++) {
             float *n = unit.data() + 3 * (size_t)i;

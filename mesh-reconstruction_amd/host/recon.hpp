@@ -57,6 +57,14 @@ float sampleImage(const Mat image, float radiusSquared, const float x, const flo
 Mat alphaShapeFaces(const Mat points);                // recon.hpp:33
 Mat alphaShapeFaces(const Mat points, float *alpha);  // recon.hpp:34: faces F x 3 i32 of the alpha shape that is one solid component; *alpha = the value chosen
 Mesh poissonSurface(const Mat points, const Mat normals);  // recon.hpp:37: points N x 4 homogeneous, normals N x 3
+// Not part of the reference's interface: what the call above does with the LENGTHS of the normals (triangulatePixels scales them by a
+// pdf, util.cpp:322-327).  The reference uses them as confidences on both backends (cgal_poisson.cpp:58-69; pcl.cpp:23 + 198-202); this
+// library's default normalises them first -- a deliberate divergence, measured on the pipeline's own clouds (host/poisson.cpp, DESIGN.md
+// section 9).  POISSON_CONFIDENCE_NORMALS restores the reference's semantics.
+enum PoissonNormals { POISSON_UNIT_NORMALS = 0, POISSON_CONFIDENCE_NORMALS = 1 };
+Mesh poissonSurface(const Mat points, const Mat normals, PoissonNormals mode);
+void setPoissonNormals(PoissonNormals mode);  // what the two-argument call does from now on (process-wide; the reference is single-threaded)
+PoissonNormals poissonNormals();
 
 // == configuration (configuration.cpp) ==
 class Configuration {

@@ -251,6 +251,25 @@ static int run_gpu(const std::string &tracks, const std::string &out)
                m.faces.rows, worst, vol, sphere, min_angle);
         CHECK(m.faces.rows > 1000 && worst < 0.02 && std::fabs(vol - sphere) < 0.02 * sphere && hp.alphaVals.back() == 0.25f, "tessellate with the built-in Poisson surface");
         CHECK(min_angle >= 20.0 - 1e-4, "poissonSurface keeps the reference's angle bound (cgal_poisson.cpp:50)");
+        // which default is intended: the two-argument call normalises the normals -- lengths varying over two decades give the
+        // mesh of unit normals, byte for byte -- and POISSON_CONFIDENCE_NORMALS (the reference's semantics) uses them: another mesh
+        Mat scaled(n, 3, mvs::F32C1);
+        for (int i = 0; i < n; i++) {
+            const float s = std::ldexp(1.0f, -(i % 7)) * (1.0f + 0.25f * (float)(i % 3));
+            for (int k = 0; k < 3; k++) scaled.at<float>(i, k) = nrm.at<float>(i, k) * s;
+        }
+        CHECK(poissonNormals() == POISSON_UNIT_NORMALS, "the default of poissonSurface(points, normals) is unit normals");
+        const Mesh unit_mesh = poissonSurface(pts, nrm), scaled_mesh = poissonSurface(pts, scaled), conf_mesh = poissonSurface(pts, scaled, POISSON_CONFIDENCE_NORMALS);
+        bool same = unit_mesh.vertices.rows == scaled_mesh.vertices.rows && unit_mesh.faces.rows == scaled_mesh.faces.rows;
+        double dmax = 0.0;
+        for (int i = 0; same && i < unit_mesh.vertices.rows; i++)
+            for (int k = 0; k < 4; k++) dmax = std::max(dmax, (double)std::fabs(unit_mesh.vertices.at<float>(i, k) - scaled_mesh.vertices.at<float>(i, k)));
+        CHECK(same && dmax < 1e-4, "poissonSurface normalises the normals by default");
+        setPoissonNormals(POISSON_CONFIDENCE_NORMALS);
+        const Mesh conf2 = poissonSurface(pts, scaled);
+        setPoissonNormals(POISSON_UNIT_NORMALS);
+        CHECK(conf2.vertices.rows == conf_mesh.vertices.rows && conf2.faces.rows == conf_mesh.faces.rows, "setPoissonNormals switches the two-argument call");
+        CHECK(conf_mesh.vertices.rows != unit_mesh.vertices.rows || conf_mesh.faces.rows != unit_mesh.faces.rows, "confidence normals give another mesh than unit normals");
     }
     std::ofstream sel(out + "/chosen.txt");
     int mains = 0, pairs = 0;

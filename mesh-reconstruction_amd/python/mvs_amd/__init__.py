@@ -197,8 +197,9 @@ def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0, criteria=REF
     (out of the solid) -> (vertices V x 4 float32 with w = 1, faces F x 3 int32).  criteria = (min angle in degrees, max facet radius and
     max facet distance in units of the samples' average spacing), the reference's by default; None: the surface-nets mesh as it is.
     support_spacings: the level set is meshed only within that many average spacings of the samples (0: everywhere; include/mvs.h).
-    use_precision: keep the normals' lengths as confidences (pcl.cpp:198-202's USE_PRECISION); by default they are normalised to unit length
-    first, like the reference's PCL backend does (host/poisson.cpp says why).
+    use_precision: keep the normals' lengths as confidences -- what BOTH backends of the reference do (cgal_poisson.cpp:58-69 hands them to
+    CGAL as they are; pcl.cpp:23 defines USE_PRECISION, so pcl.cpp:198-202 sets setConfidence(true)).  The default, False, normalises them to
+    unit length first: a deliberate divergence from the reference, measured on the pipeline's own clouds (host/poisson.cpp).
     report: a dict that receives the fields of mvs_criteria_report, the average spacing and the support radius in nodes"""
     lib = load_library()
     pts = np.ascontiguousarray(points, np.float32)

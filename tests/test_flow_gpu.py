@@ -34,6 +34,32 @@ def test_calculate_flow_matches_oracle(oracle, W, H, farneback):
     assert not got[..., 3].any()
 
 
+def test_farneback_tall_tiles_match_oracle(oracle):
+    """1280 x 720 (window 20): the finest levels run the tiled iteration kernel with 64 x 16 tiles (8 rows / 4 pixels per thread), the
+    coarse ones with 64 x 8 -- same sums in the same order as the oracle's, bit for bit"""
+    W, H = 1280, 720
+    a, b = _pair(W, H, 3.5, -2.0, seed=5)
+    ref = oracle.calculate_flow(a, b, True)
+    with mvs_amd.Context(W, H) as ctx:
+        got = ctx.flow(a, b, True)
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("W,H", [(1920, 1080), (3840, 2160), (1000, 1099)])
+def test_farneback_tiled_iteration_equals_the_direct_one(monkeypatch, W, H):
+    """the tiled iteration kernel (every value read once per thread, running sums in registers) against the round-2 kernel that sums each
+    window term by term (test hook MVS_FB_DIRECT_BOX, itself equal to the oracle at the sizes the oracle is run at): windows 30, 60 and 20
+    with ragged tile edges; single flows and the batched pass of mvs_process_frame's shape"""
+    a, b = _pair(W, H, 4.0, 1.5, seed=W)
+    with mvs_amd.Context(W, H) as ctx:
+        got = ctx.flow(a, b, True)
+    monkeypatch.setenv("MVS_FB_DIRECT_BOX", "1")
+    with mvs_amd.Context(W, H) as ctx:
+        ref = ctx.flow(a, b, True)
+    np.testing.assert_array_equal(got, ref)
+    assert np.abs(got[..., :2]).max() > 1.0
+
+
 def test_flow_of_mixed_background_stage(oracle):
     """flow.cpp is called on (originalImage, mixBackground(projected)) (recon.cpp:86-89): outside the mask the two
     images are identical, so the flow vanishes there"""

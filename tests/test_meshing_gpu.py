@@ -278,6 +278,24 @@ def test_tessellate_of_the_cpp_mirror_reaches_it(tmp_path):
     assert "gpu selftest: 0 failures" in r.stdout and "poissonSurface:" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_the_wrappers_default_is_unit_normals_and_the_references_semantics_are_one_flag_away():
+    """both backends of the reference use the normals' lengths as confidences (cgal_poisson.cpp:58-69; pcl.cpp:23 + 198-202).
+    mvs_amd.poisson_surface (like host/poisson.cpp) normalises them BY DEFAULT -- a deliberate divergence recorded in DESIGN.md section 9 --
+    and use_precision=True is the reference's behaviour.  This pins which is which."""
+    rng = np.random.default_rng(11)
+    d = rng.normal(size=(6000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = np.concatenate([d * 0.8, np.ones((len(d), 1))], 1).astype(np.float32)
+    lengths = (10.0 ** rng.uniform(-2.0, 0.0, len(d)))[:, None]          # two decades, like triangulatePixels' pdf
+    v_unit, f_unit = mvs_amd.poisson_surface(pts, d.astype(np.float32))
+    v_def, f_def = mvs_amd.poisson_surface(pts, (d * lengths).astype(np.float32))
+    v_conf, f_conf = mvs_amd.poisson_surface(pts, (d * lengths).astype(np.float32), use_precision=True)
+    assert v_def.shape == v_unit.shape and np.array_equal(f_def, f_unit) and np.abs(v_def - v_unit).max() < 1e-4   # the lengths did not matter
+    assert v_conf.shape != v_unit.shape or not np.array_equal(f_conf, f_unit)                                          # here they did
+    v_same, f_same = mvs_amd.poisson_surface(pts, d.astype(np.float32), use_precision=True)                            # unit lengths: no difference
+    np.testing.assert_array_equal(f_same, f_unit)
+
+
 def test_config5_outer_iteration_closes_points_filter_poisson_mesh_render():
     """recon.cpp:114-136 + 42: the point blocks of a few zatisi main frames -> filterPoints -> poissonSurface -> the mesh the next
     iteration renders.  (Synthetic frames: the cloud is whatever the flows give; what is checked is that the stages connect --

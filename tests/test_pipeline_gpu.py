@@ -53,6 +53,25 @@ def test_process_frame_equals_stagewise_and_oracle(oracle, farneback):
     np.testing.assert_allclose(pts[ok, 4:], o_pts[ok, 4:], rtol=1e-5, atol=1e-9)
 
 
+def test_process_frame_farneback_batch_at_a_window_the_tiled_iteration_serves():
+    """1280 x 720, window 20: the batched Farneback pass of mvs_process_frame (all side views per launch, blockIdx.z = flow) runs the tiled
+    iteration kernel -- its per-flow strides included -- and must equal the one-flow-at-a-time entry points, which equal the oracle
+    (tests/test_flow_gpu.py)"""
+    W, H, nside = 1280, 720, 3
+    verts, faces, main, sides, main_img, side_imgs = _setup(W, H, nside)
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.load_mesh(verts, faces)
+        pts = ctx.process_frame(main, main_img, sides, side_imgs, True)
+        depth = ctx.depth(main)
+        flows = []
+        for cam, img in zip(sides, side_imgs):
+            mixed, depth = ctx.mix_background(ctx.projected(main, img, cam), main_img, depth)
+            flows.append(ctx.flow(main_img, mixed, True))
+        ref_pts = ctx.triangulate(flows, main, sides, depth)
+    np.testing.assert_array_equal(pts, ref_pts)
+    assert pts.shape[0] > 0.2 * W * H
+
+
 def test_process_frame_is_faster_than_stagewise():
     W, H, nside = 640, 480, 4
     verts, faces, main, sides, main_img, side_imgs = _setup(W, H, nside)
