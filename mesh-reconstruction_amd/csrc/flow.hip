@@ -18,6 +18,8 @@
 // blocking in LDS; the 13 separate kernels remain as the A/B form) -> add increment.
 #include "mvs_internal.hpp"
 
+#include <atomic>
+
 #include <cmath>
 #include <cstdlib>
 
@@ -381,13 +383,13 @@ struct FbAcc {
     double s[N][5];
 };
 
-template <int PY>
-__global__ __launch_bounds__(256) void farneback_iteration_tiled(const float *__restrict__ M_in, const float *__restrict__ R0,
+template <int PY, int PX, int THREADS>
+__global__ __launch_bounds__(THREADS) void farneback_iteration_tiled(const float *__restrict__ M_in, const float *__restrict__ R0,
                                                                  const float *__restrict__ R1, int w, int h, int m, double scale,
                                                                  float *__restrict__ flow, float *__restrict__ M_out, ptrdiff_t m_z, ptrdiff_t r1_z,
                                                                  ptrdiff_t flow_z)
 {
-    constexpr int TY = 2 * PY, PX = PY / 2;
+    constexpr int TY = PX * 4, NQ = TY / PY;  // rows of the tile (64 / PX threads per row, 256 threads in the horizontal phase), row groups of the vertical phase
     extern __shared__ double fb_vs[];  // [TY][5][colsP]
     M_in += m_z * blockIdx.z;
     R1 += r1_z * blockIdx.z;
@@ -395,8 +397,8 @@ __global__ __launch_bounds__(256) void farneback_iteration_tiled(const float *__
     if (M_out) M_out += m_z * blockIdx.z;
     const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * TY, cols = 64 + 2 * m, colsP = cols + cols / PX + 1;
     // ---- vertical sums: one (column, group of PY rows) per thread ----
-    for (int item = threadIdx.x; item < 2 * cols; item += 256) {
-        const int q = item >= cols ? 1 : 0, k = item - q * cols;
+    for (int item = threadIdx.x; item < NQ * cols; item += THREADS) {
+        const int q = item / cols, k = item - q * cols;
         const int yb = Y0 + q * PY;
         if (yb >= h) continue;
         const int gx = clampi(X0 - m + k, 0, w - 1);
@@ -476,6 +478,7 @@ __global__ __launch_bounds__(256) void farneback_iteration_tiled(const float *__
     __syncthreads();
     // ---- horizontal sums, solve, next M: PX consecutive pixels of one row per thread ----
     constexpr int GPR = 64 / PX;  // threads per row
+    if (threadIdx.x >= 256) return;  // (a 512-thread workgroup: twice the wavefronts for the vertical walk, the latency-bound half)
     const int r = threadIdx.x / GPR, g = threadIdx.x - r * GPR, lx0 = g * PX, y = Y0 + r;
     if (y >= h || X0 + lx0 >= w) return;
     FbAcc<PX> t;
@@ -1030,24 +1033,21 @@ static int launch_fb_iteration(mvs_ctx *ctx, const float *M_in, const float *R0,
     }
     const int cols = 64 + 2 * m;
     const bool tall = (size_t)div_up(w, 64) * div_up(h, 16) * B >= 2 * (size_t)ctx->num_cus;
-    if (tall) {
-        const size_t lds = (size_t)16 * 5 * (cols + cols / 4 + 1) * sizeof(double);
-        static bool attr_done = false;  // (per process; the attribute is a property of the kernel, not of a context)
-        if (!attr_done) {
-            MVS_HIP(ctx, hipFuncSetAttribute((const void *)farneback_iteration_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_done = true;
+    static std::atomic<unsigned> attr_set{0};  // per process: the LDS ceiling is a property of the kernel, set once each (bit = variant)
+    auto go = [&](auto kernel, int ty, int px, int threads, unsigned bit) -> int {
+        const size_t lds = (size_t)ty * 5 * (cols + cols / px + 1) * sizeof(double);
+        if (!(attr_set.load() & bit)) {
+            MVS_HIP(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set.fetch_or(bit);
         }
-        farneback_iteration_tiled<8><<<dim3(div_up(w, 64), div_up(h, 16), B), 256, lds, st>>>(M_in, R0, R1, w, h, m, scale, flow, M_out, m_z, r1_z, flow_z);
-    } else {
-        const size_t lds = (size_t)8 * 5 * (cols + cols / 2 + 1) * sizeof(double);
-        static bool attr_done = false;
-        if (!attr_done) {
-            MVS_HIP(ctx, hipFuncSetAttribute((const void *)farneback_iteration_tiled<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_done = true;
-        }
-        farneback_iteration_tiled<4><<<dim3(div_up(w, 64), div_up(h, 8), B), 256, lds, st>>>(M_in, R0, R1, w, h, m, scale, flow, M_out, m_z, r1_z, flow_z);
-    }
-    return MVS_OK;
+        kernel<<<dim3(div_up(w, 64), div_up(h, ty), B), threads, lds, st>>>(M_in, R0, R1, w, h, m, scale, flow, M_out, m_z, r1_z, flow_z);
+        return MVS_OK;
+    };
+    // 64 x 16 tiles, 8 rows per thread of the vertical walk; (test hook MVS_FB_VARIANT=2: 4 rows per thread on 512 threads -- twice the
+    // wavefronts for the walk, measured SLOWER: 3.51 vs 3.16 ms per 1080p flow, its extra loads cost more than its occupancy buys)
+    if (tall && ctx->hooks.fb_variant == 2) return go(farneback_iteration_tiled<4, 4, 512>, 16, 4, 512, 4u);
+    if (tall) return go(farneback_iteration_tiled<8, 4, 256>, 16, 4, 256, 1u);
+    return go(farneback_iteration_tiled<4, 2, 256>, 8, 2, 256, 2u);   // 64 x 8 tiles
 }
 
 // cv::FarnebackOpticalFlow::calc, flags 0.  f0/f1: f32 frames (W*H); flow_out: W*H*2.  arena: >= 30*P floats.

@@ -616,7 +616,7 @@ extern "C" int mvs_alpha_shape_faces(const float *points, int rows, int cols, fl
     if (solid_components) *solid_components = r.components;
     if (faces) {
         if (face_capacity < *face_count) return 1;
-        std::memcpy(faces, r.faces.data(), r.faces.size() * sizeof(int32_t));
+        if (!r.faces.empty()) std::memcpy(faces, r.faces.data(), r.faces.size() * sizeof(int32_t));  // (memcpy from a null source is undefined even for 0 bytes: UBSan)
     }
     return 0;
 }
@@ -633,7 +633,7 @@ extern "C" int mvs_delaunay3_cells(const float *points, int rows, int cols, int3
     *cell_count = (int)(r.cells.size() / 4);
     if (cells) {
         if (cell_capacity < *cell_count) return 1;
-        std::memcpy(cells, r.cells.data(), r.cells.size() * sizeof(int32_t));
+        if (!r.cells.empty()) std::memcpy(cells, r.cells.data(), r.cells.size() * sizeof(int32_t));
     }
     return 0;
 }

@@ -43,7 +43,36 @@ struct Node {
         return *n;
     }
     double num() const { return atof(scalar.c_str()); }
+    // an integer the file is allowed to say: anything else -- not a number, NaN, beyond [lo, hi] -- is a rejected file, not a cast
+    // of an out-of-range double (undefined behaviour; found by tools/fuzz/fuzz_readers.cpp in its first second)
+    int integer(int lo, int hi, const char *what) const
+    {
+        const double v = atof(scalar.c_str());
+        if (!(v >= (double)lo && v <= (double)hi)) throw std::runtime_error(std::string("tracks YAML: ") + what + " out of range: '" + scalar + "'");
+        return (int)v;
+    }
 };
+
+// an integer token of a flow sequence, same rule
+int integerToken(const std::string &s, int lo, int hi, const char *what)
+{
+    const double v = atof(s.c_str());
+    if (!(v >= (double)lo && v <= (double)hi)) throw std::runtime_error(std::string("tracks YAML: ") + what + " out of range: '" + s + "'");
+    return (int)v;
+}
+
+// the bytes of `path` from the stream's current position to its end (what a header may promise at most)
+size_t bytesLeft(std::ifstream &f)
+{
+    const std::streampos here = f.tellg();
+    f.seekg(0, std::ios::end);
+    const std::streampos end = f.tellg();
+    f.seekg(here);
+    return (here < 0 || end < here) ? 0 : (size_t)(end - here);
+}
+
+constexpr int kMaxYamlDepth = 32;      // nesting of blocks (the exporter writes 4 levels)
+constexpr int kMaxFrameNumber = 1 << 22;  // 1-based frame numbers of a clip (46 hours at 25 frames per second)
 
 struct Line {
     int indent;
@@ -87,11 +116,12 @@ std::vector<Line> tokenize(std::istream &in)
     return lines;
 }
 
-Node parseValue(const std::vector<Line> &lines, size_t &i, int parentIndent);
+Node parseValue(const std::vector<Line> &lines, size_t &i, int parentIndent, int depth);
 
 // parse a block (map or sequence) whose entries sit at `indent`
-Node parseBlock(const std::vector<Line> &lines, size_t &i, int indent)
+Node parseBlock(const std::vector<Line> &lines, size_t &i, int indent, int depth = 0)
 {
+    if (depth > kMaxYamlDepth) throw std::runtime_error("tracks YAML: blocks nested deeper than 32 levels");  // (recursion bounded: a file cannot overflow the stack)
     Node n;
     if (i < lines.size() && lines[i].dash && lines[i].indent == indent) {
         n.kind = Node::Seq;
@@ -102,7 +132,7 @@ Node parseBlock(const std::vector<Line> &lines, size_t &i, int indent)
             while (i < lines.size() && lines[i].indent == indent && (first || !lines[i].dash)) {
                 first = false;
                 const std::string key = lines[i].key;
-                item.map.push_back(std::make_pair(key, parseValue(lines, i, indent)));
+                item.map.push_back(std::make_pair(key, parseValue(lines, i, indent, depth)));
             }
             n.seq.push_back(item);
         }
@@ -111,12 +141,12 @@ Node parseBlock(const std::vector<Line> &lines, size_t &i, int indent)
     n.kind = Node::Map;
     while (i < lines.size() && lines[i].indent == indent && !lines[i].dash) {
         const std::string key = lines[i].key;
-        n.map.push_back(std::make_pair(key, parseValue(lines, i, indent)));
+        n.map.push_back(std::make_pair(key, parseValue(lines, i, indent, depth)));
     }
     return n;
 }
 
-Node parseValue(const std::vector<Line> &lines, size_t &i, int parentIndent)
+Node parseValue(const std::vector<Line> &lines, size_t &i, int parentIndent, int depth)
 {
     const Line &l = lines[i++];
     Node n;
@@ -126,7 +156,7 @@ Node parseValue(const std::vector<Line> &lines, size_t &i, int parentIndent)
         v = sp == std::string::npos ? std::string() : trim(v.substr(sp));
     }
     if (v.empty()) {
-        if (i < lines.size() && lines[i].indent > parentIndent) return parseBlock(lines, i, lines[i].indent);
+        if (i < lines.size() && lines[i].indent > parentIndent) return parseBlock(lines, i, lines[i].indent, depth + 1);
         return n;
     }
     if (v[0] == '[') {
@@ -147,9 +177,9 @@ Node parseValue(const std::vector<Line> &lines, size_t &i, int parentIndent)
 
 Mat matrixOf(const Node &n)
 {
-    const int rows = (int)n.at("rows").num(), cols = (int)n.at("cols").num();
+    const int rows = n.at("rows").integer(0, 4096, "matrix rows"), cols = n.at("cols").integer(0, 4096, "matrix cols");
     const Node &data = n.at("data");
-    if ((int)data.flow.size() != rows * cols) throw std::runtime_error("tracks YAML: opencv-matrix data size mismatch");
+    if (data.flow.size() != (size_t)rows * (size_t)cols) throw std::runtime_error("tracks YAML: opencv-matrix data size mismatch");
     if (n.at("dt").scalar != "f") throw std::runtime_error("tracks YAML: only dt: f matrices are supported");
     Mat m(rows, cols, mvs::F32C1);
     for (int i = 0; i < rows * cols; i++) m.ptr<float>()[i] = (float)atof(data.flow[i].c_str());
@@ -171,6 +201,7 @@ bool readPgm(const std::string &path, int w, int h, Mat &out)
     f >> magic >> pw >> ph >> maxv;
     f.get();
     if (magic != "P5" || pw < 1 || ph < 1 || pw > 16384 || ph > 16384 || maxv != 255) throw std::runtime_error("frame " + path + ": expected a binary 8-bit PGM of at most 16384 x 16384");
+    if (bytesLeft(f) < (size_t)pw * ph) throw std::runtime_error("frame " + path + ": truncated (the header promises more pixels than the file holds)");  // before anything is allocated
     (void)w;  // a frame of another size than the (scaled) clip is resized by the caller, as configuration.cpp:232-233 does
     (void)h;
     out.create(ph, pw, mvs::U8C1);
@@ -188,6 +219,7 @@ bool readPpm(const std::string &path, int w, int h, Mat &out)
     f >> magic >> pw >> ph >> maxv;
     f.get();
     if (magic != "P6" || pw < 1 || ph < 1 || pw > 16384 || ph > 16384 || maxv != 255) throw std::runtime_error("frame " + path + ": expected a binary 8-bit PPM of at most 16384 x 16384");
+    if (bytesLeft(f) < (size_t)pw * ph * 3) throw std::runtime_error("frame " + path + ": truncated (the header promises more pixels than the file holds)");
     (void)w;
     (void)h;
     out.create(ph, pw, mvs::U8C3);
@@ -213,8 +245,8 @@ bool readY4m(const std::string &path, int skipFrames, int count, std::vector<Mat
     std::istringstream tags(header.substr(10));
     std::string tag;
     while (tags >> tag) {
-        if (tag[0] == 'W') w = atoi(tag.c_str() + 1);
-        else if (tag[0] == 'H') h = atoi(tag.c_str() + 1);
+        if (tag[0] == 'W') w = (int)std::min(1000000L, std::max(0L, strtol(tag.c_str() + 1, nullptr, 10)));   // (atoi of a number beyond int is undefined)
+        else if (tag[0] == 'H') h = (int)std::min(1000000L, std::max(0L, strtol(tag.c_str() + 1, nullptr, 10)));
         else if (tag[0] == 'C') {
             const std::string c = tag.substr(1);
             // exact tags only: C420p10 / C420p12 / C420p16 carry two bytes per sample and would decode as garbage
@@ -227,6 +259,11 @@ bool readY4m(const std::string &path, int skipFrames, int count, std::vector<Mat
     }
     if (w < 1 || h < 1 || w > 16384 || h > 16384) throw std::runtime_error("clip " + path + ": YUV4MPEG2 header without a size (or beyond 16384 x 16384)");
     const size_t cpw = cw ? (size_t)(w + cw - 1) / cw : 0, cph = ch ? (size_t)(h + ch - 1) / ch : 0;
+    if (count < 0 || skipFrames < 1) throw std::runtime_error("clip " + path + ": bad frame count / skip");
+    if (bytesLeft(f) < (size_t)w * h + 2 * cpw * cph) {  // not one whole frame: nothing is allocated for a header's promise
+        bgr.assign(count, Mat());
+        return true;
+    }
     std::vector<uint8_t> Y((size_t)w * h), U(cpw * cph), V(cpw * cph);
     bgr.assign(count, Mat());
     int next = 0;  // tracked frame waiting for stream frame next * skipFrames
@@ -364,14 +401,16 @@ void Configuration::parseYaml(const std::string &path)
     const Node root = parseBlock(lines, i, 0);
 
     const Node &clip = root.at("clip");  // configuration.cpp:145-166
-    width = (int)clip.at("width").num();
-    height = (int)clip.at("height").num();
+    width = clip.at("width").integer(2, 16384, "clip width");   // (what mvs_create accepts)
+    height = clip.at("height").integer(2, 16384, "clip height");
     clipPath = dirName(path) + "/" + clip.at("path").scalar;
     centerX = (float)clip.at("center-x").num();
     centerY = (float)clip.at("center-y").num();
     if (scalingFactor != 1 && scalingFactor != 0) {
-        width = (int)(width / scalingFactor);
-        height = (int)(height / scalingFactor);
+        const double sw = width / scalingFactor, sh = height / scalingFactor;
+        if (!(sw >= 2 && sw <= 16384 && sh >= 2 && sh <= 16384)) throw std::runtime_error("tracks YAML: the scaled clip size is outside 2..16384");
+        width = (int)sw;
+        height = (int)sh;
         centerX /= scalingFactor;
         centerY /= scalingFactor;
     }
@@ -382,12 +421,13 @@ void Configuration::parseYaml(const std::string &path)
     if (tracks)
         for (const Node &t : tracks->seq) {
             const Mat bundle = matrixOf(t.at("bundle"));  // 4 x 1
+            if (bundle.rows != 4 || bundle.cols != 1) throw std::runtime_error("tracks YAML: a bundle must be a 4 x 1 matrix");
             Mat row(1, 4, mvs::F32C1);
             for (int k = 0; k < 4; k++) row.at<float>(0, k) = bundle.at<float>(k, 0);
             bundles.push_back(row);
             std::set<int> enabled;
             for (const std::string &s : t.at("frames-enabled").flow) {
-                const int f = atoi(s.c_str());
+                const int f = integerToken(s, -kMaxFrameNumber, kMaxFrameNumber, "frames-enabled entry");
                 if ((f - 1) % (int)skipFrames == 0) enabled.insert((f - 1) / (int)skipFrames);
             }
             bundlesEnabled.push_back(enabled);
@@ -396,7 +436,7 @@ void Configuration::parseYaml(const std::string &path)
     int trackedFrameCount = -1;  // configuration.cpp:200-224
     std::map<int, const Node *> byIndex;
     for (const Node &c : root.at("camera").seq) {
-        int fi = (int)c.at("frame").num();
+        int fi = c.at("frame").integer(-kMaxFrameNumber, kMaxFrameNumber, "camera frame number");   // (the arrays below are sized by the largest one)
         if (fi <= 0) throw std::runtime_error("tracks YAML: frame numbers are 1-based");
         fi -= 1;
         if (fi % (int)skipFrames) continue;
@@ -412,6 +452,7 @@ void Configuration::parseYaml(const std::string &path)
         nearVals[kv.first] = (float)kv.second->at("near").num();
         farVals[kv.first] = (float)kv.second->at("far").num();
         cameras[kv.first] = matrixOf(kv.second->at("projection"));
+        if (cameras[kv.first].rows != 4 || cameras[kv.first].cols != 4) throw std::runtime_error("tracks YAML: a projection must be a 4 x 4 matrix");
         if (!(nearVals[kv.first] > 0 && farVals[kv.first] > 0)) throw std::runtime_error("tracks YAML: near/far must be positive");
     }
     frames.assign(trackedFrameCount, Mat());

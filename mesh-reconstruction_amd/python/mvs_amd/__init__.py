@@ -11,7 +11,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libmvs_hip.so")
+# MVS_BUILD_VARIANT=san: the address / undefined-behaviour sanitized host build (`make sanitize`: san/lib, san/bin) instead of lib / bin
+_VARIANT = os.environ.get("MVS_BUILD_VARIANT", "")
+LIB_DIR = os.path.join(PKG_ROOT, _VARIANT, "lib") if _VARIANT else os.path.join(PKG_ROOT, "lib")
+BIN_DIR = os.path.join(PKG_ROOT, _VARIANT, "bin") if _VARIANT else os.path.join(PKG_ROOT, "bin")
+LIB_PATH = os.path.join(LIB_DIR, "libmvs_hip.so")
 
 MVS_SWEEP_VOLUME = 1
 MVS_SWEEP_FUSED_ARGMIN = 2

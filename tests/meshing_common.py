@@ -5,7 +5,9 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIBDIR = os.path.join(ROOT, "mesh-reconstruction_amd", "lib")
+import mvs_amd  # noqa: E402
+
+LIBDIR = mvs_amd.LIB_DIR   # (lib, or san/lib under MVS_BUILD_VARIANT=san)
 
 
 def host_lib():

@@ -7,7 +7,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB = os.path.join(ORACLE_DIR, "_build", "libmvs_oracle.so")
+LIB = os.path.join(ORACLE_DIR, "_build", os.environ.get("MVS_BUILD_VARIANT", ""), "libmvs_oracle.so")   # (_build/san under MVS_BUILD_VARIANT=san)
 
 _fp, _u8p, _i32p, _u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
 

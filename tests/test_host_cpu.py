@@ -5,7 +5,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SELFTEST = os.path.join(ROOT, "mesh-reconstruction_amd", "bin", "host_selftest")
+SELFTEST = os.path.join(ROOT, "mesh-reconstruction_amd", os.environ.get("MVS_BUILD_VARIANT", ""), "bin", "host_selftest")
 TRACKS = os.path.join(ROOT, "tests", "data", "tracks")
 
 
@@ -18,7 +18,7 @@ def test_host_selftest_cpu():
 
 
 def test_host_library_links_only_the_c_abi():
-    lib = os.path.join(ROOT, "mesh-reconstruction_amd", "lib", "libmvs_host.so")
+    lib = os.path.join(ROOT, "mesh-reconstruction_amd", os.environ.get("MVS_BUILD_VARIANT", ""), "lib", "libmvs_host.so")
     out = subprocess.check_output(["readelf", "-d", lib]).decode()
     assert "libmvs_hip.so" in out and "oracle" not in out
     syms = subprocess.check_output(["nm", "-DC", lib]).decode()

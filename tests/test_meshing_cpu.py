@@ -142,7 +142,7 @@ def _det_int(m):
 
 def test_the_cpp_mirror_uses_it_for_the_first_iteration():
     import subprocess
-    exe = os.path.join(ROOT, "mesh-reconstruction_amd", "bin", "host_selftest")
+    exe = os.path.join(ROOT, "mesh-reconstruction_amd", os.environ.get("MVS_BUILD_VARIANT", ""), "bin", "host_selftest")
     r = subprocess.run([exe, "cpu", os.path.join(ROOT, "tests", "data", "tracks")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "cpu selftest: 0 failures" in r.stdout and "alpha shape of the zatisi bundle" in r.stdout
 

@@ -273,7 +273,7 @@ def test_a_rerun_gives_the_same_bytes_and_bad_arguments_fail(hip):
 
 
 def test_tessellate_of_the_cpp_mirror_reaches_it(tmp_path):
-    exe = os.path.join(ROOT, "mesh-reconstruction_amd", "bin", "host_selftest")
+    exe = os.path.join(ROOT, "mesh-reconstruction_amd", os.environ.get("MVS_BUILD_VARIANT", ""), "bin", "host_selftest")
     r = subprocess.run([exe, "gpu", os.path.join(ROOT, "tests", "data", "tracks"), str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert "gpu selftest: 0 failures" in r.stdout and "poissonSurface:" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -282,6 +282,7 @@ def test_the_wrappers_default_is_unit_normals_and_the_references_semantics_are_o
     """both backends of the reference use the normals' lengths as confidences (cgal_poisson.cpp:58-69; pcl.cpp:23 + 198-202).
     mvs_amd.poisson_surface (like host/poisson.cpp) normalises them BY DEFAULT -- a deliberate divergence recorded in DESIGN.md section 9 --
     and use_precision=True is the reference's behaviour.  This pins which is which."""
+    import mvs_amd
     rng = np.random.default_rng(11)
     d = rng.normal(size=(6000, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)

@@ -10,7 +10,7 @@ import numpy as np
 import tracks_yaml as tracks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SELFTEST = os.path.join(ROOT, "mesh-reconstruction_amd", "bin", "host_selftest")
+SELFTEST = os.path.join(ROOT, "mesh-reconstruction_amd", os.environ.get("MVS_BUILD_VARIANT", ""), "bin", "host_selftest")
 TRACKS = os.path.join(ROOT, "tests", "data", "tracks")
 
 
