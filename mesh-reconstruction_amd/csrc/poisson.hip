@@ -101,6 +101,7 @@ __global__ void splat_kernel(Grid g, const float *__restrict__ pts, const float 
 // bound of the true ones), so that no input can turn the search into an n^2 scan that runs for minutes.  The host sums the per-sample
 // means in sample order (deterministic).
 constexpr int KNN_BUDGET = 1 << 17;
+constexpr int KNN_ROW_COST = 16;  // what a probed cell row is charged, in candidates (two ~20-step binary searches)
 struct CellGrid {
     float ox, oy, oz, inv, cell;
     int nx, ny, nz;
@@ -164,7 +165,8 @@ __global__ void knn_spacing_kernel(CellGrid c, const unsigned *__restrict__ keys
                 const int a = lower_bound_u32(keys, n, row + (unsigned)i0);
                 int b = lower_bound_u32(keys, n, row + (unsigned)i1 + 1u);
                 if (best[KNN - 1] == 0.0f || budget <= 0) b = a;  // nothing can come closer than coincident samples; or the budget is spent
-                budget -= b - a;
+                budget -= (b - a) + KNN_ROW_COST;  // a probed row costs its two binary searches even when it is empty (a far
+                                                   // outlier -- homogeneous w near 0 -- walks (2R + 1)^2 empty rows per doubling of R)
                 for (int t = a; t < b; t++) {
                     if (t == s) continue;
                     const float4 q = sorted[t];
@@ -191,7 +193,9 @@ __global__ void knn_spacing_kernel(CellGrid c, const unsigned *__restrict__ keys
             sum += sqrtf(best[t]);
             m++;
         }
-    out[ids[s]] = m ? sum / (float)m : 0.0f;
+    // CGAL::compute_average_spacing(points, k) queries k + 1 neighbours -- the query point itself comes first, at distance 0 -- and divides the
+    // sum of the distances by the number of points visited, k + 1 (compute_average_spacing.h; ADVICE r04: rounds 3-4 divided by k)
+    out[ids[s]] = m ? sum / (float)(m + 1) : 0.0f;
 }
 
 __global__ void fixed_to_float_kernel(const fix_t *__restrict__ a, float *__restrict__ out, size_t n)

@@ -22,6 +22,7 @@
 // What it reports is what the criteria ask: how many facets are still below the angle bound (0 on every surface of the test-suite),
 // how many are above the radius bound, the smallest angle and the largest circumradius found.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -58,6 +59,40 @@ struct Work {
     long long stamp_now = 0;
     double q_bound = 0.0, guard = 0.0;
     int collapses = 0, flips = 0;
+
+    // undo log of the rescue round (below): every facet and incidence list is saved before it changes; rolled back newest first
+    struct Journal {
+        bool on = false;
+        std::vector<std::pair<int, std::array<int32_t, 3>>> faces;
+        std::vector<std::pair<int, std::vector<int>>> lists;
+        int collapses = 0, flips = 0;
+    } journal;
+    void save_face(int face)
+    {
+        if (journal.on) journal.faces.push_back({face, {f[3 * face], f[3 * face + 1], f[3 * face + 2]}});
+    }
+    void save_list(int v)
+    {
+        if (journal.on) journal.lists.push_back({v, inc[(size_t)v]});
+    }
+    void journal_begin()
+    {
+        journal.on = true;
+        journal.faces.clear();
+        journal.lists.clear();
+        journal.collapses = collapses;
+        journal.flips = flips;
+    }
+    void journal_commit() { journal.on = false; }
+    void journal_rollback()
+    {
+        for (size_t i = journal.faces.size(); i-- > 0;)
+            for (int k = 0; k < 3; k++) f[3 * journal.faces[i].first + k] = journal.faces[i].second[(size_t)k];
+        for (size_t i = journal.lists.size(); i-- > 0;) inc[(size_t)journal.lists[i].first] = journal.lists[i].second;
+        collapses = journal.collapses;
+        flips = journal.flips;
+        journal.on = false;
+    }
 
     double q_of(int face) const { return quality(p[f[3 * face]], p[f[3 * face + 1]], p[f[3 * face + 2]]); }
     V3 normal_of(int a, int b, int c) const { return cross(sub(p[b], p[a]), sub(p[c], p[a])); }
@@ -158,12 +193,17 @@ struct Work {
             for (int j = 0; j < 3; j++) {
                 const int w = f[3 * face + j];
                 if (w == u) continue;
+                save_list(w);
                 forget(inc[w], face);
             }
+            save_face(face);
             f[3 * face] = f[3 * face + 1] = f[3 * face + 2] = -1;
         }
+        save_list(v);
+        save_list(u);
         for (int face : inc[u]) {
             if (face == e[0] || face == e[1]) continue;
+            save_face(face);
             for (int j = 0; j < 3; j++)
                 if (f[3 * face + j] == u) f[3 * face + j] = v;
             inc[v].push_back(face);
@@ -207,6 +247,12 @@ struct Work {
         int f1 = e[0], f2 = e[1];
         if (!directed(f1, u, v)) std::swap(f1, f2);
         const int c = third(f1, u, v), d = third(f2, u, v);
+        save_face(f1);
+        save_face(f2);
+        save_list(u);
+        save_list(v);
+        save_list(c);
+        save_list(d);
         f[3 * f1] = u, f[3 * f1 + 1] = d, f[3 * f1 + 2] = c;
         f[3 * f2] = d, f[3 * f2 + 1] = v, f[3 * f2 + 2] = c;
         forget(inc[v], f1);
@@ -234,6 +280,67 @@ struct Work {
         if (best.kind == 1) do_collapse(best.u, best.v, touched);
         else if (best.kind == 2) do_flip(best.u, best.v, touched);
         return best.kind != 0;
+    }
+
+    // The rescue round (round 5): a facet every single operation would leave next to a WORSE facet -- a local minimum of the greedy rule
+    // above; one or two per 60 000 facets on the test surfaces -- gets a look-ahead: each valid operation on its edges (best result
+    // first), improvement or not, is applied on trial, the facets it leaves below the bound are handed to improve() in turn (at most
+    // RESCUE_STEPS follow-up operations), and the sequence is kept only if NO facet it touched ends below the bound; otherwise every
+    // change is rolled back.  Same guards as everywhere: no vertex moves, none is added, the link condition and the distance bound hold
+    // for every single operation.
+    static constexpr int RESCUE_STEPS = 6;
+    bool alive_bad(int face) const { return f[3 * face] >= 0 && q_of(face) < q_bound; }
+    bool rescue(int face, std::vector<int> &touched)
+    {
+        std::vector<Candidate> cands;
+        for (int k = 0; k < 3; k++) {
+            const int u = f[3 * face + k], v = f[3 * face + (k + 1) % 3];
+            double before = 0.0;
+            double a = try_collapse(u, v, &before);
+            if (a > -2.0) cands.push_back({1, u, v, a});
+            a = try_collapse(v, u, &before);
+            if (a > -2.0) cands.push_back({1, v, u, a});
+            a = try_flip(u, v, &before);
+            if (a > -2.0) cands.push_back({2, u, v, a});
+        }
+        std::stable_sort(cands.begin(), cands.end(), [](const Candidate &x, const Candidate &y) { return x.after > y.after; });
+        for (const Candidate &c : cands) {
+            journal_begin();
+            std::vector<int> trial, work;
+            if (c.kind == 1) do_collapse(c.u, c.v, trial);
+            else do_flip(c.u, c.v, trial);
+            for (int t : trial)
+                if (alive_bad(t)) work.push_back(t);
+            bool ok = true;
+            int steps = 0;
+            for (size_t head = 0; head < work.size(); head++) {
+                const int j = work[head];
+                if (!alive_bad(j)) continue;
+                if (steps++ >= RESCUE_STEPS) {
+                    ok = false;
+                    break;
+                }
+                std::vector<int> t2;
+                if (!improve(j, t2)) {
+                    ok = false;
+                    break;
+                }
+                for (int t : t2) {
+                    trial.push_back(t);
+                    if (alive_bad(t)) work.push_back(t);
+                }
+            }
+            for (size_t i = 0; ok && i < trial.size(); i++)
+                if (alive_bad(trial[i])) ok = false;
+            if (ok && alive_bad(face)) ok = false;
+            if (ok) {
+                journal_commit();
+                touched.insert(touched.end(), trial.begin(), trial.end());
+                return true;
+            }
+            journal_rollback();
+        }
+        return false;
     }
 };
 
@@ -288,8 +395,9 @@ extern "C" int mvs_surface_enforce_criteria(mvs_surface *s, float min_angle_deg,
             if (w.f[3 * i] >= 0 && w.q_of(i) < w.q_bound) queue.push_back(i);
         const size_t budget = 2 * (size_t)nf + 1000;  // (collapses are finite by themselves; the cap is for flips chasing each other: a clean surface needs nf / 50 operations)
         size_t done = 0;
-        // second round: the facets the first one could not help, with half of the distance bound to move in instead of a quarter
-        for (int round = 0; round < 2; round++) {
+        // second round: the facets the first one could not help, with half of the distance bound to move in instead of a quarter; third
+        // round (round 5): with the whole bound -- the distance the reference itself allows a facet (cgal_poisson.cpp:52)
+        for (int round = 0; round < 3; round++) {
             for (size_t head = 0; head < queue.size() && done < budget; head++) {
                 const int face = queue[head];
                 if (w.f[3 * face] < 0 || w.q_of(face) >= w.q_bound) continue;
@@ -307,7 +415,22 @@ extern "C" int mvs_surface_enforce_criteria(mvs_surface *s, float min_angle_deg,
             left.erase(std::unique(left.begin(), left.end()), left.end());
             if (left.empty()) break;
             queue.swap(left);
-            w.guard = 0.5 * (double)max_distance;
+            w.guard = (round == 0 ? 0.5 : 1.0) * (double)max_distance;
+        }
+        // rescue round: what three greedy rounds left below the bound, with look-ahead (Work::rescue), under the whole distance bound
+        {
+            std::vector<int> left;
+            for (int face : queue)
+                if (w.alive_bad(face)) left.push_back(face);
+            std::sort(left.begin(), left.end());
+            left.erase(std::unique(left.begin(), left.end()), left.end());
+            w.guard = (double)max_distance;
+            for (size_t head = 0; head < left.size() && head < 4096; head++) {  // (a clean surface leaves a handful; the cap bounds a hopeless one)
+                const int face = left[head];
+                if (!w.alive_bad(face)) continue;
+                touched.clear();
+                (void)w.rescue(face, touched);
+            }
         }
         r.collapses = w.collapses, r.flips = w.flips;
         // compact: vertices still used, in their old order; facets in their old order

@@ -105,14 +105,15 @@ SPLAT_SCALE = np.float32(65536.0)
 
 
 def average_spacing(points, k=6):
-    """CGAL::compute_average_spacing(points, k) (cgal_poisson.cpp:77): per sample the mean distance to its k nearest OTHER samples
-    (CGAL queries k + 1 neighbours and skips the query point), averaged over the samples; scipy's k-d tree, float64"""
+    """CGAL::compute_average_spacing(points, k) (cgal_poisson.cpp:77): CGAL queries k + 1 neighbours per sample -- the sample itself comes
+    first, at distance 0 -- and divides the sum of the distances by the k + 1 points visited (compute_average_spacing.h, as recalled: CGAL
+    is not in this image); averaged over the samples; scipy's k-d tree, float64"""
     from scipy.spatial import cKDTree
     p = np.asarray(points, np.float32)
     xyz = (p[:, :3] / p[:, 3:4]).astype(np.float64)
     kk = min(k, len(xyz) - 1)
     d, _ = cKDTree(xyz).query(xyz, k=kk + 1)
-    return float(d[:, 1:].mean())
+    return float((d.sum(1) / (kk + 1)).mean())
 
 
 def poisson_grid(points, grid_log2):
@@ -393,16 +394,43 @@ def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_dista
             return None
         return after, before
 
+    journal = {"on": False, "log": [], "count": None}
+
+    def save_face(i):
+        if journal["on"]:
+            journal["log"].append(("f", i, list(f[i])))
+
+    def save_list(w):
+        if journal["on"]:
+            journal["log"].append(("l", w, list(inc[w])))
+
+    def journal_begin():
+        journal["on"], journal["log"], journal["count"] = True, [], dict(count)
+
+    def journal_rollback():
+        for kind, idx, old in reversed(journal["log"]):
+            if kind == "f":
+                f[idx] = old
+            else:
+                inc[idx] = old
+        count.update(journal["count"])
+        journal["on"] = False
+
     def do_collapse(u, v, touched):
         e = edge_facets(u, v)[:2]
         for i in e:
             for w in f[i]:
                 if w != u:
+                    save_list(w)
                     inc[w].remove(i)
+            save_face(i)
             f[i] = [-1, -1, -1]
+        save_list(v)
+        save_list(u)
         for i in inc[u]:
             if i == e[0] or i == e[1]:
                 continue
+            save_face(i)
             f[i] = [v if w == u else w for w in f[i]]
             inc[v].append(i)
             touched.append(i)
@@ -449,6 +477,8 @@ def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_dista
     def do_flip(u, v, touched):
         f1, f2 = flip_pair(u, v)
         c, d = third(f1, u, v), third(f2, u, v)
+        save_face(f1), save_face(f2)
+        save_list(u), save_list(v), save_list(c), save_list(d)
         f[f1] = [u, d, c]
         f[f2] = [d, v, c]
         inc[v].remove(f1)
@@ -472,9 +502,61 @@ def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_dista
             do_flip(best[1], best[2], touched)
         return best[0] != 0
 
+    def alive_bad(i):
+        return f[i][0] >= 0 and q_of(i) < q_bound
+
+    def rescue(i, touched):
+        """csrc/surface_criteria.cpp Work::rescue: every valid operation on the facet's edges, best result first, applied on trial; the facets
+        it leaves below the bound go to improve() in turn (at most 6 follow-up operations); kept only if nothing it touched ends below the
+        bound, rolled back otherwise"""
+        cands = []
+        for k in range(3):
+            u, v = f[i][k], f[i][(k + 1) % 3]
+            for kind, a, b, fn in ((1, u, v, try_collapse), (1, v, u, try_collapse), (2, u, v, try_flip)):
+                r = fn(a, b)
+                if r is not None:
+                    cands.append((kind, a, b, r[0]))
+        cands.sort(key=lambda c: -c[3])   # stable, like std::stable_sort
+        for kind, a, b, _ in cands:
+            journal_begin()
+            trial = []
+            if kind == 1:
+                do_collapse(a, b, trial)
+            else:
+                do_flip(a, b, trial)
+            work = [t for t in trial if alive_bad(t)]
+            ok, steps, head = True, 0, 0
+            while head < len(work):
+                j = work[head]
+                head += 1
+                if not alive_bad(j):
+                    continue
+                if steps >= 6:
+                    ok = False
+                    break
+                steps += 1
+                t2 = []
+                if not improve(j, t2):
+                    ok = False
+                    break
+                for t in t2:
+                    trial.append(t)
+                    if alive_bad(t):
+                        work.append(t)
+            if ok and any(alive_bad(t) for t in trial):
+                ok = False
+            if ok and alive_bad(i):
+                ok = False
+            if ok:
+                journal["on"] = False
+                touched += trial
+                return True
+            journal_rollback()
+        return False
+
     queue = [i for i in range(nf) if f[i][0] >= 0 and q_of(i) < q_bound]
     budget, done = 2 * nf + 1000, 0
-    for _round in range(2):
+    for rnd in range(3):
         head = 0
         while head < len(queue) and done < budget:
             i = queue[head]
@@ -489,7 +571,12 @@ def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_dista
         if not left:
             break
         queue = left
-        guard[0] = 0.5 * float(np.float32(max_distance))
+        guard[0] = (0.5 if rnd == 0 else 1.0) * float(np.float32(max_distance))
+    left = sorted(set(i for i in queue if alive_bad(i)))
+    guard[0] = float(np.float32(max_distance))
+    for i in left[:4096]:
+        if alive_bad(i):
+            rescue(i, [])
     used = np.zeros(nv, bool)
     alive = [t for t in f if t[0] >= 0]
     for t in alive:
