@@ -56,6 +56,15 @@ __global__ void probe(float *out, unsigned long long *cyc, float seed)
             if (OP == 26) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(*(double *)&a[i & ~1]) : "v"(*(double *)&b[0]));
             if (OP == 27) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(*(double *)&a[i & ~1]) : "v"(c0));
             if (OP == 28) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[i]) : "v"(*(double *)&b[0]));
+            // round 5: what sweep_exact_rect's row loop is made of, and what could replace parts of it
+            if (OP == 29) { int sg; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sg) : "v"(a[i])); asm volatile("" :: "s"(sg)); }
+            if (OP == 30) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
+            if (OP == 31) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(a[i]) : "v"(c0));
+            if (OP == 32) asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));
+            if (OP == 33) asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(a[i]));
+            if (OP == 34) asm volatile("v_sad_u16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));
+            if (OP == 35) { int sg; asm volatile("v_readlane_b32 %0, %1, 3\n\ts_nop 1\n\tv_fmac_f32 %2, %0, %3" : "=&s"(sg), "+v"(b[i]) , "+v"(a[i]) : "v"(c0)); }
+            if (OP == 36) asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]\n\tv_fma_mix_f32 %0, %0, %1, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\tv_fmac_f32 %0, %1, %2\n\tv_cvt_i32_f32 %0, %0\n\tv_sad_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -157,6 +166,14 @@ int main()
     run<26>("v_mul_f64", out, cyc, 64);
     run<27>("v_cvt_f64_f32", out, cyc, 64);
     run<28>("v_cvt_f32_f64", out, cyc, 64);
+    run<29>("v_readlane_b32", out, cyc, 64);
+    run<30>("v_add_u32", out, cyc, 64);
+    run<31>("v_cvt_pk_u8_f32", out, cyc, 64);
+    run<32>("v_sad_u8", out, cyc, 64);
+    run<33>("v_cvt_u32_f32", out, cyc, 64);
+    run<34>("v_sad_u16", out, cyc, 64);
+    run<35>("readlane+nop+fmac(s)", out, cyc, 64);
+    run<36>("mix,mix,fmac,cvt,sad (5)", out, cyc, 64);
     for (int stride : {1, 2, 3}) {
         for (int wps : {1, 2, 4}) {
             probe_lds<8><<<256 * wps, 256>>>(out, cyc, stride);
