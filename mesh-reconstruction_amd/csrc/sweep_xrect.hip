@@ -32,10 +32,12 @@ namespace mvs {
 
 namespace {
 
-constexpr int XR_TILE_H = 8, XR_PC = 16, XR_KW = 4;  // tile rows, planes per chunk, planes per wavefront
+constexpr int XR_TILE_H = 8, XR_PC = 16, XR_KW = 4;  // tile rows, planes per chunk, planes per wavefront (round 5 built 8 planes per wavefront on 32-plane chunks -- the code below is
+                                                      // generic in both -- and dropped it: on a ring of views the widest and the tallest box belong to DIFFERENT views, the slot holds their product,
+                                                      // and at c3 it no longer fits 24 KiB: the plan falls back to sweep_tiled; where it fits, the copy volume per sample does not shrink)
 constexpr int XR_MAX_NI = 6;                          // 1 KiB copy instructions per wavefront and region, at most (24 KiB per slot: c3's boxes are ~84 quads x 24 rows of 8 bytes)
 constexpr int XR_MAX_REGIONS = 256;                    // (chunks x views) of one workgroup: 16 KiB of records at the most
-constexpr int XR_WAVES = 4;                           // launch bound: <= 128 VGPRs (two 18 KiB slots at c3 leave room for four workgroups per CU anyway)
+constexpr int XR_WAVES = 4;                           // launch bound: <= 128 VGPRs (two 16 KiB slots + 16 KiB of records at c3: three workgroups per CU)
 
 typedef const __attribute__((address_space(4))) uint32_t *cu32;
 typedef const __attribute__((address_space(4))) float *cf32;
@@ -82,9 +84,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint3
 // ------------------------------------------------------------------------------------------------------
 // planner: one 8-dword record per (tile column, view, chunk) and per (tile row, view, chunk)
 // ------------------------------------------------------------------------------------------------------
-// X record: q0, q2, q3, r = RN(1 / q11) | box (x0 | quads << 16; 0 quads: nothing of the tile column in frame) | flags | 8 x0 | 0
-// Y record: q5, q6, q7, 8 (pad_slab v + y0 pitch) | box (y0 | rows << 16) | flags | 0 | 0
-// flags: bit d = every valid pixel of the tile column (row) is in frame at plane d of the chunk; bit 16 + d = some pixel is.
+// X record: q0, q2, q3, r = RN(1 / q11) | box (x0 | quads << 16; 0 quads: nothing of the tile column in frame) | full | 8 x0 | some
+// Y record: q5, q6, q7, 8 (pad_slab v + y0 pitch) | box (y0 | rows << 16) | full | 0 | some
+// full: bit d = every valid pixel of the tile column (row) is in frame at plane d of the chunk; some: bit d = some pixel is.
 // cx over the tile's columns and the chunk's planes is monotone in both (compositions of roundings of monotone functions): the box is
 // bounded by the four corner evaluations, and a plane is in frame for every column iff it is for the two end columns.  Samples out of
 // frame (cx <= 0.5 or >= W + 0.5) are masked in the kernel and need no texel, hence the clamp.  stats: [0] widest box, [1] tallest.
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void plan_xrect(XrArgs a, int tiles_y, uint32_
     const int p0 = t * (is_y ? XR_TILE_H : TILE_W), p1 = min(p0 + (is_y ? XR_TILE_H : TILE_W), size) - 1;
     const float lim = (float)size + 0.5f;
     float lo = 3.0e38f, hi = -3.0e38f;
-    uint32_t flags = 0u;
+    uint32_t flags = 0u, some = 0u;
     for (int k = 0; k < XR_PC; k++) {
         const float z = a.z[min(d0 + k, a.D - 1)];
         float c[2];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void plan_xrect(XrArgs a, int tiles_y, uint32_
         }
         const float cl = fminf(c[0], c[1]), ch = fmaxf(c[0], c[1]);
         if (cl > 0.5f && ch < lim) flags |= 1u << k;
-        if (ch > 0.5f && cl < lim) flags |= 1u << (16 + k);
+        if (ch > 0.5f && cl < lim) some |= 1u << k;
         if (d0 + k < a.D) {
             lo = fminf(lo, cl);
             hi = fmaxf(hi, ch);
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void plan_xrect(XrArgs a, int tiles_y, uint32_
         if (!is_y) extent = (extent + 1) & ~1;
         box = (uint32_t)i0 | ((uint32_t)extent << 16);
     } else {
-        flags = 0u;
+        flags = some = 0u;
     }
     if (live) {
         uint32_t *rec = (is_y ? yrec : xrec) + (size_t)e * 8;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void plan_xrect(XrArgs a, int tiles_y, uint32_
         rec[4] = box;
         rec[5] = flags;
         rec[6] = is_y ? 0u : 8u * (uint32_t)i0;
-        rec[7] = 0u;
+        rec[7] = some;
     }
     // one atomic per wavefront and counter (the host waits for the kernel before it reads them)
     int wx = (live && !is_y) ? extent : 0, wy = (live && is_y) ? extent : 0;
@@ -270,12 +272,23 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
 #pragma unroll
         for (int k = 0; k < XR_KW; k++) acc[j][k] = 0u;
     }
-    int notfull[XR_KW] = {0, 0, 0, 0};  // per plane of this wavefront: views of the current chunk whose count did NOT go to every cell of the plane (wave-uniform)
-    float zc[XR_KW] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int notfull[XR_KW];  // per plane of this wavefront: views of the current chunk whose count did NOT go to every cell of the plane (wave-uniform)
+    float zc[XR_KW];
+#pragma unroll
+    for (int k = 0; k < XR_KW; k++) {
+        notfull[k] = 0;
+        zc[k] = 0.0f;
+    }
 
     uint32_t slot_cur = 0u, slot_nxt = (uint32_t)a.slot_bytes;
     int chunk = chunk_first, v = a.v0;
     const uint32_t ctab_addr = lds_base + ctab_byte;
+    // 32 bytes per wavefront behind the records: the 8 row fractions of a plane go from lanes 0..7 to ALL lanes through LDS -- one ds_write_b32,
+    // then one ds_read_b32 per row with the same address on every lane (a broadcast: conflict-free, and issued to the LDS pipe, which this
+    // kernel leaves two thirds idle) -- instead of one v_readlane_b32 per (row, plane) on the vector unit, which is what bounds it (round 5:
+    // tools/valu_microbench prices v_readlane at 4.2 of the row loop's 27 cycles)
+    const uint32_t fy_wave_addr = ctab_addr + 64u * (uint32_t)max(nreg, 1) + 32u * (uint32_t)wave;
+    const uint32_t fy_lane_addr = fy_wave_addr + 4u * (uint32_t)(lane & 7);
     // records of region 0 (its copy goes out before the loop) -- 64 bytes per region
     u32x4 x0r, x1r, y0r, y1r;
     lds_read_record(ctab_addr, x0r, x1r, y0r, y1r);
@@ -303,13 +316,15 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
         const float q5 = __builtin_bit_cast(float, u5), q6 = __builtin_bit_cast(float, u6), q7 = __builtin_bit_cast(float, u7);
         const uint32_t xb = (uint32_t)__builtin_amdgcn_readfirstlane((int)x1r.x), yb = (uint32_t)__builtin_amdgcn_readfirstlane((int)y1r.x);
         const uint32_t xfl = (uint32_t)__builtin_amdgcn_readfirstlane((int)x1r.y), yfl = (uint32_t)__builtin_amdgcn_readfirstlane((int)y1r.y);
+        const uint32_t xsm = (uint32_t)__builtin_amdgcn_readfirstlane((int)x1r.w), ysm = (uint32_t)__builtin_amdgcn_readfirstlane((int)y1r.w);
         const float Ax = __builtin_fmaf(q0, xn, q3), Ayl = __builtin_fmaf(q5, ynl, q7);
         const int x0 = (int)(xb & 0xffffu), y0 = (int)(yb & 0xffffu);
         const uint32_t slot_addr = lds_base + slot_cur;
-        const uint32_t both_fl = (xfl & yfl) >> (4 * wave);  // bit k: plane k of this wavefront is in frame for every pixel of the tile; bit 16 + k: for some pixel
+        const uint32_t both_fl = (xfl & yfl) >> (XR_KW * wave);  // bit k: plane k of this wavefront is in frame for every pixel of the tile
+        const uint32_t both_sm = (xsm & ysm) >> (XR_KW * wave);  // bit k: for some pixel
 #pragma unroll
         for (int k = 0; k < XR_KW; k++) {
-            if (!((both_fl >> (16 + k)) & 1u) || XR_DBG(a, 2)) {  // nothing of the tile in frame at this plane
+            if (!((both_sm >> k) & 1u) || XR_DBG(a, 2)) {  // nothing of the tile in frame at this plane
                 notfull[k]++;
                 continue;
             }
@@ -323,19 +338,25 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
             // rows of the tile usually sample consecutive texel rows (cy advances by one per row up to its rounding): then a row's address is the previous one + a stride
             const bool consecutive = XR_DBG(a, 16) || ((uint32_t)__builtin_amdgcn_ballot_w64(iyl - (lane & 7) == iy0) & 0xffu) == 0xffu;
             if (((both_fl >> k) & 1u) && consecutive) {
-                // the 8 reads first, one wait, then the arithmetic
+                // the row fractions to LDS, the 8 quad reads and the 8 broadcast reads of the fractions, one wait, then the arithmetic
                 unsigned long long h[8];
+                float fyv[8];
                 uint32_t ad = addrx + (uint32_t)(iy0 - y0) * rs8;
+                asm volatile("ds_write_b32 %0, %1" ::"v"(fy_lane_addr), "v"(fyl) : "memory");
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     asm volatile("ds_read_b64 %0, %1" : "=v"(h[j]) : "v"(ad));
                     ad += rs8;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]));
+#pragma unroll
+                for (int j = 0; j < 8; j++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fyv[j]) : "v"(fy_wave_addr), "n"(4 * j));
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]), "+v"(fyv[0]), "+v"(fyv[1]), "+v"(fyv[2]),
+                               "+v"(fyv[3]), "+v"(fyv[4]), "+v"(fyv[5]), "+v"(fyv[6]), "+v"(fyv[7]));
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const half4_t q4 = __builtin_bit_cast(half4_t, h[j]);
-                    const float fy = XR_DBG(a, 16) ? zc[(j + k) & 3] : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fyl), j));  // (experiment 16: what the per-row values cost -- an SGPR that is there anyway)
+                    const float fy = XR_DBG(a, 16) ? zc[(j + k) & (XR_KW - 1)] : fyv[j];  // (experiment 16: what the per-row values cost)
                     const float ta = __builtin_fmaf(fx, (float)q4[1], (float)q4[0]);
                     const float tb = __builtin_fmaf(fx, (float)q4[3], (float)q4[2]);
                     acc[j][k] = sad_u32((uint32_t)(int)__builtin_fmaf(fy, tb, ta), Im[j], acc[j][k]);
@@ -563,7 +584,7 @@ int sweep_xrect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsig
     if (!want) want = div_up(16 * ctx->num_cus, tiles);
     p.cps = div_up(nch, max(1, min(want, nch)));
     p.cps = max(1, min(p.cps, XR_MAX_REGIONS / max(1, p.vcount)));  // the records of a workgroup's regions live in LDS (64 bytes each)
-    size_t lds = 2 * (size_t)a.slot_bytes + 64 * (size_t)p.cps * (size_t)max(1, p.vcount);
+    size_t lds = 2 * (size_t)a.slot_bytes + 64 * (size_t)p.cps * (size_t)max(1, p.vcount) + 128;  // slots, records, 32 bytes per wavefront for the row fractions
     if (fused) lds = lds < 16384 ? 16384 : lds;  // the cross-wavefront depth selection borrows 16 KiB
     a.cps = p.cps;
     const int nsplit = div_up(nch, p.cps);
