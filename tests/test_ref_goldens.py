@@ -10,6 +10,18 @@ import pytest
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
+# what each array of the reference's outputs will be held to the day the files exist (tools/ref_goldens/README.md has the same table with
+# the reasons); the assertions below use these numbers
+TOLERANCES = {
+    "depth": {"coverage_equal_min": 0.995, "abs_max_where_both_cover": 2.0 / (1 << 22)},
+    "projected_mask": {"equal_min": 0.99},
+    "projected_intensity": {"within_1_grey_level_min": 0.97, "mean_abs_max": 0.5},
+    "mixed": "exact", "depth_after_mix": "exact",
+    "compare": {"rtol": 1e-5, "atol": 1e-3},
+    "flow_remap": {"within_1_grey_level_min": 0.99},
+    "flow_farneback": {"mean_abs_px_max": 0.05}, "flow_variational": {"mean_abs_px_max": 0.05},
+}
+
 
 def _load(name):
     path = os.path.join(GOLD, name)
@@ -26,13 +38,13 @@ def test_oracle_renderer_against_reference_goldens(oracle):
     covered = (d != 1.0) & (g["depth"] != 1.0)
     # GL rasterisation rules at silhouettes and its depth-buffer quantisation (typically 24 bit) are the driver's: coverage may differ
     # on a thin band of edge pixels, depth by the quantisation step
-    assert (covered == ((d != 1.0) | (g["depth"] != 1.0))).mean() > 0.995
-    assert np.abs(d[covered] - g["depth"][covered]).max() < 2.0 / (1 << 22)
+    assert (covered == ((d != 1.0) | (g["depth"] != 1.0))).mean() > TOLERANCES["depth"]["coverage_equal_min"]
+    assert np.abs(d[covered] - g["depth"][covered]).max() < TOLERANCES["depth"]["abs_max_where_both_cover"]
     p = oracle.projected(soup, g["in_mvp"], g["in_frame_b"], g["in_side_mvp"])
     both = (p[..., 1] == 255) & (g["projected"][..., 1] == 255)
-    assert (p[..., 1] == g["projected"][..., 1]).mean() > 0.99
+    assert (p[..., 1] == g["projected"][..., 1]).mean() > TOLERANCES["projected_mask"]["equal_min"]
     diff = np.abs(p[..., 0].astype(int) - g["projected"][..., 0].astype(int))[both]
-    assert np.mean(diff <= 1) > 0.97 and diff.mean() < 0.5   # texture filtering is the driver's
+    assert np.mean(diff <= 1) > TOLERANCES["projected_intensity"]["within_1_grey_level_min"] and diff.mean() < TOLERANCES["projected_intensity"]["mean_abs_max"]   # texture filtering is the driver's
     mixed, d2 = oracle.mix_background(g["projected"], g["in_frame_a"], g["depth"].copy())
     np.testing.assert_array_equal(mixed, g["mixed"])          # util.cpp:366-387 is plain byte logic: exact
     np.testing.assert_array_equal(d2, g["depth_after_mix"])
@@ -41,11 +53,11 @@ def test_oracle_renderer_against_reference_goldens(oracle):
 def test_oracle_flow_stages_against_reference_goldens(oracle):
     g = _load("ref_flow.npz")
     a, b = g["in_frame_a"], g["in_frame_b"]
-    np.testing.assert_allclose(oracle.compare(a, b), g["compare"], rtol=1e-5, atol=1e-3)      # pyrDown / pyrUp: f32 sums in OpenCV's order
+    np.testing.assert_allclose(oracle.compare(a, b), g["compare"], **TOLERANCES["compare"])      # pyrDown / pyrUp: f32 sums in OpenCV's order
     fv = oracle.calculate_flow(a, b, False)
     ff = oracle.calculate_flow(a, b, True)
     # restated from the papers + OpenCV's documented parameters (OpenCV version unpinned): flows agree to a fraction of a pixel
-    assert np.abs(fv[..., :2] - g["flow_variational"][..., :2]).mean() < 0.05
-    assert np.abs(ff[..., :2] - g["flow_farneback"][..., :2]).mean() < 0.05
+    assert np.abs(fv[..., :2] - g["flow_variational"][..., :2]).mean() < TOLERANCES["flow_variational"]["mean_abs_px_max"]
+    assert np.abs(ff[..., :2] - g["flow_farneback"][..., :2]).mean() < TOLERANCES["flow_farneback"]["mean_abs_px_max"]
     r = oracle.flow_remap(g["flow_variational"], b)
-    assert np.mean(np.abs(r.astype(int) - g["flow_remap"].astype(int)) <= 1) > 0.99                # cv::remap's Q15 bicubic table
+    assert np.mean(np.abs(r.astype(int) - g["flow_remap"].astype(int)) <= 1) > TOLERANCES["flow_remap"]["within_1_grey_level_min"]                # cv::remap's Q15 bicubic table
