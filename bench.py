@@ -127,7 +127,7 @@ def rocprof_kernel_ms(kernel, config):
             rows = list(csv.DictReader(open(path)))
         except Exception:
             continue
-        mine = [r for r in rows if ("mvs::%s<" % kernel) in r["Name"] or ("mvs::%s(" % kernel) in r["Name"]]
+        mine = [r for r in rows if ("::%s<" % kernel) in r["Name"] or ("::%s(" % kernel) in r["Name"]]   # (mvs::, or mvs::(anonymous namespace)::)
         if not mine:
             continue
         top = max(mine, key=lambda r: float(r["TotalDurationNs"]))

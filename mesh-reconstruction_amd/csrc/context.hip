@@ -269,6 +269,8 @@ void mvs_destroy(mvs_ctx *ctx)
     if (ctx->own_stream && ctx->own_stream != ctx->stream) (void)hipStreamSynchronize(ctx->own_stream);
     for (auto &lane : ctx->lanes)  // before any buffer is freed: a lane may still read frame_buf or its arena
         if (lane.stream) (void)hipStreamSynchronize(lane.stream);
+    for (hipGraphExec_t g : ctx->flow_graph)
+        if (g) (void)hipGraphExecDestroy(g);
     DevBuf *bufs[] = {&ctx->main_img, &ctx->side_pads, &ctx->qmats, &ctx->ztab, &ctx->plan, &ctx->upload,
                       &ctx->volume_own, &ctx->depth, &ctx->cost, &ctx->index, &ctx->soup, &ctx->r_zbuf,
                       &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2,

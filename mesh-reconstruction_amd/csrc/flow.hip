@@ -45,6 +45,12 @@ struct Taps {
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);    \
     if (x >= w || y >= h) return;
 
+__global__ __launch_bounds__(256) void zero_f32_kernel(float *__restrict__ d, size_t n)  // (test hook MVS_FLOW_GRAPH=2: a kernel in place of the captured hipMemsetAsync nodes)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = 0.0f;
+}
+
 __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t *__restrict__ s, float *__restrict__ d, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1093,7 +1099,10 @@ static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, floa
         const int w = lw[k], h = lh[k];
         flow = k == 0 ? flow_out : (prevflow == flowA ? flowB : flowA);
         if (!prevflow) {
-            MVS_HIP(ctx, hipMemsetAsync(flow, 0, sizeof(float) * (size_t)w * h * 2, st));
+            if (ctx->hooks.flow_graph_kernel_memset)
+                zero_f32_kernel<<<(unsigned)(((size_t)w * h * 2 + 255) / 256), 256, 0, st>>>(flow, (size_t)w * h * 2);
+            else
+                MVS_HIP(ctx, hipMemsetAsync(flow, 0, sizeof(float) * (size_t)w * h * 2, st));
         } else {
             resize_linear_kernel<2><<<g2(w, h), 256, 0, st>>>(prevflow, pw, ph, flow, w, h, (float)(1. / pyr_scale), 1);
         }
@@ -1225,7 +1234,10 @@ static int flow_run(mvs_ctx *ctx, const FlowBufs &b, int use_farneback)
             const int winsize = (H + W) / 100, poly_n = poly_sigma < 1.5 ? 5 : 7;
             if ((r = farneback_device(ctx, b.f0, b.f1, b.flow2, b.arena, 10, 0.8, winsize, 7, poly_n, poly_sigma))) return r;
         } else {
-            MVS_HIP(ctx, hipMemsetAsync(b.flow2, 0, sizeof(float) * 2 * P, st));  // flow.cpp:31 (uninitialised there), A-11
+            if (ctx->hooks.flow_graph_kernel_memset)
+                zero_f32_kernel<<<g1(2 * P), 256, 0, st>>>(b.flow2, 2 * P);
+            else
+                MVS_HIP(ctx, hipMemsetAsync(b.flow2, 0, sizeof(float) * 2 * P, st));  // flow.cpp:31 (uninitialised there), A-11
             if ((r = variational_device(ctx, b.f0, b.f1, b.flow2, b.arena))) return r;
         }
         if ((r = remap_device(ctx, b.flow2, 2, b.n8, b.r8))) return r;  // flow.cpp:34
@@ -1239,6 +1251,28 @@ static int flow_run(mvs_ctx *ctx, const FlowBufs &b, int use_farneback)
     // results afterwards -- silently, deterministically within the process, differently from process to process --
     // and that on this ROCm the eager launches are no slower (mvs_process_frame 1.69 ms against 1.95 with the graphs).
     ProfileScope ps(ctx, MVS_K_FLOW);
+    if (ctx->hooks.flow_graph) {  // test hook: the graph replay of rounds 2-3, kept for the reproducer of what round 4 found (tools/graph_repro.py)
+        const int gi = use_farneback ? 1 : 0;
+        if (ctx->flow_graph[gi] && ctx->flow_graph_arena[gi] != ctx->flow_arena.ptr) {
+            (void)hipGraphExecDestroy(ctx->flow_graph[gi]);
+            ctx->flow_graph[gi] = nullptr;
+        }
+        if (!ctx->flow_graph[gi]) {
+            hipGraph_t graph = nullptr;
+            MVS_HIP(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int r = enqueue();
+            const hipError_t e = hipStreamEndCapture(st, &graph);
+            if (r != MVS_OK || e != hipSuccess || !graph || hipGraphInstantiate(&ctx->flow_graph[gi], graph, nullptr, nullptr, 0) != hipSuccess) {
+                ctx->flow_graph[gi] = nullptr;
+                if (graph) (void)hipGraphDestroy(graph);
+                return fail(ctx, MVS_EHIP, "MVS_FLOW_GRAPH: capture / instantiation failed");
+            }
+            (void)hipGraphDestroy(graph);
+            ctx->flow_graph_arena[gi] = ctx->flow_arena.ptr;
+        }
+        MVS_HIP(ctx, hipGraphLaunch(ctx->flow_graph[gi], st));
+        return MVS_OK;
+    }
     return enqueue();
 }
 
@@ -1400,6 +1434,17 @@ int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, 
 using namespace mvs;
 
 extern "C" {
+
+// test hook (not in mvs.h; tools/graph_repro.py): the first `count` floats of calculateFlow's work arena, as the last mvs_flow left them
+int mvs_test_flow_arena(mvs_ctx *ctx, float *out, size_t count)
+{
+    if (!ctx || !out) return MVS_EINVAL;
+    if (!ctx->flow_arena.ptr || count * sizeof(float) > ctx->flow_arena.bytes) return fail(ctx, MVS_ESTATE, "mvs_test_flow_arena: the arena holds %zu bytes", ctx->flow_arena.bytes);
+    MVS_HIP(ctx, hipSetDevice(ctx->device));
+    MVS_HIP(ctx, hipMemcpyAsync(out, ctx->flow_arena.ptr, count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
 
 int mvs_flow(mvs_ctx *ctx, const uint8_t *prev_hw, const uint8_t *next_hw, int use_farneback, float *out_hw4)
 {

@@ -53,6 +53,8 @@ Hooks read_hooks()
     h.fb_unfused = present("MVS_FB_UNFUSED");
     h.var_unfused = present("MVS_VAR_UNFUSED");
     h.fb_direct_box = present("MVS_FB_DIRECT_BOX");
+    h.flow_graph = present("MVS_FLOW_GRAPH");
+    h.flow_graph_kernel_memset = number("MVS_FLOW_GRAPH", 0) == 2;
     h.fb_variant = number("MVS_FB_VARIANT", 0);
     h.raster_bins = number("MVS_RASTER_BINS", -1);
     h.poison_alloc = present("MVS_POISON_ALLOC");

@@ -34,6 +34,9 @@ struct Hooks {
     bool fb_unfused = false;           // MVS_FB_UNFUSED=1: Farneback iteration as three kernels
     bool var_unfused = false;          // MVS_VAR_UNFUSED=1: variational fixed-point iteration as separate kernels
     bool fb_direct_box = false;        // MVS_FB_DIRECT_BOX=1: the fused Farneback iteration sums its window term by term (round 2-4's kernel)
+    bool flow_graph = false;           // MVS_FLOW_GRAPH=1: mvs_flow replays its kernel sequence as a hipGraph, as rounds 2-3 did (tools/graph_repro.py: the
+                                       // replay-after-first-Poisson-call corruption of round 4; never set otherwise)
+    bool flow_graph_kernel_memset = false;  // MVS_FLOW_GRAPH=2: the same, with the sequence's hipMemsetAsync calls replaced by a zero-fill kernel (the A/B of the finding)
     int fb_variant = 0;                // MVS_FB_VARIANT=2: the tall Farneback tiles with 512 threads x 4 rows instead of 256 x 8 (timing A/B: slower)
     int raster_bins = -1;              // MVS_RASTER_BINS=0|1: never / always bin the faces per tile
     bool poison_alloc = false;         // MVS_POISON_ALLOC=1: fresh device allocations are filled with 0xFF bytes

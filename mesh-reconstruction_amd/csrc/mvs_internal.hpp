@@ -104,6 +104,8 @@ struct mvs_ctx {
     int texture_filter = MVS_FILTER_MIPMAP;  // Render::projected's frame texture: mip chain + trilinear (the reference's request) or level 0 only
     mvs::DevBuf cubic_tab;           // Q15 bicubic weights for remap (32*32*16 shorts)
     mvs::DevBuf flow_arena;          // optical-flow pyramids and work buffers
+    hipGraphExec_t flow_graph[2] = {nullptr, nullptr};  // test hook MVS_FLOW_GRAPH only (tools/graph_repro.py): calculateFlow per algorithm as a replayed graph
+    void *flow_graph_arena[2] = {nullptr, nullptr};
     mvs::DevBuf flow_batch_arena;    // the same for the batched Farneback of mvs_process_frame (all side views of a main frame per launch)
     mvs::DevBuf frame_buf;           // mvs_process_frame: frames, depth, warped image, flows of one main frame
     mvs::DevBuf best_parts;          // plane-split sweeps: partial (best cell, best index) per split and pixel

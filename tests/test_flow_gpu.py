@@ -71,3 +71,23 @@ def test_flow_of_mixed_background_stage(oracle):
         out = ctx.flow(a, mixed, False)
     np.testing.assert_array_equal(out, oracle.calculate_flow(a, mixed, False))
     assert np.abs(out[:30, :40, :2]).max() < 0.05
+
+
+def test_graph_replay_after_the_first_poisson_call_is_right_without_memset_nodes():
+    """tools/graph_repro.py, the reproducer of round 4's hipGraph finding: a captured calculateFlow sequence replayed after the process's
+    first hipFFT / Poisson call.  Round 5 found the culprit -- the captured hipMemsetAsync NODE (the flow's zero initialisation) stops
+    doing its job in such replays; none of this library's kernels, none of which uses scratch.  With a zero-fill kernel in its place
+    (test hook MVS_FLOW_GRAPH=2) the replay is bit-identical to the eager launches, which is what this asserts; the library launches
+    eagerly either way."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for alg in ("farneback", "variational"):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_repro.py"), alg, "--kernel-memset"], capture_output=True, text=True, timeout=600)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+        r = json.loads(lines[0])
+        assert r["replay_before_poisson_equal"] and r["replay_after_poisson_equal"] and r["eager_after_poisson_equal"], r
+        assert r["first_buffer_that_differs"] is None
