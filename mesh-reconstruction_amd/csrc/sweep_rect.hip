@@ -551,8 +551,8 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     "s_bitcmp0_b32 %[ym], %[yb" #j "]\n\ts_cselect_b64 exec, vcc, 0\n\tv_add_u32 %[a" #j "], 0x1000000, %[a" #j "]\n\t" \
     "v_sad_u16 %[a" #j "], %[q" #j "], %[i" #j "], %[a" #j "]\n\t"
 #pragma unroll
-            for (int kk = 0; kk < (RX_DBG(a, 512) ? 2 * RX_KW : RX_KW); kk++) {
-                const int k = kk % RX_KW;
+            for (int k = 0; k < RX_KW; k++) {   // (experiment 512 -- every plane sampled twice: the work of 8 planes per wavefront, DESIGN A.5b -- has served and is gone: its
+                                                 // run-time trip count no longer compiles with the immediates below)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
                 asm volatile("s_add_u32 m0, %[slot], %[fld]\n\t"
