@@ -359,6 +359,11 @@ int mvs_profile_read(mvs_ctx *ctx, float ms_sum[MVS_K_COUNT], int launches[MVS_K
  *              mvs_poisson_surface uses MVS_POISSON_SUPPORT_DEFAULT. */
 #define MVS_POISSON_SUPPORT_DEFAULT 8.0f
 typedef struct mvs_surface mvs_surface;
+/* The first hipFFT plan of a grid size in a process costs about 2 s (rocFFT compiles its kernels for the size at run time); every
+ * later call of that size finds the plans cached.  mvs_poisson_warmup(grid_log2) pays that cost when the caller chooses -- at start-up,
+ * beside mvs_create -- instead of inside the first poissonSurface of a reconstruction: it builds and keeps the two plans of a
+ * 2^grid_log2 grid (5..9) on the calling thread's current device.  Optional; returns 0, or a negative MVS_E* code. */
+int mvs_poisson_warmup(int grid_log2);
 int mvs_poisson_surface(const float *points, const float *normals, int n, int grid_log2, float smooth_cells, int keep_fields, mvs_surface **out);
 int mvs_poisson_surface_ex(const float *points, const float *normals, int n, int grid_log2, float smooth_cells, float support_spacings, int keep_fields,
                            mvs_surface **out);

@@ -450,7 +450,55 @@ struct PlanCache {
 };
 PlanCache g_plans;
 
+// the two plans of a G^3 grid on the current device into the cache (the caller holds g_plans.m); false: hipFFT refused
+bool ensure_plans(int G, const char **why)
+{
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) {
+        *why = "hipGetDevice failed";
+        return false;
+    }
+    if (g_plans.G == G && g_plans.device == device) return true;
+    if (g_plans.G) {
+        (void)hipfftDestroy(g_plans.fwd);
+        (void)hipfftDestroy(g_plans.inv);
+        g_plans.G = 0;
+    }
+    hipfftHandle fwd = 0, inv = 0;
+    if (hipfftPlan3d(&fwd, G, G, G, HIPFFT_R2C) != HIPFFT_SUCCESS) {
+        *why = "hipfftPlan3d (R2C) failed";
+        return false;
+    }
+    if (hipfftPlan3d(&inv, G, G, G, HIPFFT_C2R) != HIPFFT_SUCCESS) {
+        (void)hipfftDestroy(fwd);
+        *why = "hipfftPlan3d (C2R) failed";
+        return false;
+    }
+    g_plans.fwd = fwd, g_plans.inv = inv, g_plans.G = G, g_plans.device = device;
+    return true;
+}
+
 }  // namespace
+
+extern "C" int mvs_poisson_warmup(int grid_log2)
+{
+    if (grid_log2 < 5 || grid_log2 > 9) {
+        g_poisson_error = "mvs_poisson_warmup: grid_log2 out of range 5..9";
+        return MVS_EINVAL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_poisson_error = "mvs_poisson_warmup: no HIP device available";
+        return MVS_EHIP;
+    }
+    std::lock_guard<std::mutex> lock(g_plans.m);
+    const char *why = "";
+    if (!ensure_plans(1 << grid_log2, &why)) {
+        g_poisson_error = std::string("mvs_poisson_warmup: ") + why;
+        return MVS_EHIP;
+    }
+    return MVS_OK;
+}
 
 extern "C" const char *mvs_surface_last_error(void) { return g_poisson_error.c_str(); }
 
@@ -618,22 +666,8 @@ extern "C" int mvs_poisson_surface_ex(const float *points, const float *normals,
         float *chi = d_real.as<float>();  // (the transform may overwrite its input: spec[0] is not used again)
         {
             std::lock_guard<std::mutex> lock(g_plans.m);  // the plans of the last grid size are kept for the process (see PlanCache)
-            int device = 0;
-            PS_TRY(hipGetDevice(&device) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: hipGetDevice failed");
-            if (g_plans.G != g.G || g_plans.device != device) {
-                if (g_plans.G) {
-                    (void)hipfftDestroy(g_plans.fwd);
-                    (void)hipfftDestroy(g_plans.inv);
-                    g_plans.G = 0;
-                }
-                hipfftHandle fwd = 0, inv = 0;
-                PS_TRY(hipfftPlan3d(&fwd, g.G, g.G, g.G, HIPFFT_R2C) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: hipfftPlan3d (R2C) failed");
-                if (hipfftPlan3d(&inv, g.G, g.G, g.G, HIPFFT_C2R) != HIPFFT_SUCCESS) {
-                    (void)hipfftDestroy(fwd);
-                    PS_TRY(false, MVS_EHIP, "mvs_poisson_surface: hipfftPlan3d (C2R) failed");
-                }
-                g_plans.fwd = fwd, g_plans.inv = inv, g_plans.G = g.G, g_plans.device = device;
-            }
+            const char *why = "";
+            if (!ensure_plans(g.G, &why)) PS_TRY(false, MVS_EHIP, why);
             PS_TRY(hipfftSetStream(g_plans.fwd, st) == HIPFFT_SUCCESS && hipfftSetStream(g_plans.inv, st) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: hipfftSetStream failed");
             for (int c = 0; c < 3; c++)
                 PS_TRY(hipfftExecR2C(g_plans.fwd, d_real.as<float>() + c * N3, spec + c * S3) == HIPFFT_SUCCESS, MVS_EHIP, "mvs_poisson_surface: forward FFT failed");

@@ -108,6 +108,7 @@ ABI = [
     ("mvs_profile_enable", _i, [_vp, _i]),
     ("mvs_profile_read", _i, [_vp, _fp, C.POINTER(_i), _i]),
     ("mvs_device_info", C.c_char_p, [_vp]),
+    ("mvs_poisson_warmup", _i, [_i]),
     ("mvs_poisson_surface", _i, [_vp, _vp, _i, _i, _f, _i, _vp]),
     ("mvs_poisson_surface_ex", _i, [_vp, _vp, _i, _i, _f, _f, _i, _vp]),
     ("mvs_surface_support", _i, [_vp, _vp]),
@@ -593,12 +594,21 @@ class Context:
         mc = _f32(np.asarray(main_cams, dtype=np.float32).reshape(M, 4, 4))
         sc = _f32(np.asarray(side_cams, dtype=np.float32).reshape(M, S, 4, 4))
         assert out.dtype == np.float32 and out.flags.c_contiguous and out.size >= M * self.H * self.W
+        assert cost_out is None or (cost_out.dtype == np.float32 and cost_out.flags.c_contiguous and cost_out.size >= M * self.H * self.W)
+        # the copy stream writes into these arrays after this call has returned: they stay referenced until the wait (a caller that
+        # drops its page-locked array -- mvs_host_free through the finalizer -- would hand the DMA freed memory: ADVICE r04)
+        if not hasattr(self, "_batch_keep"):
+            self._batch_keep = []
+        self._batch_keep.append((out, cost_out))
         self._check(self.lib.mvs_sweep_batch_async(self.h, M, ms.ctypes.data_as(C.c_void_p), mc.ctypes.data_as(C.c_void_p), S, ss.ctypes.data_as(C.c_void_p),
                                                    sc.ctypes.data_as(C.c_void_p), int(nplanes), float(z_lo), float(z_hi), out.ctypes.data_as(C.c_void_p),
                                                    cost_out.ctypes.data_as(C.c_void_p) if cost_out is not None else None))
 
     def sweep_batch_wait(self):
-        self._check(self.lib.mvs_sweep_batch_wait(self.h))
+        try:
+            self._check(self.lib.mvs_sweep_batch_wait(self.h))
+        finally:
+            self._batch_keep = []
 
     def sweep_batch(self, main_slots, main_cams, side_slots, side_cams, nplanes, z_lo=-1.0, z_hi=1.0, want_cost=False, out=None):
         """mvs_sweep_batch: main_slots [M], main_cams [M,4,4], side_slots [M,S], side_cams [M,S,4,4] -> depth [M,H,W] (, cost [M,H,W])"""

@@ -144,3 +144,12 @@ def test_no_getenv_outside_the_hooks_module():
             if "getenv" in code:
                 offenders.append("%s:%d" % (os.path.basename(path), i))
     assert not offenders, offenders
+
+
+def test_poisson_warmup_without_a_gpu_is_an_error_code():
+    lib = mvs_amd.load_library()
+    assert lib.mvs_poisson_warmup(3) == -1            # MVS_EINVAL: out of range, checked before any device is looked for
+    rc = lib.mvs_poisson_warmup(6)
+    assert rc in (0, -2)                              # MVS_OK on a GPU box, MVS_EHIP here
+    if rc:
+        assert b"HIP device" in lib.mvs_surface_last_error() or b"hip" in lib.mvs_surface_last_error().lower()

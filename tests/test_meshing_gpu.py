@@ -343,3 +343,23 @@ def test_golden_vectors(hip):
     # the level set of a field that differs in its last bits: the same surface up to the cells those bits decide
     assert abs(len(r["vertices"]) - len(g["poisson_vertices"])) <= 0.01 * len(g["poisson_vertices"]) + 2
     assert abs(mc.signed_volume(r["vertices"], r["faces"]) - mc.signed_volume(g["poisson_vertices"], g["poisson_faces"])) <= 1e-3 * abs(mc.signed_volume(g["poisson_vertices"], g["poisson_faces"]))
+
+
+def test_poisson_warmup_builds_the_plans_a_later_call_finds():
+    """mvs_poisson_warmup(grid_log2): the ~2 s of rocFFT's run-time kernel compilation for a grid size paid when the caller chooses;
+    argument errors are error codes"""
+    import time
+    import mvs_amd
+    lib = mvs_amd.load_library()
+    assert lib.mvs_poisson_warmup(4) == mvs_amd.MVS_EINVAL if hasattr(mvs_amd, "MVS_EINVAL") else lib.mvs_poisson_warmup(4) == -1
+    assert lib.mvs_poisson_warmup(10) == -1
+    assert lib.mvs_poisson_warmup(6) == 0          # 64^3
+    t0 = time.perf_counter()
+    assert lib.mvs_poisson_warmup(6) == 0          # cached: nothing to build
+    assert time.perf_counter() - t0 < 0.05
+    rng = np.random.default_rng(5)
+    d = rng.normal(size=(3000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = np.concatenate([d, np.ones((len(d), 1))], 1).astype(np.float32)
+    v, f = mvs_amd.poisson_surface(pts, d.astype(np.float32), grid_log2=6)
+    assert len(v) > 100 and len(f) > 100
