@@ -81,6 +81,43 @@ __global__ __launch_bounds__(256) void gauss_kernel(const float *__restrict__ sr
     dst[(size_t)y * w + x] = acc;
 }
 
+// Both passes of the separable filter in ONE launch (round 5): a workgroup stages its 64 x 16 output tile's (64 + 2c) x (16 + 2c) input
+// neighbourhood in LDS (reflected coordinates resolved while staging), runs the row filter over the 16 + 2c rows into a second LDS array and
+// the column filter from there -- the expressions of gauss_kernel<false> and <true> on the same values in the same order (bit-identical),
+// without the intermediate image's round trip through HBM: cv::GaussianBlur of BOTH full-resolution frames is paid once per pyramid
+// level (fastPyramids false), 22 passes over 16.6 MB per 1080p flow.
+__global__ __launch_bounds__(256) void gauss_fused_kernel(const float *__restrict__ src, int w, int h, Taps t, int ksize, float *__restrict__ dst,
+                                                          ptrdiff_t src_z, ptrdiff_t dst_z)
+{
+    extern __shared__ float g_lds[];
+    src += (ptrdiff_t)blockIdx.z * src_z;
+    dst += (ptrdiff_t)blockIdx.z * dst_z;
+    const int c = ksize / 2, X0 = blockIdx.x * 64, Y0 = blockIdx.y * 16;
+    const int IW = 64 + 2 * c, IH = 16 + 2 * c;
+    float *in = g_lds, *tmp = g_lds + IW * IH;
+    for (int i = threadIdx.x; i < IW * IH; i += 256) {
+        const int r = i / IW, q = i - r * IW;
+        in[i] = src[(size_t)refl101(Y0 - c + r, h) * w + refl101(X0 - c + q, w)];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * IH; i += 256) {  // rows: gauss_kernel<false> at (refl(Y0 - c + r), X0 + x)
+        const int r = i >> 6, x = i & 63;
+        const float *p = in + r * IW + x + c;
+        float acc = t.k[c] * p[0];
+        for (int j = 1; j <= c; j++) acc += t.k[c + j] * (p[j] + p[-j]);
+        tmp[i] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {  // columns: gauss_kernel<true> at (Y0 + r, X0 + x)
+        const int r = i >> 6, x = i & 63, gy = Y0 + r, gx = X0 + x;
+        if (gx >= w || gy >= h) continue;
+        const float *p = tmp + (r + c) * 64 + x;
+        float acc = t.k[c] * p[0];
+        for (int j = 1; j <= c; j++) acc += t.k[c + j] * (p[64 * j] + p[-64 * j]);
+        dst[(size_t)gy * w + gx] = acc;
+    }
+}
+
 __device__ __forceinline__ void linear_coeff(int d, int dsize, int ssize, int &ofs, float &a0, float &a1)
 {
     const double scale = 1. / ((double)dsize / ssize);
@@ -1112,8 +1149,13 @@ static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, floa
             const ptrdiff_t sP = (ptrdiff_t)P;
             dim3 gF = g2(W, H), gL = g2(w, h);
             gF.z = gL.z = 2;
-            gauss_kernel<false><<<gF, 256, 0, st>>>(f0, W, H, taps, smooth_sz, tmp, f1 - f0, sP);
-            gauss_kernel<true><<<gF, 256, 0, st>>>(tmp, W, H, taps, smooth_sz, blur, sP, sP);
+            if (ctx->hooks.fb_unfused) {
+                gauss_kernel<false><<<gF, 256, 0, st>>>(f0, W, H, taps, smooth_sz, tmp, f1 - f0, sP);
+                gauss_kernel<true><<<gF, 256, 0, st>>>(tmp, W, H, taps, smooth_sz, blur, sP, sP);
+            } else {
+                const int c = smooth_sz / 2;
+                gauss_fused_kernel<<<dim3(div_up(W, 64), div_up(H, 16), 2), 256, sizeof(float) * (size_t)(16 + 2 * c) * (128 + 2 * c), st>>>(f0, W, H, taps, smooth_sz, blur, f1 - f0, sP);
+            }
             resize_linear_kernel<1><<<gL, 256, 0, st>>>(blur, W, H, I, w, h, 1.f, 0, sP, sP);
             polyexp_vert<<<gL, 256, 0, st>>>(I, w, h, pt, row3, sP, 3 * sP);
             polyexp_horiz<<<gL, 256, 0, st>>>(row3, w, h, pt, R0, 3 * sP, R1 - R0);
@@ -1369,8 +1411,13 @@ static int farneback_batch_enqueue(mvs_ctx *ctx, const uint8_t *prev8, const uin
         }
         Taps taps;
         gaussian_taps(smooth_sz, sigma, taps.k);
-        gauss_kernel<false><<<gF, 256, 0, st>>>(b.F, W, H, taps, smooth_sz, b.tmp, sP, sP);
-        gauss_kernel<true><<<gF, 256, 0, st>>>(b.tmp, W, H, taps, smooth_sz, b.blur, sP, sP);
+        if (ctx->hooks.fb_unfused) {
+            gauss_kernel<false><<<gF, 256, 0, st>>>(b.F, W, H, taps, smooth_sz, b.tmp, sP, sP);
+            gauss_kernel<true><<<gF, 256, 0, st>>>(b.tmp, W, H, taps, smooth_sz, b.blur, sP, sP);
+        } else {
+            const int c = smooth_sz / 2;
+            gauss_fused_kernel<<<dim3(div_up(W, 64), div_up(H, 16), (unsigned)(B + 1)), 256, sizeof(float) * (size_t)(16 + 2 * c) * (128 + 2 * c), st>>>(b.F, W, H, taps, smooth_sz, b.blur, sP, sP);
+        }
         resize_linear_kernel<1><<<gL, 256, 0, st>>>(b.blur, W, H, b.I, w, h, 1.f, 0, sP, sP);
         polyexp_vert<<<gL, 256, 0, st>>>(b.I, w, h, pt, b.row3, sP, 3 * sP);
         polyexp_horiz<<<gL, 256, 0, st>>>(b.row3, w, h, pt, b.R, 3 * sP, 5 * sP);
