@@ -220,6 +220,66 @@ __global__ __launch_bounds__(256) void polyexp_horiz(const float *__restrict__ r
     d[4] = (float)(b6 * t.ig55);
 }
 
+// polyexp_vert + polyexp_horiz in one launch (round 5): the tile's (16 + 2n) x (64 + 2n) neighbourhood staged in LDS with the replicate
+// border resolved while staging, the vertical sums of its 16 rows x (64 + 2n) columns into a second LDS array, the horizontal pass from
+// there -- the same expressions on the same values (bit-identical), no round trip of the 12-byte-per-pixel intermediate through HBM.
+__global__ __launch_bounds__(256) void polyexp_fused_kernel(const float *__restrict__ src, int w, int h, PolyTaps t, float *__restrict__ dst5,
+                                                            ptrdiff_t src_z, ptrdiff_t dst_z)
+{
+    extern __shared__ float p_lds[];
+    src += (ptrdiff_t)blockIdx.z * src_z;
+    dst5 += (ptrdiff_t)blockIdx.z * dst_z;
+    const int n = t.n, X0 = blockIdx.x * 64, Y0 = blockIdx.y * 16;
+    const int IW = 64 + 2 * n, IH = 16 + 2 * n;
+    float *in = p_lds, *row3 = p_lds + IW * IH;  // row3: [16][IW][3]
+    for (int i = threadIdx.x; i < IW * IH; i += 256) {
+        const int r = i / IW, q = i - r * IW;
+        in[i] = src[(size_t)clampi(Y0 - n + r, 0, h - 1) * w + clampi(X0 - n + q, 0, w - 1)];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * IW; i += 256) {  // polyexp_vert at (Y0 + r, clamp(X0 - n + q)): rows y -+ k are tile rows r + n -+ k
+        const int r = i / IW, q = i - r * IW;
+        const float *c = in + (r + n) * IW + q;
+        float t0 = c[0] * t.g[0], t1 = 0.f, t2 = 0.f;
+        for (int k = 1; k <= n; k++) {
+            const float a = c[-k * IW], b = c[k * IW];
+            const float p = a + b;
+            t0 = t0 + t.g[k] * p;
+            t1 = t1 + t.xg[k] * (b - a);
+            t2 = t2 + t.xxg[k] * p;
+        }
+        float *o = row3 + (size_t)i * 3;
+        o[0] = t0;
+        o[1] = t1;
+        o[2] = t2;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {  // polyexp_horiz at (Y0 + r, X0 + x): columns x +- k are tile columns x + n +- k
+        const int r = i >> 6, x = i & 63, gy = Y0 + r, gx = X0 + x;
+        if (gx >= w || gy >= h) continue;
+        const float *c = row3 + ((size_t)r * IW + x + n) * 3;
+        float g0 = t.g[0];
+        double b1 = c[0] * g0, b2 = 0, b3 = c[1] * g0, b4 = 0, b5 = c[2] * g0, b6 = 0;
+        for (int k = 1; k <= n; k++) {
+            const float *p = c + 3 * k, *m = c - 3 * k;
+            const double tg = p[0] + m[0];
+            g0 = t.g[k];
+            b1 += tg * g0;
+            b4 += tg * t.xxg[k];
+            b2 += (p[0] - m[0]) * t.xg[k];
+            b3 += (p[1] + m[1]) * g0;
+            b6 += (p[1] - m[1]) * t.xg[k];
+            b5 += (p[2] + m[2]) * g0;
+        }
+        float *d = dst5 + ((size_t)gy * w + gx) * 5;
+        d[1] = (float)(b2 * t.ig11);
+        d[0] = (float)(b3 * t.ig11);
+        d[3] = (float)(b1 * t.ig03 + b4 * t.ig33);
+        d[2] = (float)(b1 * t.ig03 + b5 * t.ig33);
+        d[4] = (float)(b6 * t.ig55);
+    }
+}
+
 // FarnebackUpdateMatrices at one pixel: the five products of the displaced polynomial coefficients, from the pixel's own flow
 __device__ __forceinline__ void update_matrix_at(const float *__restrict__ R0, const float *__restrict__ R1, float dx, float dy,
                                                  int x, int y, int w, int h, float *__restrict__ m)
@@ -1157,8 +1217,12 @@ static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, floa
                 gauss_fused_kernel<<<dim3(div_up(W, 64), div_up(H, 16), 2), 256, sizeof(float) * (size_t)(16 + 2 * c) * (128 + 2 * c), st>>>(f0, W, H, taps, smooth_sz, blur, f1 - f0, sP);
             }
             resize_linear_kernel<1><<<gL, 256, 0, st>>>(blur, W, H, I, w, h, 1.f, 0, sP, sP);
-            polyexp_vert<<<gL, 256, 0, st>>>(I, w, h, pt, row3, sP, 3 * sP);
-            polyexp_horiz<<<gL, 256, 0, st>>>(row3, w, h, pt, R0, 3 * sP, R1 - R0);
+            if (ctx->hooks.fb_unfused) {
+                polyexp_vert<<<gL, 256, 0, st>>>(I, w, h, pt, row3, sP, 3 * sP);
+                polyexp_horiz<<<gL, 256, 0, st>>>(row3, w, h, pt, R0, 3 * sP, R1 - R0);
+            } else {
+                polyexp_fused_kernel<<<dim3(div_up(w, 64), div_up(h, 16), 2), 256, sizeof(float) * ((size_t)(16 + 2 * pt.n) * (64 + 2 * pt.n) + 3 * 16 * (size_t)(64 + 2 * pt.n)), st>>>(I, w, h, pt, R0, sP, R1 - R0);
+            }
         }
         update_matrices_kernel<<<g2(w, h), 256, 0, st>>>(R0, R1, flow, w, h, M);
         const int m = winsize / 2;
@@ -1419,8 +1483,12 @@ static int farneback_batch_enqueue(mvs_ctx *ctx, const uint8_t *prev8, const uin
             gauss_fused_kernel<<<dim3(div_up(W, 64), div_up(H, 16), (unsigned)(B + 1)), 256, sizeof(float) * (size_t)(16 + 2 * c) * (128 + 2 * c), st>>>(b.F, W, H, taps, smooth_sz, b.blur, sP, sP);
         }
         resize_linear_kernel<1><<<gL, 256, 0, st>>>(b.blur, W, H, b.I, w, h, 1.f, 0, sP, sP);
-        polyexp_vert<<<gL, 256, 0, st>>>(b.I, w, h, pt, b.row3, sP, 3 * sP);
-        polyexp_horiz<<<gL, 256, 0, st>>>(b.row3, w, h, pt, b.R, 3 * sP, 5 * sP);
+        if (ctx->hooks.fb_unfused) {
+            polyexp_vert<<<gL, 256, 0, st>>>(b.I, w, h, pt, b.row3, sP, 3 * sP);
+            polyexp_horiz<<<gL, 256, 0, st>>>(b.row3, w, h, pt, b.R, 3 * sP, 5 * sP);
+        } else {
+            polyexp_fused_kernel<<<dim3(div_up(w, 64), div_up(h, 16), (unsigned)(B + 1)), 256, sizeof(float) * ((size_t)(16 + 2 * pt.n) * (64 + 2 * pt.n) + 3 * 16 * (size_t)(64 + 2 * pt.n)), st>>>(b.I, w, h, pt, b.R, sP, 5 * sP);
+        }
         const float *R0 = b.R, *R1 = b.R + 5 * P;
         update_matrices_kernel<<<gB, 256, 0, st>>>(R0, R1, flow, w, h, b.M, 5 * sP, 2 * sP, 5 * sP);
         const double bscale = 1. / ((double)winsize * winsize);
