@@ -188,7 +188,9 @@ __device__ __forceinline__ void lds_read_record(uint32_t addr, u32x4 &x0, u32x4 
                  : "v"(addr));
 }
 
-template <bool WRITE_VOLUME, bool FUSED>
+// RS: the LDS row stride in quads as a compile-time constant (the planner rounds the widest box up to one of a few values), so that the 8
+// row reads of a plane take immediate offsets instead of one v_add_u32 each; 0: run-time stride (boxes wider than the largest constant)
+template <bool WRITE_VOLUME, bool FUSED, int RS>
 __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -343,10 +345,15 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
                 float fyv[8];
                 uint32_t ad = addrx + (uint32_t)(iy0 - y0) * rs8;
                 asm volatile("ds_write_b32 %0, %1" ::"v"(fy_lane_addr), "v"(fyl) : "memory");
+                if (RS > 0) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    asm volatile("ds_read_b64 %0, %1" : "=v"(h[j]) : "v"(ad));
-                    ad += rs8;
+                    for (int j = 0; j < 8; j++) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(h[j]) : "v"(ad), "n"(j * (RS > 0 ? RS : 1) * 8));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        asm volatile("ds_read_b64 %0, %1" : "=v"(h[j]) : "v"(ad));
+                        ad += rs8;
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fyv[j]) : "v"(fy_wave_addr), "n"(4 * j));
@@ -563,7 +570,12 @@ int sweep_xrect_plan(mvs_ctx *ctx)
         }
     }
     if (max_rw <= 0 || max_rh <= 0) return MVS_OK;  // nothing in frame anywhere: the general kernel writes the empty cells
-    const int rs = (max_rw + 1) & ~1;
+    int rs = (max_rw + 1) & ~1;
+    for (int fixed : {72, 84, 96, 112, 128})  // the strides sweep_exact_rect is instantiated for (immediate row offsets); wider boxes: run-time stride
+        if (rs <= fixed) {
+            rs = fixed;
+            break;
+        }
     const int units = rs / 2;
     const int instrs = div_up(max_rh * units, 64);  // 1 KiB copy instructions per region
     if (instrs > 4 * XR_MAX_NI) return MVS_OK;      // wide baselines / few planes: boxes too large for the slots
@@ -601,12 +613,20 @@ int sweep_xrect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsig
         MVS_HIP(ctx, hipGetLastError());
         return MVS_OK;
     };
-    if (vol && fused)
-        rc = go(sweep_exact_rect<true, true>);
-    else if (vol)
-        rc = go(sweep_exact_rect<true, false>);
-    else
-        rc = go(sweep_exact_rect<false, true>);
+    auto pick = [&](auto rs_tag) -> int {
+        constexpr int RS = decltype(rs_tag)::value;
+        if (vol && fused) return go(sweep_exact_rect<true, true, RS>);
+        if (vol) return go(sweep_exact_rect<true, false, RS>);
+        return go(sweep_exact_rect<false, true, RS>);
+    };
+    switch (a.rs) {
+    case 72: rc = pick(std::integral_constant<int, 72>{}); break;
+    case 84: rc = pick(std::integral_constant<int, 84>{}); break;
+    case 96: rc = pick(std::integral_constant<int, 96>{}); break;
+    case 112: rc = pick(std::integral_constant<int, 112>{}); break;
+    case 128: rc = pick(std::integral_constant<int, 128>{}); break;
+    default: rc = pick(std::integral_constant<int, 0>{}); break;
+    }
     if (rc) return rc;
     return nsplit;
 }
