@@ -394,6 +394,19 @@ typedef struct mvs_criteria_report {
     float max_circumradius;        /* largest facet circumradius of the result */
 } mvs_criteria_report;
 int mvs_surface_enforce_criteria(mvs_surface *s, float min_angle_deg /* [0, 60) */, float max_radius, float max_distance, mvs_criteria_report *report);
+/* The other half of what those criteria mean: they bound a facet's angles from below and its distance from the surface from above -- NOT
+ * its size (sm_radius = 300 spacings) -- so the reference's mesher returns as few facets as the curvature allows, where the grid mesher
+ * returns the grid's density.  mvs_surface_simplify removes the vertices the criteria do not need: edge collapses u -> v, shortest edge
+ * first, under the guards of mvs_surface_enforce_criteria (link condition, no facet turning over) with every rewritten facet keeping
+ * min_angle_deg and every vertex keeping an ACCUMULATED displacement of at most max_distance (a vertex inherits what was merged into it);
+ * no vertex moves, none is added, vertices on a border or on a non-manifold edge stay.  Apply after mvs_surface_enforce_criteria.
+ * poissonSurface (host/poisson.cpp) and mvs_amd.poisson_surface run it with sm_angle and sm_distance. */
+typedef struct mvs_simplify_report {
+    int collapses;
+    int vertices_before, vertices_after, facets_before, facets_after;
+    float max_accumulated_distance;
+} mvs_simplify_report;
+int mvs_surface_simplify(mvs_surface *s, float min_angle_deg /* [0, 60) */, float max_distance, mvs_simplify_report *report);
 /* a surface object over a caller's triangle mesh (vertices V x 4 with w = 1, faces F x 3), e.g. to apply the criteria to it; needs no GPU */
 int mvs_surface_from_mesh(const float *vertices, int vertex_count, const int32_t *faces, int face_count, float average_spacing, mvs_surface **out);
 void mvs_surface_free(mvs_surface *s);

@@ -58,6 +58,7 @@ struct Work {
     std::vector<long long> stamp;  // (two stamps per collapse candidate: 64 bits, so that no mesh size can wrap them)
     long long stamp_now = 0;
     double q_bound = 0.0, guard = 0.0;
+    double last_nearest = 0.0;  // of the last try_collapse that returned a result: distance of the vanishing vertex from the nearest new facet's plane
     int collapses = 0, flips = 0;
 
     // undo log of the rescue round (below): every facet and incidence list is saved before it changes; rolled back newest first
@@ -181,6 +182,7 @@ struct Work {
         }
         if (!any || nearest > guard) return -2.0;
         *before_out = before;
+        last_nearest = nearest;
         return after;
     }
 
@@ -464,6 +466,171 @@ extern "C" int mvs_surface_enforce_criteria(mvs_surface *s, float min_angle_deg,
         }
         r.min_angle_deg = fout.empty() ? 180.0f : (float)(std::acos(std::min(1.0, std::max(-1.0, -min_q))) * 180.0 / 3.14159265358979323846);
         r.max_circumradius = (float)std::sqrt(max_r2);
+        s->vertices.swap(vout);
+        s->faces.swap(fout);
+    } catch (...) {
+        return MVS_ENOMEM;
+    }
+    if (report) *report = r;
+    return MVS_OK;
+}
+
+// ---- simplification (round 5) ------------------------------------------------------------------------------------------------------
+// cgal_poisson.cpp:95-97's criteria bound a facet from BELOW only in its angles; its size may reach 300 average spacings as long as it
+// stays within 0.375 spacings of the surface -- CGAL's Delaunay refinement therefore returns a mesh whose density follows the curvature,
+// while surface nets return the grid's (171 k vertices on the pipeline's cloud where a few thousand satisfy the criteria).  This pass
+// removes vertices the criteria do not need, by the collapse of surface_criteria's first half and under its guards: an edge (shortest
+// first; lengths never change, no vertex moves) is collapsed u -> v when the link condition holds, no surviving facet turns by more than
+// ~72 degrees, EVERY facet the collapse rewrites keeps min_angle_deg, and the vertex that disappears stays within what is left of ITS
+// distance budget of the new facets' planes: a vertex carries the largest distance any vertex merged into it was moved (err[v] =
+// max(err[v], err[u] + d)), and err[u] + d <= max_distance.  That bounds where the VERTICES of the old surface end up; what a large facet does
+// between its corners -- the chord cutting across a curved surface -- is bounded by the surface's own normals: every vertex keeps the
+// normal the input mesh had there (area-weighted mean of its facets' normals), and a rewritten facet T with longest edge L whose normal
+// makes at most the angle theta with the kept normals of its three corners may lie (L / 2) tan(theta / 2) inside the surface (the sagitta of
+// the circular arc those normals describe); that, plus the largest err of its corners, must stay within max_distance too.  Vertices on a border or on
+// an edge that does not have exactly two facets are never removed (the sheet's outline and the non-manifold spots stay where they are).  Passes over the (re-collected) edge list until a
+// pass removes less than 1 % of the vertices.  Sequential host code, like the pass above; restated in oracle/meshing_oracle.py.
+extern "C" int mvs_surface_simplify(mvs_surface *s, float min_angle_deg, float max_distance, mvs_simplify_report *report)
+{
+    if (!s || !(min_angle_deg >= 0.0f) || !(min_angle_deg < 60.0f) || !(max_distance >= 0.0f)) return MVS_EINVAL;
+    const int nv = (int)(s->vertices.size() / 4), nf = (int)(s->faces.size() / 3);
+    mvs_simplify_report r;
+    std::memset(&r, 0, sizeof r);
+    r.vertices_before = nv;
+    r.facets_before = nf;
+    try {
+        Work w;
+        w.p.resize((size_t)nv);
+        for (int i = 0; i < nv; i++) w.p[(size_t)i] = {(double)s->vertices[4 * (size_t)i], (double)s->vertices[4 * (size_t)i + 1], (double)s->vertices[4 * (size_t)i + 2]};
+        w.f = s->faces;
+        w.inc.resize((size_t)nv);
+        w.stamp.assign((size_t)nv, 0);
+        for (int i = 0; i < nf; i++) {
+            const int a = w.f[3 * i], b = w.f[3 * i + 1], c = w.f[3 * i + 2];
+            if (a == b || b == c || a == c) {
+                w.f[3 * i] = w.f[3 * i + 1] = w.f[3 * i + 2] = -1;
+                continue;
+            }
+            w.inc[(size_t)a].push_back(i), w.inc[(size_t)b].push_back(i), w.inc[(size_t)c].push_back(i);
+        }
+        w.q_bound = -std::cos((double)min_angle_deg * 3.14159265358979323846 / 180.0);
+        std::vector<double> err((size_t)nv, 0.0);
+        // the input surface's normal at every vertex (unit; zero where it has none): facets in index order, so the sums are reproducible
+        std::vector<V3> vnormal((size_t)nv, V3{0.0, 0.0, 0.0});
+        for (int i = 0; i < nf; i++) {
+            if (w.f[3 * i] < 0) continue;
+            const V3 n = w.normal_of(w.f[3 * i], w.f[3 * i + 1], w.f[3 * i + 2]);
+            for (int k = 0; k < 3; k++) {
+                V3 &a = vnormal[(size_t)w.f[3 * i + k]];
+                a = {a.x + n.x, a.y + n.y, a.z + n.z};
+            }
+        }
+        for (V3 &a : vnormal) {
+            const double l = std::sqrt(dot(a, a));
+            a = l > 0.0 ? V3{a.x / l, a.y / l, a.z / l} : V3{0.0, 0.0, 0.0};
+        }
+        // how far the facets a collapse u -> v rewrites may lie from the input surface: max over them of ((L / 2) tan(theta / 2) + the largest err of
+        // the corners); 1e300: a facet whose normal is more than ~78 degrees off a corner's kept normal
+        auto deviation = [&](int u, int v) {
+            int e[2];
+            w.edge_facets(u, v, e);
+            double worst = 0.0;
+            for (int face : w.inc[(size_t)u]) {
+                if (face == e[0] || face == e[1]) continue;
+                int t[3];
+                for (int k = 0; k < 3; k++) t[k] = w.f[3 * face + k] == u ? v : w.f[3 * face + k];
+                const V3 n = w.normal_of(t[0], t[1], t[2]);
+                const double ln = std::sqrt(dot(n, n));
+                if (!(ln > 0.0)) return 1e300;
+                double c = 1.0, emax = 0.0, l2 = 0.0;
+                for (int k = 0; k < 3; k++) {
+                    c = std::min(c, dot(n, vnormal[(size_t)t[k]]) / ln);
+                    emax = std::max(emax, t[k] == v ? std::max(err[(size_t)v], err[(size_t)u]) : err[(size_t)t[k]]);
+                    const V3 d = sub(w.p[(size_t)t[k]], w.p[(size_t)t[(k + 1) % 3]]);
+                    l2 = std::max(l2, dot(d, d));
+                }
+                if (!(c > 0.2)) return 1e300;
+                worst = std::max(worst, 0.5 * std::sqrt(l2) * std::sqrt(std::max(0.0, 1.0 - c * c)) / (1.0 + c) + emax);  // (L / 2) tan(theta / 2): the sagitta of a circular arc whose end normals are theta off the chord's
+            }
+            return worst;
+        };
+        // vertices that stay: on an edge with one facet (border) or more than two (non-manifold)
+        std::vector<char> locked((size_t)nv, 0);
+        for (int i = 0; i < nf; i++) {
+            if (w.f[3 * i] < 0) continue;
+            for (int k = 0; k < 3; k++) {
+                const int u = w.f[3 * i + k], v = w.f[3 * i + (k + 1) % 3];
+                int e[2];
+                if (w.edge_facets(u, v, e) != 2) locked[(size_t)u] = locked[(size_t)v] = 1;
+            }
+        }
+        struct Edge {
+            double len2;
+            int u, v;
+        };
+        std::vector<Edge> edges;
+        std::vector<int> touched;
+        int alive = 0;
+        for (int i = 0; i < nv; i++) alive += !w.inc[(size_t)i].empty();
+        for (int pass = 0; pass < 16; pass++) {
+            edges.clear();
+            for (int i = 0; i < nf; i++) {
+                if (w.f[3 * i] < 0) continue;
+                for (int k = 0; k < 3; k++) {
+                    const int u = w.f[3 * i + k], v = w.f[3 * i + (k + 1) % 3];
+                    if (u < v) {  // (a closed oriented surface has every edge once in each direction; on a border the u > v copy may be the only one: skipped, its ends are locked anyway)
+                        const V3 d = sub(w.p[(size_t)u], w.p[(size_t)v]);
+                        edges.push_back({dot(d, d), u, v});
+                    }
+                }
+            }
+            std::sort(edges.begin(), edges.end(), [](const Edge &a, const Edge &b) { return a.len2 != b.len2 ? a.len2 < b.len2 : (a.u != b.u ? a.u < b.u : a.v < b.v); });
+            int removed = 0;
+            for (const Edge &e : edges) {
+                if (w.inc[(size_t)e.u].empty() || w.inc[(size_t)e.v].empty() || !w.connected(e.u, e.v)) continue;
+                // both directions; the one that leaves the better worst angle among the facets it rewrites
+                int best_u = -1, best_v = -1;
+                double best_after = -2.0, best_near = 0.0;
+                for (int dir = 0; dir < 2; dir++) {
+                    const int u = dir ? e.v : e.u, v = dir ? e.u : e.v;
+                    if (locked[(size_t)u]) continue;
+                    w.guard = (double)max_distance - err[(size_t)u];
+                    if (!(w.guard > 0.0)) continue;
+                    double before = 0.0;
+                    const double after = w.try_collapse(u, v, &before);
+                    if (after >= w.q_bound && after > best_after && deviation(u, v) <= (double)max_distance) best_after = after, best_u = u, best_v = v, best_near = w.last_nearest;
+                }
+                if (best_u < 0) continue;
+                touched.clear();
+                w.do_collapse(best_u, best_v, touched);
+                err[(size_t)best_v] = std::max(err[(size_t)best_v], err[(size_t)best_u] + best_near);
+                removed++;
+            }
+            alive -= removed;
+            if (removed * 100 < alive) break;
+        }
+        r.collapses = w.collapses;
+        std::vector<int> renum((size_t)nv, -1);
+        for (int i = 0; i < nf; i++)
+            if (w.f[3 * i] >= 0)
+                for (int k = 0; k < 3; k++) renum[(size_t)w.f[3 * i + k]] = 0;
+        int kept_v = 0;
+        std::vector<float> vout;
+        double max_err = 0.0;
+        for (int i = 0; i < nv; i++)
+            if (renum[(size_t)i] == 0) {
+                renum[(size_t)i] = kept_v++;
+                max_err = std::max(max_err, err[(size_t)i]);
+                for (int k = 0; k < 4; k++) vout.push_back(s->vertices[4 * (size_t)i + k]);
+            }
+        std::vector<int32_t> fout;
+        for (int i = 0; i < nf; i++) {
+            if (w.f[3 * i] < 0) continue;
+            for (int k = 0; k < 3; k++) fout.push_back(renum[(size_t)w.f[3 * i + k]]);
+        }
+        r.vertices_after = kept_v;
+        r.facets_after = (int)(fout.size() / 3);
+        r.max_accumulated_distance = (float)max_err;
         s->vertices.swap(vout);
         s->faces.swap(fout);
     } catch (...) {

@@ -13,6 +13,8 @@
 
 static PoissonNormals g_poisson_normals = POISSON_UNIT_NORMALS;  // what the reference's two-argument call does here (see below)
 
+static bool g_poisson_simplify = true;  // the facet count the criteria ask for, not the grid's (setPoissonSimplify(false): the criteria pass's mesh as it is)
+void setPoissonSimplify(bool on) { g_poisson_simplify = on; }
 void setPoissonNormals(PoissonNormals mode) { g_poisson_normals = mode; }
 PoissonNormals poissonNormals() { return g_poisson_normals; }
 
@@ -55,6 +57,12 @@ Mesh poissonSurface(const Mat points, const Mat normals, PoissonNormals mode)
     if (spacing > 0.0f && mvs_surface_enforce_criteria(s, sm_angle, sm_radius * spacing, sm_distance * spacing, nullptr) != MVS_OK) {
         mvs_surface_free(s);
         throw std::runtime_error("poissonSurface: the facet criteria pass failed");
+    }
+    // ... and what those criteria do NOT ask for is the grid's facet density: vertices the criteria do not need are removed (edge collapses
+    // under the same angle bound and an accumulated distance of at most sm_distance; csrc/surface_criteria.cpp: mvs_surface_simplify)
+    if (g_poisson_simplify && spacing > 0.0f && mvs_surface_simplify(s, sm_angle, sm_distance * spacing, nullptr) != MVS_OK) {
+        mvs_surface_free(s);
+        throw std::runtime_error("poissonSurface: the simplification pass failed");
     }
     int nv = 0, nf = 0;
     mvs_surface_counts(s, &nv, &nf);

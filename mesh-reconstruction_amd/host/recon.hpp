@@ -65,6 +65,9 @@ enum PoissonNormals { POISSON_UNIT_NORMALS = 0, POISSON_CONFIDENCE_NORMALS = 1 }
 Mesh poissonSurface(const Mat points, const Mat normals, PoissonNormals mode);
 void setPoissonNormals(PoissonNormals mode);  // what the two-argument call does from now on (process-wide; the reference is single-threaded)
 PoissonNormals poissonNormals();
+// poissonSurface ends with a simplification pass (mvs_surface_simplify: the facet count the reference's criteria ask for instead of the
+// grid's); setPoissonSimplify(false) returns the criteria pass's mesh as it is
+void setPoissonSimplify(bool on);
 
 // == configuration (configuration.cpp) ==
 class Configuration {

@@ -118,6 +118,7 @@ ABI = [
     ("mvs_surface_grid", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mvs_surface_spacing", _i, [_vp, _vp, _vp, _vp]),
     ("mvs_surface_enforce_criteria", _i, [_vp, _f, _f, _f, _vp]),
+    ("mvs_surface_simplify", _i, [_vp, _f, _f, _vp]),
     ("mvs_surface_from_mesh", _i, [_vp, _i, _vp, _i, _f, _vp]),
     ("mvs_surface_free", None, [_vp]),
     ("mvs_surface_last_error", C.c_char_p, []),
@@ -197,7 +198,7 @@ POISSON_SUPPORT_DEFAULT = 8.0   # MVS_POISSON_SUPPORT_DEFAULT (include/mvs.h)
 
 
 def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0, criteria=REFERENCE_FACET_CRITERIA, report=None, support_spacings=POISSON_SUPPORT_DEFAULT,
-                    use_precision=False):
+                    use_precision=False, simplify=True):
     """poissonSurface (recon.hpp:37) through mvs_poisson_surface + mvs_surface_enforce_criteria: points N x 4 homogeneous, normals N x 3
     (out of the solid) -> (vertices V x 4 float32 with w = 1, faces F x 3 int32).  criteria = (min angle in degrees, max facet radius and
     max facet distance in units of the samples' average spacing), the reference's by default; None: the surface-nets mesh as it is.
@@ -205,7 +206,11 @@ def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0, criteria=REF
     use_precision: keep the normals' lengths as confidences -- what BOTH backends of the reference do (cgal_poisson.cpp:58-69 hands them to
     CGAL as they are; pcl.cpp:23 defines USE_PRECISION, so pcl.cpp:198-202 sets setConfidence(true)).  The default, False, normalises them to
     unit length first: a deliberate divergence from the reference, measured on the pipeline's own clouds (host/poisson.cpp).
-    report: a dict that receives the fields of mvs_criteria_report, the average spacing and the support radius in nodes"""
+    simplify (with criteria): after the criteria pass, remove the vertices the criteria do not need (mvs_surface_simplify: edge collapses under
+    the same angle bound and an accumulated distance of at most criteria[2] spacings) -- the reference's mesher returns as few facets as the
+    curvature allows, the grid mesher the grid's density; False: the criteria pass's mesh as it is.
+    report: a dict that receives the fields of mvs_criteria_report, the average spacing, the support radius in nodes and, under "simplify",
+    the fields of mvs_simplify_report"""
     lib = load_library()
     pts = np.ascontiguousarray(points, np.float32)
     nrm = np.ascontiguousarray(normals, np.float32)
@@ -230,6 +235,13 @@ def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0, criteria=REF
                 raise MvsError("mvs_surface_enforce_criteria failed (%d)" % rc)
             if report is not None:
                 report.update({name: getattr(rep, name) for name, _ in CriteriaReport._fields_})
+            if simplify:
+                srep = SimplifyReport()
+                rc = lib.mvs_surface_simplify(s, float(criteria[0]), float(criteria[2]) * spacing.value, C.byref(srep))
+                if rc != 0:
+                    raise MvsError("mvs_surface_simplify failed (%d)" % rc)
+                if report is not None:
+                    report["simplify"] = {name: getattr(srep, name) for name, _ in SimplifyReport._fields_}
         if report is not None:
             nodes = C.c_int()
             lib.mvs_surface_support(s, C.byref(nodes))
@@ -243,6 +255,34 @@ def poisson_surface(points, normals, grid_log2=0, smooth_cells=1.0, criteria=REF
     finally:
         lib.mvs_surface_free(s)
     return v, f
+
+
+class SimplifyReport(C.Structure):
+    _fields_ = [("collapses", C.c_int), ("vertices_before", C.c_int), ("vertices_after", C.c_int), ("facets_before", C.c_int), ("facets_after", C.c_int),
+                ("max_accumulated_distance", C.c_float)]
+
+
+def simplify_surface(vertices, faces, average_spacing, criteria=REFERENCE_FACET_CRITERIA):
+    """mvs_surface_from_mesh + mvs_surface_simplify on a caller's mesh (host code, no GPU): -> (vertices, faces, report dict)"""
+    lib = load_library()
+    v = np.ascontiguousarray(vertices, np.float32)
+    f = np.ascontiguousarray(faces, np.int32)
+    s = C.c_void_p()
+    if lib.mvs_surface_from_mesh(v.ctypes.data_as(_vp), len(v), f.ctypes.data_as(_vp), len(f), float(average_spacing), C.byref(s)) != 0:
+        raise MvsError("mvs_surface_from_mesh failed")
+    try:
+        rep = SimplifyReport()
+        rc = lib.mvs_surface_simplify(s, float(criteria[0]), float(criteria[2]) * average_spacing, C.byref(rep))
+        if rc != 0:
+            raise MvsError("mvs_surface_simplify failed (%d)" % rc)
+        nv, nf = C.c_int(), C.c_int()
+        lib.mvs_surface_counts(s, C.byref(nv), C.byref(nf))
+        vo = np.zeros((nv.value, 4), np.float32)
+        fo = np.zeros((nf.value, 3), np.int32)
+        lib.mvs_surface_fetch(s, vo.ctypes.data_as(_vp), fo.ctypes.data_as(_vp))
+        return vo, fo, {name: getattr(rep, name) for name, _ in SimplifyReport._fields_}
+    finally:
+        lib.mvs_surface_free(s)
 
 
 def enforce_facet_criteria(vertices, faces, average_spacing, criteria=REFERENCE_FACET_CRITERIA):

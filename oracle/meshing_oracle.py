@@ -306,8 +306,14 @@ def surface_nets(chi, iso, origin, h, support=None):
 # (sm_distance x average spacing).  The restatement below follows the pass operation for operation in float64 Python scalars (the
 # C++ is compiled with -ffp-contract=off and uses double throughout: the same IEEE operations in the same order), including the order
 # of the incidence lists and of the work list, so that the result can be compared index for index on small meshes.
-def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_distance):
-    """-> (vertices V' x 4 float32, faces F' x 3 int32, report dict).  Pure-Python loops: use on meshes of a few ten thousand facets."""
+def simplify_surface(vertices, faces, min_angle_deg, max_distance):
+    """csrc/surface_criteria.cpp: mvs_surface_simplify, operation for operation -> (vertices, faces, report dict)"""
+    return enforce_facet_criteria(vertices, faces, min_angle_deg, 1e30, max_distance, _simplify=True)
+
+
+def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_distance, _simplify=False):
+    """-> (vertices V' x 4 float32, faces F' x 3 int32, report dict).  Pure-Python loops: use on meshes of a few ten thousand facets.
+    (_simplify: the driver of simplify_surface over the same mesh operations, instead of the criteria rounds)"""
     import math
     vin = np.asarray(vertices, np.float32)
     p = [(float(r[0]), float(r[1]), float(r[2])) for r in vin]
@@ -359,6 +365,7 @@ def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_dista
         inc[a].append(i), inc[b].append(i), inc[c].append(i)
     q_bound = -math.cos(float(np.float32(min_angle_deg)) * 3.14159265358979323846 / 180.0)
     guard = [0.25 * float(np.float32(max_distance))]
+    last_nearest = [0.0]
     count = {"collapses": 0, "flips": 0}
 
     def try_collapse(u, v):
@@ -392,6 +399,7 @@ def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_dista
             any_ = True
         if not any_ or nearest > guard[0]:
             return None
+        last_nearest[0] = nearest
         return after, before
 
     journal = {"on": False, "log": [], "count": None}
@@ -554,7 +562,86 @@ def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_dista
             journal_rollback()
         return False
 
-    queue = [i for i in range(nf) if f[i][0] >= 0 and q_of(i) < q_bound]
+    if _simplify:
+        md = float(np.float32(max_distance))
+        err = [0.0] * nv
+        vn = [(0.0, 0.0, 0.0)] * nv
+        for i in range(nf):
+            if f[i][0] < 0:
+                continue
+            n = normal_of(*f[i])
+            for w in f[i]:
+                a = vn[w]
+                vn[w] = (a[0] + n[0], a[1] + n[1], a[2] + n[2])
+        for i in range(nv):
+            l = math.sqrt(dot(vn[i], vn[i]))
+            vn[i] = (vn[i][0] / l, vn[i][1] / l, vn[i][2] / l) if l > 0.0 else (0.0, 0.0, 0.0)
+
+        def deviation(u, v):
+            e = edge_facets(u, v)[:2]
+            worst = 0.0
+            for i in inc[u]:
+                if i == e[0] or i == e[1]:
+                    continue
+                t = [v if w == u else w for w in f[i]]
+                n = normal_of(*t)
+                ln = math.sqrt(dot(n, n))
+                if not ln > 0.0:
+                    return 1e300
+                c, emax, l2 = 1.0, 0.0, 0.0
+                for k in range(3):
+                    c = min(c, dot(n, vn[t[k]]) / ln)
+                    emax = max(emax, max(err[v], err[u]) if t[k] == v else err[t[k]])
+                    d = sub(p[t[k]], p[t[(k + 1) % 3]])
+                    l2 = max(l2, dot(d, d))
+                if not c > 0.2:
+                    return 1e300
+                worst = max(worst, 0.5 * math.sqrt(l2) * math.sqrt(max(0.0, 1.0 - c * c)) / (1.0 + c) + emax)
+            return worst
+
+        locked = [False] * nv
+        for i in range(nf):
+            if f[i][0] < 0:
+                continue
+            for k in range(3):
+                u, v = f[i][k], f[i][(k + 1) % 3]
+                if len(edge_facets(u, v)) != 2:
+                    locked[u] = locked[v] = True
+        alive_v = sum(1 for i in range(nv) if inc[i])
+        for _pass in range(16):
+            edges = []
+            for i in range(nf):
+                if f[i][0] < 0:
+                    continue
+                for k in range(3):
+                    u, v = f[i][k], f[i][(k + 1) % 3]
+                    if u < v:
+                        d = sub(p[u], p[v])
+                        edges.append((dot(d, d), u, v))
+            edges.sort()
+            removed = 0
+            for _, eu, ev in edges:
+                if not inc[eu] or not inc[ev] or not any(ev in f[i] for i in inc[eu]):
+                    continue
+                best = None
+                for u, v in ((eu, ev), (ev, eu)):
+                    if locked[u]:
+                        continue
+                    guard[0] = md - err[u]
+                    if not guard[0] > 0.0:
+                        continue
+                    r = try_collapse(u, v)
+                    if r is not None and r[0] >= q_bound and (best is None or r[0] > best[2]) and deviation(u, v) <= md:
+                        best = (u, v, r[0], last_nearest[0])
+                if best is None:
+                    continue
+                do_collapse(best[0], best[1], [])
+                err[best[1]] = max(err[best[1]], err[best[0]] + best[3])
+                removed += 1
+            alive_v -= removed
+            if removed * 100 < alive_v:
+                break
+    queue = [] if _simplify else [i for i in range(nf) if f[i][0] >= 0 and q_of(i) < q_bound]
     budget, done = 2 * nf + 1000, 0
     for rnd in range(3):
         head = 0

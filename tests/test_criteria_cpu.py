@@ -232,3 +232,72 @@ def test_bad_arguments():
         assert lib.mvs_surface_enforce_criteria(s, 20.0, 1.0, 1.0, None) == 0     # report is optional
     finally:
         lib.mvs_surface_free(s)
+
+
+@pytest.mark.parametrize("name", sorted(SURFACES))
+def test_simplification_returns_the_facet_count_the_criteria_ask_for(name):
+    """cgal_poisson.cpp:95-97's criteria bound a facet's angles from below and its distance from the surface from above -- not its size --
+    so the reference's mesher returns as few facets as the curvature allows.  mvs_surface_simplify after the criteria pass: an order of
+    magnitude fewer facets, every angle still >= 20 degrees, vertices AND facet centres still within 0.375 spacings of the analytic
+    surface, the surface still closed, oriented and a manifold of the same topology and (nearly) the same volume, no vertex moved or added."""
+    make, distance = SURFACES[name]
+    pts, nrm = make(np.random.default_rng(11))
+    v, f, sp = oracle_surface(pts, nrm)
+    v1, f1, _ = mvs_amd.enforce_facet_criteria(v, f, sp)
+    v2, f2, rep = mvs_amd.simplify_surface(v1, f1, sp)
+    assert rep["facets_before"] == len(f1) and rep["facets_after"] == len(f2) and rep["vertices_after"] == len(v2)
+    assert len(f2) * 10 < len(f1), (len(f1), len(f2))
+    assert facet_angles(v2, f2).min() >= 20.0 - 1e-6
+    assert rep["max_accumulated_distance"] <= 0.375 * sp
+    if distance is not None:
+        P = np.asarray(v2, np.float64)[:, :3]
+        assert np.abs(distance(P)).max() <= 0.375 * sp
+        assert np.abs(distance(P[f2].mean(1))).max() <= 0.375 * sp            # the chords' sagitta: bounded through the kept normals
+    assert closed_oriented_manifold(f2)
+    assert len(v2) - len(f2) // 2 == len(v1) - len(f1) // 2                   # Euler characteristic
+    assert abs(mc.signed_volume(v2, f2) / mc.signed_volume(v1, f1) - 1.0) < 0.03   # (chords lie inside a convex surface: a tube of radius 0.4 meshed to 0.2 spacings loses 2 %)
+    assert rep["collapses"] == len(v1) - len(v2) and len(f1) - len(f2) == 2 * rep["collapses"]
+    rows = {r.tobytes(): i for i, r in enumerate(v1)}
+    where = np.array([rows[r.tobytes()] for r in v2])
+    assert np.all(np.diff(where) > 0)                                        # a subsequence of the input's vertices
+    # deterministic; a second application finds little left
+    v3, f3, _ = mvs_amd.simplify_surface(v1, f1, sp)
+    assert v3.tobytes() == v2.tobytes() and f3.tobytes() == f2.tobytes()
+
+
+def test_simplification_equals_the_oracle_and_keeps_borders():
+    """the oracle's restatement (oracle/meshing_oracle.py: simplify_surface, pure Python) gives the same mesh index for index; on an open
+    patch the border vertices all stay"""
+    pts, nrm = sphere(np.random.default_rng(3), 600)
+    v, f, sp = oracle_surface(pts, nrm)
+    v1, f1, _ = mvs_amd.enforce_facet_criteria(v, f, sp)
+    v2, f2, rep = mvs_amd.simplify_surface(v1, f1, sp)
+    ov, of, _ = mo.simplify_surface(v1, f1, 20.0, 0.375 * sp)
+    assert np.array_equal(ov, v2) and np.array_equal(of, f2) and len(f2) * 10 < len(f1)
+    # an open patch: the facets of the upper half only
+    keep = np.asarray(v1, np.float64)[:, 2][f1].min(1) > 0.0
+    fo = f1[keep]
+    used = np.unique(fo)
+    renum = -np.ones(len(v1), np.int64)
+    renum[used] = np.arange(len(used))
+    vo, fo = v1[used], renum[fo].astype(np.int32)
+    use = mc.edge_use(fo)
+    border = set(a for (a, b), n in use.items() if use.get((b, a), 0) == 0) | set(b for (a, b), n in use.items() if use.get((b, a), 0) == 0)
+    v3, f3, rep3 = mvs_amd.simplify_surface(vo, fo, sp)
+    assert len(f3) * 5 < len(fo)
+    kept = set(r.tobytes() for r in v3)
+    assert all(vo[i].tobytes() in kept for i in border)
+    assert facet_angles(v3, f3).min() >= 20.0 - 1e-6
+
+
+def test_simplification_argument_errors():
+    v, f = _flat_grid(4)
+    lib = mvs_amd.load_library()
+    import ctypes as C
+    s = C.c_void_p()
+    assert lib.mvs_surface_from_mesh(v.ctypes.data_as(C.c_void_p), len(v), f.ctypes.data_as(C.c_void_p), len(f), 1.0, C.byref(s)) == 0
+    assert lib.mvs_surface_simplify(None, 20.0, 0.1, None) == -1
+    assert lib.mvs_surface_simplify(s, 60.0, 0.1, None) == -1
+    assert lib.mvs_surface_simplify(s, 20.0, -1.0, None) == -1
+    assert lib.mvs_surface_simplify(s, 20.0, 0.0, None) == 0          # no budget: nothing may move
+    lib.mvs_surface_free(s)
