@@ -260,6 +260,7 @@ static int run_gpu(const std::string &tracks, const std::string &out)
             for (int k = 0; k < 3; k++) scaled.at<float>(i, k) = nrm.at<float>(i, k) * s;
         }
         CHECK(poissonNormals() == POISSON_UNIT_NORMALS, "the default of poissonSurface(points, normals) is unit normals");
+        setPoissonSimplify(false);  // (vertex-for-vertex comparisons of meshes whose fields differ in the last float bit: the grid's mesh, not the simplified one)
         const Mesh unit_mesh = poissonSurface(pts, nrm), scaled_mesh = poissonSurface(pts, scaled), conf_mesh = poissonSurface(pts, scaled, POISSON_CONFIDENCE_NORMALS);
         bool same = unit_mesh.vertices.rows == scaled_mesh.vertices.rows && unit_mesh.faces.rows == scaled_mesh.faces.rows;
         double dmax = 0.0;
@@ -271,6 +272,7 @@ static int run_gpu(const std::string &tracks, const std::string &out)
         setPoissonNormals(POISSON_UNIT_NORMALS);
         CHECK(conf2.vertices.rows == conf_mesh.vertices.rows && conf2.faces.rows == conf_mesh.faces.rows, "setPoissonNormals switches the two-argument call");
         CHECK(conf_mesh.vertices.rows != unit_mesh.vertices.rows || conf_mesh.faces.rows != unit_mesh.faces.rows, "confidence normals give another mesh than unit normals");
+        setPoissonSimplify(true);
     }
     std::ofstream sel(out + "/chosen.txt");
     int mains = 0, pairs = 0;

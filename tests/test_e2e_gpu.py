@@ -174,7 +174,7 @@ def test_the_outer_iteration_converges_on_the_surface_the_frames_show():
             assert len(keep) > 0.5 * len(cloud)
             rep = {}
             v, f = mvs_amd.poisson_surface(cloud[keep, :4], cloud[keep, 4:7], report=rep)
-            assert 1000 < len(v) < 10 * len(keep) and rep["facets_below_angle"] < 0.005 * len(f)
+            assert 1000 < len(v) < 10 * len(keep) and rep["facets_below_angle"] < 0.005 * rep["simplify"]["facets_before"]   # (counted before the simplification pass)
             mesh = (v, f)
         # measured: 0.0224 -> 0.0027 -> 0.0008, coverage 99 % -> 98 % -> 92 %
         assert errors[1] < 0.25 * errors[0] and errors[2] < 0.6 * errors[1], errors
