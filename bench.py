@@ -700,6 +700,12 @@ def main():
             alternatives[name] = {"ms_per_step": r["ms_per_step"], "samples_per_s": float(P) * D * V / (r["dt"] / args.steps), "scaling": "strong",
                                   "sweep_ms": r["sweep_ms"], "views_per_rank": r["views"], "collective_bytes_per_rank_per_step": r["collective_bytes_per_rank"],
                                   "depth_crc32": r["crc"]}
+        # and the split with no exchange at all: every rank sweeps a whole main view of its own (the reference's independent `fa` loop, recon.cpp:65;
+        # here the SAME view on every rank -- a timing of N independent sweeps, the throughput a sequence sharded by main frames reaches)
+        r = timed("frames", None)
+        alternatives["frames_weak"] = {"ms_per_step": r["ms_per_step"], "samples_per_s": float(P) * D * V * world / (r["dt"] / args.steps), "scaling": "weak",
+                                       "sweep_ms": r["sweep_ms"], "views_per_rank": r["views"], "collective_bytes_per_rank_per_step": 0.0,
+                                       "note": "N independent main views per step, no data-path collective (bench.py --shard frames makes this the line's value)"}
 
     # the same N GPUs through the product's own multi-GPU entry (mvs_comm_*: one process, rank threads, resident inputs), run by rank 0
     # as a child process while the other ranks idle on the host (a gloo barrier: no GPU work queued by anybody meanwhile)

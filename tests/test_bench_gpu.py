@@ -57,8 +57,11 @@ def test_bench_line_contract_and_two_rank_shardings():
         assert two["depth_crc32"] == single["depth_crc32"], shard   # rank 0's frame is the single-GPU frame in every mode
     full = _bench(["--with-extras"], 2)   # default N = 2 with the alternatives block
     alt = full["config"]["alternatives"]
-    assert set(alt) == {"views_allreduce", "views_reduce_scatter"}
-    for a in alt.values():
+    assert set(alt) == {"views_allreduce", "views_reduce_scatter", "frames_weak"}
+    assert alt["frames_weak"]["scaling"] == "weak" and alt["frames_weak"]["samples_per_s"] > 0 and alt["frames_weak"]["collective_bytes_per_rank_per_step"] == 0
+    for name, a in alt.items():
+        if name == "frames_weak":
+            continue
         assert a["depth_crc32"] == single["depth_crc32"] and a["collective_bytes_per_rank_per_step"] > 0 and a["views_per_rank"] == 2
     # ... and the same GPUs once more through the product's own multi-GPU entry (rank 0's child process: mvs_comm_set_* + mvs_comm_run)
     vc = full["via_comm"]
