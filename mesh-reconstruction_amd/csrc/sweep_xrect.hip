@@ -34,7 +34,10 @@ namespace {
 
 constexpr int XR_TILE_H = 8, XR_PC = 16, XR_KW = 4;  // tile rows, planes per chunk, planes per wavefront (round 5 built 8 planes per wavefront on 32-plane chunks -- the code below is
                                                       // generic in both -- and dropped it: on a ring of views the widest and the tallest box belong to DIFFERENT views, the slot holds their product,
-                                                      // and at c3 it no longer fits 24 KiB: the plan falls back to sweep_tiled; where it fits, the copy volume per sample does not shrink)
+                                                      // and at c3 it no longer fits 24 KiB: the plan falls back to sweep_tiled; where it fits, the copy volume per sample does not shrink.
+                                                      // Also built in round 5 and not kept: 64 x 16 tiles with EIGHT wavefronts of 2 planes (a plane's set-up serving 16 rows, a third less
+                                                      // copy volume): 16 rows of Im / best / bi make 150 VGPRs -- at the 128 cap that 512-thread workgroups need for two per CU the compiler
+                                                      // spills 44 of them (88 bytes of scratch per lane); at 168 one workgroup per CU is left)
 constexpr int XR_MAX_NI = 6;                          // 1 KiB copy instructions per wavefront and region, at most (24 KiB per slot: c3's boxes are ~84 quads x 24 rows of 8 bytes)
 constexpr int XR_MAX_REGIONS = 256;                    // (chunks x views) of one workgroup: 16 KiB of records at the most
 constexpr int XR_WAVES = 4;                           // launch bound: <= 128 VGPRs (two 16 KiB slots + 16 KiB of records at c3: three workgroups per CU)
