@@ -475,6 +475,8 @@ def main():
                     help="views sharding: all-reduce the volume in this many plane groups, overlapped with the sweep")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (for rocprofv3 runs: keeps per-kernel averages to the timed variant)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1, rows: the all-gather of a step's depth rows on the compute stream, in place (round 4's form), instead of beside the next step's sweep")
     ap.add_argument("--via-comm", action="store_true",
                     help="ONE process drives the N GPUs through the C ABI's communicator (mvs_comm_set_* + mvs_comm_run: rank threads, inputs "
                          "resident, rows mode gathers the depth bands on GPU 0 by peer copies) instead of one process per GPU under torch.distributed")
@@ -597,18 +599,46 @@ def main():
             # band r is rows [r * tallest, ...) of the main view, so the gathered bands ARE the depth map (its first H rows): the
             # collective reads a full band straight from the context's depth buffer and no row is copied afterwards; only a band
             # shorter than `tallest` (the last one) goes through a padded staging buffer
-            band_pad = torch.zeros((tallest, W), dtype=torch.float32, device="cuda")
-            band_cat = torch.empty((world * tallest, W), dtype=torch.float32, device="cuda")   # concatenated form: every backend
-            mine = depth_t[r0:r0 + tallest] if rn == tallest else band_pad
+            # Consecutive steps are independent main views, so the exchange of step k runs beside the sweep of step k + 1 (round 5): the
+            # band is copied into one of two staging buffers on the compute stream (1/N of 8 MB), the all-gather of that buffer goes to the
+            # communication stream behind an event, and a buffer is reused only when its previous collective has completed.  The timed
+            # region ends with every collective done (barrier()).  --no-overlap keeps round 4's form: the collective reads the context's
+            # depth buffer in place, on the compute stream.
+            overlap = not args.no_overlap
+            band_pad = [torch.zeros((tallest, W), dtype=torch.float32, device="cuda") for _ in range(2)]
+            band_cat = [torch.empty((world * tallest, W), dtype=torch.float32, device="cuda") for _ in range(2)]   # concatenated form: every backend
+            mine = depth_t[r0:r0 + tallest] if rn == tallest else band_pad[0]
+            state = {"k": 0, "work": [None, None]}
 
             def step():
                 # rows are independent: every rank sweeps its band of the SAME main view over all views and planes (volume band
                 # materialised, depth selected in the kernel); only the depth rows travel (4 B per pixel in total)
+                k = state["k"] & 1
+                state["k"] += 1
+                if not overlap:
+                    ctx.sweep_run_rows(r0, rn, 0, V, both)
+                    if rn != tallest and rn:
+                        band_pad[0][:rn].copy_(depth_t[r0:r0 + rn])
+                    dist.all_gather_into_tensor(band_cat[0], mine)
+                    return
+                if state["work"][k] is not None:
+                    state["work"][k].wait()          # the collective that last used these two buffers (two steps ago) has completed
                 ctx.sweep_run_rows(r0, rn, 0, V, both)
-                if rn != tallest and rn:
-                    band_pad[:rn].copy_(depth_t[r0:r0 + rn])
-                dist.all_gather_into_tensor(band_cat, mine)
-            return step, V, bands[0][1], 4.0 * tallest * W * (world - 1) * 2, lambda: band_cat[:H].cpu().numpy()
+                if rn:
+                    band_pad[k][:rn].copy_(depth_t[r0:r0 + rn])
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                comm_stream.wait_event(ev)
+                with torch.cuda.stream(comm_stream):
+                    state["work"][k] = dist.all_gather_into_tensor(band_cat[k], band_pad[k], async_op=True)
+
+            def finish():   # (called once, before the depth map of the last step is read)
+                for w_ in state["work"]:
+                    if w_ is not None:
+                        w_.wait()
+                torch.cuda.synchronize()
+                return band_cat[(state["k"] - 1) & 1 if overlap else 0][:H].cpu().numpy()
+            return step, V, bands[0][1], 4.0 * tallest * W * (world - 1) * 2, finish
         if mode == "views" and world > 1 and collective == "reduce_scatter":
             if D % world:
                 raise SystemExit("reduce_scatter needs the plane count (%d) divisible by the ranks (%d)" % (D, world))
@@ -893,7 +923,7 @@ def main():
             "dtype": DTYPE[args.sampler],
             "data": "synthetic (%s)" % args.data + (" [TEST HOOK: ranks share one GPU over gloo -- not a measurement]" if same_device else ""),
             "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V) + (" (GENERAL CAMERAS: side views turned by 12 mrad, not the SURVEY 8d ring)" if args.general_cameras else ""),
-                       "sampler": args.sampler, "shard": None if world == 1 else shard, "collective": args.collective if shard == "views" else ("all_gather of depth rows" if shard == "rows" and world > 1 else None),
+                       "sampler": args.sampler, "shard": None if world == 1 else shard, "collective": args.collective if shard == "views" else (("all_gather of depth rows" + ("" if args.no_overlap else ", on a second stream beside the next step's sweep (steps are independent main views; the timed region ends with every collective complete)")) if shard == "rows" and world > 1 else None),
                        "views_per_rank": primary["views"], "rows_per_rank": [n for _, n in bands] if shard == "rows" else None,
                        "collective_bytes_per_rank_per_step": primary["collective_bytes_per_rank"], "alternatives": alternatives, "device": ctx.info()},
             "roofline": {"bound": "hbm", "kernel": sweep_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
