@@ -94,10 +94,10 @@ __global__ void pad_wrap_kernel(const uint8_t *__restrict__ img, uint8_t *__rest
 // dword-aligned (W % 4 == 0) the five texels per row it needs come from two aligned dword loads.  blockIdx.z = view; the frames are
 // `imgs + img_stride * view` or, when `table` is given, table[view] (device-resident frames of the caller, mvs_sweep_set_views_device).
 __global__ __launch_bounds__(256) void quad_image_from_raw_kernel(const uint8_t *__restrict__ imgs, size_t img_stride, const uint8_t *const *__restrict__ table,
-                                                                  uint32_t *__restrict__ quads, int W, int H, int pitch, size_t pad_slab)
+                                                                  uint32_t *__restrict__ quads, int W, int H, int pitch, size_t pad_slab, int row0)
 {
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
-    const int y = blockIdx.y;
+    const int y = row0 + blockIdx.y;  // quad rows [row0, row0 + gridDim.y): the whole image, or the rows a band of mvs_sweep's pipeline needs next
     if (x >= pitch) return;
     const uint8_t *img = table ? table[blockIdx.z] : imgs + img_stride * blockIdx.z;
     uint4 q = make_uint4(0u, 0u, 0u, 0u);
@@ -286,6 +286,7 @@ void mvs_destroy(mvs_ctx *ctx)
     }
     for (hipEvent_t e : ctx->lane_events) (void)hipEventDestroy(e);
     if (ctx->plan_event) (void)hipEventDestroy(ctx->plan_event);
+    for (hipEvent_t e : ctx->band_events) (void)hipEventDestroy(e);
     for (auto &b : ctx->batch_slot) {
         if (b.swept) (void)hipEventDestroy(b.swept);
         if (b.landed) (void)hipEventDestroy(b.landed);
@@ -415,9 +416,34 @@ int sweep_upload_frames_impl(mvs_ctx *ctx, const uint8_t *const *side_frames, bo
             MVS_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->upload.ptr + P * v, side_frames[v], P, hipMemcpyHostToDevice, ctx->stream));
     }
     const dim3 grid(div_up(ctx->pad_pitch / 4, 256), H + 2, nviews);
-    quad_image_from_raw_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)ctx->upload.ptr, P, table, (uint32_t *)ctx->side_quads.ptr, W, H, ctx->pad_pitch, ctx->pad_slab);
+    quad_image_from_raw_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)ctx->upload.ptr, P, table, (uint32_t *)ctx->side_quads.ptr, W, H, ctx->pad_pitch, ctx->pad_slab, 0);
     MVS_HIP(ctx, hipGetLastError());
     ctx->pads_valid = false;     // the padded u8 frames and the exact sampler's quad image are rebuilt from the new quads when a path needs them
+    ctx->quads16_valid = false;
+    return MVS_OK;
+}
+
+// The two halves of sweep_upload_frames_impl on row ranges, for the band pipeline of the one-call mvs_sweep (sweep.hip): raw rows [r0, r1) of
+// every side view into the staging block on stream `s` (the copy stream: the rows of the next band cross PCIe while this band is swept) ...
+int sweep_upload_rows_impl(mvs_ctx *ctx, const uint8_t *const *side_frames, int r0, int r1, hipStream_t s)
+{
+    const int W = ctx->W, nviews = ctx->V;
+    const size_t P = (size_t)W * ctx->H;
+    if (r1 <= r0) return MVS_OK;
+    for (int v = 0; v < nviews; v++)
+        MVS_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->upload.ptr + P * v + (size_t)r0 * W, side_frames[v] + (size_t)r0 * W, (size_t)(r1 - r0) * W, hipMemcpyHostToDevice, s));
+    return MVS_OK;
+}
+
+// ... and quad rows [q0, q1) of all views from the raw rows in the staging block (quad row y reads raw rows y - 1 and y, wrapped), on the context's stream
+int sweep_build_quads_impl(mvs_ctx *ctx, int q0, int q1)
+{
+    if (q1 <= q0 || ctx->V <= 0) return MVS_OK;
+    const dim3 grid(div_up(ctx->pad_pitch / 4, 256), q1 - q0, ctx->V);
+    quad_image_from_raw_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)ctx->upload.ptr, (size_t)ctx->W * ctx->H, nullptr, (uint32_t *)ctx->side_quads.ptr, ctx->W, ctx->H,
+                                                             ctx->pad_pitch, ctx->pad_slab, q0);
+    MVS_HIP(ctx, hipGetLastError());
+    ctx->pads_valid = false;
     ctx->quads16_valid = false;
     return MVS_OK;
 }
@@ -465,7 +491,7 @@ int frame_upload_impl(mvs_ctx *ctx, int slot, const uint8_t *frame_hw, bool devi
     uint8_t *raw = (uint8_t *)ctx->store_raw.ptr + P * slot;
     MVS_HIP(ctx, hipMemcpyAsync(raw, frame_hw, P, device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     const dim3 grid(div_up(pitch / 4, 256), H + 2, 1);
-    quad_image_from_raw_kernel<<<grid, 256, 0, ctx->stream>>>(raw, P, nullptr, (uint32_t *)ctx->store_quads.ptr + slab * slot, W, H, pitch, slab);
+    quad_image_from_raw_kernel<<<grid, 256, 0, ctx->stream>>>(raw, P, nullptr, (uint32_t *)ctx->store_quads.ptr + slab * slot, W, H, pitch, slab, 0);
     MVS_HIP(ctx, hipGetLastError());
     ctx->store_have[slot] = 1;
     return MVS_OK;

@@ -56,6 +56,8 @@ Hooks read_hooks()
     h.flow_graph = present("MVS_FLOW_GRAPH");
     h.flow_graph_kernel_memset = number("MVS_FLOW_GRAPH", 0) == 2;
     h.fb_variant = number("MVS_FB_VARIANT", 0);
+    h.onecall_bands = number("MVS_ONECALL_BANDS", 0);
+    h.onecall_first_permille = number("MVS_ONECALL_FIRST", 0);
     h.raster_bins = number("MVS_RASTER_BINS", -1);
     h.poison_alloc = present("MVS_POISON_ALLOC");
     return h;

@@ -122,6 +122,8 @@ struct mvs_ctx {
     } batch_slot[2];
     int batch_next = 0;
     hipStream_t copy_stream = nullptr;
+    int onecall_bands_last = 0;           // row bands of the last mvs_sweep (test hook mvs_test_onecall_bands)
+    std::vector<hipEvent_t> band_events;  // mvs_sweep's band pipeline: rows uploaded / band swept, per band
     int store_cap = 0;
     std::vector<unsigned char> store_have;
     // mvs_process_frame runs the flows of one main frame's side views concurrently: a lane is everything calculateFlow keeps
@@ -181,6 +183,8 @@ struct PlanHook {  // work a caller wants queued between the planner's launches 
 };
 int sweep_fx_plan(mvs_ctx *ctx, PlanHook *between = nullptr);  // sweep_fx.hip: the fixed sampler's region plan (rectified tables or the general plan)
 int ensure_pads(mvs_ctx *ctx);     // wrap-padded u8 frames of the current side views, rebuilt from the quad images when a path needs them
+int sweep_upload_rows_impl(mvs_ctx *ctx, const uint8_t *const *side_frames, int r0, int r1, hipStream_t s);  // context.hip: band pipeline of mvs_sweep
+int sweep_build_quads_impl(mvs_ctx *ctx, int q0, int q1);
 int sweep_rect_plan(mvs_ctx *ctx, PlanHook *between = nullptr);   // sweep_rect.hip: tables + eligibility of the rectified kernel for the current fixed-sampler plan
 struct SweepParams;
 int ensure_quads16(mvs_ctx *ctx);  // exact sampler's f16 quad image of the current side views  // the deferred half of sweep_set_views_impl

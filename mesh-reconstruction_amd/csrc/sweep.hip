@@ -1143,6 +1143,169 @@ int mvs_sweep_fetch(mvs_ctx *ctx, float *depth_hw, float *cost_hw, int32_t *inde
     return MVS_OK;
 }
 
+// ---- the one-call mvs_sweep as a pipeline of row bands ---------------------------------------------------------------------------
+// RenderHIP users reach mvs_sweep first, and there the side frames' trip over PCIe is most of the call (c3: 33 MB up, 0.6 ms of sweep, 8 MB
+// down).  The fixed sampler's sweep runs on row bands (mvs_sweep_run_rows) and a band of main rows samples a band of side rows, so the call
+// is cut into bands: the side rows band b needs go up on the copy stream, their quad rows are built and the band is swept on the context's
+// stream while the rows of band b + 1 cross the bus, and the band's depths come back as soon as it is done.  WHICH side rows a band needs
+// is bounded on the host: the sample row sy / sw is a ratio of two functions affine in (xn, yn, z), so over the box (all columns) x (the
+// band's rows) x (all planes) with sw > 0 at its eight corners it takes its extremes at the corners; +- 1 row covers the f32 / 1/256-pixel
+// rounding of the kernels (a row that is copied into a region but not sampled may hold anything).  A corner behind a side camera, the exact
+// sampler, a volume request or a small image take the unbanded path.  Results are the same bits either way (tests/test_sweep_gpu.py).
+struct BandPipeline : PlanHook {
+    static constexpr int kMaxBands = 8;
+    mvs_ctx *c = nullptr;
+    const uint8_t *const *frames = nullptr;
+    int nb = 0;
+    int row0[kMaxBands + 1] = {};            // main rows of band b: [row0[b], row0[b + 1])
+    int qa[kMaxBands] = {}, qb[kMaxBands] = {};  // quad rows band b may sample: [qa, qb)
+    int up_lo = 0, up_hi = 0;                // raw rows [up_lo, up_hi) of every view are queued into the staging block ...
+    bool wrap_top = false, wrap_bot = false; // ... and raw row H - 1 / raw row 0 on their own (the wrap rows of quad rows 0 and H)
+    int q_lo = 0, q_hi = 0;                  // quad rows [q_lo, q_hi) are queued for building
+    int staged = 0;                          // bands whose rows have been queued on the copy stream
+
+    hipEvent_t up(int b) const { return c->band_events[2 * b]; }
+    hipEvent_t swept(int b) const { return c->band_events[2 * b + 1]; }
+
+    // false: some view may see part of the sweep from behind (sw <= 0): no bound, no pipeline
+    bool plan_rows()
+    {
+        const int W = c->W, H = c->H, D = c->D;
+        const double zc[2] = {c->z_host[0], c->z_host[D - 1]};
+        const double xc[2] = {1.0 / W - 1.0, (2.0 * W - 1.0) / W - 1.0};
+        for (int b = 0; b < nb; b++) {
+            const double yc[2] = {1.0 - (2.0 * row0[b] + 1.0) / H, 1.0 - (2.0 * row0[b + 1] - 1.0) / H};
+            int lo = H + 2, hi = -1;
+            for (int v = 0; v < c->V; v++) {
+                const float *q = c->q_host.data() + 12 * v;
+                double cmin = 1e300, cmax = -1e300;
+                for (int k = 0; k < 8; k++) {
+                    const double x = xc[k & 1], y = yc[(k >> 1) & 1], z = zc[k >> 2];
+                    const double sy = q[4] * x + q[5] * y + q[6] * z + q[7], sw = q[8] * x + q[9] * y + q[10] * z + q[11];
+                    if (!(sw > 1e-30)) return false;
+                    const double cy = sy / sw;
+                    if (!(cy == cy)) return false;
+                    cmin = cy < cmin ? cy : cmin;
+                    cmax = cy > cmax ? cy : cmax;
+                }
+                if (cmax < 0.25 || cmin > H + 0.75) continue;  // (in the frame: 0.5 < cy < H + 0.5) this view sees nothing of the band
+                const int a = (int)floor(cmin < 0.0 ? 0.0 : cmin) - 1, e = (int)floor(cmax > H + 1.0 ? H + 1.0 : cmax) + 2;
+                lo = a < lo ? a : lo;
+                hi = e > hi ? e : hi;
+            }
+            qa[b] = lo < 0 ? 0 : lo;
+            qb[b] = hi > H + 1 ? H + 1 : hi;  // quad row H + 1 is never sampled
+            if (qb[b] < qa[b]) qa[b] = qb[b] = 0;
+        }
+        return true;
+    }
+
+    int upload(int r0, int r1)
+    {
+        if (wrap_bot && r0 == 0) r0 = 1;  // already there: not written a second time under the eyes of a running band
+        if (wrap_top && r1 == c->H) r1 = c->H - 1;
+        return sweep_upload_rows_impl(c, frames, r0, r1, c->copy_stream);
+    }
+
+    // copy stream: the raw rows quad rows [a, e) read and the staging block does not hold yet; then the "rows of band b are up" event
+    int stage(int b, int a, int e)
+    {
+        const int H = c->H;
+        int rc;
+        if (e > a) {
+            const bool have_q = q_hi > q_lo, have_r = up_hi > up_lo;
+            const int na = have_q && q_lo < a ? q_lo : a, ne = have_q && q_hi > e ? q_hi : e;  // hull of the quad rows once this band is built
+            const int r0 = na > 0 ? na - 1 : 0, r1 = ne < H ? ne : H;                           // quad row y reads raw rows y - 1 and y (wrapped)
+            const int h0 = have_r && up_lo < r0 ? up_lo : r0, h1 = have_r && up_hi > r1 ? up_hi : r1;
+            if (na == 0 && h1 != H && !wrap_top) {  // quad row 0 reads raw row H - 1
+                if ((rc = sweep_upload_rows_impl(c, frames, H - 1, H, c->copy_stream))) return rc;
+                wrap_top = true;
+            }
+            if (ne > H && h0 != 0 && !wrap_bot) {   // quad row H reads raw row 0
+                if ((rc = sweep_upload_rows_impl(c, frames, 0, 1, c->copy_stream))) return rc;
+                wrap_bot = true;
+            }
+            if (!have_r) {
+                if ((rc = upload(h0, h1))) return rc;
+            } else {
+                if (h0 < up_lo && (rc = upload(h0, up_lo))) return rc;
+                if (h1 > up_hi && (rc = upload(up_hi, h1))) return rc;
+            }
+            up_lo = h0;
+            up_hi = h1;
+        }
+        MVS_HIP(c, hipEventRecord(up(b), c->copy_stream));
+        return MVS_OK;
+    }
+
+    // context's stream: quad rows [a, e) that are not built yet, once their raw rows have landed
+    int build(int b, int a, int e)
+    {
+        int rc;
+        MVS_HIP(c, hipStreamWaitEvent(c->stream, up(b), 0));
+        if (e <= a) return MVS_OK;
+        if (q_hi <= q_lo) {
+            if ((rc = sweep_build_quads_impl(c, a, e))) return rc;
+            q_lo = a;
+            q_hi = e;
+            return MVS_OK;
+        }
+        if (a < q_lo) {
+            if ((rc = sweep_build_quads_impl(c, a, q_lo))) return rc;
+            q_lo = a;
+        }
+        if (e > q_hi) {
+            if ((rc = sweep_build_quads_impl(c, q_hi, e))) return rc;
+            q_hi = e;
+        }
+        return MVS_OK;
+    }
+
+    // the planner's hook: band 0's rows cross the bus while the host waits for the planner's counters
+    int run() override
+    {
+        staged = 1;
+        return stage(0, qa[0], qb[0]);
+    }
+};
+
+static int sweep_banded(mvs_ctx *ctx, BandPipeline &bp, float *depth_hw, float *cost_hw)
+{
+    const int W = ctx->W, H = ctx->H;
+    int rc;
+    if (!bp.staged && (rc = bp.run())) return rc;  // (the planner had nothing to wait for: plan cache hit)
+    for (int b = 0; b < bp.nb; b++) {
+        if (b > 0 && (rc = bp.stage(b, bp.qa[b], bp.qb[b]))) return rc;
+        if ((rc = bp.build(b, bp.qa[b], bp.qb[b]))) return rc;
+        if ((rc = mvs_sweep_run_rows(ctx, 0, ctx->V, bp.row0[b], bp.row0[b + 1] - bp.row0[b], MVS_SWEEP_FUSED_ARGMIN))) return rc;
+        MVS_HIP(ctx, hipEventRecord(bp.swept(b), ctx->stream));
+        // the band before this one comes home now: its sweep has had a band's upload of time, and the copy stream is idle until the next stage
+        const int done = b - 1;
+        if (done >= 0) {
+            const size_t off = (size_t)bp.row0[done] * W, n = (size_t)(bp.row0[done + 1] - bp.row0[done]) * W;
+            MVS_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, bp.swept(done), 0));
+            MVS_HIP(ctx, hipMemcpyAsync(depth_hw + off, (const float *)ctx->depth.ptr + off, n * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+            if (cost_hw) MVS_HIP(ctx, hipMemcpyAsync(cost_hw + off, (const float *)ctx->cost.ptr + off, n * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+        }
+    }
+    // whatever no band asked for: the context's views are complete when the call returns (mvs_sweep_run on them must work)
+    if ((rc = bp.stage(bp.nb, 0, H + 2))) return rc;
+    if ((rc = bp.build(bp.nb, 0, H + 2))) return rc;
+    {
+        const int done = bp.nb - 1;
+        const size_t off = (size_t)bp.row0[done] * W, n = (size_t)(bp.row0[done + 1] - bp.row0[done]) * W;
+        MVS_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, bp.swept(done), 0));
+        MVS_HIP(ctx, hipMemcpyAsync(depth_hw + off, (const float *)ctx->depth.ptr + off, n * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+        if (cost_hw) MVS_HIP(ctx, hipMemcpyAsync(cost_hw + off, (const float *)ctx->cost.ptr + off, n * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MVS_OK;
+}
+
+// test hook (not in mvs.h; tests/test_sweep_gpu.py): the number of row bands the last mvs_sweep of this context went through (0: unbanded)
+int mvs_test_onecall_bands(const mvs_ctx *ctx) { return ctx ? ctx->onecall_bands_last : MVS_EINVAL; }
+
 int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, int nviews, const float *side_cams,
               const uint8_t *const *side_frames, int nplanes, float z_lo, float z_hi, float *depth_hw, float *cost_hw,
               float *volume_dhw)
@@ -1163,15 +1326,18 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
     struct JoinOnError {
         mvs_ctx *c;
         bool armed = true;
+        hipStream_t copy = nullptr;  // the band pipeline's second stream
         ~JoinOnError()
         {
             if (!armed) return;
+            if (copy) (void)hipStreamSynchronize(copy);
             (void)hipStreamSynchronize(c->stream);
             c->have_views = false;
             c->plan_valid = false;
             c->quads16_valid = false;
         }
     } join{ctx};
+    ctx->onecall_bands_last = 0;
     if ((rc = sweep_set_main_impl(ctx, main_cam, main_hw, false))) return rc;
     if ((rc = sweep_set_views_impl(ctx, nviews, side_cams, side_frames, false, true))) return rc;  // tables only: the frames follow below
     if ((rc = sweep_set_planes_impl(ctx, nplanes, z_lo, z_hi, false))) return rc;
@@ -1185,6 +1351,46 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
     upload.c = ctx;
     upload.frames = side_frames;
     if (ctx->sampler == MVS_SAMPLER_FIXED && nviews > 0 && nviews <= 255 && ctx->W <= 16383 && ctx->H <= 16383) {
+        // the band pipeline (above): when nothing but depths and costs is asked for and every band's side rows can be bounded
+        BandPipeline bands;
+        // Two bands by default: every band costs one more copy per view (~9 us of submission each, page-locked or not), which eats what a
+        // third band's overlap would win (c3, 16 views, ms per call: 1 band 1.90, 2: 1.67, 3: 1.98, 4: 2.04, 8: 2.90; profiles/r05/onecall_bands.json)
+        const int want = ctx->hooks.onecall_bands > 0 ? ctx->hooks.onecall_bands : 2;
+        bands.nb = want > BandPipeline::kMaxBands ? BandPipeline::kMaxBands : want;
+        if (bands.nb > ctx->H / 64) bands.nb = ctx->H / 64;  // a band is at least 64 rows
+        if (ctx->hooks.onecall_bands <= 0 && ctx->H < 256) bands.nb = 0;  // (small frames: the overlap would not pay for the extra copies)
+        if (volume_dhw) bands.nb = 0;
+        if (bands.nb >= 2) {
+            bands.c = ctx;
+            bands.frames = side_frames;
+            const int per = div_up(div_up(ctx->H, 8), bands.nb) * 8;  // mvs_sweep_run_rows: bands start on multiples of 8 rows
+            for (int b = 0; b <= bands.nb; b++) bands.row0[b] = b * per < ctx->H ? b * per : ctx->H;
+            // two bands: the second one's sweep and download are the tail nothing overlaps, so it is the smaller one (c3: 1.64 ms at 50 %, 1.60 at 58 %, 1.65 at 72 %)
+            if (bands.nb == 2) bands.row0[1] = (int)((long long)ctx->H * (ctx->hooks.onecall_first_permille > 0 ? ctx->hooks.onecall_first_permille : 580) / 8000) * 8;
+            if (bands.row0[bands.nb - 1] >= ctx->H || !bands.plan_rows()) bands.nb = 0;
+        }
+        if (bands.nb >= 2) {
+            if (!ctx->copy_stream) MVS_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            while ((int)ctx->band_events.size() < 2 * (BandPipeline::kMaxBands + 1)) {
+                hipEvent_t e = nullptr;
+                MVS_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ctx->band_events.push_back(e);
+            }
+            join.copy = ctx->copy_stream;
+            // the staging block may still be read by what an earlier call queued on the context's stream
+            MVS_HIP(ctx, hipEventRecord(bands.swept(bands.nb), ctx->stream));
+            MVS_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, bands.swept(bands.nb), 0));
+            {
+                ProfileScope ps(ctx, MVS_K_PLAN);
+                if ((rc = sweep_fx_plan(ctx, &bands))) return rc;
+                ctx->plan_shape = 3;
+                ctx->plan_valid = true;
+            }
+            if ((rc = sweep_banded(ctx, bands, depth_hw, cost_hw))) return rc;
+            ctx->onecall_bands_last = bands.nb;
+            join.armed = false;
+            return MVS_OK;
+        }
         ProfileScope ps(ctx, MVS_K_PLAN);
         if ((rc = sweep_fx_plan(ctx, &upload))) return rc;
         ctx->plan_shape = 3;

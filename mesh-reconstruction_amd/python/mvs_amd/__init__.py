@@ -150,6 +150,9 @@ def load_library(path=None):
     if hasattr(lib, "mvs_test_rcp"):
         lib.mvs_test_rcp.restype = _i
         lib.mvs_test_rcp.argtypes = [_vp, C.c_uint, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    if hasattr(lib, "mvs_test_onecall_bands"):
+        lib.mvs_test_onecall_bands.restype = _i
+        lib.mvs_test_onecall_bands.argtypes = [_vp]
     _lib = lib
     return lib
 
@@ -510,6 +513,7 @@ class Context:
         depth = np.empty((H, W), np.float32)
         cost = np.empty((H, W), np.float32) if want_cost else None
         vol = np.empty((nplanes, H, W), np.float32) if want_volume else None
+        self.D = int(nplanes)   # the views and planes stay resident: sweep_run / sweep_fetch may follow
         self._check(self.lib.mvs_sweep(self.h, _ptr(cam, _fp), _ptr(img, _u8p), V, _ptr(cams, _fp), arr, int(nplanes),
                                        float(z_lo), float(z_hi), _ptr(depth, _fp),
                                        _ptr(cost, _fp) if want_cost else None, _ptr(vol, _fp) if want_volume else None))
@@ -846,6 +850,10 @@ class Context:
         n = C.c_int(0)
         self._check(self.lib.mvs_filter_points(self.h, _ptr(pts, _fp), pts.shape[0], float(alpha), _ptr(keep, _i32p), C.byref(n)))
         return keep[:n.value].copy()
+
+    def onecall_bands(self):
+        """test hook: the row bands the last one-call sweep() of this context was pipelined in (0: the unbanded path)"""
+        return self.lib.mvs_test_onecall_bands(self.h)
 
     def test_rcp(self, exp_bits):
         a, b = C.c_ulonglong(0), C.c_ulonglong(0)
