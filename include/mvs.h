@@ -384,7 +384,9 @@ int mvs_surface_spacing(const mvs_surface *s, float *average_spacing /* of the s
  * surface a manifold wherever it was one), each guarded so that the surface moves by at most a quarter of max_distance; facets whose
  * circumradius exceeds max_radius are counted (the grid rule of mvs_poisson_surface keeps every facet two orders of magnitude below the
  * reference's bound, so nothing is done about them).  Vertices that lose all their facets are dropped; the order of the others, and of
- * the facets, is kept.  report (nullable) says what was done and what is left.  poissonSurface (host/poisson.cpp) and
+ * the facets, is kept.  Last, facets that are still below the angle bound and lie on the BORDER of an open surface (where the samples'
+ * support cut the level set) are removed when that only moves the border: a facet with two or three border edges, or with one and an
+ * interior opposite vertex.  report (nullable) says what was done and what is left.  poissonSurface (host/poisson.cpp) and
  * mvs_amd.poisson_surface apply it with the reference's three numbers. */
 typedef struct mvs_criteria_report {
     int collapses, flips;          /* operations applied */
@@ -392,6 +394,7 @@ typedef struct mvs_criteria_report {
     int facets_above_radius;       /* facets whose circumradius exceeds max_radius */
     float min_angle_deg;           /* smallest facet angle of the result (180 for an empty mesh) */
     float max_circumradius;        /* largest facet circumradius of the result */
+    int facets_trimmed;            /* facets below min_angle_deg ON THE BORDER of an open surface that were removed (the border moved; see below) */
 } mvs_criteria_report;
 int mvs_surface_enforce_criteria(mvs_surface *s, float min_angle_deg /* [0, 60) */, float max_radius, float max_distance, mvs_criteria_report *report);
 /* The other half of what those criteria mean: they bound a facet's angles from below and its distance from the surface from above -- NOT

@@ -24,8 +24,10 @@
 //      on an open or noisy cloud the level set there is a closing sheet no sample supports plus numerical fuzz at full grid
 //      resolution (measured on the config-5 cloud of the test-suite: 16 M vertices, 97 % of them tens of spacings from any sample).
 //      mvs_poisson_surface_ex(support 0) returns the closed surface;
-//   4. the level set is meshed by surface nets (one vertex per grid cell the surface passes through, at the mean of its edge
-//      crossings; one quad = two triangles per grid edge that changes sign), vertices and faces numbered in grid order by
+//   4. the level set is meshed by surface nets: one vertex per PATCH the level set cuts out of a grid cell, at the mean of the patch's
+//      edge crossings (cell_patch_table: a cell that two sheets of the surface pass through gets two vertices -- with one vertex per cell
+//      the sheets were welded there, edges with four facets that no facet criterion can repair; round 5); one quad = two triangles per
+//      grid edge that changes sign, over the patches of its four cells that contain it; vertices and faces numbered in grid order by
 //      exclusive scans (rocPRIM), faces oriented along +grad chi = the samples' normals (outward, like cgal_poisson.cpp:128-132).
 // Output: vertices N x 4 homogeneous (w = 1), faces F x 3 int32, as Mesh (recon.hpp:19-24).  Not CGAL's triangulation: a different
 // mesh of the same level set family (no Delaunay refinement; the reference's facet criteria -- angle, radius, distance, cgal_poisson.cpp:50-52 --
@@ -277,20 +279,76 @@ __global__ void support_dilate_kernel(Grid g, const unsigned char *__restrict__ 
     out[q] = v;
 }
 
-__global__ void cell_flags_kernel(Grid g, const float *__restrict__ chi, float iso, const unsigned char *__restrict__ support, int *__restrict__ flag)
+// The patches of a cell.  Entry m (bit c: corner c inside, corner bits 0 / 1 / 2 = x / y / z) packs, for each of the 12 cell edges in the
+// order of `ea` / `eb` below, the number of the patch that contains its crossing (2 bits, edges that do not cross: 0) and in bits 24-26
+// the number of patches (0..4).  Two crossings belong to one patch when a face of the cell joins them: a face with two crossings joins
+// those two, a face with four (its two inside corners on a diagonal) joins the pair around EACH INSIDE corner -- the same decision seen
+// from either cell of the face, so the patches of neighbouring cells meet edge for edge.  Patches are numbered by their lowest edge.
+// (oracle/meshing_oracle.py: cell_components restates it.)
+static void cell_patch_table(uint32_t table[256])
+{
+    static const int ea[12] = {0, 2, 4, 6, 0, 1, 4, 5, 0, 1, 2, 3}, eb[12] = {1, 3, 5, 7, 2, 3, 6, 7, 4, 5, 6, 7};
+    for (int m = 0; m < 256; m++) {
+        bool cross[12];
+        int parent[12];
+        for (int e = 0; e < 12; e++) {
+            cross[e] = ((m >> ea[e]) & 1) != ((m >> eb[e]) & 1);
+            parent[e] = e;
+        }
+        auto find = [&](int x) {
+            while (parent[x] != x) x = parent[x];
+            return x;
+        };
+        auto join = [&](int x, int y) {
+            x = find(x), y = find(y);
+            if (x != y) parent[std::max(x, y)] = std::min(x, y);
+        };
+        for (int axis = 0; axis < 3; axis++)
+            for (int side = 0; side < 2; side++) {
+                int es[4], ne = 0;
+                for (int e = 0; e < 12; e++)
+                    if (cross[e] && ((ea[e] >> axis) & 1) == side && ((eb[e] >> axis) & 1) == side) es[ne++] = e;
+                if (ne == 2) join(es[0], es[1]);
+                if (ne == 4)
+                    for (int c = 0; c < 8; c++) {
+                        if (((c >> axis) & 1) != side || !((m >> c) & 1)) continue;
+                        int mine[2], nm = 0;
+                        for (int i = 0; i < 4; i++)
+                            if (ea[es[i]] == c || eb[es[i]] == c) mine[nm++] = es[i];
+                        join(mine[0], mine[1]);
+                    }
+            }
+        int roots[12], nr = 0;
+        uint32_t word = 0;
+        for (int e = 0; e < 12; e++) {
+            if (!cross[e]) continue;
+            const int r = find(e);  // (the root is the patch's lowest edge: first seen in this order)
+            int id = 0;
+            while (id < nr && roots[id] != r) id++;
+            if (id == nr) roots[nr++] = r;
+            word |= (uint32_t)id << (2 * e);
+        }
+        table[m] = word | ((uint32_t)nr << 24);
+    }
+}
+
+// flag = the cell's number of vertices (patches; 0: not a mixed cell, or outside the samples' support); cases = its corner pattern
+__global__ void cell_flags_kernel(Grid g, const float *__restrict__ chi, float iso, const unsigned char *__restrict__ support, const uint32_t *__restrict__ patches,
+                                  int *__restrict__ flag, unsigned char *__restrict__ cases)
 {
     const int C = g.G - 1;
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (size_t)C * C * C) return;
     const int i = (int)(q % C), j = (int)((q / C) % C), k = (int)(q / ((size_t)C * C));
-    int inside = 0;
+    int m = 0;
 #pragma unroll
-    for (int c = 0; c < 8; c++) inside += chi[node(g, i + (c & 1), j + ((c >> 1) & 1), k + (c >> 2))] < iso ? 1 : 0;
-    flag[q] = (inside != 0 && inside != 8 && (!support || support[node(g, i, j, k)])) ? 1 : 0;
+    for (int c = 0; c < 8; c++) m |= (chi[node(g, i + (c & 1), j + ((c >> 1) & 1), k + (c >> 2))] < iso ? 1 : 0) << c;
+    cases[q] = (unsigned char)m;
+    flag[q] = (m != 0 && m != 255 && (!support || support[node(g, i, j, k)])) ? (int)(patches[m] >> 24) : 0;
 }
 
 __global__ void cell_vertices_kernel(Grid g, const float *__restrict__ chi, float iso, const int *__restrict__ flag, const int *__restrict__ index,
-                                     float *__restrict__ vertices)
+                                     const uint32_t *__restrict__ patches, const unsigned char *__restrict__ cases, float *__restrict__ vertices)
 {
     const int C = g.G - 1;
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -301,26 +359,30 @@ __global__ void cell_vertices_kernel(Grid g, const float *__restrict__ chi, floa
     for (int c = 0; c < 8; c++) v[c] = chi[node(g, i + (c & 1), j + ((c >> 1) & 1), k + (c >> 2))] - iso;
     // the 12 edges of the cell as pairs of corner numbers (bit 0: x, bit 1: y, bit 2: z), in a fixed order
     const int ea[12] = {0, 2, 4, 6, 0, 1, 4, 5, 0, 1, 2, 3}, eb[12] = {1, 3, 5, 7, 2, 3, 6, 7, 4, 5, 6, 7};
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    int m = 0;
+    const uint32_t word = patches[cases[q]];
+    const int np = flag[q];
+    for (int patch = 0; patch < np; patch++) {
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        int m = 0;
 #pragma unroll
-    for (int e = 0; e < 12; e++) {
-        const float a = v[ea[e]], b = v[eb[e]];
-        if ((a < 0.0f) != (b < 0.0f)) {
-            const float t = a / (a - b);
-            const int ca = ea[e], cb = eb[e];
-            sx += (float)(ca & 1) + t * (float)((cb & 1) - (ca & 1));
-            sy += (float)((ca >> 1) & 1) + t * (float)(((cb >> 1) & 1) - ((ca >> 1) & 1));
-            sz += (float)(ca >> 2) + t * (float)((cb >> 2) - (ca >> 2));
-            m++;
+        for (int e = 0; e < 12; e++) {
+            const float a = v[ea[e]], b = v[eb[e]];
+            if ((a < 0.0f) != (b < 0.0f) && (int)((word >> (2 * e)) & 3u) == patch) {
+                const float t = a / (a - b);
+                const int ca = ea[e], cb = eb[e];
+                sx += (float)(ca & 1) + t * (float)((cb & 1) - (ca & 1));
+                sy += (float)((ca >> 1) & 1) + t * (float)(((cb >> 1) & 1) - ((ca >> 1) & 1));
+                sz += (float)(ca >> 2) + t * (float)((cb >> 2) - (ca >> 2));
+                m++;
+            }
         }
+        const float inv = 1.0f / (float)m;
+        float *out = vertices + 4 * ((size_t)index[q] + patch);
+        out[0] = g.ox + g.h * ((float)i + sx * inv);
+        out[1] = g.oy + g.h * ((float)j + sy * inv);
+        out[2] = g.oz + g.h * ((float)k + sz * inv);
+        out[3] = 1.0f;
     }
-    const float inv = 1.0f / (float)m;
-    float *out = vertices + 4 * (size_t)index[q];
-    out[0] = g.ox + g.h * ((float)i + sx * inv);
-    out[1] = g.oy + g.h * ((float)j + sy * inv);
-    out[2] = g.oz + g.h * ((float)k + sz * inv);
-    out[3] = 1.0f;
 }
 
 // grid edges: 3 per node (towards +x, +y, +z); an edge makes a quad when its ends lie on different sides and all four cells around
@@ -361,7 +423,7 @@ __global__ void edge_flags_kernel(Grid g, const float *__restrict__ chi, float i
 }
 
 __global__ void edge_faces_kernel(Grid g, const float *__restrict__ chi, float iso, const unsigned char *__restrict__ support, const int *__restrict__ flag, const int *__restrict__ index,
-                                  const int *__restrict__ cell_index, int *__restrict__ faces)
+                                  const int *__restrict__ cell_index, const uint32_t *__restrict__ patches, const unsigned char *__restrict__ cases, int *__restrict__ faces)
 {
     const size_t n = (size_t)g.G * g.G * g.G;
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -378,10 +440,12 @@ __global__ void edge_faces_kernel(Grid g, const float *__restrict__ chi, float i
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         int ci = i, cj = j, ck = k;
-        if (axis == 0) cj += du[c], ck += dw[c];
-        else if (axis == 1) ck += du[c], ci += dw[c];
-        else ci += du[c], cj += dw[c];
-        v[c] = cell_index[cell_id(C, ci, cj, ck)];
+        int local;  // the grid edge inside that cell: x edges 0..3 = ly + 2 lz, y edges 4..7 = 4 + lx + 2 lz, z edges 8..11 = 8 + lx + 2 ly
+        if (axis == 0) cj += du[c], ck += dw[c], local = -du[c] - 2 * dw[c];
+        else if (axis == 1) ck += du[c], ci += dw[c], local = 4 - dw[c] - 2 * du[c];
+        else ci += du[c], cj += dw[c], local = 8 - du[c] - 2 * dw[c];
+        const size_t cell = cell_id(C, ci, cj, ck);
+        v[c] = cell_index[cell] + (int)((patches[cases[cell]] >> (2 * local)) & 3u);  // the patch of that cell the edge's crossing belongs to
     }
     if (st == 2) {  // outside -> inside along the axis: the normal points down the axis
         const int t = v[1];
@@ -479,6 +543,14 @@ bool ensure_plans(int G, const char **why)
 }
 
 }  // namespace
+
+// test hook (not in mvs.h; tests/test_meshing_cpu.py): the patch table of the surface nets, as the kernels receive it (host code, no GPU)
+extern "C" int mvs_test_cell_patch_table(uint32_t out[256])
+{
+    if (!out) return MVS_EINVAL;
+    cell_patch_table(out);
+    return MVS_OK;
+}
 
 extern "C" int mvs_poisson_warmup(int grid_log2)
 {
@@ -648,7 +720,7 @@ extern "C" int mvs_poisson_surface_ex(const float *points, const float *normals,
     res->normal_scale_log2 = nscale_log2;
     res->spacing = (float)spacing;
     res->ratio_kept = ratio_kept;
-    DevBuf d_fix, d_real, d_spec, d_flag, d_index, d_cell_index, d_tmp, d_samples, d_vertices, d_faces, d_mask;
+    DevBuf d_fix, d_real, d_spec, d_flag, d_index, d_cell_index, d_tmp, d_samples, d_vertices, d_faces, d_mask, d_patches, d_cases;
     size_t tmp_bytes = 0;
     int rc = MVS_OK;
     const char *msg = "";
@@ -700,12 +772,18 @@ extern "C" int mvs_poisson_surface_ex(const float *points, const float *normals,
         }
         // vertices
         int *flag = d_flag.as<int>(), *cell_index = d_cell_index.as<int>();
-        cell_flags_kernel<<<(unsigned)((C3 + 255) / 256), 256, 0, st>>>(g, chi, iso, support, flag);
+        uint32_t patch_table[256];
+        cell_patch_table(patch_table);
+        PS_TRY(d_patches.alloc(sizeof(patch_table)) && d_cases.alloc(C3), MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
+        PS_TRY(hipMemcpyAsync(d_patches.p, patch_table, sizeof(patch_table), hipMemcpyHostToDevice, st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: upload failed");
+        const uint32_t *patches = d_patches.as<uint32_t>();
+        const unsigned char *cases = d_cases.as<unsigned char>();
+        cell_flags_kernel<<<(unsigned)((C3 + 255) / 256), 256, 0, st>>>(g, chi, iso, support, patches, flag, d_cases.as<unsigned char>());
         PS_TRY(hipMemsetAsync(flag + C3, 0, 4, st) == hipSuccess && scan(flag, cell_index, C3 + 1, st, d_tmp, tmp_bytes), MVS_EHIP, "mvs_poisson_surface: scan failed");
         int nv = 0;
         PS_TRY(hipMemcpyAsync(&nv, cell_index + C3, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: count failed");
         PS_TRY(d_vertices.alloc((size_t)nv * 16), MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
-        if (nv > 0) cell_vertices_kernel<<<(unsigned)((C3 + 255) / 256), 256, 0, st>>>(g, chi, iso, flag, cell_index, d_vertices.as<float>());
+        if (nv > 0) cell_vertices_kernel<<<(unsigned)((C3 + 255) / 256), 256, 0, st>>>(g, chi, iso, flag, cell_index, patches, cases, d_vertices.as<float>());
         res->vertices.resize((size_t)nv * 4);
         if (nv > 0) PS_TRY(hipMemcpyAsync(res->vertices.data(), d_vertices.p, (size_t)nv * 16, hipMemcpyDeviceToHost, st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: download failed");
         // faces (the cell flags are overwritten by the edge flags: the vertex kernel above is ordered before on the stream)
@@ -722,7 +800,7 @@ extern "C" int mvs_poisson_surface_ex(const float *points, const float *normals,
                MVS_EHIP, "mvs_poisson_surface: count failed");
         const int nq = last_off + last_flag;
         PS_TRY(d_faces.alloc((size_t)nq * 24), MVS_ENOMEM, "mvs_poisson_surface: device allocation failed");
-        if (nq > 0) edge_faces_kernel<<<(unsigned)((3 * N3 + 255) / 256), 256, 0, st>>>(g, chi, iso, support, flag, index, cell_index, d_faces.as<int>());
+        if (nq > 0) edge_faces_kernel<<<(unsigned)((3 * N3 + 255) / 256), 256, 0, st>>>(g, chi, iso, support, flag, index, cell_index, patches, cases, d_faces.as<int>());
         res->faces.resize((size_t)nq * 6);
         if (nq > 0) PS_TRY(hipMemcpyAsync(res->faces.data(), d_faces.p, (size_t)nq * 24, hipMemcpyDeviceToHost, st) == hipSuccess, MVS_EHIP, "mvs_poisson_surface: download failed");
         if (keep_fields) {

@@ -190,7 +190,7 @@ def alpha_shape_faces(points, forced_alpha=0.0):
 class CriteriaReport(C.Structure):
     """mvs_criteria_report (include/mvs.h)"""
     _fields_ = [("collapses", C.c_int), ("flips", C.c_int), ("facets_below_angle", C.c_int), ("facets_above_radius", C.c_int),
-                ("min_angle_deg", C.c_float), ("max_circumradius", C.c_float)]
+                ("min_angle_deg", C.c_float), ("max_circumradius", C.c_float), ("facets_trimmed", C.c_int)]
 
 
 # cgal_poisson.cpp:50-52: sm_angle (degrees), sm_radius and sm_distance (in average spacings)

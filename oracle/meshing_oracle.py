@@ -228,8 +228,55 @@ def poisson_support(splat, nodes):
     return ndi.maximum_filter(seed, size=2 * int(nodes) + 1, mode="constant", cval=0).astype(bool)
 
 
+CELL_EDGE_A = [0, 2, 4, 6, 0, 1, 4, 5, 0, 1, 2, 3]   # the 12 edges of a cell as pairs of corner numbers (bit 0: x, bit 1: y, bit 2: z)
+CELL_EDGE_B = [1, 3, 5, 7, 2, 3, 6, 7, 4, 5, 6, 7]
+
+
+def cell_components():
+    """csrc/poisson.hip: cell_patch_table.  For each of the 256 inside / outside patterns of a cell's corners (bit c: corner c inside) the
+    patches the level set cuts out of the cell: two crossing edges belong to one patch when a face of the cell joins them -- a face with two
+    crossing edges joins those two; a face with four (two inside corners on a diagonal) joins the pair AROUND EACH INSIDE CORNER, the same
+    decision from either side of the face.  Returns (comp[256][12]: patch number of edge e or -1, numbered by lowest edge; count[256])."""
+    comp = np.full((256, 12), -1, np.int8)
+    count = np.zeros(256, np.int32)
+    for m in range(256):
+        ins = [(m >> c) & 1 for c in range(8)]
+        cross = [ins[a] != ins[b] for a, b in zip(CELL_EDGE_A, CELL_EDGE_B)]
+        parent = list(range(12))
+
+        def find(x):
+            while parent[x] != x:
+                x = parent[x]
+            return x
+
+        def join(x, y):
+            x, y = find(x), find(y)
+            if x != y:
+                parent[max(x, y)] = min(x, y)
+
+        for axis in range(3):
+            for side in range(2):
+                on = [c for c in range(8) if ((c >> axis) & 1) == side]
+                es = [e for e in range(12) if CELL_EDGE_A[e] in on and CELL_EDGE_B[e] in on and cross[e]]
+                if len(es) == 2:
+                    join(es[0], es[1])
+                elif len(es) == 4:
+                    for c in on:
+                        if ins[c]:
+                            mine = [e for e in es if CELL_EDGE_A[e] == c or CELL_EDGE_B[e] == c]
+                            join(mine[0], mine[1])
+        roots = sorted({find(e) for e in range(12) if cross[e]})
+        for e in range(12):
+            if cross[e]:
+                comp[m, e] = roots.index(find(e))
+        count[m] = len(roots)
+    return comp, count
+
+
 def surface_nets(chi, iso, origin, h, support=None):
-    """csrc/poisson.hip's meshing rules on a given field: (vertices V x 4 float32, faces F x 3 int32), numbered in its order.
+    """csrc/poisson.hip's meshing rules on a given field: (vertices V x 4 float32, faces F x 3 int32), numbered in its order.  One vertex per
+    PATCH of a cell (cell_components: a cell that two sheets of the surface pass through gets two vertices, so the sheets stay apart), at the
+    mean of the patch's edge crossings; one quad per crossing grid edge, over the patches of its four cells that contain it.
     support: poisson_support's node mask (a cell is meshed when its low corner node is inside), None: everywhere"""
     chi = np.asarray(chi, np.float32)
     iso = np.float32(iso)
@@ -237,34 +284,43 @@ def surface_nets(chi, iso, origin, h, support=None):
     C = G - 1
     inside = chi < iso                                              # [z][y][x]
     corners = [(c & 1, (c >> 1) & 1, c >> 2) for c in range(8)]
-    cnt = np.zeros((C, C, C), np.int32)
-    for (dx, dy, dz) in corners:
-        cnt += inside[dz:dz + C, dy:dy + C, dx:dx + C]
-    mixed = (cnt != 0) & (cnt != 8)
+    case = np.zeros((C, C, C), np.int32)
+    for c, (dx, dy, dz) in enumerate(corners):
+        case |= inside[dz:dz + C, dy:dy + C, dx:dx + C].astype(np.int32) << c
+    comp, count = cell_components()
+    mixed = (case != 0) & (case != 255)
     if support is not None:
         mixed &= np.asarray(support, bool)[:C, :C, :C]
-    index = np.full((C, C, C), -1, np.int64)
-    index[mixed] = np.arange(int(mixed.sum()))                       # C order = k, j, i with i fastest: the kernel's cell order
+    per_cell = np.where(mixed, count[case], 0)
+    first = np.cumsum(per_cell.ravel()) - per_cell.ravel()           # C order = k, j, i with i fastest: the kernel's cell order
+    first = first.reshape(C, C, C)
+    nv = int(per_cell.sum())
     kk, jj, ii = np.nonzero(mixed)
+    cc = case[kk, jj, ii]
     v = [chi[kk + dz, jj + dy, ii + dx] - iso for (dx, dy, dz) in corners]
-    ea = [0, 2, 4, 6, 0, 1, 4, 5, 0, 1, 2, 3]
-    eb = [1, 3, 5, 7, 2, 3, 6, 7, 4, 5, 6, 7]
-    s = np.zeros((3, len(kk)), np.float32)
-    m = np.zeros(len(kk), np.int32)
-    for a, b in zip(ea, eb):
-        va, vb = v[a], v[b]
-        cross = (va < 0) != (vb < 0)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            t = (va / (va - vb)).astype(np.float32)
-        for axis in range(3):
-            ca, cb = np.float32(corners[a][axis]), np.float32(corners[b][axis])
-            with np.errstate(invalid="ignore"):                      # (t is inf or NaN on edges that do not cross: not selected)
-                s[axis] = np.where(cross, (s[axis] + (ca + t * (cb - ca)).astype(np.float32)).astype(np.float32), s[axis])
-        m += cross
-    inv = (np.float32(1.0) / m.astype(np.float32)).astype(np.float32)
-    verts = np.ones((len(kk), 4), np.float32)
-    for axis, base in enumerate((ii, jj, kk)):
-        verts[:, axis] = origin[axis] + np.float32(h) * (base.astype(np.float32) + (s[axis] * inv).astype(np.float32)).astype(np.float32)
+    verts = np.ones((nv, 4), np.float32)
+    for patch in range(4):
+        sel = count[cc] > patch
+        if not sel.any():
+            break
+        s = np.zeros((3, len(kk)), np.float32)
+        m = np.zeros(len(kk), np.int32)
+        for e, (a, b) in enumerate(zip(CELL_EDGE_A, CELL_EDGE_B)):
+            va, vb = v[a], v[b]
+            cross = comp[cc, e] == patch
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = (va / (va - vb)).astype(np.float32)
+            for axis in range(3):
+                ca, cb = np.float32(corners[a][axis]), np.float32(corners[b][axis])
+                with np.errstate(invalid="ignore"):                  # (t is inf or NaN on edges that do not cross: not selected)
+                    s[axis] = np.where(cross, (s[axis] + (ca + t * (cb - ca)).astype(np.float32)).astype(np.float32), s[axis])
+            m += cross
+        with np.errstate(divide="ignore"):
+            inv = (np.float32(1.0) / m.astype(np.float32)).astype(np.float32)
+        rows = first[kk, jj, ii][sel] + patch
+        for axis, base in enumerate((ii, jj, kk)):
+            with np.errstate(invalid="ignore"):                      # (cells without this patch: 0 x inf, not selected)
+                verts[rows, axis] = (origin[axis] + np.float32(h) * (base.astype(np.float32) + (s[axis] * inv).astype(np.float32)).astype(np.float32))[sel]
     faces = []
     du, dw = [-1, 0, 0, -1], [-1, -1, 0, 0]
     for axis in range(3):
@@ -280,18 +336,24 @@ def surface_nets(chi, iso, origin, h, support=None):
         ek, ej, ei = np.nonzero(valid)
         st = state[ek, ej, ei]
         quad = np.zeros((len(ek), 4), np.int64)
+        have = np.ones(len(ek), bool)
         for c in range(4):
             ci, cj, ck = ei.copy(), ej.copy(), ek.copy()
             if axis == 0:
                 cj += du[c]; ck += dw[c]
+                local = -du[c] + 2 * -dw[c]                          # the grid edge inside that cell: x edges 0..3 = ly + 2 lz
             elif axis == 1:
                 ck += du[c]; ci += dw[c]
+                local = 4 + -dw[c] + 2 * -du[c]                      # y edges 4..7 = 4 + lx + 2 lz
             else:
                 ci += du[c]; cj += dw[c]
-            quad[:, c] = index[ck, cj, ci]
+                local = 8 + -du[c] + 2 * -dw[c]                      # z edges 8..11 = 8 + lx + 2 ly
+            quad[:, c] = first[ck, cj, ci] + comp[case[ck, cj, ci], local]
+            have &= mixed[ck, cj, ci]
         if support is not None:                                      # all four cells around the edge have a vertex
-            have = (quad >= 0).all(1)
             quad, st = quad[have], st[have]
+        else:
+            assert have.all()
         flip = st == 2
         q1 = np.where(flip, quad[:, 3], quad[:, 1])
         q3 = np.where(flip, quad[:, 1], quad[:, 3])
@@ -664,6 +726,34 @@ def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_dista
     for i in left[:4096]:
         if alive_bad(i):
             rescue(i, [])
+    # border trim (csrc/surface_criteria.cpp): facets still below the bound on the outline of an open surface go when that only moves the outline
+    trimmed = 0
+    if not _simplify:
+        bad = [i for i in range(nf) if alive_bad(i)]
+
+        def border_edge(a, b):
+            return len(edge_facets(a, b)) == 1
+
+        def border_vertex(v):
+            return any(x != v and border_edge(v, x) for i in inc[v] for x in f[i])
+
+        changed = True
+        while changed:
+            changed = False
+            for i in bad:
+                if f[i][0] < 0:
+                    continue
+                a, b, c = f[i]
+                on = (len(edge_facets(a, b)), len(edge_facets(b, c)), len(edge_facets(c, a)))
+                eb = tuple(n == 1 for n in on)
+                nb = sum(eb)
+                if nb == 0 or max(on) > 2 or (nb == 1 and border_vertex(c if eb[0] else (a if eb[1] else b))):
+                    continue
+                for w in (a, b, c):
+                    inc[w].remove(i)
+                f[i] = [-1, -1, -1]
+                trimmed += 1
+                changed = True
     used = np.zeros(nv, bool)
     alive = [t for t in f if t[0] >= 0]
     for t in alive:
@@ -671,6 +761,8 @@ def enforce_facet_criteria(vertices, faces, min_angle_deg, max_radius, max_dista
     renum = np.cumsum(used) - 1
     fout = np.array([[renum[w] for w in t] for t in alive], np.int32).reshape(-1, 3)
     report = dict(count)
+    if not _simplify:
+        report["facets_trimmed"] = trimmed
     min_q, max_r2, below, above = 0.0, 0.0, 0, 0
     for t in alive:
         a, b, c = p[t[0]], p[t[1]], p[t[2]]

@@ -65,6 +65,14 @@ def edge_use(faces):
     return c
 
 
+def facets_per_edge(faces):
+    """the largest number of facets that share an (undirected) edge: 2 on a manifold surface, 1 on its border"""
+    f = np.asarray(faces, np.int64)
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    e.sort(1)
+    return int(np.unique(e[:, 0] << 32 | e[:, 1], return_counts=True)[1].max())
+
+
 def poisson(hip, pts, nrm, grid_log2=0, smooth=1.0, keep=True, support=None):
     """support: None = mvs_poisson_surface (the default support radius), a number = mvs_poisson_surface_ex with that many spacings (0: no trimming)"""
     pts = np.ascontiguousarray(pts, np.float32)

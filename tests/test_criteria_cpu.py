@@ -301,3 +301,42 @@ def test_simplification_argument_errors():
     assert lib.mvs_surface_simplify(s, 20.0, -1.0, None) == -1
     assert lib.mvs_surface_simplify(s, 20.0, 0.0, None) == 0          # no budget: nothing may move
     lib.mvs_surface_free(s)
+
+
+def test_border_facets_that_cannot_be_repaired_are_trimmed():
+    """An OPEN surface (mvs_poisson_surface cuts the level set where the samples' support ends): a facet below the angle bound on the outline
+    that no collapse or flip repairs is removed when that only moves the outline -- two or three border edges, or one and an interior opposite
+    vertex; the surface stays a manifold with ONE outline, the report says how many went; a sliver on an edge with four facets stays
+    (test_what_cannot_be_helped_is_left_alone_and_reported).  C++ == oracle, index for index."""
+    n = 8
+    rng = np.random.default_rng(3)
+    P = [[i + 0.15 * rng.uniform(-1, 1), j + 0.15 * rng.uniform(-1, 1), 0.05 * np.sin(i) * np.cos(j), 1.0] for j in range(n) for i in range(n)]
+    F = []
+    for j in range(n - 1):
+        for i in range(n - 1):
+            a = j * n + i
+            F += [[a, a + 1, a + n + 1], [a, a + n + 1, a + n]]
+    for i, t, out in ((1, 0.03, 0.01), (4, 0.97, 0.02), (5, 0.5, 0.004)):      # slivers hung on the bottom border, next to a corner of their edge / flat on it
+        pa, pb = np.array(P[i][:3]), np.array(P[i + 1][:3])
+        e = pa + t * (pb - pa) + np.array([0.0, -out, 0.0])
+        P.append([e[0], e[1], e[2], 1.0])
+        F.append([i + 1, i, len(P) - 1])
+    v, f = np.array(P, np.float32), np.array(F, np.int32)
+    assert (facet_angles(v, f).min(1) < 20.0).sum() == 3
+    v2, f2, rep = mvs_amd.enforce_facet_criteria(v, f, 1.0)
+    ov, of, orep = mo.enforce_facet_criteria(v, f, 20.0, 300.0, 0.375)
+    assert np.array_equal(ov, v2) and np.array_equal(of, f2)
+    assert {k: orep[k] for k in ("collapses", "flips", "facets_trimmed", "facets_below_angle")} == {k: rep[k] for k in ("collapses", "flips", "facets_trimmed", "facets_below_angle")}
+    assert rep["facets_trimmed"] >= 1 and rep["facets_below_angle"] == 0 and facet_angles(v2, f2).min() >= 20.0
+    assert len(f2) == len(f) - rep["facets_trimmed"] - 2 * rep["collapses"]
+    use = mc.edge_use(f2)
+    border = [(a, b) for (a, b), k in use.items() if (b, a) not in use]
+    assert mc.facets_per_edge(f2) == 2 and max(use.values()) == 1
+    starts = np.bincount([a for a, _ in border], minlength=len(v2))
+    ends = np.bincount([b for _, b in border], minlength=len(v2))
+    assert starts.max() == 1 and np.array_equal(starts, ends)                   # the outline passes through each of its vertices once
+    nxt = dict(border)
+    at, steps = border[0][0], 0
+    while steps == 0 or at != border[0][0]:
+        at, steps = nxt[at], steps + 1
+    assert steps == len(border)                                                  # ... and is one loop

@@ -173,3 +173,41 @@ def test_golden_vectors_alpha_and_poisson_oracle(lib):
     np.testing.assert_allclose(chi, g["poisson_chi"], rtol=0, atol=2e-6 * float(np.ptp(g["poisson_chi"])))
     v, f = mo.surface_nets(g["poisson_chi"], g["poisson_level"], origin, h)
     assert np.array_equal(f, g["poisson_faces"]) and np.array_equal(v, g["poisson_vertices"])
+
+
+def test_surface_nets_patch_table_and_what_it_buys():
+    """csrc/poisson.hip: cell_patch_table (host code, the kernels' table) == oracle/meshing_oracle.py: cell_components; every patch is a closed
+    loop of at least 3 crossings; complementary patterns cross the same edges.  And what one vertex per PATCH instead of per cell buys: a
+    plate thinner than a cell, two sheets through the same cells, comes out as two sheets -- no edge with more than two facets (one vertex
+    per cell welds them: the oracle's previous rule is restated inline for the comparison)."""
+    import ctypes
+    import mvs_amd
+    hip = mvs_amd.load_library()
+    table = (ctypes.c_uint32 * 256)()
+    assert hip.mvs_test_cell_patch_table(table) == 0 and hip.mvs_test_cell_patch_table(None) != 0
+    comp, count = mo.cell_components()
+    assert np.bincount(count).tolist() == [2, 162, 82, 8, 2]
+    for m in range(256):
+        word = table[m]
+        assert (word >> 24) == count[m]
+        cross = comp[m] >= 0
+        assert np.array_equal(cross, comp[255 - m] >= 0)
+        for e in range(12):
+            assert ((word >> (2 * e)) & 3) == (comp[m, e] if cross[e] else 0)
+        for c in range(count[m]):
+            assert (comp[m] == c).sum() >= 3
+    G = 32
+    z, y, x = np.meshgrid(np.arange(G), np.arange(G), np.arange(G), indexing="ij")
+    chi = (np.abs(z - (6.3 + 0.37 * x + 0.23 * y)) - 0.32).astype(np.float32)
+    v, f = mo.surface_nets(chi, 0.0, np.zeros(3, np.float32), 1.0)
+    assert mc.facets_per_edge(f) == 2 and max(mc.edge_use(f).values()) == 1 and len(f) == 4502
+    # one vertex per cell on the same field: the same facets over fewer vertices, and an edge that four of them share
+    inside = chi < 0
+    C = G - 1
+    case = sum(inside[dz:dz + C, dy:dy + C, dx:dx + C].astype(np.int32) << c for c, (dx, dy, dz) in enumerate([(c & 1, (c >> 1) & 1, c >> 2) for c in range(8)]))
+    mixed = (case != 0) & (case != 255)
+    first = (np.cumsum(np.where(mixed, count[case], 0).ravel()) - np.where(mixed, count[case], 0).ravel())
+    owner = np.repeat(np.arange(mixed.size), np.where(mixed, count[case], 0).ravel())      # vertex -> cell
+    assert len(owner) == len(v) and len(np.unique(owner)) == int(mixed.sum()) < len(v)
+    welded = owner[f]
+    assert mc.facets_per_edge(welded) == 4

@@ -328,6 +328,10 @@ def test_config5_outer_iteration_closes_points_filter_poisson_mesh_render():
         # triangulatePixels scales the normals by its pdf (util.cpp:322-327): lengths far below the splat's 2^-16 quantum and two decades apart
         length = np.linalg.norm(nrm, axis=1)
         assert 0.0 < np.median(length) < 1e-3 and np.percentile(length, 99) > 10.0 * np.percentile(length, 1)
+        # the surface-nets mesh as it leaves the GPU: one vertex per patch of a cell, so no edge has more than two facets even on this cloud
+        # (round 4, one vertex per cell: 67 such edges, and 203 facets below 20 degrees after the criteria pass that nothing could repair)
+        raw_v, raw_f = mvs_amd.poisson_surface(pts, nrm, criteria=None)
+        assert mc.facets_per_edge(raw_f) == 2
         rep = {}
         v, f = mvs_amd.poisson_surface(pts, nrm, report=rep)
         assert len(v) > 100 and len(f) > 100 and np.isfinite(v).all() and f.min() >= 0 and f.max() < len(v)
@@ -342,7 +346,7 @@ def test_config5_outer_iteration_closes_points_filter_poisson_mesh_render():
         order = np.argsort(dist)
         median = dist[order][np.searchsorted(np.cumsum(area[order]), 0.5 * area.sum())]
         assert len(v) < 10 * len(pts) and median < 1.0 and area[dist < 3.0].sum() > 0.8 * area.sum() and dist.max() < 2.0 * np.sqrt(3.0) * (rep["support_nodes"] + 2)
-        assert rep["facets_below_angle"] < 0.005 * rep["simplify"]["facets_before"]    # (counted by the criteria pass, before the simplification)
+        assert rep["facets_below_angle"] < 0.0005 * rep["simplify"]["facets_before"]   # (counted by the criteria pass, before the simplification; measured: 56 of 325 k)
         assert rep["simplify"]["facets_after"] == len(f) and len(f) * 5 < rep["simplify"]["facets_before"]
         ctx.load_mesh(v, f)
         d = ctx.depth(seq.cams[seq.mains[12]])
