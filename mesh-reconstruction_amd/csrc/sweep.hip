@@ -1358,7 +1358,8 @@ int mvs_sweep(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_hw, in
         const int want = ctx->hooks.onecall_bands > 0 ? ctx->hooks.onecall_bands : 2;
         bands.nb = want > BandPipeline::kMaxBands ? BandPipeline::kMaxBands : want;
         if (bands.nb > ctx->H / 64) bands.nb = ctx->H / 64;  // a band is at least 64 rows
-        if (ctx->hooks.onecall_bands <= 0 && ctx->H < 256) bands.nb = 0;  // (small frames: the overlap would not pay for the extra copies)
+        // (small view sets: the overlap would not pay for the extra copies -- one per view and band at ~9 us each; 16 MB of side frames = 0.4 ms of upload)
+        if (ctx->hooks.onecall_bands <= 0 && (ctx->H < 256 || (size_t)nviews * (size_t)ctx->W * (size_t)ctx->H < ((size_t)16 << 20))) bands.nb = 0;
         if (volume_dhw) bands.nb = 0;
         if (bands.nb >= 2) {
             bands.c = ctx;

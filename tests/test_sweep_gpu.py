@@ -663,25 +663,26 @@ def _roll_cam(W, H, center, roll, yaw=0.0, pitch=0.0):
 
 
 BAND_CASES = {
-    # name: (W, H, side cameras as a function of the ring's, bands expected)
-    "ring": (640, 512, None, 2),
-    "ragged height": (648, 500, None, 2),
-    "small": (320, 136, None, 0),
-    "general": (640, 512, lambda W, H, c: [_rot_cam(W, H, [0.15 * np.cos(v), 0.15 * np.sin(v), 0.02 * v], 0.02 * (v - 2), -0.015 * v) for v in range(len(c))], 2),
-    "upside down": (640, 512, lambda W, H, c: [_roll_cam(W, H, [0.1, 0.05 * v, 0.0], np.pi + 0.1 * v) for v in range(len(c))], 2),
+    # name: (W, H, side cameras as a function of the ring's, can the pipeline serve them?)
+    "ring": (640, 512, None, True),
+    "ragged height": (648, 500, None, True),
+    "small": (320, 136, None, True),
+    "general": (640, 512, lambda W, H, c: [_rot_cam(W, H, [0.15 * np.cos(v), 0.15 * np.sin(v), 0.02 * v], 0.02 * (v - 2), -0.015 * v) for v in range(len(c))], True),
+    "upside down": (640, 512, lambda W, H, c: [_roll_cam(W, H, [0.1, 0.05 * v, 0.0], np.pi + 0.1 * v) for v in range(len(c))], True),
     "on its side and far off": (640, 512, lambda W, H, c: [_roll_cam(W, H, [0.1, 0.1, 0.0], 0.5 * np.pi), _roll_cam(W, H, [-0.9, 0.6, -0.3], 0.3, -0.45, 0.3)] +
-                                [_roll_cam(W, H, [0.0, -0.12, 0.0], -0.7, 0.0, 0.2)] * (len(c) - 2), 2),
-    "one camera behind": (640, 512, lambda W, H, c: list(c[:-1]) + [synth.camera_at([0.0, 0.0, -6.0], W, H, rot=np.diag([-1.0, 1.0, -1.0]))], 0),
+                                [_roll_cam(W, H, [0.0, -0.12, 0.0], -0.7, 0.0, 0.2)] * (len(c) - 2), True),
+    "one camera behind": (640, 512, lambda W, H, c: list(c[:-1]) + [synth.camera_at([0.0, 0.0, -6.0], W, H, rot=np.diag([-1.0, 1.0, -1.0]))], False),
 }
 
 
 @pytest.mark.parametrize("case", list(BAND_CASES))
 def test_one_call_band_pipeline_is_bit_identical(case, monkeypatch):
     """mvs_sweep with the fixed sampler sends the side frames over in row bands and sweeps band b while the rows of band b + 1 cross the bus
-    (sweep.hip: BandPipeline).  Depth and cost equal the resident form's (set + run + fetch) and the unbanded one-call's bit for bit, whatever
-    the cameras do to the order of the side rows; afterwards the context holds the COMPLETE views (a later mvs_sweep_run reads all rows); and
-    a camera that sees part of the sweep from behind (no bound on the rows a band samples) takes the unbanded path."""
-    W, H, cams_of, bands = BAND_CASES[case]
+    (sweep.hip: BandPipeline; by default two bands, for view sets of 16 MB and more -- here forced through the test hook).  Depth and cost
+    equal the resident form's (set + run + fetch) and the unbanded one-call's bit for bit, whatever the cameras do to the order of the side
+    rows; afterwards the context holds the COMPLETE views (a later mvs_sweep_run reads all rows); and a camera that sees part of the sweep
+    from behind (no bound on the rows a band samples) takes the unbanded path."""
+    W, H, cams_of, pipelined = BAND_CASES[case]
     D, V = 32, 5
     main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.2)
     if cams_of is not None:
@@ -690,31 +691,40 @@ def test_one_call_band_pipeline_is_bit_identical(case, monkeypatch):
     sides = [np.ascontiguousarray(np.clip(s.astype(np.int32) + rng.integers(-9, 10, s.shape), 0, 255).astype(np.uint8)) for s in sides]
     want = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN, sampler="fixed")
     assert np.isfinite(want[1]).mean() > 0.3, "the views must overlap the main view"
-    with mvs_amd.Context(W, H, sampler="fixed") as ctx:
-        for _ in range(2):   # the second call finds the plan in the cache: band 0 is staged outside the planner's hook
-            depth, cost = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_cost=True)
-            assert ctx.onecall_bands() == bands
-            np.testing.assert_array_equal(depth, want[0])
-            np.testing.assert_array_equal(cost, want[1])
-        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
-        again = ctx.sweep_fetch(want_volume=True)
-        for a, b in zip(again, want):
-            np.testing.assert_array_equal(a, b)
-        # a volume request goes through the unbanded path
-        d2, vol = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True)
-        assert ctx.onecall_bands() == 0
-        np.testing.assert_array_equal(d2, want[0])
-    monkeypatch.setenv("MVS_ONECALL_BANDS", "1")
-    with mvs_amd.Context(W, H, sampler="fixed") as ctx:
+    with mvs_amd.Context(W, H, sampler="fixed") as ctx:   # no hook: a view set this small goes up in one piece
         depth, cost = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_cost=True)
         assert ctx.onecall_bands() == 0
         np.testing.assert_array_equal(depth, want[0])
         np.testing.assert_array_equal(cost, want[1])
-    for forced in (3, 4, 8):
+    for forced in (2, 3, 4, 8):
         monkeypatch.setenv("MVS_ONECALL_BANDS", str(forced))
-        if bands or case == "small":
-            with mvs_amd.Context(W, H, sampler="fixed") as ctx:
+        with mvs_amd.Context(W, H, sampler="fixed") as ctx:
+            for _ in range(2):   # the second call finds the plan in the cache: band 0 is staged outside the planner's hook
                 depth, cost = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_cost=True)
-                assert ctx.onecall_bands() == min(forced, H // 64)
+                assert ctx.onecall_bands() == (min(forced, H // 64) if pipelined else 0)
                 np.testing.assert_array_equal(depth, want[0])
                 np.testing.assert_array_equal(cost, want[1])
+            if forced == 2:
+                ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+                again = ctx.sweep_fetch(want_volume=True)
+                for a, b in zip(again, want):
+                    np.testing.assert_array_equal(a, b)
+                # a volume request goes through the unbanded path
+                d2, vol = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True)
+                assert ctx.onecall_bands() == 0
+                np.testing.assert_array_equal(d2, want[0])
+
+
+def test_one_call_at_c3_is_pipelined_by_default():
+    """BASELINE c3's frames (16 views of 1920 x 1080: 33 MB) through mvs_sweep: two row bands without any hook, the resident form's bits"""
+    W, H, D, V = 1920, 1080, 16, 16
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V)
+    want = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, mvs_amd.MVS_SWEEP_FUSED_ARGMIN, volume=False, sampler="fixed")
+    with mvs_amd.Context(W, H, sampler="fixed") as ctx:
+        depth, cost = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_cost=True)
+        assert ctx.onecall_bands() == 2
+        np.testing.assert_array_equal(depth, want[0])
+        np.testing.assert_array_equal(cost, want[1])
+    with mvs_amd.Context(W, H, sampler="exact") as ctx:
+        ctx.sweep(main_cam, main_img, side_cams, sides, D)
+        assert ctx.onecall_bands() == 0
