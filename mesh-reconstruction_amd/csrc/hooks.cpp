@@ -41,6 +41,7 @@ Hooks read_hooks()
     h.debug_flags = flag("MVS_DEBUG_FLAGS");
     h.no_rect = present("MVS_NO_RECT");
     h.no_plan_cache = present("MVS_NO_PLAN_CACHE");
+    h.no_sep = flag("MVS_NO_SEP");
     h.plan_dump = text("MVS_PLAN_DUMP");
     h.fx_prof = present("MVS_FX_PROF");
     h.rect_verbose = present("MVS_RECT_VERBOSE");

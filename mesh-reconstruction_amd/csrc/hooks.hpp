@@ -37,6 +37,7 @@ struct Hooks {
     bool flow_graph = false;           // MVS_FLOW_GRAPH=1: mvs_flow replays its kernel sequence as a hipGraph, as rounds 2-3 did (tools/graph_repro.py: the
                                        // replay-after-first-Poisson-call corruption of round 4; never set otherwise)
     bool flow_graph_kernel_memset = false;  // MVS_FLOW_GRAPH=2: the same, with the sequence's hipMemsetAsync calls replaced by a zero-fill kernel (the A/B of the finding)
+    bool no_sep = false;               // MVS_NO_SEP=1: the general tiled kernel never takes its separable path (A/B: bit-identical)
     int onecall_bands = 0;             // MVS_ONECALL_BANDS=n: row bands of the one-call mvs_sweep's upload pipeline (default: 2 for view sets of 16 MB and more; 1 = the unbanded path)
     int onecall_first_permille = 0;    // MVS_ONECALL_FIRST=p: with two bands, the first one takes p/1000 of the rows (timing A/B)
     int fb_variant = 0;                // MVS_FB_VARIANT=2: the tall Farneback tiles with 512 threads x 4 rows instead of 256 x 8 (timing A/B: slower)

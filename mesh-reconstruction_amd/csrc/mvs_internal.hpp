@@ -84,6 +84,10 @@ struct mvs_ctx {
     bool snap_valid = false, snap_in_store = false;
     std::vector<float> snap_q, snap_z;
     std::vector<int> snap_slots;
+    mvs::DevBuf sep_tab;             // the separable path's tables for the current (views, planes): sweep_fx.hip, plan_sep_tables
+    bool sep_ok = false;
+    int sep_dpad = 0;
+    size_t sep_r_offset = 0;
     bool fx_general_planned = false; // the general tiled kernel's plan exists for the current (views, planes) (made on demand when rect_ok)
     int rect_rs = 0, rect_slot_dw = 0, rect_dpad = 0;
     std::vector<unsigned char> rect_cold_host;  // host copy of the kernel's cold block (sweep_rect.hip: RectCold)

@@ -357,6 +357,109 @@ __device__ __forceinline__ void sample_range_fx(const Affine &A, float bx, float
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// the separable path (round 5): views with the main camera's orientation
+// ------------------------------------------------------------------------------------------------------
+// A side camera that is a pure TRANSLATION of the main one (any direction: along the optical axis too) has q1 = q4 = q8 = q9 = 0, and the
+// contract's own expressions then separate: s.w = fma(z, q10, q11) depends on the plane only, Tx = fma(fma(z, q2, fma(q0, xn, q3)), 256 r, .) on
+// (column, plane), Ty on (row, plane) -- the same floating-point operations on the same operands as the general form (fma(0, t, u) = u).
+// So RN(1 / s.w) is a table entry per (view, plane), the row part of both LDS addresses -- ky << 10 for the weight word, iy << 10 for the
+// quad -- a table entry per (view, image row, plane), both read through scalar loads, and a thread's column part is shared by its rows:
+// a sample is two address adds + two ds_read_b32 + v_dot4 + v_sad_u16, no reciprocal, no projection (general form: 14 vector
+// instructions per sample, 11.5 of them the projection).  (sweep_fx_rect needs q10 = 0 and unit scale on top: every pixel at the same
+// sub-texel phase.  Here the phase varies across the tile; the weight word stays a per-sample LDS read.)  Regions of mode FAST only;
+// BORDER and GENERIC regions take the general form.  Bit-identical by construction; tests/test_sweep_gpu.py compares with the hook
+// MVS_NO_SEP=1 and with the oracle.
+__device__ __forceinline__ bool sep_view(const float *q) { return q[1] == 0.0f && q[4] == 0.0f && q[8] == 0.0f && q[9] == 0.0f; }
+
+__global__ __launch_bounds__(256) void plan_sep_tables(SweepParams p, float *__restrict__ rtab, uint2 *__restrict__ ytab, int dpad)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)p.V * p.H * dpad) return;
+    const int d = (int)(t % dpad), row = (int)((t / dpad) % p.H), v = (int)(t / ((size_t)dpad * p.H));
+    const float *q = p.Q + 12 * v;
+    const float z = p.z[min(d, p.D - 1)];
+    // as the tiled kernel forms them: the w row divided by 256 (exact), A.aw = fma(q8', xn, fma(q9', yn, q11')) = q11' for q8 = q9 = 0
+    const float r256 = rcp_rn(__builtin_fmaf(z, q[10] * 0.00390625f, q[11] * 0.00390625f));
+    const float yn = __builtin_fmaf(-(float)(2 * row + 1), p.invH, 1.0f);
+    const float ay = __builtin_fmaf(q[5], yn, q[7]);  // = fma(q4, xn, fma(q5, yn, q7)) for q4 = 0
+    const float Ty = __builtin_fmaf(__builtin_fmaf(z, q[6], ay), r256, FX_MAGIC + 4.0f);
+    const uint32_t b = __builtin_bit_cast(uint32_t, Ty);
+    ytab[t] = make_uint2(((b >> 3) & 31u) << 10, ((b >> 8) & 0x3fffu) << 10);
+    if (row == 0) rtab[(size_t)v * dpad + d] = r256;
+}
+
+// all 16 planes of one view for the two rows of a thread (a FAST region: every sample in frame).  ax / bx: the x row of the view at this
+// column; zc: the chunk's planes; rt / yt[j]: the view's tables at the chunk's first plane (and at row j of the thread; a row below the
+// image reads the last row's entries and its sums are never used); offx: as in sample_range_fx; xq0 = LDS address of quad column 0 of
+// region row 0 minus (y0 << 10).  The table entries of four planes (20 SGPRs: three scalar loads) are requested one quarter ahead of
+// their use; groups of two planes x two rows, software-pipelined over the whole chunk as in sample_range_fx (the 8 LDS reads of group
+// g + 1 are issued before group g is consumed).
+__device__ __forceinline__ void sample_view_sep(float ax, float bx, const float (&zc)[FX_PC], const float *__restrict__ rt, const uint2 *const (&yt)[FX_NPX], float offx,
+                                                uint32_t lds_base, uint32_t xq0, const uint32_t (&Im255)[FX_NPX], uint32_t (&acc)[FX_NPX][FX_PC])
+{
+    static_assert(FX_NPX == 2 && FX_PC == 16, "written for two rows per thread and chunks of 16 planes");
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    typedef const __attribute__((address_space(4))) u32x4 *c4;
+    typedef const __attribute__((address_space(4))) u32x8 *c8;
+    constexpr int GS = 2, QP = 4, NS = GS * FX_NPX, NG = FX_PC / GS;  // planes per group, planes per table load, samples per group, groups
+    u32x4 rq[2];
+    u32x8 yq0[2], yq1[2];
+    auto load_tables = [&](int quarter) {
+        rq[quarter & 1] = *(c4)(uintptr_t)(rt + QP * quarter);
+        yq0[quarter & 1] = *(c8)(uintptr_t)(yt[0] + QP * quarter);
+        yq1[quarter & 1] = *(c8)(uintptr_t)(yt[1] + QP * quarter);
+    };
+    uint32_t la[NS], ta[NS], lw[2][NS], lq[2][NS];
+    auto address_stage = [&](int g) {
+        const int slot = (g * GS / QP) & 1;
+#pragma unroll
+        for (int i = 0; i < GS; i++) {
+            const int k = g * GS + i, kk = k % QP;
+            const float sx = __builtin_fmaf(zc[k], bx, ax);
+            const uint32_t rbits = rq[slot][kk];  // (through a temporary: __builtin_bit_cast applied directly to a vector element reads element 0 with this hipcc)
+            const float Tx = __builtin_fmaf(sx, __builtin_bit_cast(float, rbits), offx);
+            const uint32_t b = __builtin_bit_cast(uint32_t, Tx);
+            const uint32_t xw = ((b >> 1) & 0x7cu) + lds_base;
+            const uint32_t xq = ((b >> 6) & 0x3fcu) + xq0;
+            la[2 * i] = xw + yq0[slot][2 * kk];
+            ta[2 * i] = xq + yq0[slot][2 * kk + 1];
+            la[2 * i + 1] = xw + yq1[slot][2 * kk];
+            ta[2 * i + 1] = xq + yq1[slot][2 * kk + 1];
+        }
+    };
+    auto issue_reads = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            asm volatile("ds_read_b32 %0, %1" : "=v"(lw[buf][n]) : "v"(la[n]));
+            asm volatile("ds_read_b32 %0, %1" : "=v"(lq[buf][n]) : "v"(ta[n]));
+        }
+    };
+    load_tables(0);
+    address_stage(0);
+    issue_reads(0);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const int buf = g & 1;
+        if ((g * GS) % QP == 0 && g * GS / QP + 1 < FX_PC / QP) load_tables(g * GS / QP + 1);  // the next quarter's entries: in flight during this quarter's first group
+        if (g + 1 < NG) address_stage(g + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lw[buf][0]), "+v"(lw[buf][1]), "+v"(lw[buf][2]), "+v"(lw[buf][3]), "+v"(lq[buf][0]), "+v"(lq[buf][1]), "+v"(lq[buf][2]), "+v"(lq[buf][3]),
+                       "+v"(la[0]), "+v"(ta[0]), "+v"(la[NS - 1]), "+v"(ta[NS - 1]));
+        if (g + 1 < NG) issue_reads(buf ^ 1);
+#pragma unroll
+        for (int i = 0; i < GS; i++) {
+            const int k = g * GS + i;
+#pragma unroll
+            for (int j = 0; j < FX_NPX; j++) {
+                const uint32_t dot = __builtin_amdgcn_udot4(lq[buf][2 * i + j], lw[buf][2 * i + j], 0u, false);
+                acc[j][k] = sad_u16(dot, Im255[j], acc[j][k]);
+            }
+        }
+    }
+}
+
 // FX_MAGIC + k as a float, for an integer |k| < 2^22: in the binade [2^23, 2^24) one ulp is 1, so the bit pattern is 0x4B400000 + k.
 // With a wave-uniform k this is scalar integer arithmetic (gfx950's SALU has no float unit; written with floats, every region
 // constant below cost a v_cvt + v_mul + v_add per wavefront and region: ~20 VALU instructions, 5 % of the kernel).
@@ -408,7 +511,7 @@ __device__ __forceinline__ void sample_range_fx_checked(const Affine &A, float b
 #define FX_PROF_MARK(i)
 #endif
 
-template <bool WRITE_VOLUME, bool FUSED>
+template <bool WRITE_VOLUME, bool FUSED, bool SEP = false>  // SEP: with the separable path compiled in (its own instantiation: the path's registers would cost the others 3 %)
 __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const uint32_t *__restrict__ lut_g)
 {
     constexpr int NPX = FX_NPX, PC = FX_PC, TILE_H = FX_TILE_H;
@@ -591,6 +694,19 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
             rg.offx = magic_plus(4 - kx0);
             rg.offy = magic_plus(4 - ky0);
             const bool wconst = uniform_f(bw) == 0.0f && !(p.debug & 4);  // wave-uniform: plane-independent w
+            if (SEP && p.sep_y && mode == FX_FAST && uniform_f(q[1]) == 0.0f && uniform_f(q[4]) == 0.0f && uniform_f(q[8]) == 0.0f && uniform_f(q[9]) == 0.0f) {
+                // the separable path (above): this view has the main camera's orientation and the whole region is in frame
+                fast_views += 1u << 24;
+                __builtin_amdgcn_s_setprio(0);
+                const int wrow = ty * TILE_H + __builtin_amdgcn_readfirstlane(wave) * NPX;  // (the wavefront's first row, as a scalar)
+                const uint2 *yt[NPX];
+#pragma unroll
+                for (int j = 0; j < NPX; j++) yt[j] = p.sep_y + ((size_t)v * p.H + min(wrow + j, p.H - 1)) * p.sep_dpad + d0;
+                const Affine A0 = view_affine(q, xn, yn[0]);
+                sample_view_sep(A0.ax, bx, zc, p.sep_r + (size_t)v * p.sep_dpad + d0, yt, rg.offx, lds_base, lds_base + 4u * FX_LUT_DW - ((uint32_t)y0 << 10), Im255, acc);
+                qcol = nqcol;
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < NPX; j++) {
                 const Affine A = view_affine(q, xn, yn[j]);
@@ -758,10 +874,10 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
     }
 }
 
-template <bool WRITE_VOLUME, bool FUSED>
+template <bool WRITE_VOLUME, bool FUSED, bool SEP = false>
 __global__ __launch_bounds__(256, FX_WG_PER_CU) void sweep_fx_tiled(SweepParams p, const uint32_t *__restrict__ lut_g)
 {
-    sweep_fx_tiled_body<WRITE_VOLUME, FUSED>(p, lut_g);
+    sweep_fx_tiled_body<WRITE_VOLUME, FUSED, SEP>(p, lut_g);
 }
 
 // several main frames in one launch (mvs_sweep_batch): blockIdx.z selects the frame's parameter block; depth selection only
@@ -839,6 +955,11 @@ int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool gen
         MVS_HIP(ctx, hipGetLastError());
         return MVS_OK;
     }
+    if (ctx->sep_ok && ctx->fx_general_planned) {
+        p.sep_y = (const uint2 *)ctx->sep_tab.ptr;
+        p.sep_r = (const float *)((const char *)ctx->sep_tab.ptr + ctx->sep_r_offset);
+        p.sep_dpad = ctx->sep_dpad;
+    }
     const int groups = div_up(p.tiles_x, 2) * div_up(p.tyn, 4);
     const int nch = p.chunk1 - p.chunk0, tiles = p.tiles_x * p.tyn;
     int want = (int)((flags >> 16) & 0xffu);  // undocumented: forced split count for timing experiments
@@ -858,7 +979,14 @@ int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool gen
         MVS_HIP(ctx, hipMemsetAsync(ctx->plan_stats.ptr, 0, 256, ctx->stream));
     }
 #endif
-    if (vol && fused)
+    if (p.sep_y) {  // some view qualifies for the separable path: the instantiation that has it
+        if (vol && fused)
+            sweep_fx_tiled<true, true, true><<<grid, 256, 0, ctx->stream>>>(p, lut);
+        else if (vol)
+            sweep_fx_tiled<true, false, true><<<grid, 256, 0, ctx->stream>>>(p, lut);
+        else
+            sweep_fx_tiled<false, true, true><<<grid, 256, 0, ctx->stream>>>(p, lut);
+    } else if (vol && fused)
         sweep_fx_tiled<true, true><<<grid, 256, 0, ctx->stream>>>(p, lut);
     else if (vol)
         sweep_fx_tiled<true, false><<<grid, 256, 0, ctx->stream>>>(p, lut);
@@ -907,6 +1035,26 @@ int sweep_fx_plan_general(mvs_ctx *ctx)
             fwrite(hdr, sizeof(int), 4, f);
             fwrite(host.data(), sizeof(uint2), n, f);
             fclose(f);
+        }
+    }
+    // the separable path's tables, when a view qualifies (plan_sep_tables above): 8 bytes per (view, image row, plane)
+    ctx->sep_ok = false;
+    if (!ctx->hooks.no_sep) {
+        bool any = false;
+        for (int v = 0; v < ctx->V && !any; v++) {
+            const float *m = ctx->q_host.data() + 12 * v;
+            any = m[1] == 0.0f && m[4] == 0.0f && m[8] == 0.0f && m[9] == 0.0f;
+        }
+        const int dpad = q.nchunks * FX_PC;
+        const size_t ny = (size_t)ctx->V * ctx->H * dpad, nr = (size_t)ctx->V * dpad;
+        if (any && ny * sizeof(uint2) <= ((size_t)256 << 20)) {
+            const size_t off_r = (ny * sizeof(uint2) + 255) & ~(size_t)255;
+            if ((rc = ensure(ctx, ctx->sep_tab, off_r + nr * sizeof(float)))) return rc;
+            plan_sep_tables<<<(unsigned)((ny + 255) / 256), 256, 0, ctx->stream>>>(q, (float *)((char *)ctx->sep_tab.ptr + off_r), (uint2 *)ctx->sep_tab.ptr, dpad);
+            MVS_HIP(ctx, hipGetLastError());
+            ctx->sep_ok = true;
+            ctx->sep_dpad = dpad;
+            ctx->sep_r_offset = off_r;
         }
     }
     ctx->fx_general_planned = true;

@@ -52,6 +52,12 @@ struct SweepParams {
     int cps;             // plane chunks per workgroup: blockIdx.y selects chunks [chunk0 + y*cps, +cps) of a tile
     uint2 *__restrict__ part;  // plane-split launches with fused depth selection: [gridDim.y][P] partial bests
     const int *__restrict__ view_slot;  // nullable: slab of view v's padded / quad image (frame store slots, mvs_sweep_batch); null = slab v
+    // separable path of the fixed sampler's general kernel (sweep_fx.hip: plan_sep_tables; null = not available): for views whose matrix has
+    // q1 = q4 = q8 = q9 = 0 (a camera with the main camera's orientation, anywhere), RN(1 / s.w) per (view, plane) and the row part of both LDS
+    // addresses per (view, image row, plane)
+    const float *__restrict__ sep_r;   // [V][sep_dpad]
+    const uint2 *__restrict__ sep_y;   // [V][H][sep_dpad]: (ky << 10, iy << 10)
+    int sep_dpad, sep_reserved;
     int debug;  // timing experiments only (bit 0: skip LDS staging -> wrong results; bit 1: linear tile order; bit 2: never use the plane-independent-w path; bit 3: exact sampler: force the 4 x 16 shape, fixed sampler: no region look-ahead; fixed sampler only: bit 4: BORDER regions as FAST, bit 5: skip the sample loop)
 };
 
@@ -195,6 +201,10 @@ inline int fill_params(mvs_ctx *ctx, SweepParams &p, int v0, int vcount, int til
     p.part = nullptr;
     p.plan_stats = nullptr;
     p.view_slot = ctx->views_in_store ? (const int *)ctx->view_slots.ptr : nullptr;  // mvs_sweep_handles: view v is slot view_slot[v] of the frame store
+    p.sep_r = nullptr;
+    p.sep_y = nullptr;
+    p.sep_dpad = 0;
+    p.sep_reserved = 0;
     p.debug = 0;
     return MVS_OK;
 }

@@ -32,8 +32,12 @@ for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     W, H = int(rng.integers(2, 700)), int(rng.integers(2, 260))
     D, V = int(rng.integers(1, 70)), int(rng.integers(1, 14))
-    main_cam = random_camera(rng, W, H, 0.05, 0.05)
-    side_cams = np.stack([random_camera(rng, W, H, rng.choice([0.1, 0.4, 1.5]), rng.choice([0.02, 0.3, 0.7])) for _ in range(V)])
+    if seed % 3 == 0:   # every camera with the same orientation (translations in all three directions, own intrinsics): the separable path of sweep_fx_tiled
+        main_cam = random_camera(rng, W, H, 0.05, 0.0)
+        side_cams = np.stack([random_camera(rng, W, H, rng.choice([0.1, 0.4, 1.5]), 0.0) if rng.uniform() < 0.85 else random_camera(rng, W, H, 0.3, 0.2) for _ in range(V)])
+    else:
+        main_cam = random_camera(rng, W, H, 0.05, 0.05)
+        side_cams = np.stack([random_camera(rng, W, H, rng.choice([0.1, 0.4, 1.5]), rng.choice([0.02, 0.3, 0.7])) for _ in range(V)])
     main_img = rng.integers(0, 256, (H, W), dtype=np.uint8)
     sides = [rng.integers(0, 256, (H, W), dtype=np.uint8) for _ in range(V)]
     z = (float(rng.uniform(-1.0, -0.2)), float(rng.uniform(0.2, 1.0)))

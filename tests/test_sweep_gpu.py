@@ -728,3 +728,41 @@ def test_one_call_at_c3_is_pipelined_by_default():
     with mvs_amd.Context(W, H, sampler="exact") as ctx:
         ctx.sweep(main_cam, main_img, side_cams, sides, D)
         assert ctx.onecall_bands() == 0
+
+
+@pytest.mark.parametrize("W,H,D,V", [(640, 360, 48, 5), (333, 203, 21, 3), (1280, 720, 64, 8)])
+def test_separable_path_of_the_general_kernel_is_bit_identical(oracle, W, H, D, V, monkeypatch):
+    """Side cameras with the main camera's orientation but off its focal plane (moved along the optical axis too: not sweep_fx_rect's case)
+    take the general kernel's separable path -- reciprocal per (view, plane) and the row part of the LDS addresses per (view, row, plane)
+    from tables, the column part shared by a thread's rows (sweep_fx.hip: plan_sep_tables / sample_view_sep).  Every cell, depth, cost and
+    index equals the oracle's and the same kernel's with the path switched off; a rotated view among them takes the general form."""
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.2)
+    side_cams = side_cams.copy()
+    for v in range(V):
+        a = 2.0 * np.pi * v / V
+        side_cams[v] = synth.camera_at([0.2 * np.cos(a), 0.2 * np.sin(a), 0.11 * (v - 1)], W, H)       # v = 1 stays in the focal plane
+    if V >= 5:
+        side_cams[3] = _rot_cam(W, H, [0.1, -0.15, 0.05], 0.02, -0.015)                                  # not separable
+    ref = oracle.sweep(main_cam, main_img, side_cams, sides, D, want_volume=True, nthreads=8, sampler="fixed")
+    both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    got = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, both, sampler="fixed")
+    _check(got, ref, D)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    assert (got[3] >> 24).max() >= V - 1
+    monkeypatch.setenv("MVS_NO_SEP", "1")
+    plain = _gpu_sweep(W, H, main_cam, main_img, side_cams, sides, D, both, sampler="fixed")
+    for a, b in zip(got, plain):
+        np.testing.assert_array_equal(a, b)
+    # fused-only launches, row bands and view subsets go through the same tables
+    monkeypatch.delenv("MVS_NO_SEP")
+    with mvs_amd.Context(W, H, sampler="fixed") as ctx:
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+        ctx.sweep_run(0, V, mvs_amd.MVS_SWEEP_FUSED_ARGMIN)
+        d, c, i, _ = ctx.sweep_fetch()
+        np.testing.assert_array_equal(d, ref[0])
+        np.testing.assert_array_equal(i, ref[2])
+        ctx.sweep_run(1, V - 1, mvs_amd.MVS_SWEEP_VOLUME)
+        vol = ctx.sweep_fetch(want_volume=True)[3]
+    sub = oracle.sweep(main_cam, main_img, side_cams[1:], sides[1:], D, want_volume=True, nthreads=8, sampler="fixed")
+    np.testing.assert_array_equal(vol, sub[3])
