@@ -770,7 +770,7 @@ def main():
         return (time.perf_counter() - t1) / n * 1e3
 
     # co-headline: the same frames under general (rotated) cameras; and the exact-f32 sampler on both geometries
-    general_ms = exact = disagreement = sustained = None
+    general_ms = exact = disagreement = sustained = translated_ms = None
     if world == 1 and not args.no_extras:
         other = "exact" if args.sampler == "fixed" else "fixed"
         gcams = general_cameras()
@@ -782,6 +782,14 @@ def main():
             general_kernel = KERNEL_OF_SHAPE.get(gctx.plan_shape())
             gctx.set_sampler(other)
             other_general_ms = time_resident(gctx, both, args.steps)
+            # ... and under side cameras that are pure translations of the main one in all three directions (off its focal plane: not the
+            # rectified kernel's case): the general kernel's separable path (sweep_fx.hip: plan_sep_tables / sample_view_sep)
+            tcams = np.stack([synth.camera_at([radius * np.cos(2.0 * np.pi * vi / max(V, 1)), radius * np.sin(2.0 * np.pi * vi / max(V, 1)), 0.1 * np.sin(1.7 * vi + 0.3)], W, H)
+                              for vi in range(V)])
+            gctx.set_sampler(args.sampler)
+            gctx.sweep_set(main_cam, main_img, tcams, sides, D)
+            time_resident(gctx, both, 10)
+            translated_ms = time_resident(gctx, both, args.steps) if args.sampler == "fixed" else None
         with mvs_amd.Context(W, H, local_rank, sampler=other) as octx2:
             octx2.set_stream(stream.cuda_stream)
             octx2.sweep_set(main_cam, main_img, side_cams, sides, D)
@@ -964,6 +972,10 @@ def main():
                 "note": "same frames, side cameras turned by 12 mrad about two axes: no view is rectified any more, the general tiled kernel "
                         "with its per-sample reciprocal runs -- the rate for rotated / forward-moving cameras such as the bundled tracks "
                         "(timing only; DESIGN.md section 4)"}
+            if translated_ms is not None:
+                out["general_camera_path"]["translation_only_cameras_ms_per_step"] = translated_ms
+                out["general_camera_path"]["translation_only_note"] = ("side cameras with the main camera's orientation, moved along the optical axis too: the same kernel's separable "
+                                                                         "path (1 / w per (view, plane) and the LDS row offsets per (view, row, plane) from tables), bit-identical")
         if flow is not None:
             out["flow"] = flow
         if exact is not None:

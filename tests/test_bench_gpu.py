@@ -85,6 +85,8 @@ def test_bench_line_contract_and_two_rank_shardings():
     assert 0.0 < cold["same_cameras_ms"] <= cold["ms"] * 1.2   # (the plan reused: not slower than planning, up to noise)
     assert "combine_best" in ext["roofline"]["ms_per_launch_covers"]
     assert "roofline_traffic" in ext["general_camera_path"]
+    # side cameras that are translations of the main one (any direction): the same kernel's separable path, faster than its general form
+    assert 0 < ext["general_camera_path"]["translation_only_cameras_ms_per_step"] < ext["general_camera_path"]["ms_per_step"]
 
 
 def test_via_comm_line():
