@@ -667,6 +667,7 @@ BAND_CASES = {
     "ring": (640, 512, None, True),
     "ragged height": (648, 500, None, True),
     "small": (320, 136, None, True),
+    "odd width": (333, 301, None, True),
     "general": (640, 512, lambda W, H, c: [_rot_cam(W, H, [0.15 * np.cos(v), 0.15 * np.sin(v), 0.02 * v], 0.02 * (v - 2), -0.015 * v) for v in range(len(c))], True),
     "upside down": (640, 512, lambda W, H, c: [_roll_cam(W, H, [0.1, 0.05 * v, 0.0], np.pi + 0.1 * v) for v in range(len(c))], True),
     "on its side and far off": (640, 512, lambda W, H, c: [_roll_cam(W, H, [0.1, 0.1, 0.0], 0.5 * np.pi), _roll_cam(W, H, [-0.9, 0.6, -0.3], 0.3, -0.45, 0.3)] +
