@@ -465,6 +465,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--general-cameras", action="store_true",
                     help="time the general-camera geometry (side cameras turned by 12 mrad: sweep_fx_tiled) instead of the SURVEY 8d ring; for profiles, not the headline")
+    ap.add_argument("--translated-cameras", action="store_true",
+                    help="time side cameras that are pure translations of the main one in all three directions (sweep_fx_tiled's separable path) instead of the SURVEY 8d ring; for profiles, not the headline")
     ap.add_argument("--fused", action="store_true", help="also time the no-volume variant (depth only)")
     ap.add_argument("--separate-argmin", action="store_true",
                     help="single GPU: run argmin_volume as its own pass over the volume (the multi-GPU views pipeline)")
@@ -559,6 +561,10 @@ def main():
 
     if args.general_cameras:  # profiling aid (tools/prof_sweep.sh <tag> --general-cameras): the general tiled kernel as the timed workload
         side_cams = general_cameras()
+        gt = None
+    if args.translated_cameras:  # profiling aid: the same kernel's separable path
+        side_cams = np.stack([synth.camera_at([radius * np.cos(2.0 * np.pi * vi / max(V, 1)), radius * np.sin(2.0 * np.pi * vi / max(V, 1)), 0.1 * np.sin(1.7 * vi + 0.3)], W, H)
+                              for vi in range(V)])
         gt = None
 
     # one explicit (non-default) stream for kernels AND collectives: torch's default stream has handle 0, which the ABI
@@ -930,7 +936,7 @@ def main():
             "vs_baseline": None,
             "dtype": DTYPE[args.sampler],
             "data": "synthetic (%s)" % args.data + (" [TEST HOOK: ranks share one GPU over gloo -- not a measurement]" if same_device else ""),
-            "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V) + (" (GENERAL CAMERAS: side views turned by 12 mrad, not the SURVEY 8d ring)" if args.general_cameras else ""),
+            "config": {"workload": "%s: %dx%d, %d planes, %d side views" % (args.config, W, H, D, V) + (" (GENERAL CAMERAS: side views turned by 12 mrad, not the SURVEY 8d ring)" if args.general_cameras else "") + (" (TRANSLATED CAMERAS: side views moved along the optical axis too, not the SURVEY 8d ring)" if args.translated_cameras else ""),
                        "sampler": args.sampler, "shard": None if world == 1 else shard, "collective": args.collective if shard == "views" else (("all_gather of depth rows" + ("" if args.no_overlap else ", on a second stream beside the next step's sweep (steps are independent main views; the timed region ends with every collective complete)")) if shard == "rows" and world > 1 else None),
                        "views_per_rank": primary["views"], "rows_per_rank": [n for _, n in bands] if shard == "rows" else None,
                        "collective_bytes_per_rank_per_step": primary["collective_bytes_per_rank"], "alternatives": alternatives, "device": ctx.info()},
