@@ -20,6 +20,11 @@
  * Parameters are the reference's: levels 10, pyr_scale 0.8, winsize (H+W)/100, iterations 7, poly_n 5 or 7,
  * poly_sigma (H+W)/1000, flags 0 (box window, zero initial flow).
  *
+ * Threads: the row loops below carry `#pragma omp parallel for`.  Every output value is computed by ONE thread from
+ * inputs no thread of the same loop writes, with the operations in the order written -- the results do not depend on
+ * the thread count (tests/test_flow_cpu.py checks 1 thread against many); it only makes 1080p / 4K parity runs minutes
+ * instead of tens of minutes.
+ *
  * Variational refinement (Brox et al., ECCV 2004, as organised in OpenCV's VariationalRefinement): see
  * orc_variational_refine below.  The reference passes an UNINITIALISED flow matrix into calc() (flow.cpp:31-32);
  * the restatement starts from zero flow.
@@ -81,6 +86,7 @@ static void gaussian_blur(const float *src, int w, int h, int ksize, double sigm
     orc_gaussian_kernel(ksize, sigma, k);
     const int c = ksize / 2;
     float *tmp = (float *)malloc(sizeof(float) * (size_t)w * h);
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             const float *s = src + (size_t)y * w;
@@ -88,6 +94,7 @@ static void gaussian_blur(const float *src, int w, int h, int ksize, double sigm
             for (int j = 1; j <= c; j++) acc += k[c + j] * (s[refl101(x + j, w)] + s[refl101(x - j, w)]);
             tmp[(size_t)y * w + x] = acc;
         }
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             float acc = k[c] * tmp[(size_t)y * w + x];
@@ -121,6 +128,7 @@ static void linear_coeff(int d, int dsize, int ssize, int *ofs, float *a0, float
 
 static void resize_linear(const float *src, int sw, int sh, int cn, float *dst, int dw, int dh)
 {
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < dh; y++) {
         int sy;
         float b0, b1;
@@ -206,8 +214,11 @@ static void poly_exp(const float *src, int w, int h, int n, double sigma, float 
     double ig[4];
     orc_farneback_gaussian(n, sigma, g, xg, xxg, ig);
     const double ig11 = ig[0], ig03 = ig[1], ig33 = ig[2], ig55 = ig[3];
-    float *rowbuf = (float *)malloc(sizeof(float) * (size_t)(w + 2 * n) * 3);
+#pragma omp parallel
+    {
+    float *rowbuf = (float *)malloc(sizeof(float) * (size_t)(w + 2 * n) * 3); /* one per thread */
     float *row = rowbuf + n * 3;
+#pragma omp for schedule(static)
     for (int y = 0; y < h; y++) {
         const float *s0 = src + (size_t)y * w;
         for (int x = 0; x < w; x++) {
@@ -254,6 +265,7 @@ static void poly_exp(const float *src, int w, int h, int n, double sigma, float 
         }
     }
     free(rowbuf);
+    }
     free(g);
 }
 
@@ -267,6 +279,7 @@ static void update_matrices(const float *R0, const float *R1, const float *flow,
 {
     static const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
     const size_t step1 = (size_t)w * 5;
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             const float *r0 = R0 + ((size_t)y * w + x) * 5;
@@ -320,6 +333,7 @@ static void update_flow_blur(const float *M, int w, int h, int block, float *flo
 {
     const int m = block / 2;
     const double scale = 1. / ((double)block * block);
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++)
             for (int c = 0; c < 5; c++) {
@@ -327,6 +341,7 @@ static void update_flow_blur(const float *M, int w, int h, int block, float *flo
                 for (int d = -m; d <= m; d++) s += M[((size_t)clampi(y + d, 0, h - 1) * w + x) * 5 + c];
                 vs[((size_t)y * w + x) * 5 + c] = s;
             }
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             double t[5];
@@ -440,6 +455,7 @@ void orc_farneback(const uint8_t *prev, const uint8_t *next, int W, int H, int l
 
 static void warp_linear_q5(const float *img, int W, int H, const float *u, const float *v, float *out)
 {
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
             const size_t p = (size_t)y * W + x;
@@ -456,11 +472,13 @@ static void warp_linear_q5(const float *img, int W, int H, const float *u, const
 
 static void ddx(const float *a, int W, int H, float *o)
 {
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) o[(size_t)y * W + x] = a[(size_t)y * W + clampi(x + 1, 0, W - 1)] - a[(size_t)y * W + clampi(x - 1, 0, W - 1)];
 }
 static void ddy(const float *a, int W, int H, float *o)
 {
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) o[(size_t)y * W + x] = a[(size_t)clampi(y + 1, 0, H - 1) * W + x] - a[(size_t)clampi(y - 1, 0, H - 1) * W + x];
 }
@@ -497,6 +515,7 @@ void orc_variational_refine(const uint8_t *I0u, const uint8_t *I1u, int W, int H
 
     for (int fp = 0; fp < fixedPointIterations; fp++) {
         /* data term */
+#pragma omp parallel for schedule(static)
         for (size_t p = 0; p < P; p++) {
             float derivNorm = Ix[p] * Ix[p] + Iy[p] * Iy[p] + zeta2;
             const float Ik1z = Iz[p] + Ix[p] * du[p] + Iy[p] * dv[p];
@@ -523,6 +542,7 @@ void orc_variational_refine(const uint8_t *I0u, const uint8_t *I1u, int W, int H
             b2[p] = B2;
         }
         /* diffusivity from the current total flow */
+#pragma omp parallel for schedule(static)
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) {
                 const size_t p = (size_t)y * W + x;
@@ -532,6 +552,7 @@ void orc_variational_refine(const uint8_t *I0u, const uint8_t *I1u, int W, int H
                 wgt[p] = alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + eps2);
             }
         /* smoothness contributions, gathered per pixel in the order left edge, right edge, upper edge, lower edge */
+#pragma omp parallel for schedule(static)
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) {
                 const size_t p = (size_t)y * W + x;
@@ -569,9 +590,10 @@ void orc_variational_refine(const uint8_t *I0u, const uint8_t *I1u, int W, int H
                 b1[p] = B1;
                 b2[p] = B2;
             }
-        /* red-black SOR */
+        /* red-black SOR: a half-sweep reads the other colour's du, dv (and the pixel's own), so its rows are independent */
         for (int it = 0; it < sorIterations; it++)
             for (int colour = 0; colour < 2; colour++)
+#pragma omp parallel for schedule(static)
                 for (int y = 0; y < H; y++)
                     for (int x = (y + colour) & 1; x < W; x += 2) {
                         const size_t p = (size_t)y * W + x;

@@ -45,6 +45,25 @@ def test_farneback_tall_tiles_match_oracle(oracle):
     np.testing.assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("W,H,farneback", [(1920, 1080, True), (1920, 1080, False), (3840, 2160, True), (3840, 2160, False)])
+def test_calculate_flow_matches_oracle_at_the_sizes_baseline_names(oracle, W, H, farneback):
+    """flow.cpp:24-26 at BASELINE's frame sizes: window (H + W) / 100 = 30 and poly 7 / 3.0 at c3, window 60 and poly 7 / 6.0 at c4 -- parameter
+    sets the smaller cases above never reach -- and the variational default (flow.cpp:29) at both; mvs_flow against oracle.calculate_flow
+    (OpenMP over rows, the same sums in the same order), all four channels, bit for bit.  The pair carries sigma = 2 noise: Farneback
+    must also RETURN the shift (most of it: the 1e-3 in the 2x2 solve biases it low), so the warp path runs on real sub-pixel flow."""
+    dx, dy = 4.0, 1.5
+    a, b = _pair(W, H, dx, dy, seed=W + farneback)
+    ref = oracle.calculate_flow(a, b, farneback)
+    with mvs_amd.Context(W, H) as ctx:
+        got = ctx.flow(a, b, farneback)
+    assert np.all(np.isfinite(got))
+    assert np.abs(got[..., :2] - ref[..., :2]).max() < TOL
+    np.testing.assert_array_equal(got, ref)
+    if farneback:
+        c = got[100:-100, 100:-100]
+        assert np.median(c[..., 0]) > 0.7 * dx and np.median(c[..., 1]) > 0.7 * dy
+
+
 @pytest.mark.parametrize("W,H", [(1920, 1080), (3840, 2160), (1000, 1099)])
 def test_farneback_tiled_iteration_equals_the_direct_one(monkeypatch, W, H):
     """the tiled iteration kernel (every value read once per thread, running sums in registers) against the round-2 kernel that sums each

@@ -53,6 +53,39 @@ def test_process_frame_equals_stagewise_and_oracle(oracle, farneback):
     np.testing.assert_allclose(pts[ok, 4:], o_pts[ok, 4:], rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("farneback", [False, True])
+def test_process_frame_equals_the_oracle_at_1080p(oracle, farneback):
+    """recon.cpp:65-117 at c3's frame size (1920 x 1080: Farneback window 30, poly 7 / 3.0; the batched pass over both side views), against the
+    oracle stage by stage: depth after mixBackground, every point bit for bit, normals to 1e-5.  The proxy mesh sits 0.08 in front of the surface
+    the frames were rendered from and the frames carry sigma = 2 sensor noise, so the flows are real (Farneback: 2-3 px of parallax error)"""
+    W, H, nside = 1920, 1080, 2
+    verts, faces, main, sides, main_img, side_imgs = _setup(W, H, nside)
+    verts = verts.copy()
+    verts[:, 2] += 0.08 * verts[:, 3]
+    rng = np.random.default_rng(7)
+
+    def noisy(im):
+        return (im.astype(np.float64) + rng.normal(0, 2, im.shape)).clip(0, 255).astype(np.uint8)
+    main_img, side_imgs = noisy(main_img), [noisy(im) for im in side_imgs]
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.load_mesh(verts, faces)
+        pts, depth_after = ctx.process_frame(main, main_img, sides, side_imgs, farneback, want_depth=True)
+    soup = oracle.load_mesh(verts, faces)
+    d = oracle.depth(soup, main, W, H)
+    oflows = []
+    for cam, img in zip(sides, side_imgs):
+        mixed, d = oracle.mix_background(oracle.projected(soup, main, img, cam), main_img, d)
+        oflows.append(oracle.calculate_flow(main_img, mixed, farneback))
+    if farneback:
+        assert min(np.median(np.abs(f[100:-100, 100:-100, :2])) for f in oflows) > 0.15
+    o_pts = oracle.triangulate_pixels(oflows, main, sides, d)
+    np.testing.assert_array_equal(depth_after, d)
+    assert pts.shape == o_pts.shape and pts.shape[0] > 0.2 * W * H
+    np.testing.assert_array_equal(pts[:, :4], o_pts[:, :4])
+    ok = np.isfinite(o_pts[:, 4:]).all(1)
+    np.testing.assert_allclose(pts[ok, 4:], o_pts[ok, 4:], rtol=1e-5, atol=1e-9)
+
+
 def test_process_frame_farneback_batch_at_a_window_the_tiled_iteration_serves():
     """1280 x 720, window 20: the batched Farneback pass of mvs_process_frame (all side views per launch, blockIdx.z = flow) runs the tiled
     iteration kernel -- its per-flow strides included -- and must equal the one-flow-at-a-time entry points, which equal the oracle
