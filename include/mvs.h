@@ -318,6 +318,25 @@ int mvs_comm_set_main(mvs_comm *comm, const float main_cam[16], const uint8_t *m
 int mvs_comm_set_views(mvs_comm *comm, int nviews, const float *side_cams /* nviews*16 */, const uint8_t *const *side_frames);
 int mvs_comm_run(mvs_comm *comm, unsigned flags);
 int mvs_comm_fetch(mvs_comm *comm, float *depth_hw /* nullable */, float *cost_hw /* nullable */);
+/* Two calls in flight (the loop of recon.cpp:65-117 over main views, or a fixed rig's next frames: the gather of view k beside the sweep of
+ * view k + 1).  mvs_comm_run_async(comm, 0) QUEUES one sweep of what is resident and returns when every rank's launches are queued -- nobody
+ * waits for a GPU: in MVS_SHARD_ROWS each rank's band leaves its context's maps by a device copy behind the sweep and travels to rank 0 on a
+ * second stream, into one of two (depth, cost) result pairs on rank 0's device, so the next call's sweep runs beside it; at most two calls are
+ * in flight (a third is refused with MVS_ESTATE until mvs_comm_wait).  mvs_comm_wait(comm) waits for the OLDEST call in flight and makes its
+ * maps the ones mvs_comm_fetch downloads; they stay valid until the second mvs_comm_run_async after that call.  The view-sharded modes end in
+ * collectives that every rank thread drives: there mvs_comm_run_async completes the call before it returns (one in flight at most) and
+ * mvs_comm_wait only publishes it.  While calls are in flight mvs_comm_run, mvs_comm_set_* and mvs_sweep_sharded return MVS_ESTATE.
+ * Launch failures are returned by mvs_comm_run_async, failures on a GPU by mvs_comm_wait.  mvs_comm_pending: calls in flight (0..2). */
+int mvs_comm_run_async(mvs_comm *comm, unsigned flags /* 0 */);
+int mvs_comm_wait(mvs_comm *comm);
+int mvs_comm_pending(const mvs_comm *comm);
+/* Where a rank's band copies travel (the resident MVS_SHARD_ROWS gather: rank r -> rank 0).  mvs_comm_create enables peer access between
+ * every rank's device and rank 0's in both directions (hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess; "already enabled" accepted) and
+ * keeps the outcome: mvs_comm_peer_access(comm, r) = 1 when rank r's copies go GPU to GPU (xGMI, or r shares rank 0's device; rank 0 itself:
+ * 1), 0 when the runtime stages them through host memory -- nothing is refused, a staged band is slow, not wrong; right after creation
+ * mvs_comm_last_error(comm) names the ranks concerned ("note: ...").  mvs_comm_device(comm, r): the HIP device ordinal of rank r. */
+int mvs_comm_peer_access(const mvs_comm *comm, int rank);
+int mvs_comm_device(const mvs_comm *comm, int rank);
 
 /* ---- kernel timing (HIP events on the context's stream) ---------------------------------------- */
 #define MVS_K_SWEEP 0

@@ -40,9 +40,11 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -187,6 +189,7 @@ struct Job {
     bool run = false;
     unsigned run_flags = 0;                      // rows mode: MVS_SWEEP_VOLUME also materialises the band of the volume
     float *depth_hw = nullptr, *cost_hw = nullptr;  // run: the maps go to the caller's host memory; both null: they stay on rank 0's GPU
+    int async_slot = -1;                         // rows, resident, mvs_comm_run_async: queue only; the maps land in rank 0's result pair of this slot
 };
 
 }  // namespace
@@ -211,6 +214,20 @@ struct mvs_comm {
     bool have_main = false, have_views = false, have_planes = false, have_result = false;
     int V = 0, D = 0;
     std::vector<int> res_v0, res_vn;  // per rank: the global view range its context holds
+    // peer access between rank r's device and rank 0's (both directions enabled at mvs_comm_create): 1 = the band copies of the resident rows
+    // mode travel GPU to GPU (xGMI, or the same device), 0 = the runtime stages them through host memory (still correct; reported)
+    std::vector<int> peer;
+    // mvs_comm_run_async (rows mode): up to two calls in flight.  Per rank and slot: the band's staging copy (so that the next sweep may overwrite
+    // the context's maps while the band is still travelling), "band staged" / "band landed on rank 0" events, a gather stream beside the sweep's;
+    // on rank 0's device one (depth, cost) pair of whole maps per slot -- what mvs_comm_wait makes the current result
+    std::vector<hipStream_t> gather_stream;
+    std::vector<std::array<mvs::DevBuf, 2>> stage;
+    std::vector<std::array<hipEvent_t, 2>> staged, sent;
+    std::vector<std::array<bool, 2>> sent_valid;
+    mvs::DevBuf result[2][2];
+    std::deque<int> pending;  // slots of the calls in flight, oldest first (-1: a call that completed synchronously, result in rank 0's context)
+    long issued = 0;
+    int result_slot = -1;     // >= 0: mvs_comm_fetch reads result[result_slot]; -1: rank 0's context
     // per call
     std::vector<int> rc;
     std::vector<std::string> msg;
@@ -268,6 +285,12 @@ mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height)
     c->rc.assign(n, MVS_OK);
     c->msg.resize(n);
     c->meet.n = n;
+    c->peer.assign(n, 1);
+    c->gather_stream.assign(n, nullptr);
+    c->stage.resize(n);
+    c->staged.assign(n, std::array<hipEvent_t, 2>{{nullptr, nullptr}});
+    c->sent.assign(n, std::array<hipEvent_t, 2>{{nullptr, nullptr}});
+    c->sent_valid.assign(n, std::array<bool, 2>{{false, false}});
     // before anything touches a GPU (the error path of a missing library must not need one).  Only the view-sharded modes need RCCL:
     // a library named explicitly must load; the default one may be absent -- rows mode works without, a views mode then says why not
     if (!c->rccl.load(hooks.rccl_library) && !hooks.rccl_library.empty()) {
@@ -285,6 +308,30 @@ mvs_comm *mvs_comm_create(const int *devices, int n, int width, int height)
         c->ctx.push_back(x);
     }
     snprintf(c->err, sizeof(c->err), "no error");
+    // Peer access rank r <-> rank 0, both directions: the resident rows mode sends every band to rank 0 with hipMemcpyPeerAsync, which is a
+    // GPU-to-GPU transfer over xGMI only when the two devices may address each other -- otherwise the runtime bounces the band through host
+    // memory, silently.  Enabled here once ("already enabled" -- by this process's PyTorch, say -- is fine), the outcome kept per rank
+    // (mvs_comm_peer_access) and named in mvs_comm_last_error right after creation; nothing is refused: a staged band is slow, not wrong.
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
+    std::string staged_ranks;
+    for (int r = 1; r < n; r++) {
+        if (devices[r] == devices[0]) continue;
+        int can_r0 = 0, can_0r = 0;
+        bool ok = hipDeviceCanAccessPeer(&can_r0, devices[r], devices[0]) == hipSuccess && hipDeviceCanAccessPeer(&can_0r, devices[0], devices[r]) == hipSuccess && can_r0 && can_0r;
+        for (int dir = 0; dir < 2 && ok; dir++) {
+            const int from = dir ? devices[0] : devices[r], to = dir ? devices[r] : devices[0];
+            const hipError_t e = hipSetDevice(from) == hipSuccess ? hipDeviceEnablePeerAccess(to, 0) : hipErrorInvalidDevice;
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+            (void)hipGetLastError();  // ("already enabled" is sticky otherwise)
+        }
+        c->peer[r] = ok ? 1 : 0;
+        if (!ok) staged_ranks += (staged_ranks.empty() ? "" : ", ") + std::to_string(r);
+    }
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    if (!staged_ranks.empty())
+        snprintf(c->err, sizeof(c->err), "note: no peer access between rank 0 (device %d) and rank(s) %s: the resident rows mode's band copies are staged through host memory",
+                 devices[0], staged_ranks.c_str());
     return c;
 }
 
@@ -316,6 +363,19 @@ void mvs_comm_destroy(mvs_comm *c)
             (void)hipStreamDestroy(c->comm_stream[i]);
         }
         for (hipEvent_t e : c->events[i]) (void)hipEventDestroy(e);
+        if (c->gather_stream[i]) {
+            (void)hipStreamSynchronize(c->gather_stream[i]);
+            (void)hipStreamDestroy(c->gather_stream[i]);
+        }
+        for (int k = 0; k < 2; k++) {
+            if (c->stage[i][k].ptr) (void)hipFree(c->stage[i][k].ptr);
+            if (c->staged[i][k]) (void)hipEventDestroy(c->staged[i][k]);
+            if (c->sent[i][k]) (void)hipEventDestroy(c->sent[i][k]);
+        }
+        if (i == 0)
+            for (auto &pair : c->result)
+                for (DevBuf &b : pair)
+                    if (b.ptr) (void)hipFree(b.ptr);
     }
     for (ncclComm_t k : c->comms)
         if (k && !c->broken && c->rccl.CommDestroy) (void)c->rccl.CommDestroy(k);  // (aborted communicators are already gone)
@@ -324,6 +384,8 @@ void mvs_comm_destroy(mvs_comm *c)
 }
 
 int mvs_comm_size(const mvs_comm *c) { return c ? c->n : MVS_EINVAL; }
+int mvs_comm_peer_access(const mvs_comm *c, int rank) { return (c && rank >= 0 && rank < c->n) ? c->peer[rank] : MVS_EINVAL; }
+int mvs_comm_device(const mvs_comm *c, int rank) { return (c && rank >= 0 && rank < c->n) ? c->devices[rank] : MVS_EINVAL; }
 mvs_ctx *mvs_comm_context(mvs_comm *c, int rank) { return (c && rank >= 0 && rank < c->n) ? c->ctx[rank] : nullptr; }
 const char *mvs_comm_last_error(const mvs_comm *c) { return c ? c->err : g_comm_err; }
 
@@ -359,7 +421,9 @@ static int comm_execute(mvs_comm *c, const Job &job)
     const int nviews = job.set_views ? job.nviews : c->V;
     const int nplanes = job.set_planes ? job.nplanes : c->D;
     const bool exchange = job.run && !rows;                                       // RCCL collectives
-    const bool gather = job.run && rows && !job.depth_hw && !job.cost_hw && n > 1;  // rows, resident: the bands travel to rank 0 by peer copies
+    const bool queued = job.run && rows && job.async_slot >= 0;                   // mvs_comm_run_async: launches only, nobody waits for a GPU
+    const bool gather = job.run && rows && !job.depth_hw && !job.cost_hw && (n > 1 || queued);  // rows, resident: the bands travel to rank 0 by peer copies
+    const int slot = job.async_slot;
     if (exchange) {
         const int e = comm_init_rccl(c, job.who);
         if (e) return e;
@@ -423,8 +487,37 @@ static int comm_execute(mvs_comm *c, const Job &job)
             if (lv0 < 0 || lv0 + vn > c->res_vn[r])
                 return fail_here(MVS_ESTATE, job.who, "this rank does not hold the views the mode needs (uploaded by mvs_sweep_sharded under another mode): call mvs_comm_set_views");
             if (rows) {
+                if (gather && (x->depth.bytes < P * 4 || x->cost.bytes < P * 4)) {
+                    // first resident run: the maps are allocated (and, under the poison hook, filled) HERE and the fill waited for, so that nothing
+                    // whole-map is ever queued on rank 0's stream behind the meet -- a later fill would land on top of the other ranks' bands
+                    if ((e = ensure(x, x->depth, P * 4)) || (e = ensure(x, x->cost, P * 4)) || (e = mvs_synchronize(x))) return fail_here(e, "device allocation", mvs_last_error(x));
+                }
+                if (queued) {
+                    if (!c->gather_stream[r] && hipStreamCreateWithFlags(&c->gather_stream[r], hipStreamNonBlocking) != hipSuccess) return fail_here(MVS_EHIP, "hipStreamCreate", "failed");
+                    for (hipEvent_t *ev : {&c->staged[r][slot], &c->sent[r][slot]})
+                        if (!*ev && hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) return fail_here(MVS_EHIP, "hipEventCreate", "failed");
+                    if (r == 0)
+                        for (DevBuf &b : c->result[slot])
+                            if (b.bytes < P * 4) {
+                                if ((e = ensure(x, b, P * 4)) || (e = mvs_synchronize(x))) return fail_here(e, "device allocation", mvs_last_error(x));
+                            }
+                    if (r > 0 && rn > 0 && c->stage[r][slot].bytes < (size_t)rn * W * 8) {
+                        if ((e = ensure(x, c->stage[r][slot], (size_t)rn * W * 8)) || (e = mvs_synchronize(x))) return fail_here(e, "device allocation", mvs_last_error(x));
+                    }
+                    // the slot's staging buffer is free again when the band of the call two back has landed (a wait on the GPU, not the host)
+                    if (c->sent_valid[r][slot] && r > 0 && hipStreamWaitEvent(st, c->sent[r][slot], 0) != hipSuccess) return fail_here(MVS_EHIP, "hipStreamWaitEvent", "failed");
+                }
                 if (rn > 0) {
                     if ((e = mvs_sweep_run_rows(x, 0, nviews, r0, rn, MVS_SWEEP_FUSED_ARGMIN | (job.run_flags & MVS_SWEEP_VOLUME)))) return fail_here(e, "mvs_sweep_run_rows", mvs_last_error(x));
+                    if (queued && r > 0) {
+                        // the band leaves the context's maps at once (a device copy of 8 bytes per band pixel): the next call's sweep may overwrite them
+                        float *sd = (float *)c->stage[r][slot].ptr;
+                        const size_t off = (size_t)r0 * W, cells = (size_t)rn * W;
+                        if (hipMemcpyAsync(sd, (const float *)x->depth.ptr + off, cells * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                            hipMemcpyAsync(sd + cells, (const float *)x->cost.ptr + off, cells * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                            hipEventRecord(c->staged[r][slot], st) != hipSuccess)
+                            return fail_here(MVS_EHIP, "hipMemcpyAsync", "band to its staging buffer");
+                    }
                     // the one-call form: the band goes straight into the caller's maps: 4 bytes per pixel and map, no collective
                     if (job.depth_hw && hipMemcpyAsync(job.depth_hw + (size_t)r0 * W, (const float *)x->depth.ptr + (size_t)r0 * W, (size_t)rn * W * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
                         return fail_here(MVS_EHIP, "hipMemcpyAsync", "depth band");
@@ -460,9 +553,32 @@ static int comm_execute(mvs_comm *c, const Job &job)
             return;
         }
         int e;
+        if (queued) {
+            // mvs_comm_run_async: rank 0 copies its own band into the slot's result pair behind its sweep; every other rank sends its staged band
+            // there on its gather stream -- beside the NEXT call's sweep on the rank's main stream.  Nobody waits: mvs_comm_wait does.
+            float *rd = (float *)c->result[slot][0].ptr, *rc_ = (float *)c->result[slot][1].ptr;
+            const size_t off = (size_t)r0 * W, cells = (size_t)rn * W;
+            if (rn > 0 && r == 0) {
+                if (hipMemcpyAsync(rd + off, (const float *)x->depth.ptr + off, cells * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                    hipMemcpyAsync(rc_ + off, (const float *)x->cost.ptr + off, cells * 4, hipMemcpyDeviceToDevice, st) != hipSuccess || hipEventRecord(c->sent[r][slot], st) != hipSuccess)
+                    fail_here(MVS_EHIP, "hipMemcpyAsync", "rank 0's band to the result maps");
+                else
+                    c->sent_valid[r][slot] = true;
+            } else if (rn > 0) {
+                hipStream_t gs = c->gather_stream[r];
+                const float *sd = (const float *)c->stage[r][slot].ptr;
+                if (hipStreamWaitEvent(gs, c->staged[r][slot], 0) != hipSuccess ||
+                    hipMemcpyPeerAsync(rd + off, c->devices[0], sd, c->devices[r], cells * 4, gs) != hipSuccess ||
+                    hipMemcpyPeerAsync(rc_ + off, c->devices[0], sd + cells, c->devices[r], cells * 4, gs) != hipSuccess || hipEventRecord(c->sent[r][slot], gs) != hipSuccess)
+                    fail_here(MVS_EHIP, "hipMemcpyPeerAsync", "band to rank 0");
+                else
+                    c->sent_valid[r][slot] = true;
+            }
+            return;
+        }
         if (gather) {
-            // rows, resident: rank 0's maps exist (its launch is queued) and every other rank copies its band into them over xGMI -- a peer
-            // copy on the rank's own stream behind its sweep; 4 bytes per pixel and map in total, no collective, no host memory
+            // rows, resident: rank 0's maps exist (allocated and filled before the meet) and every other rank copies its band into them over xGMI -- a
+            // peer copy on the rank's own stream behind its sweep; 4 bytes per pixel and map in total, no collective, no host memory
             if (r > 0 && rn > 0) {
                 mvs_ctx *x0 = c->ctx[0];
                 const size_t off = (size_t)r0 * W, bytes = (size_t)rn * W * 4;
@@ -526,7 +642,12 @@ static int comm_execute(mvs_comm *c, const Job &job)
             fail_here(e, "mvs_synchronize", mvs_last_error(x));
         }
     };
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);   // rank 0's share runs on the calling thread and selects rank 0's device: put the caller's back afterwards
     c->ranks.dispatch(n, worker);
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    // new inputs: the maps on rank 0 belong to a view that is no longer resident -- a fetch before the next run must not return them as current
+    if (job.set_planes || job.main_hw || job.set_views) c->have_result = false;
     // what the ranks hold now (a failed upload leaves the communicator without that input, like a context)
     bool ok = true;
     for (int r = 0; r < n; r++) ok = ok && c->rc[r] == MVS_OK;
@@ -542,7 +663,10 @@ static int comm_execute(mvs_comm *c, const Job &job)
         c->have_views = ok;
         c->V = job.nviews;
     }
-    if (job.run) c->have_result = ok;
+    if (job.run && !queued) {
+        c->have_result = ok;
+        c->result_slot = -1;
+    }
     for (int r = 0; r < n; r++)
         if (c->rc[r] != MVS_OK) return comm_fail(c, c->rc[r], "%s: rank %d (device %d): %s", job.who, r, c->devices[r], c->msg[r].c_str());
     return MVS_OK;
@@ -565,6 +689,7 @@ int mvs_sweep_sharded(mvs_comm *c, const float main_cam[16], const uint8_t *main
 {
     if (!c) return MVS_EINVAL;
     if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_sweep_sharded: the communicators were aborted after a failed collective; create a new mvs_comm");
+    if (!c->pending.empty()) return comm_fail(c, MVS_ESTATE, "mvs_sweep_sharded: %d call(s) of mvs_comm_run_async in flight: mvs_comm_wait first", (int)c->pending.size());
     if (!main_cam || !main_hw || !depth_hw || nviews < 0 || (nviews > 0 && (!side_cams || !side_frames)))
         return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: null argument");
     if (nplanes < 1 || nplanes > 4096) return comm_fail(c, MVS_EINVAL, "mvs_sweep_sharded: nplanes=%d out of range 1..4096", nplanes);
@@ -596,6 +721,7 @@ int mvs_comm_set_planes(mvs_comm *c, int nplanes, float z_lo, float z_hi)
 {
     if (!c) return MVS_EINVAL;
     if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_comm_set_planes: the communicators were aborted after a failed collective; create a new mvs_comm");
+    if (!c->pending.empty()) return comm_fail(c, MVS_ESTATE, "mvs_comm_set_planes: %d call(s) of mvs_comm_run_async in flight: mvs_comm_wait first", (int)c->pending.size());
     if (nplanes < 1 || nplanes > 4096) return comm_fail(c, MVS_EINVAL, "mvs_comm_set_planes: nplanes=%d out of range 1..4096", nplanes);
     Job job;
     job.who = "mvs_comm_set_planes";
@@ -610,6 +736,7 @@ int mvs_comm_set_main(mvs_comm *c, const float main_cam[16], const uint8_t *main
 {
     if (!c) return MVS_EINVAL;
     if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_comm_set_main: the communicators were aborted after a failed collective; create a new mvs_comm");
+    if (!c->pending.empty()) return comm_fail(c, MVS_ESTATE, "mvs_comm_set_main: %d call(s) of mvs_comm_run_async in flight: mvs_comm_wait first", (int)c->pending.size());
     if (!main_cam || !main_hw) return comm_fail(c, MVS_EINVAL, "mvs_comm_set_main: null argument");
     Job job;
     job.who = "mvs_comm_set_main";
@@ -622,6 +749,7 @@ int mvs_comm_set_views(mvs_comm *c, int nviews, const float *side_cams, const ui
 {
     if (!c) return MVS_EINVAL;
     if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_comm_set_views: the communicators were aborted after a failed collective; create a new mvs_comm");
+    if (!c->pending.empty()) return comm_fail(c, MVS_ESTATE, "mvs_comm_set_views: %d call(s) of mvs_comm_run_async in flight: mvs_comm_wait first", (int)c->pending.size());
     if (nviews < 0 || (nviews > 0 && (!side_cams || !side_frames))) return comm_fail(c, MVS_EINVAL, "mvs_comm_set_views: null argument");
     if (!c->have_main) return comm_fail(c, MVS_ESTATE, "mvs_comm_set_views: call mvs_comm_set_main first");
     for (int v = 0; v < nviews; v++)
@@ -641,6 +769,7 @@ int mvs_comm_run(mvs_comm *c, unsigned flags)
 {
     if (!c) return MVS_EINVAL;
     if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_comm_run: the communicators were aborted after a failed collective; create a new mvs_comm");
+    if (!c->pending.empty()) return comm_fail(c, MVS_ESTATE, "mvs_comm_run: %d call(s) of mvs_comm_run_async in flight: mvs_comm_wait first", (int)c->pending.size());
     if (!c->have_main || !c->have_views || !c->have_planes)
         return comm_fail(c, MVS_ESTATE, "mvs_comm_run: set planes, main view and side views first (mvs_comm_set_planes / _set_main / _set_views)");
     if (flags & ~(unsigned)MVS_SWEEP_VOLUME) return comm_fail(c, MVS_EINVAL, "mvs_comm_run: flags may only carry MVS_SWEEP_VOLUME");
@@ -653,16 +782,78 @@ int mvs_comm_run(mvs_comm *c, unsigned flags)
     return comm_execute(c, job);
 }
 
+int mvs_comm_run_async(mvs_comm *c, unsigned flags)
+{
+    if (!c) return MVS_EINVAL;
+    if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_comm_run_async: the communicators were aborted after a failed collective; create a new mvs_comm");
+    if (!c->have_main || !c->have_views || !c->have_planes)
+        return comm_fail(c, MVS_ESTATE, "mvs_comm_run_async: set planes, main view and side views first (mvs_comm_set_planes / _set_main / _set_views)");
+    if (flags) return comm_fail(c, MVS_EINVAL, "mvs_comm_run_async: flags must be 0");
+    if (c->pending.size() >= 2) return comm_fail(c, MVS_ESTATE, "mvs_comm_run_async: two calls are in flight already: mvs_comm_wait for the older one first");
+    if (!c->pending.empty() && (c->mode != MVS_SHARD_ROWS || c->pending.front() < 0))
+        return comm_fail(c, MVS_ESTATE, "mvs_comm_run_async: only MVS_SHARD_ROWS keeps two calls in flight (a view-sharded call completes inside mvs_comm_run_async): mvs_comm_wait first");
+    int e = comm_check_views(c, "mvs_comm_run_async", c->V);
+    if (e) return e;
+    Job job;
+    job.who = "mvs_comm_run_async";
+    job.run = true;
+    if (c->mode == MVS_SHARD_ROWS) {
+        job.async_slot = (int)(c->issued & 1);
+        if ((e = comm_execute(c, job))) return e;
+        c->pending.push_back(job.async_slot);
+    } else {
+        // the view-sharded modes end in collectives every rank thread has to drive: they run to completion here (documented: include/mvs.h)
+        if ((e = comm_execute(c, job))) return e;
+        c->have_result = false;
+        c->pending.push_back(-1);
+    }
+    c->issued++;
+    return MVS_OK;
+}
+
+int mvs_comm_wait(mvs_comm *c)
+{
+    if (!c) return MVS_EINVAL;
+    if (c->pending.empty()) return comm_fail(c, MVS_ESTATE, "mvs_comm_wait: no call in flight (mvs_comm_run_async)");
+    const int slot = c->pending.front();
+    c->pending.pop_front();
+    if (slot >= 0)
+        for (int r = 0; r < c->n; r++)
+            if (c->sent_valid[r][slot]) {
+                const hipError_t q = hipEventSynchronize(c->sent[r][slot]);
+                if (q != hipSuccess) {
+                    c->have_result = false;
+                    return comm_fail(c, MVS_EHIP, "mvs_comm_wait: rank %d (device %d): %s", r, c->devices[r], hipGetErrorString(q));
+                }
+            }
+    c->result_slot = slot;
+    c->have_result = true;
+    return MVS_OK;
+}
+
+int mvs_comm_pending(const mvs_comm *c) { return c ? (int)c->pending.size() : MVS_EINVAL; }
+
 int mvs_comm_fetch(mvs_comm *c, float *depth_hw, float *cost_hw)
 {
     if (!c) return MVS_EINVAL;
-    if (!c->have_result) return comm_fail(c, MVS_ESTATE, "mvs_comm_fetch: no result yet (mvs_comm_run)");
-    // rank 0 alone: its context holds the maps of the whole view
+    if (c->broken) return comm_fail(c, MVS_ESTATE, "mvs_comm_fetch: the communicators were aborted after a failed collective; create a new mvs_comm");
+    if (!c->have_result) return comm_fail(c, MVS_ESTATE, "mvs_comm_fetch: no result yet (mvs_comm_run, or mvs_comm_run_async + mvs_comm_wait), or new inputs were set since");
+    // rank 0 alone: its context (or, after mvs_comm_wait, the waited call's result pair on its device) holds the maps of the whole view
     mvs_ctx *x = c->ctx[0];
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
     if (hipSetDevice(c->devices[0]) != hipSuccess) return comm_fail(c, MVS_EHIP, "mvs_comm_fetch: hipSetDevice failed");
-    const int e = mvs_sweep_fetch(x, depth_hw, cost_hw, nullptr, nullptr);
-    if (e) return comm_fail(c, e, "mvs_comm_fetch: %s", mvs_last_error(x));
-    return MVS_OK;
+    int e = MVS_OK;
+    if (c->result_slot >= 0) {
+        const size_t bytes = (size_t)c->W * c->H * 4;
+        if ((depth_hw && hipMemcpy(depth_hw, c->result[c->result_slot][0].ptr, bytes, hipMemcpyDeviceToHost) != hipSuccess) ||
+            (cost_hw && hipMemcpy(cost_hw, c->result[c->result_slot][1].ptr, bytes, hipMemcpyDeviceToHost) != hipSuccess))
+            e = comm_fail(c, MVS_EHIP, "mvs_comm_fetch: hipMemcpy of the result maps failed");
+    } else if ((e = mvs_sweep_fetch(x, depth_hw, cost_hw, nullptr, nullptr))) {
+        e = comm_fail(c, e, "mvs_comm_fetch: %s", mvs_last_error(x));
+    }
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    return e;
 }
 
 }  // extern "C"

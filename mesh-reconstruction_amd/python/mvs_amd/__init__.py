@@ -103,6 +103,11 @@ ABI = [
     ("mvs_comm_set_views", _i, [_vp, _i, _fp, C.POINTER(_u8p)]),
     ("mvs_comm_run", _i, [_vp, C.c_uint]),
     ("mvs_comm_fetch", _i, [_vp, _fp, _fp]),
+    ("mvs_comm_run_async", _i, [_vp, C.c_uint]),
+    ("mvs_comm_wait", _i, [_vp]),
+    ("mvs_comm_pending", _i, [_vp]),
+    ("mvs_comm_peer_access", _i, [_vp, _i]),
+    ("mvs_comm_device", _i, [_vp, _i]),
     ("mvs_sweep_set_plan_cache", _i, [_vp, _i]),
     ("mvs_sweep_sharded", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _f, _f, _fp, _fp]),
     ("mvs_profile_enable", _i, [_vp, _i]),
@@ -441,6 +446,27 @@ class Comm:
     def run(self, flags=0):
         """one sweep of what is resident in the current mode; the maps stay on rank 0's GPU (mvs_comm_run)"""
         self._check(self.lib.mvs_comm_run(self.h, int(flags)))
+
+    def run_async(self):
+        """queue one sweep of what is resident (mvs_comm_run_async): up to two in flight in rows mode; wait() publishes the oldest"""
+        self._check(self.lib.mvs_comm_run_async(self.h, 0))
+
+    def wait(self):
+        self._check(self.lib.mvs_comm_wait(self.h))
+
+    def pending(self):
+        return self.lib.mvs_comm_pending(self.h)
+
+    def peer_access(self):
+        """per rank: 1 = its band copies travel GPU to GPU to rank 0, 0 = staged through host memory (mvs_comm_peer_access)"""
+        return [self.lib.mvs_comm_peer_access(self.h, r) for r in range(self.size())]
+
+    def devices(self):
+        return [self.lib.mvs_comm_device(self.h, r) for r in range(self.size())]
+
+    def note(self):
+        """mvs_comm_last_error: after creation, "no error" or the note naming ranks without peer access"""
+        return self.lib.mvs_comm_last_error(self.h).decode()
 
     def fetch(self, want_cost=True):
         depth = np.empty((self.H, self.W), np.float32)

@@ -87,6 +87,13 @@ def test_bench_line_contract_and_two_rank_shardings():
     assert "roofline_traffic" in ext["general_camera_path"]
     # side cameras that are translations of the main one (any direction): the same kernel's separable path, faster than its general form
     assert 0 < ext["general_camera_path"]["translation_only_cameras_ms_per_step"] < ext["general_camera_path"]["ms_per_step"]
+    # the flow block: Farneback returns the pair's known shift at every size it reports (round 5 timed a pair it returned nothing on)
+    for name, f in ext["flow"].items():
+        if name.startswith("farneback"):
+            assert f["recovered_fraction"] >= 0.70 and f["epe_vs_known_shift"] < 0.35 * (f["known_shift_px"][0] ** 2 + f["known_shift_px"][1] ** 2) ** 0.5, (name, f)
+            assert 0 < f["fused_floor_bytes"] < f["algorithmic_bytes"] and 0 < f["frac_fused_floor"] < f["frac"] < 1
+        elif name.startswith("variational"):
+            assert 0 < f["recovered_fraction"] < 1 and f["device_ms"] > 0
 
 
 def test_via_comm_line():

@@ -207,3 +207,87 @@ def test_every_mode_at_c4_size(loopback, n):
         d, c = comm.sweep(main_cam, main_img, side_cams, sides, D)
         np.testing.assert_array_equal(d, d1)
         np.testing.assert_array_equal(c, c1)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n", [1, 2, 8])
+def test_two_calls_in_flight_keep_their_results_apart(loopback, n, monkeypatch):
+    """mvs_comm_run_async / mvs_comm_wait (rows mode): view A queued, view B uploaded and queued while A may still be travelling, then the
+    waits publish A and B in order -- each equal to the single-GPU sweep of its own view (two result pairs on rank 0, a staging copy per rank
+    and slot).  Under the poison hook every fresh allocation is 0xFF-filled on its stream: a fill that could land after a band would show."""
+    monkeypatch.setenv("MVS_POISON_ALLOC", "1")
+    W, H, D, V = 640, 360, 48, 6
+    main_cam, main_img, side_cams, sides, dA, cA = _scene(W, H, D, V)
+    with mvs_amd.Context(W, H) as ctx:
+        dB, cB = ctx.sweep(side_cams[0], sides[0], side_cams[1:5], sides[1:5], D, want_cost=True)
+    with mvs_amd.Comm([0] * n, W, H) as comm:
+        assert comm.peer_access() == [1] * n and comm.devices() == [0] * n and comm.note() == "no error"
+        comm.set(main_cam, main_img, side_cams, sides, D)
+        with pytest.raises(mvs_amd.MvsError, match="no call in flight"):
+            comm.wait()
+        comm.run_async()
+        comm.run_async()
+        assert comm.pending() == 2
+        with pytest.raises(mvs_amd.MvsError, match="two calls are in flight"):
+            comm.run_async()
+        with pytest.raises(mvs_amd.MvsError, match="in flight"):
+            comm.run()
+        with pytest.raises(mvs_amd.MvsError, match="in flight"):
+            comm.set(main_cam, main_img, side_cams, sides, D)
+        comm.wait()
+        d, c = comm.fetch()
+        np.testing.assert_array_equal(d, dA)
+        np.testing.assert_array_equal(c, cA)
+        comm.wait()
+        assert comm.pending() == 0
+        # A in flight; B uploaded (the upload waits for A's sweeps, not for A's bands), B queued; results published in order
+        comm.run_async()
+        comm.wait()
+        comm.run_async()                                                      # A again, in flight while ...
+        comm.wait()
+        comm.set(side_cams[0], sides[0], side_cams[1:5], sides[1:5], D)       # ... new inputs: the old maps are no longer "the result"
+        with pytest.raises(mvs_amd.MvsError, match="no result yet"):
+            comm.fetch()
+        comm.run_async()
+        comm.run_async()
+        comm.wait()
+        d, c = comm.fetch()
+        np.testing.assert_array_equal(d, dB)
+        np.testing.assert_array_equal(c, cB)
+        comm.wait()
+        np.testing.assert_array_equal(comm.fetch()[0], dB)
+        # many calls back to back, two in flight throughout
+        comm.run_async()
+        for _ in range(20):
+            comm.run_async()
+            comm.wait()
+        comm.wait()
+        np.testing.assert_array_equal(comm.fetch()[0], dB)
+        # the synchronous call still works afterwards and publishes rank 0's context maps
+        comm.run()
+        np.testing.assert_array_equal(comm.fetch()[0], dB)
+        # a view-sharded mode completes inside run_async: one in flight, wait publishes it
+        if n > 1:
+            comm.set_mode("views", 2)
+            comm.run_async()
+            with pytest.raises(mvs_amd.MvsError, match="only MVS_SHARD_ROWS"):
+                comm.run_async()
+            comm.wait()
+            d, c = comm.fetch()
+            np.testing.assert_array_equal(d, dB)
+            np.testing.assert_array_equal(c, cB)
+
+
+def test_a_sync_resident_run_under_the_poison_hook(loopback, monkeypatch):
+    """rank 0's maps are allocated -- and, under MVS_POISON_ALLOC, filled -- before the ranks meet, so no whole-map fill can land
+    on rank 0's stream behind another rank's band copy on the first resident run"""
+    monkeypatch.setenv("MVS_POISON_ALLOC", "1")
+    W, H, D, V = 640, 360, 48, 6
+    main_cam, main_img, side_cams, sides, dA, cA = _scene(W, H, D, V)
+    for _ in range(3):
+        with mvs_amd.Comm([0] * 8, W, H) as comm:
+            comm.set(main_cam, main_img, side_cams, sides, D)
+            comm.run()
+            d, c = comm.fetch()
+            np.testing.assert_array_equal(d, dA)
+            np.testing.assert_array_equal(c, cA)
