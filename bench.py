@@ -443,6 +443,25 @@ def run_via_comm(args, same_device):
                 if mode == "rows":
                     raise
                 results[mode] = {"error": str(e)}
+        # rows mode once more with two calls in flight (mvs_comm_run_async / mvs_comm_wait): the bands of call k travel to rank 0 beside the sweep
+        # of call k + 1; the timed region ends when every call has been waited for
+        comm.set_mode("rows")
+        for _ in range(CLOCK_RAMP_STEPS + args.warmup):
+            comm.run_async()
+            comm.wait()
+        t0 = time.perf_counter()
+        comm.run_async()
+        for _ in range(args.steps - 1):
+            comm.run_async()
+            comm.wait()
+        comm.wait()
+        dt = time.perf_counter() - t0
+        crc = zlib.crc32(np.ascontiguousarray(comm.fetch(want_cost=False)).tobytes())
+        if crc != crc1:
+            raise SystemExit("via-comm rows_async: depth crc %08x, the single-GPU sweep of the same view %08x" % (crc, crc1))
+        results["rows_async"] = {"ms_per_step": dt / args.steps * 1e3, "samples_per_s": float(P) * D * V / (dt / args.steps), "depth_crc32": crc,
+                                 "bytes_between_gpus_per_step": 8.0 * P * (N - 1) / N, "in_flight": 2}
+        peer_access, comm_devices, comm_note = comm.peer_access(), comm.devices(), comm.note()
     rows = results["rows"]
     rows_alg_bytes = float(min(band, H)) * W * (V + 8.0 * D + 9.0)   # rank 0's band, SURVEY 8(d)
     achieved = rows_alg_bytes / (rows["ms_per_step"] * 1e-3) / 1e9
@@ -455,6 +474,8 @@ def run_via_comm(args, same_device):
                    "entry": "mvs_comm_set_* + mvs_comm_run (include/mvs.h): one process, %d rank threads, inputs resident; each timed call returns when every "
                             "rank has finished and -- rows mode -- its band of the depth and cost maps is on GPU 0 (peer copies, no collective)" % N,
                    "shard": "rows", "rows_per_rank": band, "modes": results, "upload_all_ranks_ms": upload_ms,
+                   "peer_access": peer_access, "devices": comm_devices, "peer_access_note": "mvs_comm_peer_access per rank: 1 = its band copies to rank 0 travel GPU to GPU, 0 = staged "
+                   "through host memory; mvs_comm_create says: " + comm_note,
                    "single_gpu_resident_ms_per_step": single_ms, "speedup_vs_single_gpu_in_process": single_ms / rows["ms_per_step"], "device": info},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "bytes_per_launch": rows_alg_bytes, "bytes_formula": "P_band (V + 8 D + 9), SURVEY.md 8(d): rank 0's row band",
@@ -489,10 +510,138 @@ def via_comm_child(args, timeout_s):
             return {"error": "exit code %d: %s" % (child.returncode, (se or so)[-600:])}
         rec = json.loads(lines[0])
         return {"ms_per_step": rec["ms_per_step"], "samples_per_s": rec["value"], "entry": rec["config"]["entry"], "modes": rec["config"]["modes"],
+                "peer_access": rec["config"].get("peer_access"), "devices": rec["config"].get("devices"),
                 "single_gpu_resident_ms_per_step": rec["config"]["single_gpu_resident_ms_per_step"],
                 "speedup_vs_single_gpu_in_process": rec["config"]["speedup_vs_single_gpu_in_process"], "depth_crc32": rec["depth_crc32"], "data": rec["data"]}
     except Exception as e:   # never let this block cost the line
         return {"error": repr(e)}
+
+
+def device_identity(torch, index):
+    """what tells two GPUs apart, as far as this torch exposes it: PCI domain:bus:device, UUID, name; and whether `index` may address device 0"""
+    props = torch.cuda.get_device_properties(index)
+    pci = None
+    if all(hasattr(props, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        pci = "%04x:%02x:%02x" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+    try:
+        peer = bool(torch.cuda.can_device_access_peer(index, 0)) if index != 0 else True
+    except Exception:
+        peer = None
+    return {"local_index": int(index), "pci_bus_id": pci, "uuid": str(getattr(props, "uuid", "")) or None, "name": props.name, "peer_access_to_device0": peer}
+
+
+def overlapped_rows_step(ctx, depth_t, bands, rank, world, W, V, flags, dist, torch, stream, comm_stream, overlap):
+    """The rows-mode step of the torch.distributed path: this rank's band of the main view swept (volume band materialised, depth selected in the
+    kernel), the depth rows all-gathered.  Consecutive steps are independent main views, so the exchange of step k runs beside the sweep of step
+    k + 1: the band is copied into one of two staging buffers on the compute stream, the all-gather of that buffer goes to the communication
+    stream behind an event, and a buffer is reused only when its previous collective has completed.  `overlap` False keeps round 4's form (the
+    collective on the compute stream).  Returns (step, finish, tallest): finish() waits for everything and returns the gathered depth map."""
+    r0, rn = bands[rank]
+    tallest = max(n for _, n in bands)
+    H = sum(n for _, n in bands)
+    band_pad = [torch.zeros((tallest, W), dtype=torch.float32, device="cuda") for _ in range(2)]
+    band_cat = [torch.empty((world * tallest, W), dtype=torch.float32, device="cuda") for _ in range(2)]   # concatenated form: every backend
+    mine = depth_t[r0:r0 + tallest] if rn == tallest else band_pad[0]
+    state = {"k": 0, "work": [None, None]}
+
+    def step():
+        k = state["k"] & 1
+        state["k"] += 1
+        if not overlap:
+            ctx.sweep_run_rows(r0, rn, 0, V, flags)
+            if rn != tallest and rn:
+                band_pad[0][:rn].copy_(depth_t[r0:r0 + rn])
+            dist.all_gather_into_tensor(band_cat[0], mine)
+            return
+        if state["work"][k] is not None:
+            state["work"][k].wait()          # the collective that last used these two buffers (two steps ago) has completed
+        ctx.sweep_run_rows(r0, rn, 0, V, flags)
+        if rn:
+            band_pad[k][:rn].copy_(depth_t[r0:r0 + rn])
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        comm_stream.wait_event(ev)
+        with torch.cuda.stream(comm_stream):
+            state["work"][k] = dist.all_gather_into_tensor(band_cat[k], band_pad[k], async_op=True)
+
+    def finish():   # (called once, before the depth map of the last step is read)
+        for w_ in state["work"]:
+            if w_ is not None:
+                w_.wait()
+        torch.cuda.synchronize()
+        return band_cat[(state["k"] - 1) & 1 if overlap else 0][:H].cpu().numpy()
+    return step, finish, tallest
+
+
+C4_CONFIG = (3840, 2160, 256, 32)
+
+
+def c4_rows_block(args, rank, local_rank, world, dist, torch, np, mvs_amd, synth, mdist, stream, comm_stream):
+    """BASELINE config 4 (3840 x 2160, 256 planes, 32 side views) in rows mode on the same N ranks, beside the c3 headline: every rank holds all
+    views, sweeps its band, the depth rows are all-gathered beside the next step's sweep -- the same step as the headline's.  Noise frames (the
+    4K scene takes minutes to ray-cast on the host; the sweep's time does not depend on the image content), the gathered depth map checked (CRC)
+    against rank 0's in-process single-GPU sweep of the whole view, which is also the T1 of `speedup`.  Returns the block on rank 0, None elsewhere."""
+    W, H, D, V = C4_CONFIG
+    P = W * H
+    both = mvs_amd.MVS_SWEEP_VOLUME | mvs_amd.MVS_SWEEP_FUSED_ARGMIN
+    steps = max(5, args.steps // 4)
+    main_cam, main_img, side_cams, sides = synth.noise_views(W, H, V, seed=synth.SEED_NOISE)
+    try:
+        ctx = mvs_amd.Context(W, H, local_rank, sampler=args.sampler)
+        ctx.set_stream(stream.cuda_stream)
+        ctx.sweep_set(main_cam, main_img, side_cams, sides, D)
+        bands = mdist.equal_row_bands(H, world, ctx.row_granularity())
+        tallest = max(n for _, n in bands)
+        # the volume: the whole view's on rank 0 (its single-GPU reference run), a band's elsewhere would do -- but a context sweeps rows of ITS volume,
+        # so every rank takes the whole 8.5 GB (288 GB per GPU)
+        vol_t = torch.empty(D * P, dtype=torch.int32, device="cuda")
+        ctx.sweep_use_volume(vol_t.data_ptr(), vol_t.numel() * 4)
+        ctx.sweep_run(0, V, both)
+        depth1 = ctx.sweep_fetch()[0]
+        crc1 = zlib.crc32(np.ascontiguousarray(depth1).tobytes())
+        for _ in range(3):
+            ctx.sweep_run(0, V, both)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.sweep_run(0, V, both)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t0) / steps * 1e3
+        depth_t = torch.as_tensor(ctx.depth_device_array(), device="cuda")
+        step, finish, _ = overlapped_rows_step(ctx, depth_t, bands, rank, world, W, V, both, dist, torch, stream, comm_stream, not args.no_overlap)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt, single_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, single_max = float(t[0].item()), float(t[1].item())
+        crc = zlib.crc32(np.ascontiguousarray(finish()).tobytes())
+        ctx.close()
+        del vol_t, depth_t
+        torch.cuda.empty_cache()
+        if crc != crc1:
+            raise SystemExit("rank %d: c4 rows sharding produced depth crc %08x, the single-GPU sweep of the same view %08x" % (rank, crc, crc1))
+        if rank != 0:
+            return None
+        ms = dt / steps * 1e3
+        return {"workload": "c4: %dx%d, %d planes, %d side views" % (W, H, D, V), "data": "synthetic (noise)", "shard": "rows", "scaling": "strong", "steps": steps,
+                "ms_per_step": ms, "samples_per_s": float(P) * D * V / (ms * 1e-3), "rows_per_rank": [n for _, n in bands],
+                "single_gpu_ms_per_step": single_ms, "single_gpu_ms_per_step_slowest_rank": single_max, "speedup_vs_single_gpu_in_process": single_ms / ms,
+                "collective_bytes_per_rank_per_step": 4.0 * tallest * W * (world - 1) * 2, "depth_crc32": crc, "depth_crc32_single_gpu": crc1,
+                "roofline_frac_band": float(bands[0][1]) * W * (V + 8.0 * D + 9.0) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "the headline's step at BASELINE config 4: north_star's >= 6 x at 8 GPUs is testable here (a 1/8 band of c3 is 0.1 ms of work); "
+                        "speedup = this process's single-GPU time of the whole view / the N-rank step (max over ranks)"}
+    except mvs_amd.MvsError as e:   # never let this block cost the line
+        return {"error": str(e)} if rank == 0 else None
 
 
 def main():
@@ -648,50 +797,9 @@ def main():
     def make_step(mode, collective):
         """returns (step function, views swept per rank, rows swept by rank 0, collective bytes sent+received per rank and step)"""
         if mode == "rows" and world > 1:
-            r0, rn = bands[rank]
-            tallest = max(n for _, n in bands)
-            # band r is rows [r * tallest, ...) of the main view, so the gathered bands ARE the depth map (its first H rows): the
-            # collective reads a full band straight from the context's depth buffer and no row is copied afterwards; only a band
-            # shorter than `tallest` (the last one) goes through a padded staging buffer
-            # Consecutive steps are independent main views, so the exchange of step k runs beside the sweep of step k + 1 (round 5): the
-            # band is copied into one of two staging buffers on the compute stream (1/N of 8 MB), the all-gather of that buffer goes to the
-            # communication stream behind an event, and a buffer is reused only when its previous collective has completed.  The timed
-            # region ends with every collective done (barrier()).  --no-overlap keeps round 4's form: the collective reads the context's
-            # depth buffer in place, on the compute stream.
-            overlap = not args.no_overlap
-            band_pad = [torch.zeros((tallest, W), dtype=torch.float32, device="cuda") for _ in range(2)]
-            band_cat = [torch.empty((world * tallest, W), dtype=torch.float32, device="cuda") for _ in range(2)]   # concatenated form: every backend
-            mine = depth_t[r0:r0 + tallest] if rn == tallest else band_pad[0]
-            state = {"k": 0, "work": [None, None]}
-
-            def step():
-                # rows are independent: every rank sweeps its band of the SAME main view over all views and planes (volume band
-                # materialised, depth selected in the kernel); only the depth rows travel (4 B per pixel in total)
-                k = state["k"] & 1
-                state["k"] += 1
-                if not overlap:
-                    ctx.sweep_run_rows(r0, rn, 0, V, both)
-                    if rn != tallest and rn:
-                        band_pad[0][:rn].copy_(depth_t[r0:r0 + rn])
-                    dist.all_gather_into_tensor(band_cat[0], mine)
-                    return
-                if state["work"][k] is not None:
-                    state["work"][k].wait()          # the collective that last used these two buffers (two steps ago) has completed
-                ctx.sweep_run_rows(r0, rn, 0, V, both)
-                if rn:
-                    band_pad[k][:rn].copy_(depth_t[r0:r0 + rn])
-                ev = torch.cuda.Event()
-                ev.record(stream)
-                comm_stream.wait_event(ev)
-                with torch.cuda.stream(comm_stream):
-                    state["work"][k] = dist.all_gather_into_tensor(band_cat[k], band_pad[k], async_op=True)
-
-            def finish():   # (called once, before the depth map of the last step is read)
-                for w_ in state["work"]:
-                    if w_ is not None:
-                        w_.wait()
-                torch.cuda.synchronize()
-                return band_cat[(state["k"] - 1) & 1 if overlap else 0][:H].cpu().numpy()
+            # rows are independent: every rank sweeps its band of the SAME main view over all views and planes; only the depth rows travel
+            # (4 B per pixel in total), beside the next step's sweep (overlapped_rows_step above)
+            step, finish, tallest = overlapped_rows_step(ctx, depth_t, bands, rank, world, W, V, both, dist, torch, stream, comm_stream, not args.no_overlap)
             return step, V, bands[0][1], 4.0 * tallest * W * (world - 1) * 2, finish
         if mode == "views" and world > 1 and collective == "reduce_scatter":
             if D % world:
@@ -790,6 +898,24 @@ def main():
         alternatives["frames_weak"] = {"ms_per_step": r["ms_per_step"], "samples_per_s": float(P) * D * V * world / (r["dt"] / args.steps), "scaling": "weak",
                                        "sweep_ms": r["sweep_ms"], "views_per_rank": r["views"], "collective_bytes_per_rank_per_step": 0.0,
                                        "note": "N independent main views per step, no data-path collective (bench.py --shard frames makes this the line's value)"}
+
+    # N > 1: what proves that N ranks ran on N distinct GPUs: the sum of 1 over the process group, every rank's device
+    # identity (PCI bus id + UUID where torch exposes them), whether each rank's device may address rank 0's directly
+    verify = None
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int32, device="cuda")
+        dist.all_reduce(one)
+        ids = [None] * world
+        dist.all_gather_object(ids, device_identity(torch, local_rank))
+        if rank == 0:
+            keys = [i["pci_bus_id"] or i["uuid"] or "?%d" % k for k, i in enumerate(ids)]
+            verify = {"rccl_ranks": int(one.item()), "backend": dist.get_backend(), "devices": ids, "distinct_devices": len(set(keys)),
+                      "peer_access_to_rank0": [i["peer_access_to_device0"] for i in ids]}
+    # ... and BASELINE's config 4 in rows mode beside the headline (3840 x 2160 x 256 x 32: the size at which 8 GPUs can reach north_star's 6 x;
+    # a 1/8 band of c3 is launch-sized work)
+    c4_rows = None
+    if world > 1 and not args.no_extras and shard == "rows" and args.config != "c4":
+        c4_rows = c4_rows_block(args, rank, local_rank, world, dist, torch, np, mvs_amd, synth, mdist, stream, comm_stream)
 
     # the same N GPUs through the product's own multi-GPU entry (mvs_comm_*: one process, rank threads, resident inputs), run by rank 0
     # as a child process while the other ranks idle on the host (a gloo barrier: no GPU work queued by anybody meanwhile)
@@ -973,6 +1099,16 @@ def main():
         argmin_bytes = 4.0 * P * D + 12.0 * P
         achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         traffic = pmc_traffic(sweep_kernel, args.config) if world == 1 else None
+        # what the FUSED kernel must move (SURVEY 8d "also report ... the fused lower bound"): the images once, the volume written once and never
+        # read back (depth is selected in registers), depth + best cost written.  B_alg above credits a 4 P D volume read that does not happen.
+        must_move = P_loc * (primary["views"] + 1.0 + 4.0 * D + 8.0)
+
+        def must_move_fields(ms, traffic_bytes):
+            f = {"must_move_bytes": must_move, "must_move_formula": "P (V_loc + 1) + 4 P D + 8 P: images in, volume out, depth + best cost out (no volume read-back)",
+                 "frac_must_move": must_move / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None}
+            if traffic_bytes:
+                f["traffic_ratio"] = {"vs_bytes_per_launch": traffic_bytes / sweep_bytes, "vs_must_move_bytes": traffic_bytes / must_move}
+            return f
         out = {
             "metric": "cost-volume samples/sec (pixels x planes x views)",
             "value": samples_per_step / (primary["dt"] / args.steps),
@@ -1005,6 +1141,7 @@ def main():
             "depth_crc32": primary["crc"],   # equal across N for the strong-scaling shardings (asserted against the in-process single-GPU run)
             "depth_crc32_single_gpu": crc1,
         }
+        out["roofline"].update(must_move_fields(sweep_ms, traffic["bytes"] if traffic else None))
         prof = rocprof_kernel_ms(sweep_kernel, args.config) if world == 1 else None
         if prof is not None:   # the same two kernels as the committed rocprofv3 summary has them (print both)
             both_ms = prof["sweep_ms"] + prof["combine_best_ms"]
@@ -1012,6 +1149,10 @@ def main():
                                                           "source": prof["source"], "frac_sweep_only": sweep_bytes / (prof["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                           "frac_with_combine_best": sweep_bytes / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                           "note": "a committed profile of an earlier run of the same command under rocprofv3, not this run"}
+        if verify is not None:
+            out["multi_gpu_check"] = verify
+        if c4_rows is not None:
+            out["c4_rows"] = c4_rows
         if via_comm is not None:
             out["via_comm"] = via_comm
         if cold is not None:
@@ -1026,6 +1167,7 @@ def main():
                 "note": "same frames, side cameras turned by 12 mrad about two axes: no view is rectified any more, the general tiled kernel "
                         "with its per-sample reciprocal runs -- the rate for rotated / forward-moving cameras such as the bundled tracks "
                         "(timing only; DESIGN.md section 4)"}
+            out["general_camera_path"].update(must_move_fields(general_ms, gtraffic["bytes"] if gtraffic else None))
             if translated_ms is not None:
                 out["general_camera_path"]["translation_only_cameras_ms_per_step"] = translated_ms
                 out["general_camera_path"]["translation_only_note"] = ("side cameras with the main camera's orientation, moved along the optical axis too: the same kernel's separable "
@@ -1033,6 +1175,11 @@ def main():
         if flow is not None:
             out["flow"] = flow
         if exact is not None:
+            if exact.get("kernel"):
+                xtraffic = pmc_traffic(exact["kernel"], args.config, tag="exact")
+                exact["roofline_traffic"] = xtraffic["bytes"] if xtraffic else None
+                exact["roofline_traffic_source"] = xtraffic["source"] if xtraffic else None
+                exact.update(must_move_fields(exact["ms_per_step"], xtraffic["bytes"] if xtraffic else None))
             out["exact_sampler"] = exact
         if disagreement is not None:
             out["sampler_disagreement"] = disagreement

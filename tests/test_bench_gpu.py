@@ -48,6 +48,10 @@ def test_bench_line_contract_and_two_rank_shardings():
     dflt = _bench([], 2)
     assert dflt["n_gpus"] == 2 and dflt["scaling"] == "strong" and dflt["config"]["shard"] == "rows"
     assert dflt["depth_crc32"] == single["depth_crc32"] == dflt["depth_crc32_single_gpu"]
+    # the self-verifying block of an N > 1 line: the group's size as a collective saw it, one identity per rank (here: the SAME device twice -- the hook)
+    chk = dflt["multi_gpu_check"]
+    assert chk["rccl_ranks"] == 2 and chk["backend"] == "gloo" and len(chk["devices"]) == 2 and chk["distinct_devices"] == 1
+    assert chk["peer_access_to_rank0"] == [True, True] and "c4_rows" not in dflt   # (--no-extras)
     rs = _bench(["--shard", "views", "--collective", "reduce_scatter"], 2)   # partial selection per plane slice + merge
     assert rs["depth_crc32"] == single["depth_crc32"] and rs["config"]["collective"] == "reduce_scatter"
     for shard, scaling in (("views", "strong"), ("rows", "strong"), ("frames", "weak")):
@@ -67,7 +71,13 @@ def test_bench_line_contract_and_two_rank_shardings():
     vc = full["via_comm"]
     assert "error" not in vc, vc
     assert vc["depth_crc32"] == single["depth_crc32"] and vc["ms_per_step"] > 0 and "mvs_comm_run" in vc["entry"] and "TEST HOOK" in vc["data"]
-    assert set(vc["modes"]) == {"rows", "views", "views_scatter"} and all(m["depth_crc32"] == single["depth_crc32"] for m in vc["modes"].values())
+    assert set(vc["modes"]) == {"rows", "rows_async", "views", "views_scatter"} and all(m["depth_crc32"] == single["depth_crc32"] for m in vc["modes"].values())
+    assert vc["peer_access"] == [1, 1] and vc["devices"] == [0, 0] and vc["modes"]["rows_async"]["in_flight"] == 2
+    # BASELINE's config 4 in rows mode beside the headline: same step, its own single-GPU reference, depth map reproduced
+    c4 = full["c4_rows"]
+    assert "error" not in c4, c4
+    assert c4["workload"].startswith("c4: 3840x2160, 256 planes, 32") and c4["depth_crc32"] == c4["depth_crc32_single_gpu"]
+    assert c4["ms_per_step"] > 0 and c4["single_gpu_ms_per_step"] > 0 and c4["speedup_vs_single_gpu_in_process"] > 0 and sum(c4["rows_per_rank"]) == 2160
     for s in ("exact",):
         ex = _bench(["--sampler", s], 1)
         assert ex["roofline"]["kernel"] in ("sweep_tiled", "sweep_exact_rect") and ex["depth_check"] is True   # (the ring is rectified: sweep_exact_rect where its boxes fit the LDS slots)
@@ -110,4 +120,5 @@ def test_via_comm_line():
     assert rec["n_gpus"] == 3 and rec["scaling"] == "strong" and "TEST HOOK" in rec["data"] and rec["depth_check"] is True
     assert rec["depth_crc32"] == rec["depth_crc32_single_gpu"]
     modes = rec["config"]["modes"]
-    assert set(modes) == {"rows", "views", "views_scatter"} and all(m["depth_crc32"] == rec["depth_crc32"] for m in modes.values())
+    assert set(modes) == {"rows", "rows_async", "views", "views_scatter"} and all(m["depth_crc32"] == rec["depth_crc32"] for m in modes.values())
+    assert rec["config"]["peer_access"] == [1, 1, 1] and rec["config"]["devices"] == [0, 0, 0] and "no error" in rec["config"]["peer_access_note"]

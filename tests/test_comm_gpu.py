@@ -81,6 +81,21 @@ def test_multi_device_comm_equals_single_gpu(ndev):
             d, c = comm.sweep(main_cam, main_img, side_cams, sides, D)
             np.testing.assert_array_equal(d, d1)
             np.testing.assert_array_equal(c, c1)
+        # the resident rows mode between REAL devices: peer access enabled both ways at creation, the bands travel GPU to GPU; two calls in flight
+        assert comm.devices() == list(range(ndev)) and len(comm.peer_access()) == ndev and comm.peer_access()[0] == 1
+        assert (comm.note() == "no error") == all(comm.peer_access()), comm.note()
+        comm.set_mode("rows")
+        comm.set(main_cam, main_img, side_cams, sides, D)
+        comm.run()
+        np.testing.assert_array_equal(comm.fetch()[0], d1)
+        comm.run_async()
+        comm.run_async()
+        for _ in range(2):
+            comm.wait()
+            d, c = comm.fetch()
+            np.testing.assert_array_equal(d, d1)
+            np.testing.assert_array_equal(c, c1)
+        comm.set_mode("views_scatter")
         d, c = comm.sweep(main_cam, main_img, side_cams, sides, D - 1)        # (scatter mode) all-reduce fallback
     with mvs_amd.Context(W, H) as ctx:
         d2, c2 = ctx.sweep(main_cam, main_img, side_cams, sides, D - 1, want_cost=True)
@@ -108,5 +123,8 @@ def test_bench_over_rccl_matches_single_gpu():
     assert out.returncode == 0 and len(lines) == 1, out.stderr[-3000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == n and line["depth_crc32"] == line["depth_crc32_single_gpu"]
+    chk = line["multi_gpu_check"]   # N ranks on N DISTINCT devices, as RCCL itself saw the group
+    assert chk["rccl_ranks"] == n and chk["backend"] == "nccl" and chk["distinct_devices"] == n
+    assert line["c4_rows"]["depth_crc32"] == line["c4_rows"]["depth_crc32_single_gpu"]
     for alt in line["config"]["alternatives"].values():
         assert alt["depth_crc32"] == line["depth_crc32_single_gpu"]
