@@ -651,6 +651,7 @@ Configuration::Configuration(int argc, char **argv)
                                            {"scale", required_argument, 0, 's'},        {"skip-frames", required_argument, 0, 'k'},
                                            {"farneback", no_argument, 0, 'f'},          {"verbose", no_argument, 0, 'v'},
                                            {"hyper-verbose", no_argument, 0, 'V'},      {"help", no_argument, 0, 'h'},
+                                           {"sweep-planes", required_argument, 0, 1000},  // (not in the reference: recon.hpp's sweepPlanes)
                                            {0, 0, 0, 0}};
     for (;;) {
         int option_index = 0;
@@ -673,6 +674,7 @@ Configuration::Configuration(int argc, char **argv)
             if (verbosity < 2) verbosity = 2;
             break;
         case 'V': verbosity = 99; break;
+        case 1000: sweepPlanes = std::max(0, atoi(optarg)); break;
         default:
             throw std::runtime_error("Usage: recon [OPTIONS] [INPUT_FILE]  (options: -c f, -e, -f, -h, -i s, -k i, -m s, -n i, -o s, -s f, -v, -V)");
         }

@@ -1,0 +1,95 @@
+// driver.cpp -- the loop of the reference's driver (recon.cpp:42-136) as two functions of the host mirror, so that the D-plane sweep
+// can sit inside it: trackMainFrame = one pass of the `fa` loop body (recon.cpp:65-117), reconstructPoints = the outer iteration
+// (recon.cpp:42-136).  recon.cpp itself stays what it is: a reference build linked per INTEGRATION.md runs its own main() against
+// RenderHIP / calculateFlow exactly as before.  These functions are for a caller who wants the benchmarked capability (cost volume +
+// depth selection over resident frames, mvs_sweep_handles) in that loop: `--sweep-planes N` (Configuration::sweepPlanes, default 0 =
+// off) makes trackMainFrame hand the flows and triangulatePixels the swept depth instead of the proxy mesh's z-buffer.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+
+#include "recon.hpp"
+
+namespace {
+
+// the planes of a sweep span the proxy's own depth range seen from the main camera, widened by a quarter of it on both sides (and never
+// beyond the NDC cube): the proxy says roughly where the surface is, the sweep decides where exactly
+bool sweepRange(const Mat &proxyDepth, float &zLo, float &zHi)
+{
+    float lo = 2.f, hi = -2.f;
+    const float *d = proxyDepth.ptr<float>();
+    for (size_t i = 0; i < proxyDepth.total(); i++)
+        if (d[i] != backgroundDepth) {
+            lo = std::min(lo, d[i]);
+            hi = std::max(hi, d[i]);
+        }
+    if (lo > hi) return false;  // the proxy covers nothing of this view
+    const float margin = std::max(0.25f * (hi - lo), 1e-4f);
+    zLo = std::max(-1.f, lo - margin);
+    zHi = std::min(1.f, hi + margin);
+    return zHi > zLo;
+}
+
+}  // namespace
+
+Mat trackMainFrame(Configuration &config, Render *render, int fa, const std::vector<int> &sideFrames, Mat *depthUsed)
+{
+    const Mat originalImage = config.frame(fa);
+    const Mat mainCamera = config.camera(fa);
+    Mat depth = render->depth(mainCamera);  // recon.cpp:70
+    DepthSweep *sweeper = config.sweepPlanes > 0 ? dynamic_cast<DepthSweep *>(render) : nullptr;
+    float zLo = -1.f, zHi = 1.f;
+    bool swept = false;
+    if (sweeper && !sideFrames.empty() && sweepRange(depth, zLo, zHi)) {
+        // frames go to the device once per sequence: whatever this view needs and the store does not hold yet
+        if (sweeper->storeCapacity() < config.frameCount()) sweeper->storeFrames(config.frameCount());
+        std::vector<Mat> sideCameras;
+        for (int fb : sideFrames) {
+            if (!sweeper->frameStored(fb)) sweeper->storeFrame(fb, config.frame(fb));
+            sideCameras.push_back(config.camera(fb));
+        }
+        if (!sweeper->frameStored(fa)) sweeper->storeFrame(fa, originalImage);
+        Mat sweptDepth = sweeper->sweepDepth(fa, mainCamera, sideFrames, sideCameras, config.sweepPlanes, zLo, zHi);
+        // the proxy still says WHERE there is a surface (recon.cpp reconstructs what the mesh covers); the sweep says how deep it is
+        float *dp = depth.ptr<float>();
+        const float *sp = sweptDepth.ptr<float>();
+        for (size_t i = 0; i < depth.total(); i++)
+            if (dp[i] != backgroundDepth) dp[i] = sp[i];
+        swept = true;
+    }
+    MatList flows, cameras;
+    for (int fb : sideFrames) {  // recon.cpp:81-112
+        Mat projectedImage = swept ? sweeper->projectedByDepth(mainCamera, depth, config.frame(fb), config.camera(fb))
+                                   : render->projected(mainCamera, config.frame(fb), config.camera(fb));
+        projectedImage = mixBackground(projectedImage, originalImage, depth);
+        flows.push_back(calculateFlow(originalImage, projectedImage, config.useFarneback));
+        cameras.push_back(config.camera(fb));
+    }
+    if (depthUsed) *depthUsed = depth.clone();
+    return triangulatePixels(flows, mainCamera, cameras, depth);  // recon.cpp:114
+}
+
+void reconstructPoints(Configuration &config, Heuristic &hint, Render *render, Mat &points, Mat &normals)
+{
+    while (hint.notHappy(points)) {  // recon.cpp:42
+        const Mesh mesh = hint.tessellate(points, normals);
+        render->loadMesh(mesh);
+        if (hint.chooseCameras(mesh, config.allCameras(), *render) == 0) throw std::runtime_error("Heuristic has chosen no cameras");  // recon.cpp:54-57
+        for (int fa = hint.beginMain(); fa != Heuristic::sentinel; fa = hint.nextMain()) {
+            std::vector<int> sides;
+            for (int fb = hint.beginSide(fa); fb != Heuristic::sentinel; fb = hint.nextSide(fa)) sides.push_back(fb);
+            const Mat tri = trackMainFrame(config, render, fa, sides);
+            // recon.cpp:115-116: columns 0-3 are the points, 4-6 the normals
+            Mat p(tri.rows, 4, mvs::F32C1), n(tri.rows, 3, mvs::F32C1);
+            for (int i = 0; i < tri.rows; i++) {
+                const float *row = tri.ptr<float>(i);
+                std::copy(row, row + 4, p.ptr<float>(i));
+                std::copy(row + 4, row + 7, n.ptr<float>(i));
+            }
+            points.push_back(p);
+            normals.push_back(n);
+            if (config.verbosity >= 2) printf(" After processing main frame %i: %i points\n", fa, points.rows);
+        }
+        hint.filterPoints(points, normals);  // recon.cpp:123
+    }
+}

@@ -101,6 +101,7 @@ public:
     std::vector<float> lensDistortion;
     float centerX = 0, centerY = 0;
     bool doEstimateExposure = false;
+    int sweepPlanes = 0;           // --sweep-planes N (long option only; not in the reference): 0 = the reference's path, N > 0 = trackMainFrame's swept depth
 
 protected:
     void parseYaml(const std::string &path);
@@ -133,6 +134,36 @@ public:
     virtual ~DepthProbe() {}
     virtual void depthAt(const Mat camera, int n, const int32_t *rows, const int32_t *cols, float *out) const = 0;
 };
+
+// Optional extension a renderer may also implement (RenderHIP does): the D-plane sweep -- plane-sweep photometric cost volume + per-pixel depth
+// selection, the generalisation of shader.frag:11-25 from the mesh's one depth per pixel to `planes` hypotheses -- over frames kept on the device.
+// Not part of the reference's interface (the reference has no D-plane path); trackMainFrame below uses it when Configuration::sweepPlanes > 0.
+class DepthSweep {
+public:
+    virtual ~DepthSweep() {}
+    // the sequence's frames, uploaded ONCE (Configuration load) and swept many times: size the store (emptying it), then one call per frame
+    virtual void storeFrames(int frameCount) = 0;
+    virtual int storeCapacity() const = 0;                      // frames the store was sized for (0 before storeFrames)
+    virtual void storeFrame(int frameNo, const Mat gray) = 0;   // H x W u8 of the render size
+    virtual bool frameStored(int frameNo) const = 0;
+    // depth map of the main view (H x W f32, main-camera NDC z like Render::depth, backgroundDepth where no side view sees the pixel on any plane):
+    // the plane of lowest mean |I_main - I_side warped| among `planes` planes spread evenly over (zLo, zHi); main and side views are stored frames
+    virtual Mat sweepDepth(int mainFrame, const Mat mainCamera, const std::vector<int> &sideFrames, const std::vector<Mat> &sideCameras, int planes,
+                           float zLo = -1.f, float zHi = 1.f, Mat *bestCost = nullptr) = 0;
+    // Render::projected with a depth map in place of the mesh (no shadow test: a depth map has one surface per pixel): H x W x 3 u8,
+    // (intensity, 255, 255) where the pixel's point lands inside `frame`, (0, 0, 0) elsewhere -- what mixBackground expects (util.cpp:376-377)
+    virtual Mat projectedByDepth(const Mat camera, const Mat depth, const Mat frame, const Mat projector) = 0;
+};
+
+// == the driver's loop (recon.cpp:42-136) as functions, so that the sweep can sit inside it ==
+// recon.cpp:65-117 for ONE main frame: depth map, per side view projected -> mixBackground -> calculateFlow, then triangulatePixels; returns the
+// rows (x, y, z, w, nx, ny, nz).  With config.sweepPlanes == 0 (the default) these are exactly the reference's calls.  With sweepPlanes > 0 and a
+// renderer that implements DepthSweep the depth map handed to the flows and to triangulatePixels is the SWEPT one -- `sweepPlanes` planes across the
+// proxy mesh's own depth range widened by a quarter on both sides, kept only where the proxy covers the pixel -- and the side frames are warped
+// through it (projectedByDepth) instead of through the mesh: the flow then only has to correct what is left after depth selection.
+Mat trackMainFrame(Configuration &config, Render *render, int mainFrame, const std::vector<int> &sideFrames, Mat *depthUsed = nullptr);
+// recon.cpp:42-136: the outer iteration (tessellate -> loadMesh -> chooseCameras -> every main frame -> filterPoints) until the heuristic is happy
+void reconstructPoints(Configuration &config, Heuristic &hint, Render *render, Mat &points, Mat &normals);
 
 // == heuristic ==
 typedef std::pair<int, std::vector<int>> numberedVector;

@@ -48,7 +48,7 @@ void expect(const Mat &m, int type, const char *what)
 
 }  // namespace
 
-class RenderHIP : public Render, public DepthProbe {
+class RenderHIP : public Render, public DepthProbe, public DepthSweep {
 public:
     RenderHIP(int width, int height) : w(width), h(height)
     {
@@ -93,11 +93,66 @@ public:
         if (mvs_depth_probe(ctx, camera.ptr<float>(), n, rows, cols, out)) raise(ctx, "depthAt");
     }
 
+    // ---- DepthSweep: the frame store + mvs_sweep_handles (one main view over stored frames: nothing uploaded, copied or re-prepared per view) ----
+    void storeFrames(int frameCount) override
+    {
+        if (mvs_frame_store(ctx, frameCount)) raise(ctx, "storeFrames");
+        stored.assign((size_t)frameCount, 0);
+    }
+    int storeCapacity() const override { return (int)stored.size(); }
+    void storeFrame(int frameNo, const Mat gray) override
+    {
+        expect(gray, mvs::U8C1, "storeFrame frame");
+        if (gray.cols != w || gray.rows != h) throw std::runtime_error("storeFrame: frame size differs from the render size");
+        if (frameNo < 0 || frameNo >= (int)stored.size()) throw std::runtime_error("storeFrame: frame number outside the store (storeFrames)");
+        // the upload is asynchronous and the caller's Mat may go away: wait here (once per frame of the sequence, not per sweep)
+        if (mvs_frame_upload(ctx, frameNo, gray.ptr<uint8_t>()) || mvs_synchronize(ctx)) raise(ctx, "storeFrame");
+        stored[(size_t)frameNo] = 1;
+    }
+    bool frameStored(int frameNo) const override { return frameNo >= 0 && frameNo < (int)stored.size() && stored[(size_t)frameNo]; }
+    Mat sweepDepth(int mainFrame, const Mat mainCamera, const std::vector<int> &sideFrames, const std::vector<Mat> &sideCameras, int planes, float zLo, float zHi,
+                   Mat *bestCost) override
+    {
+        expect(mainCamera, mvs::F32C1, "sweepDepth mainCamera");
+        if (sideFrames.size() != sideCameras.size()) throw std::runtime_error("sweepDepth: one camera per side frame expected");
+        if (!frameStored(mainFrame)) throw std::runtime_error("sweepDepth: the main frame is not in the store (storeFrame)");
+        std::vector<float> cams;
+        for (size_t i = 0; i < sideFrames.size(); i++) {
+            if (!frameStored(sideFrames[i])) throw std::runtime_error("sweepDepth: a side frame is not in the store (storeFrame)");
+            expect(sideCameras[i], mvs::F32C1, "sweepDepth side camera");
+            cams.insert(cams.end(), sideCameras[i].ptr<float>(), sideCameras[i].ptr<float>() + 16);
+        }
+        Mat depth(h, w, mvs::F32C1);
+        if (bestCost) bestCost->create(h, w, mvs::F32C1);
+        if (mvs_sweep_handles(ctx, mainFrame, mainCamera.ptr<float>(), (int)sideFrames.size(), sideFrames.data(), cams.data(), planes, zLo, zHi, depth.ptr<float>(),
+                              bestCost ? bestCost->ptr<float>() : nullptr))
+            raise(ctx, "sweepDepth");
+        return depth;
+    }
+    Mat projectedByDepth(const Mat camera, const Mat depth, const Mat frame, const Mat projector) override
+    {
+        expect(camera, mvs::F32C1, "projectedByDepth camera");
+        expect(projector, mvs::F32C1, "projectedByDepth projector");
+        expect(depth, mvs::F32C1, "projectedByDepth depth");
+        expect(frame, mvs::U8C1, "projectedByDepth frame");
+        if (frame.cols != w || frame.rows != h || depth.cols != w || depth.rows != h) throw std::runtime_error("projectedByDepth: size differs from the render size");
+        std::vector<uint8_t> pairs((size_t)w * h * 2);
+        if (mvs_warp_by_depth(ctx, camera.ptr<float>(), depth.ptr<float>(), projector.ptr<float>(), frame.ptr<uint8_t>(), pairs.data())) raise(ctx, "projectedByDepth");
+        Mat result(h, w, mvs::U8C3);
+        uint8_t *out = result.ptr<uint8_t>();
+        for (size_t p = 0; p < (size_t)w * h; p++) {
+            out[3 * p] = pairs[2 * p];
+            out[3 * p + 1] = out[3 * p + 2] = pairs[2 * p + 1];
+        }
+        return result;
+    }
+
     mvs_ctx *context() const { return ctx; }
 
 protected:
     mvs_ctx *ctx;
     int w, h;
+    std::vector<unsigned char> stored;
 };
 
 // render_glx.cpp:57-62

@@ -453,9 +453,74 @@ static int run_choose(int argc, char **argv)
     return 0;
 }
 
+// host_selftest sweep <tracks yaml> <verts.f32> <faces.i32> <out dir> <planes> <farneback 0|1> <main frame> <side frame> [<side frame> ...]
+// The sweep behind the C++ seam (recon.hpp: DepthSweep, trackMainFrame): the frames come from the YAML's `<clip>.frames` directory, the proxy
+// mesh from raw files.  Writes (a) RenderHIP::sweepDepth of the main frame against the side frames over the whole NDC range -- compared bit for
+// bit with mvs_sweep through the Python binding; (b) trackMainFrame's point rows and the depth map it used, with Configuration::sweepPlanes = 0
+// (the reference's path) and = <planes> (the swept depth) -- compared with the surface the frames were rendered from (tests/test_host_gpu.py).
+static int run_sweep(int argc, char **argv)
+{
+    Configuration config(argv[2]);
+    const std::string out = argv[5];
+    const int planes = atoi(argv[6]);
+    config.useFarneback = atoi(argv[7]) != 0;
+    const int fa = atoi(argv[8]);
+    std::vector<int> sides;
+    for (int i = 9; i < argc; i++) sides.push_back(atoi(argv[i]));
+    auto slurp = [](const char *path) {
+        std::ifstream f(path, std::ios::binary);
+        return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    };
+    const std::vector<char> vb = slurp(argv[3]), fb = slurp(argv[4]);
+    Mesh mesh(Mat((int)(vb.size() / 16), 4, mvs::F32C1), Mat((int)(fb.size() / 12), 3, mvs::S32C1));
+    std::memcpy(mesh.vertices.data, vb.data(), vb.size());
+    std::memcpy(mesh.faces.data, fb.data(), fb.size());
+    Heuristic hint(&config);
+    Render *render = spawnRender(hint);
+    render->loadMesh(mesh);
+    DepthSweep *sweeper = dynamic_cast<DepthSweep *>(render);
+    CHECK(sweeper != nullptr, "spawnRender's renderer implements DepthSweep");
+    if (!sweeper) return 1;
+    // (a) the extension itself
+    CHECK(sweeper->storeCapacity() == 0 && !sweeper->frameStored(fa), "an empty store");
+    sweeper->storeFrames(config.frameCount());
+    std::vector<Mat> sideCameras;
+    for (int s : sides) {
+        sweeper->storeFrame(s, config.frame(s));
+        sideCameras.push_back(config.camera(s));
+    }
+    bool threw = false;
+    try { sweeper->sweepDepth(fa, config.camera(fa), sides, sideCameras, planes); } catch (const std::exception &) { threw = true; }
+    CHECK(threw, "sweepDepth refuses a main frame that is not in the store");
+    sweeper->storeFrame(fa, config.frame(fa));
+    Mat cost;
+    const Mat whole = sweeper->sweepDepth(fa, config.camera(fa), sides, sideCameras, planes, -1.f, 1.f, &cost);
+    CHECK(whole.rows == config.height && whole.cols == config.width && cost.rows == config.height, "sweepDepth's maps have the render size");
+    writeRaw(out + "/sweep_depth.f32", whole);
+    writeRaw(out + "/sweep_cost.f32", cost);
+    // (b) the driver's loop body, both ways
+    for (int pass = 0; pass < 2; pass++) {
+        config.sweepPlanes = pass ? planes : 0;
+        Mat used;
+        const auto t0 = std::chrono::steady_clock::now();
+        const Mat tri = trackMainFrame(config, render, fa, sides, &used);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        printf("trackMainFrame(sweepPlanes = %d): %d points, %.2f ms\n", config.sweepPlanes, tri.rows, ms);
+        CHECK(tri.cols == 7 && tri.rows > 0, "trackMainFrame produced %d x %d", tri.rows, tri.cols);
+        const std::string tag = pass ? "swept" : "proxy";
+        writeRaw(out + "/points_" + tag + ".f32", tri);
+        writeRaw(out + "/depth_" + tag + ".f32", used);
+        std::ofstream(out + "/meta_" + tag + ".txt") << tri.rows << "\n";
+    }
+    delete render;
+    printf("%s\n", fails ? "SELFTEST FAILED" : "sweep selftest OK");
+    return fails ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
+        if (argc >= 10 && !strcmp(argv[1], "sweep")) return run_sweep(argc, argv);
         if (argc >= 4 && !strcmp(argv[1], "exposure")) return run_exposure(argv[2], argv[3]);
         if (argc >= 4 && !strcmp(argv[1], "frames")) return run_frames(argv[2], argv[3], argc > 4 ? atoi(argv[4]) : 1);
         if (argc >= 7 && !strcmp(argv[1], "choose")) return run_choose(argc, argv);
@@ -465,6 +530,6 @@ int main(int argc, char **argv)
         printf("exception: %s\n", e.what());
         return 2;
     }
-    printf("usage: host_selftest cpu <tracks dir> | gpu <tracks dir> <out dir> | exposure <tracks yaml> <out dir>\n");
+    printf("usage: host_selftest cpu <tracks dir> | gpu <tracks dir> <out dir> | exposure <tracks yaml> <out dir> | sweep <tracks yaml> <verts> <faces> <out dir> <planes> <farneback> <main> <sides...>\n");
     return 64;
 }

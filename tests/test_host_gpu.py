@@ -97,3 +97,73 @@ def test_a_clip_of_another_size_is_resized_on_the_way_in(oracle, tmp_path):
     """configuration.cpp:232-233 (cv::resize of every decoded frame that is not the clip's size) behind the YUV4MPEG2 reader"""
     import y4m_common
     y4m_common.run(tmp_path, oracle, scale=2)
+
+
+def test_the_sweep_behind_the_cpp_seam(tmp_path):
+    """RenderHIP::sweepDepth / projectedByDepth and the driver's loop body trackMainFrame (host/recon.hpp, host/driver.cpp) on the scene of
+    tests/test_e2e_gpu.py: frames of the zatisi cameras rendered from a bumped surface T, handed to the C++ mirror as a `<clip>.frames`
+    directory; the proxy mesh is the plane without the bump.  (a) the swept depth map that comes back through the C++ seam equals mvs_sweep
+    through the Python binding, bit for bit (frame store + mvs_sweep_handles against the one-call entry); (b) with --sweep-planes the points
+    trackMainFrame returns lie closer to T than the reference path's (proxy z-buffer) after the same single pass -- the outer iteration
+    starts where the reference's would be after several rounds."""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import c5_common
+    import mvs_amd
+    import scipy.ndimage as ndi
+    from test_e2e_gpu import _sheets
+    seq = c5_common.Sequence()
+    W, H = seq.W, seq.H
+    (Tv, Tf), (Pv, Pf) = _sheets(seq, 0.03)
+    rng = np.random.default_rng(10)
+    tex = ndi.gaussian_filter(rng.normal(size=(H, W)), 2.5)
+    tex = (127.5 + 110.0 * tex / np.abs(tex).max()).clip(0, 255).astype(np.uint8)
+    f = seq.mains[12]
+    sides = seq.sides(f)
+    shutil.copy(os.path.join(TRACKS, "zatisi.yaml"), tmp_path / "zatisi.yaml")
+    os.makedirs(tmp_path / "zatisi.avi.frames")
+    D = 48
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.load_mesh(Tv, Tf)
+        frames = {j: ctx.projected(seq.cams[j], tex, seq.cams[seq.n // 2])[:, :, 0].copy() for j in [f] + sides}
+        z_true = ctx.depth(seq.cams[f]).astype(np.float64)
+        for j, img in frames.items():
+            with open(tmp_path / "zatisi.avi.frames" / ("%06d.pgm" % (j + 1)), "wb") as fh:
+                fh.write(b"P5\n%d %d\n255\n" % (W, H) + img.tobytes())
+        d_py, c_py = ctx.sweep(seq.cams[f], frames[f], np.stack([seq.cams[j] for j in sides]), [frames[j] for j in sides], D, want_cost=True)
+        ctx.load_mesh(Pv, Pf)
+        z_proxy = ctx.depth(seq.cams[f]).astype(np.float64)
+    Pv.astype(np.float32).tofile(tmp_path / "verts.f32")
+    Pf.astype(np.int32).tofile(tmp_path / "faces.i32")
+    out = tmp_path / "out"
+    os.makedirs(out)
+    r = subprocess.run([SELFTEST, "sweep", str(tmp_path / "zatisi.yaml"), str(tmp_path / "verts.f32"), str(tmp_path / "faces.i32"), str(out), str(D), "1", str(f)] +
+                       [str(j) for j in sides], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sweep selftest OK" in r.stdout, r.stdout + r.stderr
+    # (a) the same maps through both doors
+    np.testing.assert_array_equal(np.fromfile(out / "sweep_depth.f32", np.float32).reshape(H, W), d_py)
+    np.testing.assert_array_equal(np.fromfile(out / "sweep_cost.f32", np.float32).reshape(H, W), c_py)
+    # (b) one pass of the loop body, the reference's way and with the swept depth
+    cam = np.asarray(seq.cams[f], np.float64)
+    med = {}
+    for tag in ("proxy", "swept"):
+        n = int(open(out / ("meta_%s.txt" % tag)).read())
+        pts = np.fromfile(out / ("points_%s.f32" % tag), np.float32).reshape(n, 7)
+        assert n > 50000
+        clip = pts[:, :4].astype(np.float64) @ cam.T
+        clip = clip[np.isfinite(clip).all(1) & (clip[:, 3] != 0.0)]
+        ndc = clip[:, :3] / clip[:, 3:4]
+        col = np.floor((ndc[:, 0] + 1.0) * 0.5 * W).astype(int)
+        row = np.floor((1.0 - ndc[:, 1]) * 0.5 * H).astype(int)
+        ok = (col >= 0) & (col < W) & (row >= 0) & (row < H)
+        col, row, z = col[ok], row[ok], ndc[ok, 2]
+        zt, zp = z_true[row, col], z_proxy[row, col]
+        have = (zt < 1.0) & (zp < 1.0)
+        med[tag] = float(np.median(np.abs(z - zt)[have]))
+        med[tag + "_proxy_error"] = float(np.median(np.abs(zp - zt)[have]))
+        used = np.fromfile(out / ("depth_%s.f32" % tag), np.float32).reshape(H, W)
+        assert ((used < 1.0) <= (z_proxy < 1.0)).all()          # the proxy still says WHERE there is a surface
+    print("median |z - z_true| after one pass: reference path %.5f, swept depth %.5f (proxy mesh itself %.5f)" % (med["proxy"], med["swept"], med["proxy_proxy_error"]))
+    assert med["proxy"] < med["proxy_proxy_error"]       # the reference's path moves towards the surface (tests/test_e2e_gpu.py) ...
+    assert med["swept"] < 0.6 * med["proxy"], med        # ... and the swept depth is already there
