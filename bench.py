@@ -40,6 +40,9 @@ CONFIGS = {
     "c2": (1280, 720, 64, 8),
     "c3": (1920, 1080, 128, 16),
     "c4": (3840, 2160, 256, 32),
+    # profiling aid, not a BASELINE config: c3's frame and planes with 4 side views -- the same tiles and plane chunks, a quarter of the quad images
+    # (34 MB instead of 137 MB): how the fetched bytes scale with the views (profiles/r06)
+    "c3v4": (1920, 1080, 128, 4),
     # c5: the bundled zatisi sequence (120 calibrated 640x480 frames), 128 planes, 4 side views per main frame; a step is
     # one main frame through the one-call entry mvs_sweep (upload, pad, plan, sweep, depth download).  Not the default.
     "c5": (640, 480, 128, 4),
