@@ -86,13 +86,10 @@ __global__ __launch_bounds__(256) void gauss_kernel(const float *__restrict__ sr
 // the column filter from there -- the expressions of gauss_kernel<false> and <true> on the same values in the same order (bit-identical),
 // without the intermediate image's round trip through HBM: cv::GaussianBlur of BOTH full-resolution frames is paid once per pyramid
 // level (fastPyramids false), 22 passes over 16.6 MB per 1080p flow.
-__global__ __launch_bounds__(256) void gauss_fused_kernel(const float *__restrict__ src, int w, int h, Taps t, int ksize, float *__restrict__ dst,
-                                                          ptrdiff_t src_z, ptrdiff_t dst_z)
+// (body: src / dst already point at the image; kc[j] = tap c + j of the symmetric kernel, j = 0 .. c)
+__device__ __forceinline__ void gauss_fused_body(const float *__restrict__ src, int w, int h, const float *__restrict__ kc, int c, float *__restrict__ dst,
+                                                 int X0, int Y0, float *__restrict__ g_lds)
 {
-    extern __shared__ float g_lds[];
-    src += (ptrdiff_t)blockIdx.z * src_z;
-    dst += (ptrdiff_t)blockIdx.z * dst_z;
-    const int c = ksize / 2, X0 = blockIdx.x * 64, Y0 = blockIdx.y * 16;
     const int IW = 64 + 2 * c, IH = 16 + 2 * c;
     float *in = g_lds, *tmp = g_lds + IW * IH;
     for (int i = threadIdx.x; i < IW * IH; i += 256) {
@@ -103,8 +100,8 @@ __global__ __launch_bounds__(256) void gauss_fused_kernel(const float *__restric
     for (int i = threadIdx.x; i < 64 * IH; i += 256) {  // rows: gauss_kernel<false> at (refl(Y0 - c + r), X0 + x)
         const int r = i >> 6, x = i & 63;
         const float *p = in + r * IW + x + c;
-        float acc = t.k[c] * p[0];
-        for (int j = 1; j <= c; j++) acc += t.k[c + j] * (p[j] + p[-j]);
+        float acc = kc[0] * p[0];
+        for (int j = 1; j <= c; j++) acc += kc[j] * (p[j] + p[-j]);
         tmp[i] = acc;
     }
     __syncthreads();
@@ -112,10 +109,44 @@ __global__ __launch_bounds__(256) void gauss_fused_kernel(const float *__restric
         const int r = i >> 6, x = i & 63, gy = Y0 + r, gx = X0 + x;
         if (gx >= w || gy >= h) continue;
         const float *p = tmp + (r + c) * 64 + x;
-        float acc = t.k[c] * p[0];
-        for (int j = 1; j <= c; j++) acc += t.k[c + j] * (p[64 * j] + p[-64 * j]);
+        float acc = kc[0] * p[0];
+        for (int j = 1; j <= c; j++) acc += kc[j] * (p[64 * j] + p[-64 * j]);
         dst[(size_t)gy * w + gx] = acc;
     }
+}
+
+__global__ __launch_bounds__(256) void gauss_fused_kernel(const float *__restrict__ src, int w, int h, Taps t, int ksize, float *__restrict__ dst,
+                                                          ptrdiff_t src_z, ptrdiff_t dst_z)
+{
+    extern __shared__ float g_lds[];
+    const int c = ksize / 2;
+    gauss_fused_body(src + (ptrdiff_t)blockIdx.z * src_z, w, h, t.k + c, c, dst + (ptrdiff_t)blockIdx.z * dst_z, blockIdx.x * 64, blockIdx.y * 16, g_lds);
+}
+
+// The pyramid preparation of ALL levels in three launches (round 6).  cv::FarnebackOpticalFlow blurs both full-resolution frames once per
+// level (fastPyramids false), resizes and expands them -- 3 launches per level, 33 per flow, none of which depends on the flow chain; at
+// 640 x 480 they were a quarter of a call's time, each on the critical path (and a second stream does not hide them: a cross-stream event
+// wait costs ~25 us on this ROCm, measured -- DESIGN.md section 6).  Here blockIdx.z = level * images + image and the level's constants
+// come from the kernel arguments; the bodies are the per-level kernels' own.  Needs every level's blur / I / R at once (FbLevels::*_off,
+// in floats from the bases): used for frames up to FB_BATCH_PREP_MAX_PIXELS, where launches -- not bytes -- are what a flow costs.
+struct FbLevelDesc {
+    int w, h, c, pad;              // level size, half width of the blur kernel
+    size_t blur_off, i_off, r_off; // per level; images n * W*H (blur), n * w*h (I), n * 5 w*h (R) apart inside it
+    float kc[32];                  // taps c .. 2c of the symmetric blur kernel
+};
+struct FbLevels {
+    int n, nimg;
+    FbLevelDesc lv[11];
+};
+constexpr size_t FB_BATCH_PREP_MAX_PIXELS = 1280 * 720;
+
+__global__ __launch_bounds__(256) void gauss_fused_levels_kernel(const float *__restrict__ F, int W, int H, FbLevels L, float *__restrict__ blur)
+{
+    extern __shared__ float g_lds[];
+    const int lev = blockIdx.z / L.nimg, img = blockIdx.z - lev * L.nimg;
+    const FbLevelDesc &d = L.lv[lev];
+    const size_t P = (size_t)W * H;
+    gauss_fused_body(F + img * P, W, H, d.kc, d.c, blur + d.blur_off + img * P, blockIdx.x * 64, blockIdx.y * 16, g_lds);
 }
 
 __device__ __forceinline__ void linear_coeff(int d, int dsize, int ssize, int &ofs, float &a0, float &a1)
@@ -159,6 +190,24 @@ __global__ __launch_bounds__(256) void resize_linear_kernel(const float *__restr
         if (domul) v *= mul;
         dst[((size_t)y * w + x) * CN + c] = v;
     }
+}
+
+__global__ __launch_bounds__(256) void resize_levels_kernel(const float *__restrict__ blur, int W, int H, FbLevels L, float *__restrict__ I)
+{
+    const int lev = blockIdx.z / L.nimg, img = blockIdx.z - lev * L.nimg;
+    const FbLevelDesc &d = L.lv[lev];
+    const int w = d.w, h = d.h;
+    PIX2D
+    const float *src = blur + d.blur_off + (size_t)img * W * H;
+    float *dst = I + d.i_off + (size_t)img * w * h;
+    int sx, sy;
+    float a0, a1, b0, b1;
+    linear_coeff(x, w, W, sx, a0, a1);
+    linear_coeff(y, h, H, sy, b0, b1);
+    const int sx1 = sx + 1 < W ? sx + 1 : sx, sy1 = sy + 1 < H ? sy + 1 : sy;
+    const float r0 = src[(size_t)sy * W + sx] * a0 + src[(size_t)sy * W + sx1] * a1;   // resize_linear_kernel<1>, no `*= mul`
+    const float r1 = src[(size_t)sy1 * W + sx] * a0 + src[(size_t)sy1 * W + sx1] * a1;
+    dst[(size_t)y * w + x] = r0 * b0 + r1 * b1;
 }
 
 struct PolyTaps {
@@ -223,13 +272,10 @@ __global__ __launch_bounds__(256) void polyexp_horiz(const float *__restrict__ r
 // polyexp_vert + polyexp_horiz in one launch (round 5): the tile's (16 + 2n) x (64 + 2n) neighbourhood staged in LDS with the replicate
 // border resolved while staging, the vertical sums of its 16 rows x (64 + 2n) columns into a second LDS array, the horizontal pass from
 // there -- the same expressions on the same values (bit-identical), no round trip of the 12-byte-per-pixel intermediate through HBM.
-__global__ __launch_bounds__(256) void polyexp_fused_kernel(const float *__restrict__ src, int w, int h, PolyTaps t, float *__restrict__ dst5,
-                                                            ptrdiff_t src_z, ptrdiff_t dst_z)
+__device__ __forceinline__ void polyexp_fused_body(const float *__restrict__ src, int w, int h, const PolyTaps &t, float *__restrict__ dst5, int X0, int Y0,
+                                                   float *__restrict__ p_lds)
 {
-    extern __shared__ float p_lds[];
-    src += (ptrdiff_t)blockIdx.z * src_z;
-    dst5 += (ptrdiff_t)blockIdx.z * dst_z;
-    const int n = t.n, X0 = blockIdx.x * 64, Y0 = blockIdx.y * 16;
+    const int n = t.n;
     const int IW = 64 + 2 * n, IH = 16 + 2 * n;
     float *in = p_lds, *row3 = p_lds + IW * IH;  // row3: [16][IW][3]
     for (int i = threadIdx.x; i < IW * IH; i += 256) {
@@ -278,6 +324,24 @@ __global__ __launch_bounds__(256) void polyexp_fused_kernel(const float *__restr
         d[2] = (float)(b1 * t.ig03 + b5 * t.ig33);
         d[4] = (float)(b6 * t.ig55);
     }
+}
+
+__global__ __launch_bounds__(256) void polyexp_fused_kernel(const float *__restrict__ src, int w, int h, PolyTaps t, float *__restrict__ dst5,
+                                                            ptrdiff_t src_z, ptrdiff_t dst_z)
+{
+    extern __shared__ float p_lds[];
+    polyexp_fused_body(src + (ptrdiff_t)blockIdx.z * src_z, w, h, t, dst5 + (ptrdiff_t)blockIdx.z * dst_z, blockIdx.x * 64, blockIdx.y * 16, p_lds);
+}
+
+__global__ __launch_bounds__(256) void polyexp_levels_kernel(const float *__restrict__ I, FbLevels L, PolyTaps t, float *__restrict__ R)
+{
+    extern __shared__ float p_lds[];
+    const int lev = blockIdx.z / L.nimg, img = blockIdx.z - lev * L.nimg;
+    const FbLevelDesc &d = L.lv[lev];
+    const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * 16;
+    if (X0 >= d.w || Y0 >= d.h) return;   // (the grid is the finest level's)
+    const size_t pk = (size_t)d.w * d.h;
+    polyexp_fused_body(I + d.i_off + img * pk, d.w, d.h, t, R + d.r_off + img * 5 * pk, X0, Y0, p_lds);
 }
 
 // FarnebackUpdateMatrices at one pixel: the five products of the displaced polynomial coefficients, from the pixel's own flow
@@ -387,6 +451,38 @@ __global__ __launch_bounds__(256) void update_matrices_kernel(const float *__res
     M += m_z * blockIdx.z;
     update_matrix_at(R0, R1, flow[((size_t)y * w + x) * 2], flow[((size_t)y * w + x) * 2 + 1], x, y, w, h,
                      M + ((size_t)y * w + x) * 5);
+}
+
+// The first two launches of a pyramid level in one (round 6): the flow carried down from the coarser level -- resize_linear_kernel<2> with
+// its `*= 1 / pyrScale`, or zeros at the coarsest level (flags == 0: no initial flow) -- and FarnebackUpdateMatrices on it.  The matrices
+// need the pixel's OWN flow only, so the value goes from the register into both: the same operations on the same values, two launches
+// of ~5 us fewer on each of the 11 levels' critical path (and no memset node for a caller's graph to trip over).
+__global__ __launch_bounds__(256) void upsample_update_kernel(const float *__restrict__ prevflow, int pw, int ph, float mul, const float *__restrict__ R0,
+                                                              const float *__restrict__ R1, float *__restrict__ flow, int w, int h, float *__restrict__ M,
+                                                              ptrdiff_t r1_z, ptrdiff_t flow_z, ptrdiff_t m_z)
+{
+    PIX2D
+    R1 += r1_z * blockIdx.z;
+    flow += flow_z * blockIdx.z;
+    M += m_z * blockIdx.z;
+    float v[2] = {0.f, 0.f};
+    if (prevflow) {
+        prevflow += flow_z * blockIdx.z;
+        int sx, sy;
+        float a0, a1, b0, b1;
+        linear_coeff(x, w, pw, sx, a0, a1);
+        linear_coeff(y, h, ph, sy, b0, b1);
+        const int sx1 = sx + 1 < pw ? sx + 1 : sx, sy1 = sy + 1 < ph ? sy + 1 : sy;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float r0 = prevflow[((size_t)sy * pw + sx) * 2 + c] * a0 + prevflow[((size_t)sy * pw + sx1) * 2 + c] * a1;
+            const float r1 = prevflow[((size_t)sy1 * pw + sx) * 2 + c] * a0 + prevflow[((size_t)sy1 * pw + sx1) * 2 + c] * a1;
+            v[c] = (r0 * b0 + r1 * b1) * mul;
+        }
+    }
+    flow[((size_t)y * w + x) * 2] = v[0];
+    flow[((size_t)y * w + x) * 2 + 1] = v[1];
+    update_matrix_at(R0, R1, v[0], v[1], x, y, w, h, M + ((size_t)y * w + x) * 5);
 }
 
 __global__ __launch_bounds__(256) void box_vert_kernel(const float *__restrict__ M, int w, int h, int m,
@@ -1153,13 +1249,44 @@ static int launch_fb_iteration(mvs_ctx *ctx, const float *M_in, const float *R0,
     return go(farneback_iteration_tiled<4, 2, 256>, 8, 2, 256, 2u);   // 64 x 8 tiles
 }
 
-// cv::FarnebackOpticalFlow::calc, flags 0.  f0/f1: f32 frames (W*H); flow_out: W*H*2.  arena: >= 30*P floats.
-static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, float *flow_out, float *arena, int levels,
-                            double pyr_scale, int winsize, int iterations, int poly_n, double poly_sigma)
+// The buffers of one Farneback chain over B flows that share their first frame (B = 1: calculateFlow itself).  Images: 0 = the previous frame,
+// 1 + i = next frame i, P floats apart in F and blur, w*h apart in a level's I, 5 w*h apart in its R.
+struct FbBufs {
+    const float *F;
+    float *tmp, *row3;            // the unfused A/B form only (MVS_FB_UNFUSED)
+    float *blur, *I, *R;          // one level's worth each (n P, n P, 5 n P) -- or, prepared for all levels at once, `levels_floats` of them
+    size_t blur_cap, i_cap, r_cap; // floats available behind the three pointers
+    float *M, *M2;                // B x 5 P each (ping-pong of the fused iteration)
+    double *vs;                   // 5 P doubles, B == 1, unfused form only
+    float *flowA, *flowB;         // B x 2 P each
+};
+
+// floats of blur / I / R when every level is prepared at once: (levels + 1) n P, n sum(w_k h_k), 5 n sum(w_k h_k) with sum < 2.8 P
+static void fb_all_levels_floats(size_t P, size_t n, size_t &blur, size_t &I, size_t &R)
+{
+    blur = 11 * n * P;
+    I = 3 * n * P;
+    R = 15 * n * P;
+}
+
+// cv::FarnebackOpticalFlow::calc, flags 0, for B flows against one previous frame (farneback_device: B = 1; mvs_process_frame's batched pass:
+// every side view of a main frame, blockIdx.z = flow).  flow_out: B x W*H*2.  Per pyramid level, coarse to fine:
+//   preparation  GaussianBlur of every full-resolution frame, resize to the level, polynomial expansion -- depends on the frames alone:
+//                for frames up to FB_BATCH_PREP_MAX_PIXELS all levels are prepared up front in THREE launches (round 6; 33 before);
+//   chain        the flow carried down + the first matrices (one launch; two before), then `iterations` fused iterations -- each needs
+//                the whole previous one.
+// The same kernels' bodies on the same values either way (MVS_FB_SERIAL_PREP=1 keeps the per-level preparation: A/B, tests).
+static int farneback_run(mvs_ctx *ctx, const FbBufs &b, int B, float *flow_out, int levels, double pyr_scale, int winsize, int iterations, int poly_n,
+                         double poly_sigma)
 {
     const int W = ctx->W, H = ctx->H;
     const size_t P = (size_t)W * H;
+    const ptrdiff_t sP = (ptrdiff_t)P;
     if (poly_n > 15) return fail(ctx, MVS_EINVAL, "farneback: poly_n %d too large", poly_n);
+    const int m = winsize / 2;
+    // MVS_FB_UNFUSED=1 keeps the three-launch form of an iteration (A/B timing, single flows); windows beyond the LDS buffer use it too
+    const bool unfused = B == 1 && (ctx->hooks.fb_unfused || m > FB_MAXM);
+    if (B != 1 && m > FB_MAXM) return fail(ctx, MVS_EINVAL, "farneback (batched): window %d beyond the fused iteration's buffer", winsize);
     int lw[64], lh[64];
     double ls[64];
     {
@@ -1178,68 +1305,105 @@ static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, floa
             lh[k] = (int)std::lrint(H * scale);
         }
     }
-    double *vs = (double *)arena;  // 5*P doubles first: keeps them 8-byte aligned for any P
-    // per-frame scratch comes in pairs (frame 0 at the pointer, frame 1 one stride further): both frames go through
-    // every preparation kernel in one launch (blockIdx.z)
-    float *tmp = arena + 10 * P, *blur = tmp + 2 * P, *I = blur + 2 * P, *row3 = I + 2 * P, *R0 = row3 + 6 * P, *R1 = R0 + 5 * P,
-          *M = R1 + 5 * P, *flowA = M + 5 * P, *flowB = flowA + 2 * P;  // 41*P floats in total
     PolyTaps pt;
     farneback_taps(poly_n, poly_sigma, pt);
     hipStream_t st = ctx->stream;
-    float *flow = nullptr, *prevflow = nullptr;
-    int pw = 0, ph = 0;
-    for (int k = levels; k >= 0; k--) {
-        const double sigma = (1. / ls[k] - 1) * 0.5;
+    const unsigned nimg = (unsigned)B + 1;
+    auto blur_size = [&](int k, double &sigma) {
+        sigma = (1. / ls[k] - 1) * 0.5;
         int smooth_sz = (int)std::lrint(sigma * 5) | 1;
-        if (smooth_sz < 3) smooth_sz = 3;
-        if (smooth_sz > 63) return fail(ctx, MVS_EINVAL, "farneback: smoothing kernel %d too large", smooth_sz);
-        const int w = lw[k], h = lh[k];
-        flow = k == 0 ? flow_out : (prevflow == flowA ? flowB : flowA);
-        if (!prevflow) {
-            if (ctx->hooks.flow_graph_kernel_memset)
-                zero_f32_kernel<<<(unsigned)(((size_t)w * h * 2 + 255) / 256), 256, 0, st>>>(flow, (size_t)w * h * 2);
-            else
-                MVS_HIP(ctx, hipMemsetAsync(flow, 0, sizeof(float) * (size_t)w * h * 2, st));
-        } else {
-            resize_linear_kernel<2><<<g2(w, h), 256, 0, st>>>(prevflow, pw, ph, flow, w, h, (float)(1. / pyr_scale), 1);
+        return smooth_sz < 3 ? 3 : smooth_sz;
+    };
+    for (int k = 0; k <= levels; k++) {
+        double sigma;
+        if (blur_size(k, sigma) > 63) return fail(ctx, MVS_EINVAL, "farneback: smoothing kernel %d too large", blur_size(k, sigma));
+    }
+    // ---- preparation of every level at once ----
+    FbLevels L;
+    L.n = levels + 1;
+    L.nimg = (int)nimg;
+    bool all_levels = !ctx->hooks.fb_unfused && !ctx->hooks.fb_serial_prep && P <= FB_BATCH_PREP_MAX_PIXELS && levels + 1 <= 11;
+    if (all_levels) {
+        size_t bo = 0, io = 0, ro = 0;
+        int cmax = 0;
+        for (int k = 0; k <= levels; k++) {
+            double sigma;
+            const int smooth_sz = blur_size(k, sigma);
+            Taps taps;
+            gaussian_taps(smooth_sz, sigma, taps.k);
+            FbLevelDesc &d = L.lv[k];
+            d.w = lw[k];
+            d.h = lh[k];
+            d.c = smooth_sz / 2;
+            d.pad = 0;
+            d.blur_off = bo;
+            d.i_off = io;
+            d.r_off = ro;
+            for (int j = 0; j <= d.c; j++) d.kc[j] = taps.k[d.c + j];
+            for (int j = d.c + 1; j < 32; j++) d.kc[j] = 0.f;
+            cmax = std::max(cmax, d.c);
+            bo += (size_t)nimg * P;
+            io += (size_t)nimg * d.w * d.h;
+            ro += (size_t)nimg * 5 * d.w * d.h;
         }
+        all_levels = bo <= b.blur_cap && io <= b.i_cap && ro <= b.r_cap;
+        if (all_levels) {
+            const unsigned z = (unsigned)(levels + 1) * nimg;
+            gauss_fused_levels_kernel<<<dim3(div_up(W, 64), div_up(H, 16), z), 256, sizeof(float) * (size_t)(16 + 2 * cmax) * (128 + 2 * cmax), st>>>(b.F, W, H, L, b.blur);
+            dim3 gL = g2(W, H);
+            gL.z = z;
+            resize_levels_kernel<<<gL, 256, 0, st>>>(b.blur, W, H, L, b.I);
+            polyexp_levels_kernel<<<dim3(div_up(W, 64), div_up(H, 16), z), 256, sizeof(float) * ((size_t)(16 + 2 * pt.n) * (64 + 2 * pt.n) + 3 * 16 * (size_t)(64 + 2 * pt.n)), st>>>(b.I, L, pt, b.R);
+            MVS_HIP(ctx, hipGetLastError());
+        }
+    }
+    auto prepare = [&](int k) {   // one level, into the first level's worth of blur / I / R (image strides P / P / 5 P)
+        double sigma;
+        const int smooth_sz = blur_size(k, sigma);
+        const int w = lw[k], h = lh[k];
         Taps taps;
         gaussian_taps(smooth_sz, sigma, taps.k);
-        {
-            const ptrdiff_t sP = (ptrdiff_t)P;
-            dim3 gF = g2(W, H), gL = g2(w, h);
-            gF.z = gL.z = 2;
-            if (ctx->hooks.fb_unfused) {
-                gauss_kernel<false><<<gF, 256, 0, st>>>(f0, W, H, taps, smooth_sz, tmp, f1 - f0, sP);
-                gauss_kernel<true><<<gF, 256, 0, st>>>(tmp, W, H, taps, smooth_sz, blur, sP, sP);
-            } else {
-                const int c = smooth_sz / 2;
-                gauss_fused_kernel<<<dim3(div_up(W, 64), div_up(H, 16), 2), 256, sizeof(float) * (size_t)(16 + 2 * c) * (128 + 2 * c), st>>>(f0, W, H, taps, smooth_sz, blur, f1 - f0, sP);
-            }
-            resize_linear_kernel<1><<<gL, 256, 0, st>>>(blur, W, H, I, w, h, 1.f, 0, sP, sP);
-            if (ctx->hooks.fb_unfused) {
-                polyexp_vert<<<gL, 256, 0, st>>>(I, w, h, pt, row3, sP, 3 * sP);
-                polyexp_horiz<<<gL, 256, 0, st>>>(row3, w, h, pt, R0, 3 * sP, R1 - R0);
-            } else {
-                polyexp_fused_kernel<<<dim3(div_up(w, 64), div_up(h, 16), 2), 256, sizeof(float) * ((size_t)(16 + 2 * pt.n) * (64 + 2 * pt.n) + 3 * 16 * (size_t)(64 + 2 * pt.n)), st>>>(I, w, h, pt, R0, sP, R1 - R0);
-            }
+        dim3 gF = g2(W, H), gL = g2(w, h);
+        gF.z = gL.z = nimg;
+        if (ctx->hooks.fb_unfused) {
+            gauss_kernel<false><<<gF, 256, 0, st>>>(b.F, W, H, taps, smooth_sz, b.tmp, sP, sP);
+            gauss_kernel<true><<<gF, 256, 0, st>>>(b.tmp, W, H, taps, smooth_sz, b.blur, sP, sP);
+        } else {
+            const int c = smooth_sz / 2;
+            gauss_fused_kernel<<<dim3(div_up(W, 64), div_up(H, 16), nimg), 256, sizeof(float) * (size_t)(16 + 2 * c) * (128 + 2 * c), st>>>(b.F, W, H, taps, smooth_sz, b.blur, sP, sP);
         }
-        update_matrices_kernel<<<g2(w, h), 256, 0, st>>>(R0, R1, flow, w, h, M);
-        const int m = winsize / 2;
-        const double bscale = 1. / ((double)winsize * winsize);
-        // MVS_FB_UNFUSED=1 keeps the three-launch form of an iteration (A/B timing); windows beyond the LDS buffer use it too
-        const bool unfused = ctx->hooks.fb_unfused;
-        if (unfused || m > FB_MAXM) {
+        resize_linear_kernel<1><<<gL, 256, 0, st>>>(b.blur, W, H, b.I, w, h, 1.f, 0, sP, sP);
+        if (ctx->hooks.fb_unfused) {
+            polyexp_vert<<<gL, 256, 0, st>>>(b.I, w, h, pt, b.row3, sP, 3 * sP);
+            polyexp_horiz<<<gL, 256, 0, st>>>(b.row3, w, h, pt, b.R, 3 * sP, 5 * sP);
+        } else {
+            polyexp_fused_kernel<<<dim3(div_up(w, 64), div_up(h, 16), nimg), 256, sizeof(float) * ((size_t)(16 + 2 * pt.n) * (64 + 2 * pt.n) + 3 * 16 * (size_t)(64 + 2 * pt.n)), st>>>(b.I, w, h, pt, b.R, sP, 5 * sP);
+        }
+    };
+    int r;
+    float *flow = nullptr, *prevflow = nullptr;
+    int pw = 0, ph = 0;
+    const double bscale = 1. / ((double)winsize * winsize);
+    for (int k = levels; k >= 0; k--) {
+        const int w = lw[k], h = lh[k];
+        if (!all_levels) prepare(k);
+        // R of image i of this level: 5 w h apart behind the level's offset when all levels were prepared, 5 P apart otherwise
+        const ptrdiff_t r_img = all_levels ? 5 * (ptrdiff_t)w * h : 5 * sP;
+        const float *R0 = b.R + (all_levels ? L.lv[k].r_off : 0), *R1 = R0 + r_img;
+        flow = k == 0 ? flow_out : (prevflow == b.flowA ? b.flowB : b.flowA);
+        dim3 gB = g2(w, h);
+        gB.z = (unsigned)B;
+        upsample_update_kernel<<<gB, 256, 0, st>>>(prevflow, pw, ph, (float)(1. / pyr_scale), R0, R1, flow, w, h, b.M, r_img, 2 * sP, 5 * sP);
+        if (unfused) {
             for (int it = 0; it < iterations; it++) {
-                box_vert_kernel<<<g2(w, h), 256, 0, st>>>(M, w, h, m, vs);
-                box_horiz_solve_kernel<<<g2(w, h), 256, 0, st>>>(vs, w, h, m, bscale, flow);
-                if (it < iterations - 1) update_matrices_kernel<<<g2(w, h), 256, 0, st>>>(R0, R1, flow, w, h, M);
+                box_vert_kernel<<<g2(w, h), 256, 0, st>>>(b.M, w, h, m, b.vs);
+                box_horiz_solve_kernel<<<g2(w, h), 256, 0, st>>>(b.vs, w, h, m, bscale, flow);
+                if (it < iterations - 1) update_matrices_kernel<<<g2(w, h), 256, 0, st>>>(R0, R1, flow, w, h, b.M);
             }
         } else {
-            float *M_cur = M, *M_nxt = (float *)vs;  // the fused form keeps the vertical sums on chip: vs is free
+            float *M_cur = b.M, *M_nxt = b.M2;
             for (int it = 0; it < iterations; it++) {
-                int r = launch_fb_iteration(ctx, M_cur, R0, R1, w, h, m, bscale, flow, it < iterations - 1 ? M_nxt : nullptr, 1, 0, 0, 0);
-                if (r) return r;
+                if ((r = launch_fb_iteration(ctx, M_cur, R0, R1, w, h, m, bscale, flow, it < iterations - 1 ? M_nxt : nullptr, B, 5 * sP, r_img, 2 * sP))) return r;
                 std::swap(M_cur, M_nxt);
             }
         }
@@ -1249,6 +1413,45 @@ static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, floa
         ph = h;
     }
     return MVS_OK;
+}
+
+// calculateFlow's Farneback on the context's arena.  f0 / f1: f32 frames (W*H each, f1 = f0 + W*H); flow_out: W*H*2.  arena: fb_work_floats(P) floats.
+static size_t fb_work_floats(size_t P)
+{
+    size_t blur = 2 * P, I = 2 * P, R = 10 * P;
+    if (P <= FB_BATCH_PREP_MAX_PIXELS) fb_all_levels_floats(P, 2, blur, I, R);
+    return 10 * P + 2 * P + 6 * P + blur + I + R + 5 * P + 2 * P + 2 * P;   // vs, tmp, row3, blur, I, R, M, flowA, flowB
+}
+
+static int farneback_device(mvs_ctx *ctx, const float *f0, const float *f1, float *flow_out, float *arena, int levels,
+                            double pyr_scale, int winsize, int iterations, int poly_n, double poly_sigma)
+{
+    const size_t P = (size_t)ctx->W * ctx->H;
+    if (f1 != f0 + P) return fail(ctx, MVS_EINVAL, "farneback: the two frames must be adjacent in memory");
+    FbBufs b;
+    b.F = f0;
+    b.vs = (double *)arena;  // 5 P doubles first: keeps them 8-byte aligned for any P
+    float *p = arena + 10 * P;
+    auto take = [&](size_t count) {
+        float *q = p;
+        p += count;
+        return q;
+    };
+    b.tmp = take(2 * P);
+    b.row3 = take(6 * P);
+    b.blur_cap = 2 * P;
+    b.i_cap = 2 * P;
+    b.r_cap = 10 * P;
+    if (P <= FB_BATCH_PREP_MAX_PIXELS) fb_all_levels_floats(P, 2, b.blur_cap, b.i_cap, b.r_cap);
+    b.blur = take(b.blur_cap);
+    b.I = take(b.i_cap);
+    b.R = take(b.r_cap);
+    b.M = take(5 * P);
+    b.M2 = (float *)b.vs;  // the fused form keeps the vertical sums on chip: vs is free
+    b.flowA = take(2 * P);
+    b.flowB = take(2 * P);
+    if ((size_t)(p - arena) > fb_work_floats(P)) return fail(ctx, MVS_ESTATE, "farneback: arena layout exceeds its %zu floats", fb_work_floats(P));
+    return farneback_run(ctx, b, 1, flow_out, levels, pyr_scale, winsize, iterations, poly_n, poly_sigma);
 }
 
 // VariationalRefinement::calc with OpenCV's defaults; flow (W*H*2) is refined in place.  arena: >= 22*P floats.
@@ -1304,15 +1507,16 @@ struct FlowBufs {
     uint8_t *p8, *n8, *r8;
 };
 
-static int flow_prepare(mvs_ctx *ctx, FlowBufs &b)
+static int flow_prepare(mvs_ctx *ctx, FlowBufs &b, int use_farneback)
 {
     const size_t P = (size_t)ctx->W * ctx->H;
-    // arena: work (42P floats, starts with 5P doubles) first, then f0, f1, flow2, var, out4; u8: prev, next, remapped
-    const size_t work = 42;
+    // arena: work (fb_work_floats(P) floats, at least the variational path's 22 P; starts with 5P doubles) first, then f0, f1, flow2, var, out4; u8: prev, next, remapped
+    // (sized for the algorithm that runs: the variational default needs 22 P, and mvs_process_frame keeps one arena per flow lane)
+    const size_t work = use_farneback ? std::max(fb_work_floats(P), (size_t)42 * P) : (size_t)42 * P;
     int rc;
-    if ((rc = ensure(ctx, ctx->flow_arena, sizeof(float) * P * (2 + 2 + 1 + 4 + work) + 3 * P + 256))) return rc;
+    if ((rc = ensure(ctx, ctx->flow_arena, sizeof(float) * (P * (2 + 2 + 1 + 4) + work) + 3 * P + 256))) return rc;
     b.arena = (float *)ctx->flow_arena.ptr;
-    b.f0 = b.arena + work * P;
+    b.f0 = b.arena + work;
     b.f1 = b.f0 + P;
     b.flow2 = b.f1 + P;
     b.var = b.flow2 + 2 * P;
@@ -1390,7 +1594,8 @@ static int flow_run(mvs_ctx *ctx, const FlowBufs &b, int use_farneback)
 // and everything that depends on the first frame alone (its blur, its polynomial expansion R0) is computed once, not B times.
 // Per-pixel arithmetic and summation orders are those of farneback_device: results are bit-identical.
 struct FlowBatchBufs {
-    float *F, *tmp, *blur, *I, *row3, *R, *M, *M2, *flowA, *flowB, *flow2, *var;
+    FbBufs fb;
+    float *F, *flow2, *var;
     uint8_t *r8;
     size_t floats;
 };
@@ -1406,15 +1611,21 @@ static FlowBatchBufs flow_batch_layout(float *arena, size_t P, int B)
         return r;
     };
     b.F = take(n * P);
-    b.tmp = take(n * P);
-    b.blur = take(n * P);
-    b.I = take(n * P);
-    b.row3 = take(n * 3 * P);
-    b.R = take(n * 5 * P);
-    b.M = take((size_t)B * 5 * P);
-    b.M2 = take((size_t)B * 5 * P);
-    b.flowA = take((size_t)B * 2 * P);
-    b.flowB = take((size_t)B * 2 * P);
+    b.fb.F = b.F;
+    b.fb.vs = nullptr;
+    b.fb.tmp = take(n * P);
+    b.fb.row3 = take(n * 3 * P);
+    b.fb.blur_cap = n * P;
+    b.fb.i_cap = n * P;
+    b.fb.r_cap = n * 5 * P;
+    if (P <= FB_BATCH_PREP_MAX_PIXELS) fb_all_levels_floats(P, n, b.fb.blur_cap, b.fb.i_cap, b.fb.r_cap);
+    b.fb.blur = take(b.fb.blur_cap);
+    b.fb.I = take(b.fb.i_cap);
+    b.fb.R = take(b.fb.r_cap);
+    b.fb.M = take((size_t)B * 5 * P);
+    b.fb.M2 = take((size_t)B * 5 * P);
+    b.fb.flowA = take((size_t)B * 2 * P);
+    b.fb.flowB = take((size_t)B * 2 * P);
     b.flow2 = take((size_t)B * 2 * P);
     b.var = take((size_t)B * P);
     b.r8 = (uint8_t *)take(((size_t)B * P + 3) / 4);
@@ -1426,86 +1637,15 @@ static int farneback_batch_enqueue(mvs_ctx *ctx, const uint8_t *prev8, const uin
 {
     const int W = ctx->W, H = ctx->H;
     const size_t P = (size_t)W * H;
-    const ptrdiff_t sP = (ptrdiff_t)P;
     hipStream_t st = ctx->stream;
-    const double poly_sigma = (H + W) / 1000.0, pyr_scale = 0.8;  // flow.cpp:24-25
-    const int winsize = (H + W) / 100, poly_n = poly_sigma < 1.5 ? 5 : 7, iterations = 7;
-    int levels = 10;
-    if (poly_n > 15) return fail(ctx, MVS_EINVAL, "farneback: poly_n %d too large", poly_n);
-    const int m = winsize / 2;
-    if (m > FB_MAXM) return fail(ctx, MVS_EINVAL, "farneback (batched): window %d beyond the fused iteration's buffer", winsize);
-    int lw[64], lh[64];
-    double ls[64];
-    {
-        int k;
-        double scale = 1;
-        for (k = 0; k < levels; k++) {
-            scale *= pyr_scale;
-            if (W * scale < 32 || H * scale < 32) break;
-        }
-        levels = k;
-        for (k = 0; k <= levels; k++) {
-            scale = 1;
-            for (int i = 0; i < k; i++) scale *= pyr_scale;
-            ls[k] = scale;
-            lw[k] = (int)std::lrint(W * scale);
-            lh[k] = (int)std::lrint(H * scale);
-        }
-    }
+    const double poly_sigma = (H + W) / 1000.0;  // flow.cpp:24-25
+    const int winsize = (H + W) / 100, poly_n = poly_sigma < 1.5 ? 5 : 7;
     u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(prev8, b.F, P);
     u8_to_f32_kernel<<<g1(P * B), 256, 0, st>>>(next8, b.F + P, P * B);
-    PolyTaps pt;
-    farneback_taps(poly_n, poly_sigma, pt);
-    float *flow = nullptr, *prevflow = nullptr;
-    int pw = 0, ph = 0;
-    for (int k = levels; k >= 0; k--) {
-        const double sigma = (1. / ls[k] - 1) * 0.5;
-        int smooth_sz = (int)std::lrint(sigma * 5) | 1;
-        if (smooth_sz < 3) smooth_sz = 3;
-        if (smooth_sz > 63) return fail(ctx, MVS_EINVAL, "farneback: smoothing kernel %d too large", smooth_sz);
-        const int w = lw[k], h = lh[k];
-        flow = k == 0 ? b.flow2 : (prevflow == b.flowA ? b.flowB : b.flowA);
-        dim3 gF = g2(W, H), gL = g2(w, h), gB = g2(w, h);
-        gF.z = gL.z = (unsigned)(B + 1);
-        gB.z = (unsigned)B;
-        if (!prevflow) {
-            MVS_HIP(ctx, hipMemsetAsync(flow, 0, sizeof(float) * 2 * P * B, st));
-        } else {
-            resize_linear_kernel<2><<<gB, 256, 0, st>>>(prevflow, pw, ph, flow, w, h, (float)(1. / pyr_scale), 1, 2 * sP, 2 * sP);
-        }
-        Taps taps;
-        gaussian_taps(smooth_sz, sigma, taps.k);
-        if (ctx->hooks.fb_unfused) {
-            gauss_kernel<false><<<gF, 256, 0, st>>>(b.F, W, H, taps, smooth_sz, b.tmp, sP, sP);
-            gauss_kernel<true><<<gF, 256, 0, st>>>(b.tmp, W, H, taps, smooth_sz, b.blur, sP, sP);
-        } else {
-            const int c = smooth_sz / 2;
-            gauss_fused_kernel<<<dim3(div_up(W, 64), div_up(H, 16), (unsigned)(B + 1)), 256, sizeof(float) * (size_t)(16 + 2 * c) * (128 + 2 * c), st>>>(b.F, W, H, taps, smooth_sz, b.blur, sP, sP);
-        }
-        resize_linear_kernel<1><<<gL, 256, 0, st>>>(b.blur, W, H, b.I, w, h, 1.f, 0, sP, sP);
-        if (ctx->hooks.fb_unfused) {
-            polyexp_vert<<<gL, 256, 0, st>>>(b.I, w, h, pt, b.row3, sP, 3 * sP);
-            polyexp_horiz<<<gL, 256, 0, st>>>(b.row3, w, h, pt, b.R, 3 * sP, 5 * sP);
-        } else {
-            polyexp_fused_kernel<<<dim3(div_up(w, 64), div_up(h, 16), (unsigned)(B + 1)), 256, sizeof(float) * ((size_t)(16 + 2 * pt.n) * (64 + 2 * pt.n) + 3 * 16 * (size_t)(64 + 2 * pt.n)), st>>>(b.I, w, h, pt, b.R, sP, 5 * sP);
-        }
-        const float *R0 = b.R, *R1 = b.R + 5 * P;
-        update_matrices_kernel<<<gB, 256, 0, st>>>(R0, R1, flow, w, h, b.M, 5 * sP, 2 * sP, 5 * sP);
-        const double bscale = 1. / ((double)winsize * winsize);
-        float *M_cur = b.M, *M_nxt = b.M2;
-        for (int it = 0; it < iterations; it++) {
-            int r = launch_fb_iteration(ctx, M_cur, R0, R1, w, h, m, bscale, flow, it < iterations - 1 ? M_nxt : nullptr, B, 5 * sP, 5 * sP, 2 * sP);
-            if (r) return r;
-            std::swap(M_cur, M_nxt);
-        }
-        MVS_HIP(ctx, hipGetLastError());
-        prevflow = flow;
-        pw = w;
-        ph = h;
-    }
+    int r;
+    if ((r = farneback_run(ctx, b.fb, B, b.flow2, 10, 0.8, winsize, 7, poly_n, poly_sigma))) return r;
     // variance channel per flow: compare(prev, flowRemap(flow, next)) (flow.cpp:34), then the packing (37-41)
     for (int i = 0; i < B; i++) {
-        int r;
         if ((r = remap_device(ctx, b.flow2 + (size_t)i * 2 * P, 2, next8 + (size_t)i * P, b.r8 + (size_t)i * P))) return r;
         if ((r = compare_device(ctx, prev8, b.r8 + (size_t)i * P, b.var + (size_t)i * P))) return r;
         pack_flow4<<<g1(P), 256, 0, st>>>(b.flow2 + (size_t)i * 2 * P, b.var + (size_t)i * P, out4 + (size_t)i * 4 * P, P);
@@ -1535,7 +1675,7 @@ int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, 
 {
     const size_t P = (size_t)ctx->W * ctx->H;
     FlowBufs b;
-    int rc = flow_prepare(ctx, b);
+    int rc = flow_prepare(ctx, b, use_farneback);
     if (rc) return rc;
     MVS_HIP(ctx, hipMemcpyAsync(b.p8, prev_dev, P, hipMemcpyDeviceToDevice, ctx->stream));
     MVS_HIP(ctx, hipMemcpyAsync(b.n8, next_dev, P, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1567,7 +1707,7 @@ int mvs_flow(mvs_ctx *ctx, const uint8_t *prev_hw, const uint8_t *next_hw, int u
     MVS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)ctx->W * ctx->H;
     FlowBufs b;
-    int rc = flow_prepare(ctx, b);
+    int rc = flow_prepare(ctx, b, use_farneback);
     if (rc) return rc;
     MVS_HIP(ctx, hipMemcpyAsync(b.p8, prev_hw, P, hipMemcpyHostToDevice, ctx->stream));
     MVS_HIP(ctx, hipMemcpyAsync(b.n8, next_hw, P, hipMemcpyHostToDevice, ctx->stream));

@@ -52,6 +52,7 @@ Hooks read_hooks()
     h.serial_flows = present("MVS_SERIAL_FLOWS");
     h.fb_lanes = present("MVS_FB_LANES");
     h.fb_unfused = present("MVS_FB_UNFUSED");
+    h.fb_serial_prep = present("MVS_FB_SERIAL_PREP");
     h.var_unfused = present("MVS_VAR_UNFUSED");
     h.fb_direct_box = present("MVS_FB_DIRECT_BOX");
     h.flow_graph = present("MVS_FLOW_GRAPH");

@@ -32,6 +32,7 @@ struct Hooks {
     bool serial_flows = false;         // MVS_SERIAL_FLOWS=1: mvs_process_frame runs its flows on the main stream (A/B of the lanes)
     bool fb_lanes = false;             // MVS_FB_LANES=1: Farneback flows one chain per side view on the lanes (A/B of the batched pass)
     bool fb_unfused = false;           // MVS_FB_UNFUSED=1: Farneback iteration as three kernels
+    bool fb_serial_prep = false;       // MVS_FB_SERIAL_PREP=1: Farneback's pyramid preparation level by level (3 launches per level) instead of all levels in 3 launches (A/B of round 6's form)
     bool var_unfused = false;          // MVS_VAR_UNFUSED=1: variational fixed-point iteration as separate kernels
     bool fb_direct_box = false;        // MVS_FB_DIRECT_BOX=1: the fused Farneback iteration sums its window term by term (round 2-4's kernel)
     bool flow_graph = false;           // MVS_FLOW_GRAPH=1: mvs_flow replays its kernel sequence as a hipGraph, as rounds 2-3 did (tools/graph_repro.py: the

@@ -26,13 +26,17 @@ fb = alg == "farneback"
 P = W * H
 # the arena in the order calculateFlow's kernels write it (csrc/flow.hip: flow_prepare, farneback_device / variational_device), in units of P floats
 # (after a call the buffers hold what the LAST pyramid level, level 0, left in them)
-LAYOUT = [("f0, f1 (u8_to_f32_kernel)", 42, 44)] + \
-         ([("gauss tmp (gauss_kernel<false>)", 10, 12), ("blur (gauss_kernel<true>)", 12, 14), ("level images (resize_linear_kernel<1>)", 14, 16),
-           ("polyexp rows (polyexp_vert)", 16, 22), ("R0, R1 (polyexp_horiz)", 22, 32), ("coarse flows A / B (resize_linear_kernel<2>, iteration of level 1)", 37, 41),
-           ("M (update_matrices_kernel, then farneback_iteration_* every second iteration)", 32, 37),
-           ("M ping-pong / box sums (farneback_iteration_* every other iteration)", 0, 10)] if fb else
+# (round 6: Farneback prepares all pyramid levels at once for frames up to 1280 x 720 -- blur / level images / R hold every level -- and its
+# work area is 85 P floats; the variational path keeps 42 P)
+WORK = 85 if fb else 42
+LEVEL_PIXELS = sum(int(round(W * 0.8 ** k)) * int(round(H * 0.8 ** k)) for k in range(11))   # (the part of the level buffers that is written)
+LAYOUT = [("f0, f1 (u8_to_f32_kernel)", WORK, WORK + 2)] + \
+         ([("blur of every level (gauss_fused_levels_kernel)", 18, 40), ("level images (resize_levels_kernel)", 40, 40 + 2 * LEVEL_PIXELS / P),
+           ("R0, R1 of every level (polyexp_levels_kernel)", 46, 46 + 10 * LEVEL_PIXELS / P), ("coarse flows A / B (upsample_update_kernel, iteration of level 1)", 81, 85),
+           ("M (upsample_update_kernel, then farneback_iteration_* every second iteration)", 76, 81),
+           ("M ping-pong (farneback_iteration_* every other iteration)", 0, 10)] if fb else
           [("variational work buffers, first half (warp_q5, diff_kernel, var_fixed_point_fused ...)", 0, 11), ("variational work buffers, second half", 11, 22)]) + \
-         [("flow (farneback_iteration_* of level 0 / var_finish)", 44, 46), ("variance (remap_cubic + compare)", 46, 47), ("packed result (pack_flow4)", 47, 51)]
+         [("flow (farneback_iteration_* of level 0 / var_finish)", WORK + 2, WORK + 4), ("variance (remap_cubic + compare)", WORK + 4, WORK + 5), ("packed result (pack_flow4)", WORK + 5, WORK + 9)]
 
 yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
 tex = lambda x, y: 127 + 50 * np.sin(x / 7.0) * np.cos(y / 9.0) + 40 * np.sin((x + y) / 13.0) + 30 * np.cos((x - 2 * y) / 17.0)  # noqa: E731
@@ -44,7 +48,7 @@ lib.mvs_test_flow_arena.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t
 
 
 def arena(ctx):
-    out = np.empty(51 * P, np.float32)
+    out = np.empty((WORK + 9) * P, np.float32)
     rc = lib.mvs_test_flow_arena(ctx.h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size)
     assert rc == 0, rc
     return out
@@ -52,7 +56,7 @@ def arena(ctx):
 
 def differences(x, ref):
     """per buffer, in the order the kernels write them: how many floats differ"""
-    return [{"buffer": name, "floats_differing": int(np.count_nonzero(x[lo * P:hi * P].view(np.uint32) != ref[lo * P:hi * P].view(np.uint32))), "of": (hi - lo) * P}
+    return [{"buffer": name, "floats_differing": int(np.count_nonzero(x[int(round(lo * P)):int(round(hi * P))].view(np.uint32) != ref[int(round(lo * P)):int(round(hi * P))].view(np.uint32))), "of": int(round((hi - lo) * P))}
             for name, lo, hi in LAYOUT]
 
 
