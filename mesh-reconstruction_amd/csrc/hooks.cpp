@@ -1,8 +1,12 @@
 // hooks.cpp -- the one place where libmvs_hip.so reads the environment (hooks.hpp).
 #include "hooks.hpp"
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
+
+extern char **environ;
 
 namespace mvs {
 
@@ -33,7 +37,22 @@ Hooks read_hooks()
 {
     Hooks h;
     h.enabled = flag("MVS_TEST_HOOKS");
-    if (!h.enabled) return h;  // production: nothing else is looked at
+    if (!h.enabled) {
+        // production: nothing else is looked at -- but a hook variable that is SET and ignored is a silent A/B with two equal arms
+        // (tools/time_process_frame.py under MVS_SERIAL_FLOWS=1), so say so once per process.  MVS_DEVICE belongs to the C++
+        // host mirror (host/render_hip.cpp), MVS_BUILD_VARIANT / MVS_BENCH_* to the Python harness: not library hooks.
+        static std::once_flag warned;
+        std::call_once(warned, [] {
+            for (char **e = environ; e && *e; e++)
+                if (!strncmp(*e, "MVS_", 4) && strncmp(*e, "MVS_TEST_HOOKS=", 15) && strncmp(*e, "MVS_DEVICE=", 11) && strncmp(*e, "MVS_BUILD_VARIANT=", 18) &&
+                    strncmp(*e, "MVS_BENCH_", 10)) {
+                    fprintf(stderr, "libmvs_hip: %.*s is set but MVS_TEST_HOOKS=1 is not: the library ignores its environment hooks (INTEGRATION.md section 7)\n",
+                            (int)strcspn(*e, "="), *e);
+                    break;
+                }
+        });
+        return h;
+    }
     h.rccl_library = text("MVS_RCCL_LIBRARY");
     h.comm_allow_same_device = flag("MVS_COMM_ALLOW_SAME_DEVICE");
     h.comm_fail_rank = number("MVS_COMM_TEST_FAIL_RANK", -1);
@@ -43,9 +62,7 @@ Hooks read_hooks()
     h.no_plan_cache = present("MVS_NO_PLAN_CACHE");
     h.no_sep = flag("MVS_NO_SEP");
     h.plan_dump = text("MVS_PLAN_DUMP");
-    h.fx_prof = present("MVS_FX_PROF");
     h.rect_verbose = present("MVS_RECT_VERBOSE");
-    h.rx_lds = number("MVS_RX_LDS", 0);
     h.filter_timing = present("MVS_FILTER_TIMING");
     h.filter_sorted_lists = number("MVS_FILTER_SORTED_LISTS", -1);
     h.filter_max_rounds = number("MVS_FILTER_MAX_ROUNDS", 2048);

@@ -22,9 +22,7 @@ struct Hooks {
     bool no_rect = false;              // MVS_NO_RECT=1: never plan the rectified-view kernels
     bool no_plan_cache = false;        // MVS_NO_PLAN_CACHE=1: initial state of mvs_sweep_set_plan_cache (0 = plan every view set)
     std::string plan_dump;             // MVS_PLAN_DUMP=<file>: plan_regions_fx writes its descriptors there (tools/plan_hist.py)
-    bool fx_prof = false;              // MVS_FX_PROF=1: section timers of the general kernel's planner (tools/fx_sections.py)
     bool rect_verbose = false;         // MVS_RECT_VERBOSE=1: box sizes of the rectified planners on stderr
-    int rx_lds = 0;                    // MVS_RX_LDS=<bytes>: LDS request of sweep_fx_rect raised to this (occupancy experiments)
     // ---- other stages ----
     bool filter_timing = false;        // MVS_FILTER_TIMING=1: stage timer of mvs_filter_points on stderr
     int filter_sorted_lists = -1;      // MVS_FILTER_SORTED_LISTS=0|1: never / always the global-sort path of the neighbour lists

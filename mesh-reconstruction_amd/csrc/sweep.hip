@@ -1182,11 +1182,19 @@ struct BandPipeline : PlanHook {
                 for (int k = 0; k < 8; k++) {
                     const double x = xc[k & 1], y = yc[(k >> 1) & 1], z = zc[k >> 2];
                     const double sy = q[4] * x + q[5] * y + q[6] * z + q[7], sw = q[8] * x + q[9] * y + q[10] * z + q[11];
-                    if (!(sw > 1e-30)) return false;
+                    // The kernels form sy, sw and sy / sw in f32 (FMAs + a correctly rounded reciprocal): each of the two sums carries a few ulps
+                    // of its LARGEST term, so when sw is the small difference of large terms -- a side camera whose centre lies just outside
+                    // the sweep box -- the f32 row can differ from this double bound by more than the fixed margin.  Such a view takes the
+                    // unbanded path: sw must be well conditioned at every corner, and what rounding is left goes into `slack`.
+                    const double wmag = fabs(q[8] * x) + fabs(q[9] * y) + fabs(q[10] * z) + fabs(q[11]);
+                    const double ymag = fabs(q[4] * x) + fabs(q[5] * y) + fabs(q[6] * z) + fabs(q[7]);
+                    if (!(sw > 1e-30) || !(sw >= 1e-3 * wmag)) return false;
                     const double cy = sy / sw;
                     if (!(cy == cy)) return false;
-                    cmin = cy < cmin ? cy : cmin;
-                    cmax = cy > cmax ? cy : cmax;
+                    // |d(sy / sw)| <= (|d sy| + |cy| |d sw|) / sw with |d s| <= 4 ulp_f32 x the sum's magnitude
+                    const double slack = 4.0 * 5.97e-8 * (ymag + fabs(cy) * wmag) / sw;
+                    cmin = cy - slack < cmin ? cy - slack : cmin;
+                    cmax = cy + slack > cmax ? cy + slack : cmax;
                 }
                 if (cmax < 0.25 || cmin > H + 0.75) continue;  // (in the frame: 0.5 < cy < H + 0.5) this view sees nothing of the band
                 const int a = (int)floor(cmin < 0.0 ? 0.0 : cmin) - 1, e = (int)floor(cmax > H + 1.0 ? H + 1.0 : cmax) + 2;

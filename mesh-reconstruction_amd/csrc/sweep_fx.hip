@@ -496,20 +496,8 @@ __device__ __forceinline__ void sample_range_fx_checked(const Affine &A, float b
 
 // 4 workgroups per CU (<= 128 VGPRs, 39.5 KiB of LDS each): at 2 per CU the LDS reads no longer hide behind the VALU work
 // (19.0 vs 14.6 ns per wave-sample, tools/sweep_v2_probe.hip).
-// Timing experiments (tools/exp_fx.py, tools/fx_sections.py) are compiled in with -DMVS_FX_EXPERIMENTS only: even never-taken
-// branches on p.debug change register allocation enough to cost the production kernel a few per cent.
-#ifndef MVS_FX_CUT
-#define MVS_FX_CUT 0  // timing experiments WITHOUT instrumentation (tools/build_variant.sh cutNN "-DMVS_FX_CUT=NN" csrc/sweep_fx.hip): 1 no copies, 32 no sample loop, 64 no per-view barrier, 128 no chunk epilogue, 256 no cold paths (GENERIC regions, per-sample frame tests: what the hot path alone needs in registers) -- wrong results
-#endif
-#ifdef MVS_FX_EXPERIMENTS
-#define FX_PROF_DECL unsigned long long pt_prev = 0, pt_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_iter = 0, pt_chunks = 0; const bool pt_on = p.plan_stats != nullptr && threadIdx.x < 64
-#define FX_PROF_START() do { if (pt_on) pt_prev = __builtin_amdgcn_s_memtime(); } while (0)
-#define FX_PROF_MARK(i) do { if (pt_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt_sum[i] += t_ - pt_prev; pt_prev = t_; } } while (0)
-#else
-#define FX_PROF_DECL
-#define FX_PROF_START()
-#define FX_PROF_MARK(i)
-#endif
+// (Rounds 2-5 carried timing experiments here -- a section profile with s_memtime, run-time cuts on p.debug, compile-time cuts -- behind
+// -DMVS_FX_EXPERIMENTS / -DMVS_FX_CUT; what they measured is docs/experiments.md.  Round 6 removed them: the kernel is the product.)
 
 template <bool WRITE_VOLUME, bool FUSED, bool SEP = false>  // SEP: with the separable path compiled in (its own instantiation: the path's registers would cost the others 3 %)
 __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const uint32_t *__restrict__ lut_g)
@@ -554,7 +542,6 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
 
     const int chunk_first = p.chunk0 + (int)blockIdx.y * p.cps;
     const int chunk_last = min(p.chunk1, chunk_first + p.cps);
-    FX_PROF_DECL;
     // Region pipeline.  `qcol` = first quad column of the region being sampled; `ahead` = the region of the view at hand was requested
     // while the previous staged view was being sampled (its copy is in flight or has landed).  When the descriptors of ALL this
     // workgroup's (chunk, view) regions fit the table (`whole_wg`: c3 has 4 chunks x 16 views), they and the view constants are loaded
@@ -600,7 +587,6 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
         for (int v = p.v0; v < vend; v++) {
             const int vi = (v - p.v0) & (FX_VB - 1);
             if (vi == 0 && !whole_wg) {  // next batch of per-view constants (wave-uniform branch; no region is in flight here: ahead == false)
-                FX_PROF_START();
                 __syncthreads();
                 const int nb = min(FX_VB, vend - v);
                 // the w row goes in divided by 256: then RN(1 / s.w) IS 256 r, bit for bit (a power of two commutes with the roundings of
@@ -609,9 +595,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
                 for (int i = threadIdx.x; i <= nb; i += 256) dtab[i] = i < nb ? plan[v + i] : make_uint2(0u, 0u);  // + a SKIP sentinel
                 __syncthreads();
                 dnext = dtab[0];
-                FX_PROF_MARK(7);
             }
-            FX_PROF_START();
             // the per-view bookkeeping below is a chain of dependent scalar work and LDS round trips: let it overtake the other
             // wavefronts' sample loops on this SIMD (priority back to 0 before this wavefront's own sample loop)
             __builtin_amdgcn_s_setprio(3);
@@ -619,9 +603,6 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
             dnext = dtab[dbase + vi + 1];  // the next region's descriptor (or the sentinel): in flight with this view's constants, one wait for all
             unsigned mode = (unsigned)__builtin_amdgcn_readfirstlane((int)((desc.y >> 16) & 7u));
             if (mode == FX_SKIP) continue;
-#ifdef MVS_FX_EXPERIMENTS
-            if ((p.debug & 16) && mode == FX_BORDER) mode = FX_FAST;  // timing experiment only (wrong counts at the frame border)
-#endif
             float q[12];  // wave-uniform values, kept in VGPRs: they are only ever VALU operands (v_fma allows one SGPR, and that is z)
             {
                 const float4 qa = *(const float4 *)(qtab + 12 * vi), qb = *(const float4 *)(qtab + 12 * vi + 4), qc = *(const float4 *)(qtab + 12 * vi + 8);
@@ -629,11 +610,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
                 q[8] = qc.x; q[9] = qc.y; q[10] = qc.z; q[11] = qc.w;
             }
             const float bx = q[2], by = q[6], bw = q[10];
-#ifdef MVS_FX_EXPERIMENTS
-            if (pt_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            FX_PROF_MARK(0);
-#endif
-            if (__builtin_expect(mode == FX_GENERIC, 0) && !(MVS_FX_CUT & 256)) {
+            if (__builtin_expect(mode == FX_GENERIC, 0)) {
                 row_checked = ~0u;  // (its samples carry their own counts)
                 const uint32_t *qv = p.quads + p.pad_slab * (size_t)__builtin_amdgcn_readfirstlane((int)(desc.y >> 19));
 #pragma unroll
@@ -653,25 +630,12 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
             if (!ahead) {
                 __syncthreads();  // every wavefront is done with the region these rows held
                 qcol = 0;
-#ifdef MVS_FX_EXPERIMENTS
-                if (!(p.debug & 1))  // timing experiment only: no copies
-#endif
-                if (!(MVS_FX_CUT & 1))
                 stage_region_fx(p.quads + p.pad_slab * (size_t)__builtin_amdgcn_readfirstlane((int)(desc.y >> 19)), p.pitch, x0, y0, rw, rh, qcol, lds);
             }
-#ifdef MVS_FX_EXPERIMENTS
-            if (p.debug & 64)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // timing experiment only (racy): what the per-view barrier costs
-            else
-#endif
-            if (MVS_FX_CUT & 64)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else
             __syncthreads();  // this view's region has landed (the barrier drains vmcnt) and the previous one is no longer read
             // Request the next staged view's region into the other half of the rows, if both regions are at most FX_HALF_COL quads
             // wide: its copy (L2 / Infinity Cache latency, 1-2 us) then overlaps this view's sampling (0.5 us of work for the
             // workgroup) and one barrier per region goes away.  Debug bit 3 switches it off (tests: bit-identical either way).
-            FX_PROF_MARK(1);
             ahead = false;
             int nqcol = 0;
             if (!(p.debug & 8) && rw <= FX_HALF_COL) {
@@ -679,16 +643,11 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
                 const int rwn = __builtin_amdgcn_readfirstlane((int)(dnext.y & 0xffu));
                 if ((mn == FX_FAST || mn == FX_BORDER) && rwn <= FX_HALF_COL) {
                     nqcol = qcol ? 0 : FX_HALF_COL;  // (the next view, or after the last view the first view of the workgroup's next chunk: its slab is in the descriptor)
-#ifdef MVS_FX_EXPERIMENTS
-                    if (!(p.debug & 1))
-#endif
-                    if (!(MVS_FX_CUT & 1))
-                        stage_region_fx(p.quads + p.pad_slab * (size_t)__builtin_amdgcn_readfirstlane((int)(dnext.y >> 19)), p.pitch, __builtin_amdgcn_readfirstlane((int)(dnext.x & 0xffffu)),
+                    stage_region_fx(p.quads + p.pad_slab * (size_t)__builtin_amdgcn_readfirstlane((int)(dnext.y >> 19)), p.pitch, __builtin_amdgcn_readfirstlane((int)(dnext.x & 0xffffu)),
                                         __builtin_amdgcn_readfirstlane((int)(dnext.x >> 16)), rwn, __builtin_amdgcn_readfirstlane((int)((dnext.y >> 8) & 0xffu)), nqcol, lds);
                     ahead = true;
                 }
             }
-            FX_PROF_MARK(2);
             FxRegion rg;
             const int kx0 = 256 * (x0 - qcol), ky0 = 256 * y0;  // region column rx sits in quad column qcol + rx of the LDS rows
             rg.offx = magic_plus(4 - kx0);
@@ -731,7 +690,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
                     }
                     checked = __builtin_amdgcn_ballot_w64(!inside && ok[j]) != 0ull;
                 }
-                if (checked && !(MVS_FX_CUT & 256)) {
+                if (checked) {
                     row_checked |= 1u << j;
                     if (ok[j]) sample_range_fx_checked<0, PC>(A, bx, by, bw, zc, rg, lds, Im255[j], acc[j]);
                     continue;
@@ -742,35 +701,20 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
                 } else {
                     lane_views[j] += 1u << 24;
                 }
-#ifdef MVS_FX_EXPERIMENTS
-                if (p.debug & 32) continue;  // timing experiment only: everything but the sample loop
-#endif
-                if (MVS_FX_CUT & 32) continue;
                 __builtin_amdgcn_s_setprio(0);
-                if (j == 0) FX_PROF_MARK(3);
                 if (wconst) {
                     const float r256c = rcp_rn(__builtin_fmaf(zc[0], bw, A.aw));
                     sample_range_fx<0, PC, true>(A, bx, by, bw, r256c, zc, rg.offx, rg.offy, lds_base, Im255[j], acc[j]);
                 } else {
                     sample_range_fx<0, PC, false>(A, bx, by, bw, 0.0f, zc, rg.offx, rg.offy, lds_base, Im255[j], acc[j]);
                 }
-                if (j == 0) FX_PROF_MARK(4);
             }
             qcol = nqcol;
-#ifdef MVS_FX_EXPERIMENTS
-            FX_PROF_MARK(5);
-            pt_iter++;
-#endif
         }
 
         // Epilogue of the chunk.  The plane base is wave-uniform (SGPR pair) and the pixel a 32-bit lane offset, so a store needs no
         // 64-bit per-lane pointer; the running best is kept as (sum, count) with the start value (1, 0), which makes
         // "s * bc < bs * c" true for the first cell with a view in frame and false for every empty cell: no other test per plane.
-#ifdef MVS_FX_EXPERIMENTS
-        if (p.debug & 128) continue;  // timing experiment only: no chunk epilogue
-        FX_PROF_START();
-#endif
-        if (MVS_FX_CUT & 128) continue;
         uint32_t *const vol_chunk = WRITE_VOLUME ? p.volume + (size_t)d0 * P : nullptr;
         const bool whole = d0 + PC <= p.D;  // uniform: every plane of the chunk exists
         // the chunk's 16 planes as one buffer resource (plane k at byte offset 4 P k: below 2^32 for frames up to 8192^2; larger frames
@@ -846,19 +790,7 @@ __device__ __forceinline__ void sweep_fx_tiled_body(const SweepParams &p, const 
                 if (FUSED) best_state[j * 256 + threadIdx.x] = make_uint2(best, (uint32_t)bi);
             }
         }
-#ifdef MVS_FX_EXPERIMENTS
-        FX_PROF_MARK(6);
-        pt_chunks++;
-#endif
     }
-#ifdef MVS_FX_EXPERIMENTS
-    if (pt_on && threadIdx.x == 0) {
-        unsigned long long *out = (unsigned long long *)((char *)p.plan_stats + 64);
-        for (int i = 0; i < 8; i++) atomicAdd(out + i, pt_sum[i]);
-        atomicAdd(out + 8, pt_iter);
-        atomicAdd(out + 9, pt_chunks);
-    }
-#endif
     if (FUSED) {
 #pragma unroll
         for (int j = 0; j < NPX; j++)
@@ -971,14 +903,6 @@ int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool gen
         p.part = (uint2 *)ctx->best_parts.ptr;
     }
     const dim3 grid((unsigned)(div_up(groups, 8) * 64), (unsigned)nsplit);
-#ifdef MVS_FX_EXPERIMENTS
-    const bool prof = ctx->hooks.fx_prof;
-    if (prof) {  // per-section cycle sums of wavefront 0 of every workgroup (s_memtime), printed after the launch
-        if ((rc = ensure(ctx, ctx->plan_stats, 256))) return rc;
-        p.plan_stats = (int *)ctx->plan_stats.ptr;
-        MVS_HIP(ctx, hipMemsetAsync(ctx->plan_stats.ptr, 0, 256, ctx->stream));
-    }
-#endif
     if (p.sep_y) {  // some view qualifies for the separable path: the instantiation that has it
         if (vol && fused)
             sweep_fx_tiled<true, true, true><<<grid, 256, 0, ctx->stream>>>(p, lut);
@@ -993,18 +917,6 @@ int sweep_fx_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, bool gen
     else
         sweep_fx_tiled<false, true><<<grid, 256, 0, ctx->stream>>>(p, lut);
     MVS_HIP(ctx, hipGetLastError());
-#ifdef MVS_FX_EXPERIMENTS
-    if (prof) {
-        unsigned long long h[16];
-        MVS_HIP(ctx, hipMemcpyAsync(h, (char *)ctx->plan_stats.ptr + 64, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-        MVS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        static const char *names[8] = {"top->tables read", "->barrier passed", "->look-ahead issued", "->first loop", "loop j=0", "loop j=1 + end", "epilogue", "batch load"};
-        fprintf(stderr, "fx prof: iterations %llu chunks %llu;", h[8], h[9]);
-        for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.0f |", names[i], (double)h[i] / (double)(i < 6 ? (h[8] ? h[8] : 1) : (h[9] ? h[9] : 1)));
-        fprintf(stderr, " s_memtime ticks per iteration / chunk\n");
-        p.plan_stats = nullptr;
-    }
-#endif
     return nsplit;  // > 0: the caller merges the partial bests when p.part is set
 }
 

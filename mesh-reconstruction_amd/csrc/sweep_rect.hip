@@ -351,7 +351,6 @@ struct RectArgs {
     size_t pad_slab;
     int pitch, W, H, D, V, v0, vcount, nchunks, chunk0, chunk1, cps, ty0, tyn, tiles_x;
     int slot_dw;   // dwords per LDS slot = 256 x copy instructions per region (one instruction fills 256 dwords); two slots
-    int debug;     // timing experiments, honoured by builds with -DMVS_RX_EXPERIMENTS only: 1 no copies, 2 no sampling, 4 no barrier, 8 every copy from one box, 16 no epilogue, 32 every plane taken for FULL, 64 no masks, 128 no failed-certificate block, 256 the plain comparison throughout, 512 half the regions with each sampled / copied / finished twice = the work of 8 planes per wavefront (wrong results)
 };
 
 template <typename T>
@@ -359,13 +358,6 @@ __device__ __forceinline__ T cold_get(uintptr_t c, size_t off)
 {
     return *(const __attribute__((address_space(4))) T *)(c + off);
 }
-#ifdef MVS_RX_EXPERIMENTS
-#define RX_DBG(a, bit) (((a).debug & (bit)) != 0)
-#elif defined(MVS_RX_CUT)  // the same experiments decided at compile time (no run-time flag in the code: the production kernel minus the cut)
-#define RX_DBG(a, bit) (((MVS_RX_CUT) & (bit)) != 0)
-#else
-#define RX_DBG(a, bit) false
-#endif
 #define RX_COLD(c, T, field) cold_get<T>((uintptr_t)(c), offsetof(RectCold, field))
 
 // raw buffer resource over `bytes` bytes at p (gfx950: dword 3 = 0x00020000, 32-bit data format): buffer instructions take a
@@ -411,9 +403,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     }
 
     const int chunk_first = a.chunk0 + (int)blockIdx.y * a.cps;
-    const int chunk_last_all = min(a.chunk1, chunk_first + a.cps);
-    // (timing experiment 512: half the regions, each sampled and finished twice -- the work of 8 planes per wavefront at today's registers and copies; wrong results)
-    const int chunk_last = RX_DBG(a, 512) ? chunk_first + max(1, (chunk_last_all - chunk_first) / 2) : chunk_last_all;
+    const int chunk_last = min(a.chunk1, chunk_first + a.cps);
     const int vend = a.v0 + a.vcount;
     const int nreg = (chunk_last - chunk_first) * a.vcount;
 
@@ -428,9 +418,8 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
     // empty), ysrc / yn = Y record dwords 2 / 3 (byte offset of the box's first row in the quad images; rows | y0 << 8).  Rows of RS
     // quads, 64 16-byte units per instruction; only the last instruction of a region runs under a lane mask.
     auto issue_copy = [&](uint32_t xsx, uint32_t ysrc, uint32_t yn, uint32_t slot_dw0) {
-        if (RX_DBG(a, 1)) return;
         const int n = (int)((yn & 0xffu) * (xsx >> 16));
-        const uint32_t src = RX_DBG(a, 8) ? 0u : (xsx & 0xffffu) + ysrc;  // (experiment 8: every region copies the same box: the copies hit in L2)
+        const uint32_t src = (xsx & 0xffffu) + ysrc;
         uint32_t *dst = smem + slot_dw0 + SLOT_BIAS_DW + wave * 256;  // (the records' offsets are biased: pixel 0 of a partly visible tile lies before the box)
         const int left = n - wave * 64;  // units of the region this wavefront still has to copy (wave-uniform)
         auto copy = [&](int t, bool whole) {
@@ -513,25 +502,24 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
         // every copy and every record this wavefront asked for has landed ...
         wait_vm<0>();
         // ... and so have every other wavefront's; nobody reads region r - 1 any more
-        if (!RX_DBG(a, 4)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         // request region r + 1 into the other slot and the records of region r + 2: in flight during this region's sampling
         if (r + 1 < nreg) issue_copy(rdl(x1r, 6), rdl(y1r, 2), rdl(y1r, 3), slot_nxt);
-        if (RX_DBG(a, 512) && r + 1 < nreg) issue_copy(rdl(x1r, 6), rdl(y1r, 2), rdl(y1r, 3), slot_nxt);  // (twice the bytes per region, like a 32-plane box)
         const uint32_t x2r = load_x(c2.xo), y2r = load_y(c2.xo + ydelta);
         advance(c2);
         const uint32_t rsum = x0r + y0r;                            // (one vector add, two v_readlane: not four and two scalar adds)
         const uint32_t sum01 = rdl(rsum, 0), sum23 = rdl(rsum, 1);  // per plane: LDS byte offset, or a flag bit
         const uint32_t we[RX_KW] = {rdl(x0r, 2), rdl(x0r, 3), rdl(x0r, 4), rdl(x0r, 5)};
-        const uint32_t fmask = (RX_DBG(a, 32) || RX_DBG(a, 128)) ? 0x3fffu : 0xffffu;
+        const uint32_t fmask = 0xffffu;
         const uint32_t fld[RX_KW] = {sum01 & fmask, (sum01 >> 16) & fmask, sum23 & fmask, (sum23 >> 16) & fmask};
 
         // ---- sample region r ----
-        const uint32_t special = (RX_DBG(a, 32) || RX_DBG(a, 128)) ? 0u : (sum01 | sum23) & 0xc000c000u;
-        if (!RX_DBG(a, 2)) {
+        const uint32_t special = (sum01 | sum23) & 0xc000c000u;
+        {
             const uint32_t slot_byte = lds_base + slot_cur * 4u;
             uint32_t qd[1][8];
             // per plane: what is out of frame although the certificates hold (0: nothing -- with no flag in the field that is a FULL plane)
-            const uint32_t xmasks = (RX_DBG(a, 32) || RX_DBG(a, 64)) ? 0u : rdl(x0r, 7), ymasks = (RX_DBG(a, 32) || RX_DBG(a, 64)) ? 0u : rdl(y0r, 4);
+            const uint32_t xmasks = rdl(x0r, 7), ymasks = rdl(y0r, 4);
             const uint32_t anymask = xmasks | ymasks;
             if (__builtin_expect(anymask != 0u, 0)) {
 #pragma unroll
@@ -676,7 +664,7 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
         }
 
         // ---- chunk epilogue ----
-        if (v + 1 == vend && !RX_DBG(a, 16)) {
+        if (v + 1 == vend) {
             const int d0 = chunk * RX_PC + wave * RX_KW;
             const size_t P = (size_t)a.W * a.H;
             const uint32_t pix0 = 4u * (uint32_t)(row0 * a.W + col);  // byte offset of this lane's first pixel inside a plane
@@ -684,19 +672,18 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
             // While every plane of every chunk so far was FULL for every view, every cell carries the same count and the packed cells
             // compare like their sums: "cell < best" (best starts at 0xffffffff) instead of the cross-multiplied comparison.  The
             // first chunk with a plane that is not FULL ends that for the rest of the workgroup (same packed cells, start value 1).
-            if (FUSED && plain && spacc != 0u && !RX_DBG(a, 256)) {
+            if (FUSED && plain && spacc != 0u) {
                 plain = false;
 #pragma unroll
                 for (int j = 0; j < 8; j++) best[j] = bi[j] < 0 ? 1u : best[j];
             }
-            int d_extra = 0;  // (experiment 512 only)
             auto finish = [&](auto checked_rows, auto plain_compare) {
 #pragma unroll
                 for (int k = 0; k < RX_KW; k++) {
                     const uint32_t cntk = ((uint32_t)a.vcount - ((spacc >> (8 * k)) & 0xffu)) << 24;  // FULL planes: every cell gets the view's count
-                    if (d0 + k + d_extra < a.D) {
+                    if (d0 + k < a.D) {
                         // one resource per plane (a volume can exceed the 4 GiB a resource spans), rows by the wave-uniform offset
-                        const __amdgpu_buffer_rsrc_t rvol = make_rsrc(WRITE_VOLUME ? a.volume + (size_t)(d0 + k + d_extra) * P : nullptr, 0xffffffffu);
+                        const __amdgpu_buffer_rsrc_t rvol = make_rsrc(WRITE_VOLUME ? a.volume + (size_t)(d0 + k) * P : nullptr, 0xffffffffu);
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
                             if (!checked_rows.value || j < nrows) {
@@ -712,11 +699,6 @@ __global__ __launch_bounds__(256, RX_WAVES_PER_SIMD) void sweep_fx_rect(RectArgs
                     }
                 }
             };
-            if (RX_DBG(a, 512) && col_ok) {  // the other half of the workgroup's planes: the same store traffic
-                d_extra = (chunk_last - chunk_first) * RX_PC;
-                finish(std::false_type{}, std::true_type{});
-                d_extra = 0;
-            }
             if (col_ok) {
                 if (nrows == 8 && plain)
                     finish(std::false_type{}, std::true_type{});
@@ -973,12 +955,8 @@ int sweep_rect_launch(mvs_ctx *ctx, SweepParams &p, bool vol, bool fused, unsign
     a.tyn = p.tyn;
     a.tiles_x = p.tiles_x;
     a.slot_dw = ctx->rect_slot_dw;
-    a.debug = p.debug;
     size_t lds = ((size_t)2 * a.slot_dw + RX_BIAS_X + (size_t)RX_BIAS_Y * ctx->rect_rs) * 4;  // two slots, the second one's data ends a bias further on
     if (fused) lds = lds < 16384 ? 16384 : lds;  // the cross-wavefront depth selection borrows 16 KiB
-#ifdef MVS_RX_CUT
-    if (ctx->hooks.rx_lds > 0) lds = std::max(lds, (size_t)ctx->hooks.rx_lds);  // timing experiments: occupancy through the LDS request
-#endif
     if (lds > 160 * 1024) return fail(ctx, MVS_EINVAL, "sweep_rect_launch: %zu bytes of LDS", lds);
 
     const int groups = div_up(p.tiles_x, 2) * div_up(p.tyn, 4);

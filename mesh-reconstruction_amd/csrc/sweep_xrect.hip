@@ -64,13 +64,7 @@ struct XrArgs {
     int rs;          // quads per LDS row (even)
     int slot_bytes;  // bytes per LDS slot (a multiple of 4096)
     float invW, invH, Wp, Hp;
-    int debug;  // timing experiments (MVS_XR_EXPERIMENTS builds only): 1 no copies, 2 no sampling, 8 every copy from one box, 16 the per-row values (texel row, fraction) for free -- wrong results
 };
-#ifdef MVS_XR_EXPERIMENTS
-#define XR_DBG(a, bit) (((a).debug & (bit)) != 0)
-#else
-#define XR_DBG(a, bit) false
-#endif
 
 __device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t acc)
 {
@@ -252,9 +246,9 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
     // copy of the region whose X / Y records are (xr, yr) into the slot at `slot_byte`
     auto issue_copy = [&](const u32x4 &xr1, const u32x4 &yr0, const u32x4 &yr1, uint32_t slot_byte) {
         const uint32_t xb = (uint32_t)__builtin_amdgcn_readfirstlane((int)xr1.x), yb = (uint32_t)__builtin_amdgcn_readfirstlane((int)yr1.x);
-        if ((xb >> 16) == 0u || (yb >> 16) == 0u || XR_DBG(a, 1)) return;
+        if ((xb >> 16) == 0u || (yb >> 16) == 0u) return;
         const int n = (int)(yb >> 16) * units;  // whole rows of rs quads (what lies right of the box is copied along and never read)
-        const uint32_t src = XR_DBG(a, 8) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)xr1.z) + (uint32_t)__builtin_amdgcn_readfirstlane((int)yr0.w);
+        const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)xr1.z) + (uint32_t)__builtin_amdgcn_readfirstlane((int)yr0.w);
         char *dst = (char *)smem + slot_byte + wave * 1024;
 #pragma unroll
         for (int t = 0; t < XR_MAX_NI; t++) {
@@ -329,7 +323,7 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
         const uint32_t both_sm = (xsm & ysm) >> (XR_KW * wave);  // bit k: for some pixel
 #pragma unroll
         for (int k = 0; k < XR_KW; k++) {
-            if (!((both_sm >> k) & 1u) || XR_DBG(a, 2)) {  // nothing of the tile in frame at this plane
+            if (!((both_sm >> k) & 1u)) {  // nothing of the tile in frame at this plane
                 notfull[k]++;
                 continue;
             }
@@ -339,9 +333,9 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
             const uint32_t addrx = slot_addr + (uint32_t)(((int)cx - x0) << 3);
             const float fyl = __builtin_amdgcn_fractf(cyl);
             const int iyl = (int)cyl;
-            const int iy0 = XR_DBG(a, 16) ? y0 : __builtin_amdgcn_readlane(iyl, 0);
+            const int iy0 = __builtin_amdgcn_readlane(iyl, 0);
             // rows of the tile usually sample consecutive texel rows (cy advances by one per row up to its rounding): then a row's address is the previous one + a stride
-            const bool consecutive = XR_DBG(a, 16) || ((uint32_t)__builtin_amdgcn_ballot_w64(iyl - (lane & 7) == iy0) & 0xffu) == 0xffu;
+            const bool consecutive = ((uint32_t)__builtin_amdgcn_ballot_w64(iyl - (lane & 7) == iy0) & 0xffu) == 0xffu;
             if (((both_fl >> k) & 1u) && consecutive) {
                 // the row fractions to LDS, the 8 quad reads and the 8 broadcast reads of the fractions, one wait, then the arithmetic
                 unsigned long long h[8];
@@ -366,7 +360,7 @@ __global__ __launch_bounds__(256, XR_WAVES) void sweep_exact_rect(XrArgs a)
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const half4_t q4 = __builtin_bit_cast(half4_t, h[j]);
-                    const float fy = XR_DBG(a, 16) ? zc[(j + k) & (XR_KW - 1)] : fyv[j];  // (experiment 16: what the per-row values cost)
+                    const float fy = fyv[j];
                     const float ta = __builtin_fmaf(fx, (float)q4[1], (float)q4[0]);
                     const float tb = __builtin_fmaf(fx, (float)q4[3], (float)q4[2]);
                     acc[j][k] = sad_u32((uint32_t)(int)__builtin_fmaf(fy, tb, ta), Im[j], acc[j][k]);
@@ -522,7 +516,6 @@ void fill_args(mvs_ctx *ctx, const SweepParams &p, XrArgs &a)
     a.invH = p.invH;
     a.Wp = p.Wp;
     a.Hp = p.Hp;
-    a.debug = p.debug;
     a.rs = ctx->xrect_rs;
     a.slot_bytes = ctx->xrect_slot_bytes;
     const size_t nxb = (size_t)a.tiles_x * a.V * a.nchunks;

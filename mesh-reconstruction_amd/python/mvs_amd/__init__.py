@@ -670,6 +670,9 @@ class Context:
         if not hasattr(self, "_batch_keep"):
             self._batch_keep = []
         self._batch_keep.append((out, cost_out))
+        # the library keeps two batches in flight and waits for the oldest itself when a third is queued (batch_slot[2]): the arrays of
+        # anything older are complete and need no reference from here (a caller that never calls the wait would otherwise pin them all)
+        del self._batch_keep[:-2]
         self._check(self.lib.mvs_sweep_batch_async(self.h, M, ms.ctypes.data_as(C.c_void_p), mc.ctypes.data_as(C.c_void_p), S, ss.ctypes.data_as(C.c_void_p),
                                                    sc.ctypes.data_as(C.c_void_p), int(nplanes), float(z_lo), float(z_hi), out.ctypes.data_as(C.c_void_p),
                                                    cost_out.ctypes.data_as(C.c_void_p) if cost_out is not None else None))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds mesh-reconstruction_amd/lib/variants/libmvs_hip_<tag>.so from the current tree with extra compiler flags applied to chosen
-# sources (default: csrc/sweep_rect.hip), for A/B timings in ONE GPU session (MVS_HIP_LIBRARY=<that file> python tools/exp_rect.py ...).
+# sources (default: csrc/sweep_rect.hip), for A/B timings in ONE GPU session (MVS_HIP_LIBRARY=<that file> python tools/time_general.py ...).
 #   tools/build_variant.sh <tag> "<extra flags>" [source ...]
 set -e
 cd "$(dirname "$0")/../mesh-reconstruction_amd"

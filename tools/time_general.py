@@ -53,8 +53,3 @@ with mvs_amd.Context(W, H, sampler="fixed") as ctx:
     timeit(ctx, both, 10)
     print(name, "rotated cameras:      volume+fused %.3f ms  fused only %.3f  volume only %.3f   (plan shape %d)" %
           (timeit(ctx, both), timeit(ctx, mvs_amd.MVS_SWEEP_FUSED_ARGMIN), timeit(ctx, mvs_amd.MVS_SWEEP_VOLUME), ctx.plan_shape()))
-    if "--exp" in sys.argv:  # needs a -DMVS_FX_EXPERIMENTS build of csrc/sweep_fx.hip (tools/build_variant.sh fxexp -DMVS_FX_EXPERIMENTS csrc/sweep_fx.hip)
-        for label, bits in (("full", 0), ("no copies", 1), ("no sample loop", 32), ("no loop, no copies", 33), ("no per-view barrier", 64), ("no epilogue", 128),
-                            ("no loop, no epilogue", 160), ("skeleton: no loop, copies, barrier, epilogue", 225), ("border as fast", 16), ("no look-ahead", 8)):
-            print("   %-46s %.3f ms  (fused only %.3f, volume only %.3f)" % (label, timeit(ctx, both | (bits << 8)), timeit(ctx, mvs_amd.MVS_SWEEP_FUSED_ARGMIN | (bits << 8)),
-                                                                           timeit(ctx, mvs_amd.MVS_SWEEP_VOLUME | (bits << 8))))

@@ -2,6 +2,7 @@
 640 x 480, both flow algorithms; and the same under MVS_SERIAL_FLOWS=1 / MVS_FB_LANES=1 when those are set in the environment.
 python tools/time_process_frame.py"""
 import os, sys, time
+os.environ.setdefault("MVS_TEST_HOOKS", "1")   # the A/B variables above are environment hooks: read only under the master switch (INTEGRATION.md section 7)
 import torch  # noqa: F401 (HIP runtime first)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mesh-reconstruction_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
