@@ -371,6 +371,86 @@ def flow_block(mvs_amd, np, device):
     return out
 
 
+def reference_stage_block(mvs_amd, np, device):
+    """The reference's own per-frame stage on the record (BASELINE config 1's shape: recon.cpp:65-117 at 640 x 480 on the zatisi cameras, 4 side views per
+    main frame): mvs_process_frame -- depth, per side view projected -> mixBackground -> calculateFlow, triangulatePixels, points downloaded -- as ONE context
+    sees it (the latency of a main frame) and over a SEQUENCE: the main frames of the `fa` loop are independent, one of them keeps a fraction of the GPU busy
+    (chains of small launches), so four host threads with a context each take every fourth main frame.  Frames are synthetic (the clip is not in the
+    reference checkout); the proxy mesh is a plane through the bundle points' centroid facing the middle camera.  Every thread's point blocks are checked
+    (CRC) against the single-context ones."""
+    import threading
+    from mvs_amd import tracks
+    t = tracks.load("zatisi.yaml")
+    W, H, cams, n = t["width"], t["height"], t["cameras"], len(t["cameras"])
+    rng = np.random.Generator(np.random.PCG64(0x5EED0005))
+    big = np.kron(rng.integers(0, 256, (H // 4 + 2, W // 4 + 64), dtype=np.uint8).astype(np.float32), np.ones((4, 4), np.float32))
+    frames = [np.ascontiguousarray(big[:H, 2 * (f % 100):2 * (f % 100) + W]).astype(np.uint8) for f in range(n)]
+    xyz = t["bundles"][:, :3] / t["bundles"][:, 3:4]
+    g = xyz.mean(0).astype(np.float64)
+    c = np.linalg.svd(np.asarray(cams[n // 2], np.float64)[[0, 1, 3], :])[2][-1]
+    nrm = (c[:3] / c[3] - g) / np.linalg.norm(c[:3] / c[3] - g)
+    a = np.cross(nrm, [0.0, 0.0, 1.0] if abs(nrm[2]) < 0.9 else [1.0, 0.0, 0.0])
+    a /= np.linalg.norm(a)
+    b = np.cross(nrm, a)
+    tt = np.linspace(-0.6 * np.abs(xyz - g).max(), 0.6 * np.abs(xyz - g).max(), 48)
+    U, V = np.meshgrid(tt, tt)
+    verts = np.concatenate([g[None, :] + U.reshape(-1, 1) * a[None, :] + V.reshape(-1, 1) * b[None, :], np.ones((48 * 48, 1))], 1).astype(np.float32)
+    idx = np.arange(48 * 48).reshape(48, 48)
+    q0, q1, q2, q3 = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
+    faces = np.concatenate([np.stack([q0, q1, q2], 1), np.stack([q1, q3, q2], 1)]).astype(np.int32)
+    mains = list(range(8, 104, 8))   # 12 main frames
+    sides = {f: [min(n - 1, max(0, f + o)) for o in (-10, -5, 5, 10)] for f in mains}
+    out = {"workload": "%dx%d, 4 side views per main frame, %d main frames of tracks/zatisi.yaml's cameras, synthetic frames" % (W, H, len(mains))}
+    for name, fb in (("variational", False), ("farneback", True)):
+        def frame_args(f):
+            return cams[f], frames[f], np.stack([cams[j] for j in sides[f]]), [frames[j] for j in sides[f]], fb
+        ref, npts = {}, 0
+        with mvs_amd.Context(W, H, device) as ctx:
+            ctx.load_mesh(verts, faces)
+            for f in mains:   # (untimed: the reference results, and the warm-up)
+                pts = ctx.process_frame(*frame_args(f))
+                ref[f] = zlib.crc32(np.ascontiguousarray(pts[:, :4]).tobytes())
+                npts += len(pts)
+            t0 = time.perf_counter()
+            for f in mains:
+                ctx.process_frame(*frame_args(f))
+            one = (time.perf_counter() - t0) / len(mains) * 1e3
+        nthreads = 4
+        ctxs = [mvs_amd.Context(W, H, device) for _ in range(nthreads)]
+        for cx in ctxs:
+            cx.load_mesh(verts, faces)
+        results = [dict() for _ in range(nthreads)]
+
+        def work(k, keep):
+            for f in mains[k::nthreads]:
+                pts = ctxs[k].process_frame(*frame_args(f))
+                if keep:
+                    results[k][f] = zlib.crc32(np.ascontiguousarray(pts[:, :4]).tobytes())
+
+        def run(keep):
+            th = [threading.Thread(target=work, args=(k, keep)) for k in range(nthreads)]
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            return time.perf_counter() - t0
+        run(True)
+        many = min(run(False), run(False)) / len(mains) * 1e3
+        for cx in ctxs:
+            cx.close()
+        equal = all(results[k][f] == ref[f] for k in range(nthreads) for f in mains[k::nthreads])
+        if not equal:
+            raise SystemExit("reference stage: a thread's point block differs from the single-context result")
+        out[name] = {"ms_per_main_frame_one_context": one, "ms_per_main_frame_%d_contexts_on_threads" % nthreads: many,
+                     "main_frames_per_s_one_context": 1e3 / one, "main_frames_per_s_%d_contexts" % nthreads: 1e3 / many,
+                     "points_per_main_frame": npts // len(mains), "thread_results_equal_single_context": equal}
+    out["note"] = ("mvs_process_frame (include/mvs.h): the body of recon.cpp's main-camera loop on device-resident data, host frames in, the (x, y, z, w, nx, ny, nz) rows out; "
+                   "one context = a main frame's latency; N contexts on N host threads of ONE GPU = the throughput of a sequence (the `fa` loop's iterations are independent; "
+                   "calls on one context are serialised by the caller, contexts are independent)")
+    return out
+
+
 def run_via_comm(args, same_device):
     """ONE process, N GPUs, through the C ABI's communicator: planes, main view and all side views uploaded to every rank once
     (mvs_comm_set_*), then K timed mvs_comm_run calls -- each returns when every rank thread has finished its share and, in rows mode,
@@ -1078,9 +1158,10 @@ def main():
         onecall_ms = (time.perf_counter() - t1) / n1 * 1e3
         octx.close()
 
-    flow = None
+    flow = ref_stage = None
     if world == 1 and not args.no_extras:
         flow = flow_block(mvs_amd, np, local_rank)
+        ref_stage = reference_stage_block(mvs_amd, np, local_rank)
 
     # sanity: the timed path produced the surface it was rendered from
     depth = primary["depth"]
@@ -1177,6 +1258,8 @@ def main():
                                                                          "path (1 / w per (view, plane) and the LDS row offsets per (view, row, plane) from tables), bit-identical")
         if flow is not None:
             out["flow"] = flow
+        if ref_stage is not None:
+            out["reference_stage"] = ref_stage
         if exact is not None:
             if exact.get("kernel"):
                 xtraffic = pmc_traffic(exact["kernel"], args.config, tag="exact")

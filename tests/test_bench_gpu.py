@@ -97,6 +97,11 @@ def test_bench_line_contract_and_two_rank_shardings():
     assert "roofline_traffic" in ext["general_camera_path"]
     # side cameras that are translations of the main one (any direction): the same kernel's separable path, faster than its general form
     assert 0 < ext["general_camera_path"]["translation_only_cameras_ms_per_step"] < ext["general_camera_path"]["ms_per_step"]
+    # the reference's own per-frame stage: one context's latency and four contexts' throughput on one GPU, every thread's points equal the single context's
+    for alg in ("variational", "farneback"):
+        rs = ext["reference_stage"][alg]
+        assert rs["thread_results_equal_single_context"] is True and rs["points_per_main_frame"] > 50000
+        assert 0 < rs["ms_per_main_frame_4_contexts_on_threads"] < rs["ms_per_main_frame_one_context"]
     # the flow block: Farneback returns the pair's known shift at every size it reports (round 5 timed a pair it returned nothing on)
     for name, f in ext["flow"].items():
         if name.startswith("farneback"):

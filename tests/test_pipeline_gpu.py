@@ -211,3 +211,37 @@ def test_no_scratch_of_one_stage_shows_in_another_stages_result():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "perf"))
     import fuzz_pipeline
     assert sum(fuzz_pipeline.run(seed, 25) for seed in (21, 22)) == 0
+
+
+def test_contexts_on_host_threads_are_independent():
+    """a sequence's main frames are independent (recon.cpp:65): N host threads with a context each on ONE GPU (the library serialises nothing
+    between contexts; calls on one context are the caller's to serialise) must return what a single context returns, for both flow algorithms --
+    the lanes, arenas and streams of one context must not leak into another's (bench.py's reference_stage block times exactly this)"""
+    import threading
+    import zlib
+    W, H, nside = 320, 240, 3
+    verts, faces, main, sides, main_img, side_imgs = _setup(W, H, nside)
+    variants = [(main_img, side_imgs), (side_imgs[0], [main_img] + side_imgs[1:]), (side_imgs[1], [side_imgs[0], main_img] + side_imgs[2:])]
+    ref = {}
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.load_mesh(verts, faces)
+        for fb in (False, True):
+            for v, (m, s) in enumerate(variants):
+                ref[fb, v] = zlib.crc32(ctx.process_frame(main, m, sides, s, fb).tobytes())
+    bad = []
+
+    def work(k):
+        with mvs_amd.Context(W, H) as c:
+            c.load_mesh(verts, faces)
+            for rep in range(4):
+                for fb in ((False, True) if k % 2 else (True, False)):
+                    v = (k + rep) % len(variants)
+                    m, s = variants[v]
+                    if zlib.crc32(c.process_frame(main, m, sides, s, fb).tobytes()) != ref[fb, v]:
+                        bad.append((k, rep, fb, v))
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad, bad
