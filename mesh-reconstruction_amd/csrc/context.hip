@@ -275,7 +275,7 @@ void mvs_destroy(mvs_ctx *ctx)
                       &ctx->volume_own, &ctx->depth, &ctx->cost, &ctx->index, &ctx->soup, &ctx->r_zbuf,
                       &ctx->r_shadow, &ctx->r_frame, &ctx->r_out3, &ctx->r_tmp0, &ctx->r_tmp1, &ctx->r_tmp2,
                       &ctx->cubic_tab, &ctx->flow_arena, &ctx->frame_buf, &ctx->best_parts, &ctx->plan_stats, &ctx->probe_buf, &ctx->filter_sort, &ctx->raster_bins, &ctx->fx_lut, &ctx->side_quads, &ctx->side_quads16,
-                      &ctx->r_mips, &ctx->flow_batch_arena, &ctx->rect_tab, &ctx->store_raw, &ctx->store_quads, &ctx->batch_slot[0].buf, &ctx->batch_slot[1].buf, &ctx->frame_ptrs, &ctx->view_slots, &ctx->xrect_tab, &ctx->sep_tab};
+                      &ctx->r_mips, &ctx->flow_batch_arena, &ctx->rect_tab, &ctx->r_tris_main, &ctx->store_raw, &ctx->store_quads, &ctx->batch_slot[0].buf, &ctx->batch_slot[1].buf, &ctx->frame_ptrs, &ctx->view_slots, &ctx->xrect_tab, &ctx->sep_tab};
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     for (auto &lane : ctx->lanes) {

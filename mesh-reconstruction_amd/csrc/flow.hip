@@ -1120,6 +1120,9 @@ __global__ __launch_bounds__(256) void pack_flow4(const float *__restrict__ flow
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    flow2 += 2 * n * blockIdx.y;  // blockIdx.y = flow of a batch (tightly packed)
+    var += n * blockIdx.y;
+    out4 += 4 * n * blockIdx.y;
     out4[4 * i] = flow2[2 * i];
     out4[4 * i + 1] = flow2[2 * i + 1];
     out4[4 * i + 2] = var[i];
@@ -1644,12 +1647,11 @@ static int farneback_batch_enqueue(mvs_ctx *ctx, const uint8_t *prev8, const uin
     u8_to_f32_kernel<<<g1(P * B), 256, 0, st>>>(next8, b.F + P, P * B);
     int r;
     if ((r = farneback_run(ctx, b.fb, B, b.flow2, 10, 0.8, winsize, 7, poly_n, poly_sigma))) return r;
-    // variance channel per flow: compare(prev, flowRemap(flow, next)) (flow.cpp:34), then the packing (37-41)
-    for (int i = 0; i < B; i++) {
-        if ((r = remap_device(ctx, b.flow2 + (size_t)i * 2 * P, 2, next8 + (size_t)i * P, b.r8 + (size_t)i * P))) return r;
-        if ((r = compare_device(ctx, prev8, b.r8 + (size_t)i * P, b.var + (size_t)i * P))) return r;
-        pack_flow4<<<g1(P), 256, 0, st>>>(b.flow2 + (size_t)i * 2 * P, b.var + (size_t)i * P, out4 + (size_t)i * 4 * P, P);
-    }
+    // variance channel of every flow: compare(prev, flowRemap(flow_i, next_i)) (flow.cpp:34), then the packing (37-41) -- each launch covers all B
+    // flows (round 6: twelve launches instead of twelve per side view)
+    if ((r = remap_batch_device(ctx, b.flow2, 2, (ptrdiff_t)(2 * P), next8, B, b.r8))) return r;
+    if ((r = compare_batch_device(ctx, prev8, b.r8, B, b.var))) return r;
+    pack_flow4<<<dim3(g1(P), (unsigned)B), 256, 0, st>>>(b.flow2, b.var, out4, P);
     MVS_HIP(ctx, hipGetLastError());
     return MVS_OK;
 }
@@ -1664,7 +1666,7 @@ int flow_farneback_batch_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uin
     const FlowBatchBufs probe = flow_batch_layout(nullptr, P, B);
     if ((rc = ensure(ctx, ctx->flow_batch_arena, sizeof(float) * probe.floats + 256))) return rc;
     if ((rc = ensure_cubic_table(ctx))) return rc;
-    if ((rc = compare_prepare(ctx))) return rc;
+    if ((rc = compare_prepare(ctx, B))) return rc;
     const FlowBatchBufs b = flow_batch_layout((float *)ctx->flow_batch_arena.ptr, P, B);
     ProfileScope ps(ctx, MVS_K_FLOW);  // (eager launches: see flow_run)
     return farneback_batch_enqueue(ctx, prev_dev, next_dev, B, out4_dev, b);
@@ -1677,11 +1679,13 @@ int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, 
     FlowBufs b;
     int rc = flow_prepare(ctx, b, use_farneback);
     if (rc) return rc;
-    MVS_HIP(ctx, hipMemcpyAsync(b.p8, prev_dev, P, hipMemcpyDeviceToDevice, ctx->stream));
-    MVS_HIP(ctx, hipMemcpyAsync(b.n8, next_dev, P, hipMemcpyDeviceToDevice, ctx->stream));
-    if ((rc = flow_run(ctx, b, use_farneback))) return rc;
-    MVS_HIP(ctx, hipMemcpyAsync(out4_dev, b.out4, sizeof(float) * 4 * P, hipMemcpyDeviceToDevice, ctx->stream));
-    return MVS_OK;
+    // the caller's device buffers ARE the inputs and the output (round 6: three device-to-device copies per flow fewer -- each a launch of its own
+    // with ~10 us of host latency, per side view of every main frame); the arena's own p8 / n8 / out4 serve mvs_flow's host buffers
+    (void)P;
+    b.p8 = const_cast<uint8_t *>(prev_dev);
+    b.n8 = const_cast<uint8_t *>(next_dev);
+    b.out4 = out4_dev;
+    return flow_run(ctx, b, use_farneback);
 }
 
 }  // namespace mvs

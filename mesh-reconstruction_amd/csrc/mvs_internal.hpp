@@ -105,6 +105,7 @@ struct mvs_ctx {
     mvs::DevBuf soup;                // 9 floats per face, dehomogenised triangle soup
     int nfaces = 0;
     mvs::DevBuf r_zbuf, r_shadow, r_frame, r_out3, r_tmp0, r_tmp1, r_tmp2, r_mips;
+    mvs::DevBuf r_tris_main;         // Render::projected's main pass: the main camera's triangle records (raster.hip: projected_main_pass)
     int texture_filter = MVS_FILTER_MIPMAP;  // Render::projected's frame texture: mip chain + trilinear (the reference's request) or level 0 only
     mvs::DevBuf cubic_tab;           // Q15 bicubic weights for remap (32*32*16 shorts)
     mvs::DevBuf flow_arena;          // optical-flow pyramids and work buffers
@@ -197,15 +198,20 @@ int sweep_set_planes_impl(mvs_ctx *ctx, int nplanes, float z_lo, float z_hi, boo
 // device-buffer forms used by the flow stage (photometric.hip)
 int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, float *out);
 int remap_device(mvs_ctx *ctx, const float *flow, int stride, const uint8_t *img, uint8_t *out);
+// the same for B pairs per launch (photometric.hip): compare(prev, next_i), flowRemap(flow_i, img_i)
+int compare_batch_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, int B, float *out);
+int remap_batch_device(mvs_ctx *ctx, const float *flow, int stride, ptrdiff_t flow_z, const uint8_t *img, int B, uint8_t *out);
 int ensure_cubic_table(mvs_ctx *ctx);
 // raster.hip / flow.hip / triangulate.hip on device buffers (pipeline.hip strings them together)
 int depth_device(mvs_ctx *ctx, const float cam[16], float *out_dev);
 int projected_device(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev);
+int projected_main_pass(mvs_ctx *ctx, const float cam[16]);   // the half of projected() that does not depend on the side view ...
+int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev);   // ... and the half that does
 int mix_background_device(mvs_ctx *ctx, const uint8_t *img3_dev, const uint8_t *bg_dev, float *depth_dev, uint8_t *out_dev);
 int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int use_farneback, float *out4_dev);
 int flow_farneback_batch_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int B, float *out4_dev);  // next: B frames, W*H bytes apart
 int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows, bool on_device, const float main_cam[16],
                      const float *side_cams, const float *depth, float *out_points7, int *out_count);
-int compare_prepare(mvs_ctx *ctx);  // allocates compare_device's arena
+int compare_prepare(mvs_ctx *ctx, int pairs = 1);  // allocates compare_device's arena (for `pairs` image pairs per launch: compare_batch_device)
 
 }  // namespace mvs

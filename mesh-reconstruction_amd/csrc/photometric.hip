@@ -56,11 +56,17 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__
 // one level of compare(): pyrDown of both images and their absolute difference (util.cpp:343-350) in one launch
 __global__ __launch_bounds__(256) void pyr_down_pair_absdiff(const float *__restrict__ a, const float *__restrict__ b, int w, int h,
                                                              float *__restrict__ da, float *__restrict__ db,
-                                                             float *__restrict__ dd, int dw, int dh)
+                                                             float *__restrict__ dd, int dw, int dh, ptrdiff_t z_stride = 0)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= dw || y >= dh) return;
+    const ptrdiff_t zo = z_stride * blockIdx.z;  // blockIdx.z = image pair of a batch (every pointer lives in that pair's arena)
+    a += zo;
+    b += zo;
+    da += zo;
+    db += zo;
+    dd += zo;
     const float va = pyr_down_at(a, w, h, x, y), vb = pyr_down_at(b, w, h, x, y);
     const size_t o = (size_t)y * dw + x;
     da[o] = va;
@@ -94,11 +100,13 @@ __device__ __forceinline__ float pyr_up_at(const float *__restrict__ src, int sw
 
 // acc[y][x] += pyrUp(src)[y][x]
 __global__ __launch_bounds__(256) void pyr_up_add_kernel(const float *__restrict__ src, int sw, int sh,
-                                                         float *__restrict__ acc, int dw, int dh)
+                                                         float *__restrict__ acc, int dw, int dh, ptrdiff_t src_z = 0, ptrdiff_t acc_z = 0)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= dw || y >= dh) return;
+    src += src_z * blockIdx.z;
+    acc += acc_z * blockIdx.z;
     acc[(size_t)y * dw + x] += pyr_up_at(src, sw, sh, x, y);
 }
 
@@ -112,8 +120,11 @@ struct PyrTail {
     unsigned off[24];  // element offset of each level inside the A / B / D arenas
 };
 
-__global__ __launch_bounds__(1024) void pyramid_tail(float *__restrict__ A, float *__restrict__ B, float *__restrict__ D, PyrTail t)
+__global__ __launch_bounds__(1024) void pyramid_tail(float *__restrict__ A, float *__restrict__ B, float *__restrict__ D, PyrTail t, ptrdiff_t z_stride = 0)
 {
+    A += z_stride * blockIdx.x;  // one workgroup per image pair of a batch
+    B += z_stride * blockIdx.x;
+    D += z_stride * blockIdx.x;
     for (int i = t.first + 1; i < t.nlev; i++) {
         const int n = t.w[i] * t.h[i];
         for (int c = threadIdx.x; c < n; c += blockDim.x) {
@@ -138,10 +149,14 @@ __global__ __launch_bounds__(1024) void pyramid_tail(float *__restrict__ A, floa
 
 __global__ __launch_bounds__(256) void u8_to_f32_pair_absdiff(const uint8_t *__restrict__ a8, const uint8_t *__restrict__ b8,
                                                               float *__restrict__ a, float *__restrict__ b,
-                                                              float *__restrict__ d, size_t n)
+                                                              float *__restrict__ d, size_t n, ptrdiff_t b8_z = 0, ptrdiff_t arena_z = 0, ptrdiff_t d_z = 0)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    b8 += b8_z * blockIdx.y;  // blockIdx.y = image pair of a batch: the first image is common, the second and the outputs advance
+    a += arena_z * blockIdx.y;
+    b += arena_z * blockIdx.y;
+    d += d_z * blockIdx.y;
     const float fa = (float)a8[i], fb = (float)b8[i];
     a[i] = fa;
     b[i] = fb;
@@ -158,11 +173,14 @@ __global__ __launch_bounds__(256) void absdiff_kernel(const float *__restrict__ 
 
 __global__ __launch_bounds__(256) void remap_cubic_kernel(const float *__restrict__ flow, int stride,
                                                           const uint8_t *__restrict__ img, int W, int H,
-                                                          const short *__restrict__ itab, uint8_t *__restrict__ out)
+                                                          const short *__restrict__ itab, uint8_t *__restrict__ out, ptrdiff_t flow_z = 0, ptrdiff_t img_z = 0)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
+    flow += flow_z * blockIdx.z;  // blockIdx.z = flow of a batch (image and output W*H bytes apart)
+    img += img_z * blockIdx.z;
+    out += img_z * blockIdx.z;
     const float *f = flow + ((size_t)y * W + x) * stride;
     const float mx = f[0] + (float)x, my = f[1] + (float)y;
     const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
@@ -245,10 +263,13 @@ static size_t compare_total(int W, int H)
     return total;
 }
 
-int compare_prepare(mvs_ctx *ctx) { return ensure(ctx, ctx->r_tmp1, sizeof(float) * compare_total(ctx->W, ctx->H) * 3); }
+int compare_prepare(mvs_ctx *ctx, int pairs) { return ensure(ctx, ctx->r_tmp1, sizeof(float) * compare_total(ctx->W, ctx->H) * 3 * (size_t)(pairs < 1 ? 1 : pairs)); }
 
-// compare() on device buffers: prev8/next8 (W*H u8) -> out (W*H f32).  All in-stream, no sync.
-int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, float *out)
+// compare() on device buffers for B image pairs that share their first image: prev8 (W*H u8), next8 (B x W*H u8) -> out (B x W*H f32).
+// Every launch covers all pairs (blockIdx.z / .y = pair; each pair has its own a / b / diff pyramids): the pyramids of a 640 x 480 pair
+// are ten launches of ~5 us, and mvs_process_frame's batched Farneback pass used to pay them once per side view (round 6).  All
+// in-stream, no sync; B = 1 is compare() itself.
+int compare_batch_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, int B, float *out)
 {
     const int W = ctx->W, H = ctx->H;
     // level geometry (util.cpp:335,341-351)
@@ -267,10 +288,11 @@ int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, flo
     }
     size_t total = 0;
     for (int i = 0; i < nlev; i++) total += (size_t)lw[i] * lh[i];
-    // arena: a-pyramid, b-pyramid, diff-pyramid (level 0 of diff is `out`)
-    int rc = ensure(ctx, ctx->r_tmp1, sizeof(float) * total * 3);
+    // arena per pair: a-pyramid, b-pyramid, diff-pyramid (level 0 of diff is `out`)
+    int rc = ensure(ctx, ctx->r_tmp1, sizeof(float) * total * 3 * (size_t)B);
     if (rc) return rc;
-    float *A = (float *)ctx->r_tmp1.ptr, *B = A + total, *D = B + total;
+    const ptrdiff_t az = (ptrdiff_t)(3 * total);
+    float *A = (float *)ctx->r_tmp1.ptr, *Bp = A + total, *D = Bp + total;
     std::vector<size_t> off(nlev);
     size_t o = 0;
     for (int i = 0; i < nlev; i++) {
@@ -278,7 +300,7 @@ int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, flo
         o += (size_t)lw[i] * lh[i];
     }
     const size_t P = (size_t)W * H;
-    u8_to_f32_pair_absdiff<<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(prev8, next8, A, B, out, P);
+    u8_to_f32_pair_absdiff<<<dim3((unsigned)((P + 255) / 256), (unsigned)B), 256, 0, ctx->stream>>>(prev8, next8, A, Bp, out, P, (ptrdiff_t)P, az, (ptrdiff_t)P);
     MVS_HIP(ctx, hipGetLastError());
     // levels of at most 4096 cells (never level 0, whose difference lives in `out`) are finished by one workgroup
     int tail = nlev;
@@ -287,9 +309,14 @@ int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, flo
             tail = i;
             break;
         }
+    auto grid = [&](int w, int h) {
+        dim3 g = grid2d(w, h);
+        g.z = (unsigned)B;
+        return g;
+    };
     for (int i = 1; i < nlev && i <= tail; i++) {
-        pyr_down_pair_absdiff<<<grid2d(lw[i], lh[i]), 256, 0, ctx->stream>>>(A + off[i - 1], B + off[i - 1], lw[i - 1], lh[i - 1],
-                                                                             A + off[i], B + off[i], D + off[i], lw[i], lh[i]);
+        pyr_down_pair_absdiff<<<grid(lw[i], lh[i]), 256, 0, ctx->stream>>>(A + off[i - 1], Bp + off[i - 1], lw[i - 1], lh[i - 1],
+                                                                           A + off[i], Bp + off[i], D + off[i], lw[i], lh[i], az);
         MVS_HIP(ctx, hipGetLastError());
     }
     int up_from = nlev - 2;
@@ -302,17 +329,19 @@ int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, flo
             t.h[i] = lh[i];
             t.off[i] = (unsigned)off[i];
         }
-        pyramid_tail<<<1, 1024, 0, ctx->stream>>>(A, B, D, t);
+        pyramid_tail<<<(unsigned)B, 1024, 0, ctx->stream>>>(A, Bp, D, t, az);
         MVS_HIP(ctx, hipGetLastError());
         up_from = tail - 1;
     }
     for (int i = up_from; i >= 0; i--) {
         float *dst = i == 0 ? out : D + off[i];
-        pyr_up_add_kernel<<<grid2d(lw[i], lh[i]), 256, 0, ctx->stream>>>(D + off[i + 1], lw[i + 1], lh[i + 1], dst, lw[i], lh[i]);
+        pyr_up_add_kernel<<<grid(lw[i], lh[i]), 256, 0, ctx->stream>>>(D + off[i + 1], lw[i + 1], lh[i + 1], dst, lw[i], lh[i], az, i == 0 ? (ptrdiff_t)P : az);
         MVS_HIP(ctx, hipGetLastError());
     }
     return MVS_OK;
 }
+
+int compare_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, float *out) { return compare_batch_device(ctx, prev8, next8, 1, out); }
 
 int ensure_cubic_table(mvs_ctx *ctx)
 {
@@ -327,15 +356,19 @@ int ensure_cubic_table(mvs_ctx *ctx)
 }
 
 // flowRemap on device buffers
-int remap_device(mvs_ctx *ctx, const float *flow, int stride, const uint8_t *img, uint8_t *out)
+// flowRemap for B (flow, image) pairs in one launch: flows `flow_z` floats apart, images and outputs W*H bytes apart (B = 1: flowRemap itself)
+int remap_batch_device(mvs_ctx *ctx, const float *flow, int stride, ptrdiff_t flow_z, const uint8_t *img, int B, uint8_t *out)
 {
     int rc = ensure_cubic_table(ctx);
     if (rc) return rc;
-    remap_cubic_kernel<<<grid2d(ctx->W, ctx->H), 256, 0, ctx->stream>>>(flow, stride, img, ctx->W, ctx->H,
-                                                                       (const short *)ctx->cubic_tab.ptr, out);
+    dim3 g = grid2d(ctx->W, ctx->H);
+    g.z = (unsigned)B;
+    remap_cubic_kernel<<<g, 256, 0, ctx->stream>>>(flow, stride, img, ctx->W, ctx->H, (const short *)ctx->cubic_tab.ptr, out, flow_z, (ptrdiff_t)ctx->W * ctx->H);
     MVS_HIP(ctx, hipGetLastError());
     return MVS_OK;
 }
+
+int remap_device(mvs_ctx *ctx, const float *flow, int stride, const uint8_t *img, uint8_t *out) { return remap_batch_device(ctx, flow, stride, 0, img, 1, out); }
 
 }  // namespace mvs
 

@@ -31,11 +31,11 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     MVS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)ctx->W * ctx->H;
     hipStream_t st = ctx->stream;
-    // frame_buf: main u8 | side u8 | out3 (3P u8) | mixed u8 x nside | pad to 256 | depth (P f32) | flows (nside * 4P f32)
-    const size_t bytes_u8 = ((5 + (size_t)nside) * P + 255) & ~(size_t)255;
+    // frame_buf: main u8 | side u8 x nside | out3 (3P u8) | mixed u8 x nside | pad to 256 | depth (P f32) | flows (nside * 4P f32)
+    const size_t bytes_u8 = ((4 + 2 * (size_t)nside) * P + 255) & ~(size_t)255;
     int rc = ensure(ctx, ctx->frame_buf, bytes_u8 + sizeof(float) * P * (1 + 4 * (size_t)nside) + 256);
     if (rc) return rc;
-    uint8_t *d_main = (uint8_t *)ctx->frame_buf.ptr, *d_side = d_main + P, *d_out3 = d_side + P, *d_mixed0 = d_out3 + 3 * P;
+    uint8_t *d_main = (uint8_t *)ctx->frame_buf.ptr, *d_side0 = d_main + P, *d_out3 = d_side0 + (size_t)nside * P, *d_mixed0 = d_out3 + 3 * P;
     float *d_depth = (float *)((uint8_t *)ctx->frame_buf.ptr + bytes_u8), *d_flows = d_depth + P;
 
     // The flows of the side views depend only on (main frame, mixed_i): each runs in a lane of its own (stream + arena +
@@ -85,14 +85,19 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
         }
     } join{ctx, st, nlanes};
 
-    MVS_HIP(ctx, hipMemcpyAsync(d_main, main_frame_hw, P, hipMemcpyHostToDevice, st));
+    for (int i = 0; i < nside; i++)
+        if (!side_frames_hw[i]) return fail(ctx, MVS_EINVAL, "mvs_process_frame: side_frames[%d] is null", i);
+    // What needs no frame goes first -- the depth map and the half of projected() that rasterises the mesh from the MAIN camera (once per main frame,
+    // not once per side view: round 6) -- so the GPU works while the host stages the frames; then all frames go up back to back (a copy from pageable
+    // memory in between two kernels cost 14 us of idle stream per side view)
     if ((rc = depth_device(ctx, main_cam, d_depth))) return rc;  // recon.cpp:70
+    if (nside > 0 && (rc = projected_main_pass(ctx, main_cam))) return rc;
+    MVS_HIP(ctx, hipMemcpyAsync(d_main, main_frame_hw, P, hipMemcpyHostToDevice, st));
+    for (int i = 0; i < nside; i++) MVS_HIP(ctx, hipMemcpyAsync(d_side0 + (size_t)i * P, side_frames_hw[i], P, hipMemcpyHostToDevice, st));
     std::vector<const float *> flow_ptrs((size_t)(nside > 0 ? nside : 1), nullptr);
     for (int i = 0; i < nside; i++) {
-        if (!side_frames_hw[i]) return fail(ctx, MVS_EINVAL, "mvs_process_frame: side_frames[%d] is null", i);
         uint8_t *d_mixed = d_mixed0 + (size_t)i * P;
-        MVS_HIP(ctx, hipMemcpyAsync(d_side, side_frames_hw[i], P, hipMemcpyHostToDevice, st));
-        if ((rc = projected_device(ctx, main_cam, d_side, side_cams + 16 * i, d_out3))) return rc;   // :85
+        if ((rc = projected_side_pass(ctx, d_side0 + (size_t)i * P, side_cams + 16 * i, d_out3))) return rc;   // :85
         if ((rc = mix_background_device(ctx, d_out3, d_main, d_depth, d_mixed))) return rc;           // :86
         float *fl = d_flows + (size_t)i * 4 * P;
         if (fb_batch) {
