@@ -57,6 +57,15 @@ __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t *__restric
     if (i < n) d[i] = (float)s[i];
 }
 
+__global__ __launch_bounds__(256) void u8_to_f32_pair_kernel(const uint8_t *__restrict__ s0, const uint8_t *__restrict__ s1, float *__restrict__ d0, float *__restrict__ d1, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        d0[i] = (float)s0[i];
+        d1[i] = (float)s1[i];
+    }
+}
+
 // symmetric separable filter, REFLECT_101: acc = k[c]*S[0]; acc += k[c+j]*(S[+j] + S[-j])
 template <bool COLS>
 __global__ __launch_bounds__(256) void gauss_kernel(const float *__restrict__ src, int w, int h, Taps t, int ksize,
@@ -798,6 +807,27 @@ struct VarBufs {
     float *Wu, *Wv, *du, *dv, *Iz, *Ix, *Iy, *Ixx, *Ixy, *Iyy, *Ixz, *Iyz, *a11, *a12, *a22, *b1, *b2, *wgt;
 };
 
+// All seven derivative images of the refinement in ONE launch (round 6; seven diff_kernel launches before -- a 640 x 480 refinement is launches, not
+// bytes, and mvs_process_frame runs four of them per main frame): Ix, Iy of A; Ixz, Iyz of Iz; Ixx, Ixy of Ix; Iyy of Iy.  A second derivative needs the
+// first one at the pixel's neighbours; each of those is ONE subtraction of two values of A, so it is formed again here from A -- the same operation on the
+// same operands as diff_kernel's stored value: the same bits -- instead of waiting for a kernel that stores it.
+__global__ __launch_bounds__(256) void var_derivatives_kernel(const float *__restrict__ A, const float *__restrict__ Iz, int w, int h, VarBufs B)
+{
+    PIX2D
+    auto cx = [&](int v) { return clampi(v, 0, w - 1); };
+    auto cy = [&](int v) { return clampi(v, 0, h - 1); };
+    auto ddx = [&](const float *__restrict__ a, int yy, int xx) { return a[(size_t)yy * w + cx(xx + 1)] - a[(size_t)yy * w + cx(xx - 1)]; };   // diff_kernel<false> at (yy, xx)
+    auto ddy = [&](const float *__restrict__ a, int yy, int xx) { return a[(size_t)cy(yy + 1) * w + xx] - a[(size_t)cy(yy - 1) * w + xx]; };   // diff_kernel<true> at (yy, xx)
+    const size_t p = (size_t)y * w + x;
+    B.Ix[p] = ddx(A, y, x);
+    B.Iy[p] = ddy(A, y, x);
+    B.Ixz[p] = ddx(Iz, y, x);
+    B.Iyz[p] = ddy(Iz, y, x);
+    B.Ixx[p] = ddx(A, y, cx(x + 1)) - ddx(A, y, cx(x - 1));   // diff_kernel<false>(Ix)
+    B.Ixy[p] = ddx(A, cy(y + 1), x) - ddx(A, cy(y - 1), x);   // diff_kernel<true>(Ix)
+    B.Iyy[p] = ddy(A, cy(y + 1), x) - ddy(A, cy(y - 1), x);   // diff_kernel<true>(Iy)
+}
+
 __global__ __launch_bounds__(256) void var_data_term(VarBufs B, int w, int h)
 {
     PIX2D
@@ -1470,13 +1500,17 @@ static int variational_device(mvs_ctx *ctx, const float *I0, const float *I1, fl
     for (size_t i = 0; i < sizeof(slots) / sizeof(slots[0]); i++) *slots[i] = arena + i * P;
     split_flow_kernel<<<g1(P), 256, 0, st>>>(flow, B.Wu, B.Wv, B.du, B.dv, P);
     warp_q5_kernel<<<g2(w, h), 256, 0, st>>>(I1, w, h, B.Wu, B.Wv, I0, A, B.Iz);
-    diff_kernel<false><<<g2(w, h), 256, 0, st>>>(A, w, h, B.Ix);
-    diff_kernel<true><<<g2(w, h), 256, 0, st>>>(A, w, h, B.Iy);
-    diff_kernel<false><<<g2(w, h), 256, 0, st>>>(B.Iz, w, h, B.Ixz);
-    diff_kernel<true><<<g2(w, h), 256, 0, st>>>(B.Iz, w, h, B.Iyz);
-    diff_kernel<false><<<g2(w, h), 256, 0, st>>>(B.Ix, w, h, B.Ixx);
-    diff_kernel<true><<<g2(w, h), 256, 0, st>>>(B.Ix, w, h, B.Ixy);
-    diff_kernel<true><<<g2(w, h), 256, 0, st>>>(B.Iy, w, h, B.Iyy);
+    if (ctx->hooks.var_unfused) {   // (the A/B form keeps the seven separate launches too)
+        diff_kernel<false><<<g2(w, h), 256, 0, st>>>(A, w, h, B.Ix);
+        diff_kernel<true><<<g2(w, h), 256, 0, st>>>(A, w, h, B.Iy);
+        diff_kernel<false><<<g2(w, h), 256, 0, st>>>(B.Iz, w, h, B.Ixz);
+        diff_kernel<true><<<g2(w, h), 256, 0, st>>>(B.Iz, w, h, B.Iyz);
+        diff_kernel<false><<<g2(w, h), 256, 0, st>>>(B.Ix, w, h, B.Ixx);
+        diff_kernel<true><<<g2(w, h), 256, 0, st>>>(B.Ix, w, h, B.Ixy);
+        diff_kernel<true><<<g2(w, h), 256, 0, st>>>(B.Iy, w, h, B.Iyy);
+    } else {
+        var_derivatives_kernel<<<g2(w, h), 256, 0, st>>>(A, B.Iz, w, h, B);
+    }
     const dim3 half(div_up((w + 1) / 2, 64), div_up(h, 4));
     // MVS_VAR_UNFUSED=1 keeps the 13-launch form of a fixed-point iteration (A/B timing and the cross-check test)
     const bool unfused = ctx->hooks.var_unfused;
@@ -1533,14 +1567,14 @@ static int flow_prepare(mvs_ctx *ctx, FlowBufs &b, int use_farneback)
 
 // flow.cpp:19-42 on the buffers of `b`: inputs b.p8 / b.n8 (u8), output b.out4.  Everything between is a fixed
 // sequence of kernels on fixed buffers.
-static int flow_run(mvs_ctx *ctx, const FlowBufs &b, int use_farneback)
+// flow_only: stop after the flow (b.flow2): the variance channel and the packing are the caller's (flow_variance_batch_device)
+static int flow_run(mvs_ctx *ctx, const FlowBufs &b, int use_farneback, bool flow_only = false)
 {
     const int W = ctx->W, H = ctx->H;
     const size_t P = (size_t)W * H;
     hipStream_t st = ctx->stream;
     auto enqueue = [&]() -> int {
-        u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(b.p8, b.f0, P);
-        u8_to_f32_kernel<<<g1(P), 256, 0, st>>>(b.n8, b.f1, P);
+        u8_to_f32_pair_kernel<<<g1(P), 256, 0, st>>>(b.p8, b.n8, b.f0, b.f1, P);
         int r;
         if (use_farneback) {
             const double poly_sigma = (H + W) / 1000.0;  // flow.cpp:24-25
@@ -1552,6 +1586,10 @@ static int flow_run(mvs_ctx *ctx, const FlowBufs &b, int use_farneback)
             else
                 MVS_HIP(ctx, hipMemsetAsync(b.flow2, 0, sizeof(float) * 2 * P, st));  // flow.cpp:31 (uninitialised there), A-11
             if ((r = variational_device(ctx, b.f0, b.f1, b.flow2, b.arena))) return r;
+        }
+        if (flow_only) {
+            MVS_HIP(ctx, hipGetLastError());
+            return MVS_OK;
         }
         if ((r = remap_device(ctx, b.flow2, 2, b.n8, b.r8))) return r;  // flow.cpp:34
         if ((r = compare_device(ctx, b.p8, b.r8, b.var))) return r;
@@ -1686,6 +1724,33 @@ int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, 
     b.n8 = const_cast<uint8_t *>(next_dev);
     b.out4 = out4_dev;
     return flow_run(ctx, b, use_farneback);
+}
+
+// the dense flow alone (W*H*2 f32 into flow2_dev), without the variance channel: mvs_process_frame computes the variance channels of all its
+// side views in one batched pass afterwards (flow_variance_batch_device) instead of twelve launches per side view on the flow's own lane
+int flow_only_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int use_farneback, float *flow2_dev)
+{
+    FlowBufs b;
+    int rc = flow_prepare(ctx, b, use_farneback);
+    if (rc) return rc;
+    b.p8 = const_cast<uint8_t *>(prev_dev);
+    b.n8 = const_cast<uint8_t *>(next_dev);
+    b.flow2 = flow2_dev;
+    return flow_run(ctx, b, use_farneback, true);
+}
+
+// flow.cpp:34-41 for B flows against one previous frame: variance_i = compare(prev, flowRemap(flow_i, next_i)), out4_i = (u, v, variance, 0).
+// flow2: B x 2P f32, next8 / r8 (scratch): B x P u8, var (scratch): B x P f32, out4: B x 4P f32.  Twelve launches whatever B.
+int flow_variance_batch_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, const float *flow2, int B, uint8_t *r8, float *var, float *out4)
+{
+    const size_t P = (size_t)ctx->W * ctx->H;
+    int r;
+    if ((r = compare_prepare(ctx, B))) return r;
+    if ((r = remap_batch_device(ctx, flow2, 2, (ptrdiff_t)(2 * P), next8, B, r8))) return r;
+    if ((r = compare_batch_device(ctx, prev8, r8, B, var))) return r;
+    pack_flow4<<<dim3(g1(P), (unsigned)B), 256, 0, ctx->stream>>>(flow2, var, out4, P);
+    MVS_HIP(ctx, hipGetLastError());
+    return MVS_OK;
 }
 
 }  // namespace mvs

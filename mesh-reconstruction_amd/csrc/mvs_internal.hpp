@@ -209,6 +209,8 @@ int projected_main_pass(mvs_ctx *ctx, const float cam[16]);   // the half of pro
 int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev);   // ... and the half that does
 int mix_background_device(mvs_ctx *ctx, const uint8_t *img3_dev, const uint8_t *bg_dev, float *depth_dev, uint8_t *out_dev);
 int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int use_farneback, float *out4_dev);
+int flow_only_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int use_farneback, float *flow2_dev);  // without the variance channel ...
+int flow_variance_batch_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t *next8, const float *flow2, int B, uint8_t *r8, float *var, float *out4);  // ... which this adds for B flows per launch
 int flow_farneback_batch_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int B, float *out4_dev);  // next: B frames, W*H bytes apart
 int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows, bool on_device, const float main_cam[16],
                      const float *side_cams, const float *depth, float *out_points7, int *out_count);

@@ -31,12 +31,14 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     MVS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)ctx->W * ctx->H;
     hipStream_t st = ctx->stream;
-    // frame_buf: main u8 | side u8 x nside | out3 (3P u8) | mixed u8 x nside | pad to 256 | depth (P f32) | flows (nside * 4P f32)
-    const size_t bytes_u8 = ((4 + 2 * (size_t)nside) * P + 255) & ~(size_t)255;
-    int rc = ensure(ctx, ctx->frame_buf, bytes_u8 + sizeof(float) * P * (1 + 4 * (size_t)nside) + 256);
+    // frame_buf: main u8 | side u8 x nside | out3 (3P u8) | mixed u8 x nside | remapped u8 x nside | pad to 256 | depth (P f32) | flows (nside * 4P f32) |
+    // raw flows (nside * 2P f32) | variances (nside * P f32)
+    const size_t bytes_u8 = ((4 + 3 * (size_t)nside) * P + 255) & ~(size_t)255;
+    int rc = ensure(ctx, ctx->frame_buf, bytes_u8 + sizeof(float) * P * (1 + 7 * (size_t)nside) + 256);
     if (rc) return rc;
     uint8_t *d_main = (uint8_t *)ctx->frame_buf.ptr, *d_side0 = d_main + P, *d_out3 = d_side0 + (size_t)nside * P, *d_mixed0 = d_out3 + 3 * P;
-    float *d_depth = (float *)((uint8_t *)ctx->frame_buf.ptr + bytes_u8), *d_flows = d_depth + P;
+    uint8_t *d_remapped = d_mixed0 + (size_t)nside * P;
+    float *d_depth = (float *)((uint8_t *)ctx->frame_buf.ptr + bytes_u8), *d_flows = d_depth + P, *d_flow2 = d_flows + 4 * (size_t)nside * P, *d_var = d_flow2 + 2 * (size_t)nside * P;
 
     // The flows of the side views depend only on (main frame, mixed_i): each runs in a lane of its own (stream + arena +
     // pyramid) while the main stream goes on rasterising the next view; a flow is a chain of small kernels that fills
@@ -103,7 +105,7 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
         if (fb_batch) {
             // (after the loop)
         } else if (nlanes == 0) {
-            if ((rc = flow_device(ctx, d_main, d_mixed, use_farneback, fl))) return rc;               // :89
+            if ((rc = flow_only_device(ctx, d_main, d_mixed, use_farneback, d_flow2 + (size_t)i * 2 * P))) return rc;               // :89 (the flow; its variance channel below)
         } else {
             mvs_ctx::FlowLane &lane = ctx->lanes[i % nlanes];
             hipEvent_t ready = ctx->lane_events[2 * i], done = ctx->lane_events[2 * i + 1];
@@ -111,7 +113,7 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
             MVS_HIP(ctx, hipStreamWaitEvent(lane.stream, ready, 0));
             {
                 LaneScope scope(ctx, lane);
-                rc = flow_device(ctx, d_main, d_mixed, use_farneback, fl);                            // :89
+                rc = flow_only_device(ctx, d_main, d_mixed, use_farneback, d_flow2 + (size_t)i * 2 * P);   // :89 (the flow; its variance channel below)
                 if (rc == MVS_OK && hipEventRecord(done, ctx->stream) != hipSuccess) rc = fail(ctx, MVS_EHIP, "hipEventRecord");
             }
             if (rc) return rc;
@@ -120,6 +122,9 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     }
     if (fb_batch && (rc = flow_farneback_batch_device(ctx, d_main, d_mixed0, nside, d_flows))) return rc;                                            // :89, all side views
     for (int i = 0; i < nside && nlanes > 0; i++) MVS_HIP(ctx, hipStreamWaitEvent(st, ctx->lane_events[2 * i + 1], 0));
+    // flow.cpp:34-41 for every side view at once: the variance channels are twelve launches per flow of ~5 us each -- on the main stream, all flows per
+    // launch, they are twelve per main frame (round 6; the batched Farneback pass does the same inside flow_farneback_batch_device)
+    if (!fb_batch && nside > 0 && (rc = flow_variance_batch_device(ctx, d_main, d_mixed0, d_flow2, nside, d_remapped, d_var, d_flows))) return rc;
     if (depth_after_hw) MVS_HIP(ctx, hipMemcpyAsync(depth_after_hw, d_depth, sizeof(float) * P, hipMemcpyDeviceToHost, st));
     rc = triangulate_impl(ctx, nside, flow_ptrs.data(), true, main_cam, side_cams, d_depth, out_points7, out_count);  // :114
     if (rc == MVS_OK) join.armed = false;  // triangulate_impl synchronised the main stream, which had joined every lane
