@@ -652,6 +652,7 @@ Configuration::Configuration(int argc, char **argv)
                                            {"farneback", no_argument, 0, 'f'},          {"verbose", no_argument, 0, 'v'},
                                            {"hyper-verbose", no_argument, 0, 'V'},      {"help", no_argument, 0, 'h'},
                                            {"sweep-planes", required_argument, 0, 1000},  // (not in the reference: recon.hpp's sweepPlanes)
+                                           {"threads", required_argument, 0, 1001},       // (not in the reference: recon.hpp's threads)
                                            {0, 0, 0, 0}};
     for (;;) {
         int option_index = 0;
@@ -675,6 +676,7 @@ Configuration::Configuration(int argc, char **argv)
             break;
         case 'V': verbosity = 99; break;
         case 1000: sweepPlanes = std::max(0, atoi(optarg)); break;
+        case 1001: threads = std::min(64, std::max(1, atoi(optarg))); break;
         default:
             throw std::runtime_error("Usage: recon [OPTIONS] [INPUT_FILE]  (options: -c f, -e, -f, -h, -i s, -k i, -m s, -n i, -o s, -s f, -v, -V)");
         }

@@ -5,8 +5,13 @@
 // depth selection over resident frames, mvs_sweep_handles) in that loop: `--sweep-planes N` (Configuration::sweepPlanes, default 0 =
 // off) makes trackMainFrame hand the flows and triangulatePixels the swept depth instead of the proxy mesh's z-buffer.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <exception>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "recon.hpp"
 
@@ -69,26 +74,66 @@ Mat trackMainFrame(Configuration &config, Render *render, int fa, const std::vec
     return triangulatePixels(flows, mainCamera, cameras, depth);  // recon.cpp:114
 }
 
+std::vector<Mat> trackMainFrames(Configuration &config, Heuristic &hint, Render *render, const Mesh &mesh, const std::vector<numberedVector> &schedule)
+{
+    std::vector<Mat> blocks(schedule.size());
+    const int n = std::max(1, std::min(config.threads, (int)schedule.size()));
+    if (n == 1) {
+        for (size_t i = 0; i < schedule.size(); i++) blocks[i] = trackMainFrame(config, render, schedule[i].first, schedule[i].second);
+        return blocks;
+    }
+    // One main frame keeps a fraction of the GPU busy and one host thread queues its ~200 launches: N threads, each with a renderer
+    // (a context) of its own and the free functions' per-thread contexts, take main frames from a shared counter.  Thread 0 is the caller with `render`.
+    std::vector<std::unique_ptr<Render>> extra;
+    for (int k = 1; k < n; k++) {
+        extra.emplace_back(spawnRender(hint));
+        extra.back()->loadMesh(mesh);
+    }
+    std::atomic<size_t> next{0};
+    std::mutex err_mutex;
+    std::exception_ptr err;
+    auto work = [&](Render *r) {
+        try {
+            for (size_t i = next.fetch_add(1); i < schedule.size(); i = next.fetch_add(1)) blocks[i] = trackMainFrame(config, r, schedule[i].first, schedule[i].second);
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(err_mutex);
+            if (!err) err = std::current_exception();
+            next.store(schedule.size());  // nobody starts another frame
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < n; k++) threads.emplace_back(work, extra[(size_t)k - 1].get());
+    work(render);
+    for (auto &t : threads) t.join();
+    if (err) std::rethrow_exception(err);
+    return blocks;
+}
+
 void reconstructPoints(Configuration &config, Heuristic &hint, Render *render, Mat &points, Mat &normals)
 {
     while (hint.notHappy(points)) {  // recon.cpp:42
         const Mesh mesh = hint.tessellate(points, normals);
         render->loadMesh(mesh);
         if (hint.chooseCameras(mesh, config.allCameras(), *render) == 0) throw std::runtime_error("Heuristic has chosen no cameras");  // recon.cpp:54-57
+        std::vector<numberedVector> schedule;
         for (int fa = hint.beginMain(); fa != Heuristic::sentinel; fa = hint.nextMain()) {
             std::vector<int> sides;
             for (int fb = hint.beginSide(fa); fb != Heuristic::sentinel; fb = hint.nextSide(fa)) sides.push_back(fb);
-            const Mat tri = trackMainFrame(config, render, fa, sides);
+            schedule.emplace_back(fa, sides);
+        }
+        const std::vector<Mat> blocks = trackMainFrames(config, hint, render, mesh, schedule);
+        for (size_t i = 0; i < blocks.size(); i++) {
+            const Mat &tri = blocks[i];
             // recon.cpp:115-116: columns 0-3 are the points, 4-6 the normals
             Mat p(tri.rows, 4, mvs::F32C1), n(tri.rows, 3, mvs::F32C1);
-            for (int i = 0; i < tri.rows; i++) {
-                const float *row = tri.ptr<float>(i);
-                std::copy(row, row + 4, p.ptr<float>(i));
-                std::copy(row + 4, row + 7, n.ptr<float>(i));
+            for (int r = 0; r < tri.rows; r++) {
+                const float *row = tri.ptr<float>(r);
+                std::copy(row, row + 4, p.ptr<float>(r));
+                std::copy(row + 4, row + 7, n.ptr<float>(r));
             }
             points.push_back(p);
             normals.push_back(n);
-            if (config.verbosity >= 2) printf(" After processing main frame %i: %i points\n", fa, points.rows);
+            if (config.verbosity >= 2) printf(" After processing main frame %i: %i points\n", schedule[i].first, points.rows);
         }
         hint.filterPoints(points, normals);  // recon.cpp:123
     }

@@ -102,6 +102,8 @@ public:
     float centerX = 0, centerY = 0;
     bool doEstimateExposure = false;
     int sweepPlanes = 0;           // --sweep-planes N (long option only; not in the reference): 0 = the reference's path, N > 0 = trackMainFrame's swept depth
+    int threads = 1;               // --threads N (long option only; not in the reference): reconstructPoints runs the main frames of one outer iteration on N host
+                                   // threads, each with a renderer and contexts of its own on the one GPU (the `fa` loop's iterations are independent)
 
 protected:
     void parseYaml(const std::string &path);
@@ -155,6 +157,8 @@ public:
     virtual Mat projectedByDepth(const Mat camera, const Mat depth, const Mat frame, const Mat projector) = 0;
 };
 
+typedef std::pair<int, std::vector<int>> numberedVector;   // (main frame, its side frames): recon.hpp:102
+
 // == the driver's loop (recon.cpp:42-136) as functions, so that the sweep can sit inside it ==
 // recon.cpp:65-117 for ONE main frame: depth map, per side view projected -> mixBackground -> calculateFlow, then triangulatePixels; returns the
 // rows (x, y, z, w, nx, ny, nz).  With config.sweepPlanes == 0 (the default) these are exactly the reference's calls.  With sweepPlanes > 0 and a
@@ -162,11 +166,15 @@ public:
 // proxy mesh's own depth range widened by a quarter on both sides, kept only where the proxy covers the pixel -- and the side frames are warped
 // through it (projectedByDepth) instead of through the mesh: the flow then only has to correct what is left after depth selection.
 Mat trackMainFrame(Configuration &config, Render *render, int mainFrame, const std::vector<int> &sideFrames, Mat *depthUsed = nullptr);
-// recon.cpp:42-136: the outer iteration (tessellate -> loadMesh -> chooseCameras -> every main frame -> filterPoints) until the heuristic is happy
+// recon.cpp:42-136: the outer iteration (tessellate -> loadMesh -> chooseCameras -> every main frame -> filterPoints) until the heuristic is happy.
+// With config.threads > 1 the main frames of an iteration are tracked by that many host threads (renderers of their own from spawnRender, the mesh loaded
+// into each); the point blocks are appended in the order of the `fa` loop whatever thread produced them, so the result does not depend on the thread count.
 void reconstructPoints(Configuration &config, Heuristic &hint, Render *render, Mat &points, Mat &normals);
+// the same for a given schedule of (main frame, side frames), mesh already loaded into `render`: what one iteration's tracking phase does (recon.cpp:65-117 over
+// all main frames); returns the point blocks in schedule order.  `mesh` is loaded into the extra renderers of threads 2 .. N.
+std::vector<Mat> trackMainFrames(Configuration &config, Heuristic &hint, Render *render, const Mesh &mesh, const std::vector<numberedVector> &schedule);
 
 // == heuristic ==
-typedef std::pair<int, std::vector<int>> numberedVector;
 
 // cv::theRNG() as the reference uses it through cv::randu<float>() (heuristic.cpp:207,365,400,450): OpenCV's
 // multiply-with-carry generator, default state 0xffffffff, never seeded by the reference -> a fixed stream.

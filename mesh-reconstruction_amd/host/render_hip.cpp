@@ -7,7 +7,6 @@
 // device inside each call and never retained.
 #include <cmath>
 #include <cstdlib>
-#include <mutex>
 
 #include "../../include/mvs.h"
 #include "recon.hpp"
@@ -25,19 +24,26 @@ int device_from_env()
     return e ? atoi(e) : 0;
 }
 
-// the reference's free functions carry no context argument; they share one context per image size
-std::mutex g_mutex;
-std::map<std::pair<int, int>, mvs_ctx *> g_ctx;
+// the reference's free functions carry no context argument; they share one context per image size AND HOST THREAD: calls on one context are the
+// caller's to serialise (include/mvs.h), and reconstructPoints runs trackMainFrame on several threads (host/driver.cpp) -- each thread's calculateFlow,
+// mixBackground, triangulatePixels ... then work on contexts of their own, destroyed when the thread ends (the main thread's at process exit)
+struct ThreadContexts {
+    std::map<std::pair<int, int>, mvs_ctx *> ctx;
+    ~ThreadContexts()
+    {
+        for (auto &kv : ctx) mvs_destroy(kv.second);
+    }
+};
+thread_local ThreadContexts t_ctx;
 
 mvs_ctx *shared_ctx(int w, int h)
 {
-    std::lock_guard<std::mutex> lock(g_mutex);
     auto key = std::make_pair(w, h);
-    auto it = g_ctx.find(key);
-    if (it != g_ctx.end()) return it->second;
+    auto it = t_ctx.ctx.find(key);
+    if (it != t_ctx.ctx.end()) return it->second;
     mvs_ctx *c = mvs_create(device_from_env(), w, h);
     if (!c) raise(nullptr, "mvs_create");
-    g_ctx[key] = c;
+    t_ctx.ctx[key] = c;
     return c;
 }
 

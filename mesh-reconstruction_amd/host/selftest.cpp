@@ -517,9 +517,63 @@ static int run_sweep(int argc, char **argv)
     return fails ? 1 : 0;
 }
 
+// host_selftest sequence <tracks yaml> <verts.f32> <faces.i32> <threads> <farneback 0|1> <main frame> [<main frame> ...]
+// trackMainFrames (host/driver.cpp) over a schedule of main frames, each with its neighbours at -10, -5, +5, +10 frames (frames from the YAML's
+// `<clip>.frames` directory): once on one thread and once on <threads> threads with a renderer and contexts each -- the point blocks must be the same
+// bytes in the same order whatever the thread count; prints both times.
+static int run_sequence(int argc, char **argv)
+{
+    Configuration config(argv[2]);
+    const int threads = atoi(argv[5]);
+    config.useFarneback = atoi(argv[6]) != 0;
+    auto slurp = [](const char *path) {
+        std::ifstream f(path, std::ios::binary);
+        return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    };
+    const std::vector<char> vb = slurp(argv[3]), fb = slurp(argv[4]);
+    Mesh mesh(Mat((int)(vb.size() / 16), 4, mvs::F32C1), Mat((int)(fb.size() / 12), 3, mvs::S32C1));
+    std::memcpy(mesh.vertices.data, vb.data(), vb.size());
+    std::memcpy(mesh.faces.data, fb.data(), fb.size());
+    std::vector<numberedVector> schedule;
+    for (int i = 7; i < argc; i++) {
+        const int fa = atoi(argv[i]);
+        std::vector<int> sides;
+        for (int o : {-10, -5, 5, 10}) sides.push_back(std::min(config.frameCount() - 1, std::max(0, fa + o)));
+        schedule.emplace_back(fa, sides);
+    }
+    Heuristic hint(&config);
+    Render *render = spawnRender(hint);
+    render->loadMesh(mesh);
+    std::vector<Mat> ref;
+    double ms[2] = {0, 0};
+    for (int pass = 0; pass < 2; pass++) {
+        config.threads = pass ? threads : 1;
+        trackMainFrames(config, hint, render, mesh, schedule);  // warm-up: contexts, arenas
+        const auto t0 = std::chrono::steady_clock::now();
+        const std::vector<Mat> blocks = trackMainFrames(config, hint, render, mesh, schedule);
+        ms[pass] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (double)schedule.size();
+        if (!pass) {
+            ref = blocks;
+            continue;
+        }
+        CHECK(blocks.size() == ref.size(), "one block per main frame");
+        for (size_t i = 0; i < blocks.size() && i < ref.size(); i++) {
+            CHECK(blocks[i].rows == ref[i].rows && blocks[i].rows > 0, "main frame %d: %d points on %d threads, %d on one", schedule[i].first, blocks[i].rows, threads, ref[i].rows);
+            if (blocks[i].rows == ref[i].rows)
+                CHECK(!std::memcmp(blocks[i].data, ref[i].data, blocks[i].total() * blocks[i].elemSize()), "main frame %d: the points differ between 1 and %d threads", schedule[i].first, threads);
+        }
+    }
+    printf("trackMainFrames, %zu main frames, %s flow: %.2f ms per main frame on one thread, %.2f ms on %d threads\n", schedule.size(), config.useFarneback ? "Farneback" : "variational",
+           ms[0], ms[1], threads);
+    delete render;
+    printf("%s\n", fails ? "SELFTEST FAILED" : "sequence selftest OK");
+    return fails ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
+        if (argc >= 8 && !strcmp(argv[1], "sequence")) return run_sequence(argc, argv);
         if (argc >= 10 && !strcmp(argv[1], "sweep")) return run_sweep(argc, argv);
         if (argc >= 4 && !strcmp(argv[1], "exposure")) return run_exposure(argv[2], argv[3]);
         if (argc >= 4 && !strcmp(argv[1], "frames")) return run_frames(argv[2], argv[3], argc > 4 ? atoi(argv[4]) : 1);

@@ -167,3 +167,39 @@ def test_the_sweep_behind_the_cpp_seam(tmp_path):
     print("median |z - z_true| after one pass: reference path %.5f, swept depth %.5f (proxy mesh itself %.5f)" % (med["proxy"], med["swept"], med["proxy_proxy_error"]))
     assert med["proxy"] < med["proxy_proxy_error"]       # the reference's path moves towards the surface (tests/test_e2e_gpu.py) ...
     assert med["swept"] < 0.6 * med["proxy"], med        # ... and the swept depth is already there
+
+
+def test_the_driver_tracks_a_sequence_on_several_threads(tmp_path):
+    """trackMainFrames (host/driver.cpp; `--threads N`): the main frames of one outer iteration on N host threads, each with a renderer and the free
+    functions' contexts of its own on the one GPU -- the point blocks are the same bytes in the same order as on one thread, for both flow algorithms
+    (host_selftest compares them and prints the two times)"""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import c5_common
+    import mvs_amd
+    import scipy.ndimage as ndi
+    from test_e2e_gpu import _sheets
+    seq = c5_common.Sequence()
+    W, H = seq.W, seq.H
+    (Tv, Tf), (Pv, Pf) = _sheets(seq, 0.03)
+    rng = np.random.default_rng(10)
+    tex = ndi.gaussian_filter(rng.normal(size=(H, W)), 2.5)
+    tex = (127.5 + 110.0 * tex / np.abs(tex).max()).clip(0, 255).astype(np.uint8)
+    mains = [40, 48, 56, 64, 72, 80]
+    need = sorted(set(j for f in mains for j in [f] + seq.sides(f)))
+    shutil.copy(os.path.join(TRACKS, "zatisi.yaml"), tmp_path / "zatisi.yaml")
+    os.makedirs(tmp_path / "zatisi.avi.frames")
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.load_mesh(Tv, Tf)
+        for j in need:
+            img = ctx.projected(seq.cams[j], tex, seq.cams[seq.n // 2])[:, :, 0].copy()
+            with open(tmp_path / "zatisi.avi.frames" / ("%06d.pgm" % (j + 1)), "wb") as fh:
+                fh.write(b"P5\n%d %d\n255\n" % (W, H) + img.tobytes())
+    Pv.astype(np.float32).tofile(tmp_path / "verts.f32")
+    Pf.astype(np.int32).tofile(tmp_path / "faces.i32")
+    for fb in ("0", "1"):
+        r = subprocess.run([SELFTEST, "sequence", str(tmp_path / "zatisi.yaml"), str(tmp_path / "verts.f32"), str(tmp_path / "faces.i32"), "4", fb] + [str(f) for f in mains],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "sequence selftest OK" in r.stdout, r.stdout + r.stderr
+        print(r.stdout.strip().splitlines()[-2])
