@@ -62,6 +62,18 @@ Mat trackMainFrame(Configuration &config, Render *render, int fa, const std::vec
             if (dp[i] != backgroundDepth) dp[i] = sp[i];
         swept = true;
     }
+    if (!swept) {
+        // the reference's calls exactly; through the renderer's one-call form when it has one (the same rows bit for bit, tests/test_pipeline_gpu.py:
+        // every intermediate stays on the device instead of crossing PCIe after each stage)
+        if (FrameTracker *tracker = dynamic_cast<FrameTracker *>(render)) {
+            std::vector<Mat> sideCams, sideImgs;
+            for (int fb : sideFrames) {
+                sideCams.push_back(config.camera(fb));
+                sideImgs.push_back(config.frame(fb));
+            }
+            return tracker->trackFrame(mainCamera, originalImage, sideCams, sideImgs, config.useFarneback, depthUsed);
+        }
+    }
     MatList flows, cameras;
     for (int fb : sideFrames) {  // recon.cpp:81-112
         Mat projectedImage = swept ? sweeper->projectedByDepth(mainCamera, depth, config.frame(fb), config.camera(fb))
@@ -84,11 +96,20 @@ std::vector<Mat> trackMainFrames(Configuration &config, Heuristic &hint, Render 
     }
     // One main frame keeps a fraction of the GPU busy and one host thread queues its ~200 launches: N threads, each with a renderer
     // (a context) of its own and the free functions' per-thread contexts, take main frames from a shared counter.  Thread 0 is the caller with `render`.
-    std::vector<std::unique_ptr<Render>> extra;
-    for (int k = 1; k < n; k++) {
-        extra.emplace_back(spawnRender(hint));
-        extra.back()->loadMesh(mesh);
+    // The extra renderers live as long as the process (a context takes milliseconds to create and its arenas grow on first use: not once per outer
+    // iteration); the mesh of THIS iteration goes into each.  One sequence at a time: the pool is locked for the call.
+    static std::mutex pool_mutex;
+    static std::vector<std::unique_ptr<Render>> pool;
+    static mvs::Size pool_size;
+    std::lock_guard<std::mutex> pool_lock(pool_mutex);
+    const mvs::Size size = hint.renderSize();
+    if (size.width != pool_size.width || size.height != pool_size.height) {
+        pool.clear();
+        pool_size = size;
     }
+    while ((int)pool.size() < n - 1) pool.emplace_back(spawnRender(hint));
+    std::vector<std::unique_ptr<Render>> &extra = pool;
+    for (int k = 1; k < n; k++) extra[(size_t)k - 1]->loadMesh(mesh);
     std::atomic<size_t> next{0};
     std::mutex err_mutex;
     std::exception_ptr err;

@@ -157,6 +157,17 @@ public:
     virtual Mat projectedByDepth(const Mat camera, const Mat depth, const Mat frame, const Mat projector) = 0;
 };
 
+// Optional extension a renderer may also implement (RenderHIP does): the whole body of the `fa` loop (recon.cpp:65-117) in one call on the renderer's own
+// context -- depth, per side view projected -> mixBackground -> calculateFlow, triangulatePixels -- with every intermediate kept on the device
+// (mvs_process_frame): the same rows (x, y, z, w, nx, ny, nz), bit for bit, as the stage-by-stage calls, without their seven host round trips per side view.
+// Not part of the reference's interface; trackMainFrame uses it when present.
+class FrameTracker {
+public:
+    virtual ~FrameTracker() {}
+    virtual Mat trackFrame(const Mat mainCamera, const Mat mainFrame, const std::vector<Mat> &sideCameras, const std::vector<Mat> &sideFrames, bool useFarneback,
+                           Mat *depthAfter = nullptr) = 0;
+};
+
 typedef std::pair<int, std::vector<int>> numberedVector;   // (main frame, its side frames): recon.hpp:102
 
 // == the driver's loop (recon.cpp:42-136) as functions, so that the sweep can sit inside it ==

@@ -7,6 +7,7 @@
 // device inside each call and never retained.
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "../../include/mvs.h"
 #include "recon.hpp"
@@ -54,7 +55,7 @@ void expect(const Mat &m, int type, const char *what)
 
 }  // namespace
 
-class RenderHIP : public Render, public DepthProbe, public DepthSweep {
+class RenderHIP : public Render, public DepthProbe, public DepthSweep, public FrameTracker {
 public:
     RenderHIP(int width, int height) : w(width), h(height)
     {
@@ -153,12 +154,41 @@ public:
         return result;
     }
 
+    // ---- FrameTracker: mvs_process_frame on this renderer's context (its mesh is the one loadMesh put there) ----
+    Mat trackFrame(const Mat mainCamera, const Mat mainFrame, const std::vector<Mat> &sideCameras, const std::vector<Mat> &sideFrames, bool useFarneback, Mat *depthAfter) override
+    {
+        expect(mainCamera, mvs::F32C1, "trackFrame mainCamera");
+        expect(mainFrame, mvs::U8C1, "trackFrame mainFrame");
+        if (mainFrame.cols != w || mainFrame.rows != h) throw std::runtime_error("trackFrame: frame size differs from the render size");
+        if (sideCameras.size() != sideFrames.size()) throw std::runtime_error("trackFrame: one camera per side frame expected");
+        std::vector<float> cams;
+        std::vector<const uint8_t *> frames;
+        for (size_t i = 0; i < sideFrames.size(); i++) {
+            expect(sideCameras[i], mvs::F32C1, "trackFrame side camera");
+            expect(sideFrames[i], mvs::U8C1, "trackFrame side frame");
+            if (sideFrames[i].cols != w || sideFrames[i].rows != h) throw std::runtime_error("trackFrame: frame size differs from the render size");
+            cams.insert(cams.end(), sideCameras[i].ptr<float>(), sideCameras[i].ptr<float>() + 16);
+            frames.push_back(sideFrames[i].ptr<uint8_t>());
+        }
+        // room for one row per pixel, kept with the renderer (a fresh 8.6 MB Mat per main frame would be zero-filled and then copied again)
+        if (rows_scratch.size() < (size_t)w * h * 7) rows_scratch.resize((size_t)w * h * 7);
+        if (depthAfter) depthAfter->create(h, w, mvs::F32C1);
+        int n = 0;
+        if (mvs_process_frame(ctx, mainCamera.ptr<float>(), mainFrame.ptr<uint8_t>(), (int)frames.size(), cams.data(), frames.data(), useFarneback ? 1 : 0, rows_scratch.data(), &n,
+                              depthAfter ? depthAfter->ptr<float>() : nullptr))
+            raise(ctx, "trackFrame");
+        Mat rows(n, 7, mvs::F32C1);
+        if (n > 0) std::memcpy(rows.data, rows_scratch.data(), (size_t)n * 7 * sizeof(float));
+        return rows;
+    }
+
     mvs_ctx *context() const { return ctx; }
 
 protected:
     mvs_ctx *ctx;
     int w, h;
     std::vector<unsigned char> stored;
+    std::vector<float> rows_scratch;
 };
 
 // render_glx.cpp:57-62
