@@ -291,3 +291,26 @@ def test_a_sync_resident_run_under_the_poison_hook(loopback, monkeypatch):
             d, c = comm.fetch()
             np.testing.assert_array_equal(d, dA)
             np.testing.assert_array_equal(c, cA)
+
+
+def test_two_calls_in_flight_with_ranks_that_have_no_rows(loopback):
+    """72 rows on 8 ranks: the row bands are two tile rows each, ranks 5-7 sweep nothing and send nothing -- the queue, the waits and the published
+    maps must not depend on every rank taking part; both samplers' row granularities (8 and 16 rows)"""
+    W, H, D, V = 320, 72, 40, 3
+    main_cam, main_img, side_cams, sides, _ = synth.make_views(W, H, V, radius=0.3)
+    for sampler in ("fixed", "exact"):
+        with mvs_amd.Context(W, H, sampler=sampler) as ctx:
+            d1, c1 = ctx.sweep(main_cam, main_img, side_cams, sides, D, want_cost=True)
+        with mvs_amd.Comm([0] * 8, W, H, sampler=sampler) as comm:
+            comm.set(main_cam, main_img, side_cams, sides, D)
+            comm.run_async()
+            comm.run_async()
+            for _ in range(2):
+                comm.wait()
+                d, c = comm.fetch()
+                np.testing.assert_array_equal(d, d1, err_msg=sampler)
+                np.testing.assert_array_equal(c, c1, err_msg=sampler)
+            for _ in range(5):
+                comm.run_async()
+                comm.wait()
+            np.testing.assert_array_equal(comm.fetch()[0], d1)
