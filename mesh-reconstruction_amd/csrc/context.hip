@@ -267,8 +267,7 @@ void mvs_destroy(mvs_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->own_stream && ctx->own_stream != ctx->stream) (void)hipStreamSynchronize(ctx->own_stream);
-    for (auto &lane : ctx->lanes)  // before any buffer is freed: a lane may still read frame_buf or its arena
-        if (lane.stream) (void)hipStreamSynchronize(lane.stream);
+    lanes_shutdown(ctx);  // lane threads joined, lane streams drained, the shadows' arenas freed: before any buffer a lane may still read goes
     for (hipGraphExec_t g : ctx->flow_graph)
         if (g) (void)hipGraphExecDestroy(g);
     DevBuf *bufs[] = {&ctx->main_img, &ctx->side_pads, &ctx->qmats, &ctx->ztab, &ctx->plan, &ctx->upload,
@@ -278,12 +277,8 @@ void mvs_destroy(mvs_ctx *ctx)
                       &ctx->r_mips, &ctx->flow_batch_arena, &ctx->rect_tab, &ctx->r_tris_main, &ctx->store_raw, &ctx->store_quads, &ctx->batch_slot[0].buf, &ctx->batch_slot[1].buf, &ctx->frame_ptrs, &ctx->view_slots, &ctx->xrect_tab, &ctx->sep_tab};
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
-    for (auto &lane : ctx->lanes) {
-        if (lane.stream) (void)hipStreamSynchronize(lane.stream);
-        if (lane.arena.ptr) (void)hipFree(lane.arena.ptr);
-        if (lane.cmp.ptr) (void)hipFree(lane.cmp.ptr);
+    for (auto &lane : ctx->lanes)
         if (lane.stream) (void)hipStreamDestroy(lane.stream);
-    }
     for (hipEvent_t e : ctx->lane_events) (void)hipEventDestroy(e);
     if (ctx->plan_event) (void)hipEventDestroy(ctx->plan_event);
     for (hipEvent_t e : ctx->band_events) (void)hipEventDestroy(e);

@@ -1544,7 +1544,7 @@ struct FlowBufs {
     uint8_t *p8, *n8, *r8;
 };
 
-static int flow_prepare(mvs_ctx *ctx, FlowBufs &b, int use_farneback)
+static int flow_prepare(mvs_ctx *ctx, FlowBufs &b, int use_farneback, bool flow_only = false)
 {
     const size_t P = (size_t)ctx->W * ctx->H;
     // arena: work (fb_work_floats(P) floats, at least the variational path's 22 P; starts with 5P doubles) first, then f0, f1, flow2, var, out4; u8: prev, next, remapped
@@ -1561,6 +1561,7 @@ static int flow_prepare(mvs_ctx *ctx, FlowBufs &b, int use_farneback)
     b.p8 = (uint8_t *)(b.out4 + 4 * P);
     b.n8 = b.p8 + P;
     b.r8 = b.n8 + P;
+    if (flow_only) return MVS_OK;  // (no variance channel: neither the bicubic table nor compare()'s pyramids -- a lane's shadow context never has them)
     if ((rc = ensure_cubic_table(ctx))) return rc;
     return compare_prepare(ctx);
 }
@@ -1731,7 +1732,7 @@ int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, 
 int flow_only_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int use_farneback, float *flow2_dev)
 {
     FlowBufs b;
-    int rc = flow_prepare(ctx, b, use_farneback);
+    int rc = flow_prepare(ctx, b, use_farneback, true);
     if (rc) return rc;
     b.p8 = const_cast<uint8_t *>(prev_dev);
     b.n8 = const_cast<uint8_t *>(next_dev);

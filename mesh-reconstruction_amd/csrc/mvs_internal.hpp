@@ -133,9 +133,13 @@ struct mvs_ctx {
     std::vector<unsigned char> store_have;
     // mvs_process_frame runs the flows of one main frame's side views concurrently: a lane is everything calculateFlow keeps
     // per call (stream, arena, compare pyramid); pipeline.hip swaps a lane into the fields below for one call
+    // A lane: the stream one side view's flow runs on, a SHADOW context that stands for this context on that stream (device, size, hooks; its own flow
+    // arena; nothing else is used through it) and a host thread that queues the flow's launches while the calling thread goes on with the next side
+    // view (pipeline.hip: a main frame is ~150 launches at ~6 us of host time each, the calling thread alone was the bottleneck).
     struct FlowLane {
         hipStream_t stream = nullptr;
-        mvs::DevBuf arena, cmp;
+        mvs_ctx *shadow = nullptr;
+        void *worker = nullptr;   // pipeline.hip: LaneWorker
     };
     static constexpr int kFlowLanes = 4;
     FlowLane lanes[kFlowLanes];
@@ -214,6 +218,7 @@ int flow_variance_batch_device(mvs_ctx *ctx, const uint8_t *prev8, const uint8_t
 int flow_farneback_batch_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int B, float *out4_dev);  // next: B frames, W*H bytes apart
 int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows, bool on_device, const float main_cam[16],
                      const float *side_cams, const float *depth, float *out_points7, int *out_count);
+void lanes_shutdown(mvs_ctx *ctx);   // pipeline.hip: joins the lane threads, frees the shadows' arenas (mvs_destroy)
 int compare_prepare(mvs_ctx *ctx, int pairs = 1);  // allocates compare_device's arena (for `pairs` image pairs per launch: compare_batch_device)
 
 }  // namespace mvs

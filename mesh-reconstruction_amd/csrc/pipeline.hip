@@ -14,9 +14,97 @@
 #include "mvs_internal.hpp"
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <thread>
 
 using namespace mvs;
+
+namespace {
+
+// One host thread per flow lane: takes jobs (queue one side view's flow on the lane's stream) in order; idle() returns when everything handed over has
+// been queued.  Started by the first call that uses the lane, joined by lanes_shutdown (mvs_destroy).
+struct LaneWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv, done;
+    std::deque<std::function<void()>> jobs;
+    bool busy = false, quit = false;
+    int device = 0;
+
+    void loop()
+    {
+        (void)hipSetDevice(device);
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [&] { return quit || !jobs.empty(); });
+                if (jobs.empty()) return;  // quit
+                job = std::move(jobs.front());
+                jobs.pop_front();
+                busy = true;
+            }
+            job();
+            {
+                std::lock_guard<std::mutex> lock(m);
+                busy = false;
+                if (jobs.empty()) done.notify_all();
+            }
+        }
+    }
+    void submit(std::function<void()> job)
+    {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            if (!th.joinable()) th = std::thread(&LaneWorker::loop, this);
+            jobs.push_back(std::move(job));
+        }
+        cv.notify_one();
+    }
+    void idle()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        done.wait(lock, [&] { return jobs.empty() && !busy; });
+    }
+    void stop()
+    {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            quit = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
+}  // namespace
+
+namespace mvs {
+
+void lanes_shutdown(mvs_ctx *ctx)
+{
+    for (auto &lane : ctx->lanes) {
+        if (lane.worker) {
+            LaneWorker *w = (LaneWorker *)lane.worker;
+            w->stop();
+            delete w;
+            lane.worker = nullptr;
+        }
+        if (lane.stream) (void)hipStreamSynchronize(lane.stream);
+        if (lane.shadow) {
+            if (lane.shadow->flow_arena.ptr) (void)hipFree(lane.shadow->flow_arena.ptr);
+            delete lane.shadow;
+            lane.shadow = nullptr;
+        }
+    }
+}
+
+}  // namespace mvs
 
 extern "C" {
 
@@ -57,18 +145,28 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
         MVS_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->lane_events.push_back(e);
     }
-    struct LaneScope {  // calculateFlow's per-call state <-> a lane
-        mvs_ctx *c;
-        mvs_ctx::FlowLane &l;
-        void swap()
-        {
-            std::swap(c->stream, l.stream);
-            std::swap(c->flow_arena, l.arena);
-            std::swap(c->r_tmp1, l.cmp);
+    // a lane's shadow context: this context's stand-in on the lane's stream (flow_only_device reads device, size, hooks, stream and its own flow arena)
+    for (int l = 0; l < nlanes; l++) {
+        mvs_ctx::FlowLane &lane = ctx->lanes[l];
+        if (!lane.shadow) {
+            lane.shadow = new (std::nothrow) mvs_ctx();
+            if (!lane.shadow) return fail(ctx, MVS_ENOMEM, "mvs_process_frame: out of host memory");
+            lane.shadow->device = ctx->device;
+            lane.shadow->W = ctx->W;
+            lane.shadow->H = ctx->H;
+            lane.shadow->num_cus = ctx->num_cus;
+            lane.shadow->hooks = ctx->hooks;
+            snprintf(lane.shadow->err, sizeof(lane.shadow->err), "no error");
         }
-        LaneScope(mvs_ctx *ctx_, mvs_ctx::FlowLane &lane) : c(ctx_), l(lane) { swap(); }
-        ~LaneScope() { swap(); }
-    };
+        lane.shadow->stream = lane.stream;
+        if (!lane.worker) {
+            LaneWorker *w = new (std::nothrow) LaneWorker();
+            if (!w) return fail(ctx, MVS_ENOMEM, "mvs_process_frame: out of host memory");
+            w->device = ctx->device;
+            lane.worker = w;
+        }
+    }
+    std::vector<int> lane_rc((size_t)(nside > 0 ? nside : 1), MVS_OK);
 
     // Any early return below leaves kernels and host-to-device copies of the caller's frames in flight on the main stream
     // and on the lanes: the guard joins them all first, so neither the caller's buffers nor this context's arenas (which a
@@ -81,9 +179,11 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
         ~JoinOnError()
         {
             if (!armed) return;
+            for (int l = 0; l < nlanes; l++)
+                if (c->lanes[l].worker) ((LaneWorker *)c->lanes[l].worker)->idle();  // nothing is being queued any more ...
             (void)hipStreamSynchronize(st);
             for (int l = 0; l < nlanes; l++)
-                if (c->lanes[l].stream) (void)hipStreamSynchronize(c->lanes[l].stream);
+                if (c->lanes[l].stream) (void)hipStreamSynchronize(c->lanes[l].stream);  // ... and nothing queued is still running
         }
     } join{ctx, st, nlanes};
 
@@ -107,21 +207,32 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
         } else if (nlanes == 0) {
             if ((rc = flow_only_device(ctx, d_main, d_mixed, use_farneback, d_flow2 + (size_t)i * 2 * P))) return rc;               // :89 (the flow; its variance channel below)
         } else {
+            // the lane's host thread queues this view's flow (a dozen launches for the variational refinement, ~100 for a Farneback chain) while this thread
+            // goes on with the next side view; the lane's stream waits for `ready` (this view's mixed image), the main stream later for `done`
             mvs_ctx::FlowLane &lane = ctx->lanes[i % nlanes];
             hipEvent_t ready = ctx->lane_events[2 * i], done = ctx->lane_events[2 * i + 1];
             MVS_HIP(ctx, hipEventRecord(ready, st));
-            MVS_HIP(ctx, hipStreamWaitEvent(lane.stream, ready, 0));
-            {
-                LaneScope scope(ctx, lane);
-                rc = flow_only_device(ctx, d_main, d_mixed, use_farneback, d_flow2 + (size_t)i * 2 * P);   // :89 (the flow; its variance channel below)
-                if (rc == MVS_OK && hipEventRecord(done, ctx->stream) != hipSuccess) rc = fail(ctx, MVS_EHIP, "hipEventRecord");
-            }
-            if (rc) return rc;
+            mvs_ctx *shadow = lane.shadow;
+            hipStream_t ls = lane.stream;
+            float *flow2_i = d_flow2 + (size_t)i * 2 * P;
+            int *rc_i = &lane_rc[(size_t)i];
+            ((LaneWorker *)lane.worker)->submit([=]() {
+                int r = MVS_OK;
+                if (hipStreamWaitEvent(ls, ready, 0) != hipSuccess) r = MVS_EHIP;
+                if (r == MVS_OK) r = flow_only_device(shadow, d_main, d_mixed, use_farneback, flow2_i);   // :89 (the flow; its variance channel below)
+                if (r == MVS_OK && hipEventRecord(done, ls) != hipSuccess) r = MVS_EHIP;
+                *rc_i = r;
+            });
         }
         flow_ptrs[i] = fl;
     }
     if (fb_batch && (rc = flow_farneback_batch_device(ctx, d_main, d_mixed0, nside, d_flows))) return rc;                                            // :89, all side views
-    for (int i = 0; i < nside && nlanes > 0; i++) MVS_HIP(ctx, hipStreamWaitEvent(st, ctx->lane_events[2 * i + 1], 0));
+    if (nlanes > 0) {
+        for (int l = 0; l < nlanes; l++) ((LaneWorker *)ctx->lanes[l].worker)->idle();   // every flow is queued (and every `done` recorded)
+        for (int i = 0; i < nside; i++)
+            if (lane_rc[(size_t)i] != MVS_OK) return fail(ctx, lane_rc[(size_t)i], "mvs_process_frame: flow of side view %d: %s", i, ctx->lanes[i % nlanes].shadow->err);
+        for (int i = 0; i < nside; i++) MVS_HIP(ctx, hipStreamWaitEvent(st, ctx->lane_events[2 * i + 1], 0));
+    }
     // flow.cpp:34-41 for every side view at once: the variance channels are twelve launches per flow of ~5 us each -- on the main stream, all flows per
     // launch, they are twelve per main frame (round 6; the batched Farneback pass does the same inside flow_farneback_batch_device)
     if (!fb_batch && nside > 0 && (rc = flow_variance_batch_device(ctx, d_main, d_mixed0, d_flow2, nside, d_remapped, d_var, d_flows))) return rc;

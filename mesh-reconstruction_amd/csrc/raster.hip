@@ -368,15 +368,23 @@ __global__ __launch_bounds__(256) void raster_tiles(const TriRec *__restrict__ t
 // (render_glx.cpp:292-297 reads the already-filtered left neighbour).  One workgroup, blocked scan.
 __global__ __launch_bounds__(256) void row0_prefix_min(const float *__restrict__ a, int W, float *__restrict__ hf0)
 {
-    __shared__ float part[256];
+    __shared__ float part[2][256];
     const int per = (W + 255) / 256;
     const int s = threadIdx.x * per, e = min(s + per, W);
     float m = 3.0e38f;
     for (int j = s; j < e; j++) m = fminf(m, a[j]);
-    part[threadIdx.x] = m;
+    // inclusive prefix minima of the 256 block minima by doubling (min is exact and associative: any order gives the same values; the first
+    // form had thread t walk t partials one after the other -- 14 us of one workgroup on the critical path of every side view)
+    int cur = 0;
+    part[0][threadIdx.x] = m;
     __syncthreads();
-    float run = 3.0e38f;
-    for (int k = 0; k < (int)threadIdx.x; k++) run = fminf(run, part[k]);  // exclusive prefix of block minima
+    for (int d = 1; d < 256; d <<= 1) {
+        const float v = threadIdx.x >= (unsigned)d ? fminf(part[cur][threadIdx.x], part[cur][threadIdx.x - d]) : part[cur][threadIdx.x];
+        part[cur ^ 1][threadIdx.x] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    float run = threadIdx.x > 0 ? part[cur][threadIdx.x - 1] : 3.0e38f;  // exclusive prefix of block minima
     for (int j = s; j < e; j++) {
         // hf0[j] = min(a[0..j+1]) for 1 <= j <= W-2
         run = fminf(run, a[j]);
