@@ -106,6 +106,11 @@ struct mvs_ctx {
     int nfaces = 0;
     mvs::DevBuf r_zbuf, r_shadow, r_frame, r_out3, r_tmp0, r_tmp1, r_tmp2, r_mips;
     mvs::DevBuf r_tris_main;         // Render::projected's main pass: the main camera's triangle records (raster.hip: projected_main_pass)
+    // Render::projected's frame textures as raster.hip last made them (projected_textures): bytes per frame in r_frame / r_mips, how many frames were
+    // prepared up front (mvs_process_frame: all side views at once), and the mip-chain description of one frame (raster.hip's MipArgs, opaque here)
+    size_t tex_frame_bytes = 0, tex_mips_bytes = 0;
+    int tex_prepared = 0;
+    unsigned char tex_mip[256] = {0};
     int texture_filter = MVS_FILTER_MIPMAP;  // Render::projected's frame texture: mip chain + trilinear (the reference's request) or level 0 only
     mvs::DevBuf cubic_tab;           // Q15 bicubic weights for remap (32*32*16 shorts)
     mvs::DevBuf flow_arena;          // optical-flow pyramids and work buffers
@@ -210,7 +215,8 @@ int ensure_cubic_table(mvs_ctx *ctx);
 int depth_device(mvs_ctx *ctx, const float cam[16], float *out_dev);
 int projected_device(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev);
 int projected_main_pass(mvs_ctx *ctx, const float cam[16]);   // the half of projected() that does not depend on the side view ...
-int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev);   // ... and the half that does
+int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev, int prepared_view = -1);   // ... and the half that does
+int projected_prepare_views(mvs_ctx *ctx, const uint8_t *frames_dev, int nframes);   // the frame textures (wrap padding + mip chain) of nframes side frames, W*H bytes apart, per launch
 int mix_background_device(mvs_ctx *ctx, const uint8_t *img3_dev, const uint8_t *bg_dev, float *depth_dev, uint8_t *out_dev);
 int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int use_farneback, float *out4_dev);
 int flow_only_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int use_farneback, float *flow2_dev);  // without the variance channel ...

@@ -196,10 +196,11 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     if (nside > 0 && (rc = projected_main_pass(ctx, main_cam))) return rc;
     MVS_HIP(ctx, hipMemcpyAsync(d_main, main_frame_hw, P, hipMemcpyHostToDevice, st));
     for (int i = 0; i < nside; i++) MVS_HIP(ctx, hipMemcpyAsync(d_side0 + (size_t)i * P, side_frames_hw[i], P, hipMemcpyHostToDevice, st));
+    if (nside > 0 && (rc = projected_prepare_views(ctx, d_side0, nside))) return rc;   // every side frame's texture (wrap padding, mip chain): five launches in all
     std::vector<const float *> flow_ptrs((size_t)(nside > 0 ? nside : 1), nullptr);
     for (int i = 0; i < nside; i++) {
         uint8_t *d_mixed = d_mixed0 + (size_t)i * P;
-        if ((rc = projected_side_pass(ctx, d_side0 + (size_t)i * P, side_cams + 16 * i, d_out3))) return rc;   // :85
+        if ((rc = projected_side_pass(ctx, d_side0 + (size_t)i * P, side_cams + 16 * i, d_out3, i))) return rc;   // :85
         if ((rc = mix_background_device(ctx, d_out3, d_main, d_depth, d_mixed))) return rc;           // :86
         float *fl = d_flows + (size_t)i * 4 * P;
         if (fb_batch) {

@@ -434,10 +434,13 @@ struct MipArgs {
 };
 
 // wrap-padded level l from wrap-padded level l - 1 (one thread per padded texel)
-__global__ __launch_bounds__(256) void mip_reduce(const uint8_t *__restrict__ src, int pw, int ph, int sp, uint8_t *__restrict__ dst, int w, int h, int dp)
+__global__ __launch_bounds__(256) void mip_reduce(const uint8_t *__restrict__ src, int pw, int ph, int sp, uint8_t *__restrict__ dst, int w, int h, int dp,
+                                                  size_t src_z = 0, size_t dst_z = 0)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
     if (c >= w + 2 || r >= h + 2) return;
+    src += src_z * blockIdx.z;  // blockIdx.z = frame of a batch (mvs_process_frame prepares the textures of all its side views at once)
+    dst += dst_z * blockIdx.z;
     int j = r - 1, i = c - 1;
     j = j < 0 ? h - 1 : (j >= h ? 0 : j);
     i = i < 0 ? w - 1 : (i >= w ? 0 : i);
@@ -447,8 +450,10 @@ __global__ __launch_bounds__(256) void mip_reduce(const uint8_t *__restrict__ sr
 }
 
 // the small levels (<= 64 x 64 texels and everything above them) in one workgroup: one launch instead of one per level
-__global__ __launch_bounds__(256) void mip_tail(uint8_t *__restrict__ mips, const uint8_t *__restrict__ level0, MipArgs m, int first)
+__global__ __launch_bounds__(256) void mip_tail(uint8_t *__restrict__ mips, const uint8_t *__restrict__ level0, MipArgs m, int first, size_t mips_z = 0, size_t level0_z = 0)
 {
+    mips += mips_z * blockIdx.x;  // one workgroup per frame of a batch
+    level0 += level0_z * blockIdx.x;
     for (int l = first; l <= m.levels; l++) {
         const uint8_t *src = l - 1 == 0 ? level0 : mips + m.off[l - 1];
         uint8_t *dst = mips + m.off[l];
@@ -579,8 +584,24 @@ __global__ __launch_bounds__(256) void mix_background(const uint8_t *__restrict_
     if (masked) depth[i] = MVS_BACKGROUND_DEPTH;
 }
 
-// defined in context.hip
-__global__ void pad_wrap_kernel(const uint8_t *__restrict__ img, uint8_t *__restrict__ pad, int W, int H, int pitch);
+// pad_wrap_kernel (context.hip) for N frames per launch: frames W*H bytes apart, padded copies `pad_z` bytes apart (blockIdx.z = frame)
+__global__ __launch_bounds__(256) void pad_wrap_frames(const uint8_t *__restrict__ img, uint8_t *__restrict__ pad, int W, int H, int pitch, size_t pad_z)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= pitch) return;
+    img += (size_t)W * H * blockIdx.z;
+    pad += pad_z * blockIdx.z;
+    uint8_t v = 0;
+    if (c < W + 2) {
+        int sr = r - 1;
+        sr = sr < 0 ? H - 1 : (sr >= H ? 0 : sr);
+        int sc = c - 1;
+        sc = sc < 0 ? W - 1 : (sc >= W ? 0 : sc);
+        v = img[(size_t)sr * W + sc];
+    }
+    pad[(size_t)r * pitch + c] = v;
+}
 
 // (tris_buf: where this camera's triangle records go -- the context's scratch by default; mvs_process_frame keeps the main camera's in a buffer of
 // their own for the whole frame)
@@ -661,24 +682,25 @@ int projected_main_pass(mvs_ctx *ctx, const float cam[16])
     return run_raster(ctx, cam, 0, (float *)ctx->r_zbuf.ptr, (int *)ctx->r_tmp0.ptr, &ctx->r_tris_main);
 }
 
-int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev)
+// The frame texture of Render::projected for `nframes` side frames at once (frames W*H bytes apart): the wrap-padded copy and its mip chain, the
+// same kernels' arithmetic per frame, every launch covering all frames (round 6: five launches per main frame instead of five per side view).
+// Frame i's padded copy is at r_frame + i * tex_frame_bytes, its mips at r_mips + i * tex_mips_bytes; `mip` describes one frame's chain.
+static int projected_textures(mvs_ctx *ctx, const uint8_t *frames_dev, int nframes, MipArgs &mip)
 {
-    if (!ctx->soup.ptr) return fail(ctx, MVS_ESTATE, "no mesh loaded (mvs_load_mesh)");
     const int W = ctx->W, H = ctx->H;
-    const size_t P = (size_t)W * H;
     const int pitch = ((W + 2 + 63) / 64) * 64;
+    const size_t frame_bytes = ((size_t)pitch * (H + 2) + 64 + 63) & ~(size_t)63;
     int rc;
-    if ((rc = ensure(ctx, ctx->r_shadow, 2 * P * sizeof(float) + sizeof(float) * (size_t)W))) return rc;  // raw, dilated, hf0
-    if ((rc = ensure(ctx, ctx->r_frame, (size_t)pitch * (H + 2) + 64))) return rc;
-    float *sh_raw = (float *)ctx->r_shadow.ptr, *sh_dil = sh_raw + P, *hf0 = sh_dil + P;
-    pad_wrap_kernel<<<dim3(div_up(pitch, 256), H + 2), 256, 0, ctx->stream>>>(frame_dev, (uint8_t *)ctx->r_frame.ptr, W, H, pitch);
+    if ((rc = ensure(ctx, ctx->r_frame, frame_bytes * (size_t)nframes))) return rc;
+    pad_wrap_frames<<<dim3(div_up(pitch, 256), H + 2, (unsigned)nframes), 256, 0, ctx->stream>>>(frames_dev, (uint8_t *)ctx->r_frame.ptr, W, H, pitch, frame_bytes);
     MVS_HIP(ctx, hipGetLastError());
-    // the frame texture's mip chain (what the reference asks GL for; mvs_set_texture_filter(MVS_FILTER_LEVEL0) switches it off)
-    MipArgs mip;
     memset(&mip, 0, sizeof(mip));
     mip.w[0] = W;
     mip.h[0] = H;
     mip.pitch[0] = pitch;
+    ctx->tex_frame_bytes = frame_bytes;
+    ctx->tex_mips_bytes = 0;
+    // the frame texture's mip chain (what the reference asks GL for; mvs_set_texture_filter(MVS_FILTER_LEVEL0) switches it off)
     if (ctx->texture_filter == MVS_FILTER_MIPMAP) {
         size_t off = 0;
         int l = 0;
@@ -691,7 +713,9 @@ int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float proj
             off += ((size_t)mip.pitch[l] * (mip.h[l] + 2) + 63) & ~(size_t)63;
         }
         mip.levels = l;
-        if ((rc = ensure(ctx, ctx->r_mips, off + 64))) return rc;
+        const size_t mips_bytes = (off + 64 + 63) & ~(size_t)63;
+        ctx->tex_mips_bytes = mips_bytes;
+        if ((rc = ensure(ctx, ctx->r_mips, mips_bytes * (size_t)nframes))) return rc;
         uint8_t *mips = (uint8_t *)ctx->r_mips.ptr;
         int first_tail = mip.levels + 1;
         for (int k = 1; k <= mip.levels; k++) {
@@ -700,12 +724,47 @@ int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float proj
                 break;
             }
             const uint8_t *src = k == 1 ? (const uint8_t *)ctx->r_frame.ptr : mips + mip.off[k - 1];
-            mip_reduce<<<dim3(div_up(mip.w[k] + 2, 256), mip.h[k] + 2), 256, 0, ctx->stream>>>(src, mip.w[k - 1], mip.h[k - 1], mip.pitch[k - 1], mips + mip.off[k], mip.w[k],
-                                                                                          mip.h[k], mip.pitch[k]);
+            mip_reduce<<<dim3(div_up(mip.w[k] + 2, 256), mip.h[k] + 2, (unsigned)nframes), 256, 0, ctx->stream>>>(src, mip.w[k - 1], mip.h[k - 1], mip.pitch[k - 1], mips + mip.off[k],
+                                                                                                          mip.w[k], mip.h[k], mip.pitch[k], k == 1 ? frame_bytes : mips_bytes, mips_bytes);
         }
-        if (first_tail <= mip.levels) mip_tail<<<1, 256, 0, ctx->stream>>>(mips, (const uint8_t *)ctx->r_frame.ptr, mip, first_tail);
+        if (first_tail <= mip.levels) mip_tail<<<(unsigned)nframes, 256, 0, ctx->stream>>>(mips, (const uint8_t *)ctx->r_frame.ptr, mip, first_tail, mips_bytes, frame_bytes);
         MVS_HIP(ctx, hipGetLastError());
     }
+    static_assert(sizeof(MipArgs) <= sizeof(ctx->tex_mip), "mvs_ctx::tex_mip holds a MipArgs");
+    memcpy(ctx->tex_mip, &mip, sizeof(mip));
+    return MVS_OK;
+}
+
+// mvs_process_frame: the textures of all side frames up front (they depend on the frames alone)
+int projected_prepare_views(mvs_ctx *ctx, const uint8_t *frames_dev, int nframes)
+{
+    MipArgs mip;
+    const int rc = projected_textures(ctx, frames_dev, nframes, mip);
+    ctx->tex_prepared = rc == MVS_OK ? nframes : 0;
+    return rc;
+}
+
+// prepared_view >= 0: the texture of that frame was made by projected_prepare_views (frame_dev is not read); -1: made here
+int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev, int prepared_view)
+{
+    if (!ctx->soup.ptr) return fail(ctx, MVS_ESTATE, "no mesh loaded (mvs_load_mesh)");
+    const int W = ctx->W, H = ctx->H;
+    const size_t P = (size_t)W * H;
+    const int pitch = ((W + 2 + 63) / 64) * 64;
+    int rc;
+    if ((rc = ensure(ctx, ctx->r_shadow, 2 * P * sizeof(float) + sizeof(float) * (size_t)W))) return rc;  // raw, dilated, hf0
+    float *sh_raw = (float *)ctx->r_shadow.ptr, *sh_dil = sh_raw + P, *hf0 = sh_dil + P;
+    MipArgs mip;
+    if (prepared_view >= 0) {
+        if (prepared_view >= ctx->tex_prepared) return fail(ctx, MVS_ESTATE, "projected: texture %d was not prepared", prepared_view);
+        memcpy(&mip, ctx->tex_mip, sizeof(mip));
+    } else {
+        if ((rc = projected_textures(ctx, frame_dev, 1, mip))) return rc;
+        ctx->tex_prepared = 0;
+        prepared_view = 0;
+    }
+    const uint8_t *tex_frame = (const uint8_t *)ctx->r_frame.ptr + ctx->tex_frame_bytes * (size_t)prepared_view;
+    const uint8_t *tex_mips = ctx->r_mips.ptr ? (const uint8_t *)ctx->r_mips.ptr + ctx->tex_mips_bytes * (size_t)prepared_view : nullptr;
     // pass 1: shadow map from the projector, GL orientation, then the dilation quirk
     if ((rc = run_raster(ctx, projector, 1, sh_raw, nullptr))) return rc;
     row0_prefix_min<<<1, 256, 0, ctx->stream>>>(sh_raw, W, hf0);
@@ -718,7 +777,7 @@ int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float proj
     ProfileScope ps(ctx, MVS_K_PROJECT);
     project_texture<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, ctx->stream>>>(
         (const float *)ctx->soup.ptr, (const TriRec *)ctx->r_tris_main.ptr, (const int *)ctx->r_tmp0.ptr, sh_dil,
-        (const uint8_t *)ctx->r_frame.ptr, pitch, prj, W, H, 1.0f / (float)W, 1.0f / (float)H, out3_dev, (const uint8_t *)ctx->r_mips.ptr, mip);
+        tex_frame, pitch, prj, W, H, 1.0f / (float)W, 1.0f / (float)H, out3_dev, tex_mips, mip);
     MVS_HIP(ctx, hipGetLastError());
     return MVS_OK;
 }
@@ -726,7 +785,7 @@ int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float proj
 int projected_device(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev)
 {
     int rc = projected_main_pass(ctx, cam);
-    return rc ? rc : projected_side_pass(ctx, frame_dev, projector, out3_dev);
+    return rc ? rc : projected_side_pass(ctx, frame_dev, projector, out3_dev, -1);
 }
 
 int mix_background_device(mvs_ctx *ctx, const uint8_t *img3_dev, const uint8_t *bg_dev, float *depth_dev, uint8_t *out_dev)
