@@ -200,8 +200,7 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     std::vector<const float *> flow_ptrs((size_t)(nside > 0 ? nside : 1), nullptr);
     for (int i = 0; i < nside; i++) {
         uint8_t *d_mixed = d_mixed0 + (size_t)i * P;
-        if ((rc = projected_side_pass(ctx, d_side0 + (size_t)i * P, side_cams + 16 * i, d_out3, i))) return rc;   // :85
-        if ((rc = mix_background_device(ctx, d_out3, d_main, d_depth, d_mixed))) return rc;           // :86
+        if ((rc = projected_side_pass(ctx, d_side0 + (size_t)i * P, side_cams + 16 * i, d_out3, i, d_main, d_depth, d_mixed))) return rc;   // :85 + :86 (mixBackground inside the fragment program's launch)
         float *fl = d_flows + (size_t)i * 4 * P;
         if (fb_batch) {
             // (after the loop)

@@ -506,7 +506,8 @@ __global__ __launch_bounds__(256) void project_texture(const float *__restrict__
                                                        const int *__restrict__ ids, const float *__restrict__ shadow_gl,
                                                        const uint8_t *__restrict__ pad, int pitch, CamArg prj, int W,
                                                        int H, float invW, float invH, uint8_t *__restrict__ out3,
-                                                       const uint8_t *__restrict__ mips, MipArgs mip)
+                                                       const uint8_t *__restrict__ mips, MipArgs mip, const uint8_t *__restrict__ mix_bg = nullptr,
+                                                       float *__restrict__ mix_depth = nullptr, uint8_t *__restrict__ mix_out = nullptr)
 {
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -567,6 +568,14 @@ __global__ __launch_bounds__(256) void project_texture(const float *__restrict__
                 }
             }
         }
+    }
+    if (mix_out) {
+        // mixBackground (util.cpp:366-387) on the fragment just shaded: mvs_process_frame needs the mixed image and the masked depth, never the RGB8
+        // frame itself -- the same selects on the same values as the mix_background kernel, one launch and 3 P bytes of traffic fewer per side view
+        const bool masked = mix_depth[p] == MVS_BACKGROUND_DEPTH || g == 0;
+        mix_out[p] = masked ? mix_bg[p] : r;
+        if (masked) mix_depth[p] = MVS_BACKGROUND_DEPTH;
+        return;
     }
     out3[3 * p + 0] = r;
     out3[3 * p + 1] = g;
@@ -744,8 +753,10 @@ int projected_prepare_views(mvs_ctx *ctx, const uint8_t *frames_dev, int nframes
     return rc;
 }
 
-// prepared_view >= 0: the texture of that frame was made by projected_prepare_views (frame_dev is not read); -1: made here
-int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev, int prepared_view)
+// prepared_view >= 0: the texture of that frame was made by projected_prepare_views (frame_dev is not read); -1: made here.
+// mix_out != nullptr: mixBackground(projected, mix_bg, mix_depth) is what comes out (into mix_out; mix_depth updated), out3_dev is not written.
+int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev, int prepared_view, const uint8_t *mix_bg, float *mix_depth,
+                        uint8_t *mix_out)
 {
     if (!ctx->soup.ptr) return fail(ctx, MVS_ESTATE, "no mesh loaded (mvs_load_mesh)");
     const int W = ctx->W, H = ctx->H;
@@ -777,7 +788,7 @@ int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float proj
     ProfileScope ps(ctx, MVS_K_PROJECT);
     project_texture<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, ctx->stream>>>(
         (const float *)ctx->soup.ptr, (const TriRec *)ctx->r_tris_main.ptr, (const int *)ctx->r_tmp0.ptr, sh_dil,
-        tex_frame, pitch, prj, W, H, 1.0f / (float)W, 1.0f / (float)H, out3_dev, tex_mips, mip);
+        tex_frame, pitch, prj, W, H, 1.0f / (float)W, 1.0f / (float)H, out3_dev, tex_mips, mip, mix_bg, mix_depth, mix_out);
     MVS_HIP(ctx, hipGetLastError());
     return MVS_OK;
 }
@@ -785,7 +796,7 @@ int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float proj
 int projected_device(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev)
 {
     int rc = projected_main_pass(ctx, cam);
-    return rc ? rc : projected_side_pass(ctx, frame_dev, projector, out3_dev, -1);
+    return rc ? rc : projected_side_pass(ctx, frame_dev, projector, out3_dev, -1, nullptr, nullptr, nullptr);
 }
 
 int mix_background_device(mvs_ctx *ctx, const uint8_t *img3_dev, const uint8_t *bg_dev, float *depth_dev, uint8_t *out_dev)

@@ -603,11 +603,24 @@ int triangulate_impl(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, bo
             ptrs[i] = d_flows + (size_t)i * 4 * P;
         }
     }
-    MVS_HIP(ctx, hipMemcpyAsync(d_depth, depth_hw, sizeof(float) * P, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    MVS_HIP(ctx, hipMemcpyAsync(d_pre, pre.data(), sizeof(CamPre) * pre.size(), hipMemcpyHostToDevice, st));
-    MVS_HIP(ctx, hipMemcpyAsync(d_minv, Minv, sizeof(Minv), hipMemcpyHostToDevice, st));
-    MVS_HIP(ctx, hipMemcpyAsync(d_mc, main_center, sizeof(main_center), hipMemcpyHostToDevice, st));
-    MVS_HIP(ctx, hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(float *) * ptrs.size(), hipMemcpyHostToDevice, st));
+    // the depth map: a device buffer of the caller is read in place (mvs_process_frame: one copy launch fewer), a host buffer goes up
+    if (on_device)
+        d_depth = const_cast<float *>(depth_hw);
+    else
+        MVS_HIP(ctx, hipMemcpyAsync(d_depth, depth_hw, sizeof(float) * P, hipMemcpyHostToDevice, st));
+    // the small tables are adjacent in the arena (camera records | inverse main matrix | main centre | flow pointers): ONE upload instead of four
+    {
+        std::vector<unsigned char> host_tables(tables, 0);
+        unsigned char *hp = host_tables.data();
+        memcpy(hp, pre.data(), sizeof(CamPre) * pre.size());
+        hp += sizeof(CamPre) * pre.size();
+        memcpy(hp, Minv, sizeof(Minv));
+        hp += sizeof(float) * 16;
+        memcpy(hp, main_center, sizeof(main_center));
+        hp += sizeof(float) * 4;
+        memcpy(hp, ptrs.data(), sizeof(float *) * ptrs.size());
+        MVS_HIP(ctx, hipMemcpyAsync(d_pre, host_tables.data(), tables, hipMemcpyHostToDevice, st));  // (pageable source: staged before the call returns)
+    }
     sobel_kernel<<<dim3(div_up(W, 64), div_up(H, 4)), 256, 0, st>>>(d_depth, W, H, d_grad);
     {
         const dim3 grid(div_up(W, 64), div_up(H, 2));
