@@ -106,6 +106,10 @@ static int run_cpu(const std::string &tracks)
         const char *argv[] = {"recon", "-n", "3", "-c", "7.5", "-f", "-v", "-o", "x.obj", y.c_str()};
         Configuration c(10, const_cast<char **>(argv));
         CHECK(c.iterationCount == 3 && c.cameraThreshold == 7.5f && c.useFarneback && c.verbosity == 2 && c.outFileName == "x.obj", "getopt");
+        CHECK(c.sweepPlanes == 0 && c.threads == 1, "the two long options the reference does not have default to the reference's behaviour");
+        const char *argv2[] = {"recon", "--sweep-planes", "48", "--threads", "4", "--input", y.c_str()};
+        Configuration c2(7, const_cast<char **>(argv2));
+        CHECK(c2.sweepPlanes == 48 && c2.threads == 4 && !c2.useFarneback && c2.iterationCount == 2, "--sweep-planes / --threads");
         Heuristic h(&c);
         CHECK(h.notHappy(Mat()) && h.notHappy(Mat()) && h.notHappy(Mat()) && !h.notHappy(Mat()), "notHappy counts iterations");
         CHECK(h.renderSize().width == 640 && h.renderSize().height == 480, "renderSize");
