@@ -136,8 +136,7 @@ struct mvs_ctx {
     std::vector<hipEvent_t> band_events;  // mvs_sweep's band pipeline: rows uploaded / band swept, per band
     int store_cap = 0;
     std::vector<unsigned char> store_have;
-    // mvs_process_frame runs the flows of one main frame's side views concurrently: a lane is everything calculateFlow keeps
-    // per call (stream, arena, compare pyramid); pipeline.hip swaps a lane into the fields below for one call
+    // mvs_process_frame runs the flows of one main frame's side views concurrently, one lane each:
     // A lane: the stream one side view's flow runs on, a SHADOW context that stands for this context on that stream (device, size, hooks; its own flow
     // arena; nothing else is used through it) and a host thread that queues the flow's launches while the calling thread goes on with the next side
     // view (pipeline.hip: a main frame is ~150 launches at ~6 us of host time each, the calling thread alone was the bottleneck).

@@ -8,9 +8,11 @@
 // Through the one-stage entry points of mvs.h each of these crosses PCIe twice (cv::Mat in, cv::Mat out), as the
 // reference's own GL path does (two glReadPixels + two uploads per pair, render_glx.cpp:286,325,359,75).  Here the
 // frames go up once, every intermediate (depth, warped image, mask, flows) stays in HBM, and only the points come
-// back.  The flows of the side views are independent of each other, so each runs in one of four lanes (stream + arena +
-// compare pyramid) while the main stream rasterises the next view.  Same kernels, same arithmetic: the result equals the
-// stage-by-stage calls bit for bit (tests/test_pipeline_gpu.py).
+// back.  The flows of the side views are independent of each other, so each runs in one of four lanes -- a stream, a shadow context with
+// the lane's flow arena, and (round 6) a host thread that queues the flow's launches -- while the calling thread and the main stream go on
+// with the next view; what does not depend on the side view (the depth map, the main-camera half of projected(), every frame's texture) is
+// done once up front, and the variance channels of all flows in one batched pass at the end.  Same kernels' arithmetic: the result equals
+// the stage-by-stage calls bit for bit (tests/test_pipeline_gpu.py).
 #include "mvs_internal.hpp"
 
 #include <algorithm>
@@ -128,9 +130,9 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     uint8_t *d_remapped = d_mixed0 + (size_t)nside * P;
     float *d_depth = (float *)((uint8_t *)ctx->frame_buf.ptr + bytes_u8), *d_flows = d_depth + P, *d_flow2 = d_flows + 4 * (size_t)nside * P, *d_var = d_flow2 + 2 * (size_t)nside * P;
 
-    // The flows of the side views depend only on (main frame, mixed_i): each runs in a lane of its own (stream + arena +
-    // pyramid) while the main stream goes on rasterising the next view; a flow is a chain of small kernels that fills
-    // 150 of 256 CUs at best, so up to four of them overlap.  Everything joins before triangulatePixels.
+    // The flows of the side views depend only on (main frame, mixed_i): each runs in a lane of its own while the main stream goes on
+    // rasterising the next view; a flow is a chain of small kernels that fills 150 of 256 CUs at best, so up to four of them overlap.
+    // Everything joins before the batched variance pass and triangulatePixels.
     const bool serial = ctx->hooks.serial_flows;  // A/B: all flows in the main stream, as before
     // Farneback (-f): the flows of all side views in ONE pass after the last mixed image (every launch covers all of them; what
     // depends on the main frame alone is computed once) -- a Farneback flow is ~150 launches of a few microseconds, and concurrency
