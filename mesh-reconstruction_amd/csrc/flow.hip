@@ -952,34 +952,50 @@ __global__ __launch_bounds__(256) void var_sor_pass(VarBufs B, int w, int h, int
 // Every cell is evaluated with the expressions of the kernels above in the same order, so the result is bit-identical
 // (tests/test_flow_gpu.py compares both forms).  du/dv ping-pong between two buffers because neighbouring workgroups
 // read each other's halo at the start.
-constexpr int VT_W = 64, VT_H = 32, VT_HALO = 10, VT_RW = VT_W + 2 * VT_HALO, VT_RH = VT_H + 2 * VT_HALO,
-              VT_CELLS = VT_RW * VT_RH, VT_THREADS = 1024, VT_PER = (VT_CELLS + VT_THREADS - 1) / VT_THREADS;
+//
+// Thread mapping (round 6, second form): a thread owns SLOTS, a slot = two horizontally adjacent cells (2j, 2j + 1) of a region
+// row -- one red, one black -- and keeps both cells' coefficients in registers under their COLOUR, so in a half-step every
+// lane of a wavefront updates a cell (the first form gave a thread single cells in raster order: half the lanes of every
+// wavefront sat out each half-step, and the 4368 cells of its 84 x 52 region made a ragged fifth pass that the barrier
+// made everybody wait for).  84 x 48 cells = 2016 slots: two per thread, no ragged pass.  In LDS the two colours live in
+// separate planes -- [colour][row][x >> 1] -- so consecutive lanes read consecutive words; the neighbours of a cell are all
+// in the other plane: left / right at j - 1 + e and j + e (e = parity of row + colour), up / down at j of the rows above / below.
+constexpr int VT_W = 64, VT_H = 28, VT_HALO = 10, VT_RW = VT_W + 2 * VT_HALO, VT_RH = VT_H + 2 * VT_HALO,
+              VT_CELLS = VT_RW * VT_RH, VT_HW = VT_RW / 2, VT_SLOTS = VT_CELLS / 2, VT_THREADS = 1024,
+              VT_PER = (VT_SLOTS + VT_THREADS - 1) / VT_THREADS, VT_LOADS = (VT_CELLS + VT_THREADS - 1) / VT_THREADS,
+              VT_PLANE = VT_SLOTS + 16,   // (+ 16 words: the two planes' banks interleave when raster-ordered lanes fill them)
+              VT_LDS = 2 * VT_PLANE;
+static_assert(VT_W % 2 == 0 && VT_H % 2 == 0 && VT_HALO % 2 == 0, "a region's origin must be an even cell: a cell's colour is the parity of its region coordinates");
+
+__device__ __forceinline__ int vt_idx(int ry, int rx) { return ((rx + ry) & 1) * VT_PLANE + ry * VT_HW + (rx >> 1); }
 
 __global__ __launch_bounds__(VT_THREADS) void var_fixed_point_fused(VarBufs B, const float *__restrict__ du_in,
                                                                       const float *__restrict__ dv_in,
                                                                       float *__restrict__ du_out,
                                                                       float *__restrict__ dv_out, int w, int h, int sor_iters)
 {
-    __shared__ float s_du[VT_CELLS], s_dv[VT_CELLS], s_wu[VT_CELLS], s_wv[VT_CELLS], s_wgt[VT_CELLS];
-    const int X0 = blockIdx.x * VT_W - VT_HALO, Y0 = blockIdx.y * VT_H - VT_HALO;
+    __shared__ float s_du[VT_LDS], s_dv[VT_LDS], s_wu[VT_LDS], s_wv[VT_LDS], s_wgt[VT_LDS];
+    const int X0 = blockIdx.x * VT_W - VT_HALO, Y0 = blockIdx.y * VT_H - VT_HALO;   // both even
     const float omega = 1.6f;
 
-    float a11[VT_PER], a12[VT_PER], a22[VT_PER], b1[VT_PER], b2[VT_PER];
-    int lim[VT_PER];       // half-steps this cell can take part in (-1: outside the image)
-    unsigned nb[VT_PER];   // bit 0..3: has left / right / up / down neighbour in the image; bit 4: colour
+    // per (slot, colour): the cell's coefficients, the half-steps it can take part in (-1: outside the image) and which neighbours the image has
+    float a11[VT_PER][2], a12[VT_PER][2], a22[VT_PER][2], b1[VT_PER][2], b2[VT_PER][2];
+    int lim[VT_PER][2];
+    unsigned nb[VT_PER][2];   // bit 0..3: has left / right / up / down neighbour in the image
+    int own[VT_PER][2];       // the cell's word in its plane's arrays
 
-    // phase 0: region -> LDS
+    // phase 0: region -> LDS (raster order: coalesced reads)
 #pragma unroll
-    for (int k = 0; k < VT_PER; k++) {
+    for (int k = 0; k < VT_LOADS; k++) {
         const int c = threadIdx.x + k * VT_THREADS;
         if (c < VT_CELLS) {
-            const int ry = c / VT_RW, rx = c - ry * VT_RW, x = X0 + rx, y = Y0 + ry;
+            const int ry = c / VT_RW, rx = c - ry * VT_RW, x = X0 + rx, y = Y0 + ry, i = vt_idx(ry, rx);
             const bool in = x >= 0 && x < w && y >= 0 && y < h;
             const size_t p = in ? (size_t)y * w + x : 0;
-            s_du[c] = in ? du_in[p] : 0.f;
-            s_dv[c] = in ? dv_in[p] : 0.f;
-            s_wu[c] = in ? B.Wu[p] : 0.f;
-            s_wv[c] = in ? B.Wv[p] : 0.f;
+            s_du[i] = in ? du_in[p] : 0.f;
+            s_dv[i] = in ? dv_in[p] : 0.f;
+            s_wu[i] = in ? B.Wu[p] : 0.f;
+            s_wv[i] = in ? B.Wv[p] : 0.f;
         }
     }
     __syncthreads();
@@ -987,153 +1003,175 @@ __global__ __launch_bounds__(VT_THREADS) void var_fixed_point_fused(VarBufs B, c
     // phase 1: data term (pointwise) and diffusivity (right / down neighbours)
 #pragma unroll
     for (int k = 0; k < VT_PER; k++) {
-        const int c = threadIdx.x + k * VT_THREADS;
-        lim[k] = -1;
-        nb[k] = 0;
-        a11[k] = a12[k] = a22[k] = 1.f;
-        b1[k] = b2[k] = 0.f;
-        if (c >= VT_CELLS) continue;
-        const int ry = c / VT_RW, rx = c - ry * VT_RW, x = X0 + rx, y = Y0 + ry;
-        if (!(x >= 0 && x < w && y >= 0 && y < h)) {
-            s_wgt[c] = 0.f;
-            continue;
-        }
-        const size_t p = (size_t)y * w + x;
-        // distance to each region side that is a cut through the image (a side at/after the image border is no cut)
-        const int dl = X0 > 0 ? rx : 1 << 20, dr = X0 + VT_RW < w ? VT_RW - 1 - rx : 1 << 20;
-        const int du_ = Y0 > 0 ? ry : 1 << 20, dd = Y0 + VT_RH < h ? VT_RH - 1 - ry : 1 << 20;
-        lim[k] = min(min(dl, dr), min(du_, dd));
-        nb[k] = (x > 0 ? 1u : 0u) | (x + 1 < w ? 2u : 0u) | (y > 0 ? 4u : 0u) | (y + 1 < h ? 8u : 0u) | (((x + y) & 1) ? 16u : 0u);
-        {
-            const float zeta2 = 0.1f * 0.1f, eps2 = 0.001f * 0.001f, gamma2 = 10.f / 2, delta2 = 5.f / 2;
-            const float Ix = B.Ix[p], Iy = B.Iy[p], Iz = B.Iz[p], Ixx = B.Ixx[p], Ixy = B.Ixy[p], Iyy = B.Iyy[p],
-                        Ixz = B.Ixz[p], Iyz = B.Iyz[p], du = s_du[c], dv = s_dv[c];
-            float derivNorm = Ix * Ix + Iy * Iy + zeta2;
-            const float Ik1z = Iz + Ix * du + Iy * dv;
-            float weight = (delta2 / sqrtf(Ik1z * Ik1z / derivNorm + eps2)) / derivNorm;
-            float A11 = weight * (Ix * Ix) + zeta2;
-            float A12 = weight * (Ix * Iy);
-            float A22 = weight * (Iy * Iy) + zeta2;
-            float B1 = -weight * (Iz * Ix);
-            float B2 = -weight * (Iz * Iy);
-            derivNorm = Ixx * Ixx + Ixy * Ixy + zeta2;
-            const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + zeta2;
-            const float Ik1zx = Ixz + Ixx * du + Ixy * dv;
-            const float Ik1zy = Iyz + Ixy * du + Iyy * dv;
-            weight = gamma2 / sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + eps2);
-            A11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
-            A12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
-            A22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
-            B1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
-            B2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
-            a11[k] = A11;
-            a12[k] = A12;
-            a22[k] = A22;
-            b1[k] = B1;
-            b2[k] = B2;
-        }
-        {
-            const float eps2 = 0.001f * 0.001f, alpha2 = 20.f / 2;
-            const int cr = rx + 1 < VT_RW ? c + 1 : c, cd = ry + 1 < VT_RH ? c + VT_RW : c;  // clamped: such cells have lim 0
-            const float cu = s_wu[c] + s_du[c], cv = s_wv[c] + s_dv[c];
-            const float ux = (nb[k] & 2u) ? (s_wu[cr] + s_du[cr]) - cu : 0.f, vx = (nb[k] & 2u) ? (s_wv[cr] + s_dv[cr]) - cv : 0.f;
-            const float uy = (nb[k] & 8u) ? (s_wu[cd] + s_du[cd]) - cu : 0.f, vy = (nb[k] & 8u) ? (s_wv[cd] + s_dv[cd]) - cv : 0.f;
-            s_wgt[c] = alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + eps2);
+        const int q = threadIdx.x + k * VT_THREADS;
+        const int ry = q / VT_HW, j = q - ry * VT_HW;
+#pragma unroll
+        for (int col = 0; col < 2; col++) {
+            lim[k][col] = -1;
+            nb[k][col] = 0;
+            own[k][col] = 0;
+            a11[k][col] = a12[k][col] = a22[k][col] = 1.f;
+            b1[k][col] = b2[k][col] = 0.f;
+            if (q >= VT_SLOTS) continue;
+            const int rx = 2 * j + ((ry + col) & 1), x = X0 + rx, y = Y0 + ry, c = vt_idx(ry, rx);
+            own[k][col] = c;
+            if (!(x >= 0 && x < w && y >= 0 && y < h)) {
+                s_wgt[c] = 0.f;
+                continue;
+            }
+            const size_t p = (size_t)y * w + x;
+            // distance to each region side that is a cut through the image (a side at/after the image border is no cut)
+            const int dl = X0 > 0 ? rx : 1 << 20, dr = X0 + VT_RW < w ? VT_RW - 1 - rx : 1 << 20;
+            const int du_ = Y0 > 0 ? ry : 1 << 20, dd = Y0 + VT_RH < h ? VT_RH - 1 - ry : 1 << 20;
+            lim[k][col] = min(min(dl, dr), min(du_, dd));
+            nb[k][col] = (x > 0 ? 1u : 0u) | (x + 1 < w ? 2u : 0u) | (y > 0 ? 4u : 0u) | (y + 1 < h ? 8u : 0u);
+            {
+                const float zeta2 = 0.1f * 0.1f, eps2 = 0.001f * 0.001f, gamma2 = 10.f / 2, delta2 = 5.f / 2;
+                const float Ix = B.Ix[p], Iy = B.Iy[p], Iz = B.Iz[p], Ixx = B.Ixx[p], Ixy = B.Ixy[p], Iyy = B.Iyy[p],
+                            Ixz = B.Ixz[p], Iyz = B.Iyz[p], du = s_du[c], dv = s_dv[c];
+                float derivNorm = Ix * Ix + Iy * Iy + zeta2;
+                const float Ik1z = Iz + Ix * du + Iy * dv;
+                float weight = (delta2 / sqrtf(Ik1z * Ik1z / derivNorm + eps2)) / derivNorm;
+                float A11 = weight * (Ix * Ix) + zeta2;
+                float A12 = weight * (Ix * Iy);
+                float A22 = weight * (Iy * Iy) + zeta2;
+                float B1 = -weight * (Iz * Ix);
+                float B2 = -weight * (Iz * Iy);
+                derivNorm = Ixx * Ixx + Ixy * Ixy + zeta2;
+                const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + zeta2;
+                const float Ik1zx = Ixz + Ixx * du + Ixy * dv;
+                const float Ik1zy = Iyz + Ixy * du + Iyy * dv;
+                weight = gamma2 / sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + eps2);
+                A11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
+                A12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
+                A22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
+                B1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
+                B2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
+                a11[k][col] = A11;
+                a12[k][col] = A12;
+                a22[k][col] = A22;
+                b1[k][col] = B1;
+                b2[k][col] = B2;
+            }
+            {
+                const float eps2 = 0.001f * 0.001f, alpha2 = 20.f / 2;
+                const int cr = rx + 1 < VT_RW ? vt_idx(ry, rx + 1) : c, cd = ry + 1 < VT_RH ? vt_idx(ry + 1, rx) : c;  // clamped: such cells have lim 0
+                const float cu = s_wu[c] + s_du[c], cv = s_wv[c] + s_dv[c];
+                const float ux = (nb[k][col] & 2u) ? (s_wu[cr] + s_du[cr]) - cu : 0.f, vx = (nb[k][col] & 2u) ? (s_wv[cr] + s_dv[cr]) - cv : 0.f;
+                const float uy = (nb[k][col] & 8u) ? (s_wu[cd] + s_du[cd]) - cu : 0.f, vy = (nb[k][col] & 8u) ? (s_wv[cd] + s_dv[cd]) - cv : 0.f;
+                s_wgt[c] = alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + eps2);
+            }
         }
     }
     __syncthreads();
 
     // phase 2: smoothness gather -> final coefficients; neighbour weights stay in registers for the sweeps
-    float wl[VT_PER], wr[VT_PER], wt_[VT_PER];  // wgt[p-1], wgt[p] (right and down), wgt[p-w]
+    float wl[VT_PER][2], wr[VT_PER][2], wt_[VT_PER][2];  // wgt[p-1], wgt[p] (right and down), wgt[p-w]
 #pragma unroll
     for (int k = 0; k < VT_PER; k++) {
-        const int c = threadIdx.x + k * VT_THREADS;
-        wl[k] = wr[k] = wt_[k] = 0.f;
-        if (c >= VT_CELLS || lim[k] < 0) continue;
-        const int ry = c / VT_RW, rx = c - ry * VT_RW;
-        const int cl = rx > 0 ? c - 1 : c, cr = rx + 1 < VT_RW ? c + 1 : c, cu = ry > 0 ? c - VT_RW : c, cd = ry + 1 < VT_RH ? c + VT_RW : c;
-        float A11 = a11[k], A22 = a22[k], B1 = b1[k], B2 = b2[k];
-        wl[k] = s_wgt[cl];
-        wr[k] = s_wgt[c];
-        wt_[k] = s_wgt[cu];
-        if (nb[k] & 1u) {
-            const float wt = wl[k];
-            B1 -= wt * (s_wu[c] - s_wu[cl]);
-            B2 -= wt * (s_wv[c] - s_wv[cl]);
-            A11 += wt;
-            A22 += wt;
+        const int q = threadIdx.x + k * VT_THREADS;
+        const int ry = q / VT_HW, j = q - ry * VT_HW;
+#pragma unroll
+        for (int col = 0; col < 2; col++) {
+            wl[k][col] = wr[k][col] = wt_[k][col] = 0.f;
+            if (q >= VT_SLOTS || lim[k][col] < 0) continue;
+            const int rx = 2 * j + ((ry + col) & 1), c = own[k][col];
+            const int cl = rx > 0 ? vt_idx(ry, rx - 1) : c, cr = rx + 1 < VT_RW ? vt_idx(ry, rx + 1) : c, cu = ry > 0 ? vt_idx(ry - 1, rx) : c,
+                      cd = ry + 1 < VT_RH ? vt_idx(ry + 1, rx) : c;
+            float A11 = a11[k][col], A22 = a22[k][col], B1 = b1[k][col], B2 = b2[k][col];
+            const unsigned n = nb[k][col];
+            wl[k][col] = s_wgt[cl];
+            wr[k][col] = s_wgt[c];
+            wt_[k][col] = s_wgt[cu];
+            if (n & 1u) {
+                const float wt = wl[k][col];
+                B1 -= wt * (s_wu[c] - s_wu[cl]);
+                B2 -= wt * (s_wv[c] - s_wv[cl]);
+                A11 += wt;
+                A22 += wt;
+            }
+            if (n & 2u) {
+                const float wt = wr[k][col];
+                B1 += wt * (s_wu[cr] - s_wu[c]);
+                B2 += wt * (s_wv[cr] - s_wv[c]);
+                A11 += wt;
+                A22 += wt;
+            }
+            if (n & 4u) {
+                const float wt = wt_[k][col];
+                B1 -= wt * (s_wu[c] - s_wu[cu]);
+                B2 -= wt * (s_wv[c] - s_wv[cu]);
+                A11 += wt;
+                A22 += wt;
+            }
+            if (n & 8u) {
+                const float wt = wr[k][col];
+                B1 += wt * (s_wu[cd] - s_wu[c]);
+                B2 += wt * (s_wv[cd] - s_wv[c]);
+                A11 += wt;
+                A22 += wt;
+            }
+            a11[k][col] = A11;
+            a22[k][col] = A22;
+            b1[k][col] = B1;
+            b2[k][col] = B2;
         }
-        if (nb[k] & 2u) {
-            const float wt = wr[k];
-            B1 += wt * (s_wu[cr] - s_wu[c]);
-            B2 += wt * (s_wv[cr] - s_wv[c]);
-            A11 += wt;
-            A22 += wt;
-        }
-        if (nb[k] & 4u) {
-            const float wt = wt_[k];
-            B1 -= wt * (s_wu[c] - s_wu[cu]);
-            B2 -= wt * (s_wv[c] - s_wv[cu]);
-            A11 += wt;
-            A22 += wt;
-        }
-        if (nb[k] & 8u) {
-            const float wt = wr[k];
-            B1 += wt * (s_wu[cd] - s_wu[c]);
-            B2 += wt * (s_wv[cd] - s_wv[c]);
-            A11 += wt;
-            A22 += wt;
-        }
-        a11[k] = A11;
-        a22[k] = A22;
-        b1[k] = B1;
-        b2[k] = B2;
     }
     // (no barrier needed: the sweeps below read s_du / s_dv only, which nobody has written since phase 0)
 
-    // phase 3: red-black SOR, colour 0 then colour 1 per iteration
-    for (int s = 0; s < 2 * sor_iters; s++) {
-        const unsigned colour = (unsigned)(s & 1);
+    // phase 3: red-black SOR, colour 0 then colour 1 per iteration.  A cell that takes part (lim > s >= 0) is at least one cell inside the region, so
+    // its neighbours' words exist; they are in the other colour's plane: row * VT_HW + j is the cell's word within a plane
+    for (int it = 0; it < sor_iters; it++) {
 #pragma unroll
-        for (int k = 0; k < VT_PER; k++) {
-            const int c = threadIdx.x + k * VT_THREADS;
-            if (lim[k] <= s || ((nb[k] >> 4) & 1u) != colour) continue;  // lim >= s+1: all inputs still exact
-            float sU = 0.f, sV = 0.f;
-            if (nb[k] & 1u) {
-                sU += wl[k] * s_du[c - 1];
-                sV += wl[k] * s_dv[c - 1];
+        for (int col = 0; col < 2; col++) {
+            const int s = 2 * it + col;
+#pragma unroll
+            for (int k = 0; k < VT_PER; k++) {
+                if (lim[k][col] <= s) continue;  // lim >= s+1: all inputs still exact
+                const int c = own[k][col], o = c + (1 - 2 * col) * VT_PLANE;   // the same word in the other plane
+                const int q = threadIdx.x + k * VT_THREADS, e = ((q / VT_HW) + col) & 1;
+                const unsigned n = nb[k][col];
+                float sU = 0.f, sV = 0.f;
+                if (n & 1u) {
+                    sU += wl[k][col] * s_du[o - 1 + e];
+                    sV += wl[k][col] * s_dv[o - 1 + e];
+                }
+                if (n & 2u) {
+                    sU += wr[k][col] * s_du[o + e];
+                    sV += wr[k][col] * s_dv[o + e];
+                }
+                if (n & 4u) {
+                    sU += wt_[k][col] * s_du[o - VT_HW];
+                    sV += wt_[k][col] * s_dv[o - VT_HW];
+                }
+                if (n & 8u) {
+                    sU += wr[k][col] * s_du[o + VT_HW];
+                    sV += wr[k][col] * s_dv[o + VT_HW];
+                }
+                float du = s_du[c], dv = s_dv[c];
+                du += omega * ((sU + b1[k][col] - dv * a12[k][col]) / a11[k][col] - du);
+                dv += omega * ((sV + b2[k][col] - du * a12[k][col]) / a22[k][col] - dv);
+                s_du[c] = du;
+                s_dv[c] = dv;
             }
-            if (nb[k] & 2u) {
-                sU += wr[k] * s_du[c + 1];
-                sV += wr[k] * s_dv[c + 1];
-            }
-            if (nb[k] & 4u) {
-                sU += wt_[k] * s_du[c - VT_RW];
-                sV += wt_[k] * s_dv[c - VT_RW];
-            }
-            if (nb[k] & 8u) {
-                sU += wr[k] * s_du[c + VT_RW];
-                sV += wr[k] * s_dv[c + VT_RW];
-            }
-            float du = s_du[c], dv = s_dv[c];
-            du += omega * ((sU + b1[k] - dv * a12[k]) / a11[k] - du);
-            dv += omega * ((sV + b2[k] - du * a12[k]) / a22[k] - dv);
-            s_du[c] = du;
-            s_dv[c] = dv;
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // phase 4: core -> global
 #pragma unroll
     for (int k = 0; k < VT_PER; k++) {
-        const int c = threadIdx.x + k * VT_THREADS;
-        if (c >= VT_CELLS || lim[k] < 0) continue;
-        const int ry = c / VT_RW, rx = c - ry * VT_RW;
-        if (rx < VT_HALO || rx >= VT_HALO + VT_W || ry < VT_HALO || ry >= VT_HALO + VT_H) continue;
-        const size_t p = (size_t)(Y0 + ry) * w + (X0 + rx);
-        du_out[p] = s_du[c];
-        dv_out[p] = s_dv[c];
+        const int q = threadIdx.x + k * VT_THREADS;
+        const int ry = q / VT_HW, j = q - ry * VT_HW;
+#pragma unroll
+        for (int col = 0; col < 2; col++) {
+            if (q >= VT_SLOTS || lim[k][col] < 0) continue;
+            const int rx = 2 * j + ((ry + col) & 1);
+            if (rx < VT_HALO || rx >= VT_HALO + VT_W || ry < VT_HALO || ry >= VT_HALO + VT_H) continue;
+            const size_t p = (size_t)(Y0 + ry) * w + (X0 + rx);
+            du_out[p] = s_du[own[k][col]];
+            dv_out[p] = s_dv[own[k][col]];
+        }
     }
 }
 

@@ -139,7 +139,10 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     // between lanes does not buy what sharing the launches does.  MVS_FB_LANES=1 keeps the per-view chains on the lanes (A/B).
     const bool fb_lanes = ctx->hooks.fb_lanes;
     const bool fb_batch = use_farneback && nside > 0 && !serial && !fb_lanes;
-    const int nlanes = (serial || fb_batch) ? 0 : std::min(nside, (int)mvs_ctx::kFlowLanes);
+    // The LAST side view's flow stays on the main stream: after that view's side pass the main stream has nothing to do until the flows join, and HIP
+    // serves a process's streams from four hardware queues -- main stream + four lanes made the fourth lane share a queue with another one, and its flow
+    // started when that one's had finished (200 us of a 1.5 ms call at 640 x 480 with four side views, profiles/r06).
+    const int nlanes = (serial || fb_batch) ? 0 : std::max(0, std::min(nside - 1, (int)mvs_ctx::kFlowLanes));
     for (int l = 0; l < nlanes; l++)
         if (!ctx->lanes[l].stream) MVS_HIP(ctx, hipStreamCreateWithFlags(&ctx->lanes[l].stream, hipStreamNonBlocking));
     while ((int)ctx->lane_events.size() < 2 * nside) {
@@ -206,7 +209,7 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
         float *fl = d_flows + (size_t)i * 4 * P;
         if (fb_batch) {
             // (after the loop)
-        } else if (nlanes == 0) {
+        } else if (nlanes == 0 || i == nside - 1) {
             if ((rc = flow_only_device(ctx, d_main, d_mixed, use_farneback, d_flow2 + (size_t)i * 2 * P))) return rc;               // :89 (the flow; its variance channel below)
         } else {
             // the lane's host thread queues this view's flow (a dozen launches for the variational refinement, ~100 for a Farneback chain) while this thread
@@ -231,9 +234,9 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     if (fb_batch && (rc = flow_farneback_batch_device(ctx, d_main, d_mixed0, nside, d_flows))) return rc;                                            // :89, all side views
     if (nlanes > 0) {
         for (int l = 0; l < nlanes; l++) ((LaneWorker *)ctx->lanes[l].worker)->idle();   // every flow is queued (and every `done` recorded)
-        for (int i = 0; i < nside; i++)
+        for (int i = 0; i < nside - 1; i++)
             if (lane_rc[(size_t)i] != MVS_OK) return fail(ctx, lane_rc[(size_t)i], "mvs_process_frame: flow of side view %d: %s", i, ctx->lanes[i % nlanes].shadow->err);
-        for (int i = 0; i < nside; i++) MVS_HIP(ctx, hipStreamWaitEvent(st, ctx->lane_events[2 * i + 1], 0));
+        for (int i = 0; i < nside - 1; i++) MVS_HIP(ctx, hipStreamWaitEvent(st, ctx->lane_events[2 * i + 1], 0));
     }
     // flow.cpp:34-41 for every side view at once: the variance channels are twelve launches per flow of ~5 us each -- on the main stream, all flows per
     // launch, they are twelve per main frame (round 6; the batched Farneback pass does the same inside flow_farneback_batch_device)
