@@ -97,6 +97,12 @@ int mvs_triangulate(mvs_ctx *ctx, int nviews, const float *const *flows_hw4, con
 int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_frame_hw, int nside,
                       const float *side_cams /* nside*16 */, const uint8_t *const *side_frames_hw, int use_farneback,
                       float *out_points7, int *out_count, float *depth_after_hw);
+/* The same with the frames taken from the context's frame store (mvs_frame_store / mvs_frame_upload, below): recon.cpp:65-117 reads every frame of a
+ * sequence about five times -- once as a main frame (configuration.cpp frame(i), recon.cpp:68), four times as a side view (:80) -- and through the
+ * store it crosses PCIe once.  main_slot / side_slots name filled slots (MVS_ESTATE otherwise); results are those of mvs_process_frame on the
+ * same frames, bit for bit; stream-ordered behind the uploads that filled the slots. */
+int mvs_process_frame_slots(mvs_ctx *ctx, const float main_cam[16], int main_slot, int nside, const float *side_cams /* nside*16 */,
+                            const int *side_slots, int use_farneback, float *out_points7, int *out_count, float *depth_after_hw);
 
 /* cv::resize(frame, Size(dw, dh)) as Configuration applies it to every decoded frame when -s / the clip size asks for it
  * (configuration.cpp:233: INTER_LINEAR -- the CV_INTER_AREA in that call lands in the ignored fx argument): OpenCV's fixed-point

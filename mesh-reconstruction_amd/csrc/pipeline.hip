@@ -108,16 +108,22 @@ void lanes_shutdown(mvs_ctx *ctx)
 
 }  // namespace mvs
 
-extern "C" {
-
-int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_frame_hw, int nside, const float *side_cams,
-                      const uint8_t *const *side_frames_hw, int use_farneback, float *out_points7, int *out_count,
-                      float *depth_after_hw /* nullable */)
+// One main frame.  The frames are host buffers (main_frame_hw / side_frames_hw: mvs_process_frame) or slots of the frame store (main_slot /
+// side_slots: mvs_process_frame_slots -- a sequence's frames cross PCIe once instead of once per main frame they take part in).
+static int process_frame_impl(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_frame_hw, int main_slot, int nside, const float *side_cams,
+                              const uint8_t *const *side_frames_hw, const int *side_slots, int use_farneback, float *out_points7, int *out_count,
+                              float *depth_after_hw /* nullable */)
 {
-    if (!ctx || !main_cam || !main_frame_hw || !out_points7 || !out_count || nside < 0 || (nside > 0 && (!side_cams || !side_frames_hw)))
-        return fail(ctx, MVS_EINVAL, "mvs_process_frame: bad arguments");
+    const bool slots = !main_frame_hw;
     if (nside > 32) return fail(ctx, MVS_EINVAL, "mvs_process_frame: at most 32 side views");
     if (!ctx->soup.ptr) return fail(ctx, MVS_ESTATE, "mvs_process_frame: no mesh loaded (mvs_load_mesh)");
+    if (slots) {
+        for (int i = -1; i < nside; i++) {
+            const int slot = i < 0 ? main_slot : side_slots[i];
+            if (slot < 0 || slot >= ctx->store_cap) return fail(ctx, MVS_EINVAL, "mvs_process_frame_slots: slot %d outside the store (capacity %d: mvs_frame_store first)", slot, ctx->store_cap);
+            if (!ctx->store_have[(size_t)slot]) return fail(ctx, MVS_ESTATE, "mvs_process_frame_slots: slot %d holds no frame (mvs_frame_upload)", slot);
+        }
+    }
     MVS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)ctx->W * ctx->H;
     hipStream_t st = ctx->stream;
@@ -192,15 +198,22 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
         }
     } join{ctx, st, nlanes};
 
-    for (int i = 0; i < nside; i++)
-        if (!side_frames_hw[i]) return fail(ctx, MVS_EINVAL, "mvs_process_frame: side_frames[%d] is null", i);
+    if (!slots)
+        for (int i = 0; i < nside; i++)
+            if (!side_frames_hw[i]) return fail(ctx, MVS_EINVAL, "mvs_process_frame: side_frames[%d] is null", i);
     // What needs no frame goes first -- the depth map and the half of projected() that rasterises the mesh from the MAIN camera (once per main frame,
     // not once per side view: round 6) -- so the GPU works while the host stages the frames; then all frames go up back to back (a copy from pageable
     // memory in between two kernels cost 14 us of idle stream per side view)
     if ((rc = depth_device(ctx, main_cam, d_depth))) return rc;  // recon.cpp:70
     if (nside > 0 && (rc = projected_main_pass(ctx, main_cam))) return rc;
-    MVS_HIP(ctx, hipMemcpyAsync(d_main, main_frame_hw, P, hipMemcpyHostToDevice, st));
-    for (int i = 0; i < nside; i++) MVS_HIP(ctx, hipMemcpyAsync(d_side0 + (size_t)i * P, side_frames_hw[i], P, hipMemcpyHostToDevice, st));
+    if (slots) {  // (stream-ordered behind the uploads that filled the slots; the side views go where projected_prepare_views wants them: side by side)
+        const uint8_t *raw = (const uint8_t *)ctx->store_raw.ptr;
+        MVS_HIP(ctx, hipMemcpyAsync(d_main, raw + P * (size_t)main_slot, P, hipMemcpyDeviceToDevice, st));
+        for (int i = 0; i < nside; i++) MVS_HIP(ctx, hipMemcpyAsync(d_side0 + (size_t)i * P, raw + P * (size_t)side_slots[i], P, hipMemcpyDeviceToDevice, st));
+    } else {
+        MVS_HIP(ctx, hipMemcpyAsync(d_main, main_frame_hw, P, hipMemcpyHostToDevice, st));
+        for (int i = 0; i < nside; i++) MVS_HIP(ctx, hipMemcpyAsync(d_side0 + (size_t)i * P, side_frames_hw[i], P, hipMemcpyHostToDevice, st));
+    }
     if (nside > 0 && (rc = projected_prepare_views(ctx, d_side0, nside))) return rc;   // every side frame's texture (wrap padding, mip chain): five launches in all
     std::vector<const float *> flow_ptrs((size_t)(nside > 0 ? nside : 1), nullptr);
     for (int i = 0; i < nside; i++) {
@@ -245,6 +258,25 @@ int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *mai
     rc = triangulate_impl(ctx, nside, flow_ptrs.data(), true, main_cam, side_cams, d_depth, out_points7, out_count);  // :114
     if (rc == MVS_OK) join.armed = false;  // triangulate_impl synchronised the main stream, which had joined every lane
     return rc;
+}
+
+extern "C" {
+
+int mvs_process_frame(mvs_ctx *ctx, const float main_cam[16], const uint8_t *main_frame_hw, int nside, const float *side_cams,
+                      const uint8_t *const *side_frames_hw, int use_farneback, float *out_points7, int *out_count,
+                      float *depth_after_hw /* nullable */)
+{
+    if (!ctx || !main_cam || !main_frame_hw || !out_points7 || !out_count || nside < 0 || (nside > 0 && (!side_cams || !side_frames_hw)))
+        return fail(ctx, MVS_EINVAL, "mvs_process_frame: bad arguments");
+    return process_frame_impl(ctx, main_cam, main_frame_hw, -1, nside, side_cams, side_frames_hw, nullptr, use_farneback, out_points7, out_count, depth_after_hw);
+}
+
+int mvs_process_frame_slots(mvs_ctx *ctx, const float main_cam[16], int main_slot, int nside, const float *side_cams, const int *side_slots,
+                            int use_farneback, float *out_points7, int *out_count, float *depth_after_hw /* nullable */)
+{
+    if (!ctx || !main_cam || !out_points7 || !out_count || nside < 0 || (nside > 0 && (!side_cams || !side_slots)))
+        return fail(ctx, MVS_EINVAL, "mvs_process_frame_slots: bad arguments");
+    return process_frame_impl(ctx, main_cam, nullptr, main_slot, nside, side_cams, nullptr, side_slots, use_farneback, out_points7, out_count, depth_after_hw);
 }
 
 }  // extern "C"

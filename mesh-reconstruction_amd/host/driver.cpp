@@ -35,6 +35,9 @@ bool sweepRange(const Mat &proxyDepth, float &zLo, float &zHi)
     return zHi > zLo;
 }
 
+// a renderer keeps a sequence's frames in its frame store while the whole sequence stays below this (per renderer; 5 bytes per pixel and frame)
+const size_t storeBudgetBytes = (size_t)8 << 30;
+
 }  // namespace
 
 Mat trackMainFrame(Configuration &config, Render *render, int fa, const std::vector<int> &sideFrames, Mat *depthUsed)
@@ -67,10 +70,19 @@ Mat trackMainFrame(Configuration &config, Render *render, int fa, const std::vec
         // every intermediate stays on the device instead of crossing PCIe after each stage)
         if (FrameTracker *tracker = dynamic_cast<FrameTracker *>(render)) {
             std::vector<Mat> sideCams, sideImgs;
-            for (int fb : sideFrames) {
-                sideCams.push_back(config.camera(fb));
-                sideImgs.push_back(config.frame(fb));
+            for (int fb : sideFrames) sideCams.push_back(config.camera(fb));
+            // a renderer with a frame store keeps the sequence's frames on the device (a frame is a main frame once and a side view about four times:
+            // it crosses PCIe once) -- as long as the whole sequence fits the budget below; otherwise the frames travel with every call
+            DepthSweep *store = dynamic_cast<DepthSweep *>(render);
+            const size_t storeBytes = (size_t)config.frameCount() * originalImage.total() * 5;   // raw frame + the sweep's quad image per slot
+            if (store && storeBytes <= storeBudgetBytes) {
+                if (store->storeCapacity() < config.frameCount()) store->storeFrames(config.frameCount());
+                if (!store->frameStored(fa)) store->storeFrame(fa, originalImage);
+                for (int fb : sideFrames)
+                    if (!store->frameStored(fb)) store->storeFrame(fb, config.frame(fb));
+                return tracker->trackStoredFrame(mainCamera, fa, sideCams, sideFrames, config.useFarneback, depthUsed);
             }
+            for (int fb : sideFrames) sideImgs.push_back(config.frame(fb));
             return tracker->trackFrame(mainCamera, originalImage, sideCams, sideImgs, config.useFarneback, depthUsed);
         }
     }
@@ -110,16 +122,29 @@ std::vector<Mat> trackMainFrames(Configuration &config, Heuristic &hint, Render 
     while ((int)pool.size() < n - 1) pool.emplace_back(spawnRender(hint));
     std::vector<std::unique_ptr<Render>> &extra = pool;
     for (int k = 1; k < n; k++) extra[(size_t)k - 1]->loadMesh(mesh);
+    // every renderer's frame store is sized before the threads start (trackMainFrame would do it at a renderer's first frame: an allocation of the whole
+    // sequence's size in the middle of the loop)
+    if (config.sweepPlanes == 0 && !schedule.empty()) {
+        const Mat first = config.frame(schedule[0].first);
+        if ((size_t)config.frameCount() * first.total() * 5 <= storeBudgetBytes)
+            for (int k = 0; k < n; k++)
+                if (DepthSweep *store = dynamic_cast<DepthSweep *>(k ? extra[(size_t)k - 1].get() : render))
+                    if (store->storeCapacity() < config.frameCount()) store->storeFrames(config.frameCount());
+    }
+    // Main frames are handed out in CHUNKS of consecutive schedule entries (two chunks per thread): neighbouring main frames share their side frames, and a
+    // renderer uploads a frame once for all the main frames IT tracks -- one frame at a time from a shared counter would send every frame to every renderer.
+    const size_t chunk = std::max<size_t>(1, schedule.size() / (2 * (size_t)n));
     std::atomic<size_t> next{0};
     std::mutex err_mutex;
     std::exception_ptr err;
     auto work = [&](Render *r) {
         try {
-            for (size_t i = next.fetch_add(1); i < schedule.size(); i = next.fetch_add(1)) blocks[i] = trackMainFrame(config, r, schedule[i].first, schedule[i].second);
+            for (size_t c = next.fetch_add(chunk); c < schedule.size(); c = next.fetch_add(chunk))
+                for (size_t i = c; i < std::min(schedule.size(), c + chunk); i++) blocks[i] = trackMainFrame(config, r, schedule[i].first, schedule[i].second);
         } catch (...) {
             std::lock_guard<std::mutex> lock(err_mutex);
             if (!err) err = std::current_exception();
-            next.store(schedule.size());  // nobody starts another frame
+            next.store(schedule.size());  // nobody starts another chunk
         }
     };
     std::vector<std::thread> threads;

@@ -166,6 +166,10 @@ public:
     virtual ~FrameTracker() {}
     virtual Mat trackFrame(const Mat mainCamera, const Mat mainFrame, const std::vector<Mat> &sideCameras, const std::vector<Mat> &sideFrames, bool useFarneback,
                            Mat *depthAfter = nullptr) = 0;
+    // the same with the frames named by number in the renderer's frame store (DepthSweep::storeFrame): the `fa` loop reads every frame of a sequence about
+    // five times (once as a main frame, four times as a side view), through the store it crosses PCIe once (mvs_process_frame_slots)
+    virtual Mat trackStoredFrame(const Mat mainCamera, int mainFrame, const std::vector<Mat> &sideCameras, const std::vector<int> &sideFrames, bool useFarneback,
+                                 Mat *depthAfter = nullptr) = 0;
 };
 
 typedef std::pair<int, std::vector<int>> numberedVector;   // (main frame, its side frames): recon.hpp:102

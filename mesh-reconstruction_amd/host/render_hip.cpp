@@ -182,6 +182,28 @@ public:
         return rows;
     }
 
+    Mat trackStoredFrame(const Mat mainCamera, int mainFrame, const std::vector<Mat> &sideCameras, const std::vector<int> &sideFrames, bool useFarneback, Mat *depthAfter) override
+    {
+        expect(mainCamera, mvs::F32C1, "trackStoredFrame mainCamera");
+        if (sideCameras.size() != sideFrames.size()) throw std::runtime_error("trackStoredFrame: one camera per side frame expected");
+        if (!frameStored(mainFrame)) throw std::runtime_error("trackStoredFrame: the main frame is not in the store (storeFrame)");
+        std::vector<float> cams;
+        for (size_t i = 0; i < sideFrames.size(); i++) {
+            if (!frameStored(sideFrames[i])) throw std::runtime_error("trackStoredFrame: a side frame is not in the store (storeFrame)");
+            expect(sideCameras[i], mvs::F32C1, "trackStoredFrame side camera");
+            cams.insert(cams.end(), sideCameras[i].ptr<float>(), sideCameras[i].ptr<float>() + 16);
+        }
+        if (rows_scratch.size() < (size_t)w * h * 7) rows_scratch.resize((size_t)w * h * 7);
+        if (depthAfter) depthAfter->create(h, w, mvs::F32C1);
+        int n = 0;
+        if (mvs_process_frame_slots(ctx, mainCamera.ptr<float>(), mainFrame, (int)sideFrames.size(), cams.data(), sideFrames.data(), useFarneback ? 1 : 0, rows_scratch.data(), &n,
+                                    depthAfter ? depthAfter->ptr<float>() : nullptr))
+            raise(ctx, "trackStoredFrame");
+        Mat rows(n, 7, mvs::F32C1);
+        if (n > 0) std::memcpy(rows.data, rows_scratch.data(), (size_t)n * 7 * sizeof(float));
+        return rows;
+    }
+
     mvs_ctx *context() const { return ctx; }
 
 protected:

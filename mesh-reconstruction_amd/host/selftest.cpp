@@ -567,6 +567,23 @@ static int run_sequence(int argc, char **argv)
                 CHECK(!std::memcmp(blocks[i].data, ref[i].data, blocks[i].total() * blocks[i].elemSize()), "main frame %d: the points differ between 1 and %d threads", schedule[i].first, threads);
         }
     }
+    // and the first main frame through the reference's own calls, stage by stage with host frames (recon.cpp:65-117 as written): trackMainFrame took its
+    // frames from the renderer's frame store and ran the whole body in one device-resident call -- the same rows, bit for bit
+    if (!schedule.empty() && !ref.empty()) {
+        const int fa = schedule[0].first;
+        const Mat originalImage = config.frame(fa), mainCamera = config.camera(fa);
+        Mat depth = render->depth(mainCamera);
+        MatList flows, cameras;
+        for (int fb2 : schedule[0].second) {
+            Mat projectedImage = render->projected(mainCamera, config.frame(fb2), config.camera(fb2));
+            projectedImage = mixBackground(projectedImage, originalImage, depth);
+            flows.push_back(calculateFlow(originalImage, projectedImage, config.useFarneback));
+            cameras.push_back(config.camera(fb2));
+        }
+        const Mat rows = triangulatePixels(flows, mainCamera, cameras, depth);
+        CHECK(rows.rows == ref[0].rows, "main frame %d: %d points stage by stage, %d from the frame store", fa, rows.rows, ref[0].rows);
+        if (rows.rows == ref[0].rows) CHECK(!std::memcmp(rows.data, ref[0].data, rows.total() * rows.elemSize()), "main frame %d: stage-by-stage points differ from the stored-frame call's", fa);
+    }
     printf("trackMainFrames, %zu main frames, %s flow: %.2f ms per main frame on one thread, %.2f ms on %d threads\n", schedule.size(), config.useFarneback ? "Farneback" : "variational",
            ms[0], ms[1], threads);
     delete render;

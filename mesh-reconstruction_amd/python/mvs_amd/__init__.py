@@ -52,6 +52,7 @@ ABI = [
     ("mvs_flow", _i, [_vp, _u8p, _u8p, _i, _fp]),
     ("mvs_triangulate", _i, [_vp, _i, C.POINTER(_fp), _fp, _fp, _fp, _fp, C.POINTER(_i)]),
     ("mvs_process_frame", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _fp, C.POINTER(_i), _fp]),
+    ("mvs_process_frame_slots", _i, [_vp, _fp, _i, _i, _fp, _i32p, _i, _fp, C.POINTER(_i), _fp]),
     ("mvs_filter_points", _i, [_vp, _fp, _i, _f, _i32p, C.POINTER(_i)]),
     ("mvs_sweep", _i, [_vp, _fp, _u8p, _i, _fp, C.POINTER(_u8p), _i, _f, _f, _fp, _fp, _fp]),
     ("mvs_warp_by_depth", _i, [_vp, _fp, _fp, _fp, _u8p, _u8p]),
@@ -868,6 +869,23 @@ class Context:
         self._check(self.lib.mvs_process_frame(self.h, _ptr(cam, _fp), _ptr(mf, _u8p), V, _ptr(cams, _fp), arr,
                                                1 if use_farneback else 0, _ptr(out, _fp), C.byref(n),
                                                _ptr(depth, _fp) if want_depth else None))
+        pts = out[:n.value].copy() if copy else out[:n.value]
+        return (pts, depth) if want_depth else pts
+
+    def process_frame_slots(self, main_cam, main_slot, side_cams, side_slots, use_farneback=False, want_depth=False, copy=True):
+        """mvs_process_frame_slots: process_frame() with the frames taken from the frame store (frame_store / frame_upload)."""
+        V = len(side_slots)
+        cam = _f32(main_cam, (4, 4))
+        cams = _f32(np.asarray(side_cams, dtype=np.float32).reshape(V, 4, 4)) if V else np.zeros((1, 4, 4), np.float32)
+        slots = np.ascontiguousarray(np.asarray(list(side_slots) if V else [0], dtype=np.int32))
+        if getattr(self, "_pf_out", None) is None:
+            self._pf_out = np.zeros((self.H * self.W, 7), np.float32)
+        out = self._pf_out
+        depth = np.empty((self.H, self.W), np.float32) if want_depth else None
+        n = C.c_int(0)
+        self._check(self.lib.mvs_process_frame_slots(self.h, _ptr(cam, _fp), int(main_slot), V, _ptr(cams, _fp), _ptr(slots, _i32p),
+                                                     1 if use_farneback else 0, _ptr(out, _fp), C.byref(n),
+                                                     _ptr(depth, _fp) if want_depth else None))
         pts = out[:n.value].copy() if copy else out[:n.value]
         return (pts, depth) if want_depth else pts
 

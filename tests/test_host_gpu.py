@@ -186,7 +186,7 @@ def test_the_driver_tracks_a_sequence_on_several_threads(tmp_path):
     rng = np.random.default_rng(10)
     tex = ndi.gaussian_filter(rng.normal(size=(H, W)), 2.5)
     tex = (127.5 + 110.0 * tex / np.abs(tex).max()).clip(0, 255).astype(np.uint8)
-    mains = [40, 48, 56, 64, 72, 80]
+    mains = list(range(20, 92, 3))   # 24 main frames with overlapping neighbourhoods: a renderer's frame store serves several main frames per upload
     need = sorted(set(j for f in mains for j in [f] + seq.sides(f)))
     shutil.copy(os.path.join(TRACKS, "zatisi.yaml"), tmp_path / "zatisi.yaml")
     os.makedirs(tmp_path / "zatisi.avi.frames")

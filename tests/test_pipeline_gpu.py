@@ -159,6 +159,40 @@ def test_process_frame_side_view_counts(nside):
             np.testing.assert_array_equal(pts, ref)
 
 
+@pytest.mark.parametrize("farneback", [False, True])
+def test_process_frame_from_the_frame_store(farneback):
+    """mvs_process_frame_slots: the frames of a sequence uploaded once (mvs_frame_upload), every main frame's call naming slots -- the points and
+    the depth map of mvs_process_frame on the same frames, bit for bit; slots refilled between calls are seen; bad and empty slots are refused"""
+    W, H = 320, 240
+    verts, faces = scenes.heightfield_mesh(48, extent=1.4)
+    sc = synth.Scene(freq_scale=0.2)
+    centres = [[0.05 * k - 0.15, 0.03 * np.sin(k), 0.01 * (k % 3 - 1)] for k in range(7)]
+    cams = [synth.camera_at(c, W, H) for c in centres]
+    frames = [sc.render(c, W, H) for c in centres]
+    with mvs_amd.Context(W, H) as ctx:
+        ctx.load_mesh(verts, faces)
+        ctx.frame_store(8)
+        with pytest.raises(mvs_amd.MvsError):
+            ctx.process_frame_slots(cams[2], 2, np.stack([cams[0]]), [0], farneback)       # nothing uploaded yet
+        for k, f in enumerate(frames):
+            ctx.frame_upload(k, f)
+        for main, side in ((2, [0, 1, 3, 4]), (3, [1, 2, 4, 5]), (4, [2, 6]), (5, [])):
+            side_cams = np.stack([cams[k] for k in side]) if side else np.zeros((0, 4, 4), np.float32)
+            ref, ref_depth = ctx.process_frame(cams[main], frames[main], side_cams, [frames[k] for k in side], farneback, want_depth=True)
+            pts, depth = ctx.process_frame_slots(cams[main], main, side_cams, side, farneback, want_depth=True)
+            np.testing.assert_array_equal(depth, ref_depth)
+            np.testing.assert_array_equal(pts, ref)
+        # a slot refilled with another frame is what the next call reads
+        ctx.frame_upload(7, frames[0])
+        a = ctx.process_frame_slots(cams[2], 2, np.stack([cams[0], cams[1]]), [7, 1], farneback)
+        b = ctx.process_frame(cams[2], frames[2], np.stack([cams[0], cams[1]]), [frames[0], frames[1]], farneback)
+        np.testing.assert_array_equal(a, b)
+        with pytest.raises(mvs_amd.MvsError):
+            ctx.process_frame_slots(cams[2], 2, np.stack([cams[0]]), [8], farneback)       # outside the store
+        with pytest.raises(mvs_amd.MvsError):
+            ctx.process_frame_slots(cams[2], -1, np.stack([cams[0]]), [0], farneback)
+
+
 def test_stage_matches_the_committed_golden_vectors():
     """every stage of the reference's per-frame path, HIP through the C ABI, against tests/golden/stage_small.npz (written by the
     oracle via tests/golden/make_golden.py and committed): no oracle runs here, so HIP and oracle cannot drift together unnoticed"""

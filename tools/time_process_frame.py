@@ -17,3 +17,12 @@ with mvs_amd.Context(seq.W, seq.H) as ctx:
         t0 = time.perf_counter()
         for _ in range(50): ctx.process_frame(seq.cams[f], mf, cams, frames, fb, copy=False)
         print("mvs_process_frame, %d x %d, %d side views, %s flow: %.2f ms per main frame" % (seq.W, seq.H, len(ids), "Farneback" if fb else "variational", (time.perf_counter() - t0) / 50 * 1e3))
+    # the same main frame with its frames taken from the frame store (mvs_process_frame_slots): uploaded once, not once per call
+    ctx.frame_store(len(ids) + 1)
+    for k, fr in enumerate([mf] + frames): ctx.frame_upload(k, fr)
+    slots = list(range(1, len(ids) + 1))
+    for fb in (False, True):
+        for _ in range(3): ctx.process_frame_slots(seq.cams[f], 0, cams, slots, fb, copy=False)
+        t0 = time.perf_counter()
+        for _ in range(50): ctx.process_frame_slots(seq.cams[f], 0, cams, slots, fb, copy=False)
+        print("mvs_process_frame_slots (frames in the frame store), %s flow: %.2f ms per main frame" % ("Farneback" if fb else "variational", (time.perf_counter() - t0) / 50 * 1e3))
