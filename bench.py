@@ -415,20 +415,35 @@ def reference_stage_block(mvs_amd, np, device):
             for f in mains:
                 ctx.process_frame(*frame_args(f))
             one = (time.perf_counter() - t0) / len(mains) * 1e3
+            # the same main frames with the sequence's frames in the context's frame store (mvs_process_frame_slots): uploaded once, not per main frame
+            ctx.frame_store(n)
+            for j in range(n):
+                ctx.frame_upload(j, frames[j])
+            for f in mains:
+                pts = ctx.process_frame_slots(cams[f], f, np.stack([cams[j] for j in sides[f]]), sides[f], fb)
+                if zlib.crc32(np.ascontiguousarray(pts[:, :4]).tobytes()) != ref[f]:
+                    raise SystemExit("reference stage: mvs_process_frame_slots differs from mvs_process_frame on main frame %d" % f)
+            t0 = time.perf_counter()
+            for f in mains:
+                ctx.process_frame_slots(cams[f], f, np.stack([cams[j] for j in sides[f]]), sides[f], fb)
+            one_store = (time.perf_counter() - t0) / len(mains) * 1e3
         nthreads = 4
         ctxs = [mvs_amd.Context(W, H, device) for _ in range(nthreads)]
         for cx in ctxs:
             cx.load_mesh(verts, faces)
         results = [dict() for _ in range(nthreads)]
 
-        def work(k, keep):
+        def work(k, keep, store):
             for f in mains[k::nthreads]:
-                pts = ctxs[k].process_frame(*frame_args(f))
+                if store:
+                    pts = ctxs[k].process_frame_slots(cams[f], f, np.stack([cams[j] for j in sides[f]]), sides[f], fb)
+                else:
+                    pts = ctxs[k].process_frame(*frame_args(f))
                 if keep:
                     results[k][f] = zlib.crc32(np.ascontiguousarray(pts[:, :4]).tobytes())
 
-        def run(keep):
-            th = [threading.Thread(target=work, args=(k, keep)) for k in range(nthreads)]
+        def run(keep, store=False):
+            th = [threading.Thread(target=work, args=(k, keep, store)) for k in range(nthreads)]
             t0 = time.perf_counter()
             for x in th:
                 x.start()
@@ -437,16 +452,25 @@ def reference_stage_block(mvs_amd, np, device):
             return time.perf_counter() - t0
         run(True)
         many = min(run(False), run(False)) / len(mains) * 1e3
+        equal = all(results[k][f] == ref[f] for k in range(nthreads) for f in mains[k::nthreads])
+        for cx in ctxs:   # (untimed: every context's store holds the sequence)
+            cx.frame_store(n)
+            for j in range(n):
+                cx.frame_upload(j, frames[j])
+        run(True, True)
+        many_store = min(run(False, True), run(False, True)) / len(mains) * 1e3
+        equal = equal and all(results[k][f] == ref[f] for k in range(nthreads) for f in mains[k::nthreads])
         for cx in ctxs:
             cx.close()
-        equal = all(results[k][f] == ref[f] for k in range(nthreads) for f in mains[k::nthreads])
         if not equal:
             raise SystemExit("reference stage: a thread's point block differs from the single-context result")
         out[name] = {"ms_per_main_frame_one_context": one, "ms_per_main_frame_%d_contexts_on_threads" % nthreads: many,
+                     "ms_per_main_frame_one_context_frame_store": one_store, "ms_per_main_frame_%d_contexts_frame_store" % nthreads: many_store,
                      "main_frames_per_s_one_context": 1e3 / one, "main_frames_per_s_%d_contexts" % nthreads: 1e3 / many,
+                     "main_frames_per_s_%d_contexts_frame_store" % nthreads: 1e3 / many_store,
                      "points_per_main_frame": npts // len(mains), "thread_results_equal_single_context": equal}
     out["note"] = ("mvs_process_frame (include/mvs.h): the body of recon.cpp's main-camera loop on device-resident data, host frames in, the (x, y, z, w, nx, ny, nz) rows out; "
-                   "one context = a main frame's latency; N contexts on N host threads of ONE GPU = the throughput of a sequence (the `fa` loop's iterations are independent; "
+                   "*_frame_store: mvs_process_frame_slots, the sequence's frames uploaded once into the context's frame store instead of with every main frame; one context = a main frame's latency; N contexts on N host threads of ONE GPU = the throughput of a sequence (the `fa` loop's iterations are independent; "
                    "calls on one context are serialised by the caller, contexts are independent)")
     return out
 

@@ -102,6 +102,9 @@ def test_bench_line_contract_and_two_rank_shardings():
         rs = ext["reference_stage"][alg]
         assert rs["thread_results_equal_single_context"] is True and rs["points_per_main_frame"] > 50000
         assert 0 < rs["ms_per_main_frame_4_contexts_on_threads"] < rs["ms_per_main_frame_one_context"]
+        # with the sequence's frames in the frame store (mvs_process_frame_slots; CRC-checked against the host-frame calls inside bench.py)
+        assert 0 < rs["ms_per_main_frame_one_context_frame_store"] < 1.1 * rs["ms_per_main_frame_one_context"]
+        assert 0 < rs["ms_per_main_frame_4_contexts_frame_store"] < rs["ms_per_main_frame_one_context"]
     # the flow block: Farneback returns the pair's known shift at every size it reports (round 5 timed a pair it returned nothing on)
     for name, f in ext["flow"].items():
         if name.startswith("farneback"):
