@@ -216,7 +216,7 @@ int projected_device(mvs_ctx *ctx, const float cam[16], const uint8_t *frame_dev
 int projected_main_pass(mvs_ctx *ctx, const float cam[16]);   // the half of projected() that does not depend on the side view ...
 int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float projector[16], uint8_t *out3_dev, int prepared_view = -1, const uint8_t *mix_bg = nullptr,
                         float *mix_depth = nullptr, uint8_t *mix_out = nullptr);   // ... and the half that does
-int projected_prepare_views(mvs_ctx *ctx, const uint8_t *frames_dev, int nframes);   // the frame textures (wrap padding + mip chain) of nframes side frames, W*H bytes apart, per launch
+int projected_prepare_views(mvs_ctx *ctx, const uint8_t *const *frames_dev, int nframes);   // the frame textures (wrap padding + mip chain) of nframes (<= 32) side frames, a device pointer each, per launch
 int mix_background_device(mvs_ctx *ctx, const uint8_t *img3_dev, const uint8_t *bg_dev, float *depth_dev, uint8_t *out_dev);
 int flow_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int use_farneback, float *out4_dev);
 int flow_only_device(mvs_ctx *ctx, const uint8_t *prev_dev, const uint8_t *next_dev, int use_farneback, float *flow2_dev);  // without the variance channel ...

@@ -206,24 +206,31 @@ static int process_frame_impl(mvs_ctx *ctx, const float main_cam[16], const uint
     // memory in between two kernels cost 14 us of idle stream per side view)
     if ((rc = depth_device(ctx, main_cam, d_depth))) return rc;  // recon.cpp:70
     if (nside > 0 && (rc = projected_main_pass(ctx, main_cam))) return rc;
-    if (slots) {  // (stream-ordered behind the uploads that filled the slots; the side views go where projected_prepare_views wants them: side by side)
+    // where the frames are on the device: the slots of the frame store as they lie (stream-ordered behind the uploads that filled them; nothing is copied),
+    // or this call's upload buffer
+    const uint8_t *main_dev = d_main;
+    std::vector<const uint8_t *> side_dev((size_t)(nside > 0 ? nside : 1), nullptr);
+    if (slots) {
         const uint8_t *raw = (const uint8_t *)ctx->store_raw.ptr;
-        MVS_HIP(ctx, hipMemcpyAsync(d_main, raw + P * (size_t)main_slot, P, hipMemcpyDeviceToDevice, st));
-        for (int i = 0; i < nside; i++) MVS_HIP(ctx, hipMemcpyAsync(d_side0 + (size_t)i * P, raw + P * (size_t)side_slots[i], P, hipMemcpyDeviceToDevice, st));
+        main_dev = raw + P * (size_t)main_slot;
+        for (int i = 0; i < nside; i++) side_dev[(size_t)i] = raw + P * (size_t)side_slots[i];
     } else {
         MVS_HIP(ctx, hipMemcpyAsync(d_main, main_frame_hw, P, hipMemcpyHostToDevice, st));
-        for (int i = 0; i < nside; i++) MVS_HIP(ctx, hipMemcpyAsync(d_side0 + (size_t)i * P, side_frames_hw[i], P, hipMemcpyHostToDevice, st));
+        for (int i = 0; i < nside; i++) {
+            MVS_HIP(ctx, hipMemcpyAsync(d_side0 + (size_t)i * P, side_frames_hw[i], P, hipMemcpyHostToDevice, st));
+            side_dev[(size_t)i] = d_side0 + (size_t)i * P;
+        }
     }
-    if (nside > 0 && (rc = projected_prepare_views(ctx, d_side0, nside))) return rc;   // every side frame's texture (wrap padding, mip chain): five launches in all
+    if (nside > 0 && (rc = projected_prepare_views(ctx, side_dev.data(), nside))) return rc;   // every side frame's texture (wrap padding, mip chain): five launches in all
     std::vector<const float *> flow_ptrs((size_t)(nside > 0 ? nside : 1), nullptr);
     for (int i = 0; i < nside; i++) {
         uint8_t *d_mixed = d_mixed0 + (size_t)i * P;
-        if ((rc = projected_side_pass(ctx, d_side0 + (size_t)i * P, side_cams + 16 * i, d_out3, i, d_main, d_depth, d_mixed))) return rc;   // :85 + :86 (mixBackground inside the fragment program's launch)
+        if ((rc = projected_side_pass(ctx, side_dev[(size_t)i], side_cams + 16 * i, d_out3, i, main_dev, d_depth, d_mixed))) return rc;   // :85 + :86 (mixBackground inside the fragment program's launch)
         float *fl = d_flows + (size_t)i * 4 * P;
         if (fb_batch) {
             // (after the loop)
         } else if (nlanes == 0 || i == nside - 1) {
-            if ((rc = flow_only_device(ctx, d_main, d_mixed, use_farneback, d_flow2 + (size_t)i * 2 * P))) return rc;               // :89 (the flow; its variance channel below)
+            if ((rc = flow_only_device(ctx, main_dev, d_mixed, use_farneback, d_flow2 + (size_t)i * 2 * P))) return rc;               // :89 (the flow; its variance channel below)
         } else {
             // the lane's host thread queues this view's flow (a dozen launches for the variational refinement, ~100 for a Farneback chain) while this thread
             // goes on with the next side view; the lane's stream waits for `ready` (this view's mixed image), the main stream later for `done`
@@ -237,14 +244,14 @@ static int process_frame_impl(mvs_ctx *ctx, const float main_cam[16], const uint
             ((LaneWorker *)lane.worker)->submit([=]() {
                 int r = MVS_OK;
                 if (hipStreamWaitEvent(ls, ready, 0) != hipSuccess) r = MVS_EHIP;
-                if (r == MVS_OK) r = flow_only_device(shadow, d_main, d_mixed, use_farneback, flow2_i);   // :89 (the flow; its variance channel below)
+                if (r == MVS_OK) r = flow_only_device(shadow, main_dev, d_mixed, use_farneback, flow2_i);   // :89 (the flow; its variance channel below)
                 if (r == MVS_OK && hipEventRecord(done, ls) != hipSuccess) r = MVS_EHIP;
                 *rc_i = r;
             });
         }
         flow_ptrs[i] = fl;
     }
-    if (fb_batch && (rc = flow_farneback_batch_device(ctx, d_main, d_mixed0, nside, d_flows))) return rc;                                            // :89, all side views
+    if (fb_batch && (rc = flow_farneback_batch_device(ctx, main_dev, d_mixed0, nside, d_flows))) return rc;                                            // :89, all side views
     if (nlanes > 0) {
         for (int l = 0; l < nlanes; l++) ((LaneWorker *)ctx->lanes[l].worker)->idle();   // every flow is queued (and every `done` recorded)
         for (int i = 0; i < nside - 1; i++)
@@ -253,7 +260,7 @@ static int process_frame_impl(mvs_ctx *ctx, const float main_cam[16], const uint
     }
     // flow.cpp:34-41 for every side view at once: the variance channels are twelve launches per flow of ~5 us each -- on the main stream, all flows per
     // launch, they are twelve per main frame (round 6; the batched Farneback pass does the same inside flow_farneback_batch_device)
-    if (!fb_batch && nside > 0 && (rc = flow_variance_batch_device(ctx, d_main, d_mixed0, d_flow2, nside, d_remapped, d_var, d_flows))) return rc;
+    if (!fb_batch && nside > 0 && (rc = flow_variance_batch_device(ctx, main_dev, d_mixed0, d_flow2, nside, d_remapped, d_var, d_flows))) return rc;
     if (depth_after_hw) MVS_HIP(ctx, hipMemcpyAsync(depth_after_hw, d_depth, sizeof(float) * P, hipMemcpyDeviceToHost, st));
     rc = triangulate_impl(ctx, nside, flow_ptrs.data(), true, main_cam, side_cams, d_depth, out_points7, out_count);  // :114
     if (rc == MVS_OK) join.armed = false;  // triangulate_impl synchronised the main stream, which had joined every lane

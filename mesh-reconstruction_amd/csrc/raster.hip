@@ -593,13 +593,18 @@ __global__ __launch_bounds__(256) void mix_background(const uint8_t *__restrict_
     if (masked) depth[i] = MVS_BACKGROUND_DEPTH;
 }
 
-// pad_wrap_kernel (context.hip) for N frames per launch: frames W*H bytes apart, padded copies `pad_z` bytes apart (blockIdx.z = frame)
-__global__ __launch_bounds__(256) void pad_wrap_frames(const uint8_t *__restrict__ img, uint8_t *__restrict__ pad, int W, int H, int pitch, size_t pad_z)
+// pad_wrap_kernel (context.hip) for N frames per launch: the frames wherever they are (a pointer each: side by side in mvs_process_frame's buffer, or
+// slots of the frame store), padded copies `pad_z` bytes apart (blockIdx.z = frame)
+struct FramePtrs {
+    const uint8_t *p[32];
+};
+
+__global__ __launch_bounds__(256) void pad_wrap_frames(FramePtrs frames, uint8_t *__restrict__ pad, int W, int H, int pitch, size_t pad_z)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     if (c >= pitch) return;
-    img += (size_t)W * H * blockIdx.z;
+    const uint8_t *__restrict__ img = frames.p[blockIdx.z];
     pad += pad_z * blockIdx.z;
     uint8_t v = 0;
     if (c < W + 2) {
@@ -694,14 +699,15 @@ int projected_main_pass(mvs_ctx *ctx, const float cam[16])
 // The frame texture of Render::projected for `nframes` side frames at once (frames W*H bytes apart): the wrap-padded copy and its mip chain, the
 // same kernels' arithmetic per frame, every launch covering all frames (round 6: five launches per main frame instead of five per side view).
 // Frame i's padded copy is at r_frame + i * tex_frame_bytes, its mips at r_mips + i * tex_mips_bytes; `mip` describes one frame's chain.
-static int projected_textures(mvs_ctx *ctx, const uint8_t *frames_dev, int nframes, MipArgs &mip)
+static int projected_textures(mvs_ctx *ctx, const FramePtrs &frames, int nframes, MipArgs &mip)
 {
     const int W = ctx->W, H = ctx->H;
     const int pitch = ((W + 2 + 63) / 64) * 64;
     const size_t frame_bytes = ((size_t)pitch * (H + 2) + 64 + 63) & ~(size_t)63;
     int rc;
+    if (nframes > 32) return fail(ctx, MVS_EINVAL, "projected: at most 32 frame textures per pass");
     if ((rc = ensure(ctx, ctx->r_frame, frame_bytes * (size_t)nframes))) return rc;
-    pad_wrap_frames<<<dim3(div_up(pitch, 256), H + 2, (unsigned)nframes), 256, 0, ctx->stream>>>(frames_dev, (uint8_t *)ctx->r_frame.ptr, W, H, pitch, frame_bytes);
+    pad_wrap_frames<<<dim3(div_up(pitch, 256), H + 2, (unsigned)nframes), 256, 0, ctx->stream>>>(frames, (uint8_t *)ctx->r_frame.ptr, W, H, pitch, frame_bytes);
     MVS_HIP(ctx, hipGetLastError());
     memset(&mip, 0, sizeof(mip));
     mip.w[0] = W;
@@ -745,10 +751,13 @@ static int projected_textures(mvs_ctx *ctx, const uint8_t *frames_dev, int nfram
 }
 
 // mvs_process_frame: the textures of all side frames up front (they depend on the frames alone)
-int projected_prepare_views(mvs_ctx *ctx, const uint8_t *frames_dev, int nframes)
+int projected_prepare_views(mvs_ctx *ctx, const uint8_t *const *frames_dev, int nframes)
 {
     MipArgs mip;
-    const int rc = projected_textures(ctx, frames_dev, nframes, mip);
+    FramePtrs fp;
+    memset(&fp, 0, sizeof(fp));
+    for (int i = 0; i < nframes && i < 32; i++) fp.p[i] = frames_dev[i];
+    const int rc = projected_textures(ctx, fp, nframes, mip);
     ctx->tex_prepared = rc == MVS_OK ? nframes : 0;
     return rc;
 }
@@ -770,7 +779,10 @@ int projected_side_pass(mvs_ctx *ctx, const uint8_t *frame_dev, const float proj
         if (prepared_view >= ctx->tex_prepared) return fail(ctx, MVS_ESTATE, "projected: texture %d was not prepared", prepared_view);
         memcpy(&mip, ctx->tex_mip, sizeof(mip));
     } else {
-        if ((rc = projected_textures(ctx, frame_dev, 1, mip))) return rc;
+        FramePtrs fp;
+        memset(&fp, 0, sizeof(fp));
+        fp.p[0] = frame_dev;
+        if ((rc = projected_textures(ctx, fp, 1, mip))) return rc;
         ctx->tex_prepared = 0;
         prepared_view = 0;
     }
